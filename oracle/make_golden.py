@@ -1,0 +1,239 @@
+"""Pin the oracle against the REAL reference and write tests/golden/*.npz  (run in the build container only).
+
+    python oracle/make_golden.py            # needs /root/reference; never runs on the GPU box
+
+What it does:
+1. installs inert ``sys.modules`` stubs for the third-party imports the image lacks (thop, cv2,
+   torchvision, pycocotools, tensorboard) -- none of them takes part in model / loss arithmetic;
+2. imports the reference through its own plugin API (``builder.export_from_registry``);
+3. asserts ``oracle.yolov8_ref`` == reference: init weights bit-exact, train/eval forward, v8 loss,
+   every parameter gradient, and two Adam steps, to fp32 round-off;
+4. writes small fixtures (inputs + expected outputs, data only) that ``tests/test_oracle_golden.py``
+   re-checks against the oracle wherever the reference is absent.
+
+The NMS fixture is produced by ``oracle.nms_ref`` itself (upstream parity unpinned -- see its header).
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("CVX_REFERENCE", "/root/reference")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _install_stubs():
+    class _Inert:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, *a, **k):
+            return _Inert()
+
+        def __getattr__(self, n):
+            if n.startswith("__"):
+                raise AttributeError(n)
+            return _Inert()
+
+    def _mod(name):
+        m = types.ModuleType(name)
+
+        def _ga(n):
+            if n.startswith("__"):
+                raise AttributeError(n)
+            return _Inert()
+
+        m.__getattr__ = _ga
+        m.__path__ = []
+        sys.modules[name] = m
+
+    for n in ("thop", "cv2", "torchvision", "torchvision.ops", "torchvision.transforms",
+              "torchvision.transforms.functional", "torchvision.models", "pycocotools", "pycocotools.coco",
+              "pycocotools.cocoeval", "tensorboard", "torch.utils.tensorboard"):
+        if n not in sys.modules:
+            _mod(n)
+
+
+def _import_reference():
+    """Returns the reference's (cfg, algorithm instance) for yolo8_det with the repo's own same-named
+    modules kept out of the way."""
+    sys.dont_write_bytecode = True
+    _install_stubs()
+    for k in [k for k in sys.modules if k.split(".")[0] in ("builder", "registry", "check", "configs", "core")]:
+        del sys.modules[k]
+    sys.path = [p for p in sys.path if os.path.abspath(p or ".") != ROOT]
+    sys.path.insert(0, REF)
+    import builder  # noqa: the reference's
+    assert os.path.abspath(builder.__file__).startswith(REF), builder.__file__
+    return builder
+
+
+def main():
+    sys.path.insert(0, ROOT)
+    from oracle import yolov8_ref as O
+    from oracle import nms_ref, synth
+    os.makedirs(GOLD, exist_ok=True)
+    builder = _import_reference()
+    torch.set_num_threads(8)
+    report = {}
+
+    # ---- 1. init weights ----------------------------------------------------------------------
+    torch.manual_seed(0)
+    cfg, algo_cls, _ = builder.export_from_registry("yolo8_det")
+    algo = algo_cls(cfg, torch.device("cpu"))
+    model, name = algo.build_model()
+    ref_sd = model.state_dict()
+    my_sd = O.init_state_dict("n", 80, seed=0)
+    assert list(ref_sd.keys()) == list(my_sd.keys()), "state_dict key order differs"
+    for k in ref_sd:
+        assert ref_sd[k].shape == my_sd[k].shape, k
+        assert torch.equal(ref_sd[k], my_sd[k]), f"init mismatch {k}"
+    report["init"] = "bit-exact, %d tensors" % len(ref_sd)
+    sums = {k: [float(v.double().sum()), float(v.double().abs().sum())] for k, v in ref_sd.items()}
+    with open(os.path.join(GOLD, "yolov8n_seed0_init_sums.json"), "w") as f:
+        json.dump(sums, f)
+
+    # ---- 2. forward (train + eval), small input -----------------------------------------------
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(2, 3, 128, 128, generator=g)
+    model.train()
+    ref_train = [t.detach().clone() for t in model(x.clone())]
+    sd_a = {k: v.clone() for k, v in my_sd.items()}
+    my_train = O.forward(sd_a, x.clone(), "n", 80, training=True)
+    for r, m in zip(ref_train, my_train):
+        assert torch.allclose(r, m, rtol=1e-5, atol=1e-6), float((r - m).abs().max())
+    for k, v in model.state_dict().items():                  # BN running stats after one train fwd
+        assert torch.allclose(v.float(), sd_a[k].float(), rtol=1e-5, atol=1e-7), k
+    model.eval()
+    with torch.no_grad():
+        ref_y, ref_feats = model(x.clone())
+        my_y, my_feats = O.forward(sd_a, x.clone(), "n", 80, training=False)
+    assert torch.allclose(ref_y, my_y, rtol=1e-5, atol=1e-5), float((ref_y - my_y).abs().max())
+    report["forward"] = "train+eval allclose 1e-5"
+    bn_probe = {k: sd_a[k].numpy() for k in ("model.0.bn.running_mean", "model.0.bn.running_var",
+                                             "model.22.cv3.2.1.bn.running_mean", "model.22.cv3.2.1.bn.running_var")}
+    np.savez_compressed(os.path.join(GOLD, "yolov8n_fwd_128.npz"), x=x.numpy(),
+                        train0=ref_train[0].numpy(), train1=ref_train[1].numpy(), train2=ref_train[2].numpy(),
+                        eval_y=ref_y.numpy(), **{"bn:" + k: v for k, v in bn_probe.items()})
+
+    # ---- 3. loss + grads + two Adam steps -----------------------------------------------------
+    torch.manual_seed(0)
+    cfg, algo_cls, _ = builder.export_from_registry("yolo8_det")
+    algo = algo_cls(cfg, torch.device("cpu"))
+    model, _ = algo.build_model()
+    crit = algo.build_loss(model)
+    from core.trainer.lr_scheduler import get_optimizer
+    opt = get_optimizer("Adam", model, 1e-3)
+    my_sd = O.init_state_dict("n", 80, seed=0)
+    state = {}
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(4, 3, 160, 160, generator=g)
+    batch = synth.targets(4, seed=2)
+    keys = O.trainable_keys(my_sd)
+    named = dict(model.named_parameters())
+    step_out = {}
+    model.train()
+    for step in range(2):
+        opt.zero_grad()
+        preds = model(x.clone())
+        loss, items = crit(preds, {k: v.clone() for k, v in batch.items()})
+        loss.backward()
+        ref_grads = {k: named[k].grad.detach().clone() for k in keys if named[k].grad is not None}
+        opt.step()
+        my_loss, my_items, my_grads, _ = O.train_step(my_sd, x.clone(), batch, state, "n", 80, 1e-3)
+        assert torch.allclose(loss.detach(), my_loss, rtol=1e-5), (float(loss), float(my_loss))
+        assert torch.allclose(items, my_items, rtol=1e-5, atol=1e-6), (items, my_items)
+        worst = 0.0
+        for k in keys:
+            if k not in ref_grads:
+                continue
+            gr, gm = ref_grads[k], my_grads[k]
+            err = float((gr - gm).norm() / (gr.norm() + 1e-12))
+            worst = max(worst, err)
+            assert err < 2e-4, (k, err)
+        for k, v in model.state_dict().items():
+            if v.dtype.is_floating_point:
+                assert torch.allclose(v, my_sd[k], rtol=1e-4, atol=1e-6), (k, float((v - my_sd[k]).abs().max()))
+        step_out[step] = dict(loss=float(loss), items=items.numpy().copy(), worst_grad_rel=worst,
+                              grad_norms=np.array([float(ref_grads[k].norm()) if k in ref_grads else 0.0 for k in keys]),
+                              g_stem=ref_grads["model.0.conv.weight"].numpy().copy(),
+                              g_c2f=ref_grads["model.2.m.0.cv1.conv.weight"].numpy().copy(),
+                              g_headb=ref_grads["model.22.cv3.0.2.bias"].numpy().copy(),
+                              g_bn=ref_grads["model.9.cv2.bn.weight"].numpy().copy())
+    report["train"] = {s: dict(loss=v["loss"], worst_grad_rel=v["worst_grad_rel"]) for s, v in step_out.items()}
+    post = model.state_dict()
+    np.savez_compressed(
+        os.path.join(GOLD, "yolov8n_train_160.npz"), x=x.numpy(), batch_idx=batch["batch_idx"].numpy(),
+        cls=batch["cls"].numpy(), bboxes=batch["bboxes"].numpy(), keys=np.array(keys),
+        loss=np.array([step_out[0]["loss"], step_out[1]["loss"]]),
+        items=np.stack([step_out[0]["items"], step_out[1]["items"]]),
+        grad_norms=np.stack([step_out[0]["grad_norms"], step_out[1]["grad_norms"]]),
+        g_stem=step_out[0]["g_stem"], g_c2f=step_out[0]["g_c2f"], g_headb=step_out[0]["g_headb"], g_bn=step_out[0]["g_bn"],
+        w_stem_after2=post["model.0.conv.weight"].numpy(), w_head_after2=post["model.22.cv2.1.2.weight"].numpy(),
+        bn_after2=post["model.4.m.1.cv2.bn.weight"].numpy(), rv_after2=post["model.4.m.1.cv2.bn.running_var"].numpy())
+
+    # ---- 4. assigner-only fixture (pins TAL edge handling on harder targets) -------------------
+    from core.utils.bboxes import TaskAlignedAssigner
+    g = torch.Generator().manual_seed(5)
+    B, A, nc, G = 2, 336, 80, 6
+    anchors, stride_t = O.make_anchors([(16, 16), (8, 8), (4, 4)], (8.0, 16.0, 32.0))
+    pd_scores = torch.rand(B, A, nc, generator=g) * 0.3
+    ctr = anchors * stride_t
+    half = torch.rand(B, A, 2, generator=g) * 40 + 4
+    pd_bboxes = torch.cat((ctr - half, ctr + half * (0.5 + torch.rand(B, A, 2, generator=g))), -1)
+    gxy = torch.rand(B, G, 2, generator=g) * 80 + 24
+    gwh = torch.rand(B, G, 2, generator=g) * 60 + 10
+    gt_bboxes = torch.cat((gxy - gwh / 2, gxy + gwh / 2), -1)
+    gt_labels = torch.randint(0, nc, (B, G, 1), generator=g).float()
+    gt_bboxes[1, 4:] = 0                                   # padded rows in image 1
+    gt_labels[1, 4:] = 0
+    gt_bboxes[0, 1] = gt_bboxes[0, 0] + 3.0                # heavy overlap -> multi-assignment path
+    mask_gt = (gt_bboxes.sum(2, keepdim=True) > 0).float()
+    ref_asg = TaskAlignedAssigner(topk=10, num_classes=nc, alpha=0.5, beta=6.0)
+    _, rb, rs, rf, ri = ref_asg(pd_scores, pd_bboxes, ctr, gt_labels, gt_bboxes, mask_gt)
+    mb, ms, mf, mi = O.task_aligned_assign(pd_scores, pd_bboxes, ctr, gt_labels, gt_bboxes, mask_gt)
+    assert torch.equal(rf, mf) and torch.equal(ri, mi), "assigner fg/gt_idx mismatch"
+    assert torch.allclose(rb, mb) and torch.allclose(rs, ms, rtol=1e-5, atol=1e-7)
+    report["assigner"] = "fg=%d exact" % int(rf.sum())
+    np.savez_compressed(os.path.join(GOLD, "tal_assign.npz"), pd_scores=pd_scores.numpy(), pd_bboxes=pd_bboxes.numpy(),
+                        anc=ctr.numpy(), gt_labels=gt_labels.numpy(), gt_bboxes=gt_bboxes.numpy(), mask_gt=mask_gt.numpy(),
+                        t_boxes=rb.numpy(), t_scores_sum=rs.sum(-1).numpy(), t_cls=rs.argmax(-1).numpy(),
+                        fg=rf.numpy(), gt_idx=ri.numpy())
+
+    # ---- 5. full-size forward, sub-sampled ----------------------------------------------------
+    torch.manual_seed(0)
+    cfg, algo_cls, _ = builder.export_from_registry("yolo8_det")
+    model, _ = algo_cls(cfg, torch.device("cpu")).build_model()
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(1, 3, 640, 640, generator=g)
+    model.train()
+    with torch.no_grad():
+        full = model(x)
+    sub = {f"lvl{i}": t.flatten()[::97].numpy() for i, t in enumerate(full)}
+    norms = np.array([float(t.norm()) for t in full])
+    my = O.forward(O.init_state_dict("n", 80, seed=0), x, "n", 80, training=True)
+    for r, m in zip(full, my):
+        assert torch.allclose(r, m.detach(), rtol=1e-5, atol=1e-5)
+    np.savez_compressed(os.path.join(GOLD, "yolov8n_fwd_640_sub.npz"), norms=norms, **sub)
+    report["forward640"] = "allclose; norms " + str(norms.tolist())
+
+    # ---- 6. NMS tail fixture (oracle-generated; upstream parity unpinned) ----------------------
+    pred = synth.nms_pred(7)
+    res = nms_ref.non_max_suppression(pred, 0.25, 0.7, 300)
+    np.savez_compressed(os.path.join(GOLD, "nms_tail.npz"), seed=np.array(7), pred_sum=np.array(pred.astype(np.float64).sum()),
+                        keep0=res[0][1], keep1=res[1][1], rows0=res[0][0], rows1=res[1][0])
+    report["nms"] = "kept %d / %d" % (len(res[0][1]), len(res[1][1]))
+
+    with open(os.path.join(GOLD, "PIN_REPORT.json"), "w") as f:
+        json.dump(report, f, indent=1)
+    print(json.dumps(report, indent=1))
+
+
+if __name__ == "__main__":
+    main()

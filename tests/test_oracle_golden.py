@@ -1,0 +1,136 @@
+"""CPU: the oracle restatement against the golden vectors captured from the real reference
+(oracle/make_golden.py; tests/golden/PIN_REPORT.json records that run)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import nms_ref, synth
+from oracle import yolov8_ref as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_init_matches_reference_checksums():
+    sd = O.init_state_dict("n", 80, seed=0)
+    sums = json.load(open(os.path.join(GOLD, "yolov8n_seed0_init_sums.json")))
+    assert list(sums.keys()) == list(sd.keys()) and len(sd) == 355
+    for k, (s, a) in sums.items():
+        v = sd[k].double()
+        assert float(v.sum()) == s and float(v.abs().sum()) == a, k
+    n_params = sum(v.numel() for k, v in sd.items() if not k.endswith(("running_mean", "running_var", "num_batches_tracked")))
+    assert n_params == 3157200          # yolo_v8.py:111
+    assert sum(sd[k].numel() for k in O.trainable_keys(sd)) == 3157184
+
+
+def test_forward_train_and_eval(gold):
+    g = gold("yolov8n_fwd_128.npz")
+    sd = O.init_state_dict("n", 80, seed=0)
+    x = torch.from_numpy(g["x"])
+    outs = O.forward(sd, x, "n", 80, training=True)
+    for i, o in enumerate(outs):
+        np.testing.assert_allclose(o.numpy(), g[f"train{i}"], rtol=1e-5, atol=1e-6)
+    for k in g.files:
+        if k.startswith("bn:"):
+            np.testing.assert_allclose(sd[k[3:]].numpy(), g[k], rtol=1e-5, atol=1e-7)
+    with torch.no_grad():
+        y, _ = O.forward(sd, x, "n", 80, training=False)
+    np.testing.assert_allclose(y.numpy(), g["eval_y"], rtol=1e-5, atol=1e-5)
+
+
+def test_train_two_steps(gold):
+    g = gold("yolov8n_train_160.npz")
+    sd = O.init_state_dict("n", 80, seed=0)
+    batch = {"batch_idx": torch.from_numpy(g["batch_idx"]), "cls": torch.from_numpy(g["cls"]),
+             "bboxes": torch.from_numpy(g["bboxes"])}
+    assert all(torch.equal(batch[k], synth.targets(4, seed=2)[k]) for k in batch)
+    x = torch.from_numpy(g["x"])
+    keys = O.trainable_keys(sd)
+    assert list(g["keys"]) == keys
+    state = {}
+    for step in range(2):
+        loss, items, grads, _ = O.train_step(sd, x, batch, state)
+        np.testing.assert_allclose(float(loss), g["loss"][step], rtol=1e-5)
+        np.testing.assert_allclose(items.numpy(), g["items"][step], rtol=1e-5, atol=1e-6)
+        norms = np.array([float(grads[k].norm()) for k in keys])
+        np.testing.assert_allclose(norms, g["grad_norms"][step], rtol=2e-4, atol=1e-7)
+        if step == 0:
+            np.testing.assert_allclose(grads["model.0.conv.weight"].numpy(), g["g_stem"], rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(grads["model.2.m.0.cv1.conv.weight"].numpy(), g["g_c2f"], rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(grads["model.22.cv3.0.2.bias"].numpy(), g["g_headb"], rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(grads["model.9.cv2.bn.weight"].numpy(), g["g_bn"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(sd["model.0.conv.weight"].numpy(), g["w_stem_after2"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(sd["model.22.cv2.1.2.weight"].numpy(), g["w_head_after2"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(sd["model.4.m.1.cv2.bn.weight"].numpy(), g["bn_after2"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(sd["model.4.m.1.cv2.bn.running_var"].numpy(), g["rv_after2"], rtol=1e-4, atol=1e-6)
+
+
+def test_assigner_fixture(gold):
+    g = gold("tal_assign.npz")
+    t = lambda k: torch.from_numpy(g[k])  # noqa: E731
+    tb, ts, fg, gi = O.task_aligned_assign(t("pd_scores"), t("pd_bboxes"), t("anc"), t("gt_labels"), t("gt_bboxes"),
+                                           t("mask_gt"))
+    assert np.array_equal(fg.numpy(), g["fg"]) and np.array_equal(gi.numpy(), g["gt_idx"])
+    np.testing.assert_allclose(tb.numpy(), g["t_boxes"])
+    np.testing.assert_allclose(ts.sum(-1).numpy(), g["t_scores_sum"], rtol=1e-5, atol=1e-7)
+    assert int(fg.sum()) > 20 and int((fg.sum(0) > 0).sum()) > 0
+
+
+def test_assigner_empty_targets():
+    pd_scores = torch.rand(2, 84, 80)
+    tb, ts, fg, gi = O.task_aligned_assign(pd_scores, torch.rand(2, 84, 4), torch.rand(84, 2), torch.zeros(2, 0, 1),
+                                           torch.zeros(2, 0, 4), torch.zeros(2, 0, 1))
+    assert not fg.any() and float(ts.sum()) == 0.0
+
+
+def test_forward_640_subsample(gold):
+    g = gold("yolov8n_fwd_640_sub.npz")
+    sd = O.init_state_dict("n", 80, seed=0)
+    with torch.no_grad():
+        outs = O.forward(sd, synth.images(1, 640, 640, seed=1), "n", 80, training=True)
+    assert [tuple(o.shape) for o in outs] == [(1, 144, 80, 80), (1, 144, 40, 40), (1, 144, 20, 20)]
+    for i, o in enumerate(outs):
+        np.testing.assert_allclose(o.flatten()[::97].numpy(), g[f"lvl{i}"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(float(o.norm()), g["norms"][i], rtol=1e-5)
+
+
+def test_nms_fixture_and_properties(gold):
+    g = gold("nms_tail.npz")
+    pred = synth.nms_pred(int(g["seed"]))
+    assert float(pred.astype(np.float64).sum()) == float(g["pred_sum"])
+    res = nms_ref.non_max_suppression(pred, 0.25, 0.7, 300)
+    for i, (rows, keep) in enumerate(res):
+        assert np.array_equal(keep, g[f"keep{i}"])
+        np.testing.assert_array_equal(rows, g[f"rows{i}"])
+        assert np.all(np.diff(rows[:, 4]) <= 0)                      # descending score
+        assert rows.shape[0] <= 300 and np.all(rows[:, 4] > 0.25)
+    # idempotence: NMS of the kept set keeps everything
+    rows = res[0][0]
+    again = nms_ref.greedy_nms_per_class(rows[:, :4], rows[:, 5].astype(np.int64), 0.7)
+    assert np.array_equal(again, np.arange(rows.shape[0]))
+
+
+def test_nms_edge_cases():
+    empty = np.zeros((1, 84, 8400), np.float32)
+    rows, keep = nms_ref.non_max_suppression(empty)[0]
+    assert rows.shape == (0, 6) and keep.shape == (0,)
+    # two identical boxes, same class -> one survives (the lower anchor index on the score tie)
+    p = np.zeros((1, 84, 16), np.float32)
+    p[0, :4, 3] = p[0, :4, 9] = (100, 100, 50, 50)
+    p[0, 4 + 7, 3] = p[0, 4 + 7, 9] = 0.9
+    rows, keep = nms_ref.non_max_suppression(p)[0]
+    assert keep.tolist() == [3]
+    # same boxes, different classes -> both survive (class-aware)
+    p[0, 4 + 7, 9] = 0
+    p[0, 4 + 8, 9] = 0.8
+    rows, keep = nms_ref.non_max_suppression(p)[0]
+    assert keep.tolist() == [3, 9] and rows[:, 5].tolist() == [7.0, 8.0]
+
+
+def test_decode_box_letterbox_roundtrip():
+    rows = np.array([[100, 200, 300, 400, 0.9, 3]], np.float32)
+    box, conf, cls = nms_ref.decode_box(rows, (640, 640), (480, 640), letterbox=True)
+    # 640x480 image letterboxed into 640x640: scale 1, 80 px bars top/bottom
+    np.testing.assert_allclose(box, [[100, 120, 300, 320]], atol=1e-3)
+    assert cls.dtype == np.int64 and cls[0] == 3
