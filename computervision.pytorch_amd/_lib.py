@@ -1,0 +1,108 @@
+"""ctypes binding of ``libcvx_engine.so`` (C ABI declared in ``include/cvx_engine.h``).
+
+The product path has no fallback: if the HIP library is missing or a call fails, ``CvxError`` is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcvx_engine.so")
+ABI_VERSION = 1
+
+
+class CvxError(RuntimeError):
+    pass
+
+
+class BufDesc(C.Structure):
+    _fields_ = [("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32), ("kind", C.c_int32)]
+
+
+class View(C.Structure):
+    _fields_ = [("buf", C.c_int32), ("coff", C.c_int32), ("c", C.c_int32), ("pix_off", C.c_int32)]
+
+
+class OpDesc(C.Structure):
+    _fields_ = [
+        ("type", C.c_int32),
+        ("in_", View), ("out", View), ("res", View),
+        ("ih", C.c_int32), ("iw", C.c_int32), ("oh", C.c_int32), ("ow", C.c_int32),
+        ("k", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("dil", C.c_int32),
+        ("act", C.c_int32), ("needs_dgrad", C.c_int32), ("w_cin", C.c_int32),
+        ("w_off", C.c_int64), ("gamma_off", C.c_int64), ("beta_off", C.c_int64), ("bias_off", C.c_int64),
+        ("rmean_off", C.c_int64), ("rvar_off", C.c_int64),
+    ]
+
+
+BUF_ACT_F16, BUF_PRED_F32 = 0, 1
+OP_CONV, OP_MAXPOOL5, OP_UPSAMPLE2 = 1, 2, 3
+ACT_BN_SILU, ACT_BIAS = 1, 2
+
+_P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); every symbol include/cvx_engine.h declares
+PROTOTYPES = {
+    "cvx_last_error": (C.c_char_p, []),
+    "cvx_abi_version": (_I32, []),
+    "cvx_engine_create": (_I32, [C.POINTER(_P), C.POINTER(BufDesc), _I32, C.POINTER(OpDesc), _I32, _I32, _I32, _I32, _P]),
+    "cvx_engine_destroy": (_I32, [_P]),
+    "cvx_engine_bind": (_I32, [_P, _P, _P, _I64, _P, _I64]),
+    "cvx_engine_set_bn": (_I32, [_P, _F, _F]),
+    "cvx_engine_forward": (_I32, [_P, _P, _I32, _I32, _P]),
+    "cvx_engine_backward": (_I32, [_P, _P, _F]),
+    "cvx_engine_workspace_bytes": (_I64, [_P]),
+    "cvx_engine_debug_copy": (_I32, [_P, _I32, _I32, _P, _I64]),
+    "cvx_pred_level_to_nchw": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),
+    "cvx_nchw_grad_to_dpred": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _P, _P]),
+    "cvx_loss_v8_workspace_bytes": (_I64, [_I32, _I32, _I32, _I32]),
+    "cvx_loss_v8": (_I32, [_P, _I32, _I32, _I32, _P, _I32, _I32, C.POINTER(_I32), C.POINTER(_F), _I32, _F, _F, _F, _F, _P, _P, _P,
+                           _I64, _P]),
+    "cvx_adam_step": (_I32, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I32, _P, _I32, _P]),
+    "cvx_check_finite": (_I32, [_P, _I64, _P, _P]),
+    "cvx_decode": (_I32, [_P, _I32, _I32, _I32, C.POINTER(_I32), C.POINTER(_F), _I32, _P, _P]),
+    "cvx_nms_workspace_bytes": (_I64, [_I32, _I32]),
+    "cvx_nms": (_I32, [_P, _I32, _I32, _I32, _F, _F, _I32, _P, _P, _P, _P, _I64, _P]),
+    "cvx_conv2d_nhwc": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P]),
+    "cvx_conv2d_dgrad_nhwc": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _P]),
+    "cvx_conv2d_wgrad_workspace_bytes": (_I64, [_I32, _I32, _I32, _I32, _I32, _I32]),
+    "cvx_conv2d_wgrad_nhwc": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _I64, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads the shared library once; raises CvxError (never falls back) if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CvxError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if lib.cvx_abi_version() != ABI_VERSION:
+        raise CvxError(f"ABI mismatch: library {lib.cvx_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().cvx_last_error()
+        raise CvxError(f"{what}: {msg.decode() if msg else 'unknown error'}")
+
+
+def ptr(t):
+    """Raw device/host pointer of a torch tensor (0 -> NULL for None)."""
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def stream_ptr(device=None):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

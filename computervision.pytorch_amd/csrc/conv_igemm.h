@@ -1,0 +1,79 @@
+// Implicit-GEMM convolution on MFMA (gfx950): shared parameter block for the forward,
+// data-gradient and weight-gradient kernels.  All tensors are NHWC fp16 "views": a base pointer
+// (already advanced by the channel offset), a per-pixel stride `ld` and a per-image stride
+// `bstride` (both in elements), so channel slices of concat buffers are read and written in place.
+#pragma once
+#include "cvx_common.h"
+
+enum {
+  CVX_EPI_RAW_STATS = 0,    // train fwd: raw conv output fp16 + per-block (sum, sumsq) partials
+  CVX_EPI_AFFINE_SILU = 1,  // eval fwd: y*scale+shift -> SiLU (+residual) -> fp16
+  CVX_EPI_BIAS_F32 = 2,     // head output: +bias -> fp32
+  CVX_EPI_PLAIN = 3,        // dgrad: fp16 store (optionally accumulate into the destination)
+};
+
+#define CVX_MAX_TAPS 64
+
+// One tap of the gather: input pixel = (o2*IS + dh, o2w*IS + dw); weight block index wtap.
+struct ConvTap {
+  int dh, dw, wtap, pad_;
+};
+
+struct ConvParams {
+  // ---- gathered operand (activations for fwd, output-gradients for dgrad) ----
+  const half_t* in;
+  long long in_bstride;
+  int in_ld;
+  int IH, IW;
+  int Cin;  // multiple of 8
+  // ---- weights: [Cout rows][wt_ld], tap block `wtap` starts at wtap*Cin ----
+  const half_t* wt;
+  int wt_ld;
+  int Cout;
+  // ---- output pixel enumeration: m = (b*OH2 + oh2)*OW2 + ow2 ----
+  int B, OH2, OW2;
+  int IS;            // input coordinate multiplier
+  int OS, oph, opw;  // real output pixel = (oh2*OS+oph, ow2*OS+opw)
+  int OWr;           // real output width
+  int ntaps;
+  const ConvTap* taps;  // device memory, ntaps entries
+  // ---- epilogue ----
+  int epi;
+  int accumulate;
+  half_t* out16;
+  float* out32;
+  long long out_bstride;
+  int out_ld;
+  const half_t* res;  // optional residual (same pixel coordinates as the output)
+  long long res_bstride;
+  int res_ld;
+  const float* scale;  // AFFINE_SILU
+  const float* shift;  // AFFINE_SILU
+  const float* bias;   // BIAS_F32
+  float* stats;        // RAW_STATS: [gridDim.x][Cout][2]
+};
+
+// Launches the kernel; returns the number of M-blocks (= stats partial count) through *m_blocks.
+int cvx_conv_igemm_launch(const ConvParams& p, hipStream_t stream, int* m_blocks);
+// Number of M-blocks the launcher will use for M output pixels.
+int cvx_conv_igemm_mblocks(long long M);
+
+// Weight gradient: dW[co][tap][ci] partial sums over a slice of the pixels, written as fp32 slabs.
+struct WgradParams {
+  const half_t* x;  // forward input view
+  long long x_bstride;
+  int x_ld;
+  int IH, IW, Cin;  // Cin multiple of 8
+  const half_t* dy;  // gradient of the raw conv output: element (b, pix, co) at dy[b*dy_bstride + pix*dy_ld + co]
+  long long dy_bstride;
+  int dy_ld;
+  int Cout;
+  int B, OH, OW;  // M = B*OH*OW
+  int stride;
+  int ntaps;
+  const ConvTap* taps;  // dh/dw relative to oh*stride, wtap = tap index in the weight layout
+  float* slabs;         // [nsplit][Cout][ntaps*Cin]
+  int nsplit;
+  int cin_pad16;  // Cin rounded up to 16 (column tiling unit)
+};
+int cvx_conv_wgrad_launch(const WgradParams& p, hipStream_t stream);

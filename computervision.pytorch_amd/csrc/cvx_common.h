@@ -1,0 +1,68 @@
+// Shared device/host helpers for the MI355X (gfx950 / CDNA4) detection engine.
+// Wave = 64 lanes everywhere; fp16 storage, fp32 accumulation.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+typedef _Float16 half_t;
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef short s4 __attribute__((ext_vector_type(4)));
+typedef short s8 __attribute__((ext_vector_type(8)));
+
+#define CVX_WAVE 64
+
+// ---- error plumbing (C-ABI functions return int status, message via cvx_last_error) ----------
+void cvx_set_error(const std::string& msg);
+#define CVX_FAIL(msg)                                                         \
+  do {                                                                        \
+    cvx_set_error(std::string(__FILE__) + ":" + std::to_string(__LINE__) + ": " + (msg)); \
+    return -1;                                                                \
+  } while (0)
+#define CVX_HIP(call)                                                         \
+  do {                                                                        \
+    hipError_t e__ = (call);                                                  \
+    if (e__ != hipSuccess) CVX_FAIL(std::string(#call) + " -> " + hipGetErrorString(e__)); \
+  } while (0)
+#define CVX_CHECK(cond, msg)                                                  \
+  do {                                                                        \
+    if (!(cond)) CVX_FAIL(std::string("check failed: ") + #cond + " : " + (msg)); \
+  } while (0)
+#define CVX_TRY(call)                                                         \
+  do {                                                                        \
+    int rc__ = (call);                                                        \
+    if (rc__ != 0) return rc__;                                               \
+  } while (0)
+
+static inline int cvx_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- small device helpers ---------------------------------------------------------------------
+__device__ __forceinline__ float cvx_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float cvx_silu(float x) { return x * cvx_sigmoid(x); }
+// d silu / dx
+__device__ __forceinline__ float cvx_silu_grad(float x) {
+  float s = cvx_sigmoid(x);
+  return s * (1.0f + x * (1.0f - s));
+}
+__device__ __forceinline__ float cvx_wave_sum16(float v) {
+  // sum over the 16 lanes that share (lane >> 4)
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  return v;
+}
+__device__ __forceinline__ float cvx_wave_sum64(float v) {
+  v = cvx_wave_sum16(v);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+__device__ __forceinline__ float cvx_wave_max64(float v) {
+  for (int o = 1; o < 64; o <<= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}

@@ -1,0 +1,842 @@
+// Graph executor behind the C ABI (include/cvx_engine.h): owns workspaces (activations, raw conv
+// outputs, gradient buffers, fp16 weight shadows, gradient slabs), plans the concat-free buffer
+// views and the backward write/accumulate modes once, and replays the op list on one HIP stream.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "../../include/cvx_engine.h"
+#include "bn_act.h"
+#include "conv_igemm.h"
+#include "misc_ops.h"
+
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+void cvx_set_error(const std::string& msg) { g_last_error = msg; }
+extern "C" const char* cvx_last_error(void) { return g_last_error.c_str(); }
+extern "C" int cvx_abi_version(void) { return CVX_ABI_VERSION; }
+
+namespace {
+
+struct DgClass {
+  ConvTap* taps = nullptr;
+  int ntaps = 0, oph = 0, opw = 0, OH2 = 0, OW2 = 0;
+};
+
+struct ConvRt {
+  // static
+  ConvTap* taps_fwd = nullptr;
+  int ntaps = 0;
+  DgClass dg[16];
+  int ndg = 0;
+  long long sh_fwd = 0, sh_dg = -1;  // fp16 shadow offsets (elements)
+  int cin_g = 0;                     // gathered input channels (view channels, multiple of 8)
+  int cin_pad16 = 0;
+  // backward plan
+  int in_accum = 0, res_accum = 0;
+  // per-batch
+  half_t* ybuf = nullptr;
+  float *mean = nullptr, *invstd = nullptr, *c1 = nullptr, *c2 = nullptr, *scale = nullptr, *shift = nullptr;
+  long long slab_off = 0;
+  int nsplit = 1;
+};
+
+struct PoolRt {
+  uint8_t* idx = nullptr;
+  int in_accum = 0;
+};
+
+struct Buf {
+  cvx_buf_desc d;
+  half_t* act = nullptr;
+  half_t* grad = nullptr;
+};
+
+}  // namespace
+
+struct cvx_engine {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::vector<Buf> bufs;
+  std::vector<cvx_op_desc> ops;
+  std::vector<ConvRt> conv;  // indexed by op
+  std::vector<PoolRt> pool;  // indexed by op
+  int image_buf = -1, pred_buf = -1;
+  float* params = nullptr;
+  float* grads = nullptr;
+  float* stats = nullptr;
+  int64_t n_params = 0, n_stats = 0;
+  float bn_eps = 1e-3f, bn_momentum = 0.03f;
+  // static device memory
+  std::vector<void*> static_allocs;
+  half_t* shadow = nullptr;
+  long long shadow_elems = 0;
+  PackDesc* d_pack = nullptr;
+  BlockRef* d_pack_blocks = nullptr;
+  int n_pack_blocks = 0;
+  // batch plan
+  int planned_batch = 0;
+  bool planned_train = false;
+  std::vector<void*> batch_allocs;
+  int64_t batch_bytes = 0, static_bytes = 0;
+  float* partials = nullptr;
+  half_t* dy_scratch = nullptr;
+  float* slabs = nullptr;
+  SlabDesc* d_slab = nullptr;
+  BlockRef* d_slab_blocks = nullptr;
+  int n_slab_blocks = 0;
+  bool fwd_train_done = false;
+  int last_batch = 0;
+  float* last_pred = nullptr;
+};
+
+namespace {
+
+int dev_alloc(cvx_engine* e, std::vector<void*>& pool, int64_t& counter, void** out, long long bytes) {
+  if (bytes <= 0) bytes = 16;
+  bytes = (bytes + 255) & ~255LL;
+  CVX_HIP(hipMalloc(out, (size_t)bytes));
+  pool.push_back(*out);
+  counter += bytes;
+  return 0;
+}
+template <typename T>
+int upload(cvx_engine* e, std::vector<void*>& pool, int64_t& counter, T** out, const std::vector<T>& host) {
+  void* p = nullptr;
+  CVX_TRY(dev_alloc(e, pool, counter, &p, (long long)(host.size() * sizeof(T))));
+  if (!host.empty()) CVX_HIP(hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = (T*)p;
+  return 0;
+}
+void free_pool(std::vector<void*>& pool) {
+  for (void* p : pool) (void)hipFree(p);
+  pool.clear();
+}
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+ViewDesc make_view(const cvx_engine* e, const cvx_view& v, bool grad) {
+  ViewDesc r{nullptr, 0, 0};
+  if (v.buf < 0) return r;
+  const Buf& b = e->bufs[v.buf];
+  half_t* base = grad ? b.grad : b.act;
+  r.ld = b.d.c;
+  r.bstride = (long long)b.d.h * b.d.w * b.d.c;
+  r.p = base + (long long)v.pix_off * b.d.c + v.coff;
+  return r;
+}
+
+void wgrad_tile(int cout, int* co_b, int* j_b) {  // must mirror cvx_conv_wgrad_launch
+  if (cout <= 16) {
+    *co_b = 16;
+    *j_b = 192;
+  } else if (cout <= 32) {
+    *co_b = 32;
+    *j_b = 128;
+  } else if (cout % 64 != 0 && (cout % 48 == 0 || cout <= 96)) {
+    *co_b = 48;
+    *j_b = 128;
+  } else {
+    *co_b = 64;
+    *j_b = 64;
+  }
+}
+
+int build_static(cvx_engine* e) {
+  const int nops = (int)e->ops.size();
+  e->conv.assign(nops, ConvRt());
+  e->pool.assign(nops, PoolRt());
+  std::vector<PackDesc> packs;
+  std::vector<BlockRef> pblocks;
+  long long sh = 0;
+  for (int i = 0; i < nops; ++i) {
+    const cvx_op_desc& o = e->ops[i];
+    CVX_CHECK(o.in.buf >= 0 && o.in.buf < (int)e->bufs.size() && o.out.buf >= 0 && o.out.buf < (int)e->bufs.size(), "op view buffer index");
+    if (o.type != CVX_OP_CONV) continue;
+    ConvRt& c = e->conv[i];
+    const int T = o.k * o.k;
+    CVX_CHECK(T <= CVX_MAX_TAPS, "kernel too large");
+    CVX_CHECK(o.in.c % 8 == 0 && o.out.c % 8 == 0 && o.in.coff % 8 == 0 && o.out.coff % 8 == 0, "conv views must be 8-channel aligned");
+    CVX_CHECK(o.w_cin <= o.in.c && o.w_cin > o.in.c - 8, "w_cin vs view channels");
+    c.cin_g = o.in.c;
+    c.cin_pad16 = round_up(o.in.c, 16);
+    c.ntaps = T;
+    std::vector<ConvTap> taps(T);
+    for (int r = 0; r < o.k; ++r)
+      for (int s = 0; s < o.k; ++s) taps[r * o.k + s] = ConvTap{r * o.dil - o.pad, s * o.dil - o.pad, r * o.k + s, 0};
+    CVX_TRY(upload(e, e->static_allocs, e->static_bytes, &c.taps_fwd, taps));
+    // shadow weights
+    PackDesc pd;
+    pd.src_off = o.w_off;
+    pd.Cout = o.out.c;
+    pd.T = T;
+    pd.Cin = o.w_cin;
+    pd.Cin_pad = o.in.c;
+    pd.fwd_off = sh;
+    c.sh_fwd = sh;
+    sh += (long long)pd.Cout * T * pd.Cin_pad;
+    sh = (sh + 7) & ~7LL;
+    pd.dg_off = -1;
+    if (o.needs_dgrad) {
+      CVX_CHECK(o.w_cin == o.in.c, "dgrad needs unpadded input channels");
+      pd.dg_off = sh;
+      c.sh_dg = sh;
+      sh += (long long)pd.Cin * T * pd.Cout;
+      sh = (sh + 7) & ~7LL;
+      // data-gradient tap classes: one per output phase of the forward stride
+      const int S = o.stride;
+      CVX_CHECK(S * S <= 16, "stride too large");
+      for (int ph = 0; ph < S; ++ph)
+        for (int pw = 0; pw < S; ++pw) {
+          std::vector<ConvTap> dt;
+          for (int r = 0; r < o.k; ++r) {
+            int nh = ph + o.pad - r * o.dil;
+            if (((nh % S) + S) % S != 0) continue;
+            for (int s = 0; s < o.k; ++s) {
+              int nw = pw + o.pad - s * o.dil;
+              if (((nw % S) + S) % S != 0) continue;
+              dt.push_back(ConvTap{nh / S, nw / S, r * o.k + s, 0});  // exact division
+            }
+          }
+          DgClass& dc = c.dg[c.ndg++];
+          dc.ntaps = (int)dt.size();
+          dc.oph = ph;
+          dc.opw = pw;
+          dc.OH2 = (o.ih - ph + S - 1) / S;
+          dc.OW2 = (o.iw - pw + S - 1) / S;
+          if (dc.ntaps > 0) CVX_TRY(upload(e, e->static_allocs, e->static_bytes, &dc.taps, dt));
+        }
+    }
+    const int total = pd.Cout * T * pd.Cin_pad;
+    for (int s0 = 0; s0 < total; s0 += 1024) pblocks.push_back(BlockRef{(int)packs.size(), s0});
+    packs.push_back(pd);
+  }
+  e->shadow_elems = sh;
+  void* p = nullptr;
+  CVX_TRY(dev_alloc(e, e->static_allocs, e->static_bytes, &p, sh * 2));
+  e->shadow = (half_t*)p;
+  CVX_HIP(hipMemset(p, 0, (size_t)(sh * 2)));
+  CVX_TRY(upload(e, e->static_allocs, e->static_bytes, &e->d_pack, packs));
+  CVX_TRY(upload(e, e->static_allocs, e->static_bytes, &e->d_pack_blocks, pblocks));
+  e->n_pack_blocks = (int)pblocks.size();
+
+  // ---- forward plan check: activations are operands of the backward pass, so no slice may be produced twice
+  {
+    std::vector<std::vector<char>> produced(e->bufs.size());
+    for (size_t b = 0; b < e->bufs.size(); ++b) produced[b].assign(e->bufs[b].d.c, 0);
+    for (int i = 0; i < nops; ++i) {
+      const cvx_op_desc& o = e->ops[i];
+      if (e->bufs[o.out.buf].d.kind == CVX_BUF_PRED_F32) continue;
+      CVX_CHECK(o.out.coff >= 0 && o.out.coff + o.out.c <= e->bufs[o.out.buf].d.c, "output view exceeds its buffer");
+      CVX_CHECK(o.in.coff >= 0 && o.in.coff + o.in.c <= e->bufs[o.in.buf].d.c, "input view exceeds its buffer");
+      for (int ch = o.out.coff; ch < o.out.coff + o.out.c; ++ch) {
+        CVX_CHECK(!produced[o.out.buf][ch], "forward plan: buffer slice written twice (op " + std::to_string(i) + ")");
+        produced[o.out.buf][ch] = 1;
+      }
+    }
+  }
+  // ---- backward write/accumulate plan -----------------------------------------------------
+  std::vector<std::vector<char>> written(e->bufs.size());
+  for (size_t b = 0; b < e->bufs.size(); ++b) written[b].assign(e->bufs[b].d.c, 0);
+  auto claim = [&](const cvx_view& v, int* accum) -> int {
+    int nw = 0;
+    for (int ch = v.coff; ch < v.coff + v.c; ++ch) nw += written[v.buf][ch];
+    CVX_CHECK(nw == 0 || nw == v.c, "backward plan: gradient slice partially written");
+    *accum = nw == v.c;
+    for (int ch = v.coff; ch < v.coff + v.c; ++ch) written[v.buf][ch] = 1;
+    return 0;
+  };
+  for (int i = nops - 1; i >= 0; --i) {
+    const cvx_op_desc& o = e->ops[i];
+    if (e->bufs[o.out.buf].d.kind != CVX_BUF_PRED_F32) {
+      for (int ch = o.out.coff; ch < o.out.coff + o.out.c; ++ch)
+        CVX_CHECK(written[o.out.buf][ch], "backward plan: an op output has no consumer (op " + std::to_string(i) + ")");
+    }
+    if (o.type == CVX_OP_CONV) {
+      if (o.res.buf >= 0) CVX_TRY(claim(o.res, &e->conv[i].res_accum));
+      if (o.needs_dgrad) CVX_TRY(claim(o.in, &e->conv[i].in_accum));
+    } else {
+      CVX_TRY(claim(o.in, &e->pool[i].in_accum));
+    }
+  }
+  return 0;
+}
+
+int plan_batch(cvx_engine* e, int B, bool training) {
+  if (e->planned_batch == B && (e->planned_train || !training)) return 0;
+  CVX_HIP(hipStreamSynchronize(e->stream));
+  free_pool(e->batch_allocs);
+  e->batch_bytes = 0;
+  e->planned_batch = 0;
+  void* p = nullptr;
+  for (Buf& b : e->bufs) {
+    b.act = b.grad = nullptr;
+    if (b.d.kind != CVX_BUF_ACT_F16) continue;
+    long long bytes = (long long)B * b.d.h * b.d.w * b.d.c * 2;
+    CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, bytes));
+    b.act = (half_t*)p;
+    if (training) {
+      CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, bytes));
+      b.grad = (half_t*)p;
+    }
+  }
+  long long max_part = 16, max_dy = 16, slab_total = 0;
+  std::vector<SlabDesc> sdescs;
+  std::vector<BlockRef> sblocks;
+  for (size_t i = 0; i < e->ops.size(); ++i) {
+    const cvx_op_desc& o = e->ops[i];
+    if (o.type == CVX_OP_MAXPOOL5) {
+      if (training) {
+        CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, (long long)B * o.oh * o.ow * o.out.c));
+        e->pool[i].idx = (uint8_t*)p;
+      }
+      continue;
+    }
+    if (o.type != CVX_OP_CONV) continue;
+    ConvRt& c = e->conv[i];
+    const long long M = (long long)B * o.oh * o.ow;
+    const int C = o.out.c;
+    CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, 6LL * C * 4));
+    c.mean = (float*)p;
+    c.invstd = c.mean + C;
+    c.c1 = c.invstd + C;
+    c.c2 = c.c1 + C;
+    c.scale = c.c2 + C;
+    c.shift = c.scale + C;
+    if (training && o.act == CVX_ACT_BN_SILU) {
+      CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, M * C * 2));
+      c.ybuf = (half_t*)p;
+    }
+    max_part = std::max(max_part, (long long)cvx_conv_igemm_mblocks(M) * C * 2);
+    max_part = std::max(max_part, (long long)cvx_stream_blocks(M, C) * C * 2);
+    if (training) {
+      max_dy = std::max(max_dy, M * C);
+      int co_b, j_b;
+      wgrad_tile(C, &co_b, &j_b);
+      const int Jtot = c.ntaps * c.cin_pad16;
+      const long long tiles = (long long)cvx_cdiv(C, co_b) * cvx_cdiv(Jtot, j_b);
+      long long ns = std::min<long long>(std::max<long long>(1, M / 256), std::max<long long>(1, 2048 / tiles));
+      const long long slab_elems = (long long)C * Jtot;
+      ns = std::min(ns, std::max<long long>(1, (16LL << 20) / (slab_elems * 4)));
+      c.nsplit = (int)ns;
+      c.slab_off = slab_total;
+      slab_total += ns * slab_elems;
+      SlabDesc sd;
+      sd.slab_off = c.slab_off;
+      sd.dst_off = o.w_off;
+      sd.nsplit = c.nsplit;
+      sd.rows = C * c.ntaps;
+      sd.Cin = o.w_cin;
+      sd.Cin_pad = c.cin_pad16;
+      const long long total = (long long)sd.rows * sd.Cin;
+      for (long long s0 = 0; s0 < total; s0 += 1024) sblocks.push_back(BlockRef{(int)sdescs.size(), (int)s0});
+      sdescs.push_back(sd);
+    }
+  }
+  CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, max_part * 4));
+  e->partials = (float*)p;
+  if (training) {
+    CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, max_dy * 2));
+    e->dy_scratch = (half_t*)p;
+    CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, slab_total * 4));
+    e->slabs = (float*)p;
+    CVX_TRY(upload(e, e->batch_allocs, e->batch_bytes, &e->d_slab, sdescs));
+    CVX_TRY(upload(e, e->batch_allocs, e->batch_bytes, &e->d_slab_blocks, sblocks));
+    e->n_slab_blocks = (int)sblocks.size();
+  }
+  e->planned_batch = B;
+  e->planned_train = training;
+  return 0;
+}
+
+void fill_conv_fwd(const cvx_engine* e, int i, int B, ConvParams* cp) {
+  const cvx_op_desc& o = e->ops[i];
+  const ConvRt& c = e->conv[i];
+  ViewDesc in = make_view(e, o.in, false);
+  memset(cp, 0, sizeof(*cp));
+  cp->in = in.p;
+  cp->in_bstride = in.bstride;
+  cp->in_ld = in.ld;
+  cp->IH = o.ih;
+  cp->IW = o.iw;
+  cp->Cin = c.cin_g;
+  cp->wt = e->shadow + c.sh_fwd;
+  cp->wt_ld = c.ntaps * c.cin_g;
+  cp->Cout = o.out.c;
+  cp->B = B;
+  cp->OH2 = o.oh;
+  cp->OW2 = o.ow;
+  cp->IS = o.stride;
+  cp->OS = 1;
+  cp->OWr = o.ow;
+  cp->ntaps = c.ntaps;
+  cp->taps = c.taps_fwd;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" int cvx_engine_create(cvx_engine** out, const cvx_buf_desc* bufs, int32_t nbufs, const cvx_op_desc* ops, int32_t nops,
+                                 int32_t image_buf, int32_t pred_buf, int32_t device, void* hip_stream) {
+  CVX_CHECK(out && bufs && ops && nbufs > 0 && nops > 0, "null arguments");
+  CVX_HIP(hipSetDevice(device));
+  cvx_engine* e = new cvx_engine();
+  e->device = device;
+  e->stream = (hipStream_t)hip_stream;
+  e->bufs.resize(nbufs);
+  for (int i = 0; i < nbufs; ++i) e->bufs[i].d = bufs[i];
+  e->ops.assign(ops, ops + nops);
+  e->image_buf = image_buf;
+  e->pred_buf = pred_buf;
+  if (!(image_buf >= 0 && image_buf < nbufs && bufs[image_buf].c == 8 && pred_buf >= 0 && pred_buf < nbufs &&
+        bufs[pred_buf].kind == CVX_BUF_PRED_F32)) {
+    delete e;
+    CVX_FAIL("image_buf must be an 8-channel fp16 buffer and pred_buf a PRED_F32 buffer");
+  }
+  int rc = build_static(e);
+  if (rc != 0) {
+    free_pool(e->static_allocs);
+    delete e;
+    return rc;
+  }
+  *out = e;
+  return 0;
+}
+
+extern "C" int cvx_engine_destroy(cvx_engine* e) {
+  if (!e) return 0;
+  (void)hipStreamSynchronize(e->stream);
+  free_pool(e->batch_allocs);
+  free_pool(e->static_allocs);
+  delete e;
+  return 0;
+}
+
+extern "C" int cvx_engine_bind(cvx_engine* e, float* params, float* grads, int64_t n_params, float* stats, int64_t n_stats) {
+  CVX_CHECK(e && params && stats, "null arguments");
+  CVX_CHECK(((uintptr_t)params % 16) == 0 && ((uintptr_t)grads % 16) == 0, "arenas must be 16-byte aligned");
+  for (const cvx_op_desc& o : e->ops) {
+    if (o.type != CVX_OP_CONV) continue;
+    CVX_CHECK(o.w_off >= 0 && o.w_off + (int64_t)o.out.c * o.k * o.k * o.w_cin <= n_params, "weight offset out of range");
+    if (o.act == CVX_ACT_BN_SILU) {
+      CVX_CHECK(o.gamma_off >= 0 && o.gamma_off + o.out.c <= n_params && o.beta_off >= 0 && o.beta_off + o.out.c <= n_params, "bn offsets");
+      CVX_CHECK(o.rmean_off >= 0 && o.rmean_off + o.out.c <= n_stats && o.rvar_off >= 0 && o.rvar_off + o.out.c <= n_stats, "stat offsets");
+      CVX_CHECK(o.gamma_off % 4 == 0 && o.beta_off % 4 == 0 && o.rmean_off % 4 == 0 && o.rvar_off % 4 == 0, "bn offsets must be 4-aligned");
+    } else {
+      CVX_CHECK(o.bias_off >= 0 && o.bias_off + o.out.c <= n_params && o.bias_off % 4 == 0, "bias offset");
+    }
+  }
+  e->params = params;
+  e->grads = grads;
+  e->stats = stats;
+  e->n_params = n_params;
+  e->n_stats = n_stats;
+  return 0;
+}
+
+extern "C" int cvx_engine_set_bn(cvx_engine* e, float eps, float momentum) {
+  CVX_CHECK(e, "null engine");
+  e->bn_eps = eps;
+  e->bn_momentum = momentum;
+  return 0;
+}
+
+extern "C" int cvx_engine_debug_copy(cvx_engine* e, int32_t buf, int32_t which, void* dst, int64_t bytes) {
+  CVX_CHECK(e && dst && buf >= 0 && buf < (int)e->bufs.size(), "bad arguments");
+  const Buf& b = e->bufs[buf];
+  const half_t* src = which ? b.grad : b.act;
+  CVX_CHECK(src && e->planned_batch > 0, "buffer not allocated (no forward yet, or eval-only plan)");
+  const int64_t want = (int64_t)e->planned_batch * b.d.h * b.d.w * b.d.c * 2;
+  CVX_CHECK(bytes == want, "size mismatch: buffer holds " + std::to_string(want) + " bytes");
+  CVX_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDefault, e->stream));
+  return 0;
+}
+
+extern "C" int64_t cvx_engine_workspace_bytes(const cvx_engine* e) { return e ? e->batch_bytes + e->static_bytes : 0; }
+
+extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t batch, int32_t training, float* pred) {
+  CVX_CHECK(e && images && pred && batch > 0, "bad arguments");
+  CVX_CHECK(e->params, "cvx_engine_bind was not called");
+  CVX_HIP(hipSetDevice(e->device));
+  CVX_TRY(plan_batch(e, batch, training != 0));
+  hipStream_t st = e->stream;
+  const int B = batch;
+  // fp32 master -> fp16 shadows (forward layout + transposed layout for the data gradient)
+  CVX_TRY(cvx_pack_weights(e->params, e->shadow, e->d_pack, e->d_pack_blocks, e->n_pack_blocks, st));
+  const Buf& ib = e->bufs[e->image_buf];
+  CVX_TRY(cvx_image_to_nhwc8(images, B, ib.d.h, ib.d.w, ib.act, st));
+  const Buf& pb = e->bufs[e->pred_buf];
+  const long long A = (long long)pb.d.h * pb.d.w;
+
+  for (size_t i = 0; i < e->ops.size(); ++i) {
+    const cvx_op_desc& o = e->ops[i];
+    if (o.type == CVX_OP_MAXPOOL5) {
+      CVX_TRY(cvx_maxpool5_fwd(make_view(e, o.in, false), make_view(e, o.out, false), B, o.ih, o.iw, o.in.c,
+                               training ? e->pool[i].idx : nullptr, st));
+      continue;
+    }
+    if (o.type == CVX_OP_UPSAMPLE2) {
+      CVX_TRY(cvx_upsample2_fwd(make_view(e, o.in, false), make_view(e, o.out, false), B, o.ih, o.iw, o.in.c, st));
+      continue;
+    }
+    ConvRt& c = e->conv[i];
+    ConvParams cp;
+    fill_conv_fwd(e, (int)i, B, &cp);
+    const long long M = (long long)B * o.oh * o.ow;
+    const int C = o.out.c;
+    if (o.act == CVX_ACT_BIAS) {
+      cp.epi = CVX_EPI_BIAS_F32;
+      cp.bias = e->params + o.bias_off;
+      cp.out32 = pred + (long long)o.out.pix_off * pb.d.c + o.out.coff;
+      cp.out_ld = pb.d.c;
+      cp.out_bstride = A * pb.d.c;
+      CVX_TRY(cvx_conv_igemm_launch(cp, st, nullptr));
+      continue;
+    }
+    ViewDesc outv = make_view(e, o.out, false);
+    ViewDesc resv = make_view(e, o.res, false);
+    if (training) {
+      cp.epi = CVX_EPI_RAW_STATS;
+      cp.out16 = c.ybuf;
+      cp.out_ld = C;
+      cp.out_bstride = (long long)o.oh * o.ow * C;
+      cp.stats = e->partials;
+      int P = 0;
+      CVX_TRY(cvx_conv_igemm_launch(cp, st, &P));
+      CVX_TRY(cvx_bn_finalize(e->partials, P, C, M, e->bn_momentum, e->bn_eps, c.mean, c.invstd, e->stats + o.rmean_off,
+                              e->stats + o.rvar_off, st));
+      BnCoef k{c.mean, c.invstd, e->params + o.gamma_off, e->params + o.beta_off};
+      CVX_TRY(cvx_bn_silu_apply(c.ybuf, M, C, o.oh * o.ow, k, outv, resv, st));
+    } else {
+      CVX_TRY(cvx_bn_fold(C, e->params + o.gamma_off, e->params + o.beta_off, e->stats + o.rmean_off, e->stats + o.rvar_off, e->bn_eps,
+                          c.scale, c.shift, st));
+      cp.epi = CVX_EPI_AFFINE_SILU;
+      cp.scale = c.scale;
+      cp.shift = c.shift;
+      cp.out16 = outv.p;
+      cp.out_ld = outv.ld;
+      cp.out_bstride = outv.bstride;
+      cp.res = resv.p;
+      cp.res_ld = resv.ld;
+      cp.res_bstride = resv.bstride;
+      CVX_TRY(cvx_conv_igemm_launch(cp, st, nullptr));
+    }
+  }
+  e->fwd_train_done = training != 0;
+  e->last_batch = B;
+  return 0;
+}
+
+extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float loss_scale) {
+  CVX_CHECK(e && dpred_f16, "bad arguments");
+  CVX_CHECK(e->fwd_train_done, "cvx_engine_backward needs a preceding training-mode forward");
+  CVX_CHECK(e->grads, "no gradient arena bound");
+  CVX_CHECK(loss_scale > 0.f, "loss_scale must be positive");
+  CVX_HIP(hipSetDevice(e->device));
+  hipStream_t st = e->stream;
+  const int B = e->last_batch;
+  const float inv_scale = 1.0f / loss_scale;
+  const Buf& pb = e->bufs[e->pred_buf];
+  const long long A = (long long)pb.d.h * pb.d.w;
+  half_t* dpred = (half_t*)dpred_f16;
+
+  for (int i = (int)e->ops.size() - 1; i >= 0; --i) {
+    const cvx_op_desc& o = e->ops[i];
+    if (o.type == CVX_OP_MAXPOOL5) {
+      CVX_TRY(cvx_maxpool5_bwd(make_view(e, o.out, true), make_view(e, o.in, true), B, o.ih, o.iw, o.in.c, e->pool[i].idx,
+                               e->pool[i].in_accum, st));
+      continue;
+    }
+    if (o.type == CVX_OP_UPSAMPLE2) {
+      CVX_TRY(cvx_upsample2_bwd(make_view(e, o.out, true), make_view(e, o.in, true), B, o.ih, o.iw, o.in.c, e->pool[i].in_accum, st));
+      continue;
+    }
+    ConvRt& c = e->conv[i];
+    const long long M = (long long)B * o.oh * o.ow;
+    const int C = o.out.c;
+    const int hw = o.oh * o.ow;
+    ViewDesc dyv;  // gradient w.r.t. the raw conv output
+    if (o.act == CVX_ACT_BIAS) {
+      dyv.p = dpred + (long long)o.out.pix_off * pb.d.c + o.out.coff;
+      dyv.ld = pb.d.c;
+      dyv.bstride = A * pb.d.c;
+      CVX_TRY(cvx_colsum(M, C, hw, dyv, e->partials, inv_scale, e->grads + o.bias_off, st));
+    } else {
+      ViewDesc gout = make_view(e, o.out, true);
+      ViewDesc gres = make_view(e, o.res, true);
+      BnCoef k{c.mean, c.invstd, e->params + o.gamma_off, e->params + o.beta_off};
+      CVX_TRY(cvx_bn_bwd_reduce(c.ybuf, M, C, hw, k, gout, e->partials, st));
+      CVX_TRY(cvx_bn_bwd_finalize(e->partials, cvx_stream_blocks(M, C), C, M, inv_scale, c.c1, c.c2, e->grads + o.gamma_off,
+                                  e->grads + o.beta_off, st));
+      CVX_TRY(cvx_bn_bwd_apply(c.ybuf, M, C, hw, k, c.c1, c.c2, gout, e->dy_scratch, gres, c.res_accum, st));
+      dyv.p = e->dy_scratch;
+      dyv.ld = C;
+      dyv.bstride = (long long)hw * C;
+    }
+    // ---- data gradient: dx = dy (*) W^T, one launch per output phase of the forward stride ----
+    if (o.needs_dgrad) {
+      ViewDesc gin = make_view(e, o.in, true);
+      for (int q = 0; q < c.ndg; ++q) {
+        const DgClass& dc = c.dg[q];
+        if (dc.OH2 <= 0 || dc.OW2 <= 0) continue;
+        CVX_CHECK(dc.ntaps > 0, "dgrad phase without taps (stride > kernel) is not supported");
+        ConvParams cp;
+        memset(&cp, 0, sizeof(cp));
+        cp.in = dyv.p;
+        cp.in_bstride = dyv.bstride;
+        cp.in_ld = dyv.ld;
+        cp.IH = o.oh;
+        cp.IW = o.ow;
+        cp.Cin = C;
+        cp.wt = e->shadow + c.sh_dg;
+        cp.wt_ld = c.ntaps * C;
+        cp.Cout = o.in.c;
+        cp.B = B;
+        cp.OH2 = dc.OH2;
+        cp.OW2 = dc.OW2;
+        cp.IS = 1;
+        cp.OS = o.stride;
+        cp.oph = dc.oph;
+        cp.opw = dc.opw;
+        cp.OWr = o.iw;
+        cp.ntaps = dc.ntaps;
+        cp.taps = dc.taps;
+        cp.epi = CVX_EPI_PLAIN;
+        cp.accumulate = c.in_accum;
+        cp.out16 = gin.p;
+        cp.out_ld = gin.ld;
+        cp.out_bstride = gin.bstride;
+        CVX_TRY(cvx_conv_igemm_launch(cp, st, nullptr));
+      }
+    }
+    // ---- weight gradient -> fp32 slabs ----
+    {
+      ViewDesc xin = make_view(e, o.in, false);
+      WgradParams wp;
+      memset(&wp, 0, sizeof(wp));
+      wp.x = xin.p;
+      wp.x_bstride = xin.bstride;
+      wp.x_ld = xin.ld;
+      wp.IH = o.ih;
+      wp.IW = o.iw;
+      wp.Cin = c.cin_g;
+      wp.dy = dyv.p;
+      wp.dy_bstride = dyv.bstride;
+      wp.dy_ld = dyv.ld;
+      wp.Cout = C;
+      wp.B = B;
+      wp.OH = o.oh;
+      wp.OW = o.ow;
+      wp.stride = o.stride;
+      wp.ntaps = c.ntaps;
+      wp.taps = c.taps_fwd;
+      wp.slabs = e->slabs + c.slab_off;
+      wp.nsplit = c.nsplit;
+      wp.cin_pad16 = c.cin_pad16;
+      CVX_TRY(cvx_conv_wgrad_launch(wp, st));
+    }
+  }
+  CVX_TRY(cvx_reduce_slabs(e->slabs, e->grads, inv_scale, e->d_slab, e->d_slab_blocks, e->n_slab_blocks, st));
+  return 0;
+}
+
+// ---- thin C wrappers over the launchers ------------------------------------------------------
+extern "C" int cvx_pred_level_to_nchw(const float* pred, int32_t batch, int32_t anchors, int32_t no, int32_t a_off, int32_t h, int32_t w,
+                                      float* out_nchw, void* hip_stream) {
+  return cvx_pred_to_nchw(pred, batch, anchors, no, a_off, h, w, out_nchw, (hipStream_t)hip_stream);
+}
+extern "C" int cvx_nchw_grad_to_dpred(const float* grad_nchw, int32_t batch, int32_t anchors, int32_t no, int32_t a_off, int32_t h, int32_t w,
+                                      float scale, void* dpred_f16, void* hip_stream) {
+  return cvx_nchw_to_pred_f16(grad_nchw, batch, anchors, no, a_off, h, w, scale, (half_t*)dpred_f16, (hipStream_t)hip_stream);
+}
+extern "C" int cvx_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                             float eps, int32_t step, const int32_t* found_inf, int32_t zero_grad, void* hip_stream) {
+  CVX_CHECK(params && grads && exp_avg && exp_avg_sq && n > 0, "bad arguments");
+  CVX_CHECK(((uintptr_t)params % 16) == 0 && ((uintptr_t)grads % 16) == 0 && ((uintptr_t)exp_avg % 16) == 0 && ((uintptr_t)exp_avg_sq % 16) == 0,
+            "adam arenas must be 16-byte aligned");
+  return cvx_adam(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, found_inf, zero_grad, (hipStream_t)hip_stream);
+}
+extern "C" int cvx_check_finite(const float* grads, int64_t n, int32_t* found_inf, void* hip_stream) {
+  CVX_CHECK(grads && found_inf, "bad arguments");
+  return cvx_check_finite_launch(grads, n, found_inf, (hipStream_t)hip_stream);
+}
+
+// ---- single-op entry points --------------------------------------------------------------------
+namespace {
+int make_taps(std::vector<ConvTap>& host, ConvTap** dev) {
+  CVX_HIP(hipMalloc((void**)dev, host.size() * sizeof(ConvTap)));
+  CVX_HIP(hipMemcpy(*dev, host.data(), host.size() * sizeof(ConvTap), hipMemcpyHostToDevice));
+  return 0;
+}
+}  // namespace
+
+extern "C" int cvx_conv2d_nhwc(const void* x_f16, int32_t batch, int32_t ih, int32_t iw, int32_t cin, const void* w_f16, int32_t cout,
+                               int32_t k, int32_t stride, int32_t pad, int32_t dil, int32_t mode, const float* scale_or_bias,
+                               const float* shift, void* out, void* hip_stream) {
+  CVX_CHECK(x_f16 && w_f16 && out && k * k <= CVX_MAX_TAPS && stride >= 1 && dil >= 1, "bad arguments");
+  hipStream_t st = (hipStream_t)hip_stream;
+  const int oh = (ih + 2 * pad - dil * (k - 1) - 1) / stride + 1, ow = (iw + 2 * pad - dil * (k - 1) - 1) / stride + 1;
+  std::vector<ConvTap> taps;
+  for (int r = 0; r < k; ++r)
+    for (int s = 0; s < k; ++s) taps.push_back(ConvTap{r * dil - pad, s * dil - pad, r * k + s, 0});
+  ConvTap* dt = nullptr;
+  CVX_TRY(make_taps(taps, &dt));
+  ConvParams cp;
+  memset(&cp, 0, sizeof(cp));
+  cp.in = (const half_t*)x_f16;
+  cp.in_bstride = (long long)ih * iw * cin;
+  cp.in_ld = cin;
+  cp.IH = ih;
+  cp.IW = iw;
+  cp.Cin = cin;
+  cp.wt = (const half_t*)w_f16;
+  cp.wt_ld = k * k * cin;
+  cp.Cout = cout;
+  cp.B = batch;
+  cp.OH2 = oh;
+  cp.OW2 = ow;
+  cp.IS = stride;
+  cp.OS = 1;
+  cp.OWr = ow;
+  cp.ntaps = k * k;
+  cp.taps = dt;
+  cp.out_ld = cout;
+  cp.out_bstride = (long long)oh * ow * cout;
+  if (mode == 0) {
+    cp.epi = CVX_EPI_PLAIN;
+    cp.out16 = (half_t*)out;
+  } else if (mode == 1) {
+    cp.epi = CVX_EPI_AFFINE_SILU;
+    cp.scale = scale_or_bias;
+    cp.shift = shift;
+    cp.out16 = (half_t*)out;
+  } else {
+    cp.epi = CVX_EPI_BIAS_F32;
+    cp.bias = scale_or_bias;
+    cp.out32 = (float*)out;
+  }
+  int rc = cvx_conv_igemm_launch(cp, st, nullptr);
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(dt);
+  return rc;
+}
+
+extern "C" int cvx_conv2d_dgrad_nhwc(const void* dy_f16, int32_t batch, int32_t ih, int32_t iw, int32_t cin, const void* wt_f16, int32_t cout,
+                                     int32_t k, int32_t stride, int32_t pad, int32_t dil, void* dx_f16, void* hip_stream) {
+  CVX_CHECK(dy_f16 && wt_f16 && dx_f16 && k * k <= CVX_MAX_TAPS && stride >= 1 && stride <= 4, "bad arguments");
+  hipStream_t st = (hipStream_t)hip_stream;
+  const int oh = (ih + 2 * pad - dil * (k - 1) - 1) / stride + 1, ow = (iw + 2 * pad - dil * (k - 1) - 1) / stride + 1;
+  int rc = 0;
+  for (int ph = 0; ph < stride && rc == 0; ++ph)
+    for (int pw = 0; pw < stride && rc == 0; ++pw) {
+      std::vector<ConvTap> taps;
+      for (int r = 0; r < k; ++r) {
+        int nh = ph + pad - r * dil;
+        if (((nh % stride) + stride) % stride) continue;
+        for (int s = 0; s < k; ++s) {
+          int nw = pw + pad - s * dil;
+          if (((nw % stride) + stride) % stride) continue;
+          taps.push_back(ConvTap{nh / stride, nw / stride, r * k + s, 0});
+        }
+      }
+      const int OH2 = (ih - ph + stride - 1) / stride, OW2 = (iw - pw + stride - 1) / stride;
+      if (OH2 <= 0 || OW2 <= 0) continue;
+      CVX_CHECK(!taps.empty(), "dgrad phase without taps");
+      ConvTap* dt = nullptr;
+      CVX_TRY(make_taps(taps, &dt));
+      ConvParams cp;
+      memset(&cp, 0, sizeof(cp));
+      cp.in = (const half_t*)dy_f16;
+      cp.in_bstride = (long long)oh * ow * cout;
+      cp.in_ld = cout;
+      cp.IH = oh;
+      cp.IW = ow;
+      cp.Cin = cout;
+      cp.wt = (const half_t*)wt_f16;
+      cp.wt_ld = k * k * cout;
+      cp.Cout = cin;
+      cp.B = batch;
+      cp.OH2 = OH2;
+      cp.OW2 = OW2;
+      cp.IS = 1;
+      cp.OS = stride;
+      cp.oph = ph;
+      cp.opw = pw;
+      cp.OWr = iw;
+      cp.ntaps = (int)taps.size();
+      cp.taps = dt;
+      cp.epi = CVX_EPI_PLAIN;
+      cp.out16 = (half_t*)dx_f16;
+      cp.out_ld = cin;
+      cp.out_bstride = (long long)ih * iw * cin;
+      rc = cvx_conv_igemm_launch(cp, st, nullptr);
+      (void)hipStreamSynchronize(st);
+      (void)hipFree(dt);
+    }
+  return rc;
+}
+
+extern "C" int64_t cvx_conv2d_wgrad_workspace_bytes(int32_t batch, int32_t oh, int32_t ow, int32_t cin, int32_t cout, int32_t k) {
+  const long long M = (long long)batch * oh * ow;
+  long long ns = std::min<long long>(std::max<long long>(1, M / 256), 64);
+  return ns * cout * k * k * round_up(cin, 16) * 4 + 4096;
+}
+
+extern "C" int cvx_conv2d_wgrad_nhwc(const void* x_f16, const void* dy_f16, int32_t batch, int32_t ih, int32_t iw, int32_t cin, int32_t cout,
+                                     int32_t k, int32_t stride, int32_t pad, int32_t dil, float* dw, void* workspace, int64_t workspace_bytes,
+                                     void* hip_stream) {
+  CVX_CHECK(x_f16 && dy_f16 && dw && workspace && k * k <= CVX_MAX_TAPS, "bad arguments");
+  hipStream_t st = (hipStream_t)hip_stream;
+  const int oh = (ih + 2 * pad - dil * (k - 1) - 1) / stride + 1, ow = (iw + 2 * pad - dil * (k - 1) - 1) / stride + 1;
+  CVX_CHECK(workspace_bytes >= cvx_conv2d_wgrad_workspace_bytes(batch, oh, ow, cin, cout, k), "workspace too small");
+  const long long M = (long long)batch * oh * ow;
+  std::vector<ConvTap> taps;
+  for (int r = 0; r < k; ++r)
+    for (int s = 0; s < k; ++s) taps.push_back(ConvTap{r * dil - pad, s * dil - pad, r * k + s, 0});
+  ConvTap* dt = nullptr;
+  CVX_TRY(make_taps(taps, &dt));
+  WgradParams wp;
+  memset(&wp, 0, sizeof(wp));
+  wp.x = (const half_t*)x_f16;
+  wp.x_bstride = (long long)ih * iw * cin;
+  wp.x_ld = cin;
+  wp.IH = ih;
+  wp.IW = iw;
+  wp.Cin = cin;
+  wp.dy = (const half_t*)dy_f16;
+  wp.dy_bstride = (long long)oh * ow * cout;
+  wp.dy_ld = cout;
+  wp.Cout = cout;
+  wp.B = batch;
+  wp.OH = oh;
+  wp.OW = ow;
+  wp.stride = stride;
+  wp.ntaps = k * k;
+  wp.taps = dt;
+  wp.slabs = (float*)workspace;
+  wp.nsplit = (int)std::min<long long>(std::max<long long>(1, M / 256), 64);
+  wp.cin_pad16 = round_up(cin, 16);
+  int rc = cvx_conv_wgrad_launch(wp, st);
+  if (rc == 0) {
+    // reduce the slabs into dw (overwrite): zero, then the table-driven reducer with one descriptor
+    rc = hipMemsetAsync(dw, 0, (size_t)cout * k * k * cin * 4, st) == hipSuccess ? 0 : -1;
+    SlabDesc sd{0, 0, wp.nsplit, cout * k * k, cin, wp.cin_pad16};
+    std::vector<BlockRef> blocks;
+    const long long total = (long long)sd.rows * sd.Cin;
+    for (long long s0 = 0; s0 < total; s0 += 1024) blocks.push_back(BlockRef{0, (int)s0});
+    SlabDesc* dsd = nullptr;
+    BlockRef* dbl = nullptr;
+    if (hipMalloc((void**)&dsd, sizeof(sd)) != hipSuccess || hipMalloc((void**)&dbl, blocks.size() * sizeof(BlockRef)) != hipSuccess) rc = -1;
+    if (rc == 0) {
+      (void)hipMemcpy(dsd, &sd, sizeof(sd), hipMemcpyHostToDevice);
+      (void)hipMemcpy(dbl, blocks.data(), blocks.size() * sizeof(BlockRef), hipMemcpyHostToDevice);
+      rc = cvx_reduce_slabs((float*)workspace, dw, 1.0f, dsd, dbl, (int)blocks.size(), st);
+    }
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(dsd);
+    (void)hipFree(dbl);
+  }
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(dt);
+  return rc;
+}

@@ -1,0 +1,46 @@
+// Layout, pooling, resampling, weight-packing, gradient-slab reduction and Adam kernels.
+#pragma once
+#include "bn_act.h"
+
+int cvx_image_to_nhwc8(const float* img_nchw, int B, int H, int W, half_t* out, hipStream_t st);
+
+// 5x5 / stride 1 / pad 2 max pool on channel-slice views; idx (optional, train) records the argmax
+// tap (0..24, first max in row-major window order as torch does) per output element: [B*H*W][C] bytes.
+int cvx_maxpool5_fwd(const ViewDesc& in, const ViewDesc& out, int B, int H, int W, int C, uint8_t* idx, hipStream_t st);
+// gin (+)= scatter of gout through idx, written gather-style (no atomics)
+int cvx_maxpool5_bwd(const ViewDesc& gout, const ViewDesc& gin, int B, int H, int W, int C, const uint8_t* idx, int accumulate, hipStream_t st);
+
+int cvx_upsample2_fwd(const ViewDesc& in, const ViewDesc& out, int B, int H, int W, int C, hipStream_t st);  // (H,W) -> (2H,2W)
+int cvx_upsample2_bwd(const ViewDesc& gout, const ViewDesc& gin, int B, int H, int W, int C, int accumulate, hipStream_t st);
+
+// copy pred (B, A, no) fp32 level slice -> NCHW fp32 (B, no, H, W)   (API-compat outputs)
+int cvx_pred_to_nchw(const float* pred, int B, int A, int no, int a_off, int H, int W, float* out, hipStream_t st);
+int cvx_nchw_to_pred_f16(const float* g_nchw, int B, int A, int no, int a_off, int H, int W, float scale, half_t* dpred, hipStream_t st);
+
+// ---- table-driven multi-tensor kernels ---------------------------------------------------------
+struct PackDesc {        // one conv weight tensor
+  long long src_off;     // fp32 master, [Cout][T][Cin]
+  long long fwd_off;     // fp16 [Cout][T][Cin_pad]
+  long long dg_off;      // fp16 [Cin][T][Cout]  (-1: no dgrad copy)
+  int Cout, T, Cin, Cin_pad;
+};
+struct BlockRef {
+  int desc;
+  int start;  // first element (in units of the kernel's index space) this block handles
+};
+int cvx_pack_weights(const float* master, half_t* shadow, const PackDesc* descs, const BlockRef* blocks, int nblocks, hipStream_t st);
+
+struct SlabDesc {        // one weight-gradient tensor
+  long long slab_off;    // fp32 [nsplit][Cout*T][Cin_pad]
+  long long dst_off;     // fp32 grad arena [Cout*T][Cin]
+  int nsplit, rows, Cin, Cin_pad;
+};
+int cvx_reduce_slabs(const float* slabs, float* grads, float inv_scale, const SlabDesc* descs, const BlockRef* blocks, int nblocks,
+                     hipStream_t st);
+
+// Adam (torch.optim.Adam defaults semantics, no weight decay / amsgrad), fp32 state; optionally skipped
+// when *found_inf != 0; zeroes the gradient arena afterwards when zero_grad != 0.
+int cvx_adam(float* p, float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step, const int* found_inf,
+             int zero_grad, hipStream_t st);
+// sets *found_inf = 1 if any gradient is non-finite
+int cvx_check_finite_launch(const float* g, long long n, int* found_inf, hipStream_t st);

@@ -1,0 +1,323 @@
+// HBM-bound helper kernels (gfx950): layout change, SPPF max-pool, nearest upsample, weight shadow
+// packing, gradient-slab reduction, fused Adam.  16-byte accesses wherever the layout allows.
+#include "misc_ops.h"
+
+namespace {
+
+__device__ __forceinline__ long long voff(const ViewDesc& v, int b, long long pix) { return (long long)b * v.bstride + pix * v.ld; }
+
+// ---- NCHW fp32 image -> NHWC fp16 with C padded 3 -> 8 (16 B per pixel) -----------------------
+__global__ void image_to_nhwc8_kernel(const float* img, int B, int HW, half_t* out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long n = (long long)B * HW;
+  if (i >= n) return;
+  long long b = i / HW, pix = i - b * HW;
+  const float* src = img + b * 3 * HW + pix;
+  h8 o = {(half_t)src[0], (half_t)src[HW], (half_t)src[2LL * HW], (half_t)0, (half_t)0, (half_t)0, (half_t)0, (half_t)0};
+  *reinterpret_cast<h8*>(out + i * 8) = o;
+}
+
+// ---- max pool 5x5 s1 p2 ------------------------------------------------------------------------
+__global__ void maxpool5_fwd_kernel(ViewDesc in, ViewDesc out, int B, int H, int W, int CG, uint8_t* idx) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long n = (long long)B * H * W * CG;
+  if (i >= n) return;
+  int cg = (int)(i % CG);
+  long long t = i / CG;
+  int w = (int)(t % W);
+  t /= W;
+  int h = (int)(t % H);
+  int b = (int)(t / H);
+  float best[8];
+  int bi[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    best[k] = -INFINITY;
+    bi[k] = 0;
+  }
+  bool first = true;
+  for (int dy = 0; dy < 5; ++dy) {
+    int hh = h + dy - 2;
+    if (hh < 0 || hh >= H) continue;
+    for (int dx = 0; dx < 5; ++dx) {
+      int ww = w + dx - 2;
+      if (ww < 0 || ww >= W) continue;
+      h8 v = *reinterpret_cast<const h8*>(in.p + voff(in, b, (long long)hh * W + ww) + cg * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float f = (float)v[k];
+        if (first || f > best[k]) {
+          best[k] = f;
+          bi[k] = dy * 5 + dx;
+        }
+      }
+      first = false;
+    }
+  }
+  h8 o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = (half_t)best[k];
+  long long pix = (long long)h * W + w;
+  *reinterpret_cast<h8*>(out.p + voff(out, b, pix) + cg * 8) = o;
+  if (idx) {
+    unsigned long long pk = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pk |= (unsigned long long)(bi[k] & 0xff) << (8 * k);
+    *reinterpret_cast<unsigned long long*>(idx + (((long long)b * H * W + pix) * CG + cg) * 8) = pk;
+  }
+}
+
+__global__ void maxpool5_bwd_kernel(ViewDesc gout, ViewDesc gin, int B, int H, int W, int CG, const uint8_t* idx, int accumulate) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long n = (long long)B * H * W * CG;
+  if (i >= n) return;
+  int cg = (int)(i % CG);
+  long long t = i / CG;
+  int w = (int)(t % W);
+  t /= W;
+  int h = (int)(t % H);
+  int b = (int)(t / H);
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  // output (oh, ow) whose window contains (h, w): oh in [h-2, h+2]; its tap for this input is (h-oh+2, w-ow+2)
+  for (int oh = max(0, h - 2); oh <= min(H - 1, h + 2); ++oh) {
+    for (int ow = max(0, w - 2); ow <= min(W - 1, w + 2); ++ow) {
+      int tapcode = (h - oh + 2) * 5 + (w - ow + 2);
+      long long pix = (long long)oh * W + ow;
+      unsigned long long pk = *reinterpret_cast<const unsigned long long*>(idx + (((long long)b * H * W + pix) * CG + cg) * 8);
+      h8 g = *reinterpret_cast<const h8*>(gout.p + voff(gout, b, pix) + cg * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if ((int)((pk >> (8 * k)) & 0xff) == tapcode) acc[k] += (float)g[k];
+    }
+  }
+  half_t* q = gin.p + voff(gin, b, (long long)h * W + w) + cg * 8;
+  if (accumulate) {
+    h8 old = *reinterpret_cast<const h8*>(q);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += (float)old[k];
+  }
+  h8 o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = (half_t)acc[k];
+  *reinterpret_cast<h8*>(q) = o;
+}
+
+// ---- nearest 2x upsample -----------------------------------------------------------------------
+__global__ void upsample2_fwd_kernel(ViewDesc in, ViewDesc out, int B, int H, int W, int CG) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over OUTPUT elements
+  int OH = 2 * H, OW = 2 * W;
+  long long n = (long long)B * OH * OW * CG;
+  if (i >= n) return;
+  int cg = (int)(i % CG);
+  long long t = i / CG;
+  int ow = (int)(t % OW);
+  t /= OW;
+  int oh = (int)(t % OH);
+  int b = (int)(t / OH);
+  h8 v = *reinterpret_cast<const h8*>(in.p + voff(in, b, (long long)(oh >> 1) * W + (ow >> 1)) + cg * 8);
+  *reinterpret_cast<h8*>(out.p + voff(out, b, (long long)oh * OW + ow) + cg * 8) = v;
+}
+
+__global__ void upsample2_bwd_kernel(ViewDesc gout, ViewDesc gin, int B, int H, int W, int CG, int accumulate) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over INPUT elements
+  long long n = (long long)B * H * W * CG;
+  if (i >= n) return;
+  int cg = (int)(i % CG);
+  long long t = i / CG;
+  int w = (int)(t % W);
+  t /= W;
+  int h = (int)(t % H);
+  int b = (int)(t / H);
+  int OW = 2 * W;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      h8 g = *reinterpret_cast<const h8*>(gout.p + voff(gout, b, (long long)(2 * h + dy) * OW + 2 * w + dx) + cg * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += (float)g[k];
+    }
+  half_t* q = gin.p + voff(gin, b, (long long)h * W + w) + cg * 8;
+  if (accumulate) {
+    h8 old = *reinterpret_cast<const h8*>(q);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += (float)old[k];
+  }
+  h8 o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = (half_t)acc[k];
+  *reinterpret_cast<h8*>(q) = o;
+}
+
+// ---- pred (B, A, no) <-> NCHW level tensors (API-compat path only) ------------------------------
+__global__ void pred_to_nchw_kernel(const float* pred, int B, int A, int no, int a_off, int HW, float* out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over out elements (b, c, pix)
+  long long n = (long long)B * no * HW;
+  if (i >= n) return;
+  int pix = (int)(i % HW);
+  long long t = i / HW;
+  int c = (int)(t % no);
+  int b = (int)(t / no);
+  out[i] = pred[((long long)b * A + a_off + pix) * no + c];
+}
+__global__ void nchw_to_pred_f16_kernel(const float* g, int B, int A, int no, int a_off, int HW, float scale, half_t* dpred) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over (b, pix, c)
+  long long n = (long long)B * HW * no;
+  if (i >= n) return;
+  int c = (int)(i % no);
+  long long t = i / no;
+  int pix = (int)(t % HW);
+  int b = (int)(t / HW);
+  dpred[((long long)b * A + a_off + pix) * no + c] = (half_t)(g[((long long)b * no + c) * HW + pix] * scale);
+}
+
+// ---- weight shadow packing ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* master, half_t* shadow, const PackDesc* descs, const BlockRef* blocks) {
+  const BlockRef br = blocks[blockIdx.x];
+  const PackDesc d = descs[br.desc];
+  const int total = d.Cout * d.T * d.Cin_pad;
+  for (int k = 0; k < 4; ++k) {
+    int e = br.start + k * 256 + threadIdx.x;
+    if (e >= total) return;
+    int ci = e % d.Cin_pad;
+    int row = e / d.Cin_pad;  // co*T + t
+    float v = ci < d.Cin ? master[d.src_off + (long long)row * d.Cin + ci] : 0.f;
+    shadow[d.fwd_off + e] = (half_t)v;
+    if (d.dg_off >= 0 && ci < d.Cin) {
+      int t = row % d.T, co = row / d.T;
+      shadow[d.dg_off + ((long long)ci * d.T + t) * d.Cout + co] = (half_t)v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* slabs, float* grads, float inv_scale, const SlabDesc* descs,
+                                                           const BlockRef* blocks) {
+  const BlockRef br = blocks[blockIdx.x];
+  const SlabDesc d = descs[br.desc];
+  const long long total = (long long)d.rows * d.Cin;
+  const long long slab_elems = (long long)d.rows * d.Cin_pad;
+  for (int k = 0; k < 4; ++k) {
+    long long e = (long long)br.start + k * 256 + threadIdx.x;
+    if (e >= total) return;
+    int ci = (int)(e % d.Cin);
+    long long row = e / d.Cin;
+    const float* s = slabs + d.slab_off + row * d.Cin_pad + ci;
+    float acc = 0.f;
+    for (int sp = 0; sp < d.nsplit; ++sp) acc += s[(long long)sp * slab_elems];
+    grads[d.dst_off + e] += acc * inv_scale;
+  }
+}
+
+// ---- Adam ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* p, float* g, float* m, float* v, long long n, float lr_over_bc1, float b1, float b2,
+                                                   float eps, float inv_sqrt_bc2, const int* found_inf, int zero_grad) {
+  const bool skip = found_inf && *found_inf != 0;
+  long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 4 <= n) {
+    f4 gg = *reinterpret_cast<f4*>(g + i);
+    if (!skip) {
+      f4 pp = *reinterpret_cast<f4*>(p + i), mm = *reinterpret_cast<f4*>(m + i), vv = *reinterpret_cast<f4*>(v + i);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        mm[k] = b1 * mm[k] + (1.f - b1) * gg[k];
+        vv[k] = b2 * vv[k] + (1.f - b2) * gg[k] * gg[k];
+        pp[k] -= lr_over_bc1 * mm[k] / (sqrtf(vv[k]) * inv_sqrt_bc2 + eps);
+      }
+      *reinterpret_cast<f4*>(p + i) = pp;
+      *reinterpret_cast<f4*>(m + i) = mm;
+      *reinterpret_cast<f4*>(v + i) = vv;
+    }
+    if (zero_grad) *reinterpret_cast<f4*>(g + i) = f4{0.f, 0.f, 0.f, 0.f};
+  } else {
+    for (; i < n; ++i) {
+      float gg = g[i];
+      if (!skip) {
+        float mm = b1 * m[i] + (1.f - b1) * gg;
+        float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+        m[i] = mm;
+        v[i] = vv;
+        p[i] -= lr_over_bc1 * mm / (sqrtf(vv) * inv_sqrt_bc2 + eps);
+      }
+      if (zero_grad) g[i] = 0.f;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void check_finite_kernel(const float* g, long long n, int* found_inf) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  bool bad = false;
+  for (; i < n; i += stride) {
+    float x = g[i];
+    bad |= !(fabsf(x) <= 3.0e38f);
+  }
+  if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) *found_inf = 1;
+}
+
+template <typename K, typename... Args>
+int launch1d(K kern, long long n, hipStream_t st, Args... args) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(kern, dim3(cvx_cdiv(n, 256)), dim3(256), 0, st, args...);
+  CVX_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+int cvx_image_to_nhwc8(const float* img, int B, int H, int W, half_t* out, hipStream_t st) {
+  return launch1d(image_to_nhwc8_kernel, (long long)B * H * W, st, img, B, H * W, out);
+}
+int cvx_maxpool5_fwd(const ViewDesc& in, const ViewDesc& out, int B, int H, int W, int C, uint8_t* idx, hipStream_t st) {
+  CVX_CHECK(C % 8 == 0, "maxpool5: C % 8");
+  return launch1d(maxpool5_fwd_kernel, (long long)B * H * W * (C / 8), st, in, out, B, H, W, C / 8, idx);
+}
+int cvx_maxpool5_bwd(const ViewDesc& gout, const ViewDesc& gin, int B, int H, int W, int C, const uint8_t* idx, int accumulate, hipStream_t st) {
+  CVX_CHECK(C % 8 == 0 && idx, "maxpool5_bwd: C % 8 / idx");
+  return launch1d(maxpool5_bwd_kernel, (long long)B * H * W * (C / 8), st, gout, gin, B, H, W, C / 8, idx, accumulate);
+}
+int cvx_upsample2_fwd(const ViewDesc& in, const ViewDesc& out, int B, int H, int W, int C, hipStream_t st) {
+  CVX_CHECK(C % 8 == 0, "upsample2: C % 8");
+  return launch1d(upsample2_fwd_kernel, (long long)B * 4 * H * W * (C / 8), st, in, out, B, H, W, C / 8);
+}
+int cvx_upsample2_bwd(const ViewDesc& gout, const ViewDesc& gin, int B, int H, int W, int C, int accumulate, hipStream_t st) {
+  CVX_CHECK(C % 8 == 0, "upsample2_bwd: C % 8");
+  return launch1d(upsample2_bwd_kernel, (long long)B * H * W * (C / 8), st, gout, gin, B, H, W, C / 8, accumulate);
+}
+int cvx_pred_to_nchw(const float* pred, int B, int A, int no, int a_off, int H, int W, float* out, hipStream_t st) {
+  return launch1d(pred_to_nchw_kernel, (long long)B * no * H * W, st, pred, B, A, no, a_off, H * W, out);
+}
+int cvx_nchw_to_pred_f16(const float* g, int B, int A, int no, int a_off, int H, int W, float scale, half_t* dpred, hipStream_t st) {
+  return launch1d(nchw_to_pred_f16_kernel, (long long)B * no * H * W, st, g, B, A, no, a_off, H * W, scale, dpred);
+}
+int cvx_pack_weights(const float* master, half_t* shadow, const PackDesc* descs, const BlockRef* blocks, int nblocks, hipStream_t st) {
+  if (nblocks <= 0) return 0;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(nblocks), dim3(256), 0, st, master, shadow, descs, blocks);
+  CVX_HIP(hipGetLastError());
+  return 0;
+}
+int cvx_reduce_slabs(const float* slabs, float* grads, float inv_scale, const SlabDesc* descs, const BlockRef* blocks, int nblocks,
+                     hipStream_t st) {
+  if (nblocks <= 0) return 0;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(nblocks), dim3(256), 0, st, slabs, grads, inv_scale, descs, blocks);
+  CVX_HIP(hipGetLastError());
+  return 0;
+}
+int cvx_adam(float* p, float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step, const int* found_inf,
+             int zero_grad, hipStream_t st) {
+  CVX_CHECK(step >= 1, "adam: step starts at 1");
+  double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+  return launch1d(adam_kernel, (n + 3) / 4, st, p, g, m, v, n, (float)(lr / bc1), b1, b2, eps, (float)(1.0 / sqrt(bc2)), found_inf, zero_grad);
+}
+int cvx_check_finite_launch(const float* g, long long n, int* found_inf, hipStream_t st) {
+  if (n <= 0) return 0;
+  int blocks = (int)std::min<long long>(1024, (n + 255) / 256);
+  hipLaunchKernelGGL(check_finite_kernel, dim3(blocks), dim3(256), 0, st, g, n, found_inf);
+  CVX_HIP(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,166 @@
+"""Python handle on a ``cvx_engine`` (one per device and input size) plus the standalone C-ABI ops.
+
+PyTorch appears here only as the owner of device memory and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib as L
+from .graph import Graph, ParamLayout, build_yolov8_graph
+
+
+def _need_gpu(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise L.CvxError(f"{what} must live on an MI355X device (got {t.device}); the engine has no CPU path")
+
+
+class Engine:
+    def __init__(self, graph: Graph, device: torch.device):
+        self.lib = L.load()
+        self.graph = graph
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise L.CvxError("the engine needs a HIP device (torch device type 'cuda'); there is no CPU path")
+        bufs, ops = graph.c_arrays()
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.cvx_engine_create(C.byref(h), bufs, len(graph.bufs), ops, len(graph.ops), graph.image_buf, graph.pred_buf,
+                                               self.device.index or 0, L.stream_ptr(self.device)), "cvx_engine_create")
+        self.handle = h
+        self._bound = None
+
+    def bind(self, params: torch.Tensor, grads: Optional[torch.Tensor], stats: torch.Tensor):
+        for t, n in ((params, "params"), (stats, "stats")):
+            _need_gpu(t, n)
+            assert t.dtype == torch.float32 and t.is_contiguous()
+        key = (params.data_ptr(), 0 if grads is None else grads.data_ptr(), stats.data_ptr())
+        if key == self._bound:
+            return
+        L.check(self.lib.cvx_engine_bind(self.handle, L.ptr(params), L.ptr(grads), params.numel(), L.ptr(stats), stats.numel()),
+                "cvx_engine_bind")
+        self._bound = key
+        self._keep = (params, grads, stats)
+
+    def set_bn(self, eps: float, momentum: float):
+        L.check(self.lib.cvx_engine_set_bn(self.handle, eps, momentum), "cvx_engine_set_bn")
+
+    def forward(self, images: torch.Tensor, training: bool, pred: Optional[torch.Tensor] = None) -> torch.Tensor:
+        _need_gpu(images, "images")
+        images = images.contiguous().float()
+        b = images.shape[0]
+        no = self.graph.bufs[self.graph.pred_buf][2]
+        if pred is None:
+            pred = torch.empty(b, self.graph.anchors, no, device=images.device, dtype=torch.float32)
+        L.check(self.lib.cvx_engine_forward(self.handle, L.ptr(images), b, 1 if training else 0, L.ptr(pred)), "cvx_engine_forward")
+        return pred
+
+    def backward(self, dpred_f16: torch.Tensor, loss_scale: float):
+        assert dpred_f16.dtype == torch.float16 and dpred_f16.is_contiguous()
+        L.check(self.lib.cvx_engine_backward(self.handle, L.ptr(dpred_f16), float(loss_scale)), "cvx_engine_backward")
+
+    def read_buffer(self, buf: int, batch: int, grad: bool = False) -> torch.Tensor:
+        """Debug: NHWC fp16 copy of an engine buffer (activation or gradient)."""
+        h, w, c, _ = self.graph.bufs[buf]
+        out = torch.empty(batch, h, w, c, dtype=torch.float16, device=self.device)
+        L.check(self.lib.cvx_engine_debug_copy(self.handle, buf, 1 if grad else 0, L.ptr(out), out.numel() * 2), "cvx_engine_debug_copy")
+        return out
+
+    def workspace_bytes(self) -> int:
+        return int(self.lib.cvx_engine_workspace_bytes(self.handle))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.cvx_engine_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+# ---- standalone ops ---------------------------------------------------------------------------------
+def _levels(level_hw: Sequence[Sequence[int]], strides: Sequence[float]):
+    flat = [int(v) for hw in level_hw for v in hw]
+    return (C.c_int32 * len(flat))(*flat), (C.c_float * len(strides))(*[float(s) for s in strides]), len(strides)
+
+
+class V8LossOp:
+    """cvx_loss_v8: loss items + fp16 gradient w.r.t. pred (B, A, no)."""
+
+    def __init__(self, nc: int, gains=(7.5, 0.5, 1.5)):
+        self.lib = L.load()
+        self.nc = nc
+        self.gains = tuple(float(g) for g in gains)
+        self._ws = None
+
+    def __call__(self, pred: torch.Tensor, targets: torch.Tensor, level_hw, strides, loss_scale: float,
+                 dpred: Optional[torch.Tensor] = None):
+        _need_gpu(pred, "pred")
+        assert pred.dtype == torch.float32 and pred.is_contiguous()
+        B, A, no = pred.shape
+        assert no == self.nc + 64
+        n = int(targets.shape[0])
+        if n:
+            _need_gpu(targets, "targets")
+            targets = targets.contiguous().float()
+        cap = max(n, 1)
+        need = int(self.lib.cvx_loss_v8_workspace_bytes(B, A, self.nc, cap))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != pred.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=pred.device)
+        if dpred is None:
+            dpred = torch.empty(B, A, no, dtype=torch.float16, device=pred.device)
+        items = torch.empty(3, dtype=torch.float32, device=pred.device)
+        lv, st, nl = _levels(level_hw, strides)
+        L.check(self.lib.cvx_loss_v8(L.ptr(pred), B, A, self.nc, L.ptr(targets) if n else C.c_void_p(0), n, cap, lv, st, nl, self.gains[0],
+                                     self.gains[1], self.gains[2], float(loss_scale), L.ptr(items), L.ptr(dpred), L.ptr(self._ws),
+                                     self._ws.numel(), L.stream_ptr(pred.device)), "cvx_loss_v8")
+        return items, dpred
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, lr, betas, eps, step, found_inf=None, zero_grad=True):
+    lib = L.load()
+    _need_gpu(params, "params")
+    L.check(lib.cvx_adam_step(L.ptr(params), L.ptr(grads), L.ptr(exp_avg), L.ptr(exp_avg_sq), params.numel(), lr, betas[0], betas[1], eps,
+                              step, L.ptr(found_inf), 1 if zero_grad else 0, L.stream_ptr(params.device)), "cvx_adam_step")
+
+
+def check_finite(grads: torch.Tensor, found_inf: torch.Tensor):
+    lib = L.load()
+    L.check(lib.cvx_check_finite(L.ptr(grads), grads.numel(), L.ptr(found_inf), L.stream_ptr(grads.device)), "cvx_check_finite")
+
+
+def decode(pred: torch.Tensor, nc: int, level_hw, strides) -> torch.Tensor:
+    lib = L.load()
+    _need_gpu(pred, "pred")
+    B, A, no = pred.shape
+    y = torch.empty(B, 4 + nc, A, dtype=torch.float32, device=pred.device)
+    lv, st, nl = _levels(level_hw, strides)
+    L.check(lib.cvx_decode(L.ptr(pred.contiguous()), B, A, nc, lv, st, nl, L.ptr(y), L.stream_ptr(pred.device)), "cvx_decode")
+    return y
+
+
+_nms_ws = {}
+
+
+def nms(y: torch.Tensor, conf_thres: float, iou_thres: float, max_det: int = 300):
+    """y (B, 4+nc, A) fp32 -> (rows (B,max_det,6), anchor_index (B,max_det) int32, counts (B,) int32), all on device."""
+    lib = L.load()
+    _need_gpu(y, "y")
+    if not (0 <= conf_thres <= 1 and 0 <= iou_thres <= 1):
+        raise AssertionError("thresholds must lie in [0, 1]")       # ultralytics_ops.py:173-174
+    y = y.contiguous().float()
+    B, ch, A = y.shape
+    nc = ch - 4
+    need = int(lib.cvx_nms_workspace_bytes(B, A))
+    ws = _nms_ws.get(y.device)
+    if ws is None or ws.numel() < need:
+        ws = _nms_ws[y.device] = torch.empty(need, dtype=torch.uint8, device=y.device)
+    rows = torch.zeros(B, max_det, 6, dtype=torch.float32, device=y.device)
+    index = torch.zeros(B, max_det, dtype=torch.int32, device=y.device)
+    counts = torch.zeros(B, dtype=torch.int32, device=y.device)
+    L.check(lib.cvx_nms(L.ptr(y), B, A, nc, conf_thres, iou_thres, max_det, L.ptr(rows), L.ptr(index), L.ptr(counts), L.ptr(ws), ws.numel(),
+                        L.stream_ptr(y.device)), "cvx_nms")
+    return rows, index, counts

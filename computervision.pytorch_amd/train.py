@@ -1,0 +1,173 @@
+"""Loss, optimiser and the fused train step on top of the engine.
+
+* ``V8DetectionLoss`` -- the reference's ``Loss(cfg, model)`` callable (core/algorithms/yolo_v8.py:25-124):
+  ``loss, items = criterion(preds, batch)``; value and gradient come from ``cvx_loss_v8``.
+* ``FlatAdam`` -- ``torch.optim.Optimizer``-shaped wrapper over ``cvx_adam_step`` on the flat arenas
+  (the reference builds ``torch.optim.Adam`` over all parameters, core/trainer/lr_scheduler.py:37-43).
+* ``FusedTrainStep`` -- zero_grad -> forward -> loss -> backward -> [all-reduce] -> Adam as five C-ABI
+  calls with no per-parameter Python work (the reference's ``train_loop``,
+  core/trainer/yolo8_train.py:93-111).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+from .engine import V8LossOp, adam_step, check_finite
+from .graph import STRIDES
+from .model import PredList, Yolo8
+
+
+def flatten_targets(batch: Dict[str, torch.Tensor], device) -> torch.Tensor:
+    """yolo8_collate dict (core/data/collate.py:25-29) -> (N, 6) [batch_idx, cls, cx, cy, w, h] on `device`,
+    grouped by image in stable order (what Loss.preprocess does row by row, yolo_v8.py:51-65)."""
+    bi = batch["batch_idx"].reshape(-1, 1).float()
+    if bi.numel() == 0:
+        return torch.zeros(0, 6, device=device)
+    t = torch.cat((bi, batch["cls"].reshape(-1, 1).float(), batch["bboxes"].reshape(-1, 4).float()), 1).to(device)
+    order = torch.sort(t[:, 0], stable=True).indices
+    return t[order].contiguous()
+
+
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, targets, owner, level_hw):
+        items, dpred = owner.op(pred.detach().contiguous(), targets, level_hw, STRIDES, owner.loss_scale)
+        ctx.save_for_backward(dpred)
+        ctx.inv_scale = 1.0 / owner.loss_scale
+        owner.last_items = items
+        return items.sum() * pred.shape[0]                       # yolo_v8.py:124
+
+    @staticmethod
+    def backward(ctx, gout):
+        (dpred,) = ctx.saved_tensors
+        return dpred.float() * (gout * ctx.inv_scale), None, None, None
+
+
+class V8DetectionLoss:
+    def __init__(self, cfg, model: Yolo8):
+        m = model.model[-1]
+        self.nc, self.no, self.reg_max = m.nc, m.no, m.reg_max
+        self.stride = m.stride
+        self.box, self.cls, self.dfl = cfg.loss.box, cfg.loss.cls, cfg.loss.dfl
+        self.loss_scale = float(getattr(getattr(cfg, "engine", None), "loss_scale", 1024.0))
+        self.op = V8LossOp(self.nc, (self.box, self.cls, self.dfl))
+        self.device = next(model.parameters()).device
+        self.last_items = None
+
+    def __call__(self, preds, batch):
+        feats = preds[1] if isinstance(preds, tuple) else preds
+        pred = getattr(feats, "pred", None)
+        if pred is None:                                           # plain list of NCHW tensors: re-fuse (plumbing)
+            b = feats[0].shape[0]
+            pred = torch.cat([f.reshape(b, self.no, -1) for f in feats], 2).permute(0, 2, 1).contiguous()
+            level_hw = [tuple(f.shape[2:]) for f in feats]
+        else:
+            level_hw = feats.level_hw
+        targets = flatten_targets(batch, pred.device)
+        loss = _LossFn.apply(pred, targets, self, level_hw)
+        return loss, self.last_items.detach()
+
+
+class FlatAdam(torch.optim.Optimizer):
+    """Adam over the model's flat arenas; ``param_groups`` keeps torch's shape so LR schedulers work."""
+
+    def __init__(self, model: Yolo8, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.model = model
+        params = [p for p in model.parameters() if p.requires_grad]
+        super().__init__([{"params": params, "initial_lr": lr}], dict(lr=lr, betas=betas, eps=eps))
+        self._m = None
+        self._v = None
+        self._step = 0
+        self.found_inf: Optional[torch.Tensor] = None
+
+    def _ensure_state(self):
+        p = self.model.flat_params
+        if self._m is None or self._m.device != p.device:
+            self._m, self._v = torch.zeros_like(p), torch.zeros_like(p)
+
+    @torch.no_grad()
+    def step(self, closure=None, zero_grad: bool = False):
+        self._ensure_state()
+        g = self.param_groups[0]
+        self._step += 1
+        adam_step(self.model.flat_params, self.model.flat_grads, self._m, self._v, g["lr"], g["betas"], g["eps"], self._step,
+                  self.found_inf, zero_grad)
+
+    def zero_grad(self, set_to_none: bool = True):
+        self.model.flat_grads.zero_()
+
+    def state_dict(self):
+        return {"step": self._step, "exp_avg": self._m, "exp_avg_sq": self._v, "param_groups": [
+            {k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self._step = int(sd["step"])
+        self._ensure_state()
+        if sd.get("exp_avg") is not None:
+            self._m.copy_(sd["exp_avg"])
+            self._v.copy_(sd["exp_avg_sq"])
+        for g, s in zip(self.param_groups, sd.get("param_groups", [])):
+            g.update(s)
+
+
+class FusedTrainStep:
+    """One optimisation step = forward, loss(+grad), backward, optional DP all-reduce, Adam.
+
+    With ``world_size > 1`` (``torch.distributed`` initialised, backend nccl == RCCL) the flat gradient
+    arena is averaged across ranks in ``n_buckets`` contiguous slices on a side HIP stream, each slice as
+    soon as the backward pass has produced it; BN statistics stay per rank (the reference has no SyncBN).
+    """
+
+    def __init__(self, model: Yolo8, criterion: V8DetectionLoss, optimizer: FlatAdam, process_group=None, n_buckets: int = 4):
+        self.model, self.criterion, self.optimizer = model, criterion, optimizer
+        self.pg = process_group
+        self.n_buckets = n_buckets
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+        self._pred = None
+        self._dpred = None
+        self._side = None
+        self.found_inf = None
+
+    def __call__(self, images: torch.Tensor, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        m, crit = self.model, self.criterion
+        dev = m.flat_params.device
+        B, _, H, W = images.shape
+        eng = m.engine_for(H, W)
+        A, no = eng.graph.anchors, m.model[-1].no
+        if self._pred is None or self._pred.shape[0] != B or self._pred.shape[1] != A:
+            self._pred = torch.empty(B, A, no, device=dev)
+            self._dpred = torch.empty(B, A, no, device=dev, dtype=torch.float16)
+        targets = flatten_targets(batch, dev)
+        pred = m._run_forward(images, training=True, pred=self._pred)
+        items, dpred = crit.op(pred, targets, m.level_shapes(H, W), STRIDES, crit.loss_scale, self._dpred)
+        eng.backward(dpred, crit.loss_scale)
+        if self.world > 1:
+            self._allreduce(m.flat_grads)
+        self.optimizer.step(zero_grad=True)
+        return items
+
+    def _allreduce(self, g: torch.Tensor):
+        import torch.distributed as dist
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=g.device) if g.is_cuda else None
+        n = g.numel()
+        per = (n + self.n_buckets - 1) // self.n_buckets
+        per = (per + 3) & ~3
+        if self._side is None:                                    # CPU tensors (gloo tests of the bucketing logic)
+            for s in range(0, n, per):
+                dist.all_reduce(g[s:s + per], group=self.pg)
+            g.div_(self.world)
+            return
+        cur = torch.cuda.current_stream(g.device)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            for s in range(0, n, per):
+                chunk = g[s:s + per]
+                dist.all_reduce(chunk, group=self.pg)
+                chunk.div_(self.world)
+        cur.wait_stream(self._side)

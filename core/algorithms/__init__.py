@@ -1,0 +1,2 @@
+"""Algorithm classes; importing registers them as ``model_<name>`` (reference core/algorithms/__init__.py)."""
+from .yolo_v8 import YOLOv8  # noqa: F401

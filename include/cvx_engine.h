@@ -1,0 +1,151 @@
+/* cvx_engine.h -- C ABI of the MI355X (gfx950) detection engine, libcvx_engine.so.
+ *
+ * The reference (calmiLovesAI/ComputerVision.pytorch) has no C/FFI boundary: its hot path is
+ * torch.nn / ATen calls made from Python.  This header is the boundary a maintainer binds instead
+ * (ctypes stub in INTEGRATION.md); each entry point names the reference interface it replaces,
+ * as file:line under the reference tree.
+ *
+ * Conventions: plain pointers and sizes only (no torch types); every function returns 0 on success
+ * and -1 on failure with the message available from cvx_last_error(); all device pointers are HIP
+ * device memory owned by the caller unless stated; work is enqueued on the hipStream_t passed at
+ * creation (stream-ordered, no host synchronisation inside).  One engine per device, externally
+ * synchronised.  Activations are NHWC fp16, accumulation fp32, parameters/gradients fp32.
+ */
+#ifndef CVX_ENGINE_H
+#define CVX_ENGINE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CVX_ABI_VERSION 1
+
+const char* cvx_last_error(void);
+int cvx_abi_version(void);
+
+/* ---- graph description (built by the Python mirror of core/models/yolov8/yolo_v8.py:16-107) ---- */
+enum { CVX_BUF_ACT_F16 = 0, CVX_BUF_PRED_F32 = 1 };
+typedef struct {
+  int32_t h, w, c; /* per image; PRED buffers: h*w = anchors, c = no (=nc+64) */
+  int32_t kind;
+} cvx_buf_desc;
+
+typedef struct {
+  int32_t buf;     /* index into the buffer table, -1 = none */
+  int32_t coff;    /* first channel of the slice */
+  int32_t c;       /* channels in the slice */
+  int32_t pix_off; /* first pixel row (PRED buffers: anchor offset of the level), else 0 */
+} cvx_view;
+
+enum { CVX_OP_CONV = 1, CVX_OP_MAXPOOL5 = 2, CVX_OP_UPSAMPLE2 = 3 };
+enum { CVX_ACT_BN_SILU = 1, CVX_ACT_BIAS = 2 };
+
+typedef struct {
+  int32_t type;
+  cvx_view in, out, res;  /* res: residual added after the activation (Bottleneck shortcut) */
+  int32_t ih, iw, oh, ow; /* spatial size of the input / output views */
+  int32_t k, stride, pad, dil;
+  int32_t act;            /* CONV: CVX_ACT_BN_SILU (modules.py:29-30) or CVX_ACT_BIAS (modules.py:424-425 last layer) */
+  int32_t needs_dgrad;    /* 0 for the stem (input is the image) */
+  int32_t w_cin;          /* input channels of the stored weight tensor (stem: 3, its view is zero-padded to 8) */
+  /* element offsets into the caller's flat fp32 arenas; weights are stored [cout][kh][kw][cin] */
+  int64_t w_off;
+  int64_t gamma_off, beta_off; /* BN affine (param arena) */
+  int64_t bias_off;            /* CVX_ACT_BIAS */
+  int64_t rmean_off, rvar_off; /* BN running statistics (stats arena) */
+} cvx_op_desc;
+
+typedef struct cvx_engine cvx_engine;
+
+/* Builds an engine for a fixed input size.  `image_buf` is the index of the NHWC fp16 buffer
+ * (c == 8, channels 3..7 zero) the engine fills from the caller's NCHW fp32 images.
+ * Replaces: Yolo8.__init__ graph construction, core/models/yolov8/yolo_v8.py:17-62. */
+int cvx_engine_create(cvx_engine** out, const cvx_buf_desc* bufs, int32_t nbufs, const cvx_op_desc* ops, int32_t nops,
+                      int32_t image_buf, int32_t pred_buf, int32_t device, void* hip_stream);
+int cvx_engine_destroy(cvx_engine* e);
+
+/* Binds the caller-owned flat arenas (fp32): parameters, gradients (same layout) and BN running
+ * statistics.  Replaces: nn.Module parameter/buffer storage (state_dict tensors are views of these). */
+int cvx_engine_bind(cvx_engine* e, float* params, float* grads, int64_t n_params, float* stats, int64_t n_stats);
+
+/* BatchNorm hyper-parameters (core/models/yolov8/torch_utils.py:17-19: eps 1e-3, momentum 0.03). */
+int cvx_engine_set_bn(cvx_engine* e, float eps, float momentum);
+
+/* Forward pass.  images: (B,3,H,W) fp32 NCHW in [0,1]; pred: (B, A, no) fp32, anchors of the three
+ * levels concatenated (80x80, 40x40, 20x20 order), channels = [64 DFL logits | nc class logits].
+ * training != 0: batch statistics + running-stat update, activations kept for backward.
+ * Replaces: Yolo8.forward, core/models/yolov8/yolo_v8.py:78-107 (+ Conv/C2f/SPPF/Detect in modules.py). */
+int cvx_engine_forward(cvx_engine* e, const float* images, int32_t batch, int32_t training, float* pred);
+
+/* Backward pass of the last training forward.  dpred: (B, A, no) fp16 = loss_scale * dLoss/dpred.
+ * Parameter gradients are ACCUMULATED (+=, unscaled by 1/loss_scale) into the bound gradient arena.
+ * Replaces: loss.backward() through the model, core/trainer/yolo8_train.py:103,108. */
+int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float loss_scale);
+
+/* Debug/inspection: copies activation (which=0) or gradient (which=1) buffer `buf` of the last planned
+ * batch, NHWC fp16, into dst (device or host memory, `bytes` must equal batch*h*w*c*2). */
+int cvx_engine_debug_copy(cvx_engine* e, int32_t buf, int32_t which, void* dst, int64_t bytes);
+
+/* Bytes of device memory the engine currently owns (workspaces). */
+int64_t cvx_engine_workspace_bytes(const cvx_engine* e);
+
+/* Copies one level of pred into an NCHW fp32 tensor (B, no, H, W) -- the reference's output format
+ * (core/models/yolov8/modules.py:431-433) -- and the inverse for incoming NCHW gradients. */
+int cvx_pred_level_to_nchw(const float* pred, int32_t batch, int32_t anchors, int32_t no, int32_t a_off, int32_t h, int32_t w,
+                           float* out_nchw, void* hip_stream);
+int cvx_nchw_grad_to_dpred(const float* grad_nchw, int32_t batch, int32_t anchors, int32_t no, int32_t a_off, int32_t h, int32_t w,
+                           float scale, void* dpred_f16, void* hip_stream);
+
+/* ---- v8 detection loss: TaskAlignedAssigner + BCE + CIoU + DFL, forward AND gradient --------------
+ * pred (B,A,no) fp32; targets: n_targets rows [batch_idx, cls, cx, cy, w, h] (normalised, the
+ * yolo8_collate dict flattened, core/data/collate.py:25-29); level_hw: 3 x (h, w); strides: 3.
+ * Outputs: loss_items[3] = (box, cls, dfl) * gains (device fp32), dpred (B,A,no) fp16 =
+ * loss_scale * d(sum(items) * B)/dpred.  workspace: cvx_loss_v8_workspace_bytes() bytes.
+ * Replaces: Loss.__call__, core/algorithms/yolo_v8.py:75-124; TaskAlignedAssigner, core/utils/bboxes.py:275-470;
+ * BboxLoss, core/loss/ultralytics_loss.py:25-57; bbox_iou, core/utils/ultralytics_iou.py:64-117. */
+int64_t cvx_loss_v8_workspace_bytes(int32_t batch, int32_t anchors, int32_t nc, int32_t max_targets_per_image);
+int cvx_loss_v8(const float* pred, int32_t batch, int32_t anchors, int32_t nc, const float* targets, int32_t n_targets,
+                int32_t max_targets_per_image, const int32_t* level_hw, const float* strides, int32_t n_levels, float gain_box,
+                float gain_cls, float gain_dfl, float loss_scale, float* loss_items, void* dpred_f16, void* workspace,
+                int64_t workspace_bytes, void* hip_stream);
+
+/* ---- optimiser ------------------------------------------------------------------------------------
+ * torch.optim.Adam semantics (core/trainer/lr_scheduler.py:37-43): lr, betas, eps, no weight decay;
+ * `step` counts from 1.  found_inf (device int32, may be NULL): when non-zero the update is skipped
+ * (GradScaler.step semantics, core/trainer/yolo8_train.py:104).  zero_grad: clear g afterwards. */
+int cvx_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                  float eps, int32_t step, const int32_t* found_inf, int32_t zero_grad, void* hip_stream);
+int cvx_check_finite(const float* grads, int64_t n, int32_t* found_inf, void* hip_stream);
+
+/* ---- eval tail: DFL decode + sigmoid, then class-aware NMS ---------------------------------------
+ * cvx_decode: pred (B,A,no) -> y (B, 4+nc, A) fp32 [cx,cy,w,h (pixels), class scores]
+ *   Replaces: Detect eval branch, core/models/yolov8/modules.py:434-446.
+ * cvx_nms: y -> per image up to max_det rows [x1,y1,x2,y2,conf,cls] + the anchor index of each row;
+ *   counts[b] = rows kept.  Semantics = oracle/nms_ref.py (torchvision batched_nms restated).
+ *   Replaces: non_max_suppression, core/utils/ultralytics_ops.py:131-264. */
+int cvx_decode(const float* pred, int32_t batch, int32_t anchors, int32_t nc, const int32_t* level_hw, const float* strides,
+               int32_t n_levels, float* y, void* hip_stream);
+int64_t cvx_nms_workspace_bytes(int32_t batch, int32_t anchors);
+int cvx_nms(const float* y, int32_t batch, int32_t anchors, int32_t nc, float conf_thres, float iou_thres, int32_t max_det,
+            float* out_rows, int32_t* out_index, int32_t* counts, void* workspace, int64_t workspace_bytes, void* hip_stream);
+
+/* ---- single-op entry points (unit tests and other model families reuse them) -----------------------
+ * NHWC fp16 convolution, weights [cout][kh][kw][cin] fp16.  mode 0: out fp16 = conv; mode 1: out fp16 =
+ * silu(conv*scale+shift); mode 2: out fp32 = conv + bias.  Replaces: F.conv2d as used by Conv.forward,
+ * core/models/yolov8/modules.py:29-30. */
+int cvx_conv2d_nhwc(const void* x_f16, int32_t batch, int32_t ih, int32_t iw, int32_t cin, const void* w_f16, int32_t cout, int32_t k,
+                    int32_t stride, int32_t pad, int32_t dil, int32_t mode, const float* scale_or_bias, const float* shift, void* out,
+                    void* hip_stream);
+/* data gradient: dx (B,ih,iw,cin) fp16 from dy (B,oh,ow,cout) fp16 and w_t [cin][kh][kw][cout] fp16 */
+int cvx_conv2d_dgrad_nhwc(const void* dy_f16, int32_t batch, int32_t ih, int32_t iw, int32_t cin, const void* wt_f16, int32_t cout,
+                          int32_t k, int32_t stride, int32_t pad, int32_t dil, void* dx_f16, void* hip_stream);
+/* weight gradient: dw [cout][kh][kw][cin] fp32 (overwritten) from x and dy; workspace >= cvx_conv2d_wgrad_workspace_bytes */
+int64_t cvx_conv2d_wgrad_workspace_bytes(int32_t batch, int32_t oh, int32_t ow, int32_t cin, int32_t cout, int32_t k);
+int cvx_conv2d_wgrad_nhwc(const void* x_f16, const void* dy_f16, int32_t batch, int32_t ih, int32_t iw, int32_t cin, int32_t cout,
+                          int32_t k, int32_t stride, int32_t pad, int32_t dil, float* dw, void* workspace, int64_t workspace_bytes,
+                          void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CVX_ENGINE_H */
