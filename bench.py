@@ -1,0 +1,150 @@
+"""Headline benchmark: images/sec of the 640x640 YOLOv8-n TRAIN STEP (forward + v8 loss + backward + Adam)
+on N MI355X of one node.  `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches it
+under torch.distributed.run (one rank per GPU, RCCL gradient all-reduce).  Rank 0 prints ONE JSON line.
+
+* workload = BASELINE.json configs[1]: YOLOv8-n, batch 32 per GPU, 640x640 synthetic images (U[0,1), seed 1),
+  3 synthetic boxes per image, random-init weights (seed 0); inputs are resident in HBM before the timed region;
+* `roofline`: the dominant kernel family is the implicit-GEMM convolution (forward + data-gradient launches of
+  conv_igemm_kernel); achieved = algorithmic conv FLOPs of those launches / their summed kernel time, measured
+  with HIP events on the engine's launch stream over the timed steps (cvx_engine_profile); peak = MI355X dense
+  fp16 MFMA 2516.6 TFLOP/s.  The other kernel classes are reported alongside under "kernel_classes";
+* `cpu_baseline`: the CPU oracle (torch-CPU fp32 restatement of the reference, kind "port") timed on this
+  host's cores on a bounded sample (batch 8 train steps), rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_FP16_PEAK_TFLOPS = 2516.6                  # MI355X dense fp16
+HBM_PEAK_GBS = 8000.0
+TRAIN_GFLOP_PER_IMG = 26.140262                 # 3*F - 2*MAC0, YOLOv8-n 640x640
+FWD_GFLOP_PER_IMG = 8.742912
+
+
+def cpu_baseline(seconds_budget: float = 25.0):
+    from oracle import synth
+    from oracle import yolov8_ref as O
+    bs = 8
+    x, batch = synth.images(bs, 640, 640, seed=1), synth.targets(bs, seed=2)
+    sd, state = O.init_state_dict("n", 80, seed=0), {}
+    O.train_step(sd, x, batch, state)                         # warm-up (allocator, threads)
+    n, t0 = 0, time.time()
+    while n < 2 or (time.time() - t0 < seconds_budget and n < 12):
+        O.train_step(sd, x, batch, state)
+        n += 1
+    dt = (time.time() - t0) / n
+    return {"value": round(bs / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} YOLOv8-n 640x640 train steps at batch {bs} (fwd+loss+bwd+Adam), torch-CPU fp32 oracle, {dt * 1e3:.0f} ms/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--model", default="n")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("--gpus N > 1 must be launched with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    import torch.distributed as dist
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from computervision.pytorch_amd.model import Yolo8
+    from computervision.pytorch_amd.train import FlatAdam, FusedTrainStep, V8DetectionLoss
+    from configs import Yolo8DetConfig
+    from oracle import synth                                 # seeded input generators only (no oracle compute here)
+
+    cfg = Yolo8DetConfig()
+    cfg.arch.model_type = args.model
+    torch.manual_seed(0)
+    model = Yolo8(args.model, 80, loss_scale=cfg.engine.loss_scale).to(dev).train()
+    crit = V8DetectionLoss(cfg, model)
+    step = FusedTrainStep(model, crit, FlatAdam(model, lr=cfg.train.initial_lr), n_buckets=cfg.engine.allreduce_buckets)
+    B = args.batch
+    x = synth.images(B, 640, 640, seed=1 + rank).to(dev)
+    batch = synth.targets(B, seed=2 + rank)
+    batch = {k: v.to(dev) for k, v in batch.items()}         # labels resident in HBM too
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        items = step(x, batch)
+    eng = model._last_engine
+    sync()
+    eng.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        items = step(x, batch)
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile_read()
+    eng.profile(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_items = [float(v) for v in items.cpu()]
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        value = B * world * args.steps / elapsed
+        conv = {k: prof[k] for k in ("conv_fwd", "conv_dgrad")}
+        conv_ms = sum(v["ms"] for v in conv.values())
+        conv_fl = sum(v["flops"] for v in conv.values())
+        conv_launches = sum(v["launches"] for v in conv.values())
+        achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        classes = {}
+        for k, v in prof.items():
+            if v["launches"] == 0:
+                continue
+            sec = v["ms"] * 1e-3
+            classes[k] = {"ms_per_step": round(v["ms"] / args.steps, 4), "launches_per_step": v["launches"] // args.steps,
+                          "tflops": round(v["flops"] / sec / 1e12, 2) if v["flops"] else None,
+                          "algorithmic_gbs": round(v["bytes"] / sec / 1e9, 1)}
+        out = {
+            "metric": "images/sec 640x640 YOLOv8-n train step", "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"YOLOv8-{args.model} train step (fwd + v8 loss + bwd + Adam), batch {B}/GPU, 640x640, nc=80, random init",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "loss_scale": cfg.engine.loss_scale},
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (forward + data-gradient launches)",
+                         "achieved": round(achieved, 3), "peak": MFMA_FP16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / MFMA_FP16_PEAK_TFLOPS, 5), "traffic": None,
+                         "avg_launch_us": round(conv_ms * 1e3 / max(conv_launches, 1), 3), "launches_per_step": conv_launches // args.steps,
+                         "algorithmic_flops_per_step": conv_fl / args.steps},
+            "whole_step": {"train_tflops": round(value / world * TRAIN_GFLOP_PER_IMG / 1e3, 3),
+                           "frac_of_mfma_peak": round(value / world * TRAIN_GFLOP_PER_IMG / 1e3 / MFMA_FP16_PEAK_TFLOPS, 5)},
+            "kernel_classes": classes,
+            "loss_items_last_step": loss_items,
+            "engine_workspace_gib": round(eng.workspace_bytes() / 2 ** 30, 3),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

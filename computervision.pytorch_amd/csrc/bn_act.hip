@@ -20,13 +20,16 @@ __device__ __forceinline__ long long view_off(const ViewDesc& v, long long m, in
 // partial-slab combine helpers: partials laid out [P][C][2] (fp32)
 // block = 256 threads = 16 channels x 16 partial lanes
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void combine_partials(const float* part, int P, int C, int c, int lane16, double& s0, double& s1) {
+__device__ __forceinline__ void combine_partials(float* part, int P, int C, int c, int lane16, double& s0, double& s1) {
+  // the replica slabs are accumulated with atomics by the producer kernel; consume and re-zero them
   double a = 0.0, b = 0.0;
   if (c < C) {
     for (int p = lane16; p < P; p += 16) {
-      const float* q = part + ((long long)p * C + c) * 2;
+      float* q = part + ((long long)p * C + c) * 2;
       a += (double)q[0];
       b += (double)q[1];
+      q[0] = 0.f;
+      q[1] = 0.f;
     }
   }
   // lanes of one channel are 16 consecutive threads: reduce with shuffles
@@ -38,7 +41,7 @@ __device__ __forceinline__ void combine_partials(const float* part, int P, int C
   s1 = b;
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* part, int P, int C, double count, float momentum, float eps,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(float* part, int P, int C, double count, float momentum, float eps,
                                                           float* mean, float* invstd, float* rmean, float* rvar) {
   const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
   const int l16 = threadIdx.x & 15;
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* part, int
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part, int P, int C, double count, float inv_scale,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* part, int P, int C, double count, float inv_scale,
                                                               float* c1, float* c2, float* dgamma, float* dbeta) {
   const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
   const int l16 = threadIdx.x & 15;
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part,
   }
 }
 
-__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* part, int P, int C, float inv_scale, float* dbias) {
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(float* part, int P, int C, float inv_scale, float* dbias) {
   const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
   const int l16 = threadIdx.x & 15;
   double s, unused;
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const half_t* y, lon
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += 256) part[(long long)blockIdx.x * C * 2 + i] = sacc[i];
+  for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&part[(long long)(blockIdx.x % CVX_STAT_REPLICAS) * C * 2 + i], sacc[i]);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const half_t* y, long long M, int C, int hw, BnCoef k, const float* c1, const float* c2,
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(long long M, int C, 
     for (int i = 0; i < 8; ++i) atomicAdd(&sacc[(cg * 8 + i) * 2], a1[i]);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += 256) part[(long long)blockIdx.x * C * 2 + i] = sacc[i];
+  for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&part[(long long)(blockIdx.x % CVX_STAT_REPLICAS) * C * 2 + i], sacc[i]);
 }
 
 }  // namespace
@@ -246,11 +249,11 @@ int cvx_stream_rows_per_block(long long M, int C) {
   // aim for ~64 KB of fp16 rows per block, but at least 2048 blocks' worth of parallelism is not needed
   const int CG = C / 8;
   const int RP = 256 / CG;
-  long long target = (64 * 1024) / (2LL * C);
+  long long target = (16 * 1024) / (2LL * C);
   if (target < RP) target = RP;
   long long rows = ((target + RP - 1) / RP) * RP;
   long long blocks = (M + rows - 1) / rows;
-  while (blocks > 4096) {
+  while (blocks > 16384) {
     rows *= 2;
     blocks = (M + rows - 1) / rows;
   }
@@ -266,7 +269,7 @@ static int check_c(int C) {
   return 0;
 }
 
-int cvx_bn_finalize(const float* part, int P, int C, long long count, float momentum, float eps, float* mean, float* invstd, float* rmean,
+int cvx_bn_finalize(float* part, int P, int C, long long count, float momentum, float eps, float* mean, float* invstd, float* rmean,
                     float* rvar, hipStream_t st) {
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cvx_cdiv(C, 16)), dim3(256), 0, st, part, P, C, (double)count, momentum, eps, mean, invstd, rmean,
                      rvar);
@@ -293,7 +296,7 @@ int cvx_bn_bwd_reduce(const half_t* y, long long M, int C, int hw, const BnCoef&
   CVX_HIP(hipGetLastError());
   return 0;
 }
-int cvx_bn_bwd_finalize(const float* part, int P, int C, long long count, float inv_scale, float* c1, float* c2, float* dgamma, float* dbeta,
+int cvx_bn_bwd_finalize(float* part, int P, int C, long long count, float inv_scale, float* c1, float* c2, float* dgamma, float* dbeta,
                         hipStream_t st) {
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cvx_cdiv(C, 16)), dim3(256), 0, st, part, P, C, (double)count, inv_scale, c1, c2, dgamma,
                      dbeta);
@@ -314,7 +317,7 @@ int cvx_colsum(long long M, int C, int hw, const ViewDesc& g, float* part, float
   int rows = cvx_stream_rows_per_block(M, C);
   int P = cvx_stream_blocks(M, C);
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3(P), dim3(256), 0, st, M, C, hw, g, part, rows);
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cvx_cdiv(C, 16)), dim3(256), 0, st, part, P, C, inv_scale, dbias);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cvx_cdiv(C, 16)), dim3(256), 0, st, part, CVX_STAT_REPLICAS, C, inv_scale, dbias);
   CVX_HIP(hipGetLastError());
   return 0;
 }

@@ -50,8 +50,10 @@ struct ConvParams {
   const float* scale;  // AFFINE_SILU
   const float* shift;  // AFFINE_SILU
   const float* bias;   // BIAS_F32
-  float* stats;        // RAW_STATS: [gridDim.x][Cout][2]
+  float* stats;        // RAW_STATS: [stats_replicas][Cout][2], accumulated with float atomics (must be zero on entry)
+  int stats_replicas;
 };
+#define CVX_STAT_REPLICAS 32
 
 // Launches the kernel; returns the number of M-blocks (= stats partial count) through *m_blocks.
 int cvx_conv_igemm_launch(const ConvParams& p, hipStream_t stream, int* m_blocks);

@@ -180,7 +180,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       int n = nblk * BROWS + ch;
       if (n < p.Cout) {
         float v = sStat[0][ch][which] + sStat[1][ch][which] + sStat[2][ch][which] + sStat[3][ch][which];
-        p.stats[((long long)blockIdx.x * p.Cout + n) * 2 + which] = v;
+        // a few replica slabs (blockIdx mod R) keep the float atomics spread over many addresses
+        atomicAdd(&p.stats[((long long)(blockIdx.x % p.stats_replicas) * p.Cout + n) * 2 + which], v);
       }
     }
     return;

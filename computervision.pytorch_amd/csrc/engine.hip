@@ -88,6 +88,15 @@ struct cvx_engine {
   bool fwd_train_done = false;
   int last_batch = 0;
   float* last_pred = nullptr;
+  // per-kernel-class profiling with HIP events on the launch stream (bench.py's roofline object)
+  bool profile = false;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  struct ProfRec {
+    int cls;
+    double flops, bytes;
+  };
+  std::vector<ProfRec> prof_recs;
 };
 
 namespace {
@@ -114,6 +123,35 @@ void free_pool(std::vector<void*>& pool) {
 }
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+enum { PROF_CONV_FWD = 0, PROF_CONV_DGRAD = 1, PROF_CONV_WGRAD = 2, PROF_BN_FWD = 3, PROF_BN_BWD = 4, PROF_MISC = 5, PROF_SLAB_REDUCE = 6 };
+
+struct ProfScope {  // records a start/stop event pair around the launches issued while it lives
+  cvx_engine* e;
+  ProfScope(cvx_engine* eng, int cls, double flops, double bytes) : e(eng->profile ? eng : nullptr) {
+    if (!e) return;
+    while (e->ev_pool.size() < e->ev_used + 2) {
+      hipEvent_t ev;
+      if (hipEventCreate(&ev) != hipSuccess) {
+        e = nullptr;
+        return;
+      }
+      e->ev_pool.push_back(ev);
+    }
+    e->prof_recs.push_back({cls, flops, bytes});
+    (void)hipEventRecord(e->ev_pool[e->ev_used], e->stream);
+  }
+  ~ProfScope() {
+    if (!e) return;
+    (void)hipEventRecord(e->ev_pool[e->ev_used + 1], e->stream);
+    e->ev_used += 2;
+  }
+};
+
+double conv_flops(const cvx_op_desc& o, int B) { return 2.0 * B * o.oh * o.ow * o.out.c * (double)(o.k * o.k * o.w_cin); }
+double conv_bytes(const cvx_op_desc& o, int B) {
+  return 2.0 * B * ((double)o.ih * o.iw * o.w_cin + (double)o.oh * o.ow * o.out.c) + 2.0 * o.out.c * o.k * o.k * o.w_cin;
+}
 
 ViewDesc make_view(const cvx_engine* e, const cvx_view& v, bool grad) {
   ViewDesc r{nullptr, 0, 0};
@@ -307,8 +345,7 @@ int plan_batch(cvx_engine* e, int B, bool training) {
       CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, M * C * 2));
       c.ybuf = (half_t*)p;
     }
-    max_part = std::max(max_part, (long long)cvx_conv_igemm_mblocks(M) * C * 2);
-    max_part = std::max(max_part, (long long)cvx_stream_blocks(M, C) * C * 2);
+    max_part = std::max(max_part, (long long)CVX_STAT_REPLICAS * C * 2);
     if (training) {
       max_dy = std::max(max_dy, M * C);
       int co_b, j_b;
@@ -317,7 +354,8 @@ int plan_batch(cvx_engine* e, int B, bool training) {
       const long long tiles = (long long)cvx_cdiv(C, co_b) * cvx_cdiv(Jtot, j_b);
       long long ns = std::min<long long>(std::max<long long>(1, M / 256), std::max<long long>(1, 2048 / tiles));
       const long long slab_elems = (long long)C * Jtot;
-      ns = std::min(ns, std::max<long long>(1, (16LL << 20) / (slab_elems * 4)));
+      ns = std::min(ns, std::max<long long>(1, (8LL << 20) / (slab_elems * 4)));
+      ns = std::min<long long>(ns, 512);
       c.nsplit = (int)ns;
       c.slab_off = slab_total;
       slab_total += ns * slab_elems;
@@ -328,13 +366,15 @@ int plan_batch(cvx_engine* e, int B, bool training) {
       sd.rows = C * c.ntaps;
       sd.Cin = o.w_cin;
       sd.Cin_pad = c.cin_pad16;
+      sd.lanes = cvx_slab_lanes(sd.nsplit);
       const long long total = (long long)sd.rows * sd.Cin;
-      for (long long s0 = 0; s0 < total; s0 += 1024) sblocks.push_back(BlockRef{(int)sdescs.size(), (int)s0});
+      for (long long s0 = 0; s0 < total; s0 += 256 / sd.lanes) sblocks.push_back(BlockRef{(int)sdescs.size(), (int)s0});
       sdescs.push_back(sd);
     }
   }
   CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, max_part * 4));
   e->partials = (float*)p;
+  CVX_HIP(hipMemset(p, 0, (size_t)(max_part * 4)));  // replica slabs: producers add atomically, finalizers re-zero
   if (training) {
     CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, max_dy * 2));
     e->dy_scratch = (half_t*)p;
@@ -462,20 +502,25 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
   hipStream_t st = e->stream;
   const int B = batch;
   // fp32 master -> fp16 shadows (forward layout + transposed layout for the data gradient)
-  CVX_TRY(cvx_pack_weights(e->params, e->shadow, e->d_pack, e->d_pack_blocks, e->n_pack_blocks, st));
   const Buf& ib = e->bufs[e->image_buf];
-  CVX_TRY(cvx_image_to_nhwc8(images, B, ib.d.h, ib.d.w, ib.act, st));
+  {
+    ProfScope ps(e, PROF_MISC, 0, 6.0 * e->n_params + (double)B * ib.d.h * ib.d.w * (12 + 16));
+    CVX_TRY(cvx_pack_weights(e->params, e->shadow, e->d_pack, e->d_pack_blocks, e->n_pack_blocks, st));
+    CVX_TRY(cvx_image_to_nhwc8(images, B, ib.d.h, ib.d.w, ib.act, st));
+  }
   const Buf& pb = e->bufs[e->pred_buf];
   const long long A = (long long)pb.d.h * pb.d.w;
 
   for (size_t i = 0; i < e->ops.size(); ++i) {
     const cvx_op_desc& o = e->ops[i];
     if (o.type == CVX_OP_MAXPOOL5) {
+      ProfScope ps(e, PROF_MISC, 0, 4.0 * B * o.ih * o.iw * o.in.c);
       CVX_TRY(cvx_maxpool5_fwd(make_view(e, o.in, false), make_view(e, o.out, false), B, o.ih, o.iw, o.in.c,
                                training ? e->pool[i].idx : nullptr, st));
       continue;
     }
     if (o.type == CVX_OP_UPSAMPLE2) {
+      ProfScope ps(e, PROF_MISC, 0, 10.0 * B * o.ih * o.iw * o.in.c);
       CVX_TRY(cvx_upsample2_fwd(make_view(e, o.in, false), make_view(e, o.out, false), B, o.ih, o.iw, o.in.c, st));
       continue;
     }
@@ -490,6 +535,7 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
       cp.out32 = pred + (long long)o.out.pix_off * pb.d.c + o.out.coff;
       cp.out_ld = pb.d.c;
       cp.out_bstride = A * pb.d.c;
+      ProfScope ps(e, PROF_CONV_FWD, conv_flops(o, B), conv_bytes(o, B) + 2.0 * M * C);
       CVX_TRY(cvx_conv_igemm_launch(cp, st, nullptr));
       continue;
     }
@@ -501,9 +547,14 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
       cp.out_ld = C;
       cp.out_bstride = (long long)o.oh * o.ow * C;
       cp.stats = e->partials;
+      cp.stats_replicas = CVX_STAT_REPLICAS;
       int P = 0;
-      CVX_TRY(cvx_conv_igemm_launch(cp, st, &P));
-      CVX_TRY(cvx_bn_finalize(e->partials, P, C, M, e->bn_momentum, e->bn_eps, c.mean, c.invstd, e->stats + o.rmean_off,
+      {
+        ProfScope ps(e, PROF_CONV_FWD, conv_flops(o, B), conv_bytes(o, B));
+        CVX_TRY(cvx_conv_igemm_launch(cp, st, &P));
+      }
+      ProfScope ps(e, PROF_BN_FWD, 0, (resv.p ? 6.0 : 4.0) * M * C);
+      CVX_TRY(cvx_bn_finalize(e->partials, CVX_STAT_REPLICAS, C, M, e->bn_momentum, e->bn_eps, c.mean, c.invstd, e->stats + o.rmean_off,
                               e->stats + o.rvar_off, st));
       BnCoef k{c.mean, c.invstd, e->params + o.gamma_off, e->params + o.beta_off};
       CVX_TRY(cvx_bn_silu_apply(c.ybuf, M, C, o.oh * o.ow, k, outv, resv, st));
@@ -519,6 +570,7 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
       cp.res = resv.p;
       cp.res_ld = resv.ld;
       cp.res_bstride = resv.bstride;
+      ProfScope ps(e, PROF_CONV_FWD, conv_flops(o, B), conv_bytes(o, B));
       CVX_TRY(cvx_conv_igemm_launch(cp, st, nullptr));
     }
   }
@@ -543,11 +595,13 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
   for (int i = (int)e->ops.size() - 1; i >= 0; --i) {
     const cvx_op_desc& o = e->ops[i];
     if (o.type == CVX_OP_MAXPOOL5) {
+      ProfScope ps(e, PROF_MISC, 0, 7.0 * B * o.ih * o.iw * o.in.c);
       CVX_TRY(cvx_maxpool5_bwd(make_view(e, o.out, true), make_view(e, o.in, true), B, o.ih, o.iw, o.in.c, e->pool[i].idx,
                                e->pool[i].in_accum, st));
       continue;
     }
     if (o.type == CVX_OP_UPSAMPLE2) {
+      ProfScope ps(e, PROF_MISC, 0, 12.0 * B * o.ih * o.iw * o.in.c);
       CVX_TRY(cvx_upsample2_bwd(make_view(e, o.out, true), make_view(e, o.in, true), B, o.ih, o.iw, o.in.c, e->pool[i].in_accum, st));
       continue;
     }
@@ -560,13 +614,15 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
       dyv.p = dpred + (long long)o.out.pix_off * pb.d.c + o.out.coff;
       dyv.ld = pb.d.c;
       dyv.bstride = A * pb.d.c;
+      ProfScope ps(e, PROF_MISC, 0, 2.0 * M * C);
       CVX_TRY(cvx_colsum(M, C, hw, dyv, e->partials, inv_scale, e->grads + o.bias_off, st));
     } else {
       ViewDesc gout = make_view(e, o.out, true);
       ViewDesc gres = make_view(e, o.res, true);
       BnCoef k{c.mean, c.invstd, e->params + o.gamma_off, e->params + o.beta_off};
+      ProfScope ps(e, PROF_BN_BWD, 0, (gres.p ? 14.0 : 10.0) * M * C);
       CVX_TRY(cvx_bn_bwd_reduce(c.ybuf, M, C, hw, k, gout, e->partials, st));
-      CVX_TRY(cvx_bn_bwd_finalize(e->partials, cvx_stream_blocks(M, C), C, M, inv_scale, c.c1, c.c2, e->grads + o.gamma_off,
+      CVX_TRY(cvx_bn_bwd_finalize(e->partials, CVX_STAT_REPLICAS, C, M, inv_scale, c.c1, c.c2, e->grads + o.gamma_off,
                                   e->grads + o.beta_off, st));
       CVX_TRY(cvx_bn_bwd_apply(c.ybuf, M, C, hw, k, c.c1, c.c2, gout, e->dy_scratch, gres, c.res_accum, st));
       dyv.p = e->dy_scratch;
@@ -606,6 +662,8 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
         cp.out16 = gin.p;
         cp.out_ld = gin.ld;
         cp.out_bstride = gin.bstride;
+        ProfScope ps(e, PROF_CONV_DGRAD, 2.0 * B * dc.OH2 * dc.OW2 * (double)o.in.c * dc.ntaps * C,
+                     (conv_bytes(o, B) + (c.in_accum ? 2.0 * B * o.ih * o.iw * o.in.c : 0.0)) / c.ndg);
         CVX_TRY(cvx_conv_igemm_launch(cp, st, nullptr));
       }
     }
@@ -633,10 +691,47 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
       wp.slabs = e->slabs + c.slab_off;
       wp.nsplit = c.nsplit;
       wp.cin_pad16 = c.cin_pad16;
+      ProfScope ps(e, PROF_CONV_WGRAD, conv_flops(o, B), conv_bytes(o, B) + 4.0 * c.nsplit * C * c.ntaps * c.cin_pad16);
       CVX_TRY(cvx_conv_wgrad_launch(wp, st));
     }
   }
-  CVX_TRY(cvx_reduce_slabs(e->slabs, e->grads, inv_scale, e->d_slab, e->d_slab_blocks, e->n_slab_blocks, st));
+  {
+    double slab_bytes = 0;
+    for (size_t i = 0; i < e->ops.size(); ++i)
+      if (e->ops[i].type == CVX_OP_CONV) slab_bytes += 4.0 * e->conv[i].nsplit * e->ops[i].out.c * e->conv[i].ntaps * e->conv[i].cin_pad16;
+    ProfScope ps(e, PROF_SLAB_REDUCE, 0, slab_bytes + 8.0 * e->n_params);
+    CVX_TRY(cvx_reduce_slabs(e->slabs, e->grads, inv_scale, e->d_slab, e->d_slab_blocks, e->n_slab_blocks, st));
+  }
+  return 0;
+}
+
+extern "C" int cvx_engine_profile(cvx_engine* e, int32_t enable) {
+  CVX_CHECK(e, "null engine");
+  CVX_HIP(hipStreamSynchronize(e->stream));
+  e->profile = enable != 0;
+  e->ev_used = 0;
+  e->prof_recs.clear();
+  return 0;
+}
+
+extern "C" int cvx_engine_profile_read(cvx_engine* e, int32_t n_classes, double* ms, double* flops, double* bytes, int64_t* launches) {
+  CVX_CHECK(e && ms && flops && bytes && launches && n_classes >= 7, "bad arguments (7 classes)");
+  CVX_HIP(hipStreamSynchronize(e->stream));
+  for (int i = 0; i < n_classes; ++i) {
+    ms[i] = flops[i] = bytes[i] = 0;
+    launches[i] = 0;
+  }
+  for (size_t r = 0; r < e->prof_recs.size() && 2 * r + 1 < e->ev_used + 1; ++r) {
+    float t = 0.f;
+    CVX_HIP(hipEventElapsedTime(&t, e->ev_pool[2 * r], e->ev_pool[2 * r + 1]));
+    const auto& rec = e->prof_recs[r];
+    ms[rec.cls] += t;
+    flops[rec.cls] += rec.flops;
+    bytes[rec.cls] += rec.bytes;
+    launches[rec.cls] += 1;
+  }
+  e->ev_used = 0;
+  e->prof_recs.clear();
   return 0;
 }
 
@@ -820,10 +915,10 @@ extern "C" int cvx_conv2d_wgrad_nhwc(const void* x_f16, const void* dy_f16, int3
   if (rc == 0) {
     // reduce the slabs into dw (overwrite): zero, then the table-driven reducer with one descriptor
     rc = hipMemsetAsync(dw, 0, (size_t)cout * k * k * cin * 4, st) == hipSuccess ? 0 : -1;
-    SlabDesc sd{0, 0, wp.nsplit, cout * k * k, cin, wp.cin_pad16};
+    SlabDesc sd{0, 0, wp.nsplit, cout * k * k, cin, wp.cin_pad16, cvx_slab_lanes(wp.nsplit)};
     std::vector<BlockRef> blocks;
     const long long total = (long long)sd.rows * sd.Cin;
-    for (long long s0 = 0; s0 < total; s0 += 1024) blocks.push_back(BlockRef{0, (int)s0});
+    for (long long s0 = 0; s0 < total; s0 += 256 / sd.lanes) blocks.push_back(BlockRef{0, (int)s0});
     SlabDesc* dsd = nullptr;
     BlockRef* dbl = nullptr;
     if (hipMalloc((void**)&dsd, sizeof(sd)) != hipSuccess || hipMalloc((void**)&dbl, blocks.size() * sizeof(BlockRef)) != hipSuccess) rc = -1;

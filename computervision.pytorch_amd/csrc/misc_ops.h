@@ -34,7 +34,13 @@ struct SlabDesc {        // one weight-gradient tensor
   long long slab_off;    // fp32 [nsplit][Cout*T][Cin_pad]
   long long dst_off;     // fp32 grad arena [Cout*T][Cin]
   int nsplit, rows, Cin, Cin_pad;
+  int lanes;             // split-lanes per block (power of two, 1..64); a block covers 256/lanes elements
 };
+static inline int cvx_slab_lanes(int nsplit) {
+  int l = 1;
+  while (l < 64 && l * 8 < nsplit) l <<= 1;
+  return l;
+}
 int cvx_reduce_slabs(const float* slabs, float* grads, float inv_scale, const SlabDesc* descs, const BlockRef* blocks, int nblocks,
                      hipStream_t st);
 

@@ -197,20 +197,30 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* master, 
 
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* slabs, float* grads, float inv_scale, const SlabDesc* descs,
                                                            const BlockRef* blocks) {
+  // block = (256 / lanes) consecutive gradient elements x `lanes` split-lanes; each lane sums a strided
+  // subset of the splits, then a fixed-order LDS tree adds the lanes (deterministic).
+  __shared__ float sred[256];
   const BlockRef br = blocks[blockIdx.x];
   const SlabDesc d = descs[br.desc];
   const long long total = (long long)d.rows * d.Cin;
   const long long slab_elems = (long long)d.rows * d.Cin_pad;
-  for (int k = 0; k < 4; ++k) {
-    long long e = (long long)br.start + k * 256 + threadIdx.x;
-    if (e >= total) return;
+  const int LR = d.lanes, COLS = 256 / LR;
+  const int col = threadIdx.x % COLS, rl = threadIdx.x / COLS;
+  const long long e = (long long)br.start + col;
+  float acc = 0.f;
+  if (e < total) {
     int ci = (int)(e % d.Cin);
     long long row = e / d.Cin;
     const float* s = slabs + d.slab_off + row * d.Cin_pad + ci;
-    float acc = 0.f;
-    for (int sp = 0; sp < d.nsplit; ++sp) acc += s[(long long)sp * slab_elems];
-    grads[d.dst_off + e] += acc * inv_scale;
+    for (int sp = rl; sp < d.nsplit; sp += LR) acc += s[(long long)sp * slab_elems];
   }
+  sred[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off >= COLS; off >>= 1) {
+    if ((int)threadIdx.x < off) sred[threadIdx.x] += sred[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (rl == 0 && e < total) grads[d.dst_off + e] += sred[col] * inv_scale;
 }
 
 // ---- Adam ---------------------------------------------------------------------------------------

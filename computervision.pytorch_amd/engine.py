@@ -69,6 +69,18 @@ class Engine:
         L.check(self.lib.cvx_engine_debug_copy(self.handle, buf, 1 if grad else 0, L.ptr(out), out.numel() * 2), "cvx_engine_debug_copy")
         return out
 
+    PROFILE_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn_silu_fwd", "bn_silu_bwd", "misc", "slab_reduce")
+
+    def profile(self, enable: bool):
+        L.check(self.lib.cvx_engine_profile(self.handle, 1 if enable else 0), "cvx_engine_profile")
+
+    def profile_read(self):
+        """{class: dict(ms, flops, bytes, launches)} accumulated since the profiling window started."""
+        n = len(self.PROFILE_CLASSES)
+        ms, fl, by, la = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)(), (C.c_int64 * n)()
+        L.check(self.lib.cvx_engine_profile_read(self.handle, n, ms, fl, by, la), "cvx_engine_profile_read")
+        return {name: dict(ms=ms[i], flops=fl[i], bytes=by[i], launches=int(la[i])) for i, name in enumerate(self.PROFILE_CLASSES)}
+
     def workspace_bytes(self) -> int:
         return int(self.lib.cvx_engine_workspace_bytes(self.handle))
 

@@ -152,22 +152,35 @@ class FusedTrainStep:
         return items
 
     def _allreduce(self, g: torch.Tensor):
-        import torch.distributed as dist
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=g.device) if g.is_cuda else None
-        n = g.numel()
-        per = (n + self.n_buckets - 1) // self.n_buckets
-        per = (per + 3) & ~3
-        if self._side is None:                                    # CPU tensors (gloo tests of the bucketing logic)
-            for s in range(0, n, per):
-                dist.all_reduce(g[s:s + per], group=self.pg)
-            g.div_(self.world)
-            return
-        cur = torch.cuda.current_stream(g.device)
-        self._side.wait_stream(cur)
-        with torch.cuda.stream(self._side):
-            for s in range(0, n, per):
-                chunk = g[s:s + per]
-                dist.all_reduce(chunk, group=self.pg)
-                chunk.div_(self.world)
-        cur.wait_stream(self._side)
+        if self._side is None and g.is_cuda:
+            self._side = torch.cuda.Stream(device=g.device)
+        allreduce_mean_flat(g, self.world, self.pg, self.n_buckets, self._side)
+
+
+def bucket_bounds(n: int, n_buckets: int):
+    """Contiguous [start, end) slices of a flat arena, 16-byte aligned starts."""
+    per = (n + n_buckets - 1) // max(n_buckets, 1)
+    per = max((per + 3) & ~3, 4)
+    return [(s, min(n, s + per)) for s in range(0, n, per)]
+
+
+def allreduce_mean_flat(g: torch.Tensor, world: int, group=None, n_buckets: int = 4, side_stream=None):
+    """Average the flat gradient arena over the ranks: a few large contiguous all-reduces (xGMI is
+    point-to-point, so few big messages beat many small ones), issued on a side HIP stream."""
+    import torch.distributed as dist
+    if world <= 1:
+        return
+    bounds = bucket_bounds(g.numel(), n_buckets)
+    if not g.is_cuda or side_stream is None:                      # CPU tensors: gloo tests of the bucketing logic
+        for s, e in bounds:
+            dist.all_reduce(g[s:e], group=group)
+            g[s:e].div_(world)
+        return
+    cur = torch.cuda.current_stream(g.device)
+    side_stream.wait_stream(cur)
+    with torch.cuda.stream(side_stream):
+        for s, e in bounds:
+            chunk = g[s:e]
+            dist.all_reduce(chunk, group=group)
+            chunk.div_(world)
+    cur.wait_stream(side_stream)

@@ -86,6 +86,15 @@ int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float loss_scale);
  * batch, NHWC fp16, into dst (device or host memory, `bytes` must equal batch*h*w*c*2). */
 int cvx_engine_debug_copy(cvx_engine* e, int32_t buf, int32_t which, void* dst, int64_t bytes);
 
+/* Per-kernel-class timing with HIP events recorded on the engine's launch stream.  Classes: 0 conv forward
+ * (implicit GEMM), 1 conv data-gradient, 2 conv weight-gradient, 3 BN+SiLU forward passes, 4 BN+SiLU backward
+ * passes, 5 misc (layout, pool, upsample, weight shadows, bias sums), 6 gradient-slab reduction.
+ * cvx_engine_profile(e, 1) starts a window; cvx_engine_profile_read synchronises, returns the summed kernel
+ * time (ms), algorithmic FLOPs, algorithmic bytes and launch count per class since the window start, and
+ * restarts the window. */
+int cvx_engine_profile(cvx_engine* e, int32_t enable);
+int cvx_engine_profile_read(cvx_engine* e, int32_t n_classes, double* ms, double* flops, double* bytes, int64_t* launches);
+
 /* Bytes of device memory the engine currently owns (workspaces). */
 int64_t cvx_engine_workspace_bytes(const cvx_engine* e);
 

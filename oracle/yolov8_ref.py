@@ -186,14 +186,36 @@ def trainable_keys(sd: Dict[str, torch.Tensor]) -> List[str]:
 # ----------------------------------------------------------------------------------------------
 # forward graph
 # ----------------------------------------------------------------------------------------------
+# fp16-STORAGE emulation.  The reference's GPU path runs under torch.cuda.amp.autocast()
+# (core/trainer/yolo8_train.py:98-104): conv operands and activations are fp16, accumulation fp32.
+# With FP16_STORAGE[0] = True the oracle rounds exactly those tensors (weights, conv outputs, activations)
+# to fp16 and back, everything else stays fp32 -- this is what an fp16-storage engine must reproduce,
+# while the plain fp32 run is the reference's CPU path.  Casts are differentiable (straight-through).
+FP16_STORAGE = [False]
+
+
+def _q(t: torch.Tensor) -> torch.Tensor:
+    return t.half().float() if FP16_STORAGE[0] else t
+
+
 def _unit(x, sd, p, k, s, training):
     """Conv2d(no bias, 'same' pad) -> BatchNorm -> SiLU   (modules.py:29-30)."""
-    y = F.conv2d(x, sd[p + ".conv.weight"], None, s, k // 2)
-    y = F.batch_norm(y, sd[p + ".bn.running_mean"], sd[p + ".bn.running_var"], sd[p + ".bn.weight"],
-                     sd[p + ".bn.bias"], training, BN_MOMENTUM, BN_EPS)
+    y = F.conv2d(x, _q(sd[p + ".conv.weight"]), None, s, k // 2)
+    if FP16_STORAGE[0] and training:
+        # batch statistics come from the fp32 accumulators, normalisation reads the fp16-rounded tensor
+        mean, var = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=False)
+        n = y.numel() / y.shape[1]
+        with torch.no_grad():
+            sd[p + ".bn.running_mean"].mul_(1 - BN_MOMENTUM).add_(mean.detach(), alpha=BN_MOMENTUM)
+            sd[p + ".bn.running_var"].mul_(1 - BN_MOMENTUM).add_(var.detach() * (n / max(n - 1, 1)), alpha=BN_MOMENTUM)
+        y = (_q(y) - mean[None, :, None, None]) * torch.rsqrt(var + BN_EPS)[None, :, None, None]
+        y = y * sd[p + ".bn.weight"][None, :, None, None] + sd[p + ".bn.bias"][None, :, None, None]
+    else:
+        y = F.batch_norm(y, sd[p + ".bn.running_mean"], sd[p + ".bn.running_var"], sd[p + ".bn.weight"],
+                         sd[p + ".bn.bias"], training, BN_MOMENTUM, BN_EPS)
     if training:
         sd[p + ".bn.num_batches_tracked"] += 1
-    return F.silu(y)
+    return _q(F.silu(y))
 
 
 def _c2f(x, sd, p, n, shortcut, training):
@@ -202,7 +224,7 @@ def _c2f(x, sd, p, n, shortcut, training):
     for j in range(n):
         h = _unit(parts[-1], sd, f"{p}.m.{j}.cv1", 3, 1, training)
         h = _unit(h, sd, f"{p}.m.{j}.cv2", 3, 1, training)
-        parts.append(parts[-1] + h if shortcut else h)      # modules.py:134-135
+        parts.append(_q(parts[-1] + h) if shortcut else h)  # modules.py:134-135
     return _unit(torch.cat(parts, 1), sd, p + ".cv2", 1, 1, training)
 
 
@@ -250,6 +272,7 @@ def forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, model_type: str = "n",
     """
     a = arch(model_type, nc)
     saved = {}
+    x = _q(x)
     for idx, kind, kw in a["layers"]:
         p = f"model.{idx}"
         if kind == "conv":
@@ -271,7 +294,7 @@ def forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, model_type: str = "n",
                     q = f"{p}.{br}.{lvl}"
                     h = _unit(f, sd, q + ".0", 3, 1, training)
                     h = _unit(h, sd, q + ".1", 3, 1, training)
-                    branch_out.append(F.conv2d(h, sd[q + ".2.weight"], sd[q + ".2.bias"]))
+                    branch_out.append(F.conv2d(h, _q(sd[q + ".2.weight"]), sd[q + ".2.bias"]))
                 outs.append(torch.cat(branch_out, 1))
             x = outs
         saved[idx] = x

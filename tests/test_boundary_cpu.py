@@ -1,0 +1,153 @@
+"""CPU: the drop-in boundary (registry / builder / configs / model object contract) and the C-ABI library
+loading -- no compute calls (there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import builder
+import check
+import registry
+from computervision.pytorch_amd import CvxError, LIB_PATH
+from computervision.pytorch_amd import _lib as L
+from oracle import yolov8_ref as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- registry.py / builder.py / check.py (reference registry.py:1-61, builder.py:8-31, check.py:1-14) ----
+def test_register_decorator_forms_and_key_prefix(capsys):
+    reg = registry.Register("thing")
+    assert reg.name == "thing"
+
+    @reg("a")
+    def fa():
+        return 1
+
+    @reg
+    def fb():
+        return 2
+
+    assert set(reg.keys()) == {"thing_a", "thing_fb"}
+    assert reg["thing_a"] is fa and "thing_fb" in reg and fb in reg.values()
+    assert dict(reg.items())["thing_fb"]() == 2
+    reg("a")(fb)                                   # duplicate: warns and overwrites
+    assert "thing_a" in capsys.readouterr().out and reg["thing_a"] is fb
+    with pytest.raises(Exception):
+        reg["x"] = 3                               # non-callable
+    assert str(reg).startswith("{")
+
+
+def test_export_from_registry_contract():
+    cfg, algo, trainer = builder.export_from_registry("YOLO8_DET")          # lower-cased
+    assert type(cfg).__name__ == "Yolo8DetConfig" and isinstance(algo, type) and isinstance(trainer, type)
+    assert algo.__name__ == "YOLOv8" and trainer.__name__ == "Yolo8Trainer"
+    with pytest.raises(ValueError):
+        builder.export_from_registry("resnet")                               # not in check.MODELS
+    with pytest.raises(KeyError):
+        builder.export_from_registry("ssd")                                  # whitelisted, path not built yet
+    assert check.MODELS == ["yolo7", "yolo8_det", "ssd", "centernet", "deeplabv3plus"]
+
+
+def test_config_fields_match_reference_defaults():
+    cfg, _, _ = builder.export_from_registry("yolo8_det")
+    assert (cfg.arch.model_type, cfg.arch.input_size) == ("n", (3, 640, 640))
+    assert (cfg.dataset.num_classes, cfg.dataset.dataset_name) == (80, "coco")
+    t = cfg.train
+    assert (t.batch_size, t.initial_lr, t.epoch, t.warmup_iters, t.milestones, t.gamma) == (8, 1e-3, 100, 0, [], 0.1)
+    assert t.mixed_precision is True and t.num_workers == 0 and t.resume_training == "" and t.last_epoch == -1
+    assert (cfg.loss.box, cfg.loss.cls, cfg.loss.dfl) == (7.5, 0.5, 1.5)
+    assert cfg.optimizer.name == "Adam" and cfg.log.print_interval == 50
+    d = cfg.decode
+    assert (d.conf_threshold, d.nms_threshold, d.max_det, d.letterbox_image) == (0.25, 0.7, 300, True)
+
+
+# ---- model object contract -------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def model():
+    cfg, algo, _ = builder.export_from_registry("yolo8_det")
+    torch.manual_seed(0)
+    m, name = algo(cfg, torch.device("cpu")).build_model()
+    assert name == "YOLOv8n"
+    return m
+
+
+def test_state_dict_is_the_references(model):
+    sd = model.state_dict()
+    ref = O.init_state_dict("n", 80, seed=0)       # pinned bit-exact against the reference in make_golden.py
+    assert list(sd.keys()) == list(ref.keys()) and len(sd) == 355
+    for k in ref:
+        assert sd[k].shape == ref[k].shape and sd[k].dtype == ref[k].dtype, k
+        assert torch.equal(sd[k], ref[k]), k
+    det = model.model[-1]
+    assert (det.nc, det.no, det.reg_max) == (80, 144, 16) and det.stride.tolist() == [8.0, 16.0, 32.0]
+    assert sum(p.numel() for p in model.parameters()) == 3157200
+    assert sum(p.numel() for p in model.parameters() if p.requires_grad) == 3157184
+
+
+def test_parameters_are_views_of_the_flat_arenas(model):
+    flat = model.flat_params
+    w = dict(model.named_parameters())["model.22.cv3.1.0.conv.weight"]
+    assert w.shape == (80, 128, 3, 3) and w.stride() == (9 * 128, 1, 3 * 128, 128)    # [cout][kh][kw][cin] storage
+    before = float(flat.sum())
+    with torch.no_grad():
+        w.add_(1.0)
+    assert abs(float(flat.sum()) - before - w.numel()) < 1.0
+    with torch.no_grad():
+        w.sub_(1.0)
+    # fused head conv: box and class branch weights are adjacent in the arena
+    lay = model.layout
+    a, b = lay.slots["model.22.cv2.1.0.conv.weight"], lay.slots["model.22.cv3.1.0.conv.weight"]
+    assert b.offset == a.offset + 64 * 9 * 128
+
+
+def test_load_state_dict_roundtrip(model):
+    ref = O.init_state_dict("n", 80, seed=123)
+    missing = model.load_state_dict(ref, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, ref[k]), k
+    model.load_state_dict(O.init_state_dict("n", 80, seed=0))
+
+
+def test_no_cpu_fallback(model):
+    with pytest.raises(CvxError):
+        model(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(CvxError):
+        model.model[0](torch.zeros(1, 3, 64, 64))
+
+
+def test_other_scales_have_reference_parameter_counts():
+    from computervision.pytorch_amd.graph import ParamLayout, build_yolov8_graph
+    # yolo_v8.py:116: YOLOv8s 11166560 parameters (incl. the 16 frozen DFL weights)
+    lay = ParamLayout("s", 80)
+    n = sum(int(torch.tensor(s.shape).prod()) for s in lay.slots.values() if s.trainable)
+    assert n + 16 == 11166560
+    g = build_yolov8_graph(lay, 640, 640)
+    assert g.anchors == 8400 and g.level_hw == [(80, 80), (40, 40), (20, 20)]
+    with pytest.raises(ValueError):
+        build_yolov8_graph(lay, 100, 100)
+    with pytest.raises(ValueError):
+        ParamLayout("q", 80)
+
+
+# ---- the C-ABI shared library ------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(LIB_PATH), "build the HIP library first (python __graft_entry__.py)"
+    header = open(os.path.join(ROOT, "include", "cvx_engine.h")).read()
+    declared = set(re.findall(r"\b(cvx_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/cvx_engine.h but not exported"
+    assert declared == set(L.PROTOTYPES), declared ^ set(L.PROTOTYPES)
+    assert L.load().cvx_abi_version() == L.ABI_VERSION
+
+
+def test_engine_refuses_cpu_device():
+    from computervision.pytorch_amd.engine import Engine
+    from computervision.pytorch_amd.graph import ParamLayout, build_yolov8_graph
+    with pytest.raises(CvxError):
+        Engine(build_yolov8_graph(ParamLayout("n", 80), 64, 64), torch.device("cpu"))
