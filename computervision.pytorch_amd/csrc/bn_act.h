@@ -17,17 +17,27 @@ struct BnCoef {
   const float* beta;
 };
 
-int cvx_stream_rows_per_block(long long M, int C);
-int cvx_stream_blocks(long long M, int C);  // = number of partial slabs the reduce kernels write
+// training-mode forward: fixed-point statistics replicas [R][C][2] filled by the conv epilogue (zero before it)
+struct BnTrainArgs {
+  const long long* stats;
+  const float* gamma;
+  const float* beta;
+  float* mean;    // out: batch mean   (kept for backward)
+  float* invstd;  // out: 1/sqrt(var+eps)
+  float* rmean;   // running statistics, updated with `momentum` (unbiased variance)
+  float* rvar;
+  float eps, momentum;
+};
 
-int cvx_bn_finalize(float* part, int P, int C, long long count, float momentum, float eps, float* mean, float* invstd, float* rmean,
-                    float* rvar, hipStream_t st);
+int cvx_stream_rows_per_block(long long M, int C, int kb_per_block);
+
 int cvx_bn_fold(int n, const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps, float* scale, float* shift,
                 hipStream_t st);
-int cvx_bn_silu_apply(const half_t* y, long long M, int C, int hw, const BnCoef& k, const ViewDesc& out, const ViewDesc& res, hipStream_t st);
-int cvx_bn_bwd_reduce(const half_t* y, long long M, int C, int hw, const BnCoef& k, const ViewDesc& gout, float* part, hipStream_t st);
-int cvx_bn_bwd_finalize(float* part, int P, int C, long long count, float inv_scale, float* c1, float* c2, float* dgamma, float* dbeta,
-                        hipStream_t st);
-int cvx_bn_bwd_apply(const half_t* y, long long M, int C, int hw, const BnCoef& k, const float* c1, const float* c2, const ViewDesc& gout,
-                     half_t* dy, const ViewDesc& gres, int res_accumulate, hipStream_t st);
-int cvx_colsum(long long M, int C, int hw, const ViewDesc& g, float* part, float inv_scale, float* dbias, hipStream_t st);
+int cvx_bn_silu_apply(const half_t* y, long long M, int C, int hw, const BnTrainArgs& a, const ViewDesc& out, const ViewDesc& res,
+                      hipStream_t st);
+// part: replica slabs [R][C][2], zero on entry; receives (sum dz, sum dz*xhat)
+int cvx_bn_bwd_reduce(const half_t* y, long long M, int C, int hw, const BnCoef& k, const ViewDesc& gout, long long* part, hipStream_t st);
+int cvx_bn_bwd_apply(const half_t* y, long long M, int C, int hw, const BnCoef& k, const long long* part, float inv_scale, float* dgamma,
+                     float* dbeta, const ViewDesc& gout, half_t* dy, const ViewDesc& gres, int res_accumulate, hipStream_t st);
+// part: replica slabs [R][C][2], zero on entry
+int cvx_colsum(long long M, int C, int hw, const ViewDesc& g, long long* part, float inv_scale, float* dbias, hipStream_t st);

@@ -50,8 +50,9 @@ struct ConvParams {
   const float* scale;  // AFFINE_SILU
   const float* shift;  // AFFINE_SILU
   const float* bias;   // BIAS_F32
-  float* stats;        // RAW_STATS: [stats_replicas][Cout][2], accumulated with float atomics (must be zero on entry)
+  long long* stats;    // RAW_STATS: [stats_replicas][Cout][2] fixed-point (cvx_fix_atomic_add), must be zero on entry
   int stats_replicas;
+  const half_t* zeros; // >= 16 zero bytes in device memory: DMA source for padding (second-generation kernel); null -> generation one
 };
 #define CVX_STAT_REPLICAS 32
 
@@ -59,6 +60,8 @@ struct ConvParams {
 int cvx_conv_igemm_launch(const ConvParams& p, hipStream_t stream, int* m_blocks);
 // Number of M-blocks the launcher will use for M output pixels.
 int cvx_conv_igemm_mblocks(long long M);
+// second generation (LDS-DMA ring, conv_igemm_dma.hip); cvx_conv_igemm_launch forwards to it when p.zeros is set
+int cvx_conv_igemm_dma_launch(const ConvParams& p, hipStream_t stream);
 
 // Weight gradient: dW[co][tap][ci] partial sums over a slice of the pixels, written as fp32 slabs.
 struct WgradParams {

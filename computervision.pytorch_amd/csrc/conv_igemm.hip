@@ -12,6 +12,8 @@
 //   under the gfx950 lane-group rules (MI355X_MICROARCH.md, LDS section).
 // * register double buffering: the global gather for K-step s+1 is issued before the MFMAs of step s;
 //   two LDS buffers, one barrier per K-step.
+#include <cstdlib>
+
 #include "conv_igemm.h"
 
 namespace {
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       if (n < p.Cout) {
         float v = sStat[0][ch][which] + sStat[1][ch][which] + sStat[2][ch][which] + sStat[3][ch][which];
         // a few replica slabs (blockIdx mod R) keep the float atomics spread over many addresses
-        atomicAdd(&p.stats[((long long)(blockIdx.x % p.stats_replicas) * p.Cout + n) * 2 + which], v);
+        cvx_fix_atomic_add(&p.stats[((long long)(blockIdx.x % p.stats_replicas) * p.Cout + n) * 2 + which], v);
       }
     }
     return;
@@ -240,6 +242,11 @@ int cvx_conv_igemm_launch(const ConvParams& p, hipStream_t stream, int* m_blocks
   CVX_CHECK(((uintptr_t)p.in % 16) == 0 && ((uintptr_t)p.wt % 16) == 0, "conv_igemm: operands must be 16-byte aligned");
   const long long M = (long long)p.B * p.OH2 * p.OW2;
   CVX_CHECK(M > 0, "conv_igemm: empty output");
+  static const bool force_v1 = getenv("CVX_CONV_V1") != nullptr;
+  if (p.zeros && !force_v1) {
+    if (m_blocks) *m_blocks = 0;
+    return cvx_conv_igemm_dma_launch(p, stream);
+  }
   const int tiles = (p.Cout + 15) / 16;
   static const int allowed[] = {1, 2, 3, 4, 5, 6, 8};
   int gy = (tiles + 7) / 8;

@@ -1,0 +1,311 @@
+// Implicit-GEMM convolution, second generation: the K loop is fed by LDS-DMA (global_load_lds_dwordx4)
+// into a ring of LDS stages, several K-steps in flight, one raw s_barrier per step.
+//
+// Why: the first-generation kernel (conv_igemm.hip) stages through VGPRs with one K-step of prefetch, so every
+// K-step exposes a global-load latency; rocprof showed the small-spatial layers (40x40, 20x20: 100-400 workgroups,
+// 18-36 K-steps each) at 40-75 us for ~5 us of work.  Here:
+//   * each wave issues PASSES x 1 KiB DMA pieces per K-step straight into LDS (no VGPR staging, no ds_write),
+//     STAGES-1 steps ahead, and waits with a counted s_waitcnt vmcnt(N) (never 0 in the steady state);
+//   * zero fill (image border, K tail, M/N tail) = the lane points its DMA at a zero page instead of predication,
+//     so EXEC stays full and the LDS image is always completely written;
+//   * the LDS image is the same 64-byte-row, XOR-swizzled layout as generation one -- the swizzle is applied on the
+//     SOURCE side (which k-group a lane fetches), the DMA writes linearly (cdna_hip_programming.md rule 21);
+//   * tile shapes: 128x(16 NT), 64x(16 NT) (4 waves along M) and 32x(32 NTW) (2x2 waves) so that the 40x40 and
+//     20x20 levels still spread over >= 400 workgroups.
+// Operand roles, fragment maps and the epilogues are those of conv_igemm.hip.
+#include "conv_igemm.h"
+
+namespace {
+
+constexpr int BK = 32;
+
+__device__ __forceinline__ int lds_row_off(int row, int slot) { return row * BK + ((slot ^ ((row >> 1) & 3)) << 3); }
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else static_assert(N < 0, "unsupported vmcnt");
+}
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
+
+template <int WM, int WN, int MT, int NTW, int STAGES>
+__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p) {
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int BM = 16 * MT * WM, BN = 16 * NTW * WN;
+  constexpr int ROWS = ((BM + BN + 63) / 64) * 64;  // rows per stage incl. dummy tail
+  constexpr int PASSES = ROWS / 64;                 // DMA instructions per wave per K-step
+  constexpr int PRE = STAGES - 1;                   // K-steps in flight ahead of the one being computed
+  constexpr int STAGE_HALVES = ROWS * BK;
+  // ---- one LDS array (a second __shared__ object can make hipcc drain the DMA queue, guide 5.x item 4a) ----
+  constexpr int RING_BYTES = STAGES * STAGE_HALVES * 2;
+  constexpr int TAP_BYTES = CVX_MAX_TAPS * (int)sizeof(ConvTap);
+  constexpr int STAT_BYTES = WM * BN * 2 * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RING_BYTES + TAP_BYTES + STAT_BYTES];
+  half_t* ring = reinterpret_cast<half_t*>(smem);
+  ConvTap* sTap = reinterpret_cast<ConvTap*>(smem + RING_BYTES);
+  float* sStat = reinterpret_cast<float*>(smem + RING_BYTES + TAP_BYTES);  // [WM][BN][2]
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / WN, wn = wave % WN;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int nblk = blockIdx.y;
+  const long long M = (long long)p.B * p.OH2 * p.OW2;
+  const long long m_base = (long long)blockIdx.x * BM;
+
+  if (tid < p.ntaps) sTap[tid] = p.taps[tid];
+
+  // ---- per-lane DMA assignment: pass q covers stage rows q*64 + wave*16 + (lane>>2), physical slot lane&3 ----
+  const int r16 = lane >> 2;
+  const int kg = (lane & 3) ^ ((r16 >> 1) & 3);  // logical k-group this lane fetches (source-side swizzle)
+  const half_t* src_base[PASSES];                // pixel base (A rows) or weight row (B rows); nullptr = always zero
+  int ih0[PASSES], iw0[PASSES];
+#pragma unroll
+  for (int q = 0; q < PASSES; ++q) {
+    const int row = q * 64 + wave * 16 + r16;
+    src_base[q] = nullptr;
+    ih0[q] = iw0[q] = 0;
+    if (row < BM) {
+      long long m = m_base + row;
+      if (m < M) {
+        int ow2 = (int)(m % p.OW2);
+        long long t = m / p.OW2;
+        int oh2 = (int)(t % p.OH2);
+        int b = (int)(t / p.OH2);
+        ih0[q] = oh2 * p.IS;
+        iw0[q] = ow2 * p.IS;
+        src_base[q] = p.in + (long long)b * p.in_bstride;
+      }
+    } else if (row < BM + BN) {
+      int n = nblk * BN + (row - BM);
+      if (n < p.Cout) src_base[q] = p.wt + (long long)n * p.wt_ld;
+    }
+  }
+  int c = kg * 8, tap = 0;
+  while (c >= p.Cin) {
+    c -= p.Cin;
+    ++tap;
+  }
+  const int nsteps = (p.ntaps * p.Cin + BK - 1) / BK;
+  __syncthreads();  // tap table visible (no DMA outstanding yet)
+
+  auto issue = [&](int stage) {
+    const bool kvalid = tap < p.ntaps;
+    ConvTap td = sTap[kvalid ? tap : 0];
+    half_t* stage_base = ring + stage * STAGE_HALVES;
+#pragma unroll
+    for (int q = 0; q < PASSES; ++q) {
+      const int row0 = q * 64 + wave * 16;  // wave-uniform: the 16 rows of this piece are all A, all B or all dummy
+      const half_t* g = p.zeros;
+      if (row0 < BM) {
+        int ih = ih0[q] + td.dh, iw = iw0[q] + td.dw;
+        if (kvalid && src_base[q] && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW)
+          g = src_base[q] + ((long long)ih * p.IW + iw) * p.in_ld + c;
+      } else {
+        if (kvalid && src_base[q]) g = src_base[q] + td.wtap * p.Cin + c;
+      }
+      __builtin_amdgcn_global_load_lds((gbl_void_ptr)g, (lds_void_ptr)(stage_base + row0 * BK), 16, 0, 0);
+    }
+    c += BK;
+    while (c >= p.Cin) {
+      c -= p.Cin;
+      ++tap;
+    }
+  };
+
+  f4 acc[MT][NTW];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  int issued = 0;
+  for (; issued < PRE && issued < nsteps; ++issued) issue(issued % STAGES);
+
+  for (int s = 0; s < nsteps; ++s) {
+    // DMA pieces of K-step s have landed once at most (steps issued after s) * PASSES pieces remain outstanding
+    const int ahead = issued - 1 - s;  // block-uniform, in [0, PRE-1]
+    if (ahead >= PRE - 1) wait_vmcnt<(PRE - 1) * PASSES>();
+    else if (PRE >= 3 && ahead == 1) wait_vmcnt<PASSES>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // every wave's pieces of step s are in LDS; everyone is done reading stage (s-1)
+    if (issued < nsteps) {
+      issue(issued % STAGES);  // refills the stage that was computed in the previous iteration
+      ++issued;
+    }
+    const half_t* st = ring + (s % STAGES) * STAGE_HALVES;
+    h8 xa[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) xa[i] = *reinterpret_cast<const h8*>(&st[lds_row_off((wm * MT + i) * 16 + fr, fq)]);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      h8 wb = *reinterpret_cast<const h8*>(&st[lds_row_off(BM + (wn * NTW + j) * 16 + fr, fq)]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb, xa[i], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane holds pixel (fr) x channels 4*fq..4*fq+3 of every (i, j) tile ----
+  long long out_off[MT], res_off[MT];
+  bool pvalid[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    long long m = m_base + (wm * MT + i) * 16 + fr;
+    pvalid[i] = m < M;
+    long long mm = pvalid[i] ? m : 0;
+    int ow2 = (int)(mm % p.OW2);
+    long long t = mm / p.OW2;
+    int oh2 = (int)(t % p.OH2);
+    int b = (int)(t / p.OH2);
+    long long pix = (long long)(oh2 * p.OS + p.oph) * p.OWr + (ow2 * p.OS + p.opw);
+    out_off[i] = (long long)b * p.out_bstride + pix * p.out_ld;
+    res_off[i] = (long long)b * p.res_bstride + pix * p.res_ld;
+  }
+
+  if (p.epi == CVX_EPI_RAW_STATS) {
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const int chl = (wn * NTW + j) * 16 + fq * 4;  // channel inside the block's BN range
+      const int n0 = nblk * BN + chl;
+      float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        if (pvalid[i]) {
+          if (n0 < p.Cout) {
+            h4 v = {(half_t)acc[i][j][0], (half_t)acc[i][j][1], (half_t)acc[i][j][2], (half_t)acc[i][j][3]};
+            *reinterpret_cast<h4*>(p.out16 + out_off[i] + n0) = v;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            s1[r] += acc[i][j][r];
+            s2[r] += acc[i][j][r] * acc[i][j][r];
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = cvx_wave_sum16(s1[r]), b2 = cvx_wave_sum16(s2[r]);
+        if (fr == 0) {
+          sStat[(wm * BN + chl + r) * 2 + 0] = a;
+          sStat[(wm * BN + chl + r) * 2 + 1] = b2;
+        }
+      }
+    }
+    __syncthreads();
+    for (int t = tid; t < BN * 2; t += 256) {
+      int ch = t >> 1, which = t & 1;
+      int n = nblk * BN + ch;
+      if (n < p.Cout) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) v += sStat[(w * BN + ch) * 2 + which];
+        cvx_fix_atomic_add(&p.stats[((long long)(blockIdx.x % p.stats_replicas) * p.Cout + n) * 2 + which], v);
+      }
+    }
+    return;
+  }
+
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const int n0 = nblk * BN + (wn * NTW + j) * 16 + fq * 4;
+    if (n0 >= p.Cout) continue;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      if (!pvalid[i]) continue;
+      f4 v = acc[i][j];
+      if (p.epi == CVX_EPI_AFFINE_SILU) {
+        f4 sc = *reinterpret_cast<const f4*>(p.scale + n0);
+        f4 sh = *reinterpret_cast<const f4*>(p.shift + n0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = cvx_silu(v[r] * sc[r] + sh[r]);
+        if (p.res) {
+          h4 rr = *reinterpret_cast<const h4*>(p.res + res_off[i] + n0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+        }
+      } else if (p.epi == CVX_EPI_BIAS_F32) {
+        f4 bb = *reinterpret_cast<const f4*>(p.bias + n0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bb[r];
+        *reinterpret_cast<f4*>(p.out32 + out_off[i] + n0) = v;
+        continue;
+      }
+      half_t* dst = p.out16 + out_off[i] + n0;
+      if (p.accumulate) {
+        h4 old = *reinterpret_cast<const h4*>(dst);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)old[r];
+      }
+      h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+      *reinterpret_cast<h4*>(dst) = o;
+    }
+  }
+}
+
+template <int WM, int WN, int MT, int NTW>
+void launch_cfg(const ConvParams& p, hipStream_t stream, dim3 grid) {
+  constexpr int BM = 16 * MT * WM, BN = 16 * NTW * WN;
+  constexpr int STAGES = (BM + BN) <= 192 ? 4 : 3;
+  hipLaunchKernelGGL((conv_igemm_dma_kernel<WM, WN, MT, NTW, STAGES>), grid, dim3(256), 0, stream, p);
+}
+
+template <int MT>
+void launch_m4(int NT, const ConvParams& p, hipStream_t st, dim3 grid) {  // 4 waves along M
+  switch (NT) {
+    case 1: launch_cfg<4, 1, MT, 1>(p, st, grid); break;
+    case 2: launch_cfg<4, 1, MT, 2>(p, st, grid); break;
+    case 3: launch_cfg<4, 1, MT, 3>(p, st, grid); break;
+    case 4: launch_cfg<4, 1, MT, 4>(p, st, grid); break;
+    case 5: launch_cfg<4, 1, MT, 5>(p, st, grid); break;
+    case 6: launch_cfg<4, 1, MT, 6>(p, st, grid); break;
+    default: launch_cfg<4, 1, MT, 8>(p, st, grid); break;
+  }
+}
+
+}  // namespace
+
+int cvx_conv_igemm_dma_launch(const ConvParams& p, hipStream_t stream) {
+  CVX_CHECK(p.zeros && ((uintptr_t)p.zeros % 16) == 0, "conv_igemm_dma: needs a 16-byte aligned zero page");
+  const long long M = (long long)p.B * p.OH2 * p.OW2;
+  const int tiles = (p.Cout + 15) / 16;
+  static const int allowed[] = {1, 2, 3, 4, 5, 6, 8};
+  int BM = 128;
+  if (M < 128LL * 1024) BM = (M >= 64LL * 1024) ? 64 : 32;
+  if (BM == 32) {
+    // 2x2 waves: BN = 32 * NTW
+    int pairs = (tiles + 1) / 2;
+    int gy = (pairs + 3) / 4;
+    int ntw = (pairs + gy - 1) / gy;  // 1..4
+    gy = (pairs + ntw - 1) / ntw;
+    dim3 grid(cvx_cdiv(M, 32), gy);
+    switch (ntw) {
+      case 1: launch_cfg<2, 2, 1, 1>(p, stream, grid); break;
+      case 2: launch_cfg<2, 2, 1, 2>(p, stream, grid); break;
+      case 3: launch_cfg<2, 2, 1, 3>(p, stream, grid); break;
+      default: launch_cfg<2, 2, 1, 4>(p, stream, grid); break;
+    }
+  } else {
+    int gy = (tiles + 7) / 8;
+    int want = (tiles + gy - 1) / gy;
+    int NT = 8;
+    for (int a : allowed)
+      if (a >= want) {
+        NT = a;
+        break;
+      }
+    gy = (tiles + NT - 1) / NT;
+    dim3 grid(cvx_cdiv(M, BM), gy);
+    if (BM == 128) launch_m4<2>(NT, p, stream, grid);
+    else launch_m4<1>(NT, p, stream, grid);
+  }
+  CVX_HIP(hipGetLastError());
+  return 0;
+}

@@ -62,6 +62,14 @@ __device__ __forceinline__ float cvx_wave_sum64(float v) {
   v += __shfl_xor(v, 32);
   return v;
 }
+// Deterministic cross-workgroup sums: partial sums are converted to 64-bit fixed point (2^-30 resolution,
+// +-8.6e9 range) and added with integer atomics, so the total does not depend on arrival order.
+#define CVX_FIX_SCALE 1073741824.0f
+__device__ __forceinline__ void cvx_fix_atomic_add(long long* dst, float v) {
+  atomicAdd(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__float2ll_rn(v * CVX_FIX_SCALE));
+}
+__device__ __forceinline__ double cvx_fix_to_double(long long v) { return (double)v * (1.0 / 1073741824.0); }
+
 __device__ __forceinline__ float cvx_wave_max64(float v) {
   for (int o = 1; o < 64; o <<= 1) v = fmaxf(v, __shfl_xor(v, o));
   return v;

@@ -36,7 +36,10 @@ struct ConvRt {
   int in_accum = 0, res_accum = 0;
   // per-batch
   half_t* ybuf = nullptr;
-  float *mean = nullptr, *invstd = nullptr, *c1 = nullptr, *c2 = nullptr, *scale = nullptr, *shift = nullptr;
+  half_t* dybuf = nullptr;  // gradient w.r.t. the raw conv output (kept per layer: the weight-gradient runs on a side stream)
+  float *mean = nullptr, *invstd = nullptr, *scale = nullptr, *shift = nullptr;
+  long long *stat_fwd = nullptr, *stat_bwd = nullptr;  // fixed-point replica slabs [R][C][2]
+  hipEvent_t ev_dy = nullptr;
   long long slab_off = 0;
   int nsplit = 1;
 };
@@ -71,6 +74,7 @@ struct cvx_engine {
   std::vector<void*> static_allocs;
   half_t* shadow = nullptr;
   long long shadow_elems = 0;
+  half_t* zero_page = nullptr;  // DMA source for conv padding
   PackDesc* d_pack = nullptr;
   BlockRef* d_pack_blocks = nullptr;
   int n_pack_blocks = 0;
@@ -79,8 +83,10 @@ struct cvx_engine {
   bool planned_train = false;
   std::vector<void*> batch_allocs;
   int64_t batch_bytes = 0, static_bytes = 0;
-  float* partials = nullptr;
-  half_t* dy_scratch = nullptr;
+  long long* stat_region = nullptr;  // [fwd slabs | bwd slabs] of every conv op, zeroed once per pass
+  long long stat_half = 0;           // entries per half
+  hipStream_t side = nullptr;    // weight gradients run here, concurrently with the data-gradient chain
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   float* slabs = nullptr;
   SlabDesc* d_slab = nullptr;
   BlockRef* d_slab_blocks = nullptr;
@@ -128,7 +134,9 @@ enum { PROF_CONV_FWD = 0, PROF_CONV_DGRAD = 1, PROF_CONV_WGRAD = 2, PROF_BN_FWD 
 
 struct ProfScope {  // records a start/stop event pair around the launches issued while it lives
   cvx_engine* e;
-  ProfScope(cvx_engine* eng, int cls, double flops, double bytes) : e(eng->profile ? eng : nullptr) {
+  hipStream_t st;
+  ProfScope(cvx_engine* eng, int cls, double flops, double bytes, hipStream_t stream = nullptr)
+      : e(eng->profile ? eng : nullptr), st(stream ? stream : eng->stream) {
     if (!e) return;
     while (e->ev_pool.size() < e->ev_used + 2) {
       hipEvent_t ev;
@@ -139,12 +147,14 @@ struct ProfScope {  // records a start/stop event pair around the launches issue
       e->ev_pool.push_back(ev);
     }
     e->prof_recs.push_back({cls, flops, bytes});
-    (void)hipEventRecord(e->ev_pool[e->ev_used], e->stream);
+    slot = e->ev_used;
+    e->ev_used += 2;
+    (void)hipEventRecord(e->ev_pool[slot], st);
   }
+  size_t slot = 0;
   ~ProfScope() {
     if (!e) return;
-    (void)hipEventRecord(e->ev_pool[e->ev_used + 1], e->stream);
-    e->ev_used += 2;
+    (void)hipEventRecord(e->ev_pool[slot + 1], st);
   }
 };
 
@@ -254,6 +264,9 @@ int build_static(cvx_engine* e) {
   CVX_TRY(dev_alloc(e, e->static_allocs, e->static_bytes, &p, sh * 2));
   e->shadow = (half_t*)p;
   CVX_HIP(hipMemset(p, 0, (size_t)(sh * 2)));
+  CVX_TRY(dev_alloc(e, e->static_allocs, e->static_bytes, &p, 256));
+  e->zero_page = (half_t*)p;
+  CVX_HIP(hipMemset(p, 0, 256));
   CVX_TRY(upload(e, e->static_allocs, e->static_bytes, &e->d_pack, packs));
   CVX_TRY(upload(e, e->static_allocs, e->static_bytes, &e->d_pack_blocks, pblocks));
   e->n_pack_blocks = (int)pblocks.size();
@@ -303,6 +316,7 @@ int build_static(cvx_engine* e) {
 int plan_batch(cvx_engine* e, int B, bool training) {
   if (e->planned_batch == B && (e->planned_train || !training)) return 0;
   CVX_HIP(hipStreamSynchronize(e->stream));
+  if (e->side) CVX_HIP(hipStreamSynchronize(e->side));
   free_pool(e->batch_allocs);
   e->batch_bytes = 0;
   e->planned_batch = 0;
@@ -318,7 +332,7 @@ int plan_batch(cvx_engine* e, int B, bool training) {
       b.grad = (half_t*)p;
     }
   }
-  long long max_part = 16, max_dy = 16, slab_total = 0;
+  long long stat_floats = 0, slab_total = 0;
   std::vector<SlabDesc> sdescs;
   std::vector<BlockRef> sblocks;
   for (size_t i = 0; i < e->ops.size(); ++i) {
@@ -334,20 +348,20 @@ int plan_batch(cvx_engine* e, int B, bool training) {
     ConvRt& c = e->conv[i];
     const long long M = (long long)B * o.oh * o.ow;
     const int C = o.out.c;
-    CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, 6LL * C * 4));
+    CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, 4LL * C * 4));
     c.mean = (float*)p;
     c.invstd = c.mean + C;
-    c.c1 = c.invstd + C;
-    c.c2 = c.c1 + C;
-    c.scale = c.c2 + C;
+    c.scale = c.invstd + C;
     c.shift = c.scale + C;
     if (training && o.act == CVX_ACT_BN_SILU) {
       CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, M * C * 2));
       c.ybuf = (half_t*)p;
+      CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, M * C * 2));
+      c.dybuf = (half_t*)p;
     }
-    max_part = std::max(max_part, (long long)CVX_STAT_REPLICAS * C * 2);
+    c.stat_fwd = (long long*)nullptr + stat_floats;  // offset for now, rebased below
+    stat_floats += (long long)CVX_STAT_REPLICAS * C * 2;
     if (training) {
-      max_dy = std::max(max_dy, M * C);
       int co_b, j_b;
       wgrad_tile(C, &co_b, &j_b);
       const int Jtot = c.ntaps * c.cin_pad16;
@@ -372,12 +386,17 @@ int plan_batch(cvx_engine* e, int B, bool training) {
       sdescs.push_back(sd);
     }
   }
-  CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, max_part * 4));
-  e->partials = (float*)p;
-  CVX_HIP(hipMemset(p, 0, (size_t)(max_part * 4)));  // replica slabs: producers add atomically, finalizers re-zero
+  CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, 2 * stat_floats * 8));
+  e->stat_region = (long long*)p;
+  e->stat_half = stat_floats;
+  for (size_t i = 0; i < e->ops.size(); ++i) {
+    if (e->ops[i].type != CVX_OP_CONV) continue;
+    ConvRt& c = e->conv[i];
+    const long long off = c.stat_fwd - (long long*)nullptr;
+    c.stat_fwd = e->stat_region + off;
+    c.stat_bwd = e->stat_region + stat_floats + off;
+  }
   if (training) {
-    CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, max_dy * 2));
-    e->dy_scratch = (half_t*)p;
     CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, slab_total * 4));
     e->slabs = (float*)p;
     CVX_TRY(upload(e, e->batch_allocs, e->batch_bytes, &e->d_slab, sdescs));
@@ -411,6 +430,7 @@ void fill_conv_fwd(const cvx_engine* e, int i, int B, ConvParams* cp) {
   cp->OWr = o.ow;
   cp->ntaps = c.ntaps;
   cp->taps = c.taps_fwd;
+  cp->zeros = e->zero_page;
 }
 
 }  // namespace
@@ -434,6 +454,19 @@ extern "C" int cvx_engine_create(cvx_engine** out, const cvx_buf_desc* bufs, int
     CVX_FAIL("image_buf must be an 8-channel fp16 buffer and pred_buf a PRED_F32 buffer");
   }
   int rc = build_static(e);
+  if (rc == 0) {
+    if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
+      cvx_set_error("cvx_engine_create: could not create the side stream / events");
+      rc = -1;
+    }
+    for (size_t i = 0; rc == 0 && i < e->ops.size(); ++i)
+      if (e->ops[i].type == CVX_OP_CONV && hipEventCreateWithFlags(&e->conv[i].ev_dy, hipEventDisableTiming) != hipSuccess) {
+        cvx_set_error("cvx_engine_create: could not create events");
+        rc = -1;
+      }
+  }
   if (rc != 0) {
     free_pool(e->static_allocs);
     delete e;
@@ -446,6 +479,15 @@ extern "C" int cvx_engine_create(cvx_engine** out, const cvx_buf_desc* bufs, int
 extern "C" int cvx_engine_destroy(cvx_engine* e) {
   if (!e) return 0;
   (void)hipStreamSynchronize(e->stream);
+  if (e->side) {
+    (void)hipStreamSynchronize(e->side);
+    (void)hipStreamDestroy(e->side);
+  }
+  for (auto& c : e->conv)
+    if (c.ev_dy) (void)hipEventDestroy(c.ev_dy);
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   free_pool(e->batch_allocs);
   free_pool(e->static_allocs);
   delete e;
@@ -503,6 +545,7 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
   const int B = batch;
   // fp32 master -> fp16 shadows (forward layout + transposed layout for the data gradient)
   const Buf& ib = e->bufs[e->image_buf];
+  if (training) CVX_HIP(hipMemsetAsync(e->stat_region, 0, (size_t)e->stat_half * 8, st));
   {
     ProfScope ps(e, PROF_MISC, 0, 6.0 * e->n_params + (double)B * ib.d.h * ib.d.w * (12 + 16));
     CVX_TRY(cvx_pack_weights(e->params, e->shadow, e->d_pack, e->d_pack_blocks, e->n_pack_blocks, st));
@@ -546,7 +589,7 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
       cp.out16 = c.ybuf;
       cp.out_ld = C;
       cp.out_bstride = (long long)o.oh * o.ow * C;
-      cp.stats = e->partials;
+      cp.stats = c.stat_fwd;
       cp.stats_replicas = CVX_STAT_REPLICAS;
       int P = 0;
       {
@@ -554,10 +597,9 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
         CVX_TRY(cvx_conv_igemm_launch(cp, st, &P));
       }
       ProfScope ps(e, PROF_BN_FWD, 0, (resv.p ? 6.0 : 4.0) * M * C);
-      CVX_TRY(cvx_bn_finalize(e->partials, CVX_STAT_REPLICAS, C, M, e->bn_momentum, e->bn_eps, c.mean, c.invstd, e->stats + o.rmean_off,
-                              e->stats + o.rvar_off, st));
-      BnCoef k{c.mean, c.invstd, e->params + o.gamma_off, e->params + o.beta_off};
-      CVX_TRY(cvx_bn_silu_apply(c.ybuf, M, C, o.oh * o.ow, k, outv, resv, st));
+      BnTrainArgs ta{c.stat_fwd,           e->params + o.gamma_off, e->params + o.beta_off, c.mean, c.invstd, e->stats + o.rmean_off,
+                     e->stats + o.rvar_off, e->bn_eps,       e->bn_momentum};
+      CVX_TRY(cvx_bn_silu_apply(c.ybuf, M, C, o.oh * o.ow, ta, outv, resv, st));
     } else {
       CVX_TRY(cvx_bn_fold(C, e->params + o.gamma_off, e->params + o.beta_off, e->stats + o.rmean_off, e->stats + o.rvar_off, e->bn_eps,
                           c.scale, c.shift, st));
@@ -591,6 +633,10 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
   const Buf& pb = e->bufs[e->pred_buf];
   const long long A = (long long)pb.d.h * pb.d.w;
   half_t* dpred = (half_t*)dpred_f16;
+  CVX_HIP(hipMemsetAsync(e->stat_region + e->stat_half, 0, (size_t)e->stat_half * 8, st));
+  // fork: the side stream (weight gradients) starts after everything already queued on the main stream
+  CVX_HIP(hipEventRecord(e->ev_fork, st));
+  CVX_HIP(hipStreamWaitEvent(e->side, e->ev_fork, 0));
 
   for (int i = (int)e->ops.size() - 1; i >= 0; --i) {
     const cvx_op_desc& o = e->ops[i];
@@ -615,19 +661,22 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
       dyv.ld = pb.d.c;
       dyv.bstride = A * pb.d.c;
       ProfScope ps(e, PROF_MISC, 0, 2.0 * M * C);
-      CVX_TRY(cvx_colsum(M, C, hw, dyv, e->partials, inv_scale, e->grads + o.bias_off, st));
+      CVX_TRY(cvx_colsum(M, C, hw, dyv, c.stat_bwd, inv_scale, e->grads + o.bias_off, st));
     } else {
       ViewDesc gout = make_view(e, o.out, true);
       ViewDesc gres = make_view(e, o.res, true);
       BnCoef k{c.mean, c.invstd, e->params + o.gamma_off, e->params + o.beta_off};
       ProfScope ps(e, PROF_BN_BWD, 0, (gres.p ? 14.0 : 10.0) * M * C);
-      CVX_TRY(cvx_bn_bwd_reduce(c.ybuf, M, C, hw, k, gout, e->partials, st));
-      CVX_TRY(cvx_bn_bwd_finalize(e->partials, CVX_STAT_REPLICAS, C, M, inv_scale, c.c1, c.c2, e->grads + o.gamma_off,
-                                  e->grads + o.beta_off, st));
-      CVX_TRY(cvx_bn_bwd_apply(c.ybuf, M, C, hw, k, c.c1, c.c2, gout, e->dy_scratch, gres, c.res_accum, st));
-      dyv.p = e->dy_scratch;
+      CVX_TRY(cvx_bn_bwd_reduce(c.ybuf, M, C, hw, k, gout, c.stat_bwd, st));
+      CVX_TRY(cvx_bn_bwd_apply(c.ybuf, M, C, hw, k, c.stat_bwd, inv_scale, e->grads + o.gamma_off, e->grads + o.beta_off, gout, c.dybuf,
+                               gres, c.res_accum, st));
+      dyv.p = c.dybuf;
       dyv.ld = C;
       dyv.bstride = (long long)hw * C;
+    }
+    if (o.act != CVX_ACT_BIAS) {  // dy of this layer is complete: the side stream may start its weight gradient
+      CVX_HIP(hipEventRecord(c.ev_dy, st));
+      CVX_HIP(hipStreamWaitEvent(e->side, c.ev_dy, 0));
     }
     // ---- data gradient: dx = dy (*) W^T, one launch per output phase of the forward stride ----
     if (o.needs_dgrad) {
@@ -658,6 +707,7 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
         cp.ntaps = dc.ntaps;
         cp.taps = dc.taps;
         cp.epi = CVX_EPI_PLAIN;
+        cp.zeros = e->zero_page;
         cp.accumulate = c.in_accum;
         cp.out16 = gin.p;
         cp.out_ld = gin.ld;
@@ -691,10 +741,12 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
       wp.slabs = e->slabs + c.slab_off;
       wp.nsplit = c.nsplit;
       wp.cin_pad16 = c.cin_pad16;
-      ProfScope ps(e, PROF_CONV_WGRAD, conv_flops(o, B), conv_bytes(o, B) + 4.0 * c.nsplit * C * c.ntaps * c.cin_pad16);
-      CVX_TRY(cvx_conv_wgrad_launch(wp, st));
+      ProfScope ps(e, PROF_CONV_WGRAD, conv_flops(o, B), conv_bytes(o, B) + 4.0 * c.nsplit * C * c.ntaps * c.cin_pad16, e->side);
+      CVX_TRY(cvx_conv_wgrad_launch(wp, e->side));
     }
   }
+  CVX_HIP(hipEventRecord(e->ev_join, e->side));  // join: the slab reduction needs every weight-gradient slab
+  CVX_HIP(hipStreamWaitEvent(st, e->ev_join, 0));
   {
     double slab_bytes = 0;
     for (size_t i = 0; i < e->ops.size(); ++i)
@@ -759,9 +811,16 @@ extern "C" int cvx_check_finite(const float* grads, int64_t n, int32_t* found_in
 // ---- single-op entry points --------------------------------------------------------------------
 namespace {
 int make_taps(std::vector<ConvTap>& host, ConvTap** dev) {
-  CVX_HIP(hipMalloc((void**)dev, host.size() * sizeof(ConvTap)));
+  // the tap table is followed by a 256-byte zero page (DMA padding source of the second-generation kernel)
+  const size_t tb = ((host.size() * sizeof(ConvTap) + 255) / 256) * 256;
+  CVX_HIP(hipMalloc((void**)dev, tb + 256));
+  CVX_HIP(hipMemset(*dev, 0, tb + 256));
   CVX_HIP(hipMemcpy(*dev, host.data(), host.size() * sizeof(ConvTap), hipMemcpyHostToDevice));
   return 0;
+}
+const half_t* zeros_after(const ConvTap* dev, size_t ntaps) {
+  const size_t tb = ((ntaps * sizeof(ConvTap) + 255) / 256) * 256;
+  return reinterpret_cast<const half_t*>(reinterpret_cast<const char*>(dev) + tb);
 }
 }  // namespace
 
@@ -795,6 +854,7 @@ extern "C" int cvx_conv2d_nhwc(const void* x_f16, int32_t batch, int32_t ih, int
   cp.OWr = ow;
   cp.ntaps = k * k;
   cp.taps = dt;
+  cp.zeros = zeros_after(dt, taps.size());
   cp.out_ld = cout;
   cp.out_bstride = (long long)oh * ow * cout;
   if (mode == 0) {
@@ -860,6 +920,7 @@ extern "C" int cvx_conv2d_dgrad_nhwc(const void* dy_f16, int32_t batch, int32_t 
       cp.OWr = iw;
       cp.ntaps = (int)taps.size();
       cp.taps = dt;
+      cp.zeros = zeros_after(dt, taps.size());
       cp.epi = CVX_EPI_PLAIN;
       cp.out16 = (half_t*)dx_f16;
       cp.out_ld = cin;
