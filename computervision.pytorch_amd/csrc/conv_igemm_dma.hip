@@ -13,6 +13,8 @@
 //   * tile shapes: 128x(16 NT), 64x(16 NT) (4 waves along M) and 32x(32 NTW) (2x2 waves) so that the 40x40 and
 //     20x20 levels still spread over >= 400 workgroups.
 // Operand roles, fragment maps and the epilogues are those of conv_igemm.hip.
+#include <cstdlib>
+
 #include "conv_igemm.h"
 
 namespace {
@@ -23,15 +25,33 @@ __device__ __forceinline__ int lds_row_off(int row, int slot) { return row * BK 
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else static_assert(N < 0, "unsupported vmcnt");
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// waits until at most ahead*PASSES DMA pieces are outstanding (ahead is block-uniform, 0..MAXA)
+template <int PASSES, int MAXA>
+__device__ __forceinline__ void wait_steps_ahead(int ahead) {
+  if constexpr (MAXA == 0) {
+    wait_vmcnt<0>();
+  } else {
+    if (ahead >= MAXA) wait_vmcnt<MAXA * PASSES>();
+    else wait_steps_ahead<PASSES, MAXA - 1>(ahead);
+  }
+}
+
+// compile-time LDS geometry of one tile configuration (shared by kernel and launcher)
+template <int WM, int WN, int MT, int NTW, int STAGES>
+struct Geom {
+  static constexpr int BM = 16 * MT * WM, BN = 16 * NTW * WN;
+  static constexpr int ROWS = BM + BN;
+  static constexpr int PASSES = (ROWS + 63) / 64;
+  // a stage holds the real rows plus one 16-row dump piece that every out-of-range DMA piece of the last pass targets
+  static constexpr int STAGE_HALVES = (ROWS + 16) * BK;
+  static constexpr int RING_BYTES = STAGES * STAGE_HALVES * 2;
+  static constexpr int TAP_BYTES = CVX_MAX_TAPS * (int)sizeof(ConvTap);
+  static constexpr int STAT_BYTES = WM * BN * 2 * 4;
+  static constexpr int LDS_BYTES = RING_BYTES + TAP_BYTES + STAT_BYTES;
+};
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
@@ -40,18 +60,16 @@ template <int WM, int WN, int MT, int NTW, int STAGES>
 __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p) {
   static_assert(WM * WN == 4, "4 waves");
   constexpr int BM = 16 * MT * WM, BN = 16 * NTW * WN;
-  constexpr int ROWS = ((BM + BN + 63) / 64) * 64;  // rows per stage incl. dummy tail
-  constexpr int PASSES = ROWS / 64;                 // DMA instructions per wave per K-step
-  constexpr int PRE = STAGES - 1;                   // K-steps in flight ahead of the one being computed
-  constexpr int STAGE_HALVES = ROWS * BK;
-  // ---- one LDS array (a second __shared__ object can make hipcc drain the DMA queue, guide 5.x item 4a) ----
-  constexpr int RING_BYTES = STAGES * STAGE_HALVES * 2;
-  constexpr int TAP_BYTES = CVX_MAX_TAPS * (int)sizeof(ConvTap);
-  constexpr int STAT_BYTES = WM * BN * 2 * 4;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[RING_BYTES + TAP_BYTES + STAT_BYTES];
+  using G = Geom<WM, WN, MT, NTW, STAGES>;
+  constexpr int ROWS = G::ROWS;        // real rows per stage (A then B)
+  constexpr int PASSES = G::PASSES;    // DMA instructions per wave per K-step (64 rows per pass)
+  constexpr int PRE = STAGES - 1;      // K-steps in flight ahead of the one being computed
+  constexpr int STAGE_HALVES = G::STAGE_HALVES;
+  // ---- one dynamic LDS array (a second __shared__ object can make hipcc drain the DMA queue, guide 5.x item 4a) ----
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   half_t* ring = reinterpret_cast<half_t*>(smem);
-  ConvTap* sTap = reinterpret_cast<ConvTap*>(smem + RING_BYTES);
-  float* sStat = reinterpret_cast<float*>(smem + RING_BYTES + TAP_BYTES);  // [WM][BN][2]
+  ConvTap* sTap = reinterpret_cast<ConvTap*>(smem + G::RING_BYTES);
+  float* sStat = reinterpret_cast<float*>(smem + G::RING_BYTES + G::TAP_BYTES);  // [WM][BN][2]
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -103,9 +121,11 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
     half_t* stage_base = ring + stage * STAGE_HALVES;
 #pragma unroll
     for (int q = 0; q < PASSES; ++q) {
-      const int row0 = q * 64 + wave * 16;  // wave-uniform: the 16 rows of this piece are all A, all B or all dummy
+      int row0 = q * 64 + wave * 16;  // wave-uniform: the 16 rows of this piece are all A, all B or all dummy
       const half_t* g = p.zeros;
-      if (row0 < BM) {
+      if (row0 >= ROWS) {
+        row0 = ROWS;  // dump piece
+      } else if (row0 < BM) {
         int ih = ih0[q] + td.dh, iw = iw0[q] + td.dw;
         if (kvalid && src_base[q] && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW)
           g = src_base[q] + ((long long)ih * p.IW + iw) * p.in_ld + c;
@@ -132,10 +152,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
 
   for (int s = 0; s < nsteps; ++s) {
     // DMA pieces of K-step s have landed once at most (steps issued after s) * PASSES pieces remain outstanding
-    const int ahead = issued - 1 - s;  // block-uniform, in [0, PRE-1]
-    if (ahead >= PRE - 1) wait_vmcnt<(PRE - 1) * PASSES>();
-    else if (PRE >= 3 && ahead == 1) wait_vmcnt<PASSES>();
-    else wait_vmcnt<0>();
+    wait_steps_ahead<PASSES, PRE - 1>(issued - 1 - s);  // block-uniform, in [0, PRE-1]
     __builtin_amdgcn_s_barrier();  // every wave's pieces of step s are in LDS; everyone is done reading stage (s-1)
     if (issued < nsteps) {
       issue(issued % STAGES);  // refills the stage that was computed in the previous iteration
@@ -250,23 +267,45 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
   }
 }
 
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+template <int WM, int WN, int MT, int NTW, int STAGES>
+int launch_st(const ConvParams& p, hipStream_t stream, dim3 grid) {
+  using G = Geom<WM, WN, MT, NTW, STAGES>;
+  static bool attr_done = false;  // > 64 KB of dynamic LDS needs the opt-in once per kernel
+  if (!attr_done) {
+    CVX_HIP(hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<WM, WN, MT, NTW, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                G::LDS_BYTES));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv_igemm_dma_kernel<WM, WN, MT, NTW, STAGES>), grid, dim3(256), G::LDS_BYTES, stream, p);
+  return 0;
+}
+
+// ring depth per tile family.  Measured on MI355X (bench.py, bs 32): deeper rings LOSE -- 2 stages for the 128/64-row
+// tiles and 3 for the 32-row tiles were the fastest of {2,3,4,6,8}; LDS footprint (workgroups per CU) matters more than
+// K-steps in flight.  CVX_STAGES_BIG / CVX_STAGES_SMALL select among the compiled depths for A/B runs.
 template <int WM, int WN, int MT, int NTW>
-void launch_cfg(const ConvParams& p, hipStream_t stream, dim3 grid) {
-  constexpr int BM = 16 * MT * WM, BN = 16 * NTW * WN;
-  constexpr int STAGES = (BM + BN) <= 192 ? 4 : 3;
-  hipLaunchKernelGGL((conv_igemm_dma_kernel<WM, WN, MT, NTW, STAGES>), grid, dim3(256), 0, stream, p);
+int launch_cfg(const ConvParams& p, hipStream_t stream, dim3 grid) {
+  static const int st = env_int(WN == 2 ? "CVX_STAGES_SMALL" : "CVX_STAGES_BIG", WN == 2 ? 3 : 2);
+  if (st >= 4) return launch_st<WM, WN, MT, NTW, 4>(p, stream, grid);
+  if (st == 3) return launch_st<WM, WN, MT, NTW, 3>(p, stream, grid);
+  return launch_st<WM, WN, MT, NTW, 2>(p, stream, grid);
 }
 
 template <int MT>
-void launch_m4(int NT, const ConvParams& p, hipStream_t st, dim3 grid) {  // 4 waves along M
+int launch_m4(int NT, const ConvParams& p, hipStream_t st, dim3 grid) {  // 4 waves along M
   switch (NT) {
-    case 1: launch_cfg<4, 1, MT, 1>(p, st, grid); break;
-    case 2: launch_cfg<4, 1, MT, 2>(p, st, grid); break;
-    case 3: launch_cfg<4, 1, MT, 3>(p, st, grid); break;
-    case 4: launch_cfg<4, 1, MT, 4>(p, st, grid); break;
-    case 5: launch_cfg<4, 1, MT, 5>(p, st, grid); break;
-    case 6: launch_cfg<4, 1, MT, 6>(p, st, grid); break;
-    default: launch_cfg<4, 1, MT, 8>(p, st, grid); break;
+    case 1: return launch_cfg<4, 1, MT, 1>(p, st, grid);
+    case 2: return launch_cfg<4, 1, MT, 2>(p, st, grid);
+    case 3: return launch_cfg<4, 1, MT, 3>(p, st, grid);
+    case 4: return launch_cfg<4, 1, MT, 4>(p, st, grid);
+    case 5: return launch_cfg<4, 1, MT, 5>(p, st, grid);
+    case 6: return launch_cfg<4, 1, MT, 6>(p, st, grid);
+    default: return launch_cfg<4, 1, MT, 8>(p, st, grid);
   }
 }
 
@@ -287,10 +326,10 @@ int cvx_conv_igemm_dma_launch(const ConvParams& p, hipStream_t stream) {
     gy = (pairs + ntw - 1) / ntw;
     dim3 grid(cvx_cdiv(M, 32), gy);
     switch (ntw) {
-      case 1: launch_cfg<2, 2, 1, 1>(p, stream, grid); break;
-      case 2: launch_cfg<2, 2, 1, 2>(p, stream, grid); break;
-      case 3: launch_cfg<2, 2, 1, 3>(p, stream, grid); break;
-      default: launch_cfg<2, 2, 1, 4>(p, stream, grid); break;
+      case 1: CVX_TRY((launch_cfg<2, 2, 1, 1>(p, stream, grid))); break;
+      case 2: CVX_TRY((launch_cfg<2, 2, 1, 2>(p, stream, grid))); break;
+      case 3: CVX_TRY((launch_cfg<2, 2, 1, 3>(p, stream, grid))); break;
+      default: CVX_TRY((launch_cfg<2, 2, 1, 4>(p, stream, grid))); break;
     }
   } else {
     int gy = (tiles + 7) / 8;
@@ -303,8 +342,8 @@ int cvx_conv_igemm_dma_launch(const ConvParams& p, hipStream_t stream) {
       }
     gy = (tiles + NT - 1) / NT;
     dim3 grid(cvx_cdiv(M, BM), gy);
-    if (BM == 128) launch_m4<2>(NT, p, stream, grid);
-    else launch_m4<1>(NT, p, stream, grid);
+    if (BM == 128) CVX_TRY(launch_m4<2>(NT, p, stream, grid));
+    else CVX_TRY(launch_m4<1>(NT, p, stream, grid));
   }
   CVX_HIP(hipGetLastError());
   return 0;
