@@ -316,8 +316,10 @@ int cvx_conv_igemm_dma_launch(const ConvParams& p, hipStream_t stream) {
   const long long M = (long long)p.B * p.OH2 * p.OW2;
   const int tiles = (p.Cout + 15) / 16;
   static const int allowed[] = {1, 2, 3, 4, 5, 6, 8};
+  // tile height by problem size (pixels): big M -> 128 rows; below t128 -> 64 rows; below t64 -> 32 rows
+  static const long long t128 = env_int("CVX_T128", 128 * 1024), t64 = env_int("CVX_T64", 64 * 1024);
   int BM = 128;
-  if (M < 128LL * 1024) BM = (M >= 64LL * 1024) ? 64 : 32;
+  if (M < t128) BM = (M >= t64) ? 64 : 32;
   if (BM == 32) {
     // 2x2 waves: BN = 32 * NTW
     int pairs = (tiles + 1) / 2;

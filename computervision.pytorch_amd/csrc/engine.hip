@@ -2,6 +2,7 @@
 // outputs, gradient buffers, fp16 weight shadows, gradient slabs), plans the concat-free buffer
 // views and the backward write/accumulate modes once, and replays the op list on one HIP stream.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -366,10 +367,13 @@ int plan_batch(cvx_engine* e, int B, bool training) {
       wgrad_tile(C, &co_b, &j_b);
       const int Jtot = c.ntaps * c.cin_pad16;
       const long long tiles = (long long)cvx_cdiv(C, co_b) * cvx_cdiv(Jtot, j_b);
-      long long ns = std::min<long long>(std::max<long long>(1, M / 256), std::max<long long>(1, 2048 / tiles));
+      static const long long blk_target = getenv("CVX_WGRAD_BLOCKS") ? atoll(getenv("CVX_WGRAD_BLOCKS")) : 2048;
+      long long ns = std::min<long long>(std::max<long long>(1, M / 256), std::max<long long>(1, blk_target / tiles));
       const long long slab_elems = (long long)C * Jtot;
-      ns = std::min(ns, std::max<long long>(1, (8LL << 20) / (slab_elems * 4)));
-      ns = std::min<long long>(ns, 512);
+      static const long long slab_cap_mb = getenv("CVX_SLAB_MB") ? atoll(getenv("CVX_SLAB_MB")) : 8;
+      static const long long ns_cap = getenv("CVX_NSPLIT_CAP") ? atoll(getenv("CVX_NSPLIT_CAP")) : 512;
+      ns = std::min(ns, std::max<long long>(1, (slab_cap_mb << 20) / (slab_elems * 4)));
+      ns = std::min<long long>(ns, ns_cap);
       c.nsplit = (int)ns;
       c.slab_off = slab_total;
       slab_total += ns * slab_elems;
