@@ -14,21 +14,33 @@
 namespace {
 
 __device__ __forceinline__ long long view_off(const ViewDesc& v, long long m, int hw) {
-  long long b = m / hw;
-  long long pix = m - b * hw;
-  return b * v.bstride + pix * v.ld;
+  const unsigned mu = (unsigned)m;  // M < 2^32 (checked on the host): one 32-bit division per row
+  const unsigned b = mu / (unsigned)hw;
+  const unsigned pix = mu - b * (unsigned)hw;
+  return (long long)b * v.bstride + (long long)pix * v.ld;
 }
 
-// sums the CVX_STAT_REPLICAS slabs [R][C][2] for all channels into LDS (fp64 accumulate, fixed order)
+// sums the CVX_STAT_REPLICAS fixed-point slabs [R][C][2] into s0/s1 (LDS).  All 256 threads load slab entries in
+// parallel (one round of independent, coalesced 16-byte loads) and add them with INTEGER LDS atomics: exact and
+// order-independent, and the block pays one memory latency instead of R dependent ones.
 __device__ __forceinline__ void fold_replicas(const long long* part, int C, double* s0, double* s1) {
+  long long* i0 = reinterpret_cast<long long*>(s0);
+  long long* i1 = reinterpret_cast<long long*>(s1);
   for (int c = threadIdx.x; c < C; c += 256) {
-    long long a = 0, b = 0;  // integer sums: exact and order-independent
-#pragma unroll 4
-    for (int r = 0; r < CVX_STAT_REPLICAS; ++r) {
-      const long long* q = part + ((long long)r * C + c) * 2;
-      a += q[0];
-      b += q[1];
-    }
+    i0[c] = 0;
+    i1[c] = 0;
+  }
+  __syncthreads();
+  const int total = CVX_STAT_REPLICAS * C;  // entries of two 64-bit values
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const longlong2 q = *reinterpret_cast<const longlong2*>(part + (long long)e * 2);
+    const int c = e % C;
+    atomicAdd(reinterpret_cast<unsigned long long*>(&i0[c]), (unsigned long long)q.x);
+    atomicAdd(reinterpret_cast<unsigned long long*>(&i1[c]), (unsigned long long)q.y);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const long long a = i0[c], b = i1[c];
     s0[c] = cvx_fix_to_double(a);
     s1[c] = cvx_fix_to_double(b);
   }
@@ -125,44 +137,32 @@ __device__ __forceinline__ void load_coef(const BnCoef& k, int c0, Coef8& sc_sh,
   }
 }
 
-// block-level accumulation of per-thread channel sums: lanes of a wave that share a channel group are first
-// folded with shuffles (when CG divides 64), then one LDS atomic per (wave, channel), then one global atomic per channel
+// block-level accumulation of per-thread channel sums, bit-reproducible: every thread parks its fp32 partials in LDS,
+// NV*C threads then add one column each in fixed row order (no shuffles, no LDS atomics), and the block total goes to
+// a replica slab as one 64-bit fixed-point integer atomic per (channel, value).
 template <int NV>
-__device__ __forceinline__ void block_channel_sums(float (&v)[NV][8], int C, int CG, int cg, bool active, long long* sacc, long long* part) {
-  // sacc: NV*C 64-bit fixed-point accumulators in LDS.  Every addition after the per-thread fp32 partial sum is either
-  // a fixed-order shuffle butterfly or an INTEGER atomic, so the result is bit-reproducible.
-  for (int i = threadIdx.x; i < NV * C; i += 256) sacc[i] = 0;
-  __syncthreads();
-  const bool pow2 = (64 % CG) == 0;
-  if (pow2) {
+__device__ __forceinline__ void block_channel_sums(float (&v)[NV][8], int C, int CG, int cg, bool active, float* sred, long long* part) {
+  const int RP = 256 / CG;
+  if (active) {
+    float* dst = sred + (size_t)threadIdx.x * (NV * 8);
 #pragma unroll
     for (int q = 0; q < NV; ++q)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float x = active ? v[q][i] : 0.f;
-        for (int o = CG; o < 64; o <<= 1) x += __shfl_xor(x, o);
-        v[q][i] = x;
-      }
-  }
-  if (pow2 ? (int)(threadIdx.x & 63) < CG : active) {
-#pragma unroll
-    for (int q = 0; q < NV; ++q)
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        atomicAdd(reinterpret_cast<unsigned long long*>(&sacc[(cg * 8 + i) * NV + q]), (unsigned long long)__float2ll_rn(v[q][i] * CVX_FIX_SCALE));
+      for (int i = 0; i < 8; ++i) dst[q * 8 + i] = v[q][i];
   }
   __syncthreads();
-  // slab layout is [R][C][2]; NV == 1 fills only the first of each pair
-  for (int i = threadIdx.x; i < NV * C; i += 256) {
-    const int c = i / NV, q = i - c * NV;
-    atomicAdd(reinterpret_cast<unsigned long long*>(&part[((long long)(blockIdx.x % CVX_STAT_REPLICAS) * C + c) * 2 + q]),
-              (unsigned long long)sacc[i]);
+  for (int j = threadIdx.x; j < NV * C; j += 256) {
+    const int c = j / NV, q = j - c * NV;
+    const int g = c >> 3, i = c & 7;
+    float acc = 0.f;
+    for (int r = 0; r < RP; ++r) acc += sred[(size_t)(r * CG + g) * (NV * 8) + q * 8 + i];
+    cvx_fix_atomic_add(&part[((long long)(blockIdx.x % CVX_STAT_REPLICAS) * C + c) * 2 + q], acc);
   }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const half_t* y, long long M, int C, int hw, BnCoef k, ViewDesc gout, long long* part,
                                                             int rows_per_block) {
-  __shared__ long long sacc[2 * 512];
+  __shared__ float sacc[256 * 16];
   const int CG = C >> 3;
   const int RP = 256 / CG;
   const int cg = threadIdx.x % CG, r = threadIdx.x / CG;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const half_t* y, long
 
 // column sums of a [M][C] fp16 view (bias gradient of the head's 1x1 output convs)
 __global__ __launch_bounds__(256) void colsum_reduce_kernel(long long M, int C, int hw, ViewDesc g, long long* part, int rows_per_block) {
-  __shared__ long long sacc[512];
+  __shared__ float sacc[256 * 8];
   const int CG = C >> 3;
   const int RP = 256 / CG;
   const int cg = threadIdx.x % CG, r = threadIdx.x / CG;
@@ -281,8 +281,9 @@ int cvx_stream_rows_per_block(long long M, int C, int kb_per_block) {
 }
 static int blocks_for(long long M, int rows) { return (int)((M + rows - 1) / rows); }
 
-static int check_c(int C) {
+static int check_c(int C, long long M = 0) {
   CVX_CHECK(C % 8 == 0 && C >= 8 && C <= 512, "bn_act: C must be a multiple of 8 in [8, 512]");
+  CVX_CHECK(M < (1LL << 32), "bn_act: more than 2^32 rows");
   return 0;
 }
 
@@ -294,22 +295,22 @@ int cvx_bn_fold(int n, const float* gamma, const float* beta, const float* rmean
 }
 int cvx_bn_silu_apply(const half_t* y, long long M, int C, int hw, const BnTrainArgs& a, const ViewDesc& out, const ViewDesc& res,
                       hipStream_t st) {
-  CVX_TRY(check_c(C));
+  CVX_TRY(check_c(C, M));
   int rows = cvx_stream_rows_per_block(M, C, 16);
   hipLaunchKernelGGL(bn_silu_apply_kernel, dim3(blocks_for(M, rows)), dim3(256), 0, st, y, M, C, hw, a, out, res, rows);
   CVX_HIP(hipGetLastError());
   return 0;
 }
 int cvx_bn_bwd_reduce(const half_t* y, long long M, int C, int hw, const BnCoef& k, const ViewDesc& gout, long long* part, hipStream_t st) {
-  CVX_TRY(check_c(C));
-  int rows = cvx_stream_rows_per_block(M, C, 32);
+  CVX_TRY(check_c(C, M));
+  int rows = cvx_stream_rows_per_block(M, C, 64);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks_for(M, rows)), dim3(256), 0, st, y, M, C, hw, k, gout, part, rows);
   CVX_HIP(hipGetLastError());
   return 0;
 }
 int cvx_bn_bwd_apply(const half_t* y, long long M, int C, int hw, const BnCoef& k, const long long* part, float inv_scale, float* dgamma,
                      float* dbeta, const ViewDesc& gout, half_t* dy, const ViewDesc& gres, int res_accumulate, hipStream_t st) {
-  CVX_TRY(check_c(C));
+  CVX_TRY(check_c(C, M));
   int rows = cvx_stream_rows_per_block(M, C, 16);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(M, rows)), dim3(256), 0, st, y, M, C, hw, k, part, inv_scale, dgamma, dbeta, gout,
                      dy, gres, res_accumulate, rows);
@@ -317,7 +318,7 @@ int cvx_bn_bwd_apply(const half_t* y, long long M, int C, int hw, const BnCoef& 
   return 0;
 }
 int cvx_colsum(long long M, int C, int hw, const ViewDesc& g, long long* part, float inv_scale, float* dbias, hipStream_t st) {
-  CVX_TRY(check_c(C));
+  CVX_TRY(check_c(C, M));
   int rows = cvx_stream_rows_per_block(M, C, 32);
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3(blocks_for(M, rows)), dim3(256), 0, st, M, C, hw, g, part, rows);
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3(1), dim3(256), 0, st, part, C, inv_scale, dbias);

@@ -54,7 +54,7 @@ struct ConvParams {
   int stats_replicas;
   const half_t* zeros; // >= 16 zero bytes in device memory: DMA source for padding (second-generation kernel); null -> generation one
 };
-#define CVX_STAT_REPLICAS 32
+#define CVX_STAT_REPLICAS 16
 
 // Launches the kernel; returns the number of M-blocks (= stats partial count) through *m_blocks.
 int cvx_conv_igemm_launch(const ConvParams& p, hipStream_t stream, int* m_blocks);

@@ -94,10 +94,11 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
     if (row < BM) {
       long long m = m_base + row;
       if (m < M) {
-        int ow2 = (int)(m % p.OW2);
-        long long t = m / p.OW2;
-        int oh2 = (int)(t % p.OH2);
-        int b = (int)(t / p.OH2);
+        const unsigned mu = (unsigned)m;  // M < 2^31 (checked by the launcher): 32-bit divisions
+        const unsigned tq = mu / (unsigned)p.OW2;
+        int ow2 = (int)(mu - tq * (unsigned)p.OW2);
+        int b = (int)(tq / (unsigned)p.OH2);
+        int oh2 = (int)(tq - (unsigned)b * (unsigned)p.OH2);
         ih0[q] = oh2 * p.IS;
         iw0[q] = ow2 * p.IS;
         src_base[q] = p.in + (long long)b * p.in_bstride;
@@ -177,11 +178,11 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
   for (int i = 0; i < MT; ++i) {
     long long m = m_base + (wm * MT + i) * 16 + fr;
     pvalid[i] = m < M;
-    long long mm = pvalid[i] ? m : 0;
-    int ow2 = (int)(mm % p.OW2);
-    long long t = mm / p.OW2;
-    int oh2 = (int)(t % p.OH2);
-    int b = (int)(t / p.OH2);
+    const unsigned mu = pvalid[i] ? (unsigned)m : 0u;
+    const unsigned tq = mu / (unsigned)p.OW2;
+    int ow2 = (int)(mu - tq * (unsigned)p.OW2);
+    int b = (int)(tq / (unsigned)p.OH2);
+    int oh2 = (int)(tq - (unsigned)b * (unsigned)p.OH2);
     long long pix = (long long)(oh2 * p.OS + p.oph) * p.OWr + (ow2 * p.OS + p.opw);
     out_off[i] = (long long)b * p.out_bstride + pix * p.out_ld;
     res_off[i] = (long long)b * p.res_bstride + pix * p.res_ld;
@@ -314,6 +315,7 @@ int launch_m4(int NT, const ConvParams& p, hipStream_t st, dim3 grid) {  // 4 wa
 int cvx_conv_igemm_dma_launch(const ConvParams& p, hipStream_t stream) {
   CVX_CHECK(p.zeros && ((uintptr_t)p.zeros % 16) == 0, "conv_igemm_dma: needs a 16-byte aligned zero page");
   const long long M = (long long)p.B * p.OH2 * p.OW2;
+  CVX_CHECK(M < (1LL << 31), "conv_igemm_dma: more than 2^31 output pixels per launch");
   const int tiles = (p.Cout + 15) / 16;
   static const int allowed[] = {1, 2, 3, 4, 5, 6, 8};
   // tile height by problem size (pixels): big M -> 128 rows; below t128 -> 64 rows; below t64 -> 32 rows

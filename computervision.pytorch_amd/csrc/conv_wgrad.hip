@@ -73,37 +73,55 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, lo
     for (int b = 0; b < TJ; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
 
   const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  constexpr int DN = (PK + DSLOTS - 1) / DSLOTS, XN = (PK + XSLOTS - 1) / XSLOTS;
+  uint4 dreg[DN], xreg[XN];
+  // global -> registers for one 64-pixel chunk (issued one chunk ahead of the MFMAs: software prefetch)
+  auto fetch = [&](long long mc) {
+#pragma unroll
+    for (int k = 0; k < DN; ++k) {
+      const int pp = dslot + k * DSLOTS;
+      const long long m = mc + pp;
+      uint4 v = zero4;
+      if (dslot < DSLOTS && pp < PK && dcol_ok && m < m_end) {
+        const unsigned mu = (unsigned)m, b = mu / (unsigned)ohw, pix = mu - b * (unsigned)ohw;
+        v = *reinterpret_cast<const uint4*>(p.dy + (long long)b * p.dy_bstride + (long long)pix * p.dy_ld + co0 + dcg * 8);
+      }
+      dreg[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < XN; ++k) {
+      const int pp = xslot + k * XSLOTS;
+      const long long m = mc + pp;
+      uint4 v = zero4;
+      if (xslot < XSLOTS && pp < PK && xcol_ok && m < m_end) {
+        const unsigned mu = (unsigned)m, tq = mu / (unsigned)p.OW;
+        int ow = (int)(mu - tq * (unsigned)p.OW);
+        int b = (int)(tq / (unsigned)p.OH);
+        int oh = (int)(tq - (unsigned)b * (unsigned)p.OH);
+        int ih = oh * p.stride + xdh, iw = ow * p.stride + xdw;
+        if ((unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW)
+          v = *reinterpret_cast<const uint4*>(p.x + (long long)b * p.x_bstride + ((long long)ih * p.IW + iw) * p.x_ld + xci);
+      }
+      xreg[k] = v;
+    }
+  };
+  auto park = [&]() {  // registers -> LDS tiles
+#pragma unroll
+    for (int k = 0; k < DN; ++k) {
+      const int pp = dslot + k * DSLOTS;
+      if (dslot < DSLOTS && pp < PK) *reinterpret_cast<uint4*>(&sD[pp * SD + dcg * 8]) = dreg[k];
+    }
+#pragma unroll
+    for (int k = 0; k < XN; ++k) {
+      const int pp = xslot + k * XSLOTS;
+      if (xslot < XSLOTS && pp < PK) *reinterpret_cast<uint4*>(&sX[pp * SX + xcg * 8]) = xreg[k];
+    }
+  };
+  if (m_begin < m_end) fetch(m_begin);
   for (long long mc = m_begin; mc < m_end; mc += PK) {
-    // stage dY[PK][CO_B]
-    if (dslot < DSLOTS) {
-      for (int pp = dslot; pp < PK; pp += DSLOTS) {
-        long long m = mc + pp;
-        uint4 v = zero4;
-        if (dcol_ok && m < m_end) {
-          long long b = m / ohw, pix = m - b * ohw;
-          v = *reinterpret_cast<const uint4*>(p.dy + b * p.dy_bstride + pix * p.dy_ld + co0 + dcg * 8);
-        }
-        *reinterpret_cast<uint4*>(&sD[pp * SD + dcg * 8]) = v;
-      }
-    }
-    // stage Xcol[PK][J_B]  (im2col on the fly, zero outside the image)
-    if (xslot < XSLOTS) {
-      for (int pp = xslot; pp < PK; pp += XSLOTS) {
-        long long m = mc + pp;
-        uint4 v = zero4;
-        if (xcol_ok && m < m_end) {
-          int ow = (int)(m % p.OW);
-          long long t = m / p.OW;
-          int oh = (int)(t % p.OH);
-          int b = (int)(t / p.OH);
-          int ih = oh * p.stride + xdh, iw = ow * p.stride + xdw;
-          if ((unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW)
-            v = *reinterpret_cast<const uint4*>(p.x + (long long)b * p.x_bstride + ((long long)ih * p.IW + iw) * p.x_ld + xci);
-        }
-        *reinterpret_cast<uint4*>(&sX[pp * SX + xcg * 8]) = v;
-      }
-    }
+    park();
     __syncthreads();
+    if (mc + PK < m_end) fetch(mc + PK);  // in flight while the MFMAs below run
 #pragma unroll
     for (int ks = 0; ks < PK / 32; ++ks) {
       h8 fa[TI], fb[TJ];
