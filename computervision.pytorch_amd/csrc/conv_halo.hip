@@ -1,0 +1,272 @@
+// 3x3 / stride-1 convolution with the input HALO TILE resident in LDS (gfx950).
+//
+// The generic implicit-GEMM kernels re-gather every input pixel once per tap (9x) through the L2->LDS DMA path,
+// and that traffic -- not MFMA -- bounds them.  Here a workgroup owns a TH x 16 output patch of one image:
+//   * the (TH+2) x 18 x Cin input patch is DMA'd into LDS ONCE (1 KiB pieces, zero page for the image border);
+//   * the K loop streams only the weights ([BN][32] per K-step, 2-stage DMA ring, counted vmcnt, raw s_barrier);
+//   * the MFMA pixel operand of K-step (tap, channel chunk) is read straight out of the patch at the tap's
+//     (dh, dw) offset: lane = pixel column, so a 16-pixel row segment is one operand sub-tile;
+//   * patch layout [pixel][Cin/8 chunks of 16 B], chunk index XOR-swizzled by the pixel column so that 16
+//     consecutive columns reading one logical chunk spread over all banks (<= 2-way under the gfx950
+//     ds_read_b128 lane groups, checked by script); the swizzle is applied on the DMA source side.
+// Used for the forward and the stride-1 data gradient (flipped taps, transposed weights) of every 3x3 conv whose
+// gathered channel count is 16, 32, 64 or 128 -- the C2f bottlenecks and most of the Detect head, ~75 % of the MACs.
+#include <cstdlib>
+
+#include "conv_tile_common.h"
+
+namespace {
+using namespace cvx_tile;
+
+constexpr int HW = 18;  // halo patch width: 16 output columns + 2
+
+__device__ __forceinline__ int col_swz(int P, int col) {
+  // P = 16-byte chunks per pixel (2, 4, 8, 16): spreads 16 consecutive columns of one logical chunk over 64 banks
+  return P == 2 ? (col >> 3) & 1 : P == 4 ? (col >> 2) & 3 : P == 8 ? (col >> 1) & 7 : col & 15;
+}
+
+template <int WM, int WN, int MT, int NTW, int BST>
+struct HaloGeom {
+  static constexpr int TH = WM * MT;              // output rows per workgroup
+  static constexpr int BN = 16 * NTW * WN;        // output channels per workgroup
+  static constexpr int PB = (BN + 63) / 64;       // weight DMA pieces per wave per K-step
+  static constexpr int BSTAGES = BST;
+  static constexpr int BSTAGE_HALVES = (BN + 16) * BK;  // + one 16-row dump piece
+  static constexpr int TAP_BYTES = 16 * (int)sizeof(ConvTap);
+  static constexpr int STAT_BYTES = WM * BN * 2 * 4;
+  static int patch_pieces(int cin) { return ((TH + 2) * HW * (cin / 8) + 63) / 64; }
+  // patch (+1 dump piece) | weight ring | taps | stat scratch
+  static int lds_bytes(int cin) { return (patch_pieces(cin) + 1) * 1024 + BSTAGES * BSTAGE_HALVES * 2 + TAP_BYTES + STAT_BYTES; }
+};
+
+template <int WM, int WN, int MT, int NTW, int BST>
+__global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p, int tiles_x, int tiles_y, int log2cin) {
+  using G = HaloGeom<WM, WN, MT, NTW, BST>;
+  constexpr int TH = G::TH, BN = G::BN, PB = G::PB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int Cin = 1 << log2cin;
+  const int P = Cin >> 3;
+  const int npieces = ((TH + 2) * HW * P + 63) >> 6;
+  half_t* patch = reinterpret_cast<half_t*>(smem);
+  half_t* patch_dump = patch + npieces * 512;
+  half_t* ring = patch_dump + 512;
+  ConvTap* sTap = reinterpret_cast<ConvTap*>(reinterpret_cast<unsigned char*>(ring) + G::BSTAGES * G::BSTAGE_HALVES * 2);
+  float* sStat = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(sTap) + G::TAP_BYTES);
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / WN, wn = wave % WN;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int nblk = blockIdx.y;
+  int t = blockIdx.x;
+  const int tx = t % tiles_x;
+  t /= tiles_x;
+  const int ty = t % tiles_y;
+  const int b = t / tiles_y;
+  const int y0 = ty * TH, x0 = tx * 16;
+  const int H = p.IH, W = p.IW;
+
+  if (tid < p.ntaps) sTap[tid] = p.taps[tid];
+  __syncthreads();  // tap table visible -- before any DMA is issued (a __syncthreads later would drain the DMA queue)
+
+  // ---- 1. input patch -> LDS, once.  Every wave issues the same number of pieces (surplus ones hit the dump) ----
+  const half_t* img = p.in + (long long)b * p.in_bstride;
+  const int per_wave = (npieces + 3) >> 2;
+  const int units = (TH + 2) * HW * P;
+  for (int k = 0; k < per_wave; ++k) {
+    const int piece = k * 4 + wave;
+    const int u = piece * 64 + lane;
+    const half_t* g = p.zeros;
+    if (u < units) {
+      const int hp = u >> (log2cin - 3), phys = u & (P - 1);
+      const int hy = hp / HW, hx = hp - hy * HW;
+      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+        g = img + ((long long)iy * W + ix) * p.in_ld + ((phys ^ col_swz(P, hx)) << 3);
+    }
+    half_t* dst = piece < npieces ? patch + piece * 512 : patch_dump;
+    __builtin_amdgcn_global_load_lds((gbl_void_ptr)g, (lds_void_ptr)dst, 16, 0, 0);
+  }
+
+  // ---- 2. weight ring ----
+  const int r16 = lane >> 2;
+  const int kg = (lane & 3) ^ ((r16 >> 1) & 3);
+  const half_t* wrow[PB];
+#pragma unroll
+  for (int q = 0; q < PB; ++q) {
+    const int row = q * 64 + wave * 16 + r16;
+    const int n = nblk * BN + row;
+    wrow[q] = (row < BN && n < p.Cout) ? p.wt + (long long)n * p.wt_ld : nullptr;
+  }
+  int cb = kg * 8, tapb = 0;  // weight-side (tap, channel) of this lane's k-group
+  while (cb >= Cin) {
+    cb -= Cin;
+    ++tapb;
+  }
+  const int nsteps = (p.ntaps * Cin + BK - 1) / BK;
+
+  auto issue_w = [&](int stage) {
+    const bool kvalid = tapb < p.ntaps;
+    const int wtap = sTap[kvalid ? tapb : 0].wtap;
+    half_t* sb = ring + stage * G::BSTAGE_HALVES;
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+      int row0 = q * 64 + wave * 16;
+      if (row0 >= BN) row0 = BN;  // dump piece
+      const half_t* g = (kvalid && wrow[q]) ? wrow[q] + wtap * Cin + cb : p.zeros;
+      __builtin_amdgcn_global_load_lds((gbl_void_ptr)g, (lds_void_ptr)(sb + row0 * BK), 16, 0, 0);
+    }
+    cb += BK;
+    while (cb >= Cin) {
+      cb -= Cin;
+      ++tapb;
+    }
+  };
+
+  f4 acc[MT][NTW];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  // column swizzles of the three possible tap columns (patch column = fr + 1 + dw); named scalars, not an array:
+  // a runtime-indexed register array would be demoted to scratch memory
+  const int swz_m = col_swz(P, fr), swz_0 = col_swz(P, fr + 1), swz_p = col_swz(P, fr + 2);
+
+  int issued = 0;
+  for (; issued < BST - 1 && issued < nsteps; ++issued) issue_w(issued % BST);
+  for (int s = 0; s < nsteps; ++s) {
+    // the patch pieces are older than every weight piece, so the wait that lands weight stage s lands them too
+    wait_steps_ahead<PB, BST - 2>(issued - 1 - s);
+    __builtin_amdgcn_s_barrier();
+    if (issued < nsteps) {
+      issue_w(issued % BST);
+      ++issued;
+    }
+    // pixel operand: k-group 4s+fq -> (tap, channel chunk) -> patch address
+    const int k0 = (4 * s + fq) << 3;
+    int tp = k0 >> log2cin;
+    const int chunk = (k0 & (Cin - 1)) >> 3;
+    if (tp >= p.ntaps) tp = 0;  // weights of the K tail are zero; any valid address will do
+    const ConvTap td = sTap[tp];
+    const half_t* sb = ring + (s % BST) * G::BSTAGE_HALVES;
+    h8 xa[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int hrow = wm * MT + i + 1 + td.dh;
+      const int col = fr + 1 + td.dw;
+      const int sw = td.dw < 0 ? swz_m : (td.dw == 0 ? swz_0 : swz_p);
+      xa[i] = *reinterpret_cast<const h8*>(patch + (((hrow * HW + col) << (log2cin - 3)) + (chunk ^ sw)) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      h8 wb = *reinterpret_cast<const h8*>(&sb[lds_row_off((wn * NTW + j) * 16 + fr, fq)]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb, xa[i], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- 3. epilogue ----
+  long long out_off[MT], res_off[MT];
+  bool pvalid[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int oy = y0 + wm * MT + i, ox = x0 + fr;
+    pvalid[i] = oy < H && ox < W;
+    const long long pix = pvalid[i] ? (long long)oy * W + ox : 0;
+    out_off[i] = (long long)b * p.out_bstride + pix * p.out_ld;
+    res_off[i] = (long long)b * p.res_bstride + pix * p.res_ld;
+  }
+  epilogue<WM, WN, MT, NTW>(p, acc, out_off, res_off, pvalid, wm, wn, fr, fq, nblk, sStat, tid);
+}
+
+template <int WM, int WN, int MT, int NTW, int BST>
+int launch_halo_st(const ConvParams& p, hipStream_t stream, int gy, int log2cin) {
+  using G = HaloGeom<WM, WN, MT, NTW, BST>;
+  const int tiles_x = (p.IW + 15) / 16, tiles_y = (p.IH + G::TH - 1) / G::TH;
+  const int lds = G::lds_bytes(p.Cin);
+  static int attr_bytes = 0;
+  if (lds > attr_bytes) {
+    CVX_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<WM, WN, MT, NTW, BST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_bytes = lds;
+  }
+  dim3 grid(tiles_x * tiles_y * p.B, gy);
+  hipLaunchKernelGGL((conv_halo_kernel<WM, WN, MT, NTW, BST>), grid, dim3(256), lds, stream, p, tiles_x, tiles_y, log2cin);
+  return 0;
+}
+
+template <int WM, int WN, int MT, int NTW>
+int launch_halo(const ConvParams& p, hipStream_t stream, int gy, int log2cin) {
+  static const int st = getenv("CVX_HALO_BST") ? atoi(getenv("CVX_HALO_BST")) : 2;
+  if (st >= 4) return launch_halo_st<WM, WN, MT, NTW, 4>(p, stream, gy, log2cin);
+  if (st == 3) return launch_halo_st<WM, WN, MT, NTW, 3>(p, stream, gy, log2cin);
+  return launch_halo_st<WM, WN, MT, NTW, 2>(p, stream, gy, log2cin);
+}
+
+template <int WM, int MT>
+int launch_m(int NT, const ConvParams& p, hipStream_t st, int gy, int l2) {
+  switch (NT) {
+    case 1: return launch_halo<WM, 1, MT, 1>(p, st, gy, l2);
+    case 2: return launch_halo<WM, 1, MT, 2>(p, st, gy, l2);
+    case 3: return launch_halo<WM, 1, MT, 3>(p, st, gy, l2);
+    case 4: return launch_halo<WM, 1, MT, 4>(p, st, gy, l2);
+    case 5: return launch_halo<WM, 1, MT, 5>(p, st, gy, l2);
+    case 6: return launch_halo<WM, 1, MT, 6>(p, st, gy, l2);
+    default: return launch_halo<WM, 1, MT, 8>(p, st, gy, l2);
+  }
+}
+
+}  // namespace
+
+bool cvx_conv_halo_supported(const ConvParams& p) {
+  static const bool off = getenv("CVX_NO_HALO") != nullptr;
+  if (off || !p.zeros) return false;
+  if (!(p.Cin == 16 || p.Cin == 32 || p.Cin == 64 || p.Cin == 128)) return false;
+  if (p.IS != 1 || p.OS != 1 || p.oph != 0 || p.opw != 0) return false;
+  if (p.OH2 != p.IH || p.OW2 != p.IW || p.OWr != p.IW) return false;
+  if (p.ntaps != 9) return false;
+  return p.halo_taps_ok != 0;  // all |dh|,|dw| <= 1, verified on the host where the tap table was built
+}
+
+int cvx_conv_halo_launch(const ConvParams& p, hipStream_t stream) {
+  int l2 = 0;
+  while ((1 << l2) < p.Cin) ++l2;
+  const int tiles = (p.Cout + 15) / 16;
+  const long long hw = (long long)p.IH * p.IW;
+  if (hw >= 80 * 80 || hw * p.B >= 128 * 1024) {  // TH = 8
+    int gy = (tiles + 7) / 8, want = (tiles + gy - 1) / gy;
+    static const int allowed[] = {1, 2, 3, 4, 5, 6, 8};
+    int NT = 8;
+    for (int a : allowed)
+      if (a >= want) {
+        NT = a;
+        break;
+      }
+    gy = (tiles + NT - 1) / NT;
+    CVX_TRY((launch_m<4, 2>(NT, p, stream, gy, l2)));
+  } else if (hw >= 40 * 40) {  // TH = 4
+    int gy = (tiles + 7) / 8, want = (tiles + gy - 1) / gy;
+    static const int allowed[] = {1, 2, 3, 4, 5, 6, 8};
+    int NT = 8;
+    for (int a : allowed)
+      if (a >= want) {
+        NT = a;
+        break;
+      }
+    gy = (tiles + NT - 1) / NT;
+    CVX_TRY((launch_m<4, 1>(NT, p, stream, gy, l2)));
+  } else {  // TH = 2, 2x2 waves, BN = 32 * NTW
+    int pairs = (tiles + 1) / 2;
+    int gy = (pairs + 3) / 4;
+    int ntw = (pairs + gy - 1) / gy;
+    gy = (pairs + ntw - 1) / ntw;
+    switch (ntw) {
+      case 1: CVX_TRY((launch_halo<2, 2, 1, 1>(p, stream, gy, l2))); break;
+      case 2: CVX_TRY((launch_halo<2, 2, 1, 2>(p, stream, gy, l2))); break;
+      case 3: CVX_TRY((launch_halo<2, 2, 1, 3>(p, stream, gy, l2))); break;
+      default: CVX_TRY((launch_halo<2, 2, 1, 4>(p, stream, gy, l2))); break;
+    }
+  }
+  CVX_HIP(hipGetLastError());
+  return 0;
+}

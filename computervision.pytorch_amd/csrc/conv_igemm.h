@@ -53,6 +53,7 @@ struct ConvParams {
   long long* stats;    // RAW_STATS: [stats_replicas][Cout][2] fixed-point (cvx_fix_atomic_add), must be zero on entry
   int stats_replicas;
   const half_t* zeros; // >= 16 zero bytes in device memory: DMA source for padding (second-generation kernel); null -> generation one
+  int halo_taps_ok;    // 1 when the tap table is a 3x3 neighbourhood (all |dh|,|dw| <= 1): the LDS halo-tile kernel may be used
 };
 #define CVX_STAT_REPLICAS 16
 
@@ -62,6 +63,9 @@ int cvx_conv_igemm_launch(const ConvParams& p, hipStream_t stream, int* m_blocks
 int cvx_conv_igemm_mblocks(long long M);
 // second generation (LDS-DMA ring, conv_igemm_dma.hip); cvx_conv_igemm_launch forwards to it when p.zeros is set
 int cvx_conv_igemm_dma_launch(const ConvParams& p, hipStream_t stream);
+// 3x3 stride-1 halo-tile kernel (conv_halo.hip)
+bool cvx_conv_halo_supported(const ConvParams& p);
+int cvx_conv_halo_launch(const ConvParams& p, hipStream_t stream);
 
 // Weight gradient: dW[co][tap][ci] partial sums over a slice of the pixels, written as fp32 slabs.
 struct WgradParams {

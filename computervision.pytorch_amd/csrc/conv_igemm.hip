@@ -245,6 +245,7 @@ int cvx_conv_igemm_launch(const ConvParams& p, hipStream_t stream, int* m_blocks
   static const bool force_v1 = getenv("CVX_CONV_V1") != nullptr;
   if (p.zeros && !force_v1) {
     if (m_blocks) *m_blocks = 0;
+    if (cvx_conv_halo_supported(p)) return cvx_conv_halo_launch(p, stream);
     return cvx_conv_igemm_dma_launch(p, stream);
   }
   const int tiles = (p.Cout + 15) / 16;

@@ -435,6 +435,7 @@ void fill_conv_fwd(const cvx_engine* e, int i, int B, ConvParams* cp) {
   cp->ntaps = c.ntaps;
   cp->taps = c.taps_fwd;
   cp->zeros = e->zero_page;
+  cp->halo_taps_ok = (o.k == 3 && o.dil == 1 && o.pad == 1) ? 1 : 0;
 }
 
 }  // namespace
@@ -712,6 +713,7 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
         cp.taps = dc.taps;
         cp.epi = CVX_EPI_PLAIN;
         cp.zeros = e->zero_page;
+        cp.halo_taps_ok = (o.k == 3 && o.dil == 1 && o.pad == 1 && o.stride == 1) ? 1 : 0;
         cp.accumulate = c.in_accum;
         cp.out16 = gin.p;
         cp.out_ld = gin.ld;
@@ -859,6 +861,7 @@ extern "C" int cvx_conv2d_nhwc(const void* x_f16, int32_t batch, int32_t ih, int
   cp.ntaps = k * k;
   cp.taps = dt;
   cp.zeros = zeros_after(dt, taps.size());
+  cp.halo_taps_ok = (k == 3 && dil == 1 && pad == 1) ? 1 : 0;
   cp.out_ld = cout;
   cp.out_bstride = (long long)oh * ow * cout;
   if (mode == 0) {
@@ -925,6 +928,7 @@ extern "C" int cvx_conv2d_dgrad_nhwc(const void* dy_f16, int32_t batch, int32_t 
       cp.ntaps = (int)taps.size();
       cp.taps = dt;
       cp.zeros = zeros_after(dt, taps.size());
+      cp.halo_taps_ok = (k == 3 && dil == 1 && pad == 1 && stride == 1) ? 1 : 0;
       cp.epi = CVX_EPI_PLAIN;
       cp.out16 = (half_t*)dx_f16;
       cp.out_ld = cin;
