@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--model", default="n")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", type=int, default=-1, help="1: replay the step as a hipGraph (N=1 only); 0: eager; -1: default")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -77,7 +78,9 @@ def main():
     torch.manual_seed(0)
     model = Yolo8(args.model, 80, loss_scale=cfg.engine.loss_scale).to(dev).train()
     crit = V8DetectionLoss(cfg, model)
-    step = FusedTrainStep(model, crit, FlatAdam(model, lr=cfg.train.initial_lr), n_buckets=cfg.engine.allreduce_buckets)
+    use_graph = world == 1 and args.graph != 0      # default: hipGraph replay on one GPU, eager under torch.distributed
+    step = FusedTrainStep(model, crit, FlatAdam(model, lr=cfg.train.initial_lr), n_buckets=cfg.engine.allreduce_buckets,
+                          use_graph=use_graph)
     B = args.batch
     x = synth.images(B, 640, 640, seed=1 + rank).to(dev)
     batch = synth.targets(B, seed=2 + rank)
@@ -88,16 +91,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 2 if use_graph else 0)):
         items = step(x, batch)
     eng = model._last_engine
     sync()
-    eng.profile(True)
+    if not use_graph:
+        eng.profile(True)           # per-kernel-class HIP events on the launch stream, over the timed region itself
     t0 = time.perf_counter()
     for _ in range(args.steps):
         items = step(x, batch)
     sync()
     elapsed = time.perf_counter() - t0
+    prof_steps = args.steps
+    if use_graph:
+        # a replayed hipGraph carries no per-kernel events: time the kernel classes on eager steps right after
+        step.use_graph = False
+        prof_steps = 5
+        step(x, batch)
+        sync()
+        eng.profile(True)
+        for _ in range(prof_steps):
+            step(x, batch)
+        sync()
     prof = eng.profile_read()
     eng.profile(False)
     if world > 1:
@@ -119,7 +134,7 @@ def main():
             if v["launches"] == 0:
                 continue
             sec = v["ms"] * 1e-3
-            classes[k] = {"ms_per_step": round(v["ms"] / args.steps, 4), "launches_per_step": v["launches"] // args.steps,
+            classes[k] = {"ms_per_step": round(v["ms"] / prof_steps, 4), "launches_per_step": v["launches"] // prof_steps,
                           "tflops": round(v["flops"] / sec / 1e12, 2) if v["flops"] else None,
                           "algorithmic_gbs": round(v["bytes"] / sec / 1e9, 1)}
         out = {
@@ -127,12 +142,13 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"YOLOv8-{args.model} train step (fwd + v8 loss + bwd + Adam), batch {B}/GPU, 640x640, nc=80, random init",
-                       "global_batch": B * world, "parallelism": f"dp{world}", "loss_scale": cfg.engine.loss_scale},
+                       "global_batch": B * world, "parallelism": f"dp{world}", "loss_scale": cfg.engine.loss_scale,
+                       "launch": "hipGraph replay" if use_graph else "eager"},
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (forward + data-gradient launches)",
                          "achieved": round(achieved, 3), "peak": MFMA_FP16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_FP16_PEAK_TFLOPS, 5), "traffic": None,
-                         "avg_launch_us": round(conv_ms * 1e3 / max(conv_launches, 1), 3), "launches_per_step": conv_launches // args.steps,
-                         "algorithmic_flops_per_step": conv_fl / args.steps},
+                         "avg_launch_us": round(conv_ms * 1e3 / max(conv_launches, 1), 3), "launches_per_step": conv_launches // prof_steps,
+                         "algorithmic_flops_per_step": conv_fl / prof_steps},
             "whole_step": {"train_tflops": round(value / world * TRAIN_GFLOP_PER_IMG / 1e3, 3),
                            "frac_of_mfma_peak": round(value / world * TRAIN_GFLOP_PER_IMG / 1e3 / MFMA_FP16_PEAK_TFLOPS, 5)},
             "kernel_classes": classes,

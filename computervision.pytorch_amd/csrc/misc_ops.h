@@ -48,5 +48,8 @@ int cvx_reduce_slabs(const float* slabs, float* grads, float inv_scale, const Sl
 // when *found_inf != 0; zeroes the gradient arena afterwards when zero_grad != 0.
 int cvx_adam(float* p, float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step, const int* found_inf,
              int zero_grad, hipStream_t st);
+// same update with the step state on the device (state[0]=lr, [1]=step, [2],[3] derived): replayable from a hipGraph
+int cvx_adam_dev(float* p, float* g, float* m, float* v, long long n, float b1, float b2, float eps, float* state, const int* found_inf,
+                 int zero_grad, hipStream_t st);
 // sets *found_inf = 1 if any gradient is non-finite
 int cvx_check_finite_launch(const float* g, long long n, int* found_inf, hipStream_t st);

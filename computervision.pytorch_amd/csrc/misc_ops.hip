@@ -224,9 +224,22 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* slabs, f
 }
 
 // ---- Adam ---------------------------------------------------------------------------------------
+// state[0] = lr (host-written), state[1] = step count, state[2] = lr/(1-b1^t), state[3] = 1/sqrt(1-b2^t)
+__global__ void adam_advance_kernel(float* state, float b1, float b2, const int* found_inf) {
+  if (found_inf && *found_inf != 0) return;  // a skipped step does not advance the bias correction
+  const float t = state[1] + 1.f;
+  state[1] = t;
+  state[2] = state[0] / (1.f - powf(b1, t));
+  state[3] = rsqrtf(1.f - powf(b2, t));
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* p, float* g, float* m, float* v, long long n, float lr_over_bc1, float b1, float b2,
-                                                   float eps, float inv_sqrt_bc2, const int* found_inf, int zero_grad) {
+                                                   float eps, float inv_sqrt_bc2, const int* found_inf, int zero_grad, const float* state) {
   const bool skip = found_inf && *found_inf != 0;
+  if (state) {  // device-resident step state (hipGraph replay: no host-side arguments change between steps)
+    lr_over_bc1 = state[2];
+    inv_sqrt_bc2 = state[3];
+  }
   long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= n) return;
   if (i + 4 <= n) {
@@ -322,7 +335,13 @@ int cvx_adam(float* p, float* g, float* m, float* v, long long n, float lr, floa
              int zero_grad, hipStream_t st) {
   CVX_CHECK(step >= 1, "adam: step starts at 1");
   double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
-  return launch1d(adam_kernel, (n + 3) / 4, st, p, g, m, v, n, (float)(lr / bc1), b1, b2, eps, (float)(1.0 / sqrt(bc2)), found_inf, zero_grad);
+  return launch1d(adam_kernel, (n + 3) / 4, st, p, g, m, v, n, (float)(lr / bc1), b1, b2, eps, (float)(1.0 / sqrt(bc2)), found_inf, zero_grad,
+                  (const float*)nullptr);
+}
+int cvx_adam_dev(float* p, float* g, float* m, float* v, long long n, float b1, float b2, float eps, float* state, const int* found_inf,
+                 int zero_grad, hipStream_t st) {
+  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, st, state, b1, b2, found_inf);
+  return launch1d(adam_kernel, (n + 3) / 4, st, p, g, m, v, n, 0.f, b1, b2, eps, 0.f, found_inf, zero_grad, (const float*)state);
 }
 int cvx_check_finite_launch(const float* g, long long n, int* found_inf, hipStream_t st) {
   if (n <= 0) return 0;

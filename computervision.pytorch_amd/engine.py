@@ -55,11 +55,20 @@ class Engine:
         no = self.graph.bufs[self.graph.pred_buf][2]
         if pred is None:
             pred = torch.empty(b, self.graph.anchors, no, device=images.device, dtype=torch.float32)
+        self._use_current_stream()
         L.check(self.lib.cvx_engine_forward(self.handle, L.ptr(images), b, 1 if training else 0, L.ptr(pred)), "cvx_engine_forward")
         return pred
 
+    def _use_current_stream(self):
+        """Enqueue on torch's current stream of this device (it may be a stream under hipGraph capture)."""
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        if s != getattr(self, "_stream", None):
+            L.check(self.lib.cvx_engine_set_stream(self.handle, C.c_void_p(s)), "cvx_engine_set_stream")
+            self._stream = s
+
     def backward(self, dpred_f16: torch.Tensor, loss_scale: float):
         assert dpred_f16.dtype == torch.float16 and dpred_f16.is_contiguous()
+        self._use_current_stream()
         L.check(self.lib.cvx_engine_backward(self.handle, L.ptr(dpred_f16), float(loss_scale)), "cvx_engine_backward")
 
     def read_buffer(self, buf: int, batch: int, grad: bool = False) -> torch.Tensor:
@@ -137,6 +146,14 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, lr, betas, eps, step, found_in
     _need_gpu(params, "params")
     L.check(lib.cvx_adam_step(L.ptr(params), L.ptr(grads), L.ptr(exp_avg), L.ptr(exp_avg_sq), params.numel(), lr, betas[0], betas[1], eps,
                               step, L.ptr(found_inf), 1 if zero_grad else 0, L.stream_ptr(params.device)), "cvx_adam_step")
+
+
+def adam_step_dev(params, grads, exp_avg, exp_avg_sq, betas, eps, state, found_inf=None, zero_grad=True):
+    """Adam with the step state on the device (state = [lr, step, lr/bc1, 1/sqrt(bc2)]): graph-replayable."""
+    lib = L.load()
+    _need_gpu(params, "params")
+    L.check(lib.cvx_adam_step_dev(L.ptr(params), L.ptr(grads), L.ptr(exp_avg), L.ptr(exp_avg_sq), params.numel(), betas[0], betas[1], eps,
+                                  L.ptr(state), L.ptr(found_inf), 1 if zero_grad else 0, L.stream_ptr(params.device)), "cvx_adam_step_dev")
 
 
 def check_finite(grads: torch.Tensor, found_inf: torch.Tensor):

@@ -15,7 +15,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import _lib as L
-from .engine import V8LossOp, adam_step, check_finite
+from .engine import V8LossOp, adam_step, adam_step_dev, check_finite
 from .graph import STRIDES
 from .model import PredList, Yolo8
 
@@ -81,20 +81,32 @@ class FlatAdam(torch.optim.Optimizer):
         self._m = None
         self._v = None
         self._step = 0
+        self._state = None          # device [lr, step, lr/(1-b1^t), 1/sqrt(1-b2^t)]: the step advances on the device
+        self._lr_on_device = None
         self.found_inf: Optional[torch.Tensor] = None
 
     def _ensure_state(self):
         p = self.model.flat_params
         if self._m is None or self._m.device != p.device:
             self._m, self._v = torch.zeros_like(p), torch.zeros_like(p)
+            self._state = torch.tensor([self.param_groups[0]["lr"], float(self._step), 0.0, 0.0], device=p.device)
+            self._lr_on_device = self.param_groups[0]["lr"]
+
+    def sync_lr(self):
+        """Push a learning rate changed by a scheduler to the device state (call outside graph capture)."""
+        self._ensure_state()
+        lr = self.param_groups[0]["lr"]
+        if lr != self._lr_on_device:
+            self._state[0:1].fill_(lr)
+            self._lr_on_device = lr
 
     @torch.no_grad()
     def step(self, closure=None, zero_grad: bool = False):
         self._ensure_state()
         g = self.param_groups[0]
         self._step += 1
-        adam_step(self.model.flat_params, self.model.flat_grads, self._m, self._v, g["lr"], g["betas"], g["eps"], self._step,
-                  self.found_inf, zero_grad)
+        adam_step_dev(self.model.flat_params, self.model.flat_grads, self._m, self._v, g["betas"], g["eps"], self._state, self.found_inf,
+                      zero_grad)
 
     def zero_grad(self, set_to_none: bool = True):
         self.model.flat_grads.zero_()
@@ -121,10 +133,14 @@ class FusedTrainStep:
     soon as the backward pass has produced it; BN statistics stay per rank (the reference has no SyncBN).
     """
 
-    def __init__(self, model: Yolo8, criterion: V8DetectionLoss, optimizer: FlatAdam, process_group=None, n_buckets: int = 4):
+    def __init__(self, model: Yolo8, criterion: V8DetectionLoss, optimizer: FlatAdam, process_group=None, n_buckets: int = 4,
+                 use_graph: bool = False):
         self.model, self.criterion, self.optimizer = model, criterion, optimizer
         self.pg = process_group
         self.n_buckets = n_buckets
+        self.use_graph = use_graph     # replay the whole step as one hipGraph (single-GPU; shapes and target count fixed)
+        self._graph = None
+        self._graph_key = None
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
@@ -134,6 +150,36 @@ class FusedTrainStep:
         self.found_inf = None
 
     def __call__(self, images: torch.Tensor, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        if self.use_graph and self.world == 1:
+            return self._graphed(images, batch)
+        self.optimizer.sync_lr()
+        return self._eager(images, batch)
+
+    def _graphed(self, images, batch):
+        """hipGraph replay of the step: removes ~500 host launches per step.  Inputs are copied into static buffers;
+        a new (batch, size, target-count) signature is run eagerly once (plans workspaces) and then captured."""
+        dev = self.model.flat_params.device
+        n_t = int(batch["batch_idx"].numel())
+        key = (tuple(images.shape), n_t)
+        self.optimizer.sync_lr()
+        if key != self._graph_key:
+            items = self._eager(images, batch)               # warm-up: allocations, attribute opt-ins, first plan
+            self._sx = images.detach().clone()
+            self._sb = {k: v.detach().to(dev).clone() for k, v in batch.items()}
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._sitems = self._eager(self._sx, self._sb)
+            self._graph, self._graph_key = g, key
+            return items
+        self._sx.copy_(images, non_blocking=True)
+        for k, v in batch.items():
+            self._sb[k].copy_(v, non_blocking=True)
+        self._graph.replay()
+        self.optimizer._step += 1
+        return self._sitems
+
+    def _eager(self, images: torch.Tensor, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         m, crit = self.model, self.criterion
         dev = m.flat_params.device
         B, _, H, W = images.shape

@@ -56,6 +56,6 @@ class Yolo8DetConfig:
         # --- MI355X engine knobs (new; not in the reference) ---------------------------------
         self.engine = _Group(
             loss_scale=1024.0,       # static fp16 gradient scale (reference uses GradScaler)
-            graph_capture=False,     # replay the step as a hipGraph
+            graph_capture=False,     # Yolo8Trainer: replay the step as a hipGraph (needs a fixed target count per batch)
             allreduce_buckets=4,     # RCCL buckets for the flat gradient arena
         )

@@ -68,6 +68,9 @@ int cvx_engine_destroy(cvx_engine* e);
  * statistics.  Replaces: nn.Module parameter/buffer storage (state_dict tensors are views of these). */
 int cvx_engine_bind(cvx_engine* e, float* params, float* grads, int64_t n_params, float* stats, int64_t n_stats);
 
+/* Changes the HIP stream subsequent calls enqueue on (e.g. a stream that is being captured into a hipGraph). */
+int cvx_engine_set_stream(cvx_engine* e, void* hip_stream);
+
 /* BatchNorm hyper-parameters (core/models/yolov8/torch_utils.py:17-19: eps 1e-3, momentum 0.03). */
 int cvx_engine_set_bn(cvx_engine* e, float eps, float momentum);
 
@@ -125,6 +128,11 @@ int cvx_loss_v8(const float* pred, int32_t batch, int32_t anchors, int32_t nc, c
 int cvx_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
                   float eps, int32_t step, const int32_t* found_inf, int32_t zero_grad, void* hip_stream);
 int cvx_check_finite(const float* grads, int64_t n, int32_t* found_inf, void* hip_stream);
+/* Same update with the step state resident on the device -- state[0] = lr (written by the host when the schedule
+ * changes it), state[1] = step count, state[2..3] = derived bias-correction factors, advanced by the call itself --
+ * so a captured hipGraph of the whole train step can be replayed without changing any kernel argument. */
+int cvx_adam_step_dev(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1, float beta2, float eps,
+                      float* state, const int32_t* found_inf, int32_t zero_grad, void* hip_stream);
 
 /* ---- eval tail: DFL decode + sigmoid, then class-aware NMS ---------------------------------------
  * cvx_decode: pred (B,A,no) -> y (B, 4+nc, A) fp32 [cx,cy,w,h (pixels), class scores]

@@ -390,3 +390,21 @@ def test_full_size_properties_bs32(dev):
         y_all = m._run_forward(x[:4], training=False)
         y_one = m._run_forward(x[2:3], training=False)
     assert torch.equal(y_all[2:3], y_one)                 # eval BN: images do not interact, bit-identical
+
+
+def test_graph_replay_is_bit_identical_to_eager(dev):
+    """The whole step captured as one hipGraph (incl. the side-stream weight gradients and the device-resident Adam
+    step counter) must reproduce the eager step exactly: every reduction in the engine is order-independent."""
+    from computervision.pytorch_amd.train import FlatAdam, FusedTrainStep, V8DetectionLoss
+    from configs import Yolo8DetConfig
+    x, batch = synth.images(2, 128, 128, seed=1).to(dev), {k: v.to(dev) for k, v in synth.targets(2, seed=2).items()}
+    runs = []
+    for use_graph in (False, True):
+        m = new_model(dev).train()
+        step = FusedTrainStep(m, V8DetectionLoss(Yolo8DetConfig(), m), FlatAdam(m, lr=1e-3), use_graph=use_graph)
+        losses = [step(x, batch).clone() for _ in range(5)]
+        torch.cuda.synchronize()
+        runs.append((torch.stack(losses).cpu(), m.flat_params.clone().cpu(), m.flat_stats.clone().cpu()))
+    assert torch.equal(runs[0][0], runs[1][0])
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+    assert float(runs[0][0][-1].sum()) < float(runs[0][0][0].sum())
