@@ -53,6 +53,7 @@ struct ConvParams {
   long long* stats;    // RAW_STATS: [stats_replicas][Cout][2] fixed-point (cvx_fix_atomic_add), must be zero on entry
   int stats_replicas;
   const half_t* zeros; // >= 16 zero bytes in device memory: DMA source for padding (second-generation kernel); null -> generation one
+  int dbg;             // timing experiments only (CVX_DBG): 1 = halo kernel streams the weights once, 2 = no MFMA; results are WRONG
   int halo_taps_ok;    // 1 when the tap table is a 3x3 neighbourhood (all |dh|,|dw| <= 1): the LDS halo-tile kernel may be used
 };
 #define CVX_STAT_REPLICAS 16

@@ -810,9 +810,10 @@ extern "C" int cvx_adam_step(float* params, float* grads, float* exp_avg, float*
   return cvx_adam(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, found_inf, zero_grad, (hipStream_t)hip_stream);
 }
 extern "C" int cvx_adam_step_dev(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1, float beta2, float eps,
-                                 float* state, const int32_t* found_inf, int32_t zero_grad, void* hip_stream) {
+                                 float* state, const int32_t* found_inf, int32_t zero_grad, float grad_scale, void* hip_stream) {
   CVX_CHECK(params && grads && exp_avg && exp_avg_sq && state && n > 0, "bad arguments");
-  return cvx_adam_dev(params, grads, exp_avg, exp_avg_sq, n, beta1, beta2, eps, state, found_inf, zero_grad, (hipStream_t)hip_stream);
+  return cvx_adam_dev(params, grads, exp_avg, exp_avg_sq, n, beta1, beta2, eps, state, found_inf, zero_grad, grad_scale,
+                      (hipStream_t)hip_stream);
 }
 extern "C" int cvx_engine_set_stream(cvx_engine* e, void* hip_stream) {
   CVX_CHECK(e, "null engine");

@@ -50,6 +50,6 @@ int cvx_adam(float* p, float* g, float* m, float* v, long long n, float lr, floa
              int zero_grad, hipStream_t st);
 // same update with the step state on the device (state[0]=lr, [1]=step, [2],[3] derived): replayable from a hipGraph
 int cvx_adam_dev(float* p, float* g, float* m, float* v, long long n, float b1, float b2, float eps, float* state, const int* found_inf,
-                 int zero_grad, hipStream_t st);
+                 int zero_grad, float grad_scale, hipStream_t st);
 // sets *found_inf = 1 if any gradient is non-finite
 int cvx_check_finite_launch(const float* g, long long n, int* found_inf, hipStream_t st);

@@ -234,7 +234,7 @@ __global__ void adam_advance_kernel(float* state, float b1, float b2, const int*
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* p, float* g, float* m, float* v, long long n, float lr_over_bc1, float b1, float b2,
-                                                   float eps, float inv_sqrt_bc2, const int* found_inf, int zero_grad, const float* state) {
+                                                   float eps, float inv_sqrt_bc2, const int* found_inf, int zero_grad, const float* state, float gscale) {
   const bool skip = found_inf && *found_inf != 0;
   if (state) {  // device-resident step state (hipGraph replay: no host-side arguments change between steps)
     lr_over_bc1 = state[2];
@@ -244,6 +244,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, float* g, float* m,
   if (i >= n) return;
   if (i + 4 <= n) {
     f4 gg = *reinterpret_cast<f4*>(g + i);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gg[k] *= gscale;  // 1/world_size after a SUM all-reduce (1 otherwise)
     if (!skip) {
       f4 pp = *reinterpret_cast<f4*>(p + i), mm = *reinterpret_cast<f4*>(m + i), vv = *reinterpret_cast<f4*>(v + i);
 #pragma unroll
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, float* g, float* m,
     if (zero_grad) *reinterpret_cast<f4*>(g + i) = f4{0.f, 0.f, 0.f, 0.f};
   } else {
     for (; i < n; ++i) {
-      float gg = g[i];
+      float gg = g[i] * gscale;
       if (!skip) {
         float mm = b1 * m[i] + (1.f - b1) * gg;
         float vv = b2 * v[i] + (1.f - b2) * gg * gg;
@@ -336,12 +338,12 @@ int cvx_adam(float* p, float* g, float* m, float* v, long long n, float lr, floa
   CVX_CHECK(step >= 1, "adam: step starts at 1");
   double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
   return launch1d(adam_kernel, (n + 3) / 4, st, p, g, m, v, n, (float)(lr / bc1), b1, b2, eps, (float)(1.0 / sqrt(bc2)), found_inf, zero_grad,
-                  (const float*)nullptr);
+                  (const float*)nullptr, 1.0f);
 }
 int cvx_adam_dev(float* p, float* g, float* m, float* v, long long n, float b1, float b2, float eps, float* state, const int* found_inf,
-                 int zero_grad, hipStream_t st) {
+                 int zero_grad, float grad_scale, hipStream_t st) {
   hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, st, state, b1, b2, found_inf);
-  return launch1d(adam_kernel, (n + 3) / 4, st, p, g, m, v, n, 0.f, b1, b2, eps, 0.f, found_inf, zero_grad, (const float*)state);
+  return launch1d(adam_kernel, (n + 3) / 4, st, p, g, m, v, n, 0.f, b1, b2, eps, 0.f, found_inf, zero_grad, (const float*)state, grad_scale);
 }
 int cvx_check_finite_launch(const float* g, long long n, int* found_inf, hipStream_t st) {
   if (n <= 0) return 0;

@@ -148,12 +148,13 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, lr, betas, eps, step, found_in
                               step, L.ptr(found_inf), 1 if zero_grad else 0, L.stream_ptr(params.device)), "cvx_adam_step")
 
 
-def adam_step_dev(params, grads, exp_avg, exp_avg_sq, betas, eps, state, found_inf=None, zero_grad=True):
+def adam_step_dev(params, grads, exp_avg, exp_avg_sq, betas, eps, state, found_inf=None, zero_grad=True, grad_scale=1.0):
     """Adam with the step state on the device (state = [lr, step, lr/bc1, 1/sqrt(bc2)]): graph-replayable."""
     lib = L.load()
     _need_gpu(params, "params")
     L.check(lib.cvx_adam_step_dev(L.ptr(params), L.ptr(grads), L.ptr(exp_avg), L.ptr(exp_avg_sq), params.numel(), betas[0], betas[1], eps,
-                                  L.ptr(state), L.ptr(found_inf), 1 if zero_grad else 0, L.stream_ptr(params.device)), "cvx_adam_step_dev")
+                                  L.ptr(state), L.ptr(found_inf), 1 if zero_grad else 0, float(grad_scale), L.stream_ptr(params.device)),
+            "cvx_adam_step_dev")
 
 
 def check_finite(grads: torch.Tensor, found_inf: torch.Tensor):

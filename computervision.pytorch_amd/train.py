@@ -101,12 +101,12 @@ class FlatAdam(torch.optim.Optimizer):
             self._lr_on_device = lr
 
     @torch.no_grad()
-    def step(self, closure=None, zero_grad: bool = False):
+    def step(self, closure=None, zero_grad: bool = False, grad_scale: float = 1.0):
         self._ensure_state()
         g = self.param_groups[0]
         self._step += 1
         adam_step_dev(self.model.flat_params, self.model.flat_grads, self._m, self._v, g["betas"], g["eps"], self._state, self.found_inf,
-                      zero_grad)
+                      zero_grad, grad_scale)
 
     def zero_grad(self, set_to_none: bool = True):
         self.model.flat_grads.zero_()
@@ -142,15 +142,17 @@ class FusedTrainStep:
         self._graph = None
         self._graph_key = None
         self.world = 1
+        self.distributed = False
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
+            self.distributed = True     # a 1-rank group still exercises the RCCL exchange path (bench.py CVX_FORCE_DIST)
         self._pred = None
         self._dpred = None
         self._side = None
         self.found_inf = None
 
     def __call__(self, images: torch.Tensor, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
-        if self.use_graph and self.world == 1:
+        if self.use_graph and not self.distributed:
             return self._graphed(images, batch)
         self.optimizer.sync_lr()
         return self._eager(images, batch)
@@ -192,15 +194,15 @@ class FusedTrainStep:
         pred = m._run_forward(images, training=True, pred=self._pred)
         items, dpred = crit.op(pred, targets, m.level_shapes(H, W), STRIDES, crit.loss_scale, self._dpred)
         eng.backward(dpred, crit.loss_scale)
-        if self.world > 1:
-            self._allreduce(m.flat_grads)
-        self.optimizer.step(zero_grad=True)
+        if self.distributed:
+            self._allreduce(m.flat_grads)      # SUM over ranks; the mean's 1/world is folded into the Adam kernel
+        self.optimizer.step(zero_grad=True, grad_scale=1.0 / self.world)
         return items
 
     def _allreduce(self, g: torch.Tensor):
         if self._side is None and g.is_cuda:
             self._side = torch.cuda.Stream(device=g.device)
-        allreduce_mean_flat(g, self.world, self.pg, self.n_buckets, self._side)
+        allreduce_mean_flat(g, self.world, self.pg, self.n_buckets, self._side, average=False)
 
 
 def bucket_bounds(n: int, n_buckets: int):
@@ -210,17 +212,18 @@ def bucket_bounds(n: int, n_buckets: int):
     return [(s, min(n, s + per)) for s in range(0, n, per)]
 
 
-def allreduce_mean_flat(g: torch.Tensor, world: int, group=None, n_buckets: int = 4, side_stream=None):
+def allreduce_mean_flat(g: torch.Tensor, world: int, group=None, n_buckets: int = 4, side_stream=None, average: bool = True):
     """Average the flat gradient arena over the ranks: a few large contiguous all-reduces (xGMI is
     point-to-point, so few big messages beat many small ones), issued on a side HIP stream."""
     import torch.distributed as dist
-    if world <= 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return
     bounds = bucket_bounds(g.numel(), n_buckets)
     if not g.is_cuda or side_stream is None:                      # CPU tensors: gloo tests of the bucketing logic
         for s, e in bounds:
             dist.all_reduce(g[s:e], group=group)
-            g[s:e].div_(world)
+            if average:
+                g[s:e].div_(world)
         return
     cur = torch.cuda.current_stream(g.device)
     side_stream.wait_stream(cur)
@@ -228,5 +231,6 @@ def allreduce_mean_flat(g: torch.Tensor, world: int, group=None, n_buckets: int 
         for s, e in bounds:
             chunk = g[s:e]
             dist.all_reduce(chunk, group=group)
-            chunk.div_(world)
+            if average:
+                chunk.div_(world)
     cur.wait_stream(side_stream)

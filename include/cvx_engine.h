@@ -130,9 +130,10 @@ int cvx_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq
 int cvx_check_finite(const float* grads, int64_t n, int32_t* found_inf, void* hip_stream);
 /* Same update with the step state resident on the device -- state[0] = lr (written by the host when the schedule
  * changes it), state[1] = step count, state[2..3] = derived bias-correction factors, advanced by the call itself --
- * so a captured hipGraph of the whole train step can be replayed without changing any kernel argument. */
+ * so a captured hipGraph of the whole train step can be replayed without changing any kernel argument.
+ * grad_scale multiplies every gradient first (1/world_size after a SUM all-reduce of the arena; 1 otherwise). */
 int cvx_adam_step_dev(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1, float beta2, float eps,
-                      float* state, const int32_t* found_inf, int32_t zero_grad, void* hip_stream);
+                      float* state, const int32_t* found_inf, int32_t zero_grad, float grad_scale, void* hip_stream);
 
 /* ---- eval tail: DFL decode + sigmoid, then class-aware NMS ---------------------------------------
  * cvx_decode: pred (B,A,no) -> y (B, 4+nc, A) fp32 [cx,cy,w,h (pixels), class scores]
