@@ -28,10 +28,23 @@ TRAIN_GFLOP_PER_IMG = 26.140262                 # 3*F - 2*MAC0, YOLOv8-n 640x640
 FWD_GFLOP_PER_IMG = 8.742912
 
 
+def usable_cores() -> int:
+    """Cores this process may actually use: the cgroup CPU quota if there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(seconds_budget: float = 25.0):
     from oracle import synth
     from oracle import yolov8_ref as O
     bs = 8
+    torch.set_num_threads(usable_cores())                     # torch defaults to every core of the host, not this box's share
     x, batch = synth.images(bs, 640, 640, seed=1), synth.targets(bs, seed=2)
     sd, state = O.init_state_dict("n", 80, seed=0), {}
     O.train_step(sd, x, batch, state)                         # warm-up (allocator, threads)

@@ -137,11 +137,31 @@ __device__ __forceinline__ void load_coef(const BnCoef& k, int c0, Coef8& sc_sh,
   }
 }
 
-// block-level accumulation of per-thread channel sums, bit-reproducible: every thread parks its fp32 partials in LDS,
-// NV*C threads then add one column each in fixed row order (no shuffles, no LDS atomics), and the block total goes to
-// a replica slab as one 64-bit fixed-point integer atomic per (channel, value).
+// block-level accumulation of per-thread channel sums, bit-reproducible.  Lanes of a wave that share a channel group
+// (lane % CG, when CG divides 64) are folded with a fixed xor-butterfly; each wave parks its CG*8*NV sums in its own
+// LDS slot; NV*C threads add the four wave slots in fixed order and issue ONE 64-bit fixed-point atomic per value.
+// Channel-group counts that do not divide 64 (C = 80, 144: Detect head) take the parked-partials column walk instead.
 template <int NV>
 __device__ __forceinline__ void block_channel_sums(float (&v)[NV][8], int C, int CG, int cg, bool active, float* sred, long long* part) {
+  const bool pow2 = (64 % CG) == 0;
+  if (pow2) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float x = v[q][i];  // every thread is active when CG divides 64 (RP * CG == 256)
+        for (int o = CG; o < 64; o <<= 1) x += __shfl_xor(x, o);
+        if (lane < CG) sred[(wave * C + cg * 8 + i) * NV + q] = x;
+      }
+    __syncthreads();
+    for (int j = threadIdx.x; j < NV * C; j += 256) {
+      const int c = j / NV, q = j - c * NV;
+      const float acc = (sred[(0 * C + c) * NV + q] + sred[(1 * C + c) * NV + q]) + (sred[(2 * C + c) * NV + q] + sred[(3 * C + c) * NV + q]);
+      cvx_fix_atomic_add(&part[((long long)(blockIdx.x % CVX_STAT_REPLICAS) * C + c) * 2 + q], acc);
+    }
+    return;
+  }
   const int RP = 256 / CG;
   if (active) {
     float* dst = sred + (size_t)threadIdx.x * (NV * 8);
@@ -303,7 +323,7 @@ int cvx_bn_silu_apply(const half_t* y, long long M, int C, int hw, const BnTrain
 }
 int cvx_bn_bwd_reduce(const half_t* y, long long M, int C, int hw, const BnCoef& k, const ViewDesc& gout, long long* part, hipStream_t st) {
   CVX_TRY(check_c(C, M));
-  int rows = cvx_stream_rows_per_block(M, C, 64);
+  int rows = cvx_stream_rows_per_block(M, C, 16);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks_for(M, rows)), dim3(256), 0, st, y, M, C, hw, k, gout, part, rows);
   CVX_HIP(hipGetLastError());
   return 0;

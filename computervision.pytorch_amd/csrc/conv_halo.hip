@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p, int 
   for (int s = 0; s < nsteps; ++s) {
     // the patch pieces are older than every weight piece, so the wait that lands weight stage s lands them too
     wait_steps_ahead<PB, BST - 2>(issued - 1 - s);
-    __builtin_amdgcn_s_barrier();
+    workgroup_barrier();
     if (issued < nsteps) {
       if (!(p.dbg & 1)) issue_w(issued % BST);
       ++issued;

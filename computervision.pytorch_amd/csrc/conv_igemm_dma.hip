@@ -53,6 +53,12 @@ struct Geom {
   static constexpr int LDS_BYTES = RING_BYTES + TAP_BYTES + STAT_BYTES;
 };
 
+__device__ __forceinline__ void workgroup_barrier() {  // see conv_tile_common.h
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
 
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
   for (int s = 0; s < nsteps; ++s) {
     // DMA pieces of K-step s have landed once at most (steps issued after s) * PASSES pieces remain outstanding
     wait_steps_ahead<PASSES, PRE - 1>(issued - 1 - s);  // block-uniform, in [0, PRE-1]
-    __builtin_amdgcn_s_barrier();  // every wave's pieces of step s are in LDS; everyone is done reading stage (s-1)
+    workgroup_barrier();  // every wave's pieces of step s are in LDS; everyone is done reading stage (s-1)
     if (issued < nsteps) {
       issue(issued % STAGES);  // refills the stage that was computed in the previous iteration
       ++issued;

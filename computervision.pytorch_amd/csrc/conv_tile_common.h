@@ -17,6 +17,15 @@ __device__ __forceinline__ void wait_vmcnt() {
   static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// raw s_barrier (no vmcnt drain, unlike __syncthreads) fenced for the COMPILER on both sides: without the clobbers hipcc
+// may hoist the LDS fragment reads of the next phase above the barrier -- i.e. between this wave's own vmcnt wait and
+// the other waves' -- and read DMA pieces that have not landed yet (seen as a few-percent error in one tile config).
+__device__ __forceinline__ void workgroup_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // waits until at most ahead*PASSES DMA pieces are outstanding (ahead is block-uniform, 0..MAXA)
 template <int PASSES, int MAXA>
 __device__ __forceinline__ void wait_steps_ahead(int ahead) {
