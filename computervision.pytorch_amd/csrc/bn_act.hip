@@ -10,10 +10,14 @@
 // All passes are HBM-bound streams: 16-byte (8 x fp16) accesses, one fixed channel group per thread so the
 // per-channel coefficients live in registers.  The replica slabs are zeroed once per step by the engine.
 #include "bn_act.h"
+#include <cstdlib>
 
 namespace {
 
+constexpr int UNR = 4;  // rows in flight per thread in the streaming passes
+
 __device__ __forceinline__ long long view_off(const ViewDesc& v, long long m, int hw) {
+  if (v.bstride == (long long)hw * v.ld) return m * v.ld;  // images are back to back (block-uniform test): no division
   const unsigned mu = (unsigned)m;  // M < 2^32 (checked on the host): one 32-bit division per row
   const unsigned b = mu / (unsigned)hw;
   const unsigned pix = mu - b * (unsigned)hw;
@@ -104,13 +108,11 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const half_t* y, lon
   }
   const long long m0 = (long long)blockIdx.x * rows_per_block;
   const long long m1 = min(M, m0 + rows_per_block);
-  for (long long m = m0 + r; m < m1; m += RP) {
-    h8 v = *reinterpret_cast<const h8*>(y + m * C + cg * 8);
+  auto one = [&](long long m, const h8& v, const h8& rr) {
     float f[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) f[i] = cvx_silu((float)v[i] * sc[i] + sh[i]);
     if (res.p) {
-      h8 rr = *reinterpret_cast<const h8*>(res.p + view_off(res, m, hw) + cg * 8);
 #pragma unroll
       for (int i = 0; i < 8; ++i) f[i] += (float)rr[i];
     }
@@ -118,6 +120,23 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const half_t* y, lon
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = (half_t)f[i];
     *reinterpret_cast<h8*>(out.p + view_off(out, m, hw) + cg * 8) = o;
+  };
+  // UNR rows per trip with every load issued before the first use: the passes are latency-bound otherwise
+  long long m = m0 + r;
+  for (; m + (long long)(UNR - 1) * RP < m1; m += (long long)UNR * RP) {
+    h8 v[UNR], rr[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      v[u] = *reinterpret_cast<const h8*>(y + (m + u * RP) * C + cg * 8);
+      if (res.p) rr[u] = *reinterpret_cast<const h8*>(res.p + view_off(res, m + u * RP, hw) + cg * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) one(m + u * RP, v[u], rr[u]);
+  }
+  for (; m < m1; m += RP) {
+    h8 v = *reinterpret_cast<const h8*>(y + m * C + cg * 8), rr = {};
+    if (res.p) rr = *reinterpret_cast<const h8*>(res.p + view_off(res, m, hw) + cg * 8);
+    one(m, v, rr);
   }
 }
 
@@ -195,9 +214,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const half_t* y, lon
     load_coef(k, cg * 8, s, u);
     const long long m0 = (long long)blockIdx.x * rows_per_block;
     const long long m1 = min(M, m0 + rows_per_block);
-    for (long long m = m0 + r; m < m1; m += RP) {
-      h8 v = *reinterpret_cast<const h8*>(y + m * C + cg * 8);
-      h8 g = *reinterpret_cast<const h8*>(gout.p + view_off(gout, m, hw) + cg * 8);
+    auto one = [&](const h8& v, const h8& g) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         float yy = (float)v[i];
@@ -205,6 +222,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const half_t* y, lon
         acc[0][i] += dz;
         acc[1][i] += dz * ((yy - u.a[i]) * u.b[i]);
       }
+    };
+    long long m = m0 + r;
+    for (; m + (long long)(UNR - 1) * RP < m1; m += (long long)UNR * RP) {
+      h8 v[UNR], g[UNR];
+#pragma unroll
+      for (int q = 0; q < UNR; ++q) {
+        v[q] = *reinterpret_cast<const h8*>(y + (m + q * RP) * C + cg * 8);
+        g[q] = *reinterpret_cast<const h8*>(gout.p + view_off(gout, m + q * RP, hw) + cg * 8);
+      }
+#pragma unroll
+      for (int q = 0; q < UNR; ++q) one(v[q], g[q]);
+    }
+    for (; m < m1; m += RP) {
+      h8 v = *reinterpret_cast<const h8*>(y + m * C + cg * 8);
+      h8 g = *reinterpret_cast<const h8*>(gout.p + view_off(gout, m, hw) + cg * 8);
+      one(v, g);
     }
   }
   block_channel_sums<2>(acc, C, CG, cg, active, sacc, part);
@@ -238,9 +271,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const half_t* y, long
   }
   const long long m0 = (long long)blockIdx.x * rows_per_block;
   const long long m1 = min(M, m0 + rows_per_block);
-  for (long long m = m0 + r; m < m1; m += RP) {
-    h8 v = *reinterpret_cast<const h8*>(y + m * C + cg * 8);
-    h8 g = *reinterpret_cast<const h8*>(gout.p + view_off(gout, m, hw) + cg * 8);
+  auto one = [&](long long m, const h8& v, h8 g, const h8& old) {
     h8 o;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -251,14 +282,32 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const half_t* y, long
     }
     *reinterpret_cast<h8*>(dy + m * C + cg * 8) = o;
     if (gres.p) {
-      half_t* q = gres.p + view_off(gres, m, hw) + cg * 8;
       if (res_accumulate) {
-        h8 old = *reinterpret_cast<const h8*>(q);
 #pragma unroll
         for (int i = 0; i < 8; ++i) g[i] = (half_t)((float)g[i] + (float)old[i]);
       }
-      *reinterpret_cast<h8*>(q) = g;
+      *reinterpret_cast<h8*>(gres.p + view_off(gres, m, hw) + cg * 8) = g;
     }
+  };
+  const bool rd_old = gres.p && res_accumulate;
+  long long m = m0 + r;
+  for (; m + (long long)(UNR - 1) * RP < m1; m += (long long)UNR * RP) {
+    h8 v[UNR], g[UNR], old[UNR];
+#pragma unroll
+    for (int q = 0; q < UNR; ++q) {
+      v[q] = *reinterpret_cast<const h8*>(y + (m + q * RP) * C + cg * 8);
+      g[q] = *reinterpret_cast<const h8*>(gout.p + view_off(gout, m + q * RP, hw) + cg * 8);
+      if (rd_old) old[q] = *reinterpret_cast<const h8*>(gres.p + view_off(gres, m + q * RP, hw) + cg * 8);
+    }
+#pragma unroll
+    for (int q = 0; q < UNR; ++q) one(m + q * RP, v[q], g[q], old[q]);
+  }
+  for (; m < m1; m += RP) {
+    h8 v = *reinterpret_cast<const h8*>(y + m * C + cg * 8);
+    h8 g = *reinterpret_cast<const h8*>(gout.p + view_off(gout, m, hw) + cg * 8);
+    h8 old = {};
+    if (rd_old) old = *reinterpret_cast<const h8*>(gres.p + view_off(gres, m, hw) + cg * 8);
+    one(m, v, g, old);
   }
 }
 
@@ -289,6 +338,8 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(long long M, int C, 
 int cvx_stream_rows_per_block(long long M, int C, int kb_per_block) {
   const int CG = C / 8;
   const int RP = 256 / CG;
+  static const int kb_env = getenv("CVX_BN_KB") ? atoi(getenv("CVX_BN_KB")) : 0;  // tuning experiments only
+  if (kb_env > 0) kb_per_block = kb_env;
   long long target = ((long long)kb_per_block * 1024) / (2LL * C);
   if (target < RP) target = RP;
   long long rows = ((target + RP - 1) / RP) * RP;
@@ -323,7 +374,7 @@ int cvx_bn_silu_apply(const half_t* y, long long M, int C, int hw, const BnTrain
 }
 int cvx_bn_bwd_reduce(const half_t* y, long long M, int C, int hw, const BnCoef& k, const ViewDesc& gout, long long* part, hipStream_t st) {
   CVX_TRY(check_c(C, M));
-  int rows = cvx_stream_rows_per_block(M, C, 16);
+  int rows = cvx_stream_rows_per_block(M, C, 32);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks_for(M, rows)), dim3(256), 0, st, y, M, C, hw, k, gout, part, rows);
   CVX_HIP(hipGetLastError());
   return 0;
@@ -331,7 +382,7 @@ int cvx_bn_bwd_reduce(const half_t* y, long long M, int C, int hw, const BnCoef&
 int cvx_bn_bwd_apply(const half_t* y, long long M, int C, int hw, const BnCoef& k, const long long* part, float inv_scale, float* dgamma,
                      float* dbeta, const ViewDesc& gout, half_t* dy, const ViewDesc& gres, int res_accumulate, hipStream_t st) {
   CVX_TRY(check_c(C, M));
-  int rows = cvx_stream_rows_per_block(M, C, 16);
+  int rows = cvx_stream_rows_per_block(M, C, 32);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(M, rows)), dim3(256), 0, st, y, M, C, hw, k, part, inv_scale, dgamma, dbeta, gout,
                      dy, gres, res_accumulate, rows);
   CVX_HIP(hipGetLastError());

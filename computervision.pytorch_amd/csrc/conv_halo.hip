@@ -3,7 +3,8 @@
 // The generic implicit-GEMM kernels re-gather every input pixel once per tap (9x) through the L2->LDS DMA path,
 // and that traffic -- not MFMA -- bounds them.  Here a workgroup owns a TH x 16 output patch of one image:
 //   * the (TH+2) x 18 x Cin input patch is DMA'd into LDS ONCE (1 KiB pieces, zero page for the image border);
-//   * the K loop streams only the weights ([BN][32] per K-step, 2-stage DMA ring, counted vmcnt, raw s_barrier);
+//   * the workgroup's whole weight slice ([BN][9*Cin], capped at ~80 KiB by the launcher) follows it into LDS; the
+//     K loop synchronises 1-3 times in total (counted vmcnt + raw s_barrier per group of K-steps), not per K-step;
 //   * the MFMA pixel operand of K-step (tap, channel chunk) is read straight out of the patch at the tap's
 //     (dh, dw) offset: lane = pixel column, so a 16-pixel row segment is one operand sub-tile;
 //   * patch layout [pixel][Cin/8 chunks of 16 B], chunk index XOR-swizzled by the pixel column so that 16
@@ -12,6 +13,7 @@
 // Used for the forward and the stride-1 data gradient (flipped taps, transposed weights) of every 3x3 conv whose
 // gathered channel count is 16, 32, 64 or 128 -- the C2f bottlenecks and most of the Detect head, ~75 % of the MACs.
 #include <cstdlib>
+#include <type_traits>
 
 #include "conv_tile_common.h"
 
@@ -20,192 +22,263 @@ using namespace cvx_tile;
 
 constexpr int HW = 18;  // halo patch width: 16 output columns + 2
 
-__device__ __forceinline__ int col_swz(int P, int col) {
-  // P = 16-byte chunks per pixel (2, 4, 8, 16): spreads 16 consecutive columns of one logical chunk over 64 banks
-  return P == 2 ? (col >> 3) & 1 : P == 4 ? (col >> 2) & 3 : P == 8 ? (col >> 1) & 7 : col & 15;
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
 }
 
-template <int WM, int WN, int MT, int NTW, int BST>
+template <int WM, int WN, int MT, int NTW, int L2C>
 struct HaloGeom {
+  static constexpr int CIN = 1 << L2C;
+  static constexpr int P = CIN >> 3;              // 16-byte chunks per pixel
   static constexpr int TH = WM * MT;              // output rows per workgroup
   static constexpr int BN = 16 * NTW * WN;        // output channels per workgroup
-  static constexpr int PB = (BN + 63) / 64;       // weight DMA pieces per wave per K-step
-  static constexpr int BSTAGES = BST;
-  static constexpr int BSTAGE_HALVES = (BN + 16) * BK;  // + one 16-row dump piece
-  static constexpr int TAP_BYTES = 16 * (int)sizeof(ConvTap);
+  static constexpr int NPIECE = BN / 16;          // 1 KiB weight pieces (16 rows x 64 B) per K-step
+  static constexpr int PB = (NPIECE + 3) / 4;     // weight DMA instructions per wave per K-step
+  static constexpr int STEP_HALVES = BN * BK;     // LDS halves of one K-step of weights
+  static constexpr int NSTEPS = (9 * CIN + BK - 1) / BK;
+  static constexpr int UNITS = (TH + 2) * HW * P;  // 16-byte units of the patch
+  static constexpr int PATCH_PIECES = (UNITS + 63) / 64;
   static constexpr int STAT_BYTES = WM * BN * 2 * 4;
-  static int patch_pieces(int cin) { return ((TH + 2) * HW * (cin / 8) + 63) / 64; }
-  // patch (+1 dump piece) | weight ring | taps | stat scratch
-  static int lds_bytes(int cin) { return (patch_pieces(cin) + 1) * 1024 + BSTAGES * BSTAGE_HALVES * 2 + TAP_BYTES + STAT_BYTES; }
+  // 2 patch buffers (+1 dump piece) | all weights of the workgroup's BN channels | stat scratch
+  static constexpr int LDS_BYTES = (2 * PATCH_PIECES + 1) * 1024 + NSTEPS * STEP_HALVES * 2 + STAT_BYTES;
 };
 
-template <int WM, int WN, int MT, int NTW, int BST>
-__global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p, int tiles_x, int tiles_y, int log2cin) {
-  using G = HaloGeom<WM, WN, MT, NTW, BST>;
-  constexpr int TH = G::TH, BN = G::BN, PB = G::PB;
+// P 16-byte chunks per pixel (2, 4, 8, 16): spreads 16 consecutive columns of one logical chunk over 64 banks
+template <int P>
+__device__ __forceinline__ int col_swz(int col) {
+  constexpr int SH = P == 2 ? 3 : P == 4 ? 2 : P == 8 ? 1 : 0;
+  return (col >> SH) & (P - 1);
+}
+
+// PERSISTENT workgroups: gridDim.x of them per channel block walk the (image, row-tile, column-tile) list with stride
+// gridDim.x.  Per workgroup, once: the tap table arrives as two packed kernel arguments (4 bits per tap -- no memory
+// round trip between a K-step and its patch address) and the WHOLE weight slice [BN][9*Cin] (capped by the
+// launcher), DMA'd into LDS K-step by K-step.  Per tile: the halo patch lands in one of two LDS buffers -- the DMA of
+// tile t+1 is issued before the K loop of tile t, so its ~0.5 us L2->LDS latency hides behind the MFMAs -- then ONE
+// barrier, a fully unrolled K loop (Cin is a template parameter: every (tap, chunk) is a constant and the scheduler
+// overlaps the LDS fragment reads of later steps with the MFMAs of earlier ones) and the stores.  Only the first tile
+// waits for the weights, in NG groups of K-steps (counted vmcnt).  BN statistics are kept per lane across tiles and
+// folded once per workgroup.  Measured with cvx_debug_clock_buffer: the ring version paid 0.5 us per 32-wide K-step.
+template <int WM, int WN, int MT, int NTW, int L2C>
+__global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p, int tiles_x, int tiles_y, int total_tiles) {
+  using G = HaloGeom<WM, WN, MT, NTW, L2C>;
+  constexpr int TH = G::TH, BN = G::BN, PB = G::PB, Cin = G::CIN, P = G::P, L2P = L2C - 3, NSTEPS = G::NSTEPS;
+  constexpr int PER_WAVE = (G::PATCH_PIECES + 3) / 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int Cin = 1 << log2cin;
-  const int P = Cin >> 3;
-  const int npieces = ((TH + 2) * HW * P + 63) >> 6;
-  half_t* patch = reinterpret_cast<half_t*>(smem);
-  half_t* patch_dump = patch + npieces * 512;
-  half_t* ring = patch_dump + 512;
-  ConvTap* sTap = reinterpret_cast<ConvTap*>(reinterpret_cast<unsigned char*>(ring) + G::BSTAGES * G::BSTAGE_HALVES * 2);
-  float* sStat = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(sTap) + G::TAP_BYTES);
+  half_t* patch0 = reinterpret_cast<half_t*>(smem);
+  half_t* patch_dump = patch0 + 2 * G::PATCH_PIECES * 512;
+  half_t* wts = patch_dump + 512;
+  float* sStat = reinterpret_cast<float*>(wts + NSTEPS * G::STEP_HALVES);
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int wm = wave / WN, wn = wave % WN;
   const int fr = lane & 15, fq = lane >> 4;
   const int nblk = blockIdx.y;
-  int t = blockIdx.x;
-  const int tx = t % tiles_x;
-  t /= tiles_x;
-  const int ty = t % tiles_y;
-  const int b = t / tiles_y;
-  const int y0 = ty * TH, x0 = tx * 16;
   const int H = p.IH, W = p.IW;
+  clk_mark(p, 0);
 
-  if (tid < p.ntaps) sTap[tid] = p.taps[tid];
-  __syncthreads();  // tap table visible -- before any DMA is issued (a __syncthreads later would drain the DMA queue)
-
-  // ---- 1. input patch -> LDS, once.  Every wave issues the same number of pieces (surplus ones hit the dump) ----
-  const half_t* img = p.in + (long long)b * p.in_bstride;
-  const int per_wave = (npieces + 3) >> 2;
-  const int units = (TH + 2) * HW * P;
-  for (int k = 0; k < ((p.dbg & 16) ? 1 : per_wave); ++k) {
-    const int piece = k * 4 + wave;
-    const int u = piece * 64 + lane;
-    const half_t* g = p.zeros;
-    if (u < units) {
-      const int hp = u >> (log2cin - 3), phys = u & (P - 1);
-      const int hy = hp / HW, hx = hp - hy * HW;
-      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-        g = img + ((long long)iy * W + ix) * p.in_ld + ((phys ^ col_swz(P, hx)) << 3);
-    }
-    half_t* dst = piece < npieces ? patch + piece * 512 : patch_dump;
-    __builtin_amdgcn_global_load_lds((gbl_void_ptr)g, (lds_void_ptr)dst, 16, 0, 0);
-  }
-
-  // ---- 2. weight ring ----
-  const int r16 = lane >> 2;
-  const int kg = (lane & 3) ^ ((r16 >> 1) & 3);
-  const half_t* wrow[PB];
+  // halo patch of tile `tile` -> patch buffer `buf`.  Every wave issues PER_WAVE pieces (surplus ones hit the dump).
+  auto issue_patch = [&](int tile, int buf) {
+    const int tx = tile % tiles_x;
+    const int t2 = tile / tiles_x;
+    const int ty = t2 % tiles_y;
+    const int b = t2 / tiles_y;
+    const int y0 = ty * TH, x0 = tx * 16;
+    const half_t* img = p.in + (long long)b * p.in_bstride;
+    half_t* pbuf = patch0 + buf * (G::PATCH_PIECES * 512);
 #pragma unroll
-  for (int q = 0; q < PB; ++q) {
-    const int row = q * 64 + wave * 16 + r16;
-    const int n = nblk * BN + row;
-    wrow[q] = (row < BN && n < p.Cout) ? p.wt + (long long)n * p.wt_ld : nullptr;
-  }
-  int cb = kg * 8, tapb = 0;  // weight-side (tap, channel) of this lane's k-group
-  while (cb >= Cin) {
-    cb -= Cin;
-    ++tapb;
-  }
-  const int nsteps = (p.dbg & 4) ? 1 : (p.ntaps * Cin + BK - 1) / BK;
-
-  auto issue_w = [&](int stage) {
-    const bool kvalid = tapb < p.ntaps;
-    const int wtap = sTap[kvalid ? tapb : 0].wtap;
-    half_t* sb = ring + stage * G::BSTAGE_HALVES;
-#pragma unroll
-    for (int q = 0; q < PB; ++q) {
-      int row0 = q * 64 + wave * 16;
-      if (row0 >= BN) row0 = BN;  // dump piece
-      const half_t* g = (kvalid && wrow[q]) ? wrow[q] + wtap * Cin + cb : p.zeros;
-      __builtin_amdgcn_global_load_lds((gbl_void_ptr)g, (lds_void_ptr)(sb + row0 * BK), 16, 0, 0);
-    }
-    cb += BK;
-    while (cb >= Cin) {
-      cb -= Cin;
-      ++tapb;
+    for (int k = 0; k < PER_WAVE; ++k) {
+      const int piece = k * 4 + wave;
+      const int u = piece * 64 + lane;
+      const half_t* g = p.zeros;
+      if (u < G::UNITS) {
+        const int hp = u >> L2P, phys = u & (P - 1);
+        const int hy = hp / HW, hx = hp - hy * HW;
+        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+          g = img + ((long long)iy * W + ix) * p.in_ld + ((phys ^ col_swz<P>(hx)) << 3);
+      }
+      half_t* dst = piece < G::PATCH_PIECES ? pbuf + piece * 512 : patch_dump;
+      __builtin_amdgcn_global_load_lds((gbl_void_ptr)g, (lds_void_ptr)dst, 16, 0, 0);
     }
   };
 
-  f4 acc[MT][NTW];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+  int tile = blockIdx.x;  // < total_tiles (launcher)
+  issue_patch(tile, 0);
 
-  // column swizzles of the three possible tap columns (patch column = fr + 1 + dw); named scalars, not an array:
-  // a runtime-indexed register array would be demoted to scratch memory
-  const int swz_m = col_swz(P, fr), swz_0 = col_swz(P, fr + 1), swz_p = col_swz(P, fr + 2);
+  const unsigned long long pos_pack = p.halo_pos, wt_pack = p.halo_wt;  // 4 bits per tap (cvx_halo_pack_taps)
 
-  int issued = 0;
-  for (; issued < BST - 1 && issued < nsteps; ++issued) issue_w(issued % BST);
-  for (int s = 0; s < nsteps; ++s) {
-    // the patch pieces are older than every weight piece, so the wait that lands weight stage s lands them too
-    wait_steps_ahead<PB, BST - 2>(issued - 1 - s);
-    workgroup_barrier();
-    if (issued < nsteps) {
-      if (!(p.dbg & 1)) issue_w(issued % BST);
-      ++issued;
+  // ---- all weights of this workgroup's channels -> LDS, K-step after K-step ----
+  {
+    const int r16 = lane >> 2;
+    const int kg = (lane & 3) ^ ((r16 >> 1) & 3);  // logical k-group this lane fetches (source-side swizzle)
+    const half_t* wrow[PB];
+    half_t* wdst[PB];
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+      const int piece = q * 4 + wave;  // wave-uniform
+      const int n = nblk * BN + piece * 16 + r16;
+      wrow[q] = (piece < G::NPIECE && n < p.Cout) ? p.wt + (long long)n * p.wt_ld : nullptr;
+      wdst[q] = piece < G::NPIECE ? wts + piece * 512 : nullptr;
     }
-    // pixel operand: k-group 4s+fq -> (tap, channel chunk) -> patch address
-    const int k0 = (4 * s + fq) << 3;
-    int tp = k0 >> log2cin;
-    const int chunk = (k0 & (Cin - 1)) >> 3;
-    if (tp >= p.ntaps) tp = 0;  // weights of the K tail are zero; any valid address will do
-    const ConvTap td = sTap[tp];
-    const half_t* sb = ring + (s % BST) * G::BSTAGE_HALVES;
-    h8 xa[MT];
+    for (int s = 0; s < NSTEPS; ++s) {
+      const int k = s * BK + kg * 8;
+      const int tapb = k >> L2C, cb = k & (Cin - 1);
+      const bool kvalid = tapb < 9;
+      const int wtap = (int)(wt_pack >> (4 * (kvalid ? tapb : 0))) & 15;
+#pragma unroll
+      for (int q = 0; q < PB; ++q) {
+        const half_t* g = (kvalid && wrow[q]) ? wrow[q] + wtap * Cin + cb : p.zeros;
+        half_t* dst = wdst[q] ? wdst[q] + s * G::STEP_HALVES : patch_dump;
+        __builtin_amdgcn_global_load_lds((gbl_void_ptr)g, (lds_void_ptr)dst, 16, 0, 0);
+      }
+    }
+  }
+  clk_mark(p, 1);
+
+  // per-lane constant parts of the operand addresses (halves)
+  const int xbase = ((wm * MT) * HW + fr) << L2P;                   // patch unit of (row wm*MT, column fr)
+  const half_t* wbase = wts + lds_row_off(wn * NTW * 16 + fr, fq);  // + j*16 rows (swizzle term unchanged: 16 | row step)
+  f4 st1[NTW], st2[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) st1[j] = st2[j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  constexpr int NG = NSTEPS >= 12 ? 3 : (NSTEPS >= 4 ? 2 : 1);
+  bool first = true;
+  int buf = 0;
+  for (; tile < total_tiles; tile += gridDim.x, buf ^= 1) {
+    const int next = tile + gridDim.x;
+    const bool has_next = next < total_tiles;
+    f4 acc[MT][NTW];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    const half_t* patch = patch0 + buf * (G::PATCH_PIECES * 512);
+
+    static_for<0, NG>([&](auto gi) {
+      constexpr int g = decltype(gi)::value;
+      constexpr int beg = (NSTEPS * g) / NG, end = (NSTEPS * (g + 1)) / NG;
+      if (g == 0 || first) {
+        // loads retire in order.  First tile: [patch][weights...][next patch]: group g needs K-steps < end, i.e. all but
+        // the youngest `pend` weight pieces (+ the next patch, issued after barrier 0).  Later tiles: only their patch.
+        constexpr int pend = (NSTEPS - end) * PB;
+        if (first) {
+          if (g > 0 && has_next) wait_vmcnt<(pend + PER_WAVE > 63 ? 63 : pend + PER_WAVE)>();
+          else wait_vmcnt<(pend > 63 ? 63 : pend)>();
+        } else {
+          wait_vmcnt<0>();
+        }
+        workgroup_barrier();  // group 0: also "every wave is done with the other patch buffer"
+        if (g == 0) {
+          if (first) clk_mark(p, 2);
+          if (has_next) issue_patch(next, buf ^ 1);
+        }
+      }
+      // software pipeline inside the group: the LDS fragment reads of K-step s+PD are issued before the MFMAs of
+      // step s (one wave per SIMD at low occupancy: nobody else hides the ~128-cycle LDS latency).  sched_barrier pins
+      // the order, so the MFMAs wait with a COUNTED lgkmcnt for their own fragments only.
+      constexpr int PD = 2;
+      h8 xa[PD + 1][MT], wb[PD + 1][NTW];
+      auto load_step = [&](auto si) {
+        constexpr int s = decltype(si)::value;
+        constexpr int slot = (s - beg) % (PD + 1);
+        // pixel operand: k-group 4s+fq -> (tap, channel chunk) -> patch address
+        int tp, chunk;
+        if constexpr (L2C >= 5) {  // a 32-wide K-step lies inside one tap: tap and chunk base are step constants
+          tp = (BK * s) >> L2C;
+          chunk = (((BK * s) & (Cin - 1)) >> 3) + fq;
+        } else {  // Cin = 16: two taps per K-step
+          tp = 2 * s + (fq >> 1);
+          chunk = fq & 1;
+          if (tp > 8) tp = 0;  // weights of the K tail are zero; any valid address will do
+        }
+        const int code = (int)(pos_pack >> (4 * tp)) & 15;
+        const int dh = code >> 2, dw = code & 3;  // already +1
+        const int sw = col_swz<P>(fr + dw);
+        const half_t* xp = patch + ((xbase + ((dh * HW + dw) << L2P) + (chunk ^ sw)) << 3);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) xa[slot][i] = *reinterpret_cast<const h8*>(xp + ((i * HW) << (L2P + 3)));
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) wb[slot][j] = *reinterpret_cast<const h8*>(wbase + s * G::STEP_HALVES + j * 16 * BK);
+      };
+      static_for<beg, (beg + PD < end ? beg + PD : end)>(load_step);
+      static_for<beg, end>([&](auto si) {
+        constexpr int s = decltype(si)::value;
+        constexpr int slot = (s - beg) % (PD + 1);
+        if constexpr (s + PD < end) load_step(std::integral_constant<int, s + PD>{});
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+          for (int i = 0; i < MT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[slot][j], xa[slot][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+    if (first) clk_mark(p, 3);
+
+    // ---- stores ----
+    const int tx = tile % tiles_x;
+    const int t2 = tile / tiles_x;
+    const int ty = t2 % tiles_y;
+    const int b = t2 / tiles_y;
+    long long out_off[MT], res_off[MT];
+    bool pvalid[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      const int hrow = wm * MT + i + 1 + td.dh;
-      const int col = fr + 1 + td.dw;
-      const int sw = td.dw < 0 ? swz_m : (td.dw == 0 ? swz_0 : swz_p);
-      xa[i] = *reinterpret_cast<const h8*>(patch + (((hrow * HW + col) << (log2cin - 3)) + (chunk ^ sw)) * 8);
+      const int oy = ty * TH + wm * MT + i, ox = tx * 16 + fr;
+      pvalid[i] = oy < H && ox < W;
+      const long long pix = pvalid[i] ? (long long)oy * W + ox : 0;
+      out_off[i] = (long long)b * p.out_bstride + pix * p.out_ld;
+      res_off[i] = (long long)b * p.res_bstride + pix * p.res_ld;
     }
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-      h8 wb = *reinterpret_cast<const h8*>(&sb[lds_row_off((wn * NTW + j) * 16 + fr, fq)]);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-        if (!(p.dbg & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb, xa[i], acc[i][j], 0, 0, 0);
-    }
+    epilogue_tile<WM, WN, MT, NTW>(p, acc, out_off, res_off, pvalid, wn, fq, nblk, st1, st2);
+    first = false;
   }
-
-  // ---- 3. epilogue ----
-  long long out_off[MT], res_off[MT];
-  bool pvalid[MT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int oy = y0 + wm * MT + i, ox = x0 + fr;
-    pvalid[i] = oy < H && ox < W;
-    const long long pix = pvalid[i] ? (long long)oy * W + ox : 0;
-    out_off[i] = (long long)b * p.out_bstride + pix * p.out_ld;
-    res_off[i] = (long long)b * p.res_bstride + pix * p.res_ld;
-  }
-  if (p.dbg & 8) {  // timing experiment: no epilogue (one store keeps the accumulators alive)
-    if (acc[0][0][0] == 12345.678f) p.out16[0] = (half_t)acc[0][0][1];
-    return;
-  }
-  epilogue<WM, WN, MT, NTW>(p, acc, out_off, res_off, pvalid, wm, wn, fr, fq, nblk, sStat, tid);
+  if (p.epi == CVX_EPI_RAW_STATS) stats_flush<WM, WN, NTW>(p, st1, st2, wm, wn, fr, fq, nblk, sStat, tid);
+  clk_mark(p, 4);
 }
 
-template <int WM, int WN, int MT, int NTW, int BST>
-int launch_halo_st(const ConvParams& p, hipStream_t stream, int gy, int log2cin) {
-  using G = HaloGeom<WM, WN, MT, NTW, BST>;
-  const int tiles_x = (p.IW + 15) / 16, tiles_y = (p.IH + G::TH - 1) / G::TH;
-  const int lds = G::lds_bytes(p.Cin);
-  static int attr_bytes = 0;
-  if (lds > attr_bytes) {
-    CVX_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<WM, WN, MT, NTW, BST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_bytes = lds;
+template <int WM, int WN, int MT, int NTW, int L2C>
+int launch_halo_c(const ConvParams& p, hipStream_t stream, int gy) {
+  using G = HaloGeom<WM, WN, MT, NTW, L2C>;
+  if constexpr (G::LDS_BYTES > 160 * 1024) {
+    CVX_CHECK(false, "conv_halo: weight slice does not fit in LDS (launcher bug)");
+  } else {
+    const int tiles_x = (p.IW + 15) / 16, tiles_y = (p.IH + G::TH - 1) / G::TH;
+    const int total = tiles_x * tiles_y * p.B;
+    static bool attr_done = false;
+    if (!attr_done) {
+      CVX_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<WM, WN, MT, NTW, L2C>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+      attr_done = true;
+    }
+    // persistent: as many workgroups as fit on the 256 CUs at once (LDS-limited, at most CVX_HALO_OCC per CU), split
+    // over the gy channel blocks; each walks the tile list with that stride
+    static const int occ_cap = getenv("CVX_HALO_OCC") ? atoi(getenv("CVX_HALO_OCC")) : 4;
+    int per_cu = (160 * 1024) / G::LDS_BYTES;
+    per_cu = per_cu < 1 ? 1 : (per_cu > occ_cap ? occ_cap : per_cu);
+    int gx = (256 * per_cu) / gy;
+    if (gx < 1) gx = 1;
+    if (gx > total) gx = total;
+    dim3 grid(gx, gy);
+    hipLaunchKernelGGL((conv_halo_kernel<WM, WN, MT, NTW, L2C>), grid, dim3(256), G::LDS_BYTES, stream, p, tiles_x, tiles_y, total);
   }
-  dim3 grid(tiles_x * tiles_y * p.B, gy);
-  hipLaunchKernelGGL((conv_halo_kernel<WM, WN, MT, NTW, BST>), grid, dim3(256), lds, stream, p, tiles_x, tiles_y, log2cin);
   return 0;
 }
 
 template <int WM, int WN, int MT, int NTW>
 int launch_halo(const ConvParams& p, hipStream_t stream, int gy, int log2cin) {
-  static const int st = getenv("CVX_HALO_BST") ? atoi(getenv("CVX_HALO_BST")) : 2;
-  if (st >= 4) return launch_halo_st<WM, WN, MT, NTW, 4>(p, stream, gy, log2cin);
-  if (st == 3) return launch_halo_st<WM, WN, MT, NTW, 3>(p, stream, gy, log2cin);
-  return launch_halo_st<WM, WN, MT, NTW, 2>(p, stream, gy, log2cin);
+  switch (log2cin) {
+    case 4: return launch_halo_c<WM, WN, MT, NTW, 4>(p, stream, gy);
+    case 5: return launch_halo_c<WM, WN, MT, NTW, 5>(p, stream, gy);
+    case 6: return launch_halo_c<WM, WN, MT, NTW, 6>(p, stream, gy);
+    default: return launch_halo_c<WM, WN, MT, NTW, 7>(p, stream, gy);
+  }
 }
 
 template <int WM, int MT>
@@ -233,40 +306,44 @@ bool cvx_conv_halo_supported(const ConvParams& p) {
   return p.halo_taps_ok != 0;  // all |dh|,|dw| <= 1, verified on the host where the tap table was built
 }
 
-int cvx_conv_halo_launch(const ConvParams& p_in, hipStream_t stream) {
-  static const int dbg = getenv("CVX_DBG") ? atoi(getenv("CVX_DBG")) : 0;
-  ConvParams p = p_in;
-  p.dbg = dbg;
+// largest number of 16-channel tiles per workgroup whose weights (tiles*16 x 9*Cin fp16) stay within the LDS budget
+static int halo_tile_cap(int cin) {
+  static const int kb = getenv("CVX_HALO_WKB") ? atoi(getenv("CVX_HALO_WKB")) : 80;
+  int cap = (kb * 1024) / (16 * 9 * cin * 2);
+  return cap < 1 ? 1 : (cap > 8 ? 8 : cap);
+}
+
+int cvx_conv_halo_launch(const ConvParams& p, hipStream_t stream) {
   int l2 = 0;
   while ((1 << l2) < p.Cin) ++l2;
   const int tiles = (p.Cout + 15) / 16;
+  const int cap = halo_tile_cap(p.Cin);
   const long long hw = (long long)p.IH * p.IW;
+  static const int allowed[] = {1, 2, 3, 4, 5, 6, 8};
+  auto pick = [&](int* gy_out) {  // fewest channel blocks within the cap, then the smallest allowed tile count covering them
+    int gy = (tiles + cap - 1) / cap, want = (tiles + gy - 1) / gy;
+    int NT = 8;
+    for (int a : allowed)
+      if (a >= want) {
+        NT = a;
+        break;
+      }
+    while (NT > cap) --NT;  // 7 is not compiled: cap 7 -> 6
+    if (NT == 7) NT = 6;
+    *gy_out = (tiles + NT - 1) / NT;
+    return NT;
+  };
   if (hw >= 80 * 80 || hw * p.B >= 128 * 1024) {  // TH = 8
-    int gy = (tiles + 7) / 8, want = (tiles + gy - 1) / gy;
-    static const int allowed[] = {1, 2, 3, 4, 5, 6, 8};
-    int NT = 8;
-    for (int a : allowed)
-      if (a >= want) {
-        NT = a;
-        break;
-      }
-    gy = (tiles + NT - 1) / NT;
+    int gy, NT = pick(&gy);
     CVX_TRY((launch_m<4, 2>(NT, p, stream, gy, l2)));
-  } else if (hw >= 40 * 40) {  // TH = 4
-    int gy = (tiles + 7) / 8, want = (tiles + gy - 1) / gy;
-    static const int allowed[] = {1, 2, 3, 4, 5, 6, 8};
-    int NT = 8;
-    for (int a : allowed)
-      if (a >= want) {
-        NT = a;
-        break;
-      }
-    gy = (tiles + NT - 1) / NT;
+  } else if (hw >= 40 * 40 || cap < 2) {  // TH = 4
+    int gy, NT = pick(&gy);
     CVX_TRY((launch_m<4, 1>(NT, p, stream, gy, l2)));
   } else {  // TH = 2, 2x2 waves, BN = 32 * NTW
-    int pairs = (tiles + 1) / 2;
-    int gy = (pairs + 3) / 4;
+    const int pairs = (tiles + 1) / 2, pcap = cap / 2;
+    int gy = (pairs + pcap - 1) / pcap;
     int ntw = (pairs + gy - 1) / gy;
+    if (ntw > 4) ntw = 4;
     gy = (pairs + ntw - 1) / ntw;
     switch (ntw) {
       case 1: CVX_TRY((launch_halo<2, 2, 1, 1>(p, stream, gy, l2))); break;

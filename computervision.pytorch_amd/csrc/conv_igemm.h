@@ -54,10 +54,29 @@ struct ConvParams {
   int stats_replicas;
   const half_t* zeros; // >= 16 zero bytes in device memory: DMA source for padding (second-generation kernel); null -> generation one
   int dbg;             // timing experiments only (CVX_DBG): 1 = halo kernel streams the weights once, 2 = no MFMA; results are WRONG
+  unsigned long long* clk;  // tuning aid (cvx_debug_clock_buffer): thread 0 of every block stores 100 MHz timestamps, 8 slots per block
   int halo_taps_ok;    // 1 when the tap table is a 3x3 neighbourhood (all |dh|,|dw| <= 1): the LDS halo-tile kernel may be used
+  int pointwise;       // 1 when the table is the single tap (0, 0, weight tap 0): a 1x1 convolution (conv_pw.hip)
+  unsigned long long halo_pos, halo_wt;  // cvx_halo_pack_taps of the table (valid when halo_taps_ok): 4 bits per tap
 };
+
+// Packs a 9-entry tap table whose offsets all lie in the 3x3 neighbourhood into two 64-bit words, 4 bits per tap:
+// pos = (dh+1)*4 + (dw+1), wt = weight tap index.  Kernel arguments instead of a device table: the halo kernel reads
+// no tap memory at all.  Returns false (and the generic kernels are used) for any other table.
+inline bool cvx_halo_pack_taps(const ConvTap* t, int n, unsigned long long* pos, unsigned long long* wt) {
+  *pos = *wt = 0;
+  if (n != 9) return false;
+  for (int i = 0; i < 9; ++i) {
+    if (t[i].dh < -1 || t[i].dh > 1 || t[i].dw < -1 || t[i].dw > 1 || t[i].wtap < 0 || t[i].wtap > 15) return false;
+    *pos |= (unsigned long long)(((t[i].dh + 1) << 2) | (t[i].dw + 1)) << (4 * i);
+    *wt |= (unsigned long long)t[i].wtap << (4 * i);
+  }
+  return true;
+}
 #define CVX_STAT_REPLICAS 16
 
+// tuning aid: when set (cvx_debug_clock_buffer), the DMA-ring and halo kernels store per-block phase timestamps there
+extern unsigned long long* g_cvx_clk;
 // Launches the kernel; returns the number of M-blocks (= stats partial count) through *m_blocks.
 int cvx_conv_igemm_launch(const ConvParams& p, hipStream_t stream, int* m_blocks);
 // Number of M-blocks the launcher will use for M output pixels.
@@ -67,6 +86,10 @@ int cvx_conv_igemm_dma_launch(const ConvParams& p, hipStream_t stream);
 // 3x3 stride-1 halo-tile kernel (conv_halo.hip)
 bool cvx_conv_halo_supported(const ConvParams& p);
 int cvx_conv_halo_launch(const ConvParams& p, hipStream_t stream);
+// pointwise (1x1 stride-1) persistent GEMM kernel (conv_pw.hip)
+bool cvx_conv_pw_supported(const ConvParams& p);
+int cvx_conv_pw_launch(const ConvParams& p, hipStream_t stream);
+inline int cvx_taps_pointwise(const ConvTap* t, int n) { return (n == 1 && t[0].dh == 0 && t[0].dw == 0 && t[0].wtap == 0) ? 1 : 0; }
 
 // Weight gradient: dW[co][tap][ci] partial sums over a slice of the pixels, written as fp32 slabs.
 struct WgradParams {

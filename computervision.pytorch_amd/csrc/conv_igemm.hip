@@ -235,7 +235,11 @@ void launch_nt(const ConvParams& p, hipStream_t stream, dim3 grid) {
 
 int cvx_conv_igemm_mblocks(long long M) { return (int)((M + BM - 1) / BM); }
 
-int cvx_conv_igemm_launch(const ConvParams& p, hipStream_t stream, int* m_blocks) {
+unsigned long long* g_cvx_clk = nullptr;
+
+int cvx_conv_igemm_launch(const ConvParams& p_in, hipStream_t stream, int* m_blocks) {
+  ConvParams p = p_in;
+  p.clk = g_cvx_clk;
   CVX_CHECK(p.Cin % 8 == 0 && p.in_ld % 8 == 0 && p.wt_ld % 8 == 0, "conv_igemm: channel counts must be multiples of 8");
   CVX_CHECK(p.Cout % 4 == 0 && p.out_ld % 4 == 0, "conv_igemm: Cout/out_ld must be multiples of 4");
   CVX_CHECK(p.ntaps >= 1 && p.ntaps <= CVX_MAX_TAPS, "conv_igemm: bad tap count");
@@ -245,6 +249,7 @@ int cvx_conv_igemm_launch(const ConvParams& p, hipStream_t stream, int* m_blocks
   static const bool force_v1 = getenv("CVX_CONV_V1") != nullptr;
   if (p.zeros && !force_v1) {
     if (m_blocks) *m_blocks = 0;
+    if (cvx_conv_pw_supported(p)) return cvx_conv_pw_launch(p, stream);
     if (cvx_conv_halo_supported(p)) return cvx_conv_halo_launch(p, stream);
     return cvx_conv_igemm_dma_launch(p, stream);
   }

@@ -62,6 +62,15 @@ __device__ __forceinline__ void workgroup_barrier() {  // see conv_tile_common.h
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
 
+__device__ __forceinline__ void clk_mark(const ConvParams& p, int slot) {  // see conv_tile_common.h
+  if (p.clk && threadIdx.x == 0) {
+    unsigned long long* q = p.clk + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+    q[slot] = wall_clock64();
+    if (slot == 0) q[5] = clock64();
+    if (slot == 4) q[6] = clock64();
+  }
+}
+
 template <int WM, int WN, int MT, int NTW, int STAGES>
 __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p) {
   static_assert(WM * WN == 4, "4 waves");
@@ -85,6 +94,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
   const long long M = (long long)p.B * p.OH2 * p.OW2;
   const long long m_base = (long long)blockIdx.x * BM;
 
+  clk_mark(p, 0);
   if (tid < p.ntaps) sTap[tid] = p.taps[tid];
 
   // ---- per-lane DMA assignment: pass q covers stage rows q*64 + wave*16 + (lane>>2), physical slot lane&3 ----
@@ -121,6 +131,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
   }
   const int nsteps = (p.ntaps * p.Cin + BK - 1) / BK;
   __syncthreads();  // tap table visible (no DMA outstanding yet)
+  clk_mark(p, 1);
 
   auto issue = [&](int stage) {
     const bool kvalid = tap < p.ntaps;
@@ -161,6 +172,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
     // DMA pieces of K-step s have landed once at most (steps issued after s) * PASSES pieces remain outstanding
     wait_steps_ahead<PASSES, PRE - 1>(issued - 1 - s);  // block-uniform, in [0, PRE-1]
     workgroup_barrier();  // every wave's pieces of step s are in LDS; everyone is done reading stage (s-1)
+    if (s == 0) clk_mark(p, 2);
     if (issued < nsteps) {
       issue(issued % STAGES);  // refills the stage that was computed in the previous iteration
       ++issued;
@@ -177,6 +189,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
     }
   }
 
+  clk_mark(p, 3);
   // ---- epilogue: lane holds pixel (fr) x channels 4*fq..4*fq+3 of every (i, j) tile ----
   long long out_off[MT], res_off[MT];
   bool pvalid[MT];
@@ -234,6 +247,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
         cvx_fix_atomic_add(&p.stats[((long long)(blockIdx.x % p.stats_replicas) * p.Cout + n) * 2 + which], v);
       }
     }
+    clk_mark(p, 4);
     return;
   }
 
@@ -272,6 +286,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
       *reinterpret_cast<h4*>(dst) = o;
     }
   }
+  clk_mark(p, 4);
 }
 
 int env_int(const char* name, int dflt) {

@@ -41,19 +41,27 @@ void cvx_set_error(const std::string& msg);
 static inline int cvx_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---- small device helpers ---------------------------------------------------------------------
-__device__ __forceinline__ float cvx_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp each) instead of the ~10-instruction IEEE division: the elementwise BN/SiLU passes are
+// VALU-limited on the big layers, and every consumer rounds the result to fp16 anyway.
+__device__ __forceinline__ float cvx_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float cvx_silu(float x) { return x * cvx_sigmoid(x); }
 // d silu / dx
 __device__ __forceinline__ float cvx_silu_grad(float x) {
   float s = cvx_sigmoid(x);
   return s * (1.0f + x * (1.0f - s));
 }
+// sum over the 16 lanes that share (lane >> 4), every lane gets the total.  Four DPP adds (quad xor 1, quad xor 2,
+// half-row mirror, row mirror) instead of four ds_bpermute round trips through the LDS pipe.
+__device__ __forceinline__ float cvx_dpp_add(float v, float moved) { return v + moved; }
+template <int CTRL>
+__device__ __forceinline__ float cvx_dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float cvx_wave_sum16(float v) {
-  // sum over the 16 lanes that share (lane >> 4)
-  v += __shfl_xor(v, 1);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 8);
+  v += cvx_dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += cvx_dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += cvx_dpp_mov<0x141>(v);  // row_half_mirror
+  v += cvx_dpp_mov<0x140>(v);  // row_mirror
   return v;
 }
 __device__ __forceinline__ float cvx_wave_sum64(float v) {

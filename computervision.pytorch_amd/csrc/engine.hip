@@ -3,6 +3,7 @@
 // views and the backward write/accumulate modes once, and replays the op list on one HIP stream.
 #include <algorithm>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -21,12 +22,18 @@ namespace {
 
 struct DgClass {
   ConvTap* taps = nullptr;
+  bool halo_ok = false;
+  int pointwise = 0;
+  unsigned long long halo_pos = 0, halo_wt = 0;
   int ntaps = 0, oph = 0, opw = 0, OH2 = 0, OW2 = 0;
 };
 
 struct ConvRt {
   // static
   ConvTap* taps_fwd = nullptr;
+  bool halo_ok = false;
+  int pointwise = 0;
+  unsigned long long halo_pos = 0, halo_wt = 0;
   int ntaps = 0;
   DgClass dg[16];
   int ndg = 0;
@@ -102,7 +109,9 @@ struct cvx_engine {
   struct ProfRec {
     int cls;
     double flops, bytes;
+    int op;
   };
+  int cur_op = -1;  // op index the launch loops are at (profile records carry it)
   std::vector<ProfRec> prof_recs;
 };
 
@@ -147,7 +156,7 @@ struct ProfScope {  // records a start/stop event pair around the launches issue
       }
       e->ev_pool.push_back(ev);
     }
-    e->prof_recs.push_back({cls, flops, bytes});
+    e->prof_recs.push_back({cls, flops, bytes, e->cur_op});
     slot = e->ev_used;
     e->ev_used += 2;
     (void)hipEventRecord(e->ev_pool[slot], st);
@@ -214,6 +223,8 @@ int build_static(cvx_engine* e) {
     for (int r = 0; r < o.k; ++r)
       for (int s = 0; s < o.k; ++s) taps[r * o.k + s] = ConvTap{r * o.dil - o.pad, s * o.dil - o.pad, r * o.k + s, 0};
     CVX_TRY(upload(e, e->static_allocs, e->static_bytes, &c.taps_fwd, taps));
+    c.halo_ok = cvx_halo_pack_taps(taps.data(), T, &c.halo_pos, &c.halo_wt);
+    c.pointwise = cvx_taps_pointwise(taps.data(), T);
     // shadow weights
     PackDesc pd;
     pd.src_off = o.w_off;
@@ -254,6 +265,8 @@ int build_static(cvx_engine* e) {
           dc.OH2 = (o.ih - ph + S - 1) / S;
           dc.OW2 = (o.iw - pw + S - 1) / S;
           if (dc.ntaps > 0) CVX_TRY(upload(e, e->static_allocs, e->static_bytes, &dc.taps, dt));
+          dc.halo_ok = cvx_halo_pack_taps(dt.data(), dc.ntaps, &dc.halo_pos, &dc.halo_wt);
+          dc.pointwise = dc.ntaps > 0 ? cvx_taps_pointwise(dt.data(), dc.ntaps) : 0;
         }
     }
     const int total = pd.Cout * T * pd.Cin_pad;
@@ -435,7 +448,10 @@ void fill_conv_fwd(const cvx_engine* e, int i, int B, ConvParams* cp) {
   cp->ntaps = c.ntaps;
   cp->taps = c.taps_fwd;
   cp->zeros = e->zero_page;
-  cp->halo_taps_ok = (o.k == 3 && o.dil == 1 && o.pad == 1) ? 1 : 0;
+  cp->halo_taps_ok = c.halo_ok ? 1 : 0;
+  cp->pointwise = c.pointwise;
+  cp->halo_pos = c.halo_pos;
+  cp->halo_wt = c.halo_wt;
 }
 
 }  // namespace
@@ -561,6 +577,7 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
 
   for (size_t i = 0; i < e->ops.size(); ++i) {
     const cvx_op_desc& o = e->ops[i];
+    e->cur_op = (int)i;
     if (o.type == CVX_OP_MAXPOOL5) {
       ProfScope ps(e, PROF_MISC, 0, 4.0 * B * o.ih * o.iw * o.in.c);
       CVX_TRY(cvx_maxpool5_fwd(make_view(e, o.in, false), make_view(e, o.out, false), B, o.ih, o.iw, o.in.c,
@@ -621,6 +638,7 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
       CVX_TRY(cvx_conv_igemm_launch(cp, st, nullptr));
     }
   }
+  e->cur_op = -1;
   e->fwd_train_done = training != 0;
   e->last_batch = B;
   return 0;
@@ -645,6 +663,7 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
 
   for (int i = (int)e->ops.size() - 1; i >= 0; --i) {
     const cvx_op_desc& o = e->ops[i];
+    e->cur_op = i;
     if (o.type == CVX_OP_MAXPOOL5) {
       ProfScope ps(e, PROF_MISC, 0, 7.0 * B * o.ih * o.iw * o.in.c);
       CVX_TRY(cvx_maxpool5_bwd(make_view(e, o.out, true), make_view(e, o.in, true), B, o.ih, o.iw, o.in.c, e->pool[i].idx,
@@ -713,7 +732,10 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
         cp.taps = dc.taps;
         cp.epi = CVX_EPI_PLAIN;
         cp.zeros = e->zero_page;
-        cp.halo_taps_ok = (o.k == 3 && o.dil == 1 && o.pad == 1 && o.stride == 1) ? 1 : 0;
+        cp.halo_taps_ok = dc.halo_ok ? 1 : 0;
+        cp.pointwise = dc.pointwise;
+        cp.halo_pos = dc.halo_pos;
+        cp.halo_wt = dc.halo_wt;
         cp.accumulate = c.in_accum;
         cp.out16 = gin.p;
         cp.out_ld = gin.ld;
@@ -751,6 +773,7 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
       CVX_TRY(cvx_conv_wgrad_launch(wp, e->side));
     }
   }
+  e->cur_op = -1;
   CVX_HIP(hipEventRecord(e->ev_join, e->side));  // join: the slab reduction needs every weight-gradient slab
   CVX_HIP(hipStreamWaitEvent(st, e->ev_join, 0));
   {
@@ -788,6 +811,30 @@ extern "C" int cvx_engine_profile_read(cvx_engine* e, int32_t n_classes, double*
     bytes[rec.cls] += rec.bytes;
     launches[rec.cls] += 1;
   }
+  e->ev_used = 0;
+  e->prof_recs.clear();
+  return 0;
+}
+
+extern "C" int cvx_debug_clock_buffer(void* buf) {
+  g_cvx_clk = (unsigned long long*)buf;
+  return 0;
+}
+
+extern "C" int cvx_engine_profile_dump(cvx_engine* e, const char* path) {
+  CVX_CHECK(e && path, "bad arguments");
+  CVX_HIP(hipStreamSynchronize(e->stream));
+  CVX_HIP(hipStreamSynchronize(e->side));
+  FILE* f = fopen(path, "w");
+  CVX_CHECK(f, "cannot open the profile dump file");
+  fprintf(f, "class,op,flops,bytes,ms\n");
+  for (size_t r = 0; r < e->prof_recs.size() && 2 * r + 1 < e->ev_used + 1; ++r) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, e->ev_pool[2 * r], e->ev_pool[2 * r + 1]) != hipSuccess) t = -1.f;
+    const auto& rec = e->prof_recs[r];
+    fprintf(f, "%d,%d,%.0f,%.0f,%.6f\n", rec.cls, rec.op, rec.flops, rec.bytes, t);
+  }
+  fclose(f);
   e->ev_used = 0;
   e->prof_recs.clear();
   return 0;
@@ -872,7 +919,8 @@ extern "C" int cvx_conv2d_nhwc(const void* x_f16, int32_t batch, int32_t ih, int
   cp.ntaps = k * k;
   cp.taps = dt;
   cp.zeros = zeros_after(dt, taps.size());
-  cp.halo_taps_ok = (k == 3 && dil == 1 && pad == 1) ? 1 : 0;
+  cp.halo_taps_ok = cvx_halo_pack_taps(taps.data(), (int)taps.size(), &cp.halo_pos, &cp.halo_wt) ? 1 : 0;
+  cp.pointwise = cvx_taps_pointwise(taps.data(), (int)taps.size());
   cp.out_ld = cout;
   cp.out_bstride = (long long)oh * ow * cout;
   if (mode == 0) {
@@ -939,7 +987,9 @@ extern "C" int cvx_conv2d_dgrad_nhwc(const void* dy_f16, int32_t batch, int32_t 
       cp.ntaps = (int)taps.size();
       cp.taps = dt;
       cp.zeros = zeros_after(dt, taps.size());
-      cp.halo_taps_ok = (k == 3 && dil == 1 && pad == 1 && stride == 1) ? 1 : 0;
+      cp.halo_taps_ok = cvx_halo_pack_taps(taps.data(), (int)taps.size(), &cp.halo_pos, &cp.halo_wt) ? 1 : 0;
+      cp.pointwise = cvx_taps_pointwise(taps.data(), (int)taps.size());
+  cp.pointwise = cvx_taps_pointwise(taps.data(), (int)taps.size());
       cp.epi = CVX_EPI_PLAIN;
       cp.out16 = (half_t*)dx_f16;
       cp.out_ld = cin;

@@ -90,6 +90,10 @@ class Engine:
         L.check(self.lib.cvx_engine_profile_read(self.handle, n, ms, fl, by, la), "cvx_engine_profile_read")
         return {name: dict(ms=ms[i], flops=fl[i], bytes=by[i], launches=int(la[i])) for i, name in enumerate(self.PROFILE_CLASSES)}
 
+    def profile_dump(self, path: str):
+        """Per-scope CSV (class, op, flops, bytes, ms) of the current profiling window."""
+        L.check(self.lib.cvx_engine_profile_dump(self.handle, str(path).encode()), "cvx_engine_profile_dump")
+
     def workspace_bytes(self) -> int:
         return int(self.lib.cvx_engine_workspace_bytes(self.handle))
 

@@ -97,6 +97,14 @@ int cvx_engine_debug_copy(cvx_engine* e, int32_t buf, int32_t which, void* dst, 
  * restarts the window. */
 int cvx_engine_profile(cvx_engine* e, int32_t enable);
 int cvx_engine_profile_read(cvx_engine* e, int32_t n_classes, double* ms, double* flops, double* bytes, int64_t* launches);
+/* Same window, per record instead of per class: writes one CSV line "class,op,flops,bytes,ms" per timed scope to
+ * `path` (op = index into the op list, -1 for whole-pass scopes) and restarts the window.  Tuning aid. */
+int cvx_engine_profile_dump(cvx_engine* e, const char* path);
+
+/* Tuning aid: while `buf` (device memory, 8 x u64 per workgroup of the largest launch) is set, thread 0 of every
+ * workgroup of the DMA-ring / halo convolution kernels stores 100 MHz wall-clock stamps at five phases
+ * (entry, operands issued, first K-step landed, K loop done, epilogue done).  NULL switches it off. */
+int cvx_debug_clock_buffer(void* buf);
 
 /* Bytes of device memory the engine currently owns (workspaces). */
 int64_t cvx_engine_workspace_bytes(const cvx_engine* e);
