@@ -30,9 +30,10 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <int WM, int WN, int MT, int NTW, int L2C>
+template <int WM, int WN, int MT, int NTW, int CIN_>
 struct HaloGeom {
-  static constexpr int CIN = 1 << L2C;
+  static constexpr int CIN = CIN_;                // gathered channels: 16, 32, 64, 128 (power of two) or 80, 144
+  static constexpr bool POW2 = (CIN & (CIN - 1)) == 0;
   static constexpr int P = CIN >> 3;              // 16-byte chunks per pixel
   static constexpr int TH = WM * MT;              // output rows per workgroup
   static constexpr int BN = 16 * NTW * WN;        // output channels per workgroup
@@ -47,11 +48,17 @@ struct HaloGeom {
   static constexpr int LDS_BYTES = (2 * PATCH_PIECES + 1) * 1024 + NSTEPS * STEP_HALVES * 2 + STAT_BYTES;
 };
 
-// P 16-byte chunks per pixel (2, 4, 8, 16): spreads 16 consecutive columns of one logical chunk over 64 banks
+// P 16-byte chunks per pixel.  Power-of-two P (2, 4, 8, 16): XOR swizzle that spreads 16 consecutive columns of one
+// logical chunk over all 64 banks.  P = 10 / 18 (80 / 144 channels): the pixel stride of 40 / 72 dwords already walks
+// the banks with period 8 -- at most 2-way conflicts -- and an XOR would not stay inside [0, P): no swizzle.
 template <int P>
 __device__ __forceinline__ int col_swz(int col) {
-  constexpr int SH = P == 2 ? 3 : P == 4 ? 2 : P == 8 ? 1 : 0;
-  return (col >> SH) & (P - 1);
+  if constexpr ((P & (P - 1)) != 0) {
+    return 0;
+  } else {
+    constexpr int SH = P == 2 ? 3 : P == 4 ? 2 : P == 8 ? 1 : 0;
+    return (col >> SH) & (P - 1);
+  }
 }
 
 // PERSISTENT workgroups: gridDim.x of them per channel block walk the (image, row-tile, column-tile) list with stride
@@ -63,10 +70,10 @@ __device__ __forceinline__ int col_swz(int col) {
 // overlaps the LDS fragment reads of later steps with the MFMAs of earlier ones) and the stores.  Only the first tile
 // waits for the weights, in NG groups of K-steps (counted vmcnt).  BN statistics are kept per lane across tiles and
 // folded once per workgroup.  Measured with cvx_debug_clock_buffer: the ring version paid 0.5 us per 32-wide K-step.
-template <int WM, int WN, int MT, int NTW, int L2C>
+template <int WM, int WN, int MT, int NTW, int CIN>
 __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p, int tiles_x, int tiles_y, int total_tiles) {
-  using G = HaloGeom<WM, WN, MT, NTW, L2C>;
-  constexpr int TH = G::TH, BN = G::BN, PB = G::PB, Cin = G::CIN, P = G::P, L2P = L2C - 3, NSTEPS = G::NSTEPS;
+  using G = HaloGeom<WM, WN, MT, NTW, CIN>;
+  constexpr int TH = G::TH, BN = G::BN, PB = G::PB, Cin = G::CIN, P = G::P, NSTEPS = G::NSTEPS;
   constexpr int PER_WAVE = (G::PATCH_PIECES + 3) / 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   half_t* patch0 = reinterpret_cast<half_t*>(smem);
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p, int 
       const int u = piece * 64 + lane;
       const half_t* g = p.zeros;
       if (u < G::UNITS) {
-        const int hp = u >> L2P, phys = u & (P - 1);
+        const int hp = u / P, phys = u - hp * P;
         const int hy = hp / HW, hx = hp - hy * HW;
         const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
         if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
@@ -128,7 +135,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p, int 
     }
     for (int s = 0; s < NSTEPS; ++s) {
       const int k = s * BK + kg * 8;
-      const int tapb = k >> L2C, cb = k & (Cin - 1);
+      const int tapb = k / Cin, cb = k - tapb * Cin;
       const bool kvalid = tapb < 9;
       const int wtap = (int)(wt_pack >> (4 * (kvalid ? tapb : 0))) & 15;
 #pragma unroll
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p, int 
   clk_mark(p, 1);
 
   // per-lane constant parts of the operand addresses (halves)
-  const int xbase = ((wm * MT) * HW + fr) << L2P;                   // patch unit of (row wm*MT, column fr)
+  const int xbase = ((wm * MT) * HW + fr) * P;                      // patch unit of (row wm*MT, column fr)
   const half_t* wbase = wts + lds_row_off(wn * NTW * 16 + fr, fq);  // + j*16 rows (swizzle term unchanged: 16 | row step)
   f4 st1[NTW], st2[NTW];
 #pragma unroll
@@ -160,6 +167,21 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p, int 
 #pragma unroll
       for (int j = 0; j < NTW; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
     const half_t* patch = patch0 + buf * (G::PATCH_PIECES * 512);
+    // output coordinates of this tile
+    const int tx = tile % tiles_x;
+    const int t2 = tile / tiles_x;
+    const int ty = t2 % tiles_y;
+    const int b = t2 / tiles_y;
+    long long out_off[MT], res_off[MT];
+    bool pvalid[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int oy = ty * TH + wm * MT + i, ox = tx * 16 + fr;
+      pvalid[i] = oy < H && ox < W;
+      const long long pix = pvalid[i] ? (long long)oy * W + ox : 0;
+      out_off[i] = (long long)b * p.out_bstride + pix * p.out_ld;
+      res_off[i] = (long long)b * p.res_bstride + pix * p.res_ld;
+    }
 
     static_for<0, NG>([&](auto gi) {
       constexpr int g = decltype(gi)::value;
@@ -190,20 +212,21 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p, int 
         constexpr int slot = (s - beg) % (PD + 1);
         // pixel operand: k-group 4s+fq -> (tap, channel chunk) -> patch address
         int tp, chunk;
-        if constexpr (L2C >= 5) {  // a 32-wide K-step lies inside one tap: tap and chunk base are step constants
-          tp = (BK * s) >> L2C;
-          chunk = (((BK * s) & (Cin - 1)) >> 3) + fq;
-        } else {  // Cin = 16: two taps per K-step
-          tp = 2 * s + (fq >> 1);
-          chunk = fq & 1;
+        if constexpr (G::POW2 && Cin >= BK) {  // a 32-wide K-step lies inside one tap: tap and chunk base are step constants
+          tp = (BK * s) / Cin;
+          chunk = (((BK * s) % Cin) >> 3) + fq;
+        } else {  // Cin = 16 (two taps per K-step) or 80 / 144 (a K-step may straddle a tap boundary): per k-group
+          const int k0 = BK * s + 8 * fq;
+          tp = k0 / Cin;
+          chunk = (k0 - tp * Cin) >> 3;
           if (tp > 8) tp = 0;  // weights of the K tail are zero; any valid address will do
         }
         const int code = (int)(pos_pack >> (4 * tp)) & 15;
         const int dh = code >> 2, dw = code & 3;  // already +1
         const int sw = col_swz<P>(fr + dw);
-        const half_t* xp = patch + ((xbase + ((dh * HW + dw) << L2P) + (chunk ^ sw)) << 3);
+        const half_t* xp = patch + ((xbase + (dh * HW + dw) * P + (chunk ^ sw)) << 3);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) xa[slot][i] = *reinterpret_cast<const h8*>(xp + ((i * HW) << (L2P + 3)));
+        for (int i = 0; i < MT; ++i) xa[slot][i] = *reinterpret_cast<const h8*>(xp + i * HW * P * 8);
 #pragma unroll
         for (int j = 0; j < NTW; ++j) wb[slot][j] = *reinterpret_cast<const h8*>(wbase + s * G::STEP_HALVES + j * 16 * BK);
       };
@@ -223,20 +246,6 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p, int 
     if (first) clk_mark(p, 3);
 
     // ---- stores ----
-    const int tx = tile % tiles_x;
-    const int t2 = tile / tiles_x;
-    const int ty = t2 % tiles_y;
-    const int b = t2 / tiles_y;
-    long long out_off[MT], res_off[MT];
-    bool pvalid[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int oy = ty * TH + wm * MT + i, ox = tx * 16 + fr;
-      pvalid[i] = oy < H && ox < W;
-      const long long pix = pvalid[i] ? (long long)oy * W + ox : 0;
-      out_off[i] = (long long)b * p.out_bstride + pix * p.out_ld;
-      res_off[i] = (long long)b * p.res_bstride + pix * p.res_ld;
-    }
     epilogue_tile<WM, WN, MT, NTW>(p, acc, out_off, res_off, pvalid, wn, fq, nblk, st1, st2);
     first = false;
   }
@@ -244,9 +253,9 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p, int 
   clk_mark(p, 4);
 }
 
-template <int WM, int WN, int MT, int NTW, int L2C>
+template <int WM, int WN, int MT, int NTW, int CIN>
 int launch_halo_c(const ConvParams& p, hipStream_t stream, int gy) {
-  using G = HaloGeom<WM, WN, MT, NTW, L2C>;
+  using G = HaloGeom<WM, WN, MT, NTW, CIN>;
   if constexpr (G::LDS_BYTES > 160 * 1024) {
     CVX_CHECK(false, "conv_halo: weight slice does not fit in LDS (launcher bug)");
   } else {
@@ -254,7 +263,7 @@ int launch_halo_c(const ConvParams& p, hipStream_t stream, int gy) {
     const int total = tiles_x * tiles_y * p.B;
     static bool attr_done = false;
     if (!attr_done) {
-      CVX_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<WM, WN, MT, NTW, L2C>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+      CVX_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<WM, WN, MT, NTW, CIN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
       attr_done = true;
     }
     // persistent: as many workgroups as fit on the 256 CUs at once (LDS-limited, at most CVX_HALO_OCC per CU), split
@@ -266,18 +275,20 @@ int launch_halo_c(const ConvParams& p, hipStream_t stream, int gy) {
     if (gx < 1) gx = 1;
     if (gx > total) gx = total;
     dim3 grid(gx, gy);
-    hipLaunchKernelGGL((conv_halo_kernel<WM, WN, MT, NTW, L2C>), grid, dim3(256), G::LDS_BYTES, stream, p, tiles_x, tiles_y, total);
+    hipLaunchKernelGGL((conv_halo_kernel<WM, WN, MT, NTW, CIN>), grid, dim3(256), G::LDS_BYTES, stream, p, tiles_x, tiles_y, total);
   }
   return 0;
 }
 
 template <int WM, int WN, int MT, int NTW>
-int launch_halo(const ConvParams& p, hipStream_t stream, int gy, int log2cin) {
-  switch (log2cin) {
-    case 4: return launch_halo_c<WM, WN, MT, NTW, 4>(p, stream, gy);
-    case 5: return launch_halo_c<WM, WN, MT, NTW, 5>(p, stream, gy);
-    case 6: return launch_halo_c<WM, WN, MT, NTW, 6>(p, stream, gy);
-    default: return launch_halo_c<WM, WN, MT, NTW, 7>(p, stream, gy);
+int launch_halo(const ConvParams& p, hipStream_t stream, int gy, int) {
+  switch (p.Cin) {
+    case 16: return launch_halo_c<WM, WN, MT, NTW, 16>(p, stream, gy);
+    case 32: return launch_halo_c<WM, WN, MT, NTW, 32>(p, stream, gy);
+    case 64: return launch_halo_c<WM, WN, MT, NTW, 64>(p, stream, gy);
+    case 80: return launch_halo_c<WM, WN, MT, NTW, 80>(p, stream, gy);
+    case 128: return launch_halo_c<WM, WN, MT, NTW, 128>(p, stream, gy);
+    default: return launch_halo_c<WM, WN, MT, NTW, 144>(p, stream, gy);
   }
 }
 
@@ -299,7 +310,7 @@ int launch_m(int NT, const ConvParams& p, hipStream_t st, int gy, int l2) {
 bool cvx_conv_halo_supported(const ConvParams& p) {
   static const bool off = getenv("CVX_NO_HALO") != nullptr;
   if (off || !p.zeros) return false;
-  if (!(p.Cin == 16 || p.Cin == 32 || p.Cin == 64 || p.Cin == 128)) return false;
+  if (!(p.Cin == 16 || p.Cin == 32 || p.Cin == 64 || p.Cin == 80 || p.Cin == 128 || p.Cin == 144)) return false;
   if (p.IS != 1 || p.OS != 1 || p.oph != 0 || p.opw != 0) return false;
   if (p.OH2 != p.IH || p.OW2 != p.IW || p.OWr != p.IW) return false;
   if (p.ntaps != 9) return false;
@@ -308,19 +319,24 @@ bool cvx_conv_halo_supported(const ConvParams& p) {
 
 // largest number of 16-channel tiles per workgroup whose weights (tiles*16 x 9*Cin fp16) stay within the LDS budget
 static int halo_tile_cap(int cin) {
-  static const int kb = getenv("CVX_HALO_WKB") ? atoi(getenv("CVX_HALO_WKB")) : 80;
+  static const int kb = getenv("CVX_HALO_WKB") ? atoi(getenv("CVX_HALO_WKB")) : 88;
   int cap = (kb * 1024) / (16 * 9 * cin * 2);
   return cap < 1 ? 1 : (cap > 8 ? 8 : cap);
 }
 
+// LDS bytes of HaloGeom<.., TH rows, BN channels, cin> (mirrors HaloGeom::LDS_BYTES)
+static int halo_lds_bytes(int th, int wm, int bn, int cin) {
+  const int pieces = ((th + 2) * HW * (cin / 8) + 63) / 64;
+  const int nsteps = (9 * cin + BK - 1) / BK;
+  return (2 * pieces + 1) * 1024 + nsteps * bn * BK * 2 + wm * bn * 2 * 4;
+}
+
 int cvx_conv_halo_launch(const ConvParams& p, hipStream_t stream) {
-  int l2 = 0;
-  while ((1 << l2) < p.Cin) ++l2;
   const int tiles = (p.Cout + 15) / 16;
   const int cap = halo_tile_cap(p.Cin);
   const long long hw = (long long)p.IH * p.IW;
   static const int allowed[] = {1, 2, 3, 4, 5, 6, 8};
-  auto pick = [&](int* gy_out) {  // fewest channel blocks within the cap, then the smallest allowed tile count covering them
+  auto pick = [&](int th, int* gy_out) {  // fewest channel blocks within the cap and the LDS, then the smallest allowed tile count
     int gy = (tiles + cap - 1) / cap, want = (tiles + gy - 1) / gy;
     int NT = 8;
     for (int a : allowed)
@@ -330,15 +346,18 @@ int cvx_conv_halo_launch(const ConvParams& p, hipStream_t stream) {
       }
     while (NT > cap) --NT;  // 7 is not compiled: cap 7 -> 6
     if (NT == 7) NT = 6;
+    while (NT > 1 && halo_lds_bytes(th, 4, NT * 16, p.Cin) > 160 * 1024) NT = (NT == 8) ? 6 : NT - 1;
     *gy_out = (tiles + NT - 1) / NT;
     return NT;
   };
-  if (hw >= 80 * 80 || hw * p.B >= 128 * 1024) {  // TH = 8
-    int gy, NT = pick(&gy);
-    CVX_TRY((launch_m<4, 2>(NT, p, stream, gy, l2)));
-  } else if (hw >= 40 * 40 || cap < 2) {  // TH = 4
-    int gy, NT = pick(&gy);
-    CVX_TRY((launch_m<4, 1>(NT, p, stream, gy, l2)));
+  int th = (hw >= 80 * 80 || hw * p.B >= 128 * 1024) ? 8 : ((hw >= 40 * 40 || cap < 2) ? 4 : 2);
+  if (th == 8 && halo_lds_bytes(8, 4, (cap < 2 ? 1 : 2) * 16, p.Cin) > 160 * 1024) th = 4;  // wide channels: the 10-row patches do not fit twice
+  if (th == 8) {
+    int gy, NT = pick(8, &gy);
+    CVX_TRY((launch_m<4, 2>(NT, p, stream, gy, 0)));
+  } else if (th == 4) {
+    int gy, NT = pick(4, &gy);
+    CVX_TRY((launch_m<4, 1>(NT, p, stream, gy, 0)));
   } else {  // TH = 2, 2x2 waves, BN = 32 * NTW
     const int pairs = (tiles + 1) / 2, pcap = cap / 2;
     int gy = (pairs + pcap - 1) / pcap;
@@ -346,10 +365,10 @@ int cvx_conv_halo_launch(const ConvParams& p, hipStream_t stream) {
     if (ntw > 4) ntw = 4;
     gy = (pairs + ntw - 1) / ntw;
     switch (ntw) {
-      case 1: CVX_TRY((launch_halo<2, 2, 1, 1>(p, stream, gy, l2))); break;
-      case 2: CVX_TRY((launch_halo<2, 2, 1, 2>(p, stream, gy, l2))); break;
-      case 3: CVX_TRY((launch_halo<2, 2, 1, 3>(p, stream, gy, l2))); break;
-      default: CVX_TRY((launch_halo<2, 2, 1, 4>(p, stream, gy, l2))); break;
+      case 1: CVX_TRY((launch_halo<2, 2, 1, 1>(p, stream, gy, 0))); break;
+      case 2: CVX_TRY((launch_halo<2, 2, 1, 2>(p, stream, gy, 0))); break;
+      case 3: CVX_TRY((launch_halo<2, 2, 1, 3>(p, stream, gy, 0))); break;
+      default: CVX_TRY((launch_halo<2, 2, 1, 4>(p, stream, gy, 0))); break;
     }
   }
   CVX_HIP(hipGetLastError());

@@ -53,7 +53,8 @@ class fp16_storage:
 # ---- single kernels ------------------------------------------------------------------------------------
 CONV_CASES = [(2, 16, 16, 16, 16, 3, 1), (2, 20, 20, 8, 16, 3, 2), (1, 24, 24, 32, 64, 3, 2), (2, 10, 10, 64, 144, 3, 1),
               (2, 12, 12, 48, 32, 1, 1), (1, 20, 20, 384, 256, 1, 1), (3, 7, 9, 80, 80, 3, 1), (1, 13, 13, 256, 512, 3, 2),
-              (1, 5, 5, 16, 16, 3, 1), (2, 33, 17, 96, 64, 1, 1)]
+              (1, 5, 5, 16, 16, 3, 1), (2, 33, 17, 96, 64, 1, 1), (2, 40, 40, 144, 64, 3, 1), (1, 80, 80, 80, 80, 3, 1),
+              (1, 80, 80, 128, 32, 3, 1), (4, 20, 20, 128, 128, 3, 1), (1, 160, 160, 32, 32, 1, 1), (2, 20, 20, 512, 256, 1, 1)]
 
 
 @pytest.mark.parametrize("B,H,W,Ci,Co,k,s", CONV_CASES)
