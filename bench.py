@@ -4,10 +4,15 @@ under torch.distributed.run (one rank per GPU, RCCL gradient all-reduce).  Rank 
 
 * workload = BASELINE.json configs[1]: YOLOv8-n, batch 32 per GPU, 640x640 synthetic images (U[0,1), seed 1),
   3 synthetic boxes per image, random-init weights (seed 0); inputs are resident in HBM before the timed region;
-* `roofline`: the dominant kernel family is the implicit-GEMM convolution (forward + data-gradient launches of
-  conv_igemm_kernel); achieved = algorithmic conv FLOPs of those launches / their summed kernel time, measured
-  with HIP events on the engine's launch stream over the timed steps (cvx_engine_profile); peak = MI355X dense
-  fp16 MFMA 2516.6 TFLOP/s.  The other kernel classes are reported alongside under "kernel_classes";
+* `roofline`: the dominant kernel family on the critical path is the implicit-GEMM convolution -- the forward and
+  data-gradient launches of conv_halo_kernel (3x3 stride 1), conv_pw_kernel (1x1) and conv_igemm_dma_kernel (the
+  rest).  YOLOv8-n's layers have 16..256 channels: their arithmetic intensity (48..290 FLOP/B) is below the MI355X
+  ridge (2516.6 TF/s / 8 TB/s = 315 FLOP/B), so HBM is the binding roof: achieved = algorithmic bytes per launch
+  (fp16 input view + output + weights) / average launch duration, measured with HIP events on
+  the engine's launch stream (cvx_engine_profile) in a window right after the timed steps; peak = 8 TB/s.  The MFMA
+  view of the same launches is reported beside it.  `traffic` = HBM bytes per launch from rocprofv3 PMC passes
+  (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_conv_traffic_v5.json -- counters cannot be read from inside this process).
+  The other kernel classes are reported alongside under "kernel_classes";
 * `cpu_baseline`: the CPU oracle (torch-CPU fp32 restatement of the reference, kind "port") timed on this
   host's cores on a bounded sample (batch 8 train steps), rank 0, N = 1 only.
 """
@@ -144,6 +149,12 @@ def main():
         conv_fl = sum(v["flops"] for v in conv.values())
         conv_launches = sum(v["launches"] for v in conv.values())
         achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        conv_by = sum(v["bytes"] for v in conv.values())
+        conv_gbs = conv_by / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0
+        traffic = None                                   # measured HBM bytes per launch of the same kernel family (PMC passes)
+        tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic_v5.json")
+        if os.path.exists(tpath) and B == 32 and args.model == "n":
+            traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
         classes = {}
         for k, v in prof.items():
             if v["launches"] == 0:
@@ -159,11 +170,14 @@ def main():
             "config": {"workload": f"YOLOv8-{args.model} train step (fwd + v8 loss + bwd + Adam), batch {B}/GPU, 640x640, nc=80, random init",
                        "global_batch": B * world, "parallelism": f"dp{world}", "loss_scale": cfg.engine.loss_scale,
                        "launch": "hipGraph replay" if use_graph else "eager"},
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (forward + data-gradient launches)",
-                         "achieved": round(achieved, 3), "peak": MFMA_FP16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_FP16_PEAK_TFLOPS, 5), "traffic": None,
+            "roofline": {"bound": "hbm",
+                         "kernel": "implicit-GEMM convolution: conv_halo_kernel + conv_pw_kernel + conv_igemm_dma_kernel, forward + data-gradient launches",
+                         "achieved": round(conv_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(conv_gbs / HBM_PEAK_GBS, 5),
+                         "traffic": traffic,
+                         "algorithmic_bytes_per_launch": round(conv_by / max(conv_launches, 1)),
                          "avg_launch_us": round(conv_ms * 1e3 / max(conv_launches, 1), 3), "launches_per_step": conv_launches // prof_steps,
-                         "algorithmic_flops_per_step": conv_fl / prof_steps},
+                         "mfma_view": {"achieved_tflops": round(achieved, 3), "peak_tflops": MFMA_FP16_PEAK_TFLOPS,
+                                       "frac": round(achieved / MFMA_FP16_PEAK_TFLOPS, 5), "algorithmic_flops_per_step": conv_fl / prof_steps}},
             "whole_step": {"train_tflops": round(value / world * TRAIN_GFLOP_PER_IMG / 1e3, 3),
                            "frac_of_mfma_peak": round(value / world * TRAIN_GFLOP_PER_IMG / 1e3 / MFMA_FP16_PEAK_TFLOPS, 5)},
             "kernel_classes": classes,
