@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcvx_engine.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class CvxError(RuntimeError):
@@ -33,6 +33,7 @@ class OpDesc(C.Structure):
         ("act", C.c_int32), ("needs_dgrad", C.c_int32), ("w_cin", C.c_int32),
         ("w_off", C.c_int64), ("gamma_off", C.c_int64), ("beta_off", C.c_int64), ("bias_off", C.c_int64),
         ("rmean_off", C.c_int64), ("rvar_off", C.c_int64),
+        ("lane", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 

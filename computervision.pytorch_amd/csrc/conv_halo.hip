@@ -271,7 +271,7 @@ int launch_halo_c(const ConvParams& p, hipStream_t stream, int gy) {
     static const int occ_cap = getenv("CVX_HALO_OCC") ? atoi(getenv("CVX_HALO_OCC")) : 4;
     int per_cu = (160 * 1024) / G::LDS_BYTES;
     per_cu = per_cu < 1 ? 1 : (per_cu > occ_cap ? occ_cap : per_cu);
-    int gx = (256 * per_cu) / gy;
+    int gx = (256 * per_cu) / gy / (g_cvx_grid_div > 0 ? g_cvx_grid_div : 1);
     if (gx < 1) gx = 1;
     if (gx > total) gx = total;
     dim3 grid(gx, gy);

@@ -77,6 +77,9 @@ inline bool cvx_halo_pack_taps(const ConvTap* t, int n, unsigned long long* pos,
 
 // tuning aid: when set (cvx_debug_clock_buffer), the DMA-ring and halo kernels store per-block phase timestamps there
 extern unsigned long long* g_cvx_clk;
+// share of the chip a persistent conv launch should size its grid for: 1 = all CUs, n = 1/n of them (set by the engine
+// around launches on concurrent lanes, so that side-by-side persistent kernels do not queue behind each other)
+extern int g_cvx_grid_div;
 // Launches the kernel; returns the number of M-blocks (= stats partial count) through *m_blocks.
 int cvx_conv_igemm_launch(const ConvParams& p, hipStream_t stream, int* m_blocks);
 // Number of M-blocks the launcher will use for M output pixels.

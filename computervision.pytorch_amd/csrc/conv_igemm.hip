@@ -236,6 +236,7 @@ void launch_nt(const ConvParams& p, hipStream_t stream, dim3 grid) {
 int cvx_conv_igemm_mblocks(long long M) { return (int)((M + BM - 1) / BM); }
 
 unsigned long long* g_cvx_clk = nullptr;
+int g_cvx_grid_div = 1;
 
 int cvx_conv_igemm_launch(const ConvParams& p_in, hipStream_t stream, int* m_blocks) {
   ConvParams p = p_in;

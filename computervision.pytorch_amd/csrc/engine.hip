@@ -95,6 +95,12 @@ struct cvx_engine {
   long long stat_half = 0;           // entries per half
   hipStream_t side = nullptr;    // weight gradients run here, concurrently with the data-gradient chain
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // execution lanes (cvx_op_desc.lane): independent tails of the op list, each on its own stream
+  enum { MAX_LANES = 4 };
+  hipStream_t lane_stream[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_lane_fork = nullptr, ev_lane_join[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+  int n_lanes = 1;         // 1 + highest lane in use
+  int first_lane_op = -1;  // index of the first op with lane > 0 (all later ops have lane > 0)
   float* slabs = nullptr;
   SlabDesc* d_slab = nullptr;
   BlockRef* d_slab_blocks = nullptr;
@@ -476,7 +482,16 @@ extern "C" int cvx_engine_create(cvx_engine** out, const cvx_buf_desc* bufs, int
   }
   int rc = build_static(e);
   if (rc == 0) {
-    if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
+    // The weight-gradient stream is background work: lowest priority, so the dispatcher prefers the main chain, and -- the
+    // reason it matters -- a priority class of its own keeps it off the main stream's hardware queue.  (With the default
+    // round-robin mapping onto 4 hardware queues, a process that had created other streams first, e.g. RCCL's, got main
+    // and side on ONE queue: the weight gradients ran serialised, 8.8 instead of 7.4 ms/step.)  CVX_SIDE_PRIO=0: plain stream.
+    static const bool side_prio = !(getenv("CVX_SIDE_PRIO") && atoi(getenv("CVX_SIDE_PRIO")) == 0);
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    hipError_t side_rc = side_prio ? hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio_least)
+                                   : hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
+    if (side_rc != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
       cvx_set_error("cvx_engine_create: could not create the side stream / events");
@@ -487,6 +502,29 @@ extern "C" int cvx_engine_create(cvx_engine** out, const cvx_buf_desc* bufs, int
         cvx_set_error("cvx_engine_create: could not create events");
         rc = -1;
       }
+    // execution lanes: validate (lane ops form the tail of the op list) and create their streams
+    // Measured on MI355X (bench.py): the three Detect levels on three streams are SLOWER than one stream (7.66 vs 7.42
+    // ms/step; grids sized for 1/2 or 1/3 of the chip: 7.72 / 7.91) -- the persistent conv kernels already fill the CUs and
+    // the weight-gradient stream fills the gaps -- so lanes are honoured only on request (CVX_LANES=1).
+    static const bool no_lanes = getenv("CVX_LANES") == nullptr;
+    for (size_t i = 0; rc == 0 && i < e->ops.size(); ++i) {
+      int lane = no_lanes ? 0 : e->ops[i].lane;
+      e->ops[i].lane = lane;
+      if (lane < 0 || lane >= cvx_engine::MAX_LANES || (lane == 0 && e->first_lane_op >= 0)) {
+        cvx_set_error("cvx_engine_create: lanes must be 0..3 and lane ops must follow every lane-0 op");
+        rc = -1;
+      }
+      if (lane > 0 && e->first_lane_op < 0) e->first_lane_op = (int)i;
+      if (lane + 1 > e->n_lanes) e->n_lanes = lane + 1;
+    }
+    if (rc == 0 && e->n_lanes > 1) {
+      if (hipEventCreateWithFlags(&e->ev_lane_fork, hipEventDisableTiming) != hipSuccess) rc = -1;
+      for (int l = 1; rc == 0 && l < e->n_lanes; ++l)
+        if (hipStreamCreateWithFlags(&e->lane_stream[l], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_lane_join[l], hipEventDisableTiming) != hipSuccess)
+          rc = -1;
+      if (rc != 0) cvx_set_error("cvx_engine_create: could not create the lane streams / events");
+    }
   }
   if (rc != 0) {
     free_pool(e->static_allocs);
@@ -508,6 +546,14 @@ extern "C" int cvx_engine_destroy(cvx_engine* e) {
     if (c.ev_dy) (void)hipEventDestroy(c.ev_dy);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  for (int l = 1; l < cvx_engine::MAX_LANES; ++l) {
+    if (e->lane_stream[l]) {
+      (void)hipStreamSynchronize(e->lane_stream[l]);
+      (void)hipStreamDestroy(e->lane_stream[l]);
+    }
+    if (e->ev_lane_join[l]) (void)hipEventDestroy(e->ev_lane_join[l]);
+  }
+  if (e->ev_lane_fork) (void)hipEventDestroy(e->ev_lane_fork);
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   free_pool(e->batch_allocs);
   free_pool(e->static_allocs);
@@ -555,6 +601,30 @@ extern "C" int cvx_engine_debug_copy(cvx_engine* e, int32_t buf, int32_t which, 
   return 0;
 }
 
+namespace {
+// lanes start after everything queued on the main stream so far ...
+int lanes_fork(cvx_engine* e) {
+  if (e->n_lanes <= 1) return 0;
+  CVX_HIP(hipEventRecord(e->ev_lane_fork, e->stream));
+  for (int l = 1; l < e->n_lanes; ++l) CVX_HIP(hipStreamWaitEvent(e->lane_stream[l], e->ev_lane_fork, 0));
+  return 0;
+}
+// ... and the main stream continues once every lane has drained
+int lanes_join(cvx_engine* e) {
+  if (e->n_lanes <= 1) return 0;
+  for (int l = 1; l < e->n_lanes; ++l) {
+    CVX_HIP(hipEventRecord(e->ev_lane_join[l], e->lane_stream[l]));
+    CVX_HIP(hipStreamWaitEvent(e->stream, e->ev_lane_join[l], 0));
+  }
+  return 0;
+}
+inline hipStream_t op_stream(const cvx_engine* e, const cvx_op_desc& o) {
+  static const int div = getenv("CVX_LANE_DIV") ? atoi(getenv("CVX_LANE_DIV")) : 0;  // 0: one share per lane
+  g_cvx_grid_div = o.lane > 0 ? (div > 0 ? div : e->n_lanes - 1) : 1;
+  return o.lane > 0 ? e->lane_stream[o.lane] : e->stream;
+}
+}  // namespace
+
 extern "C" int64_t cvx_engine_workspace_bytes(const cvx_engine* e) { return e ? e->batch_bytes + e->static_bytes : 0; }
 
 extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t batch, int32_t training, float* pred) {
@@ -578,14 +648,16 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
   for (size_t i = 0; i < e->ops.size(); ++i) {
     const cvx_op_desc& o = e->ops[i];
     e->cur_op = (int)i;
+    if ((int)i == e->first_lane_op) CVX_TRY(lanes_fork(e));  // the Detect levels run side by side from here on
+    hipStream_t st = op_stream(e, o);
     if (o.type == CVX_OP_MAXPOOL5) {
-      ProfScope ps(e, PROF_MISC, 0, 4.0 * B * o.ih * o.iw * o.in.c);
+      ProfScope ps(e, PROF_MISC, 0, 4.0 * B * o.ih * o.iw * o.in.c, st);
       CVX_TRY(cvx_maxpool5_fwd(make_view(e, o.in, false), make_view(e, o.out, false), B, o.ih, o.iw, o.in.c,
                                training ? e->pool[i].idx : nullptr, st));
       continue;
     }
     if (o.type == CVX_OP_UPSAMPLE2) {
-      ProfScope ps(e, PROF_MISC, 0, 10.0 * B * o.ih * o.iw * o.in.c);
+      ProfScope ps(e, PROF_MISC, 0, 10.0 * B * o.ih * o.iw * o.in.c, st);
       CVX_TRY(cvx_upsample2_fwd(make_view(e, o.in, false), make_view(e, o.out, false), B, o.ih, o.iw, o.in.c, st));
       continue;
     }
@@ -600,7 +672,7 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
       cp.out32 = pred + (long long)o.out.pix_off * pb.d.c + o.out.coff;
       cp.out_ld = pb.d.c;
       cp.out_bstride = A * pb.d.c;
-      ProfScope ps(e, PROF_CONV_FWD, conv_flops(o, B), conv_bytes(o, B) + 2.0 * M * C);
+      ProfScope ps(e, PROF_CONV_FWD, conv_flops(o, B), conv_bytes(o, B) + 2.0 * M * C, st);
       CVX_TRY(cvx_conv_igemm_launch(cp, st, nullptr));
       continue;
     }
@@ -615,10 +687,10 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
       cp.stats_replicas = CVX_STAT_REPLICAS;
       int P = 0;
       {
-        ProfScope ps(e, PROF_CONV_FWD, conv_flops(o, B), conv_bytes(o, B));
+        ProfScope ps(e, PROF_CONV_FWD, conv_flops(o, B), conv_bytes(o, B), st);
         CVX_TRY(cvx_conv_igemm_launch(cp, st, &P));
       }
-      ProfScope ps(e, PROF_BN_FWD, 0, (resv.p ? 6.0 : 4.0) * M * C);
+      ProfScope ps(e, PROF_BN_FWD, 0, (resv.p ? 6.0 : 4.0) * M * C, st);
       BnTrainArgs ta{c.stat_fwd,           e->params + o.gamma_off, e->params + o.beta_off, c.mean, c.invstd, e->stats + o.rmean_off,
                      e->stats + o.rvar_off, e->bn_eps,       e->bn_momentum};
       CVX_TRY(cvx_bn_silu_apply(c.ybuf, M, C, o.oh * o.ow, ta, outv, resv, st));
@@ -634,10 +706,11 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
       cp.res = resv.p;
       cp.res_ld = resv.ld;
       cp.res_bstride = resv.bstride;
-      ProfScope ps(e, PROF_CONV_FWD, conv_flops(o, B), conv_bytes(o, B));
+      ProfScope ps(e, PROF_CONV_FWD, conv_flops(o, B), conv_bytes(o, B), st);
       CVX_TRY(cvx_conv_igemm_launch(cp, st, nullptr));
     }
   }
+  CVX_TRY(lanes_join(e));
   e->cur_op = -1;
   e->fwd_train_done = training != 0;
   e->last_batch = B;
@@ -661,17 +734,27 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
   CVX_HIP(hipEventRecord(e->ev_fork, st));
   CVX_HIP(hipStreamWaitEvent(e->side, e->ev_fork, 0));
 
+  bool lanes_open = false;
+  if (e->first_lane_op >= 0) {  // the op list ends with the lane ops: the backward pass starts with them
+    CVX_TRY(lanes_fork(e));
+    lanes_open = true;
+  }
   for (int i = (int)e->ops.size() - 1; i >= 0; --i) {
     const cvx_op_desc& o = e->ops[i];
     e->cur_op = i;
+    if (lanes_open && o.lane == 0) {  // first main-chain op: its gradient inputs were written on the lanes
+      CVX_TRY(lanes_join(e));
+      lanes_open = false;
+    }
+    hipStream_t st = op_stream(e, o);
     if (o.type == CVX_OP_MAXPOOL5) {
-      ProfScope ps(e, PROF_MISC, 0, 7.0 * B * o.ih * o.iw * o.in.c);
+      ProfScope ps(e, PROF_MISC, 0, 7.0 * B * o.ih * o.iw * o.in.c, st);
       CVX_TRY(cvx_maxpool5_bwd(make_view(e, o.out, true), make_view(e, o.in, true), B, o.ih, o.iw, o.in.c, e->pool[i].idx,
                                e->pool[i].in_accum, st));
       continue;
     }
     if (o.type == CVX_OP_UPSAMPLE2) {
-      ProfScope ps(e, PROF_MISC, 0, 12.0 * B * o.ih * o.iw * o.in.c);
+      ProfScope ps(e, PROF_MISC, 0, 12.0 * B * o.ih * o.iw * o.in.c, st);
       CVX_TRY(cvx_upsample2_bwd(make_view(e, o.out, true), make_view(e, o.in, true), B, o.ih, o.iw, o.in.c, e->pool[i].in_accum, st));
       continue;
     }
@@ -684,13 +767,13 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
       dyv.p = dpred + (long long)o.out.pix_off * pb.d.c + o.out.coff;
       dyv.ld = pb.d.c;
       dyv.bstride = A * pb.d.c;
-      ProfScope ps(e, PROF_MISC, 0, 2.0 * M * C);
+      ProfScope ps(e, PROF_MISC, 0, 2.0 * M * C, st);
       CVX_TRY(cvx_colsum(M, C, hw, dyv, c.stat_bwd, inv_scale, e->grads + o.bias_off, st));
     } else {
       ViewDesc gout = make_view(e, o.out, true);
       ViewDesc gres = make_view(e, o.res, true);
       BnCoef k{c.mean, c.invstd, e->params + o.gamma_off, e->params + o.beta_off};
-      ProfScope ps(e, PROF_BN_BWD, 0, (gres.p ? 14.0 : 10.0) * M * C);
+      ProfScope ps(e, PROF_BN_BWD, 0, (gres.p ? 14.0 : 10.0) * M * C, st);
       CVX_TRY(cvx_bn_bwd_reduce(c.ybuf, M, C, hw, k, gout, c.stat_bwd, st));
       CVX_TRY(cvx_bn_bwd_apply(c.ybuf, M, C, hw, k, c.stat_bwd, inv_scale, e->grads + o.gamma_off, e->grads + o.beta_off, gout, c.dybuf,
                                gres, c.res_accum, st));
@@ -741,7 +824,7 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
         cp.out_ld = gin.ld;
         cp.out_bstride = gin.bstride;
         ProfScope ps(e, PROF_CONV_DGRAD, 2.0 * B * dc.OH2 * dc.OW2 * (double)o.in.c * dc.ntaps * C,
-                     (conv_bytes(o, B) + (c.in_accum ? 2.0 * B * o.ih * o.iw * o.in.c : 0.0)) / c.ndg);
+                     (conv_bytes(o, B) + (c.in_accum ? 2.0 * B * o.ih * o.iw * o.in.c : 0.0)) / c.ndg, st);
         CVX_TRY(cvx_conv_igemm_launch(cp, st, nullptr));
       }
     }
@@ -773,6 +856,7 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
       CVX_TRY(cvx_conv_wgrad_launch(wp, e->side));
     }
   }
+  if (lanes_open) CVX_TRY(lanes_join(e));
   e->cur_op = -1;
   CVX_HIP(hipEventRecord(e->ev_join, e->side));  // join: the slab reduction needs every weight-gradient slab
   CVX_HIP(hipStreamWaitEvent(st, e->ev_join, 0));

@@ -193,6 +193,7 @@ class Graph:
             d.w_cin = o.get("w_cin", 0)
             for f in ("w_off", "gamma_off", "beta_off", "bias_off", "rmean_off", "rvar_off"):
                 setattr(d, f, o.get(f, 0))
+            d.lane = o.get("lane", 0)
         return bufs, ops
 
 
@@ -297,11 +298,14 @@ def build_yolov8_graph(lay: ParamLayout, H: int, W: int) -> Graph:
         h1 = buf(hh, ww, cb + cc)
         hb = buf(hh, ww, cb)
         hc = buf(hh, ww, cc)
+        first = len(g.ops)
         conv(f"22.{lvl}.0", src, View(h1, 0, cb + cc), hh, ww)
         conv(f"22.{lvl}.1b", View(h1, 0, cb), View(hb, 0, cb), hh, ww)
         conv(f"22.{lvl}.1c", View(h1, cb, cc), View(hc, 0, cc), hh, ww)
         conv(f"22.{lvl}.2b", View(hb, 0, cb), View(pred, 0, 4 * REG_MAX, a_off), hh, ww)
         conv(f"22.{lvl}.2c", View(hc, 0, cc), View(pred, 4 * REG_MAX, lay.nc, a_off), hh, ww)
+        for op in g.ops[first:]:
+            op["lane"] = 1 + lvl          # the three Detect levels are independent: own HIP stream each (cvx_op_desc.lane)
         a_off += hh * ww
     g.taps = {0: (b0, 0, c64), 1: (b1, 0, c128), 2: (b2, 0, c128), 3: (b3, 0, c256), 4: L4[:3], 5: (b5, 0, c512), 6: L6[:3],
               7: (b7, 0, c1024), 8: (b8, 0, c1024), 9: L9[:3], 12: L12[:3], 15: (b15, 0, c256), 18: (b18, 0, c512),

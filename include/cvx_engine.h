@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define CVX_ABI_VERSION 1
+#define CVX_ABI_VERSION 2
 
 const char* cvx_last_error(void);
 int cvx_abi_version(void);
@@ -53,6 +53,11 @@ typedef struct {
   int64_t gamma_off, beta_off; /* BN affine (param arena) */
   int64_t bias_off;            /* CVX_ACT_BIAS */
   int64_t rmean_off, rvar_off; /* BN running statistics (stats arena) */
+  /* Execution lane: 0 = the main chain; 1..3 = independent tails of the op list (the three Detect levels) that the
+   * engine runs on their own HIP streams, forked after the last lane-0 op of the forward pass and joined before the
+   * caller's next work (backward: forked first, joined before the first lane-0 op).  Lane ops must follow all lane-0 ops. */
+  int32_t lane;
+  int32_t reserved_;
 } cvx_op_desc;
 
 typedef struct cvx_engine cvx_engine;
