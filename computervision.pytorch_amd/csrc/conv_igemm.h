@@ -111,5 +111,17 @@ struct WgradParams {
   float* slabs;         // [nsplit][Cout][ntaps*Cin]
   int nsplit;
   int cin_pad16;  // Cin rounded up to 16 (column tiling unit)
+  int std3x3;     // 1 when taps[t] == (t/3-1, t%3-1, wtap t), t = 0..8: the register-tile kernel (conv_wgrad_halo.hip) applies
 };
 int cvx_conv_wgrad_launch(const WgradParams& p, hipStream_t stream);
+// 3x3 stride-1 kernel with the whole (co block x 9 taps x ci block) tile in registers (conv_wgrad_halo.hip)
+bool cvx_conv_wgrad_halo_supported(const WgradParams& p);
+void cvx_conv_wgrad_halo_grid(int cout, int cin, int* gx, int* gy);
+int cvx_conv_wgrad_halo_tiles(int B, int OH, int OW);
+int cvx_conv_wgrad_halo_launch(const WgradParams& p, hipStream_t stream);
+inline int cvx_taps_std3x3(const ConvTap* t, int n) {
+  if (n != 9) return 0;
+  for (int i = 0; i < 9; ++i)
+    if (t[i].dh != i / 3 - 1 || t[i].dw != i % 3 - 1 || t[i].wtap != i) return 0;
+  return 1;
+}

@@ -6,13 +6,13 @@
 // pixel-major in memory (NHWC), i.e. the reduction index is the SLOW index of both -- so the tiles are
 // staged into LDS as they lie ([pixel][channel], 16-byte loads) and the MFMA fragments are fetched
 // with the gfx950 transposing LDS read ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group).
-// The pixel range is split over blockIdx.z; every split writes its own fp32 slab (plain stores,
+// The pixel range is split over the workgroups (nsplit ranges); every split writes its own fp32 slab (plain stores,
 // deterministic), summed into the gradient arena by cvx_reduce_slabs.
 #include "conv_igemm.h"
 
 namespace {
 
-constexpr int PK = 64;    // pixels per iteration (two MFMA K-steps)
+constexpr int PK = 128;   // pixels per iteration (four MFMA K-steps between barriers)
 constexpr int RPAD = 8;   // halves of padding per LDS row (keeps tr reads <= 2-way, rows 16-B aligned)
 
 typedef s4 __attribute__((address_space(3))) * lds_s4_ptr;
@@ -28,7 +28,7 @@ __device__ __forceinline__ h8 tr_frag(const half_t* tile, int row_stride, int p0
 }
 
 template <int TI, int TJ, int WI, int WJ>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, long long pix_per_split) {
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, long long pix_per_split, int gx, int gy) {
   static_assert(WI * WJ == 4, "4 waves");
   constexpr int CO_B = 16 * TI * WI;
   constexpr int J_B = 16 * TJ * WJ;
@@ -40,11 +40,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, lo
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave / WJ, wj = wave % WJ;
-  const int co0 = blockIdx.x * CO_B;
-  const int j0 = blockIdx.y * J_B;
+  // XCD-aware block order: workgroups are dealt to the 8 XCDs round-robin by linear id, and every (co, j) tile of one
+  // pixel split reads the same dy / x pixels -- so all tiles of split z are given ids congruent to z mod 8: they share
+  // one XCD's L2 instead of fetching the operands into eight.
+  const int ntiles = gx * gy;
+  const int lin = blockIdx.x;
+  const int q = lin >> 3;
+  const int tile = q % ntiles;
+  const int bz = (q / ntiles) * 8 + (lin & 7);
+  if (bz >= p.nsplit) return;
+  const int bx = tile % gx, by = tile / gx;
+  const int co0 = bx * CO_B;
+  const int j0 = by * J_B;
   const long long ohw = (long long)p.OH * p.OW;
   const long long M = (long long)p.B * ohw;
-  const long long m_begin = (long long)blockIdx.z * pix_per_split;
+  const long long m_begin = (long long)bz * pix_per_split;
   const long long m_end = min(M, m_begin + pix_per_split);
   const int Jtot = p.ntaps * p.cin_pad16;
 
@@ -138,7 +148,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, lo
   }
 
   // ---- write the slab: lane holds column j = ..+(lane&15), rows co = ..+4*(lane>>4)+r ----
-  float* slab = p.slabs + (long long)blockIdx.z * p.Cout * Jtot;
+  float* slab = p.slabs + (long long)bz * p.Cout * Jtot;
   const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
   for (int a = 0; a < TI; ++a) {
@@ -161,8 +171,9 @@ void launch_cfg(const WgradParams& p, hipStream_t st) {
   const long long M = (long long)p.B * p.OH * p.OW;
   long long per = (M + p.nsplit - 1) / p.nsplit;
   per = ((per + PK - 1) / PK) * PK;
-  dim3 grid(cvx_cdiv(p.Cout, CO_B), cvx_cdiv(p.ntaps * p.cin_pad16, J_B), p.nsplit);
-  hipLaunchKernelGGL((conv_wgrad_kernel<TI, TJ, WI, WJ>), grid, dim3(256), 0, st, p, per);
+  const int gx = cvx_cdiv(p.Cout, CO_B), gy = cvx_cdiv(p.ntaps * p.cin_pad16, J_B);
+  const int zpad = (p.nsplit + 7) / 8 * 8;  // surplus workgroups (split >= nsplit) exit at once
+  hipLaunchKernelGGL((conv_wgrad_kernel<TI, TJ, WI, WJ>), dim3(gx * gy * zpad), dim3(256), 0, st, p, per, gx, gy);
 }
 
 }  // namespace
@@ -172,6 +183,7 @@ int cvx_conv_wgrad_launch(const WgradParams& p, hipStream_t st) {
   CVX_CHECK(p.cin_pad16 % 16 == 0 && p.cin_pad16 >= p.Cin, "wgrad: cin_pad16");
   CVX_CHECK(p.nsplit >= 1 && p.ntaps >= 1 && p.ntaps <= CVX_MAX_TAPS, "wgrad: nsplit/ntaps");
   CVX_CHECK(((uintptr_t)p.x % 16) == 0 && ((uintptr_t)p.dy % 16) == 0, "wgrad: operands must be 16-byte aligned");
+  if (cvx_conv_wgrad_halo_supported(p)) return cvx_conv_wgrad_halo_launch(p, st);
   if (p.Cout <= 16)
     launch_cfg<1, 3, 1, 4>(p, st);
   else if (p.Cout <= 32)

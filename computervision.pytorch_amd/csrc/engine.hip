@@ -33,6 +33,7 @@ struct ConvRt {
   ConvTap* taps_fwd = nullptr;
   bool halo_ok = false;
   int pointwise = 0;
+  int std3x3 = 0;
   unsigned long long halo_pos = 0, halo_wt = 0;
   int ntaps = 0;
   DgClass dg[16];
@@ -231,6 +232,7 @@ int build_static(cvx_engine* e) {
     CVX_TRY(upload(e, e->static_allocs, e->static_bytes, &c.taps_fwd, taps));
     c.halo_ok = cvx_halo_pack_taps(taps.data(), T, &c.halo_pos, &c.halo_wt);
     c.pointwise = cvx_taps_pointwise(taps.data(), T);
+    c.std3x3 = cvx_taps_std3x3(taps.data(), T);
     // shadow weights
     PackDesc pd;
     pd.src_off = o.w_off;
@@ -393,6 +395,28 @@ int plan_batch(cvx_engine* e, int B, bool training) {
       static const long long ns_cap = getenv("CVX_NSPLIT_CAP") ? atoll(getenv("CVX_NSPLIT_CAP")) : 512;
       ns = std::min(ns, std::max<long long>(1, (slab_cap_mb << 20) / (slab_elems * 4)));
       ns = std::min<long long>(ns, ns_cap);
+      {  // 3x3 stride-1 layers take the register-tile kernel: few, fat workgroups per pixel split
+        WgradParams probe;
+        memset(&probe, 0, sizeof(probe));
+        probe.std3x3 = c.std3x3;
+        probe.stride = o.stride;
+        probe.ntaps = c.ntaps;
+        probe.Cin = c.cin_g;
+        probe.IH = o.ih;
+        probe.IW = o.iw;
+        probe.OH = o.oh;
+        probe.OW = o.ow;
+        if (cvx_conv_wgrad_halo_supported(probe)) {
+          int gx, gy;
+          cvx_conv_wgrad_halo_grid(C, c.cin_g, &gx, &gy);
+          const long long ptiles = cvx_conv_wgrad_halo_tiles(B, o.oh, o.ow);
+          static const long long wh_blocks = getenv("CVX_WH_BLOCKS") ? atoll(getenv("CVX_WH_BLOCKS")) : 128;  // measured: 128 beats 64/256/512 (slab volume vs. parallelism)
+          static const long long wh_slab_mb = getenv("CVX_WH_SLAB_MB") ? atoll(getenv("CVX_WH_SLAB_MB")) : 16;
+          ns = std::max<long long>(1, wh_blocks / ((long long)gx * gy));
+          ns = std::min(ns, ptiles);
+          ns = std::min(ns, std::max<long long>(1, (wh_slab_mb << 20) / (slab_elems * 4)));
+        }
+      }
       c.nsplit = (int)ns;
       c.slab_off = slab_total;
       slab_total += ns * slab_elems;
@@ -852,8 +876,10 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
       wp.slabs = e->slabs + c.slab_off;
       wp.nsplit = c.nsplit;
       wp.cin_pad16 = c.cin_pad16;
+      wp.std3x3 = c.std3x3;
       ProfScope ps(e, PROF_CONV_WGRAD, conv_flops(o, B), conv_bytes(o, B) + 4.0 * c.nsplit * C * c.ntaps * c.cin_pad16, e->side);
-      CVX_TRY(cvx_conv_wgrad_launch(wp, e->side));
+      static const bool skip_wgrad = getenv("CVX_DBG_SKIP_WGRAD") != nullptr;  // timing experiment only: WRONG gradients
+      if (!skip_wgrad) CVX_TRY(cvx_conv_wgrad_launch(wp, e->side));
     }
   }
   if (lanes_open) CVX_TRY(lanes_join(e));
@@ -1125,6 +1151,7 @@ extern "C" int cvx_conv2d_wgrad_nhwc(const void* x_f16, const void* dy_f16, int3
   wp.slabs = (float*)workspace;
   wp.nsplit = (int)std::min<long long>(std::max<long long>(1, M / 256), 64);
   wp.cin_pad16 = round_up(cin, 16);
+  wp.std3x3 = cvx_taps_std3x3(taps.data(), (int)taps.size());
   int rc = cvx_conv_wgrad_launch(wp, st);
   if (rc == 0) {
     // reduce the slabs into dw (overwrite): zero, then the table-driven reducer with one descriptor
