@@ -36,11 +36,15 @@ __device__ __forceinline__ h8 tr_frag8(const half_t* first_pixel, int row_stride
   return __builtin_bit_cast(h8, v);
 }
 
-template <int CO_T, int CI_T>
-__global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradParams p, int tiles_x, int tiles_y, int total_tiles, int tiles_per_split) {
+// TPB taps per workgroup: 9 (small tiles: everything in one workgroup) or 3 (one kernel row dh per workgroup: a third of
+// the accumulators -- two waves per SIMD and room to pipeline the fragment reads -- and three times the workgroups per
+// pixel split, i.e. a third of the slab volume for the same parallelism; the patch and the dy tile are loaded 3 times).
+template <int CO_T, int CI_T, int TPB>
+__global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradParams p, int tiles_x, int tiles_y, int total_tiles, int tiles_per_split,
+                                                              int gy_ci) {
   constexpr int CO_B = 16 * CO_T, CI_B = 16 * CI_T;
   constexpr int SD = CO_B + RPAD, SX = CI_B + RPAD;  // LDS pixel-row strides (halves)
-  constexpr int NJ = 9 * CI_T;                       // column tiles (tap, ci tile)
+  constexpr int NJ = TPB * CI_T;                     // column tiles (tap, ci tile) of this workgroup
   constexpr int JW = (NJ + 3) / 4;                   // per wave
   constexpr int XU = (TH + 2) * PW * (CI_B / 8);     // 16-byte units of the x patch
   constexpr int DU = TH * 16 * (CO_B / 8);           // ... of the dy tile
@@ -50,7 +54,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradParams 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lg = lane & 15, fq = lane >> 4;
-  const int co0 = blockIdx.x * CO_B, ci0 = blockIdx.y * CI_B;
+  const int co0 = blockIdx.x * CO_B, ci0 = (blockIdx.y % gy_ci) * CI_B;
+  const int tap0 = (blockIdx.y / gy_ci) * TPB;
   const int t_begin = blockIdx.z * tiles_per_split;
   const int t_end = min(total_tiles, t_begin + tiles_per_split);
   const int H = p.OH, W = p.OW;  // stride 1, pad 1: input and output sizes agree
@@ -123,7 +128,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradParams 
   for (int jj = 0; jj < JW; ++jj) {
     const int jt = wave * JW + jj;
     jok[jj] = jt < NJ;
-    const int tap = jok[jj] ? jt / CI_T : 0, cit = jok[jj] ? jt - tap * CI_T : 0;
+    const int tl = jok[jj] ? jt / CI_T : 0, cit = jok[jj] ? jt - tl * CI_T : 0;
+    const int tap = tap0 + tl;
     const int dh = tap / 3, dw = tap - dh * 3;  // already +1 (standard 3x3 table: dh-1, dw-1)
     xoff[jj] = (dh * PW + dw) * SX + cit * 16;
   }
@@ -160,7 +166,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradParams 
   for (int jj = 0; jj < JW; ++jj) {
     const int jt = wave * JW + jj;
     if (jt >= NJ) continue;
-    const int tap = jt / CI_T, cit = jt - tap * CI_T;
+    const int tl = jt / CI_T, cit = jt - tl * CI_T;
+    const int tap = tap0 + tl;
     const int ci = ci0 + cit * 16 + lg;
     if (ci >= p.cin_pad16) continue;
     const int j = tap * p.cin_pad16 + ci;
@@ -180,7 +187,11 @@ int launch_wh(const WgradParams& p, hipStream_t st, int gx, int gy) {
   const int tiles_x = (p.OW + 15) / 16, tiles_y = (p.OH + TH - 1) / TH;
   const int total = tiles_x * tiles_y * p.B;
   const int per = (total + p.nsplit - 1) / p.nsplit;
-  hipLaunchKernelGGL((conv_wgrad_halo_kernel<CO_T, CI_T>), dim3(gx, gy, p.nsplit), dim3(256), 0, st, p, tiles_x, tiles_y, total, per);
+  if constexpr (CO_T * CI_T >= 8) {  // must mirror cvx_conv_wgrad_halo_grid
+    hipLaunchKernelGGL((conv_wgrad_halo_kernel<CO_T, CI_T, 3>), dim3(gx, gy * 3, p.nsplit), dim3(256), 0, st, p, tiles_x, tiles_y, total, per, gy);
+  } else {
+    hipLaunchKernelGGL((conv_wgrad_halo_kernel<CO_T, CI_T, 9>), dim3(gx, gy, p.nsplit), dim3(256), 0, st, p, tiles_x, tiles_y, total, per, gy);
+  }
   return 0;
 }
 
@@ -210,17 +221,17 @@ bool cvx_conv_wgrad_halo_supported(const WgradParams& p) {
   return !off && p.std3x3 && p.stride == 1 && p.ntaps == 9 && p.Cin >= 16 && p.IH == p.OH && p.IW == p.OW;
 }
 
+// workgroups per pixel split: gx channel blocks x gy (input-channel blocks x tap groups)
 void cvx_conv_wgrad_halo_grid(int cout, int cin, int* gx, int* gy) {
   *gx = cvx_cdiv(cout, 16 * pick_tiles(cout));
-  *gy = cvx_cdiv(cin, 16 * pick_tiles(cin));
+  *gy = cvx_cdiv(cin, 16 * pick_tiles(cin)) * (pick_tiles(cout) * pick_tiles(cin) >= 8 ? 3 : 1);
 }
 
 int cvx_conv_wgrad_halo_tiles(int B, int OH, int OW) { return ((OW + 15) / 16) * ((OH + TH - 1) / TH) * B; }
 
 int cvx_conv_wgrad_halo_launch(const WgradParams& p, hipStream_t st) {
   const int cot = pick_tiles(p.Cout), cit = pick_tiles(p.Cin);
-  int gx, gy;
-  cvx_conv_wgrad_halo_grid(p.Cout, p.Cin, &gx, &gy);
+  const int gx = cvx_cdiv(p.Cout, 16 * cot), gy = cvx_cdiv(p.Cin, 16 * cit);  // gy: input-channel blocks only
   switch (cot) {
     case 1: CVX_TRY((launch_wh_ci<1>(cit, p, st, gx, gy))); break;
     case 2: CVX_TRY((launch_wh_ci<2>(cit, p, st, gx, gy))); break;
