@@ -12,6 +12,13 @@
 #include "conv_igemm.h"
 #include "misc_ops.h"
 
+// events that only order this process's own streams on one device: no timing, no system-scope fence (the marker packet
+// between two main-chain kernels costs ~6.5 us with the default flags -- 53 of them per backward pass)
+static unsigned cvx_event_flags() {
+  static const bool sysfence = getenv("CVX_EVENT_SYSFENCE") != nullptr;
+  return hipEventDisableTiming | (sysfence ? 0u : hipEventDisableSystemFence);
+}
+
 // ---------------------------------------------------------------------------------------------
 static thread_local std::string g_last_error;
 void cvx_set_error(const std::string& msg) { g_last_error = msg; }
@@ -516,13 +523,13 @@ extern "C" int cvx_engine_create(cvx_engine** out, const cvx_buf_desc* bufs, int
     hipError_t side_rc = side_prio ? hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio_least)
                                    : hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
     if (side_rc != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&e->ev_fork, cvx_event_flags()) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_join, cvx_event_flags()) != hipSuccess) {
       cvx_set_error("cvx_engine_create: could not create the side stream / events");
       rc = -1;
     }
     for (size_t i = 0; rc == 0 && i < e->ops.size(); ++i)
-      if (e->ops[i].type == CVX_OP_CONV && hipEventCreateWithFlags(&e->conv[i].ev_dy, hipEventDisableTiming) != hipSuccess) {
+      if (e->ops[i].type == CVX_OP_CONV && hipEventCreateWithFlags(&e->conv[i].ev_dy, cvx_event_flags()) != hipSuccess) {
         cvx_set_error("cvx_engine_create: could not create events");
         rc = -1;
       }
@@ -542,10 +549,10 @@ extern "C" int cvx_engine_create(cvx_engine** out, const cvx_buf_desc* bufs, int
       if (lane + 1 > e->n_lanes) e->n_lanes = lane + 1;
     }
     if (rc == 0 && e->n_lanes > 1) {
-      if (hipEventCreateWithFlags(&e->ev_lane_fork, hipEventDisableTiming) != hipSuccess) rc = -1;
+      if (hipEventCreateWithFlags(&e->ev_lane_fork, cvx_event_flags()) != hipSuccess) rc = -1;
       for (int l = 1; rc == 0 && l < e->n_lanes; ++l)
         if (hipStreamCreateWithFlags(&e->lane_stream[l], hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&e->ev_lane_join[l], hipEventDisableTiming) != hipSuccess)
+            hipEventCreateWithFlags(&e->ev_lane_join[l], cvx_event_flags()) != hipSuccess)
           rc = -1;
       if (rc != 0) cvx_set_error("cvx_engine_create: could not create the lane streams / events");
     }
