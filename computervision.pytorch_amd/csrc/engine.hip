@@ -765,6 +765,28 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
   CVX_HIP(hipEventRecord(e->ev_fork, st));
   CVX_HIP(hipStreamWaitEvent(e->side, e->ev_fork, 0));
 
+  // weight gradients are launched on the side stream in batches: one event record on the producing stream per batch
+  struct PendingWgrad {
+    WgradParams wp;
+    double flops, bytes;
+    int op;
+  };
+  std::vector<PendingWgrad> pending;
+  static const int wg_batch_env = getenv("CVX_WGRAD_BATCH") ? atoi(getenv("CVX_WGRAD_BATCH")) : 3;
+  const int wg_batch = (e->first_lane_op >= 0 || wg_batch_env < 1) ? 1 : wg_batch_env;  // lanes: every op has its own producer stream
+  static const bool skip_wgrad = getenv("CVX_DBG_SKIP_WGRAD") != nullptr;  // timing experiment only: WRONG gradients
+  auto flush_wgrads = [&](hipEvent_t ev, hipStream_t producer) -> int {
+    if (pending.empty()) return 0;
+    CVX_HIP(hipEventRecord(ev, producer));
+    CVX_HIP(hipStreamWaitEvent(e->side, ev, 0));
+    for (const PendingWgrad& w : pending) {
+      e->cur_op = w.op;
+      ProfScope ps(e, PROF_CONV_WGRAD, w.flops, w.bytes, e->side);
+      if (!skip_wgrad) CVX_TRY(cvx_conv_wgrad_launch(w.wp, e->side));
+    }
+    pending.clear();
+    return 0;
+  };
   bool lanes_open = false;
   if (e->first_lane_op >= 0) {  // the op list ends with the lane ops: the backward pass starts with them
     CVX_TRY(lanes_fork(e));
@@ -812,10 +834,8 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
       dyv.ld = C;
       dyv.bstride = (long long)hw * C;
     }
-    if (o.act != CVX_ACT_BIAS) {  // dy of this layer is complete: the side stream may start its weight gradient
-      CVX_HIP(hipEventRecord(c.ev_dy, st));
-      CVX_HIP(hipStreamWaitEvent(e->side, c.ev_dy, 0));
-    }
+    // dy of this layer is complete here; the side stream learns it through an event, recorded once per `wg_batch`
+    // layers (a marker packet between two main-chain kernels costs ~5 us, see flush_wgrads below)
     // ---- data gradient: dx = dy (*) W^T, one launch per output phase of the forward stride ----
     if (o.needs_dgrad) {
       ViewDesc gin = make_view(e, o.in, true);
@@ -884,12 +904,13 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
       wp.nsplit = c.nsplit;
       wp.cin_pad16 = c.cin_pad16;
       wp.std3x3 = c.std3x3;
-      ProfScope ps(e, PROF_CONV_WGRAD, conv_flops(o, B), conv_bytes(o, B) + 4.0 * c.nsplit * C * c.ntaps * c.cin_pad16, e->side);
-      static const bool skip_wgrad = getenv("CVX_DBG_SKIP_WGRAD") != nullptr;  // timing experiment only: WRONG gradients
-      if (!skip_wgrad) CVX_TRY(cvx_conv_wgrad_launch(wp, e->side));
+      pending.push_back({wp, conv_flops(o, B), conv_bytes(o, B) + 4.0 * c.nsplit * C * c.ntaps * c.cin_pad16, i});
+      if ((int)pending.size() >= wg_batch || i == 0 || (lanes_open && e->ops[i].lane != (i > 0 ? e->ops[i - 1].lane : 0)))
+        CVX_TRY(flush_wgrads(c.ev_dy, st));
     }
   }
   if (lanes_open) CVX_TRY(lanes_join(e));
+  CVX_TRY(flush_wgrads(e->ev_fork, st));  // (non-conv first ops: nothing pending in practice)
   e->cur_op = -1;
   CVX_HIP(hipEventRecord(e->ev_join, e->side));  // join: the slab reduction needs every weight-gradient slab
   CVX_HIP(hipStreamWaitEvent(st, e->ev_join, 0));
