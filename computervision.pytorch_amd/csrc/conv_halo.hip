@@ -30,22 +30,23 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <int WM, int WN, int MT, int NTW, int CIN_>
+template <int WM, int WN, int MT, int NTW, int CIN_, int HV_ = 1>
 struct HaloGeom {
+  static constexpr int HV = HV_;                  // tile streams per workgroup (4 waves each) sharing the resident weights
   static constexpr int CIN = CIN_;                // gathered channels: 16, 32, 64, 128 (power of two) or 80, 144
   static constexpr bool POW2 = (CIN & (CIN - 1)) == 0;
   static constexpr int P = CIN >> 3;              // 16-byte chunks per pixel
   static constexpr int TH = WM * MT;              // output rows per workgroup
   static constexpr int BN = 16 * NTW * WN;        // output channels per workgroup
   static constexpr int NPIECE = BN / 16;          // 1 KiB weight pieces (16 rows x 64 B) per K-step
-  static constexpr int PB = (NPIECE + 3) / 4;     // weight DMA instructions per wave per K-step
+  static constexpr int PB = (NPIECE + 4 * HV_ - 1) / (4 * HV_);  // weight DMA instructions per wave per K-step
   static constexpr int STEP_HALVES = BN * BK;     // LDS halves of one K-step of weights
   static constexpr int NSTEPS = (9 * CIN + BK - 1) / BK;
   static constexpr int UNITS = (TH + 2) * HW * P;  // 16-byte units of the patch
   static constexpr int PATCH_PIECES = (UNITS + 63) / 64;
-  static constexpr int STAT_BYTES = WM * BN * 2 * 4;
-  // 2 patch buffers (+1 dump piece) | all weights of the workgroup's BN channels | stat scratch
-  static constexpr int LDS_BYTES = (2 * PATCH_PIECES + 1) * 1024 + NSTEPS * STEP_HALVES * 2 + STAT_BYTES;
+  static constexpr int STAT_BYTES = HV_ * WM * BN * 2 * 4;
+  // 2 patch buffers per tile stream (+1 dump piece) | all weights of the workgroup's BN channels | stat scratch
+  static constexpr int LDS_BYTES = (2 * HV_ * PATCH_PIECES + 1) * 1024 + NSTEPS * STEP_HALVES * 2 + STAT_BYTES;
 };
 
 // P 16-byte chunks per pixel.  Power-of-two P (2, 4, 8, 16): XOR swizzle that spreads 16 consecutive columns of one
@@ -70,19 +71,22 @@ __device__ __forceinline__ int col_swz(int col) {
 // overlaps the LDS fragment reads of later steps with the MFMAs of earlier ones) and the stores.  Only the first tile
 // waits for the weights, in NG groups of K-steps (counted vmcnt).  BN statistics are kept per lane across tiles and
 // folded once per workgroup.  Measured with cvx_debug_clock_buffer: the ring version paid 0.5 us per 32-wide K-step.
-template <int WM, int WN, int MT, int NTW, int CIN>
-__global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p, int tiles_x, int tiles_y, int total_tiles) {
-  using G = HaloGeom<WM, WN, MT, NTW, CIN>;
+// HV = 2: eight waves, two tile streams (waves 0-3 / 4-7) that share the weights and the barriers: two waves per SIMD hide
+// each other's LDS and MFMA latencies where a second workgroup per CU would not fit beside 74 KiB of weights.
+template <int WM, int WN, int MT, int NTW, int CIN, int HV>
+__global__ __launch_bounds__(256 * HV) void conv_halo_kernel(const ConvParams p, int tiles_x, int tiles_y, int total_tiles) {
+  using G = HaloGeom<WM, WN, MT, NTW, CIN, HV>;
   constexpr int TH = G::TH, BN = G::BN, PB = G::PB, Cin = G::CIN, P = G::P, NSTEPS = G::NSTEPS;
   constexpr int PER_WAVE = (G::PATCH_PIECES + 3) / 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   half_t* patch0 = reinterpret_cast<half_t*>(smem);
-  half_t* patch_dump = patch0 + 2 * G::PATCH_PIECES * 512;
+  half_t* patch_dump = patch0 + 2 * HV * G::PATCH_PIECES * 512;
   half_t* wts = patch_dump + 512;
   float* sStat = reinterpret_cast<float*>(wts + NSTEPS * G::STEP_HALVES);
 
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
+  const int wave8 = tid >> 6, lane = tid & 63;
+  const int half = wave8 >> 2, wave = wave8 & 3;  // tile stream, wave inside it
   const int wm = wave / WN, wn = wave % WN;
   const int fr = lane & 15, fq = lane >> 4;
   const int nblk = blockIdx.y;
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p, int 
     const int b = t2 / tiles_y;
     const int y0 = ty * TH, x0 = tx * 16;
     const half_t* img = p.in + (long long)b * p.in_bstride;
-    half_t* pbuf = patch0 + buf * (G::PATCH_PIECES * 512);
+    half_t* pbuf = patch0 + (half * 2 + buf) * (G::PATCH_PIECES * 512);
 #pragma unroll
     for (int k = 0; k < PER_WAVE; ++k) {
       const int piece = k * 4 + wave;
@@ -115,8 +119,17 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p, int 
     }
   };
 
-  int tile = blockIdx.x;  // < total_tiles (launcher)
-  issue_patch(tile, 0);
+  // tile streams: stream `half` of workgroup x takes tiles x*HV + half, + gridDim.x*HV, ...; the loop below runs while
+  // stream 0 has a tile, a stream without one skips the work but keeps the barriers
+  const int tstride = gridDim.x * HV;
+  int tile = blockIdx.x * HV + half;
+  bool valid = tile < total_tiles;  // stream 0: always (launcher)
+  auto dump_patch = [&]() {         // keeps the per-wave DMA count uniform for the counted waits
+#pragma unroll
+    for (int k = 0; k < PER_WAVE; ++k) __builtin_amdgcn_global_load_lds((gbl_void_ptr)p.zeros, (lds_void_ptr)patch_dump, 16, 0, 0);
+  };
+  if (valid) issue_patch(tile, 0);
+  else dump_patch();
 
   const unsigned long long pos_pack = p.halo_pos, wt_pack = p.halo_wt;  // 4 bits per tap (cvx_halo_pack_taps)
 
@@ -128,7 +141,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p, int 
     half_t* wdst[PB];
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
-      const int piece = q * 4 + wave;  // wave-uniform
+      const int piece = q * (4 * HV) + wave8;  // wave-uniform
       const int n = nblk * BN + piece * 16 + r16;
       wrow[q] = (piece < G::NPIECE && n < p.Cout) ? p.wt + (long long)n * p.wt_ld : nullptr;
       wdst[q] = piece < G::NPIECE ? wts + piece * 512 : nullptr;
@@ -158,15 +171,17 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p, int 
   constexpr int NG = NSTEPS >= 12 ? 3 : (NSTEPS >= 4 ? 2 : 1);
   bool first = true;
   int buf = 0;
-  for (; tile < total_tiles; tile += gridDim.x, buf ^= 1) {
-    const int next = tile + gridDim.x;
-    const bool has_next = next < total_tiles;
+  for (int tile0 = blockIdx.x * HV; tile0 < total_tiles; tile0 += tstride, tile += tstride, buf ^= 1) {
+    valid = tile < total_tiles;
+    const int next = tile + tstride;
+    const bool has_next = tile0 + tstride < total_tiles;  // block-uniform: stream 0 has another tile
+    const bool next_valid = next < total_tiles;
     f4 acc[MT][NTW];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NTW; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-    const half_t* patch = patch0 + buf * (G::PATCH_PIECES * 512);
+    const half_t* patch = patch0 + (half * 2 + buf) * (G::PATCH_PIECES * 512);
     // output coordinates of this tile
     const int tx = tile % tiles_x;
     const int t2 = tile / tiles_x;
@@ -199,7 +214,10 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p, int 
         workgroup_barrier();  // group 0: also "every wave is done with the other patch buffer"
         if (g == 0) {
           if (first) clk_mark(p, 2);
-          if (has_next) issue_patch(next, buf ^ 1);
+          if (has_next) {
+            if (next_valid) issue_patch(next, buf ^ 1);
+            else dump_patch();
+          }
         }
       }
       // software pipeline inside the group: the LDS fragment reads of K-step s+PD are issued before the MFMAs of
@@ -246,36 +264,51 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p, int 
     if (first) clk_mark(p, 3);
 
     // ---- stores ----
-    epilogue_tile<WM, WN, MT, NTW>(p, acc, out_off, res_off, pvalid, wn, fq, nblk, st1, st2);
+    if (valid) epilogue_tile<WM, WN, MT, NTW>(p, acc, out_off, res_off, pvalid, wn, fq, nblk, st1, st2);
     first = false;
   }
-  if (p.epi == CVX_EPI_RAW_STATS) stats_flush<WM, WN, NTW>(p, st1, st2, wm, wn, fr, fq, nblk, sStat, tid);
+  if (p.epi == CVX_EPI_RAW_STATS) stats_flush<HV * WM, WN, NTW>(p, st1, st2, half * WM + wm, wn, fr, fq, nblk, sStat, tid);
   clk_mark(p, 4);
+}
+
+template <int WM, int WN, int MT, int NTW, int CIN, int HV>
+int launch_halo_hv(const ConvParams& p, hipStream_t stream, int gy) {
+  using G = HaloGeom<WM, WN, MT, NTW, CIN, HV>;
+  const int tiles_x = (p.IW + 15) / 16, tiles_y = (p.IH + G::TH - 1) / G::TH;
+  const int total = tiles_x * tiles_y * p.B;
+  static bool attr_done = false;
+  if (!attr_done) {
+    CVX_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<WM, WN, MT, NTW, CIN, HV>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+    attr_done = true;
+  }
+  // persistent: as many workgroups as fit on the 256 CUs at once (LDS-limited, at most CVX_HALO_OCC per CU), split
+  // over the gy channel blocks; each walks the tile list with that stride (HV tiles per workgroup and trip)
+  static const int occ_cap = getenv("CVX_HALO_OCC") ? atoi(getenv("CVX_HALO_OCC")) : 4;
+  int per_cu = (160 * 1024) / G::LDS_BYTES;
+  per_cu = per_cu < 1 ? 1 : (per_cu > occ_cap ? occ_cap : per_cu);
+  if (HV == 2 && per_cu > 2) per_cu = 2;  // 8 waves each
+  int gx = (256 * per_cu) / gy / (g_cvx_grid_div > 0 ? g_cvx_grid_div : 1);
+  if (gx < 1) gx = 1;
+  if (gx * HV > total) gx = (total + HV - 1) / HV;
+  dim3 grid(gx, gy);
+  hipLaunchKernelGGL((conv_halo_kernel<WM, WN, MT, NTW, CIN, HV>), grid, dim3(256 * HV), G::LDS_BYTES, stream, p, tiles_x, tiles_y, total);
+  return 0;
 }
 
 template <int WM, int WN, int MT, int NTW, int CIN>
 int launch_halo_c(const ConvParams& p, hipStream_t stream, int gy) {
-  using G = HaloGeom<WM, WN, MT, NTW, CIN>;
-  if constexpr (G::LDS_BYTES > 160 * 1024) {
+  using G1 = HaloGeom<WM, WN, MT, NTW, CIN, 1>;
+  using G2 = HaloGeom<WM, WN, MT, NTW, CIN, 2>;
+  if constexpr (G1::LDS_BYTES > 160 * 1024) {
     CVX_CHECK(false, "conv_halo: weight slice does not fit in LDS (launcher bug)");
   } else {
-    const int tiles_x = (p.IW + 15) / 16, tiles_y = (p.IH + G::TH - 1) / G::TH;
-    const int total = tiles_x * tiles_y * p.B;
-    static bool attr_done = false;
-    if (!attr_done) {
-      CVX_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<WM, WN, MT, NTW, CIN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
-      attr_done = true;
+    // two tile streams per workgroup when only ONE single-stream workgroup would fit a CU (heavy weight slices) and the
+    // two-stream layout does; register budget halves (256 per wave), so only the moderate register tiles
+    static const bool hv2 = !(getenv("CVX_HALO_HV") && atoi(getenv("CVX_HALO_HV")) == 1);
+    if constexpr (G2::LDS_BYTES <= 160 * 1024 && 2 * G1::LDS_BYTES > 160 * 1024 && MT * NTW <= 8 && NTW <= 4) {
+      if (hv2) return launch_halo_hv<WM, WN, MT, NTW, CIN, 2>(p, stream, gy);
     }
-    // persistent: as many workgroups as fit on the 256 CUs at once (LDS-limited, at most CVX_HALO_OCC per CU), split
-    // over the gy channel blocks; each walks the tile list with that stride
-    static const int occ_cap = getenv("CVX_HALO_OCC") ? atoi(getenv("CVX_HALO_OCC")) : 4;
-    int per_cu = (160 * 1024) / G::LDS_BYTES;
-    per_cu = per_cu < 1 ? 1 : (per_cu > occ_cap ? occ_cap : per_cu);
-    int gx = (256 * per_cu) / gy / (g_cvx_grid_div > 0 ? g_cvx_grid_div : 1);
-    if (gx < 1) gx = 1;
-    if (gx > total) gx = total;
-    dim3 grid(gx, gy);
-    hipLaunchKernelGGL((conv_halo_kernel<WM, WN, MT, NTW, CIN>), grid, dim3(256), G::LDS_BYTES, stream, p, tiles_x, tiles_y, total);
+    return launch_halo_hv<WM, WN, MT, NTW, CIN, 1>(p, stream, gy);
   }
   return 0;
 }
