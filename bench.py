@@ -11,7 +11,8 @@ under torch.distributed.run (one rank per GPU, RCCL gradient all-reduce).  Rank 
   (fp16 input view + output + weights) / average launch duration, measured with HIP events on
   the engine's launch stream (cvx_engine_profile) in a window right after the timed steps; peak = 8 TB/s.  The MFMA
   view of the same launches is reported beside it.  `traffic` = HBM bytes per launch from rocprofv3 PMC passes
-  (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_conv_traffic_v5.json -- counters cannot be read from inside this process).
+  (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_conv_traffic_v7.json, tools/pmc_traffic.py -- counters cannot be read from
+  inside this process).
   The other kernel classes are reported alongside under "kernel_classes";
 * `cpu_baseline`: the CPU oracle (torch-CPU fp32 restatement of the reference, kind "port") timed on this
   host's cores on a bounded sample (batch 8 train steps), rank 0, N = 1 only.
@@ -31,6 +32,7 @@ MFMA_FP16_PEAK_TFLOPS = 2516.6                  # MI355X dense fp16 (BASELINE.md
 HBM_PEAK_GBS = 8000.0
 TRAIN_GFLOP_PER_IMG = 26.140262                 # 3*F - 2*MAC0, YOLOv8-n 640x640
 FWD_GFLOP_PER_IMG = 8.742912
+TRAFFIC_FILE = "r01_conv_traffic_v7.json"       # PMC passes of the build this file was committed with (tools/pmc_traffic.py)
 
 
 def usable_cores() -> int:
@@ -152,7 +154,7 @@ def main():
         conv_by = sum(v["bytes"] for v in conv.values())
         conv_gbs = conv_by / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0
         traffic = None                                   # measured HBM bytes per launch of the same kernel family (PMC passes)
-        tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic_v5.json")
+        tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
         if os.path.exists(tpath) and B == 32 and args.model == "n":
             traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
         classes = {}

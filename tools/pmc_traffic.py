@@ -1,0 +1,60 @@
+"""HBM traffic per kernel family from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of `python bench.py --steps 3 --warmup 2`.
+
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+
+One timed step (between two Adam launches) is summed.  Correction as MI355X_MICROARCH.md (section HBM) prescribes for gfx950:
+bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB counters; FETCH_SIZE tallies 128-byte requests at 64 bytes).
+"""
+import collections
+import csv
+import json
+import sys
+
+FAMILIES = ("conv_halo_kernel", "conv_pw_kernel", "conv_igemm_dma_kernel", "conv_wgrad_halo_kernel", "conv_wgrad_kernel", "bn_bwd_reduce",
+            "bn_bwd_apply", "bn_silu_apply", "reduce_slabs")
+CONV = ("conv_halo_kernel", "conv_pw_kernel", "conv_igemm_dma_kernel")
+
+
+def family(name):
+    for k in FAMILIES:
+        if k in name:
+            return k
+    return "other"
+
+
+def one_step(path, counter):
+    per = collections.OrderedDict()
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            per[int(r["Dispatch_Id"])] = (r["Kernel_Name"], float(r["Counter_Value"]))
+    ids = list(per)
+    adam = [i for i in ids if "adam_kernel" in per[i][0]]
+    a, b = adam[2], adam[3]
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for i in ids:
+        if a < i <= b:
+            k = family(per[i][0])
+            agg[k][0] += per[i][1]
+            agg[k][1] += 1
+    return agg
+
+
+def main():
+    fetch, write = one_step(sys.argv[1], "FETCH_SIZE"), one_step(sys.argv[2], "WRITE_SIZE")
+    fam = {k: {"fetch_kib": fetch[k][0], "write_kib": write[k][0], "launches": fetch[k][1],
+               "hbm_bytes": (2 * fetch[k][0] + write[k][0]) * 1024} for k in fetch}
+    n = sum(fam[k]["launches"] for k in CONV)
+    tot = sum(fam[k]["hbm_bytes"] for k in CONV)
+    out = {"source": "rocprofv3 --pmc FETCH_SIZE --kernel-trace / --pmc WRITE_SIZE --kernel-trace (separate passes) -- python bench.py "
+                     "--no-cpu-baseline --steps 3 --warmup 2 --profile-steps 1; one timed step",
+           "correction": "bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB counters), MI355X_MICROARCH.md section HBM",
+           "conv_family": list(CONV), "launches_per_step": n, "hbm_bytes_per_step": tot, "hbm_bytes_per_launch": tot / n,
+           "whole_step_hbm_bytes": sum(v["hbm_bytes"] for v in fam.values()), "families": fam}
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    print(f"conv family: {n} launches, {tot / 1e9:.2f} GB per step, {tot / n / 1e6:.1f} MB per launch; whole step {out['whole_step_hbm_bytes'] / 1e9:.1f} GB")
+    for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["hbm_bytes"]):
+        print(f"  {k:24s} {v['launches']:4d} launches  {v['hbm_bytes'] / 1e6:9.1f} MB")
+
+
+if __name__ == "__main__":
+    main()
