@@ -56,6 +56,13 @@ struct ConvParams {
   int dbg;             // timing experiments only (CVX_DBG): 1 = halo kernel streams the weights once, 2 = no MFMA; results are WRONG
   unsigned long long* clk;  // tuning aid (cvx_debug_clock_buffer): thread 0 of every block stores 100 MHz timestamps, 8 slots per block
   int halo_taps_ok;    // 1 when the tap table is a 3x3 neighbourhood (all |dh|,|dw| <= 1): the LDS halo-tile kernel may be used
+  // ---- optional: several launches that differ only in their tap subset and output phase (the 4 phases of a stride-2
+  // data gradient) as ONE launch of the DMA-ring kernel: blockIdx.z selects the phase, gridDim.x covers the largest ----
+  int nphase;  // 0 / 1: the fields above describe the launch
+  struct Phase {
+    const ConvTap* taps;
+    int ntaps, OH2, OW2, oph, opw;
+  } phase[4];
   int pointwise;       // 1 when the table is the single tap (0, 0, weight tap 0): a 1x1 convolution (conv_pw.hip)
   unsigned long long halo_pos, halo_wt;  // cvx_halo_pack_taps of the table (valid when halo_taps_ok): 4 bits per tap
 };

@@ -250,6 +250,7 @@ int cvx_conv_igemm_launch(const ConvParams& p_in, hipStream_t stream, int* m_blo
   static const bool force_v1 = getenv("CVX_CONV_V1") != nullptr;
   if (p.zeros && !force_v1) {
     if (m_blocks) *m_blocks = 0;
+    if (p.nphase > 1) return cvx_conv_igemm_dma_launch(p, stream);  // merged phases: the DMA-ring kernel only
     if (cvx_conv_pw_supported(p)) return cvx_conv_pw_launch(p, stream);
     if (cvx_conv_halo_supported(p)) return cvx_conv_halo_launch(p, stream);
     return cvx_conv_igemm_dma_launch(p, stream);

@@ -13,6 +13,7 @@
 //   * tile shapes: 128x(16 NT), 64x(16 NT) (4 waves along M) and 32x(32 NTW) (2x2 waves) so that the 40x40 and
 //     20x20 levels still spread over >= 400 workgroups.
 // Operand roles, fragment maps and the epilogues are those of conv_igemm.hip.
+#include <algorithm>
 #include <cstdlib>
 
 #include "conv_igemm.h"
@@ -86,16 +87,21 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
   ConvTap* sTap = reinterpret_cast<ConvTap*>(smem + G::RING_BYTES);
   float* sStat = reinterpret_cast<float*>(smem + G::RING_BYTES + G::TAP_BYTES);  // [WM][BN][2]
 
+  // phase view: the launch's own tap table / output phase, or the one blockIdx.z selects (merged stride-2 data gradients)
+  ConvParams::Phase v{p.taps, p.ntaps, p.OH2, p.OW2, p.oph, p.opw};
+  if (p.nphase > 1) v = p.phase[blockIdx.z];
+  if ((long long)blockIdx.x * BM >= (long long)p.B * v.OH2 * v.OW2) return;  // gridDim.x covers the largest phase
+
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int wm = wave / WN, wn = wave % WN;
   const int fr = lane & 15, fq = lane >> 4;
   const int nblk = blockIdx.y;
-  const long long M = (long long)p.B * p.OH2 * p.OW2;
+  const long long M = (long long)p.B * v.OH2 * v.OW2;
   const long long m_base = (long long)blockIdx.x * BM;
 
   clk_mark(p, 0);
-  if (tid < p.ntaps) sTap[tid] = p.taps[tid];
+  if (tid < v.ntaps) sTap[tid] = v.taps[tid];
 
   // ---- per-lane DMA assignment: pass q covers stage rows q*64 + wave*16 + (lane>>2), physical slot lane&3 ----
   const int r16 = lane >> 2;
@@ -111,10 +117,10 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
       long long m = m_base + row;
       if (m < M) {
         const unsigned mu = (unsigned)m;  // M < 2^31 (checked by the launcher): 32-bit divisions
-        const unsigned tq = mu / (unsigned)p.OW2;
-        int ow2 = (int)(mu - tq * (unsigned)p.OW2);
-        int b = (int)(tq / (unsigned)p.OH2);
-        int oh2 = (int)(tq - (unsigned)b * (unsigned)p.OH2);
+        const unsigned tq = mu / (unsigned)v.OW2;
+        int ow2 = (int)(mu - tq * (unsigned)v.OW2);
+        int b = (int)(tq / (unsigned)v.OH2);
+        int oh2 = (int)(tq - (unsigned)b * (unsigned)v.OH2);
         ih0[q] = oh2 * p.IS;
         iw0[q] = ow2 * p.IS;
         src_base[q] = p.in + (long long)b * p.in_bstride;
@@ -129,12 +135,12 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
     c -= p.Cin;
     ++tap;
   }
-  const int nsteps = (p.ntaps * p.Cin + BK - 1) / BK;
+  const int nsteps = (v.ntaps * p.Cin + BK - 1) / BK;
   __syncthreads();  // tap table visible (no DMA outstanding yet)
   clk_mark(p, 1);
 
   auto issue = [&](int stage) {
-    const bool kvalid = tap < p.ntaps;
+    const bool kvalid = tap < v.ntaps;
     ConvTap td = sTap[kvalid ? tap : 0];
     half_t* stage_base = ring + stage * STAGE_HALVES;
 #pragma unroll
@@ -198,11 +204,11 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
     long long m = m_base + (wm * MT + i) * 16 + fr;
     pvalid[i] = m < M;
     const unsigned mu = pvalid[i] ? (unsigned)m : 0u;
-    const unsigned tq = mu / (unsigned)p.OW2;
-    int ow2 = (int)(mu - tq * (unsigned)p.OW2);
-    int b = (int)(tq / (unsigned)p.OH2);
-    int oh2 = (int)(tq - (unsigned)b * (unsigned)p.OH2);
-    long long pix = (long long)(oh2 * p.OS + p.oph) * p.OWr + (ow2 * p.OS + p.opw);
+    const unsigned tq = mu / (unsigned)v.OW2;
+    int ow2 = (int)(mu - tq * (unsigned)v.OW2);
+    int b = (int)(tq / (unsigned)v.OH2);
+    int oh2 = (int)(tq - (unsigned)b * (unsigned)v.OH2);
+    long long pix = (long long)(oh2 * p.OS + v.oph) * p.OWr + (ow2 * p.OS + v.opw);
     out_off[i] = (long long)b * p.out_bstride + pix * p.out_ld;
     res_off[i] = (long long)b * p.res_bstride + pix * p.res_ld;
   }
@@ -335,7 +341,14 @@ int launch_m4(int NT, const ConvParams& p, hipStream_t st, dim3 grid) {  // 4 wa
 
 int cvx_conv_igemm_dma_launch(const ConvParams& p, hipStream_t stream) {
   CVX_CHECK(p.zeros && ((uintptr_t)p.zeros % 16) == 0, "conv_igemm_dma: needs a 16-byte aligned zero page");
-  const long long M = (long long)p.B * p.OH2 * p.OW2;
+  long long M = (long long)p.B * p.OH2 * p.OW2;
+  int nz = 1;
+  if (p.nphase > 1) {  // merged phases: gridDim.x covers the largest, blockIdx.z selects
+    CVX_CHECK(p.nphase <= 4, "conv_igemm_dma: at most 4 merged phases");
+    nz = p.nphase;
+    M = 0;
+    for (int q = 0; q < p.nphase; ++q) M = std::max(M, (long long)p.B * p.phase[q].OH2 * p.phase[q].OW2);
+  }
   CVX_CHECK(M < (1LL << 31), "conv_igemm_dma: more than 2^31 output pixels per launch");
   const int tiles = (p.Cout + 15) / 16;
   static const int allowed[] = {1, 2, 3, 4, 5, 6, 8};
@@ -349,7 +362,7 @@ int cvx_conv_igemm_dma_launch(const ConvParams& p, hipStream_t stream) {
     int gy = (pairs + 3) / 4;
     int ntw = (pairs + gy - 1) / gy;  // 1..4
     gy = (pairs + ntw - 1) / ntw;
-    dim3 grid(cvx_cdiv(M, 32), gy);
+    dim3 grid(cvx_cdiv(M, 32), gy, nz);
     switch (ntw) {
       case 1: CVX_TRY((launch_cfg<2, 2, 1, 1>(p, stream, grid))); break;
       case 2: CVX_TRY((launch_cfg<2, 2, 1, 2>(p, stream, grid))); break;
@@ -366,7 +379,7 @@ int cvx_conv_igemm_dma_launch(const ConvParams& p, hipStream_t stream) {
         break;
       }
     gy = (tiles + NT - 1) / NT;
-    dim3 grid(cvx_cdiv(M, BM), gy);
+    dim3 grid(cvx_cdiv(M, BM), gy, nz);
     if (BM == 128) CVX_TRY(launch_m4<2>(NT, p, stream, grid));
     else CVX_TRY(launch_m4<1>(NT, p, stream, grid));
   }

@@ -839,7 +839,13 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
     // ---- data gradient: dx = dy (*) W^T, one launch per output phase of the forward stride ----
     if (o.needs_dgrad) {
       ViewDesc gin = make_view(e, o.in, true);
+      // the phases of a strided data gradient differ only in tap subset and output phase: one launch (blockIdx.z)
+      static const bool merge_off = getenv("CVX_NO_PHASE_MERGE") != nullptr;
+      bool merged = !merge_off && c.ndg > 1 && c.ndg <= 4;
+      for (int q = 0; q < c.ndg && merged; ++q)
+        if (c.dg[q].OH2 <= 0 || c.dg[q].OW2 <= 0 || c.dg[q].ntaps <= 0) merged = false;
       for (int q = 0; q < c.ndg; ++q) {
+        if (merged && q > 0) break;  // everything went out with phase 0
         const DgClass& dc = c.dg[q];
         if (dc.OH2 <= 0 || dc.OW2 <= 0) continue;
         CVX_CHECK(dc.ntaps > 0, "dgrad phase without taps (stride > kernel) is not supported");
@@ -874,8 +880,21 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
         cp.out16 = gin.p;
         cp.out_ld = gin.ld;
         cp.out_bstride = gin.bstride;
-        ProfScope ps(e, PROF_CONV_DGRAD, 2.0 * B * dc.OH2 * dc.OW2 * (double)o.in.c * dc.ntaps * C,
-                     (conv_bytes(o, B) + (c.in_accum ? 2.0 * B * o.ih * o.iw * o.in.c : 0.0)) / c.ndg, st);
+        double fl = 2.0 * B * dc.OH2 * dc.OW2 * (double)o.in.c * dc.ntaps * C;
+        double by = (conv_bytes(o, B) + (c.in_accum ? 2.0 * B * o.ih * o.iw * o.in.c : 0.0)) / c.ndg;
+        if (merged) {
+          cp.nphase = c.ndg;
+          fl = 0;
+          for (int z = 0; z < c.ndg; ++z) {
+            const DgClass& dz = c.dg[z];
+            cp.phase[z] = ConvParams::Phase{dz.taps, dz.ntaps, dz.OH2, dz.OW2, dz.oph, dz.opw};
+            fl += 2.0 * B * dz.OH2 * dz.OW2 * (double)o.in.c * dz.ntaps * C;
+          }
+          by *= c.ndg;
+          cp.halo_taps_ok = 0;
+          cp.pointwise = 0;
+        }
+        ProfScope ps(e, PROF_CONV_DGRAD, fl, by, st);
         CVX_TRY(cvx_conv_igemm_launch(cp, st, nullptr));
       }
     }
