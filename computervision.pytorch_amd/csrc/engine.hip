@@ -113,6 +113,11 @@ struct cvx_engine {
   SlabDesc* d_slab = nullptr;
   BlockRef* d_slab_blocks = nullptr;
   int n_slab_blocks = 0;
+  // the slab reduction runs in two parts: everything but the first `tail` conv ops as soon as THEIR weight gradients are
+  // done (overlapping the last, largest-image weight gradients on the side stream), then the rest
+  int slab_tail_blocks = 0;  // reducer workgroups of the first ops (the tail of the backward pass)
+  int slab_tail_op = -1;     // op index of the last conv op outside the tail (-1: single reduction)
+  hipEvent_t ev_mid = nullptr;
   bool fwd_train_done = false;
   int last_batch = 0;
   float* last_pred = nullptr;
@@ -364,6 +369,8 @@ int plan_batch(cvx_engine* e, int B, bool training) {
   long long stat_floats = 0, slab_total = 0;
   std::vector<SlabDesc> sdescs;
   std::vector<BlockRef> sblocks;
+  e->slab_tail_blocks = 0;
+  e->slab_tail_op = -1;
   for (size_t i = 0; i < e->ops.size(); ++i) {
     const cvx_op_desc& o = e->ops[i];
     if (o.type == CVX_OP_MAXPOOL5) {
@@ -436,6 +443,11 @@ int plan_batch(cvx_engine* e, int B, bool training) {
       sd.Cin_pad = c.cin_pad16;
       sd.lanes = cvx_slab_lanes(sd.nsplit);
       const long long total = (long long)sd.rows * sd.Cin;
+      static const int tail_ops = getenv("CVX_SLAB_TAIL") ? atoi(getenv("CVX_SLAB_TAIL")) : 2;
+      if ((int)sdescs.size() == tail_ops && tail_ops > 0) {  // this is the first conv op outside the tail
+        e->slab_tail_blocks = (int)sblocks.size();
+        e->slab_tail_op = (int)i;
+      }
       for (long long s0 = 0; s0 < total; s0 += 256 / sd.lanes) sblocks.push_back(BlockRef{(int)sdescs.size(), (int)s0});
       sdescs.push_back(sd);
     }
@@ -524,7 +536,8 @@ extern "C" int cvx_engine_create(cvx_engine** out, const cvx_buf_desc* bufs, int
                                    : hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
     if (side_rc != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_fork, cvx_event_flags()) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_join, cvx_event_flags()) != hipSuccess) {
+        hipEventCreateWithFlags(&e->ev_join, cvx_event_flags()) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_mid, cvx_event_flags()) != hipSuccess) {
       cvx_set_error("cvx_engine_create: could not create the side stream / events");
       rc = -1;
     }
@@ -577,6 +590,7 @@ extern "C" int cvx_engine_destroy(cvx_engine* e) {
     if (c.ev_dy) (void)hipEventDestroy(c.ev_dy);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  if (e->ev_mid) (void)hipEventDestroy(e->ev_mid);
   for (int l = 1; l < cvx_engine::MAX_LANES; ++l) {
     if (e->lane_stream[l]) {
       (void)hipStreamSynchronize(e->lane_stream[l]);
@@ -924,21 +938,29 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
       wp.cin_pad16 = c.cin_pad16;
       wp.std3x3 = c.std3x3;
       pending.push_back({wp, conv_flops(o, B), conv_bytes(o, B) + 4.0 * c.nsplit * C * c.ntaps * c.cin_pad16, i});
-      if ((int)pending.size() >= wg_batch || i == 0 || (lanes_open && e->ops[i].lane != (i > 0 ? e->ops[i - 1].lane : 0)))
+      if ((int)pending.size() >= wg_batch || i == 0 || i == e->slab_tail_op ||
+          (lanes_open && e->ops[i].lane != (i > 0 ? e->ops[i - 1].lane : 0)))
         CVX_TRY(flush_wgrads(c.ev_dy, st));
+      if (i == e->slab_tail_op) CVX_HIP(hipEventRecord(e->ev_mid, e->side));  // every weight gradient outside the tail is queued
     }
   }
   if (lanes_open) CVX_TRY(lanes_join(e));
   CVX_TRY(flush_wgrads(e->ev_fork, st));  // (non-conv first ops: nothing pending in practice)
   e->cur_op = -1;
-  CVX_HIP(hipEventRecord(e->ev_join, e->side));  // join: the slab reduction needs every weight-gradient slab
+  double slab_bytes = 0;
+  for (size_t i = 0; i < e->ops.size(); ++i)
+    if (e->ops[i].type == CVX_OP_CONV) slab_bytes += 4.0 * e->conv[i].nsplit * e->ops[i].out.c * e->conv[i].ntaps * e->conv[i].cin_pad16;
+  const int tail = e->slab_tail_op >= 0 ? e->slab_tail_blocks : 0;
+  if (tail > 0) {  // part 1: all ops but the tail -- overlaps the tail's weight gradients still running on the side stream
+    CVX_HIP(hipStreamWaitEvent(st, e->ev_mid, 0));
+    ProfScope ps(e, PROF_SLAB_REDUCE, 0, slab_bytes + 8.0 * e->n_params);
+    CVX_TRY(cvx_reduce_slabs(e->slabs, e->grads, inv_scale, e->d_slab, e->d_slab_blocks + tail, e->n_slab_blocks - tail, st));
+  }
+  CVX_HIP(hipEventRecord(e->ev_join, e->side));  // join: the (rest of the) slab reduction needs every weight-gradient slab
   CVX_HIP(hipStreamWaitEvent(st, e->ev_join, 0));
   {
-    double slab_bytes = 0;
-    for (size_t i = 0; i < e->ops.size(); ++i)
-      if (e->ops[i].type == CVX_OP_CONV) slab_bytes += 4.0 * e->conv[i].nsplit * e->ops[i].out.c * e->conv[i].ntaps * e->conv[i].cin_pad16;
-    ProfScope ps(e, PROF_SLAB_REDUCE, 0, slab_bytes + 8.0 * e->n_params);
-    CVX_TRY(cvx_reduce_slabs(e->slabs, e->grads, inv_scale, e->d_slab, e->d_slab_blocks, e->n_slab_blocks, st));
+    ProfScope ps(e, PROF_SLAB_REDUCE, 0, tail > 0 ? 0.0 : slab_bytes + 8.0 * e->n_params);
+    CVX_TRY(cvx_reduce_slabs(e->slabs, e->grads, inv_scale, e->d_slab, e->d_slab_blocks, tail > 0 ? tail : e->n_slab_blocks, st));
   }
   return 0;
 }
