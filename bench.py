@@ -11,7 +11,7 @@ under torch.distributed.run (one rank per GPU, RCCL gradient all-reduce).  Rank 
   (fp16 input view + output + weights) / average launch duration, measured with HIP events on
   the engine's launch stream (cvx_engine_profile) in a window right after the timed steps; peak = 8 TB/s.  The MFMA
   view of the same launches is reported beside it.  `traffic` = HBM bytes per launch from rocprofv3 PMC passes
-  (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_conv_traffic_v7.json, tools/pmc_traffic.py -- counters cannot be read from
+  (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_conv_traffic_v8.json, tools/pmc_traffic.py -- counters cannot be read from
   inside this process).
   The other kernel classes are reported alongside under "kernel_classes";
 * `cpu_baseline`: the CPU oracle (torch-CPU fp32 restatement of the reference, kind "port") timed on this
@@ -32,7 +32,7 @@ MFMA_FP16_PEAK_TFLOPS = 2516.6                  # MI355X dense fp16 (BASELINE.md
 HBM_PEAK_GBS = 8000.0
 TRAIN_GFLOP_PER_IMG = 26.140262                 # 3*F - 2*MAC0, YOLOv8-n 640x640
 FWD_GFLOP_PER_IMG = 8.742912
-TRAFFIC_FILE = "r01_conv_traffic_v7.json"       # PMC passes of the build this file was committed with (tools/pmc_traffic.py)
+TRAFFIC_FILE = "r01_conv_traffic_v8.json"       # PMC passes of the build this file was committed with (tools/pmc_traffic.py)
 
 
 def usable_cores() -> int:
