@@ -53,6 +53,10 @@ PROTOTYPES = {
     "cvx_engine_set_bn": (_I32, [_P, _F, _F]),
     "cvx_engine_forward": (_I32, [_P, _P, _I32, _I32, _P]),
     "cvx_engine_backward": (_I32, [_P, _P, _F]),
+    "cvx_engine_backward_begin": (_I32, [_P, _P, _F]),
+    "cvx_engine_backward_range": (_I32, [_P, _I32, _I32]),
+    "cvx_engine_grads_ready": (_I32, [_P, _I32, _I32, _P]),
+    "cvx_engine_backward_end": (_I32, [_P]),
     "cvx_engine_workspace_bytes": (_I64, [_P]),
     "cvx_engine_debug_copy": (_I32, [_P, _I32, _I32, _P, _I64]),
     "cvx_engine_profile": (_I32, [_P, _I32]),

@@ -50,6 +50,7 @@ struct ConvRt {
   int cin_pad16 = 0;
   // backward plan
   int in_accum = 0, res_accum = 0;
+  int slab_blk0 = 0, slab_blk1 = 0;  // reducer workgroups [blk0, blk1) of this op in the slab block table
   // per-batch
   half_t* ybuf = nullptr;
   half_t* dybuf = nullptr;  // gradient w.r.t. the raw conv output (kept per layer: the weight-gradient runs on a side stream)
@@ -118,6 +119,8 @@ struct cvx_engine {
   int slab_tail_blocks = 0;  // reducer workgroups of the first ops (the tail of the backward pass)
   int slab_tail_op = -1;     // op index of the last conv op outside the tail (-1: single reduction)
   hipEvent_t ev_mid = nullptr;
+  hipEvent_t ev_seg[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // segmented backward: (main, side) pairs
+  int ev_seg_next = 0;
   bool fwd_train_done = false;
   int last_batch = 0;
   float* last_pred = nullptr;
@@ -131,8 +134,11 @@ struct cvx_engine {
     int op;
   };
   int cur_op = -1;  // op index the launch loops are at (profile records carry it)
+  struct cvx_bw_state* bw = nullptr;  // backward-pass state (whole-pass and segmented entry points)
   std::vector<ProfRec> prof_recs;
 };
+
+void cvx_engine_free_bw(cvx_engine* e);  // defined next to cvx_bw_state
 
 namespace {
 
@@ -448,7 +454,9 @@ int plan_batch(cvx_engine* e, int B, bool training) {
         e->slab_tail_blocks = (int)sblocks.size();
         e->slab_tail_op = (int)i;
       }
+      c.slab_blk0 = (int)sblocks.size();
       for (long long s0 = 0; s0 < total; s0 += 256 / sd.lanes) sblocks.push_back(BlockRef{(int)sdescs.size(), (int)s0});
+      c.slab_blk1 = (int)sblocks.size();
       sdescs.push_back(sd);
     }
   }
@@ -591,6 +599,8 @@ extern "C" int cvx_engine_destroy(cvx_engine* e) {
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->ev_mid) (void)hipEventDestroy(e->ev_mid);
+  for (hipEvent_t ev : e->ev_seg)
+    if (ev) (void)hipEventDestroy(ev);
   for (int l = 1; l < cvx_engine::MAX_LANES; ++l) {
     if (e->lane_stream[l]) {
       (void)hipStreamSynchronize(e->lane_stream[l]);
@@ -602,6 +612,7 @@ extern "C" int cvx_engine_destroy(cvx_engine* e) {
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   free_pool(e->batch_allocs);
   free_pool(e->static_allocs);
+  cvx_engine_free_bw(e);
   delete e;
   return 0;
 }
@@ -762,68 +773,95 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
   return 0;
 }
 
-extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float loss_scale) {
+// ---- backward pass state shared by the whole-pass and the segmented entry points ----
+struct PendingWgrad {
+  WgradParams wp;
+  double flops, bytes;
+  int op;
+};
+struct cvx_bw_state {
+  half_t* dpred = nullptr;
+  float inv_scale = 1.f;
+  int B = 0;
+  bool active = false, lanes_open = false;
+  int wg_batch = 1;
+  int next_op = -1;  // next op (descending) the segmented interface expects
+  std::vector<PendingWgrad> pending;
+};
+static cvx_bw_state& bw_of(cvx_engine* e) {
+  if (!e->bw) e->bw = new cvx_bw_state();
+  return *e->bw;
+}
+
+namespace {
+
+// weight gradients go to the side stream in batches: one event record on the producing stream per batch
+int flush_wgrads(cvx_engine* e, hipEvent_t ev, hipStream_t producer) {
+  cvx_bw_state& w = bw_of(e);
+  static const bool skip_wgrad = getenv("CVX_DBG_SKIP_WGRAD") != nullptr;  // timing experiment only: WRONG gradients
+  if (w.pending.empty()) return 0;
+  CVX_HIP(hipEventRecord(ev, producer));
+  CVX_HIP(hipStreamWaitEvent(e->side, ev, 0));
+  for (const PendingWgrad& g : w.pending) {
+    e->cur_op = g.op;
+    ProfScope ps(e, PROF_CONV_WGRAD, g.flops, g.bytes, e->side);
+    if (!skip_wgrad) CVX_TRY(cvx_conv_wgrad_launch(g.wp, e->side));
+  }
+  w.pending.clear();
+  return 0;
+}
+
+int backward_begin(cvx_engine* e, const void* dpred_f16, float loss_scale) {
   CVX_CHECK(e && dpred_f16, "bad arguments");
   CVX_CHECK(e->fwd_train_done, "cvx_engine_backward needs a preceding training-mode forward");
   CVX_CHECK(e->grads, "no gradient arena bound");
   CVX_CHECK(loss_scale > 0.f, "loss_scale must be positive");
   CVX_HIP(hipSetDevice(e->device));
   hipStream_t st = e->stream;
-  const int B = e->last_batch;
-  const float inv_scale = 1.0f / loss_scale;
-  const Buf& pb = e->bufs[e->pred_buf];
-  const long long A = (long long)pb.d.h * pb.d.w;
-  half_t* dpred = (half_t*)dpred_f16;
+  cvx_bw_state& w = bw_of(e);
+  w.dpred = (half_t*)dpred_f16;
+  w.inv_scale = 1.0f / loss_scale;
+  w.B = e->last_batch;
+  w.pending.clear();
+  w.active = true;
+  w.next_op = (int)e->ops.size() - 1;
+  static const int wg_batch_env = getenv("CVX_WGRAD_BATCH") ? atoi(getenv("CVX_WGRAD_BATCH")) : 3;
+  w.wg_batch = (e->first_lane_op >= 0 || wg_batch_env < 1) ? 1 : wg_batch_env;  // lanes: every op has its own producer stream
   CVX_HIP(hipMemsetAsync(e->stat_region + e->stat_half, 0, (size_t)e->stat_half * 8, st));
   // fork: the side stream (weight gradients) starts after everything already queued on the main stream
   CVX_HIP(hipEventRecord(e->ev_fork, st));
   CVX_HIP(hipStreamWaitEvent(e->side, e->ev_fork, 0));
-
-  // weight gradients are launched on the side stream in batches: one event record on the producing stream per batch
-  struct PendingWgrad {
-    WgradParams wp;
-    double flops, bytes;
-    int op;
-  };
-  std::vector<PendingWgrad> pending;
-  static const int wg_batch_env = getenv("CVX_WGRAD_BATCH") ? atoi(getenv("CVX_WGRAD_BATCH")) : 3;
-  const int wg_batch = (e->first_lane_op >= 0 || wg_batch_env < 1) ? 1 : wg_batch_env;  // lanes: every op has its own producer stream
-  static const bool skip_wgrad = getenv("CVX_DBG_SKIP_WGRAD") != nullptr;  // timing experiment only: WRONG gradients
-  auto flush_wgrads = [&](hipEvent_t ev, hipStream_t producer) -> int {
-    if (pending.empty()) return 0;
-    CVX_HIP(hipEventRecord(ev, producer));
-    CVX_HIP(hipStreamWaitEvent(e->side, ev, 0));
-    for (const PendingWgrad& w : pending) {
-      e->cur_op = w.op;
-      ProfScope ps(e, PROF_CONV_WGRAD, w.flops, w.bytes, e->side);
-      if (!skip_wgrad) CVX_TRY(cvx_conv_wgrad_launch(w.wp, e->side));
-    }
-    pending.clear();
-    return 0;
-  };
-  bool lanes_open = false;
+  w.lanes_open = false;
   if (e->first_lane_op >= 0) {  // the op list ends with the lane ops: the backward pass starts with them
     CVX_TRY(lanes_fork(e));
-    lanes_open = true;
+    w.lanes_open = true;
   }
-  for (int i = (int)e->ops.size() - 1; i >= 0; --i) {
-    const cvx_op_desc& o = e->ops[i];
-    e->cur_op = i;
-    if (lanes_open && o.lane == 0) {  // first main-chain op: its gradient inputs were written on the lanes
-      CVX_TRY(lanes_join(e));
-      lanes_open = false;
-    }
+  return 0;
+}
+
+// backward of op i: BN/bias gradients and the data gradient on the op's stream, the weight gradient queued for the side stream
+int backward_op(cvx_engine* e, int i) {
+  cvx_bw_state& w = bw_of(e);
+  const int B = w.B;
+  const Buf& pb = e->bufs[e->pred_buf];
+  const long long A = (long long)pb.d.h * pb.d.w;
+  const cvx_op_desc& o = e->ops[i];
+  e->cur_op = i;
+  if (w.lanes_open && o.lane == 0) {  // first main-chain op: its gradient inputs were written on the lanes
+    CVX_TRY(lanes_join(e));
+    w.lanes_open = false;
+  }
     hipStream_t st = op_stream(e, o);
     if (o.type == CVX_OP_MAXPOOL5) {
       ProfScope ps(e, PROF_MISC, 0, 7.0 * B * o.ih * o.iw * o.in.c, st);
       CVX_TRY(cvx_maxpool5_bwd(make_view(e, o.out, true), make_view(e, o.in, true), B, o.ih, o.iw, o.in.c, e->pool[i].idx,
                                e->pool[i].in_accum, st));
-      continue;
+      return 0;
     }
     if (o.type == CVX_OP_UPSAMPLE2) {
       ProfScope ps(e, PROF_MISC, 0, 12.0 * B * o.ih * o.iw * o.in.c, st);
       CVX_TRY(cvx_upsample2_bwd(make_view(e, o.out, true), make_view(e, o.in, true), B, o.ih, o.iw, o.in.c, e->pool[i].in_accum, st));
-      continue;
+      return 0;
     }
     ConvRt& c = e->conv[i];
     const long long M = (long long)B * o.oh * o.ow;
@@ -831,24 +869,24 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
     const int hw = o.oh * o.ow;
     ViewDesc dyv;  // gradient w.r.t. the raw conv output
     if (o.act == CVX_ACT_BIAS) {
-      dyv.p = dpred + (long long)o.out.pix_off * pb.d.c + o.out.coff;
+      dyv.p = w.dpred + (long long)o.out.pix_off * pb.d.c + o.out.coff;
       dyv.ld = pb.d.c;
       dyv.bstride = A * pb.d.c;
       ProfScope ps(e, PROF_MISC, 0, 2.0 * M * C, st);
-      CVX_TRY(cvx_colsum(M, C, hw, dyv, c.stat_bwd, inv_scale, e->grads + o.bias_off, st));
+      CVX_TRY(cvx_colsum(M, C, hw, dyv, c.stat_bwd, w.inv_scale, e->grads + o.bias_off, st));
     } else {
       ViewDesc gout = make_view(e, o.out, true);
       ViewDesc gres = make_view(e, o.res, true);
       BnCoef k{c.mean, c.invstd, e->params + o.gamma_off, e->params + o.beta_off};
       ProfScope ps(e, PROF_BN_BWD, 0, (gres.p ? 14.0 : 10.0) * M * C, st);
       CVX_TRY(cvx_bn_bwd_reduce(c.ybuf, M, C, hw, k, gout, c.stat_bwd, st));
-      CVX_TRY(cvx_bn_bwd_apply(c.ybuf, M, C, hw, k, c.stat_bwd, inv_scale, e->grads + o.gamma_off, e->grads + o.beta_off, gout, c.dybuf,
+      CVX_TRY(cvx_bn_bwd_apply(c.ybuf, M, C, hw, k, c.stat_bwd, w.inv_scale, e->grads + o.gamma_off, e->grads + o.beta_off, gout, c.dybuf,
                                gres, c.res_accum, st));
       dyv.p = c.dybuf;
       dyv.ld = C;
       dyv.bstride = (long long)hw * C;
     }
-    // dy of this layer is complete here; the side stream learns it through an event, recorded once per `wg_batch`
+    // dy of this layer is complete here; the side stream learns it through an event, recorded once per `w.wg_batch`
     // layers (a marker packet between two main-chain kernels costs ~5 us, see flush_wgrads below)
     // ---- data gradient: dx = dy (*) W^T, one launch per output phase of the forward stride ----
     if (o.needs_dgrad) {
@@ -861,7 +899,7 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
       for (int q = 0; q < c.ndg; ++q) {
         if (merged && q > 0) break;  // everything went out with phase 0
         const DgClass& dc = c.dg[q];
-        if (dc.OH2 <= 0 || dc.OW2 <= 0) continue;
+        if (dc.OH2 <= 0 || dc.OW2 <= 0) return 0;
         CVX_CHECK(dc.ntaps > 0, "dgrad phase without taps (stride > kernel) is not supported");
         ConvParams cp;
         memset(&cp, 0, sizeof(cp));
@@ -937,15 +975,26 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
       wp.nsplit = c.nsplit;
       wp.cin_pad16 = c.cin_pad16;
       wp.std3x3 = c.std3x3;
-      pending.push_back({wp, conv_flops(o, B), conv_bytes(o, B) + 4.0 * c.nsplit * C * c.ntaps * c.cin_pad16, i});
-      if ((int)pending.size() >= wg_batch || i == 0 || i == e->slab_tail_op ||
-          (lanes_open && e->ops[i].lane != (i > 0 ? e->ops[i - 1].lane : 0)))
-        CVX_TRY(flush_wgrads(c.ev_dy, st));
+      w.pending.push_back({wp, conv_flops(o, B), conv_bytes(o, B) + 4.0 * c.nsplit * C * c.ntaps * c.cin_pad16, i});
+      if ((int)w.pending.size() >= w.wg_batch || i == 0 || i == e->slab_tail_op ||
+          (w.lanes_open && e->ops[i].lane != (i > 0 ? e->ops[i - 1].lane : 0)))
+        CVX_TRY(flush_wgrads(e, c.ev_dy, st));
       if (i == e->slab_tail_op) CVX_HIP(hipEventRecord(e->ev_mid, e->side));  // every weight gradient outside the tail is queued
     }
-  }
-  if (lanes_open) CVX_TRY(lanes_join(e));
-  CVX_TRY(flush_wgrads(e->ev_fork, st));  // (non-conv first ops: nothing pending in practice)
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float loss_scale) {
+  CVX_TRY(backward_begin(e, dpred_f16, loss_scale));
+  cvx_bw_state& w = bw_of(e);
+  hipStream_t st = e->stream;
+  const float inv_scale = w.inv_scale;
+  for (int i = (int)e->ops.size() - 1; i >= 0; --i) CVX_TRY(backward_op(e, i));
+  w.active = false;
+  if (w.lanes_open) CVX_TRY(lanes_join(e));
+  CVX_TRY(flush_wgrads(e, e->ev_fork, st));  // (non-conv first ops: nothing pending in practice)
   e->cur_op = -1;
   double slab_bytes = 0;
   for (size_t i = 0; i < e->ops.size(); ++i)
@@ -962,6 +1011,69 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
     ProfScope ps(e, PROF_SLAB_REDUCE, 0, tail > 0 ? 0.0 : slab_bytes + 8.0 * e->n_params);
     CVX_TRY(cvx_reduce_slabs(e->slabs, e->grads, inv_scale, e->d_slab, e->d_slab_blocks, tail > 0 ? tail : e->n_slab_blocks, st));
   }
+  return 0;
+}
+
+void cvx_engine_free_bw(cvx_engine* e) {
+  delete e->bw;
+  e->bw = nullptr;
+}
+
+// ---- segmented backward: lets the caller exchange (all-reduce) the gradients of finished parameter ranges while the
+// rest of the pass still runs.  begin -> range(hi, lo) ... -> grads_ready(hi, lo, stream) per range -> end. ----
+extern "C" int cvx_engine_backward_begin(cvx_engine* e, const void* dpred_f16, float loss_scale) {
+  return backward_begin(e, dpred_f16, loss_scale);
+}
+
+extern "C" int cvx_engine_backward_range(cvx_engine* e, int32_t op_hi, int32_t op_lo) {
+  CVX_CHECK(e && e->bw && e->bw->active, "cvx_engine_backward_range without cvx_engine_backward_begin");
+  cvx_bw_state& w = bw_of(e);
+  CVX_CHECK(op_hi == w.next_op && op_lo >= 0 && op_lo <= op_hi, "ranges must tile the op list from the last op down to 0");
+  for (int i = op_hi; i >= op_lo; --i) CVX_TRY(backward_op(e, i));
+  w.next_op = op_lo - 1;
+  if (w.lanes_open && (op_lo == 0 || e->ops[op_lo - 1].lane == 0)) {
+    CVX_TRY(lanes_join(e));
+    w.lanes_open = false;
+  }
+  CVX_TRY(flush_wgrads(e, e->ev_fork, e->stream));  // every weight gradient of the range is queued on the side stream
+  return 0;
+}
+
+extern "C" int cvx_engine_grads_ready(cvx_engine* e, int32_t op_hi, int32_t op_lo, void* hip_stream) {
+  CVX_CHECK(e && e->bw && op_lo >= 0 && op_hi < (int)e->ops.size() && op_lo <= op_hi, "bad arguments");
+  cvx_bw_state& w = bw_of(e);
+  CVX_CHECK(w.next_op < op_lo, "cvx_engine_grads_ready: the range has not been run yet");
+  hipStream_t cs = (hipStream_t)hip_stream;
+  // the caller's stream waits for everything queued so far on the main and the side stream ...
+  hipEvent_t* ev = &e->ev_seg[(e->ev_seg_next++ % 4) * 2];
+  for (int k = 0; k < 2; ++k)
+    if (!ev[k]) CVX_HIP(hipEventCreateWithFlags(&ev[k], cvx_event_flags()));
+  CVX_HIP(hipEventRecord(ev[0], e->stream));
+  CVX_HIP(hipEventRecord(ev[1], e->side));
+  CVX_HIP(hipStreamWaitEvent(cs, ev[0], 0));
+  CVX_HIP(hipStreamWaitEvent(cs, ev[1], 0));
+  // ... then folds the weight-gradient slabs of the range's conv ops into the gradient arena there
+  int blk0 = -1, blk1 = -1;
+  for (int i = op_lo; i <= op_hi; ++i) {
+    if (e->ops[i].type != CVX_OP_CONV) continue;
+    const ConvRt& c = e->conv[i];
+    if (blk0 < 0) blk0 = c.slab_blk0;
+    CVX_CHECK(blk1 < 0 || c.slab_blk0 == blk1, "slab block table is not in op order");
+    blk1 = c.slab_blk1;
+  }
+  if (blk0 >= 0 && blk1 > blk0)
+    CVX_TRY(cvx_reduce_slabs(e->slabs, e->grads, w.inv_scale, e->d_slab, e->d_slab_blocks + blk0, blk1 - blk0, cs));
+  return 0;
+}
+
+extern "C" int cvx_engine_backward_end(cvx_engine* e) {
+  CVX_CHECK(e && e->bw && e->bw->active, "cvx_engine_backward_end without cvx_engine_backward_begin");
+  cvx_bw_state& w = bw_of(e);
+  CVX_CHECK(w.next_op < 0, "cvx_engine_backward_end: not every op range has been run");
+  w.active = false;
+  e->cur_op = -1;
+  CVX_HIP(hipEventRecord(e->ev_join, e->side));  // the main stream continues after the last weight gradient
+  CVX_HIP(hipStreamWaitEvent(e->stream, e->ev_join, 0));
   return 0;
 }
 

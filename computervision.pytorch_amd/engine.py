@@ -10,7 +10,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib as L
-from .graph import Graph, ParamLayout, build_yolov8_graph
+from .graph import Graph, ParamLayout, build_yolov8_graph, grad_buckets
 
 
 def _need_gpu(t: torch.Tensor, what: str):
@@ -70,6 +70,25 @@ class Engine:
         assert dpred_f16.dtype == torch.float16 and dpred_f16.is_contiguous()
         self._use_current_stream()
         L.check(self.lib.cvx_engine_backward(self.handle, L.ptr(dpred_f16), float(loss_scale)), "cvx_engine_backward")
+
+    # ---- segmented backward (data-parallel overlap, include/cvx_engine.h) ----
+    def backward_begin(self, dpred_f16: torch.Tensor, loss_scale: float):
+        assert dpred_f16.dtype == torch.float16 and dpred_f16.is_contiguous()
+        self._use_current_stream()
+        L.check(self.lib.cvx_engine_backward_begin(self.handle, L.ptr(dpred_f16), float(loss_scale)), "cvx_engine_backward_begin")
+
+    def backward_range(self, op_hi: int, op_lo: int):
+        L.check(self.lib.cvx_engine_backward_range(self.handle, op_hi, op_lo), "cvx_engine_backward_range")
+
+    def grads_ready(self, op_hi: int, op_lo: int, stream: torch.cuda.Stream):
+        """Makes `stream` wait for the range's gradients and fold its weight-gradient slabs into the arena there."""
+        L.check(self.lib.cvx_engine_grads_ready(self.handle, op_hi, op_lo, C.c_void_p(stream.cuda_stream)), "cvx_engine_grads_ready")
+
+    def backward_end(self):
+        L.check(self.lib.cvx_engine_backward_end(self.handle), "cvx_engine_backward_end")
+
+    def grad_buckets(self, layout: ParamLayout, n_buckets: int):
+        return grad_buckets(self.graph, layout, n_buckets)
 
     def read_buffer(self, buf: int, batch: int, grad: bool = False) -> torch.Tensor:
         """Debug: NHWC fp16 copy of an engine buffer (activation or gradient)."""

@@ -311,3 +311,59 @@ def build_yolov8_graph(lay: ParamLayout, H: int, W: int) -> Graph:
               7: (b7, 0, c1024), 8: (b8, 0, c1024), 9: L9[:3], 12: L12[:3], 15: (b15, 0, c256), 18: (b18, 0, c512),
               21: (b21, 0, c1024)}
     return g
+
+
+def grad_buckets(g: Graph, lay: ParamLayout, n_buckets: int, tail_modules: int = 2):
+    """Op ranges, in backward order, whose parameters are contiguous slices of the flat arenas:
+    ``[(op_hi, op_lo, p_start, p_end), ...]`` -- the units of the overlapped gradient exchange
+    (``cvx_engine_backward_range`` / ``cvx_engine_grads_ready``).  Cuts fall between top-level modules (model.N),
+    balanced by parameter count; the ranges tile the op list from the last op down to op 0 and the slices tile the arena.
+    The first ``tail_modules`` modules (the stem: tiny parameters, but the largest images, i.e. the longest weight
+    gradients, and the last to finish) form a bucket of their own when there is more than one bucket, so that the
+    exchange left after the end of the backward pass is a few kilobytes."""
+    mods = []                                          # [op_lo, op_hi, p_start, p_end] per top-level module, op order
+    last = None
+    for i, o in enumerate(g.ops):
+        m = o["name"].split(".")[0]
+        if m != last:
+            mods.append([i, i, None, None])
+            last = m
+        mods[-1][1] = i
+        if o["type"] == L.OP_CONV:
+            spec = lay.convs[o["name"]]
+            start = spec.w_off
+            end = ((spec.beta_off if spec.bn else spec.bias_off) + spec.cout + 3) & ~3
+            mods[-1][2] = start if mods[-1][2] is None else min(mods[-1][2], start)
+            mods[-1][3] = end if mods[-1][3] is None else max(mods[-1][3], end)
+    merged = []
+    for m in mods:                                     # parameter-free modules (upsample) ride with their predecessor
+        if m[2] is None and merged:
+            merged[-1][1] = m[1]
+        else:
+            merged.append(m)
+    if merged[0][2] is None:
+        merged[1][0] = merged[0][0]
+        merged = merged[1:]
+    tail = []
+    if int(n_buckets) > 1 and 0 < tail_modules < len(merged) - 1:
+        tail, merged = merged[:tail_modules], merged[tail_modules:]
+        n_buckets = int(n_buckets) - 1
+    total = sum(m[3] - m[2] for m in merged)
+    n = max(1, min(int(n_buckets), len(merged)))
+    groups, cur, acc = [], [], 0
+    for k in range(len(merged) - 1, -1, -1):           # backward order: the head first
+        cur.append(merged[k])
+        acc += merged[k][3] - merged[k][2]
+        groups_left = n - len(groups) - 1              # groups still to be opened after the current one
+        if groups_left > 0 and (acc >= total / n or k == groups_left):
+            groups.append(cur)
+            cur, acc = [], 0
+    if cur:
+        groups.append(cur)
+    if tail:
+        groups.append(tail)
+    out = [(max(m[1] for m in b), min(m[0] for m in b), min(m[2] for m in b), max(m[3] for m in b)) for b in groups]
+    assert out[0][0] == len(g.ops) - 1 and out[-1][1] == 0 and out[-1][2] == 0
+    for a, b in zip(out, out[1:]):
+        assert b[0] == a[1] - 1 and b[3] == a[2], (a, b)  # ops and parameters both tile without gaps
+    return out

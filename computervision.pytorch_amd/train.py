@@ -149,6 +149,7 @@ class FusedTrainStep:
         self._pred = None
         self._dpred = None
         self._side = None
+        self._buckets, self._buckets_key = None, None
         self.found_inf = None
 
     def __call__(self, images: torch.Tensor, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
@@ -193,11 +194,37 @@ class FusedTrainStep:
         targets = flatten_targets(batch, dev)
         pred = m._run_forward(images, training=True, pred=self._pred)
         items, dpred = crit.op(pred, targets, m.level_shapes(H, W), STRIDES, crit.loss_scale, self._dpred)
-        eng.backward(dpred, crit.loss_scale)
-        if self.distributed:
-            self._allreduce(m.flat_grads)      # SUM over ranks; the mean's 1/world is folded into the Adam kernel
+        if self.distributed and dev.type == "cuda":
+            self._backward_overlapped(eng, dpred, crit.loss_scale)
+        else:
+            eng.backward(dpred, crit.loss_scale)
         self.optimizer.step(zero_grad=True, grad_scale=1.0 / self.world)
         return items
+
+    def _backward_overlapped(self, eng, dpred, loss_scale):
+        """Backward in `n_buckets` op ranges (head first).  As soon as a range's gradients are final, its slice of the flat
+        gradient arena is SUM-all-reduced (RCCL) on a side HIP stream while the main stream runs the next range; the mean's
+        1/world is folded into the Adam kernel.  BASELINE.json north_star: exchange overlapped with the backward pass."""
+        import torch.distributed as dist
+        m = self.model
+        g = m.flat_grads
+        if self._side is None:
+            # high priority = a hardware queue of its own: a default-priority stream can share the main stream's queue
+            # (4 queues, round-robin), and a slab fold waiting there for the weight gradients would stall the main chain
+            self._side = torch.cuda.Stream(device=g.device, priority=-1)
+        key = id(eng)
+        if self._buckets_key != key:
+            self._buckets = eng.grad_buckets(m.layout, self.n_buckets)
+            self._buckets_key = key
+        cur = torch.cuda.current_stream(g.device)
+        eng.backward_begin(dpred, loss_scale)
+        for op_hi, op_lo, p0, p1 in self._buckets:
+            eng.backward_range(op_hi, op_lo)
+            eng.grads_ready(op_hi, op_lo, self._side)          # side stream: waits for the range, folds its slabs
+            with torch.cuda.stream(self._side):
+                dist.all_reduce(g[p0:p1], group=self.pg)       # ordered after the fold on the same stream
+        eng.backward_end()
+        cur.wait_stream(self._side)
 
     def _allreduce(self, g: torch.Tensor):
         if self._side is None and g.is_cuda:

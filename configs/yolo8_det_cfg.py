@@ -57,5 +57,5 @@ class Yolo8DetConfig:
         self.engine = _Group(
             loss_scale=1024.0,       # static fp16 gradient scale (reference uses GradScaler)
             graph_capture=False,     # Yolo8Trainer: replay the step as a hipGraph (needs a fixed target count per batch)
-            allreduce_buckets=1,     # RCCL calls per step for the flat gradient arena (12.6 MB for "n": one large message)
+            allreduce_buckets=5,     # op ranges of the overlapped gradient exchange: RCCL all-reduces per step, issued while backward runs
         )

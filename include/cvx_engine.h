@@ -94,6 +94,20 @@ int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float loss_scale);
  * batch, NHWC fp16, into dst (device or host memory, `bytes` must equal batch*h*w*c*2). */
 int cvx_engine_debug_copy(cvx_engine* e, int32_t buf, int32_t which, void* dst, int64_t bytes);
 
+/* Segmented backward for data-parallel training: the same pass as cvx_engine_backward, cut into op ranges so that the
+ * caller can exchange the gradients of finished parameter ranges (RCCL all-reduce on its own stream) while the rest of the
+ * pass still runs.  Protocol: begin; then for ranges that tile the op list from the last op down to op 0:
+ * range(op_hi, op_lo) followed at any later point by grads_ready(op_hi, op_lo, stream) -- `stream` is made to wait for
+ * the range's BN/bias gradients (main stream) and weight gradients (side stream) and then folds the range's
+ * weight-gradient slabs into the gradient arena ON `stream`; after it the parameter range of those ops is final there;
+ * end() joins the side stream.  The caller makes the engine's stream wait for `stream` before the optimiser step.
+ * Replaces: loss.backward() + DistributedDataParallel's bucketed all-reduce hooks (the reference trains single-GPU,
+ * core/trainer/yolo8_train.py:93-111; BASELINE.json north_star asks for the overlapped exchange). */
+int cvx_engine_backward_begin(cvx_engine* e, const void* dpred_f16, float loss_scale);
+int cvx_engine_backward_range(cvx_engine* e, int32_t op_hi, int32_t op_lo);
+int cvx_engine_grads_ready(cvx_engine* e, int32_t op_hi, int32_t op_lo, void* hip_stream);
+int cvx_engine_backward_end(cvx_engine* e);
+
 /* Per-kernel-class timing with HIP events recorded on the engine's launch stream.  Classes: 0 conv forward
  * (implicit GEMM), 1 conv data-gradient, 2 conv weight-gradient, 3 BN+SiLU forward passes, 4 BN+SiLU backward
  * passes, 5 misc (layout, pool, upsample, weight shadows, bias sums), 6 gradient-slab reduction.

@@ -67,3 +67,28 @@ def test_sharded_oracle_gradient_identity():
     mean = (shards[0][k] + shards[1][k]) / 2
     assert torch.isfinite(mean).all() and mean.abs().sum() > 0
     assert not torch.allclose(mean, full[k], rtol=1e-3)      # per-shard normalisers + per-shard BN statistics
+
+
+def test_grad_buckets_tile_ops_and_arena():
+    """Units of the overlapped exchange (cvx_engine_backward_range / cvx_engine_grads_ready): op ranges in backward order
+    whose parameters are contiguous, disjoint arena slices covering every parameter exactly once."""
+    from computervision.pytorch_amd.graph import ParamLayout, build_yolov8_graph, grad_buckets
+    for mt in ("n", "s"):
+        lay = ParamLayout(mt, 80)
+        g = build_yolov8_graph(lay, 256, 256)
+        for nb in (1, 2, 4, 7, 100):
+            b = grad_buckets(g, lay, nb)
+            assert 1 <= len(b) <= nb
+            if nb > 1:
+                assert b[-1][0] == 1 and b[-1][1] == 0                      # the stem (model.0, model.1) closes the pass alone
+            assert b[0][0] == len(g.ops) - 1 and b[-1][1] == 0            # ops: last ... first
+            assert b[-1][2] == 0 and b[0][3] == lay.n_params               # arena: [0, n_params)
+            for (hi0, lo0, s0, e0), (hi1, lo1, s1, e1) in zip(b, b[1:]):
+                assert hi1 == lo0 - 1 and e1 == s0 and s1 % 4 == 0
+            # every conv's parameters lie inside the slice of the bucket that runs the op
+            for i, o in enumerate(g.ops):
+                if o["type"] != 1:
+                    continue
+                spec = lay.convs[o["name"]]
+                (hi, lo, s, e), = [x for x in b if x[1] <= i <= x[0]]
+                assert s <= spec.w_off and (spec.beta_off if spec.bn else spec.bias_off) + spec.cout <= e

@@ -409,3 +409,32 @@ def test_graph_replay_is_bit_identical_to_eager(dev):
     assert torch.equal(runs[0][0], runs[1][0])
     assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
     assert float(runs[0][0][-1].sum()) < float(runs[0][0][0].sum())
+
+
+def test_overlapped_exchange_is_bit_identical_to_plain_backward(dev):
+    """Data-parallel path with one rank (RCCL group of size 1): backward cut into 4 op ranges, each range's arena slice
+    folded and all-reduced on a side stream while the next range runs, must give exactly the plain step's parameters."""
+    import torch.distributed as dist
+    from computervision.pytorch_amd.train import FlatAdam, FusedTrainStep, V8DetectionLoss
+    from configs import Yolo8DetConfig
+    x, batch = synth.images(2, 128, 128, seed=1).to(dev), {k: v.to(dev) for k, v in synth.targets(2, seed=2).items()}
+    created = False
+    if not dist.is_initialized():
+        try:
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29611", rank=0, world_size=1, device_id=dev)
+            created = True
+        except Exception as exc:                                    # no RCCL on this box: nothing to compare
+            pytest.skip(f"RCCL process group unavailable: {exc}")
+    try:
+        runs = []
+        for distributed in (False, True):
+            m = new_model(dev).train()
+            step = FusedTrainStep(m, V8DetectionLoss(Yolo8DetConfig(), m), FlatAdam(m, lr=1e-3), n_buckets=4)
+            step.distributed = distributed
+            losses = [step(x, batch).clone() for _ in range(3)]
+            torch.cuda.synchronize()
+            runs.append((torch.stack(losses).cpu(), m.flat_params.clone().cpu()))
+        assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    finally:
+        if created:
+            dist.destroy_process_group()
