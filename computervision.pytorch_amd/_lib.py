@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcvx_engine.so")
+LIB_PATH = os.environ.get("CVX_LIB") or os.path.join(_HERE, "lib", "libcvx_engine.so")   # CVX_LIB: A/B runs of two builds on one box
 ABI_VERSION = 2
 
 
