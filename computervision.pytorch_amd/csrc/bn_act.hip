@@ -1,6 +1,6 @@
 // BatchNorm(train/eval) + SiLU elementwise passes around the MFMA convolutions (gfx950).
 //
-// Forward (train):  conv epilogue adds per-channel (sum, sumsq) into a few replica slabs (float atomics) ->
+// Forward (train):  conv epilogue adds per-channel (sum, sumsq) into 16 replica slabs (64-bit fixed-point atomics) ->
 //                   bn_silu_apply: every block folds the replicas into mean/invstd (fp64, identical in all blocks),
 //                   block 0 also stores them and updates the running statistics, then
 //                   a = silu(gamma*(y-mean)*invstd+beta) (+res)

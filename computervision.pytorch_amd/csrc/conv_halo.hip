@@ -1,17 +1,18 @@
 // 3x3 / stride-1 convolution with the input HALO TILE resident in LDS (gfx950).
 //
 // The generic implicit-GEMM kernels re-gather every input pixel once per tap (9x) through the L2->LDS DMA path,
-// and that traffic -- not MFMA -- bounds them.  Here a workgroup owns a TH x 16 output patch of one image:
-//   * the (TH+2) x 18 x Cin input patch is DMA'd into LDS ONCE (1 KiB pieces, zero page for the image border);
-//   * the workgroup's whole weight slice ([BN][9*Cin], capped at ~80 KiB by the launcher) follows it into LDS; the
-//     K loop synchronises 1-3 times in total (counted vmcnt + raw s_barrier per group of K-steps), not per K-step;
+// and that traffic -- not MFMA -- bounds them.  Here a persistent workgroup walks TH x 16 output patches:
+//   * the (TH+2) x 18 x Cin input patch of a tile is DMA'd into LDS ONCE (1 KiB pieces, zero page for the image border),
+//     double-buffered: the next tile's patch is in flight during the current tile's K loop;
+//   * the workgroup's whole weight slice ([BN][9*Cin], capped at ~88 KiB by the launcher) is loaded into LDS once per
+//     workgroup lifetime; only the first tile waits for it, in 1-3 groups of K-steps (counted vmcnt + raw s_barrier);
 //   * the MFMA pixel operand of K-step (tap, channel chunk) is read straight out of the patch at the tap's
 //     (dh, dw) offset: lane = pixel column, so a 16-pixel row segment is one operand sub-tile;
 //   * patch layout [pixel][Cin/8 chunks of 16 B], chunk index XOR-swizzled by the pixel column so that 16
 //     consecutive columns reading one logical chunk spread over all banks (<= 2-way under the gfx950
 //     ds_read_b128 lane groups, checked by script); the swizzle is applied on the DMA source side.
 // Used for the forward and the stride-1 data gradient (flipped taps, transposed weights) of every 3x3 conv whose
-// gathered channel count is 16, 32, 64 or 128 -- the C2f bottlenecks and most of the Detect head, ~75 % of the MACs.
+// gathered channel count is 16, 32, 64, 80, 128 or 144 -- the C2f bottlenecks and the Detect head, ~75 % of the MACs.
 #include <cstdlib>
 #include <type_traits>
 

@@ -13,6 +13,10 @@
 //   * tile shapes: 128x(16 NT), 64x(16 NT) (4 waves along M) and 32x(32 NTW) (2x2 waves) so that the 40x40 and
 //     20x20 levels still spread over >= 400 workgroups.
 // Operand roles, fragment maps and the epilogues are those of conv_igemm.hip.
+// Since the persistent kernels (conv_halo.hip: 3x3 stride 1, conv_pw.hip: 1x1) took over most layers, this one serves the
+// stride-2 3x3 layers, the stem, 256-channel 3x3 inputs and any other shape; the output phases of a strided data gradient
+// go out as one launch (ConvParams::phase, blockIdx.z).  In-kernel clocks (cvx_debug_clock_buffer) put its K-step at one
+// L2->LDS DMA round trip, ~0.5 us, whatever the ring depth.
 #include <algorithm>
 #include <cstdlib>
 
