@@ -36,16 +36,28 @@ __global__ void maxpool5_fwd_kernel(ViewDesc in, ViewDesc out, int B, int H, int
     bi[k] = 0;
   }
   bool first = true;
+  // a window row at a time: five independent 16-byte loads from clamped (always valid) addresses, then the compares in
+  // the reference's scan order -- no branch sits between a load and the next one, so they overlap
+#pragma unroll
   for (int dy = 0; dy < 5; ++dy) {
-    int hh = h + dy - 2;
-    if (hh < 0 || hh >= H) continue;
+    const int hh = h + dy - 2;
+    const bool rok = hh >= 0 && hh < H;
+    const int hc = min(max(hh, 0), H - 1);
+    h8 v[5];
+    bool ok[5];
+#pragma unroll
     for (int dx = 0; dx < 5; ++dx) {
-      int ww = w + dx - 2;
-      if (ww < 0 || ww >= W) continue;
-      h8 v = *reinterpret_cast<const h8*>(in.p + voff(in, b, (long long)hh * W + ww) + cg * 8);
+      const int ww = w + dx - 2;
+      ok[dx] = rok && ww >= 0 && ww < W;
+      const int wc = min(max(ww, 0), W - 1);
+      v[dx] = *reinterpret_cast<const h8*>(in.p + voff(in, b, (long long)hc * W + wc) + cg * 8);
+    }
+#pragma unroll
+    for (int dx = 0; dx < 5; ++dx) {
+      if (!ok[dx]) continue;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        float f = (float)v[k];
+        float f = (float)v[dx][k];
         if (first || f > best[k]) {
           best[k] = f;
           bi[k] = dy * 5 + dx;
@@ -81,15 +93,29 @@ __global__ void maxpool5_bwd_kernel(ViewDesc gout, ViewDesc gin, int B, int H, i
 #pragma unroll
   for (int k = 0; k < 8; ++k) acc[k] = 0.f;
   // output (oh, ow) whose window contains (h, w): oh in [h-2, h+2]; its tap for this input is (h-oh+2, w-ow+2)
-  for (int oh = max(0, h - 2); oh <= min(H - 1, h + 2); ++oh) {
-    for (int ow = max(0, w - 2); ow <= min(W - 1, w + 2); ++ow) {
-      int tapcode = (h - oh + 2) * 5 + (w - ow + 2);
-      long long pix = (long long)oh * W + ow;
-      unsigned long long pk = *reinterpret_cast<const unsigned long long*>(idx + (((long long)b * H * W + pix) * CG + cg) * 8);
-      h8 g = *reinterpret_cast<const h8*>(gout.p + voff(gout, b, pix) + cg * 8);
+#pragma unroll
+  for (int dy = 0; dy < 5; ++dy) {
+    const int oh = h + dy - 2;
+    const bool rok = oh >= 0 && oh < H;
+    const int ohc = min(max(oh, 0), H - 1);
+    unsigned long long pk[5];
+    h8 g[5];
+    bool ok[5];
+#pragma unroll
+    for (int dx = 0; dx < 5; ++dx) {  // loads from clamped addresses first, uses after (see the forward kernel)
+      const int ow = w + dx - 2;
+      ok[dx] = rok && ow >= 0 && ow < W;
+      const long long pix = (long long)ohc * W + min(max(ow, 0), W - 1);
+      pk[dx] = *reinterpret_cast<const unsigned long long*>(idx + (((long long)b * H * W + pix) * CG + cg) * 8);
+      g[dx] = *reinterpret_cast<const h8*>(gout.p + voff(gout, b, pix) + cg * 8);
+    }
+#pragma unroll
+    for (int dx = 0; dx < 5; ++dx) {
+      if (!ok[dx]) continue;
+      const int tapcode = (4 - dy) * 5 + (4 - dx);  // = (h - oh + 2) * 5 + (w - ow + 2)
 #pragma unroll
       for (int k = 0; k < 8; ++k)
-        if ((int)((pk >> (8 * k)) & 0xff) == tapcode) acc[k] += (float)g[k];
+        if ((int)((pk[dx] >> (8 * k)) & 0xff) == tapcode) acc[k] += (float)g[dx][k];
     }
   }
   half_t* q = gin.p + voff(gin, b, (long long)h * W + w) + cg * 8;
