@@ -125,6 +125,59 @@ class FlatAdam(torch.optim.Optimizer):
             g.update(s)
 
 
+class DynamicLossScale:
+    """torch.cuda.amp.GradScaler's policy (the reference's mixed-precision loop, core/trainer/yolo8_train.py:99-104,
+    base.py:193-194) without its per-step host synchronisation: a step whose gradients contain inf/nan is skipped ON
+    THE DEVICE (``found_inf`` read by the fused Adam kernel); the host learns about it through a pinned flag copied
+    asynchronously and adjusts the scale when the copy has landed -- backoff x0.5 per observed overflow, growth x2 after
+    ``growth_interval`` clean steps.  The only deviation from GradScaler: the new scale takes effect one or two steps
+    after the overflow instead of on the very next step (those steps overflow again and are skipped as well)."""
+
+    def __init__(self, device, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000,
+                 min_scale=1.0, max_scale=2.0 ** 24):
+        self.scale = float(init_scale)
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, int(growth_interval)
+        self.min_scale, self.max_scale = float(min_scale), float(max_scale)
+        self.found_inf = torch.zeros(1, dtype=torch.int32, device=device)
+        self._host = torch.zeros(1, dtype=torch.int32).pin_memory() if torch.device(device).type == "cuda" else torch.zeros(1, dtype=torch.int32)
+        self._event = None
+        self._good = 0
+        self.skipped = 0
+
+    def poll(self):
+        """Apply the verdict of the last finished step, if its flag has arrived (never blocks)."""
+        if self._event is None or not self._event.query():
+            return
+        self._event = None
+        if int(self._host[0]) != 0:
+            self.scale = max(self.scale * self.backoff_factor, self.min_scale)
+            self._good = 0
+            self.skipped += 1
+        else:
+            self._good += 1
+            if self._good >= self.growth_interval:
+                self.scale = min(self.scale * self.growth_factor, self.max_scale)
+                self._good = 0
+
+    def begin_step(self) -> float:
+        self.poll()
+        self.found_inf.zero_()
+        return self.scale
+
+    def end_step(self):
+        """After the optimiser step was queued: ship the flag to the host without waiting for it."""
+        if self._event is None:                      # one verdict in flight at a time
+            self._host.copy_(self.found_inf, non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record()
+
+    def state_dict(self):
+        return {"scale": self.scale, "good_steps": self._good}
+
+    def load_state_dict(self, sd):
+        self.scale, self._good = float(sd["scale"]), int(sd.get("good_steps", 0))
+
+
 class FusedTrainStep:
     """One optimisation step = forward, loss(+grad), backward, optional DP all-reduce, Adam.
 
@@ -134,8 +187,9 @@ class FusedTrainStep:
     """
 
     def __init__(self, model: Yolo8, criterion: V8DetectionLoss, optimizer: FlatAdam, process_group=None, n_buckets: int = 4,
-                 use_graph: bool = False):
+                 use_graph: bool = False, scaler: Optional[DynamicLossScale] = None):
         self.model, self.criterion, self.optimizer = model, criterion, optimizer
+        self.scaler = scaler           # None: static loss scale (criterion.loss_scale); hipGraph replay needs the static one
         self.pg = process_group
         self.n_buckets = n_buckets
         self.use_graph = use_graph     # replay the whole step as one hipGraph (single-GPU; shapes and target count fixed)
@@ -192,13 +246,20 @@ class FusedTrainStep:
             self._pred = torch.empty(B, A, no, device=dev)
             self._dpred = torch.empty(B, A, no, device=dev, dtype=torch.float16)
         targets = flatten_targets(batch, dev)
+        dynamic = self.scaler is not None and not self.use_graph
+        scale = self.scaler.begin_step() if dynamic else crit.loss_scale
         pred = m._run_forward(images, training=True, pred=self._pred)
-        items, dpred = crit.op(pred, targets, m.level_shapes(H, W), STRIDES, crit.loss_scale, self._dpred)
+        items, dpred = crit.op(pred, targets, m.level_shapes(H, W), STRIDES, scale, self._dpred)
         if self.distributed and dev.type == "cuda":
-            self._backward_overlapped(eng, dpred, crit.loss_scale)
+            self._backward_overlapped(eng, dpred, scale)
         else:
-            eng.backward(dpred, crit.loss_scale)
+            eng.backward(dpred, scale)
+        if dynamic:                                  # GradScaler.step: skip the update when a gradient is not finite
+            check_finite(m.flat_grads, self.scaler.found_inf)
+            self.optimizer.found_inf = self.scaler.found_inf
         self.optimizer.step(zero_grad=True, grad_scale=1.0 / self.world)
+        if dynamic:
+            self.scaler.end_step()
         return items
 
     def _backward_overlapped(self, eng, dpred, loss_scale):

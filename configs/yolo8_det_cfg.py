@@ -55,7 +55,9 @@ class Yolo8DetConfig:
         )
         # --- MI355X engine knobs (new; not in the reference) ---------------------------------
         self.engine = _Group(
-            loss_scale=1024.0,       # static fp16 gradient scale (reference uses GradScaler)
+            loss_scale=1024.0,       # static fp16 gradient scale (bench.py, hipGraph replay)
+            dynamic_loss_scale=True,  # Yolo8Trainer: GradScaler policy (skip non-finite steps, backoff/growth), see train.DynamicLossScale
+            init_loss_scale=65536.0,  # GradScaler's initial scale
             graph_capture=False,     # Yolo8Trainer: replay the step as a hipGraph (needs a fixed target count per batch)
             allreduce_buckets=5,     # op ranges of the overlapped gradient exchange: RCCL all-reduces per step, issued while backward runs
         )

@@ -7,7 +7,7 @@ from typing import Dict, List
 
 import torch
 
-from computervision.pytorch_amd.train import FlatAdam, FusedTrainStep
+from computervision.pytorch_amd.train import DynamicLossScale, FlatAdam, FusedTrainStep
 from configs import Yolo8DetConfig
 from core.algorithms.yolo_v8 import YOLOv8
 from core.trainer.base import BaseTrainer
@@ -70,8 +70,12 @@ class Yolo8Trainer(BaseTrainer):
 
     def set_criterion(self):
         self.criterion = self.model_algorithm.build_loss(model=self.model)
-        self._step = FusedTrainStep(self.model, self.criterion, self.optimizer,
-                                    n_buckets=getattr(self.cfg.engine, "allreduce_buckets", 4))
+        eng_cfg = self.cfg.engine
+        scaler = None
+        if self.mixed_precision and getattr(eng_cfg, "dynamic_loss_scale", False) and not getattr(eng_cfg, "graph_capture", False):
+            scaler = DynamicLossScale(self.device, init_scale=getattr(eng_cfg, "init_loss_scale", 65536.0))
+        self._step = FusedTrainStep(self.model, self.criterion, self.optimizer, n_buckets=getattr(eng_cfg, "allreduce_buckets", 4),
+                                    scaler=scaler)
 
     def train_loop(self, batch_data, scaler) -> List:
         images = batch_data[0].to(self.device, non_blocking=True)

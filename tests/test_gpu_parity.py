@@ -438,3 +438,41 @@ def test_overlapped_exchange_is_bit_identical_to_plain_backward(dev):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_dynamic_loss_scale_skips_overflow_and_backs_off(dev):
+    """GradScaler semantics of the reference's mixed-precision loop (yolo8_train.py:99-104): a step with non-finite
+    gradients leaves parameters and Adam state untouched and halves the scale; finite steps at equal scale are
+    bit-identical to the static-scale path."""
+    from computervision.pytorch_amd.train import DynamicLossScale, FlatAdam, FusedTrainStep, V8DetectionLoss
+    from configs import Yolo8DetConfig
+    x, batch = synth.images(2, 128, 128, seed=1).to(dev), {k: v.to(dev) for k, v in synth.targets(2, seed=2).items()}
+    # (a) same scale, dynamic vs static: identical
+    runs = []
+    for dynamic in (False, True):
+        m = new_model(dev).train()
+        crit = V8DetectionLoss(Yolo8DetConfig(), m)
+        sc = DynamicLossScale(dev, init_scale=crit.loss_scale, growth_interval=1000) if dynamic else None
+        step = FusedTrainStep(m, crit, FlatAdam(m, lr=1e-3), scaler=sc)
+        for _ in range(3):
+            step(x, batch)
+        torch.cuda.synchronize()
+        runs.append(m.flat_params.clone().cpu())
+    assert torch.equal(runs[0], runs[1])
+    # (b) absurd scale: fp16 gradients overflow -> skipped steps, scale backs off until a step goes through
+    m = new_model(dev).train()
+    sc = DynamicLossScale(dev, init_scale=2.0 ** 40, growth_interval=1000)
+    opt = FlatAdam(m, lr=1e-3)
+    step = FusedTrainStep(m, V8DetectionLoss(Yolo8DetConfig(), m), opt, scaler=sc)
+    p0 = m.flat_params.clone()
+    step(x, batch)
+    torch.cuda.synchronize()
+    assert torch.equal(m.flat_params, p0)                          # skipped on the device
+    sc.poll()
+    assert sc.scale == 2.0 ** 39 and sc.skipped == 1
+    for _ in range(60):
+        step(x, batch)
+        torch.cuda.synchronize()
+    sc.poll()
+    assert sc.scale < 2.0 ** 30 and not torch.equal(m.flat_params, p0)
+    assert bool(torch.isfinite(m.flat_params).all()) and bool(torch.isfinite(opt._m).all())
