@@ -341,12 +341,35 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* pred, int B
   // ---- class BCE with logits (yolo_v8.py:113) ----
   int label = fg ? min(max(gtlabel[g], 0), nc - 1) : -1;
   const float kc = gain_cls * kscale;
-  for (int c = s; c < nc; c += 16) {
-    if (live) {
-      float x = p[4 * REG + c];
-      float t = (c == label) ? w : 0.f;
-      l_cls += fmaxf(x, 0.f) - x * t + log1pf(__expf(-fabsf(x)));
-      dp[4 * REG + c] = (half_t)((cvx_sigmoid(x) - t) * kc);
+  if ((nc & 3) == 0) {
+    // four classes per lane (16-byte loads, 8-byte stores) and ONE exponential per logit: with e = exp(-|x|),
+    // softplus(-|x|) = log1p(e) and sigmoid(x) = (x >= 0 ? 1 : e) / (1 + e)
+    for (int c4 = s * 4; c4 < nc; c4 += 64) {
+      if (live) {
+        const f4 x4 = *reinterpret_cast<const f4*>(p + 4 * REG + c4);
+        h4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float x = x4[k];
+          const float t = (c4 + k == label) ? w : 0.f;
+          const float e = __expf(-fabsf(x));
+          // log1p(e): short series where 1 + e would lose e's low bits, plain log otherwise (|error| < 1e-7 relative)
+          const float l1p = e < 1e-3f ? e * (1.f - e * (0.5f - e * (1.f / 3.f))) : __logf(1.f + e);
+          l_cls += fmaxf(x, 0.f) - x * t + l1p;
+          const float sg = (x >= 0.f ? 1.f : e) * __builtin_amdgcn_rcpf(1.f + e);
+          o[k] = (half_t)((sg - t) * kc);
+        }
+        *reinterpret_cast<h4*>(dp + 4 * REG + c4) = o;
+      }
+    }
+  } else {
+    for (int c = s; c < nc; c += 16) {
+      if (live) {
+        float x = p[4 * REG + c];
+        float t = (c == label) ? w : 0.f;
+        l_cls += fmaxf(x, 0.f) - x * t + log1pf(__expf(-fabsf(x)));
+        dp[4 * REG + c] = (half_t)((cvx_sigmoid(x) - t) * kc);
+      }
     }
   }
 
