@@ -1,6 +1,7 @@
 // BatchNorm + SiLU streaming passes (see bn_act.hip).
 #pragma once
 #include "cvx_common.h"
+#define CVX_BN_MAX_C 1024    // widest BatchNorm the streaming passes hold coefficients for (YOLOv8-m: 576, -x: 640)
 #define CVX_STAT_REPLICAS 16  // replica slabs the reduction kernels scatter their float atomics over
 
 // fp16 NHWC channel-slice view: element (b, pix, c) at p[b*bstride + pix*ld + c]

@@ -62,7 +62,7 @@ __global__ void bn_fold_kernel(int n, const float* gamma, const float* beta, con
 }
 
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const long long* part, int C, float inv_scale, float* dbias) {
-  __shared__ double s0[512], s1[512];
+  __shared__ double s0[CVX_BN_MAX_C], s1[CVX_BN_MAX_C];
   fold_replicas(part, C, s0, s1);
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) dbias[c] += (float)(s0[c] * inv_scale);
@@ -74,8 +74,8 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const long long* p
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const half_t* y, long long M, int C, int hw, BnTrainArgs a, ViewDesc out,
                                                             ViewDesc res, int rows_per_block) {
-  __shared__ double s0[512], s1[512];
-  __shared__ float s_sc[512], s_sh[512];
+  __shared__ double s0[CVX_BN_MAX_C], s1[CVX_BN_MAX_C];
+  __shared__ float s_sc[CVX_BN_MAX_C], s_sh[CVX_BN_MAX_C];
   fold_replicas(a.stats, C, s0, s1);
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const half_t* y, lon
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const half_t* y, long long M, int C, int hw, BnCoef k, const long long* part,
                                                            float inv_scale, float* dgamma, float* dbeta, ViewDesc gout, half_t* dy, ViewDesc gres,
                                                            int res_accumulate, int rows_per_block) {
-  __shared__ double s0[512], s1[512];
+  __shared__ double s0[CVX_BN_MAX_C], s1[CVX_BN_MAX_C];
   fold_replicas(part, C, s0, s1);
   __syncthreads();
   if (blockIdx.x == 0) {
@@ -353,7 +353,7 @@ int cvx_stream_rows_per_block(long long M, int C, int kb_per_block) {
 static int blocks_for(long long M, int rows) { return (int)((M + rows - 1) / rows); }
 
 static int check_c(int C, long long M = 0) {
-  CVX_CHECK(C % 8 == 0 && C >= 8 && C <= 512, "bn_act: C must be a multiple of 8 in [8, 512]");
+  CVX_CHECK(C % 8 == 0 && C >= 8 && C <= CVX_BN_MAX_C, "bn_act: C must be a multiple of 8 in [8, 1024]");
   CVX_CHECK(M < (1LL << 32), "bn_act: more than 2^32 rows");
   return 0;
 }

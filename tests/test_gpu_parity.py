@@ -476,3 +476,22 @@ def test_dynamic_loss_scale_skips_overflow_and_backs_off(dev):
     sc.poll()
     assert sc.scale < 2.0 ** 30 and not torch.equal(m.flat_params, p0)
     assert bool(torch.isfinite(m.flat_params).all()) and bool(torch.isfinite(opt._m).all())
+
+
+@pytest.mark.parametrize("scale", ["m", "x"])
+def test_wider_scales_train_through_the_engine(dev, scale):
+    """YOLOv8-m/-x reach 576/640-channel layers (BatchNorm passes up to 1024 channels, kernels fall back where a fast path
+    has no instantiation): a few fused steps must run, stay finite and reduce the loss."""
+    from computervision.pytorch_amd.model import Yolo8
+    from computervision.pytorch_amd.train import FlatAdam, FusedTrainStep, V8DetectionLoss
+    from configs import Yolo8DetConfig
+    cfg = Yolo8DetConfig()
+    cfg.arch.model_type = scale
+    torch.manual_seed(0)
+    m = Yolo8(scale, 80, loss_scale=1024.0).to(dev).train()
+    step = FusedTrainStep(m, V8DetectionLoss(cfg, m), FlatAdam(m, lr=1e-3))
+    x, batch = synth.images(2, 128, 128, seed=1).to(dev), {k: v.to(dev) for k, v in synth.targets(2, seed=2).items()}
+    losses = [float(step(x, batch).sum()) for _ in range(6)]
+    torch.cuda.synchronize()
+    assert all(np.isfinite(losses)) and bool(torch.isfinite(m.flat_params).all())
+    assert min(losses[3:]) < losses[0]
