@@ -157,6 +157,26 @@ def test_model_scale_s_runs_and_matches_oracle(dev):
         assert rel(o, r.detach()) < 2e-3
 
 
+def test_non_square_input_matches_oracle(dev):
+    """96 x 160 (3 x 5 cells at stride 32): tile edges in both directions, widths that are not multiples of 16."""
+    x = torch.rand(3, 3, 96, 160, generator=torch.Generator().manual_seed(11))
+    m = new_model(dev).train()
+    with torch.no_grad():
+        outs = m(x.to(dev))
+    assert [tuple(o.shape) for o in outs] == [(3, 144, 12, 20), (3, 144, 6, 10), (3, 144, 3, 5)]
+    with fp16_storage():
+        ref = O.forward(O.init_state_dict("n", 80, seed=0), x, "n", 80, training=True)
+    for o, r in zip(outs, ref):
+        assert rel(o, r.detach()) < 2e-3
+    # and a fused training step on it stays finite (data / weight gradients at the same odd tile edges)
+    from computervision.pytorch_amd.train import FlatAdam, FusedTrainStep, V8DetectionLoss
+    from configs import Yolo8DetConfig
+    step = FusedTrainStep(m, V8DetectionLoss(Yolo8DetConfig(), m), FlatAdam(m, lr=1e-3))
+    batch = {k: v.to(dev) for k, v in synth.targets(3, seed=5).items()}
+    losses = [float(step(x.to(dev), batch).sum()) for _ in range(4)]
+    assert all(np.isfinite(losses)) and bool(torch.isfinite(m.flat_params).all())
+
+
 # ---- loss ------------------------------------------------------------------------------------------------------
 def _loss_case(B, H, seed):
     hw = [(H // s, H // s) for s in (8, 16, 32)]
