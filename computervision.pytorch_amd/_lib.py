@@ -69,6 +69,9 @@ PROTOTYPES = {
     "cvx_loss_v8_workspace_bytes": (_I64, [_I32, _I32, _I32, _I32]),
     "cvx_loss_v8": (_I32, [_P, _I32, _I32, _I32, _P, _I32, _I32, C.POINTER(_I32), C.POINTER(_F), _I32, _F, _F, _F, _F, _P, _P, _P,
                            _I64, _P]),
+    "cvx_loss_v8_strided": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _I32, _I32, C.POINTER(_I32), C.POINTER(_F), _I32, _F, _F, _F, _F, _P, _P, _P,
+                                   _I64, _P]),
+    "cvx_decode_strided": (_I32, [_P, _I32, _I32, _I32, _I32, C.POINTER(_I32), C.POINTER(_F), _I32, _P, _P]),
     "cvx_adam_step": (_I32, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I32, _P, _I32, _P]),
     "cvx_check_finite": (_I32, [_P, _I64, _P, _P]),
     "cvx_adam_step_dev": (_I32, [_P, _P, _P, _P, _I64, _F, _F, _F, _P, _P, _I32, _F, _P]),

@@ -514,13 +514,22 @@ extern "C" int64_t cvx_loss_v8_workspace_bytes(int32_t batch, int32_t anchors, i
 extern "C" int cvx_loss_v8(const float* pred, int32_t B, int32_t A, int32_t nc, const float* targets, int32_t N, int32_t max_targets,
                            const int32_t* level_hw, const float* strides, int32_t n_levels, float gain_box, float gain_cls, float gain_dfl,
                            float loss_scale, float* loss_items, void* dpred_f16, void* workspace, int64_t workspace_bytes, void* hip_stream) {
+  return cvx_loss_v8_strided(pred, nc + 4 * REG, B, A, nc, targets, N, max_targets, level_hw, strides, n_levels, gain_box, gain_cls, gain_dfl,
+                             loss_scale, loss_items, dpred_f16, workspace, workspace_bytes, hip_stream);
+}
+
+extern "C" int cvx_loss_v8_strided(const float* pred, int32_t pred_ld, int32_t B, int32_t A, int32_t nc, const float* targets, int32_t N,
+                                   int32_t max_targets, const int32_t* level_hw, const float* strides, int32_t n_levels, float gain_box,
+                                   float gain_cls, float gain_dfl, float loss_scale, float* loss_items, void* dpred_f16, void* workspace,
+                                   int64_t workspace_bytes, void* hip_stream) {
   CVX_CHECK(pred && loss_items && dpred_f16 && workspace && level_hw && strides, "null arguments");
+  CVX_CHECK(pred_ld >= nc + 4 * REG && pred_ld % 4 == 0, "pred_ld must cover 64 + nc values and be a multiple of 4");
   CVX_CHECK(n_levels >= 1 && n_levels <= MAXLV, "1..4 levels");
   CVX_CHECK(N >= 0 && N <= max_targets && (N == 0 || targets), "targets");
   CVX_CHECK(workspace_bytes >= cvx_loss_v8_workspace_bytes(B, A, nc, max_targets), "workspace too small");
-  CVX_CHECK(((uintptr_t)pred % 16) == 0 && ((uintptr_t)dpred_f16 % 8) == 0 && (nc + 4 * REG) % 4 == 0, "alignment");
+  CVX_CHECK(((uintptr_t)pred % 16) == 0 && ((uintptr_t)dpred_f16 % 8) == 0, "alignment");
   hipStream_t st = (hipStream_t)hip_stream;
-  const int no = nc + 4 * REG;
+  const int no = pred_ld;  // row pitch of pred and dpred; columns beyond 64 + nc are neither read nor written
   Levels L;
   memset(&L, 0, sizeof(L));
   L.n = n_levels;

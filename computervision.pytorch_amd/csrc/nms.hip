@@ -224,7 +224,13 @@ long long al(long long x) { return (x + 255) & ~255LL; }
 
 extern "C" int cvx_decode(const float* pred, int32_t B, int32_t A, int32_t nc, const int32_t* level_hw, const float* strides, int32_t n_levels,
                           float* y, void* hip_stream) {
+  return cvx_decode_strided(pred, nc + 4 * REG, B, A, nc, level_hw, strides, n_levels, y, hip_stream);
+}
+
+extern "C" int cvx_decode_strided(const float* pred, int32_t pred_ld, int32_t B, int32_t A, int32_t nc, const int32_t* level_hw,
+                                  const float* strides, int32_t n_levels, float* y, void* hip_stream) {
   CVX_CHECK(pred && y && level_hw && strides && n_levels >= 1 && n_levels <= MAXLV, "bad arguments");
+  CVX_CHECK(pred_ld >= nc + 4 * REG, "pred_ld must cover 64 + nc values");
   Levels L;
   memset(&L, 0, sizeof(L));
   L.n = n_levels;
@@ -236,7 +242,7 @@ extern "C" int cvx_decode(const float* pred, int32_t B, int32_t A, int32_t nc, c
     off += level_hw[2 * i] * level_hw[2 * i + 1];
   }
   CVX_CHECK(off == A, "level sizes do not add up to the anchor count");
-  hipLaunchKernelGGL(decode_kernel, dim3(cvx_cdiv((long long)B * A, 256)), dim3(256), 0, (hipStream_t)hip_stream, pred, B, A, nc + 4 * REG, nc, L,
+  hipLaunchKernelGGL(decode_kernel, dim3(cvx_cdiv((long long)B * A, 256)), dim3(256), 0, (hipStream_t)hip_stream, pred, B, A, pred_ld, nc, L,
                      y);
   CVX_HIP(hipGetLastError());
   return 0;

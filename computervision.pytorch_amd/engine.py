@@ -132,7 +132,8 @@ def _levels(level_hw: Sequence[Sequence[int]], strides: Sequence[float]):
 
 
 class V8LossOp:
-    """cvx_loss_v8: loss items + fp16 gradient w.r.t. pred (B, A, no)."""
+    """cvx_loss_v8: loss items + fp16 gradient w.r.t. pred.  Returns ``(items, dpred)`` with dpred of shape
+    (B, A, ld), ld = row pitch of pred (>= no; columns beyond no are zero) -- the layout cvx_engine_backward reads."""
 
     def __init__(self, nc: int, gains=(7.5, 0.5, 1.5)):
         self.lib = L.load()
@@ -143,9 +144,14 @@ class V8LossOp:
     def __call__(self, pred: torch.Tensor, targets: torch.Tensor, level_hw, strides, loss_scale: float,
                  dpred: Optional[torch.Tensor] = None):
         _need_gpu(pred, "pred")
-        assert pred.dtype == torch.float32 and pred.is_contiguous()
+        # pred may be the [..., :64+nc] view of a row-padded buffer (class counts that are not multiples of 8)
         B, A, no = pred.shape
-        assert no == self.nc + 64
+        assert pred.dtype == torch.float32 and no == self.nc + 64
+        if not (pred.stride(2) == 1 and pred.stride(0) == A * pred.stride(1) and pred.stride(1) % 4 == 0):
+            padded = torch.zeros(B, A, (no + 3) & ~3, dtype=torch.float32, device=pred.device)   # 16-byte row pitch
+            padded[..., :no] = pred
+            pred = padded[..., :no]
+        ld = pred.stride(1)
         n = int(targets.shape[0])
         if n:
             _need_gpu(targets, "targets")
@@ -155,12 +161,13 @@ class V8LossOp:
         if self._ws is None or self._ws.numel() < need or self._ws.device != pred.device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=pred.device)
         if dpred is None:
-            dpred = torch.empty(B, A, no, dtype=torch.float16, device=pred.device)
+            dpred = torch.zeros(B, A, ld, dtype=torch.float16, device=pred.device)   # padding columns stay zero
+        assert dpred.is_contiguous() and dpred.shape[2] == ld
         items = torch.empty(3, dtype=torch.float32, device=pred.device)
         lv, st, nl = _levels(level_hw, strides)
-        L.check(self.lib.cvx_loss_v8(L.ptr(pred), B, A, self.nc, L.ptr(targets) if n else C.c_void_p(0), n, cap, lv, st, nl, self.gains[0],
-                                     self.gains[1], self.gains[2], float(loss_scale), L.ptr(items), L.ptr(dpred), L.ptr(self._ws),
-                                     self._ws.numel(), L.stream_ptr(pred.device)), "cvx_loss_v8")
+        L.check(self.lib.cvx_loss_v8_strided(L.ptr(pred), ld, B, A, self.nc, L.ptr(targets) if n else C.c_void_p(0), n, cap, lv, st, nl,
+                                             self.gains[0], self.gains[1], self.gains[2], float(loss_scale), L.ptr(items), L.ptr(dpred),
+                                             L.ptr(self._ws), self._ws.numel(), L.stream_ptr(pred.device)), "cvx_loss_v8")
         return items, dpred
 
 
@@ -189,9 +196,11 @@ def decode(pred: torch.Tensor, nc: int, level_hw, strides) -> torch.Tensor:
     lib = L.load()
     _need_gpu(pred, "pred")
     B, A, no = pred.shape
+    if not (pred.stride(2) == 1 and pred.stride(0) == A * pred.stride(1)):
+        pred = pred.contiguous()
     y = torch.empty(B, 4 + nc, A, dtype=torch.float32, device=pred.device)
     lv, st, nl = _levels(level_hw, strides)
-    L.check(lib.cvx_decode(L.ptr(pred.contiguous()), B, A, nc, lv, st, nl, L.ptr(y), L.stream_ptr(pred.device)), "cvx_decode")
+    L.check(lib.cvx_decode_strided(L.ptr(pred), pred.stride(1), B, A, nc, lv, st, nl, L.ptr(y), L.stream_ptr(pred.device)), "cvx_decode")
     return y
 
 

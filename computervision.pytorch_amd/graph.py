@@ -61,6 +61,7 @@ class ConvSpec:
     bias_off: int = 0
     rmean_off: int = 0
     rvar_off: int = 0
+    cout_eng: int = 0           # output channels the ENGINE computes: cout rounded up to 8 for the bias convs (zero rows)
 
     @property
     def cout(self):
@@ -82,6 +83,8 @@ class ParamLayout:
         self.c_box = max(16, self.head_in[0] // 4, REG_MAX * 4)        # modules.py:422
         self.c_cls = max(self.head_in[0], nc)
         self.no = nc + 4 * REG_MAX
+        self.nc_pad = (nc + 7) & ~7                    # class columns of the engine's pred buffer
+        self.no_pad = self.nc_pad + 4 * REG_MAX
         self.slots: "OrderedDict[str, TensorSlot]" = OrderedDict()
         self.convs: Dict[str, ConvSpec] = {}
         self._p = 0
@@ -104,14 +107,21 @@ class ParamLayout:
     def _add_conv(self, name: str, prefixes, couts, cin, k, bn=True) -> ConvSpec:
         spec = ConvSpec(list(prefixes), list(couts), cin, k, bn)
         ct = spec.cout
-        spec.w_off = self._take("param", ct * k * k * cin)
+        # the head's class conv has nc output rows; the engine's kernels work on 8-channel groups, so its arena block is
+        # padded with zero rows (weights, bias and gradients stay zero; the state_dict views cover the real rows only)
+        ce = ct if bn else (ct + 7) & ~7
+        if bn and ct % 8:
+            raise ValueError(f"{name}: {ct} output channels -- the MI355X engine needs BatchNorm layers in multiples of 8 "
+                             f"(class counts in (64, 100] must be multiples of 8 for this model scale)")
+        spec.cout_eng = ce
+        spec.w_off = self._take("param", ce * k * k * cin)
         if bn:
             spec.gamma_off = self._take("param", ct)
             spec.beta_off = self._take("param", ct)
             spec.rmean_off = self._take("stat", ct)
             spec.rvar_off = self._take("stat", ct)
         else:
-            spec.bias_off = self._take("param", ct)
+            spec.bias_off = self._take("param", ce)
         self.convs[name] = spec
         # state_dict views, segment by segment (segments are adjacent inside the op's arena block)
         c0 = 0
@@ -212,7 +222,7 @@ def build_yolov8_graph(lay: ParamLayout, H: int, W: int) -> Graph:
         s = lay.convs[name]
         k = s.k
         ho, wo = (hin + 2 * (k // 2) - k) // stride + 1, (win + 2 * (k // 2) - k) // stride + 1
-        assert vout[2] == s.cout, (name, vout, s.cout)
+        assert vout[2] == s.cout_eng, (name, vout, s.cout_eng)
         op = dict(type=L.OP_CONV, name=name, out=vout, ih=hin, iw=win, oh=ho, ow=wo, k=k, stride=stride, pad=k // 2, dil=1,
                   act=L.ACT_BN_SILU if s.bn else L.ACT_BIAS, needs_dgrad=needs_dgrad, w_cin=s.cin, w_off=s.w_off,
                   gamma_off=s.gamma_off, beta_off=s.beta_off, bias_off=s.bias_off, rmean_off=s.rmean_off, rvar_off=s.rvar_off)
@@ -290,7 +300,7 @@ def build_yolov8_graph(lay: ParamLayout, H: int, W: int) -> Graph:
     # Detect (modules.py:428-433): per level one fused 3x3 (box|cls), two 3x3, two 1x1+bias into pred
     g.level_hw = [(h8, w8), (h16, w16), (h32, w32)]
     g.anchors = sum(a * b for a, b in g.level_hw)
-    pred = buf(g.anchors, 1, lay.no, L.BUF_PRED_F32)
+    pred = buf(g.anchors, 1, lay.no_pad, L.BUF_PRED_F32)
     g.pred_buf = pred
     a_off = 0
     cb, cc = lay.c_box, lay.c_cls
@@ -303,7 +313,7 @@ def build_yolov8_graph(lay: ParamLayout, H: int, W: int) -> Graph:
         conv(f"22.{lvl}.1b", View(h1, 0, cb), View(hb, 0, cb), hh, ww)
         conv(f"22.{lvl}.1c", View(h1, cb, cc), View(hc, 0, cc), hh, ww)
         conv(f"22.{lvl}.2b", View(hb, 0, cb), View(pred, 0, 4 * REG_MAX, a_off), hh, ww)
-        conv(f"22.{lvl}.2c", View(hc, 0, cc), View(pred, 4 * REG_MAX, lay.nc, a_off), hh, ww)
+        conv(f"22.{lvl}.2c", View(hc, 0, cc), View(pred, 4 * REG_MAX, lay.nc_pad, a_off), hh, ww)
         for op in g.ops[first:]:
             op["lane"] = 1 + lvl          # the three Detect levels are independent: own HIP stream each (cvx_op_desc.lane)
         a_off += hh * ww
@@ -332,7 +342,7 @@ def grad_buckets(g: Graph, lay: ParamLayout, n_buckets: int, tail_modules: int =
         if o["type"] == L.OP_CONV:
             spec = lay.convs[o["name"]]
             start = spec.w_off
-            end = ((spec.beta_off if spec.bn else spec.bias_off) + spec.cout + 3) & ~3
+            end = ((spec.beta_off + spec.cout if spec.bn else spec.bias_off + spec.cout_eng) + 3) & ~3
             mods[-1][2] = start if mods[-1][2] is None else min(mods[-1][2], start)
             mods[-1][3] = end if mods[-1][3] is None else max(mods[-1][3], end)
     merged = []

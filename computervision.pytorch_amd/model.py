@@ -285,10 +285,11 @@ class Yolo8(nn.Module):
             raise ValueError("expected images of shape (B, 3, H, W)")
         eng = self.engine_for(int(images.shape[2]), int(images.shape[3]))
         self._last_engine = eng
-        out = eng.forward(images, training, pred)
+        out = eng.forward(images, training, pred)          # (B, A, no_pad): class columns padded to a multiple of 8
         if training:
             self._flat["nbt"] += 1
-        return out
+        no = self.layout.no
+        return out if out.shape[2] == no else out[..., :no]  # the reference's (B, A, 64 + nc) as a view of the padded rows
 
     def attach_grads(self):
         """Make ``p.grad`` of every parameter a view of the flat gradient arena (torch optimisers / GradScaler)."""
@@ -306,8 +307,12 @@ class Yolo8(nn.Module):
         if first.grad is None:               # optimizer.zero_grad(set_to_none=True) happened (or first step)
             self.flat_grads.zero_()
             self._grads_attached = False
-        dpred = (gpred * self.loss_scale).to(torch.float16).contiguous()
-        self._last_engine.backward(dpred, self.loss_scale)
+        dpred = (gpred * self.loss_scale).to(torch.float16)
+        if self.layout.no_pad != self.layout.no:             # the engine reads rows of no_pad values; the padding is zero
+            padded = torch.zeros(*dpred.shape[:2], self.layout.no_pad, dtype=torch.float16, device=dpred.device)
+            padded[..., :self.layout.no] = dpred
+            dpred = padded
+        self._last_engine.backward(dpred.contiguous(), self.loss_scale)
         if not self._grads_attached or first.grad is None:
             self.attach_grads()
 

@@ -34,7 +34,8 @@ def flatten_targets(batch: Dict[str, torch.Tensor], device) -> torch.Tensor:
 class _LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, targets, owner, level_hw):
-        items, dpred = owner.op(pred.detach().contiguous(), targets, level_hw, STRIDES, owner.loss_scale)
+        items, dpred = owner.op(pred.detach(), targets, level_hw, STRIDES, owner.loss_scale)
+        dpred = dpred[..., :pred.shape[2]]                       # row-padded buffer -> the gradient of pred itself
         ctx.save_for_backward(dpred)
         ctx.inv_scale = 1.0 / owner.loss_scale
         owner.last_items = items
@@ -241,10 +242,10 @@ class FusedTrainStep:
         dev = m.flat_params.device
         B, _, H, W = images.shape
         eng = m.engine_for(H, W)
-        A, no = eng.graph.anchors, m.model[-1].no
+        A, no = eng.graph.anchors, m.layout.no_pad          # rows of the engine's pred buffer (class columns padded to 8)
         if self._pred is None or self._pred.shape[0] != B or self._pred.shape[1] != A:
             self._pred = torch.empty(B, A, no, device=dev)
-            self._dpred = torch.empty(B, A, no, device=dev, dtype=torch.float16)
+            self._dpred = torch.zeros(B, A, no, device=dev, dtype=torch.float16)   # the loss never writes the padding
         targets = flatten_targets(batch, dev)
         dynamic = self.scaler is not None and not self.use_graph
         scale = self.scaler.begin_step() if dynamic else crit.loss_scale

@@ -147,6 +147,12 @@ int cvx_loss_v8(const float* pred, int32_t batch, int32_t anchors, int32_t nc, c
                 int32_t max_targets_per_image, const int32_t* level_hw, const float* strides, int32_t n_levels, float gain_box,
                 float gain_cls, float gain_dfl, float loss_scale, float* loss_items, void* dpred_f16, void* workspace,
                 int64_t workspace_bytes, void* hip_stream);
+/* Same with an explicit row pitch (multiple of 4, >= 64 + nc) of pred and dpred; columns beyond 64 + nc are neither read
+ * nor written (the caller keeps the padding of dpred zero). */
+int cvx_loss_v8_strided(const float* pred, int32_t pred_ld, int32_t batch, int32_t anchors, int32_t nc, const float* targets,
+                        int32_t n_targets, int32_t max_targets_per_image, const int32_t* level_hw, const float* strides, int32_t n_levels,
+                        float gain_box, float gain_cls, float gain_dfl, float loss_scale, float* loss_items, void* dpred_f16,
+                        void* workspace, int64_t workspace_bytes, void* hip_stream);
 
 /* ---- optimiser ------------------------------------------------------------------------------------
  * torch.optim.Adam semantics (core/trainer/lr_scheduler.py:37-43): lr, betas, eps, no weight decay;
@@ -170,6 +176,10 @@ int cvx_adam_step_dev(float* params, float* grads, float* exp_avg, float* exp_av
  *   Replaces: non_max_suppression, core/utils/ultralytics_ops.py:131-264. */
 int cvx_decode(const float* pred, int32_t batch, int32_t anchors, int32_t nc, const int32_t* level_hw, const float* strides,
                int32_t n_levels, float* y, void* hip_stream);
+/* Same with an explicit row pitch of pred (>= 64 + nc): class counts that are not multiples of 8 (VOC: 20) run with the
+ * class columns padded to the next multiple of 8; the padding is never read. */
+int cvx_decode_strided(const float* pred, int32_t pred_ld, int32_t batch, int32_t anchors, int32_t nc, const int32_t* level_hw,
+                       const float* strides, int32_t n_levels, float* y, void* hip_stream);
 int64_t cvx_nms_workspace_bytes(int32_t batch, int32_t anchors);
 int cvx_nms(const float* y, int32_t batch, int32_t anchors, int32_t nc, float conf_thres, float iou_thres, int32_t max_det,
             float* out_rows, int32_t* out_index, int32_t* counts, void* workspace, int64_t workspace_bytes, void* hip_stream);
