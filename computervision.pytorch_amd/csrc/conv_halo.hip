@@ -277,11 +277,8 @@ int launch_halo_hv(const ConvParams& p, hipStream_t stream, int gy) {
   using G = HaloGeom<WM, WN, MT, NTW, CIN, HV>;
   const int tiles_x = (p.IW + 15) / 16, tiles_y = (p.IH + G::TH - 1) / G::TH;
   const int total = tiles_x * tiles_y * p.B;
-  static bool attr_done = false;
-  if (!attr_done) {
-    CVX_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<WM, WN, MT, NTW, CIN, HV>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
-    attr_done = true;
-  }
+  static unsigned long long optin_mask = 0;  // per device (cvx_lds_optin)
+  CVX_TRY(cvx_lds_optin((const void*)conv_halo_kernel<WM, WN, MT, NTW, CIN, HV>, G::LDS_BYTES, &optin_mask));
   // persistent: as many workgroups as fit on the 256 CUs at once (LDS-limited, at most CVX_HALO_OCC per CU), split
   // over the gy channel blocks; each walks the tile list with that stride (HV tiles per workgroup and trip)
   static const int occ_cap = getenv("CVX_HALO_OCC") ? atoi(getenv("CVX_HALO_OCC")) : 4;

@@ -307,12 +307,8 @@ int env_int(const char* name, int dflt) {
 template <int WM, int WN, int MT, int NTW, int STAGES>
 int launch_st(const ConvParams& p, hipStream_t stream, dim3 grid) {
   using G = Geom<WM, WN, MT, NTW, STAGES>;
-  static bool attr_done = false;  // > 64 KB of dynamic LDS needs the opt-in once per kernel
-  if (!attr_done) {
-    CVX_HIP(hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<WM, WN, MT, NTW, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                G::LDS_BYTES));
-    attr_done = true;
-  }
+  static unsigned long long optin_mask = 0;  // per device (cvx_lds_optin)
+  CVX_TRY(cvx_lds_optin((const void*)conv_igemm_dma_kernel<WM, WN, MT, NTW, STAGES>, G::LDS_BYTES, &optin_mask));
   hipLaunchKernelGGL((conv_igemm_dma_kernel<WM, WN, MT, NTW, STAGES>), grid, dim3(256), G::LDS_BYTES, stream, p);
   return 0;
 }

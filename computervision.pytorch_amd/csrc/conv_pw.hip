@@ -149,11 +149,8 @@ int launch_pw(const ConvParams& p, hipStream_t stream, int gy) {
     const int hw = p.OH2 * p.OW2;
     const long long M = (long long)p.B * hw;
     const int n_wave_tiles = (int)((M + MT * 16 - 1) / (MT * 16));
-    static bool attr_done = false;
-    if (!attr_done) {
-      CVX_HIP(hipFuncSetAttribute((const void*)conv_pw_kernel<MT, NTW, NSTEPS>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
-      attr_done = true;
-    }
+    static unsigned long long optin_mask = 0;  // per device (cvx_lds_optin)
+    CVX_TRY(cvx_lds_optin((const void*)conv_pw_kernel<MT, NTW, NSTEPS>, G::LDS_BYTES, &optin_mask));
     static const int occ_cap = getenv("CVX_PW_OCC") ? atoi(getenv("CVX_PW_OCC")) : 4;
     int per_cu = (160 * 1024) / G::LDS_BYTES;
     per_cu = per_cu < 1 ? 1 : (per_cu > occ_cap ? occ_cap : per_cu);

@@ -40,6 +40,18 @@ void cvx_set_error(const std::string& msg);
 
 static inline int cvx_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// Opt-in to more than 64 KB of dynamic LDS for a kernel.  The attribute is per device: one bit per device ordinal in the
+// caller's static mask, so a process that drives several GPUs (one engine each) opts in on each of them.
+inline int cvx_lds_optin(const void* kernel, int bytes, unsigned long long* done_mask) {
+  int dev = 0;
+  CVX_HIP(hipGetDevice(&dev));
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (*done_mask & bit) return 0;
+  CVX_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  *done_mask |= bit;
+  return 0;
+}
+
 // ---- small device helpers ---------------------------------------------------------------------
 // v_exp_f32 + v_rcp_f32 (1 ulp each) instead of the ~10-instruction IEEE division: the elementwise BN/SiLU passes are
 // VALU-limited on the big layers, and every consumer rounds the result to fp16 anyway.
