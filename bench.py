@@ -137,6 +137,19 @@ def main():
     sync()
     prof = eng.profile_read()
     eng.profile(False)
+    # inference forward (BN folded into the conv epilogues, no BN passes): the north_star quotes its MFMA fraction
+    model.eval()
+    with torch.no_grad():
+        for _ in range(3):
+            model._run_forward(x, False)
+        sync()
+        t1 = time.perf_counter()
+        n_eval = 20
+        for _ in range(n_eval):
+            model._run_forward(x, False)
+        sync()
+    eval_ms = (time.perf_counter() - t1) / n_eval * 1e3
+    model.train()
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -182,6 +195,10 @@ def main():
                                        "frac": round(achieved / MFMA_FP16_PEAK_TFLOPS, 5), "algorithmic_flops_per_step": conv_fl / prof_steps}},
             "whole_step": {"train_tflops": round(value / world * TRAIN_GFLOP_PER_IMG / 1e3, 3),
                            "frac_of_mfma_peak": round(value / world * TRAIN_GFLOP_PER_IMG / 1e3 / MFMA_FP16_PEAK_TFLOPS, 5)},
+            "forward_eval": {"ms_per_batch": round(eval_ms, 4), "images_per_sec": round(B / eval_ms * 1e3, 1),
+                             "tflops": round(B * FWD_GFLOP_PER_IMG / eval_ms, 2),
+                             "frac_of_mfma_peak": round(B * FWD_GFLOP_PER_IMG / eval_ms / MFMA_FP16_PEAK_TFLOPS, 5),
+                             "note": "per GPU; eval-mode forward of the same batch, folded BN + SiLU in the conv epilogues"},
             "kernel_classes": classes,
             "loss_items_last_step": loss_items,
             "engine_workspace_gib": round(eng.workspace_bytes() / 2 ** 30, 3),

@@ -32,6 +32,15 @@ struct BnTrainArgs {
 
 int cvx_stream_rows_per_block(long long M, int C, int kb_per_block);
 
+// every BN layer of the network in one launch (eval-mode forward): one workgroup per descriptor
+struct BnFoldDesc {
+  long long gamma_off, beta_off;  // element offsets into the parameter arena
+  long long rmean_off, rvar_off;  // ... into the statistics arena
+  float* scale;                   // outputs (C floats each)
+  float* shift;
+  int C, pad_;
+};
+int cvx_bn_fold_all(const BnFoldDesc* descs, int n, const float* params, const float* stats, float eps, hipStream_t st);
 int cvx_bn_fold(int n, const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps, float* scale, float* shift,
                 hipStream_t st);
 int cvx_bn_silu_apply(const half_t* y, long long M, int C, int hw, const BnTrainArgs& a, const ViewDesc& out, const ViewDesc& res,

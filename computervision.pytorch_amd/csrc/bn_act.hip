@@ -61,6 +61,15 @@ __global__ void bn_fold_kernel(int n, const float* gamma, const float* beta, con
   }
 }
 
+__global__ __launch_bounds__(256) void bn_fold_all_kernel(const BnFoldDesc* descs, const float* params, const float* stats, float eps) {
+  const BnFoldDesc d = descs[blockIdx.x];
+  for (int i = threadIdx.x; i < d.C; i += 256) {
+    const float sc = params[d.gamma_off + i] / sqrtf(stats[d.rvar_off + i] + eps);
+    d.scale[i] = sc;
+    d.shift[i] = params[d.beta_off + i] - stats[d.rmean_off + i] * sc;
+  }
+}
+
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const long long* part, int C, float inv_scale, float* dbias) {
   __shared__ double s0[CVX_BN_MAX_C], s1[CVX_BN_MAX_C];
   fold_replicas(part, C, s0, s1);
@@ -358,6 +367,12 @@ static int check_c(int C, long long M = 0) {
   return 0;
 }
 
+int cvx_bn_fold_all(const BnFoldDesc* descs, int n, const float* params, const float* stats, float eps, hipStream_t st) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(bn_fold_all_kernel, dim3(n), dim3(256), 0, st, descs, params, stats, eps);
+  CVX_HIP(hipGetLastError());
+  return 0;
+}
 int cvx_bn_fold(int n, const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps, float* scale, float* shift,
                 hipStream_t st) {
   hipLaunchKernelGGL(bn_fold_kernel, dim3(cvx_cdiv(n, 256)), dim3(256), 0, st, n, gamma, beta, rmean, rvar, eps, scale, shift);

@@ -116,6 +116,8 @@ struct cvx_engine {
   int n_slab_blocks = 0;
   // the slab reduction runs in two parts: everything but the first `tail` conv ops as soon as THEIR weight gradients are
   // done (overlapping the last, largest-image weight gradients on the side stream), then the rest
+  BnFoldDesc* d_fold = nullptr;  // eval-mode BN fold table (one entry per BN conv), rebuilt with the batch plan
+  int n_fold = 0;
   int slab_tail_blocks = 0;  // reducer workgroups of the first ops (the tail of the backward pass)
   int slab_tail_op = -1;     // op index of the last conv op outside the tail (-1: single reduction)
   hipEvent_t ev_mid = nullptr;
@@ -375,6 +377,7 @@ int plan_batch(cvx_engine* e, int B, bool training) {
   long long stat_floats = 0, slab_total = 0;
   std::vector<SlabDesc> sdescs;
   std::vector<BlockRef> sblocks;
+  std::vector<BnFoldDesc> folds;
   e->slab_tail_blocks = 0;
   e->slab_tail_op = -1;
   for (size_t i = 0; i < e->ops.size(); ++i) {
@@ -395,6 +398,7 @@ int plan_batch(cvx_engine* e, int B, bool training) {
     c.invstd = c.mean + C;
     c.scale = c.invstd + C;
     c.shift = c.scale + C;
+    if (o.act == CVX_ACT_BN_SILU) folds.push_back(BnFoldDesc{o.gamma_off, o.beta_off, o.rmean_off, o.rvar_off, c.scale, c.shift, C, 0});
     if (training && o.act == CVX_ACT_BN_SILU) {
       CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, M * C * 2));
       c.ybuf = (half_t*)p;
@@ -460,6 +464,8 @@ int plan_batch(cvx_engine* e, int B, bool training) {
       sdescs.push_back(sd);
     }
   }
+  CVX_TRY(upload(e, e->batch_allocs, e->batch_bytes, &e->d_fold, folds));
+  e->n_fold = (int)folds.size();
   CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, 2 * stat_floats * 8));
   e->stat_region = (long long*)p;
   e->stat_half = stat_floats;
@@ -700,6 +706,7 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
   }
   const Buf& pb = e->bufs[e->pred_buf];
   const long long A = (long long)pb.d.h * pb.d.w;
+  if (!training) CVX_TRY(cvx_bn_fold_all(e->d_fold, e->n_fold, e->params, e->stats, e->bn_eps, st));  // eval: running stats -> scale/shift
 
   for (size_t i = 0; i < e->ops.size(); ++i) {
     const cvx_op_desc& o = e->ops[i];
@@ -751,8 +758,7 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
                      e->stats + o.rvar_off, e->bn_eps,       e->bn_momentum};
       CVX_TRY(cvx_bn_silu_apply(c.ybuf, M, C, o.oh * o.ow, ta, outv, resv, st));
     } else {
-      CVX_TRY(cvx_bn_fold(C, e->params + o.gamma_off, e->params + o.beta_off, e->stats + o.rmean_off, e->stats + o.rvar_off, e->bn_eps,
-                          c.scale, c.shift, st));
+      // scale / shift were folded for every layer at once before the op loop (cvx_bn_fold_all)
       cp.epi = CVX_EPI_AFFINE_SILU;
       cp.scale = c.scale;
       cp.shift = c.shift;
