@@ -117,13 +117,13 @@ def main():
 
     for _ in range(max(args.warmup, 2 if use_graph else 0)):
         items = step(x, batch)
-    eng = model._last_engine
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         items = step(x, batch)
     sync()
     elapsed = time.perf_counter() - t0
+    eng = model._last_engine                                  # exists after the first step (also with --warmup 0)
     # Per-kernel timing: HIP events recorded on the engine's launch streams around every kernel class.  The ~1000 event
     # records per step cost ~20 % of wall time, so they run on their own steps directly after the timed region (same
     # process, same buffers, same clocks) instead of inside it; `value` is never measured with them on.
