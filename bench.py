@@ -48,8 +48,8 @@ def usable_cores() -> int:
 
 
 def cpu_baseline(seconds_budget: float = 25.0):
-    from oracle import synth
-    from oracle import yolov8_ref as O
+    from computervision.pytorch_amd import synth
+    from oracle import yolov8_ref as O     # the ONLY use of oracle/ in this file: the CPU baseline leg
     bs = 8
     torch.set_num_threads(usable_cores())                     # torch defaults to every core of the host, not this box's share
     x, batch = synth.images(bs, 640, 640, seed=1), synth.targets(bs, seed=2)
@@ -95,7 +95,7 @@ def main():
     from computervision.pytorch_amd.model import Yolo8
     from computervision.pytorch_amd.train import FlatAdam, FusedTrainStep, V8DetectionLoss
     from configs import Yolo8DetConfig
-    from oracle import synth                                 # seeded input generators only (no oracle compute here)
+    from computervision.pytorch_amd import synth
 
     cfg = Yolo8DetConfig()
     cfg.arch.model_type = args.model

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CVX_LIB") or os.path.join(_HERE, "lib", "libcvx_engine.so")   # CVX_LIB: A/B runs of two builds on one box
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class CvxError(RuntimeError):
@@ -58,6 +58,7 @@ PROTOTYPES = {
     "cvx_engine_grads_ready": (_I32, [_P, _I32, _I32, _P]),
     "cvx_engine_backward_end": (_I32, [_P]),
     "cvx_engine_workspace_bytes": (_I64, [_P]),
+    "cvx_engine_plan_generation": (_I64, [_P]),
     "cvx_engine_debug_copy": (_I32, [_P, _I32, _I32, _P, _I64]),
     "cvx_engine_profile": (_I32, [_P, _I32]),
     "cvx_engine_profile_read": (_I32, [_P, _I32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -71,6 +72,8 @@ PROTOTYPES = {
                            _I64, _P]),
     "cvx_loss_v8_strided": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _I32, _I32, C.POINTER(_I32), C.POINTER(_F), _I32, _F, _F, _F, _F, _P, _P, _P,
                                    _I64, _P]),
+    "cvx_loss_v8_assignment": (_I32, [_P, _I32, _I32, _I32, _P, _P, _P]),
+    "cvx_pack_targets": (_I32, [_P, _P, _P, _I32, _P, _P]),
     "cvx_decode_strided": (_I32, [_P, _I32, _I32, _I32, _I32, C.POINTER(_I32), C.POINTER(_F), _I32, _P, _P]),
     "cvx_adam_step": (_I32, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I32, _P, _I32, _P]),
     "cvx_check_finite": (_I32, [_P, _I64, _P, _P]),
@@ -83,6 +86,15 @@ PROTOTYPES = {
     "cvx_conv2d_dgrad_nhwc": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "cvx_conv2d_wgrad_workspace_bytes": (_I64, [_I32, _I32, _I32, _I32, _I32, _I32]),
     "cvx_conv2d_wgrad_nhwc": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _I64, _P]),
+    "cvx_bn_silu_train_nhwc": (_I32, [_P, _I32, _I32, _I32, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "cvx_bn_silu_bwd_nhwc": (_I32, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _F, _P, _P, _P, _P, _I32, _P]),
+    "cvx_maxpool5_nhwc": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _P, _P]),
+    "cvx_maxpool5_bwd_nhwc": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _P, _I32, _P]),
+    "cvx_upsample2_nhwc": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _P]),
+    "cvx_upsample2_bwd_nhwc": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _I32, _P]),
+    "cvx_stem_train_nchw": (_I32, [_P, _I32, _I32, _I32, _P, _I32, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "cvx_stem_eval_nchw": (_I32, [_P, _I32, _I32, _I32, _P, _I32, _P, _P, _P, _P]),
+    "cvx_stem_wgrad_nchw": (_I32, [_P, _I32, _I32, _I32, _P, _I32, _P, _P]),
 }
 
 _lib = None

@@ -2,7 +2,8 @@
 #pragma once
 #include "cvx_common.h"
 #define CVX_BN_MAX_C 1024    // widest BatchNorm the streaming passes hold coefficients for (YOLOv8-m: 576, -x: 640)
-#define CVX_STAT_REPLICAS 16  // replica slabs the reduction kernels scatter their float atomics over
+#define CVX_STAT_REPLICAS 16  // replica slabs the reduction kernels scatter their atomics over
+#define CVX_STAT_WORDS (2 * CVX_FIX_WORDS)  // 64-bit words per channel and replica: (value 0, value 1) x (coarse, fine)
 
 // fp16 NHWC channel-slice view: element (b, pix, c) at p[b*bstride + pix*ld + c]
 struct ViewDesc {
@@ -12,13 +13,12 @@ struct ViewDesc {
 };
 
 struct BnCoef {
-  const float* mean;
-  const float* invstd;
+  const float* invstd;  // batch 1/sqrt(var+eps) of the forward pass
   const float* gamma;
   const float* beta;
 };
 
-// training-mode forward: fixed-point statistics replicas [R][C][2] filled by the conv epilogue (zero before it)
+// training-mode forward: fixed-point statistics replicas [R][C][2][CVX_FIX_WORDS] filled by the conv epilogue (zero before it)
 struct BnTrainArgs {
   const long long* stats;
   const float* gamma;
@@ -43,11 +43,15 @@ struct BnFoldDesc {
 int cvx_bn_fold_all(const BnFoldDesc* descs, int n, const float* params, const float* stats, float eps, hipStream_t st);
 int cvx_bn_fold(int n, const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps, float* scale, float* shift,
                 hipStream_t st);
-int cvx_bn_silu_apply(const half_t* y, long long M, int C, int hw, const BnTrainArgs& a, const ViewDesc& out, const ViewDesc& res,
-                      hipStream_t st);
-// part: replica slabs [R][C][2], zero on entry; receives (sum dz, sum dz*xhat)
-int cvx_bn_bwd_reduce(const half_t* y, long long M, int C, int hw, const BnCoef& k, const ViewDesc& gout, long long* part, hipStream_t st);
-int cvx_bn_bwd_apply(const half_t* y, long long M, int C, int hw, const BnCoef& k, const long long* part, float inv_scale, float* dgamma,
+// y: raw conv output, FP32 [M][C]; writes xhat = (y-mean)*invstd as fp16 [M][C] (operand of the backward passes) and
+// silu(gamma*xhat+beta) (+res) into the `out` view
+int cvx_bn_silu_apply(const float* y, long long M, int C, int hw, const BnTrainArgs& a, const ViewDesc& out, const ViewDesc& res,
+                      half_t* xhat, hipStream_t st);
+// part (zero on entry) receives per-channel (sum y, sum y^2) of an fp32 [M][C] tensor -- the conv epilogues' job in the engine
+int cvx_bn_stats_f32(const float* y, long long M, int C, long long* part, hipStream_t st);
+// part: replica slabs [R][C][2] fixed-point values, zero on entry; receives (sum dz, sum dz*xhat)
+int cvx_bn_bwd_reduce(const half_t* xhat, long long M, int C, int hw, const BnCoef& k, const ViewDesc& gout, long long* part, hipStream_t st);
+int cvx_bn_bwd_apply(const half_t* xhat, long long M, int C, int hw, const BnCoef& k, const long long* part, float inv_scale, float* dgamma,
                      float* dbeta, const ViewDesc& gout, half_t* dy, const ViewDesc& gres, int res_accumulate, hipStream_t st);
 // part: replica slabs [R][C][2], zero on entry
 int cvx_colsum(long long M, int C, int hw, const ViewDesc& g, long long* part, float inv_scale, float* dbias, hipStream_t st);

@@ -1,54 +1,23 @@
 // BatchNorm(train/eval) + SiLU elementwise passes around the MFMA convolutions (gfx950).
 //
-// Forward (train):  conv epilogue adds per-channel (sum, sumsq) into 16 replica slabs (64-bit fixed-point atomics) ->
+// Forward (train):  the conv epilogue stores the raw output y in FP32 (a transient buffer shared by all layers) and adds
+//                   per-channel (sum, sumsq) into 16 replica slabs (fixed-point integer atomics) ->
 //                   bn_silu_apply: every block folds the replicas into mean/invstd (fp64, identical in all blocks),
 //                   block 0 also stores them and updates the running statistics, then
-//                   a = silu(gamma*(y-mean)*invstd+beta) (+res)
+//                   xhat = (y-mean)*invstd  (kept, fp16, for the backward pass),  a = silu(gamma*xhat+beta) (+res).
+//                   The normalisation therefore reads the un-rounded accumulators: rounding y to fp16 first was the
+//                   largest single contribution to the forward error against the fp32 reference.
 // Backward:         bn_bwd_reduce (sum dz, sum dz*xhat into replica slabs) -> bn_bwd_apply: every block folds them
 //                   into c1/c2, block 0 accumulates dgamma/dbeta, dy = gamma*invstd*(dz - c1 - xhat*c2),
 //                   residual gradient pass-through.
-// All passes are HBM-bound streams: 16-byte (8 x fp16) accesses, one fixed channel group per thread so the
-// per-channel coefficients live in registers.  The replica slabs are zeroed once per step by the engine.
-#include "bn_act.h"
-#include <cstdlib>
+// All passes are HBM-bound streams: 16-byte accesses, one fixed channel group per thread so the per-channel
+// coefficients live in registers.  The replica slabs are zeroed once per step by the engine.
+#include "bn_common.h"
 
 namespace {
+using namespace cvx_bn;
 
 constexpr int UNR = 4;  // rows in flight per thread in the streaming passes
-
-__device__ __forceinline__ long long view_off(const ViewDesc& v, long long m, int hw) {
-  if (v.bstride == (long long)hw * v.ld) return m * v.ld;  // images are back to back (block-uniform test): no division
-  const unsigned mu = (unsigned)m;  // M < 2^32 (checked on the host): one 32-bit division per row
-  const unsigned b = mu / (unsigned)hw;
-  const unsigned pix = mu - b * (unsigned)hw;
-  return (long long)b * v.bstride + (long long)pix * v.ld;
-}
-
-// sums the CVX_STAT_REPLICAS fixed-point slabs [R][C][2] into s0/s1 (LDS).  All 256 threads load slab entries in
-// parallel (one round of independent, coalesced 16-byte loads) and add them with INTEGER LDS atomics: exact and
-// order-independent, and the block pays one memory latency instead of R dependent ones.
-__device__ __forceinline__ void fold_replicas(const long long* part, int C, double* s0, double* s1) {
-  long long* i0 = reinterpret_cast<long long*>(s0);
-  long long* i1 = reinterpret_cast<long long*>(s1);
-  for (int c = threadIdx.x; c < C; c += 256) {
-    i0[c] = 0;
-    i1[c] = 0;
-  }
-  __syncthreads();
-  const int total = CVX_STAT_REPLICAS * C;  // entries of two 64-bit values
-  for (int e = threadIdx.x; e < total; e += 256) {
-    const longlong2 q = *reinterpret_cast<const longlong2*>(part + (long long)e * 2);
-    const int c = e % C;
-    atomicAdd(reinterpret_cast<unsigned long long*>(&i0[c]), (unsigned long long)q.x);
-    atomicAdd(reinterpret_cast<unsigned long long*>(&i1[c]), (unsigned long long)q.y);
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const long long a = i0[c], b = i1[c];
-    s0[c] = cvx_fix_to_double(a);
-    s1[c] = cvx_fix_to_double(b);
-  }
-}
 
 // eval: fold running stats into per-channel scale/shift for the conv epilogue
 __global__ void bn_fold_kernel(int n, const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps,
@@ -71,9 +40,9 @@ __global__ __launch_bounds__(256) void bn_fold_all_kernel(const BnFoldDesc* desc
 }
 
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const long long* part, int C, float inv_scale, float* dbias) {
-  __shared__ double s0[CVX_BN_MAX_C], s1[CVX_BN_MAX_C];
-  fold_replicas(part, C, s0, s1);
-  __syncthreads();
+  extern __shared__ __attribute__((aligned(16))) long long ws[];
+  fold_replicas(part, C, ws);
+  const double* s0 = reinterpret_cast<const double*>(ws);
   for (int c = threadIdx.x; c < C; c += 256) dbias[c] += (float)(s0[c] * inv_scale);
 }
 
@@ -81,24 +50,28 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const long long* p
 // streaming passes.  Thread layout: CG = C/8 channel groups; thread -> (row slot r, group cg);
 // a block walks `rows_per_block` consecutive rows in steps of RP = 256 / CG.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_silu_apply_kernel(const half_t* y, long long M, int C, int hw, BnTrainArgs a, ViewDesc out,
-                                                            ViewDesc res, int rows_per_block) {
-  __shared__ double s0[CVX_BN_MAX_C], s1[CVX_BN_MAX_C];
-  __shared__ float s_sc[CVX_BN_MAX_C], s_sh[CVX_BN_MAX_C];
-  fold_replicas(a.stats, C, s0, s1);
-  __syncthreads();
+struct f8 {
+  f4 lo, hi;
+  __device__ __forceinline__ float operator[](int i) const { return i < 4 ? lo[i] : hi[i - 4]; }
+};
+__device__ __forceinline__ f8 load_f8(const float* p) { return f8{*reinterpret_cast<const f4*>(p), *reinterpret_cast<const f4*>(p + 4)}; }
+
+__global__ __launch_bounds__(256) void bn_silu_apply_kernel(const float* y, long long M, int C, int hw, BnTrainArgs a, ViewDesc out,
+                                                            ViewDesc res, half_t* xhat, int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) long long ws[];  // fold workspace | mean, invstd (2*C floats)
+  float* s_mu = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + fold_ws_bytes(C));
+  float* s_is = s_mu + C;
+  fold_replicas(a.stats, C, ws);
   for (int c = threadIdx.x; c < C; c += 256) {
-    const double cnt = (double)M;
-    double mu = s0[c] / cnt;
-    double var = s1[c] / cnt - mu * mu;
-    if (var < 0.0) var = 0.0;
-    const double is = 1.0 / sqrt(var + (double)a.eps);
-    const float g = a.gamma[c], bt = a.beta[c];
-    s_sc[c] = (float)(g * is);
-    s_sh[c] = (float)((double)bt - mu * g * is);
+    double var;
+    const BnMoments mo = moments_of(ws, C, c, M, a.eps, &var);
+    s_mu[c] = mo.mean;
+    s_is[c] = mo.invstd;
     if (blockIdx.x == 0) {
-      a.mean[c] = (float)mu;
-      a.invstd[c] = (float)is;
+      const double cnt = (double)M;
+      const double mu = reinterpret_cast<const double*>(ws)[c] / cnt;
+      a.mean[c] = mo.mean;
+      a.invstd[c] = mo.invstd;
       const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
       a.rmean[c] = (float)((1.0 - a.momentum) * (double)a.rmean[c] + a.momentum * mu);
       a.rvar[c] = (float)((1.0 - a.momentum) * (double)a.rvar[c] + a.momentum * unbiased);
@@ -109,18 +82,26 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const half_t* y, lon
   const int RP = 256 / CG;
   const int cg = threadIdx.x % CG, r = threadIdx.x / CG;
   if (r >= RP) return;
-  float sc[8], sh[8];
+  float mu[8], is[8], ga[8], be[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    sc[i] = s_sc[cg * 8 + i];
-    sh[i] = s_sh[cg * 8 + i];
+    mu[i] = s_mu[cg * 8 + i];
+    is[i] = s_is[cg * 8 + i];
+    ga[i] = a.gamma[cg * 8 + i];
+    be[i] = a.beta[cg * 8 + i];
   }
   const long long m0 = (long long)blockIdx.x * rows_per_block;
   const long long m1 = min(M, m0 + rows_per_block);
-  auto one = [&](long long m, const h8& v, const h8& rr) {
+  auto one = [&](long long m, const f8& v, const h8& rr) {
     float f[8];
+    h8 xh;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) f[i] = cvx_silu((float)v[i] * sc[i] + sh[i]);
+    for (int i = 0; i < 8; ++i) {
+      const float x = (v[i] - mu[i]) * is[i];
+      xh[i] = (half_t)x;
+      f[i] = cvx_silu(x * ga[i] + be[i]);
+    }
+    *reinterpret_cast<h8*>(xhat + m * C + cg * 8) = xh;
     if (res.p) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) f[i] += (float)rr[i];
@@ -133,17 +114,19 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const half_t* y, lon
   // UNR rows per trip with every load issued before the first use: the passes are latency-bound otherwise
   long long m = m0 + r;
   for (; m + (long long)(UNR - 1) * RP < m1; m += (long long)UNR * RP) {
-    h8 v[UNR], rr[UNR];
+    f8 v[UNR];
+    h8 rr[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      v[u] = *reinterpret_cast<const h8*>(y + (m + u * RP) * C + cg * 8);
+      v[u] = load_f8(y + (m + u * RP) * C + cg * 8);
       if (res.p) rr[u] = *reinterpret_cast<const h8*>(res.p + view_off(res, m + u * RP, hw) + cg * 8);
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) one(m + u * RP, v[u], rr[u]);
   }
   for (; m < m1; m += RP) {
-    h8 v = *reinterpret_cast<const h8*>(y + m * C + cg * 8), rr = {};
+    f8 v = load_f8(y + m * C + cg * 8);
+    h8 rr = {};
     if (res.p) rr = *reinterpret_cast<const h8*>(res.p + view_off(res, m, hw) + cg * 8);
     one(m, v, rr);
   }
@@ -153,62 +136,7 @@ struct Coef8 {
   float a[8], b[8];
 };
 
-__device__ __forceinline__ void load_coef(const BnCoef& k, int c0, Coef8& sc_sh, Coef8& mu_is) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    float mu = k.mean[c0 + i], is = k.invstd[c0 + i];
-    float g = k.gamma[c0 + i], bt = k.beta[c0 + i];
-    sc_sh.a[i] = g * is;
-    sc_sh.b[i] = bt - mu * g * is;
-    mu_is.a[i] = mu;
-    mu_is.b[i] = is;
-  }
-}
-
-// block-level accumulation of per-thread channel sums, bit-reproducible.  Lanes of a wave that share a channel group
-// (lane % CG, when CG divides 64) are folded with a fixed xor-butterfly; each wave parks its CG*8*NV sums in its own
-// LDS slot; NV*C threads add the four wave slots in fixed order and issue ONE 64-bit fixed-point atomic per value.
-// Channel-group counts that do not divide 64 (C = 80, 144: Detect head) take the parked-partials column walk instead.
-template <int NV>
-__device__ __forceinline__ void block_channel_sums(float (&v)[NV][8], int C, int CG, int cg, bool active, float* sred, long long* part) {
-  const bool pow2 = (64 % CG) == 0;
-  if (pow2) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-    for (int q = 0; q < NV; ++q)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float x = v[q][i];  // every thread is active when CG divides 64 (RP * CG == 256)
-        for (int o = CG; o < 64; o <<= 1) x += __shfl_xor(x, o);
-        if (lane < CG) sred[(wave * C + cg * 8 + i) * NV + q] = x;
-      }
-    __syncthreads();
-    for (int j = threadIdx.x; j < NV * C; j += 256) {
-      const int c = j / NV, q = j - c * NV;
-      const float acc = (sred[(0 * C + c) * NV + q] + sred[(1 * C + c) * NV + q]) + (sred[(2 * C + c) * NV + q] + sred[(3 * C + c) * NV + q]);
-      cvx_fix_atomic_add(&part[((long long)(blockIdx.x % CVX_STAT_REPLICAS) * C + c) * 2 + q], acc);
-    }
-    return;
-  }
-  const int RP = 256 / CG;
-  if (active) {
-    float* dst = sred + (size_t)threadIdx.x * (NV * 8);
-#pragma unroll
-    for (int q = 0; q < NV; ++q)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) dst[q * 8 + i] = v[q][i];
-  }
-  __syncthreads();
-  for (int j = threadIdx.x; j < NV * C; j += 256) {
-    const int c = j / NV, q = j - c * NV;
-    const int g = c >> 3, i = c & 7;
-    float acc = 0.f;
-    for (int r = 0; r < RP; ++r) acc += sred[(size_t)(r * CG + g) * (NV * 8) + q * 8 + i];
-    cvx_fix_atomic_add(&part[((long long)(blockIdx.x % CVX_STAT_REPLICAS) * C + c) * 2 + q], acc);
-  }
-}
-
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const half_t* y, long long M, int C, int hw, BnCoef k, ViewDesc gout, long long* part,
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const half_t* xhat, long long M, int C, int hw, BnCoef k, ViewDesc gout, long long* part,
                                                             int rows_per_block) {
   __shared__ float sacc[256 * 16];
   const int CG = C >> 3;
@@ -219,17 +147,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const half_t* y, lon
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[0][i] = acc[1][i] = 0.f;
   if (active) {
-    Coef8 s, u;
-    load_coef(k, cg * 8, s, u);
+    Coef8 s;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      s.a[i] = k.gamma[cg * 8 + i];
+      s.b[i] = k.beta[cg * 8 + i];
+    }
     const long long m0 = (long long)blockIdx.x * rows_per_block;
     const long long m1 = min(M, m0 + rows_per_block);
     auto one = [&](const h8& v, const h8& g) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        float yy = (float)v[i];
-        float dz = (float)g[i] * cvx_silu_grad(yy * s.a[i] + s.b[i]);
+        float xh = (float)v[i];
+        float dz = (float)g[i] * cvx_silu_grad(xh * s.a[i] + s.b[i]);
         acc[0][i] += dz;
-        acc[1][i] += dz * ((yy - u.a[i]) * u.b[i]);
+        acc[1][i] += dz * xh;
       }
     };
     long long m = m0 + r;
@@ -237,14 +169,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const half_t* y, lon
       h8 v[UNR], g[UNR];
 #pragma unroll
       for (int q = 0; q < UNR; ++q) {
-        v[q] = *reinterpret_cast<const h8*>(y + (m + q * RP) * C + cg * 8);
+        v[q] = *reinterpret_cast<const h8*>(xhat + (m + q * RP) * C + cg * 8);
         g[q] = *reinterpret_cast<const h8*>(gout.p + view_off(gout, m + q * RP, hw) + cg * 8);
       }
 #pragma unroll
       for (int q = 0; q < UNR; ++q) one(v[q], g[q]);
     }
     for (; m < m1; m += RP) {
-      h8 v = *reinterpret_cast<const h8*>(y + m * C + cg * 8);
+      h8 v = *reinterpret_cast<const h8*>(xhat + m * C + cg * 8);
       h8 g = *reinterpret_cast<const h8*>(gout.p + view_off(gout, m, hw) + cg * 8);
       one(v, g);
     }
@@ -252,12 +184,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const half_t* y, lon
   block_channel_sums<2>(acc, C, CG, cg, active, sacc, part);
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const half_t* y, long long M, int C, int hw, BnCoef k, const long long* part,
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const half_t* xhat, long long M, int C, int hw, BnCoef k, const long long* part,
                                                            float inv_scale, float* dgamma, float* dbeta, ViewDesc gout, half_t* dy, ViewDesc gres,
                                                            int res_accumulate, int rows_per_block) {
-  __shared__ double s0[CVX_BN_MAX_C], s1[CVX_BN_MAX_C];
-  fold_replicas(part, C, s0, s1);
-  __syncthreads();
+  extern __shared__ __attribute__((aligned(16))) long long ws[];
+  fold_replicas(part, C, ws);
+  const double* s0 = reinterpret_cast<const double*>(ws);
+  const double* s1 = s0 + C;
   if (blockIdx.x == 0) {
     for (int c = threadIdx.x; c < C; c += 256) {
       dgamma[c] += (float)(s1[c] * inv_scale);
@@ -268,15 +201,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const half_t* y, long
   const int RP = 256 / CG;
   const int cg = threadIdx.x % CG, r = threadIdx.x / CG;
   if (r >= RP) return;
-  Coef8 s, u;
-  load_coef(k, cg * 8, s, u);
+  Coef8 s;
   float k1[8], k2[8], gi[8];
   const double cnt = (double)M;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
+    s.a[i] = k.gamma[cg * 8 + i];
+    s.b[i] = k.beta[cg * 8 + i];
     k1[i] = (float)(s0[cg * 8 + i] / cnt);
     k2[i] = (float)(s1[cg * 8 + i] / cnt);
-    gi[i] = k.gamma[cg * 8 + i] * u.b[i];
+    gi[i] = s.a[i] * k.invstd[cg * 8 + i];
   }
   const long long m0 = (long long)blockIdx.x * rows_per_block;
   const long long m1 = min(M, m0 + rows_per_block);
@@ -284,9 +218,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const half_t* y, long
     h8 o;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      float yy = (float)v[i];
-      float dz = (float)g[i] * cvx_silu_grad(yy * s.a[i] + s.b[i]);
-      float xh = (yy - u.a[i]) * u.b[i];
+      float xh = (float)v[i];
+      float dz = (float)g[i] * cvx_silu_grad(xh * s.a[i] + s.b[i]);
       o[i] = (half_t)(gi[i] * (dz - k1[i] - xh * k2[i]));
     }
     *reinterpret_cast<h8*>(dy + m * C + cg * 8) = o;
@@ -304,7 +237,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const half_t* y, long
     h8 v[UNR], g[UNR], old[UNR];
 #pragma unroll
     for (int q = 0; q < UNR; ++q) {
-      v[q] = *reinterpret_cast<const h8*>(y + (m + q * RP) * C + cg * 8);
+      v[q] = *reinterpret_cast<const h8*>(xhat + (m + q * RP) * C + cg * 8);
       g[q] = *reinterpret_cast<const h8*>(gout.p + view_off(gout, m + q * RP, hw) + cg * 8);
       if (rd_old) old[q] = *reinterpret_cast<const h8*>(gres.p + view_off(gres, m + q * RP, hw) + cg * 8);
     }
@@ -312,12 +245,38 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const half_t* y, long
     for (int q = 0; q < UNR; ++q) one(m + q * RP, v[q], g[q], old[q]);
   }
   for (; m < m1; m += RP) {
-    h8 v = *reinterpret_cast<const h8*>(y + m * C + cg * 8);
+    h8 v = *reinterpret_cast<const h8*>(xhat + m * C + cg * 8);
     h8 g = *reinterpret_cast<const h8*>(gout.p + view_off(gout, m, hw) + cg * 8);
     h8 old = {};
     if (rd_old) old = *reinterpret_cast<const h8*>(gres.p + view_off(gres, m, hw) + cg * 8);
     one(m, v, g, old);
   }
+}
+
+// per-channel (sum, sumsq) of an fp32 [M][C] tensor into the replica slabs: what the conv epilogues do in the engine;
+// stand-alone for the single-op entry point (unit tests, other callers with an fp32 pre-activation of their own)
+__global__ __launch_bounds__(256) void bn_stats_f32_kernel(const float* y, long long M, int C, long long* part, int rows_per_block) {
+  __shared__ float sacc[256 * 16];
+  const int CG = C >> 3;
+  const int RP = 256 / CG;
+  const int cg = threadIdx.x % CG, r = threadIdx.x / CG;
+  const bool active = r < RP;
+  float acc[2][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[0][i] = acc[1][i] = 0.f;
+  if (active) {
+    const long long m0 = (long long)blockIdx.x * rows_per_block;
+    const long long m1 = min(M, m0 + rows_per_block);
+    for (long long m = m0 + r; m < m1; m += RP) {
+      const f8 v = load_f8(y + m * C + cg * 8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        acc[0][i] += v[i];
+        acc[1][i] = fmaf(v[i], v[i], acc[1][i]);
+      }
+    }
+  }
+  block_channel_sums<2>(acc, C, CG, cg, active, sacc, part);
 }
 
 // column sums of a [M][C] fp16 view (bias gradient of the head's 1x1 output convs)
@@ -347,7 +306,7 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(long long M, int C, 
 int cvx_stream_rows_per_block(long long M, int C, int kb_per_block) {
   const int CG = C / 8;
   const int RP = 256 / CG;
-  static const int kb_env = getenv("CVX_BN_KB") ? atoi(getenv("CVX_BN_KB")) : 0;  // tuning experiments only
+  static const int kb_env = cvx_tune_int("CVX_BN_KB", 0);
   if (kb_env > 0) kb_per_block = kb_env;
   long long target = ((long long)kb_per_block * 1024) / (2LL * C);
   if (target < RP) target = RP;
@@ -379,27 +338,35 @@ int cvx_bn_fold(int n, const float* gamma, const float* beta, const float* rmean
   CVX_HIP(hipGetLastError());
   return 0;
 }
-int cvx_bn_silu_apply(const half_t* y, long long M, int C, int hw, const BnTrainArgs& a, const ViewDesc& out, const ViewDesc& res,
-                      hipStream_t st) {
+int cvx_bn_silu_apply(const float* y, long long M, int C, int hw, const BnTrainArgs& a, const ViewDesc& out, const ViewDesc& res,
+                      half_t* xhat, hipStream_t st) {
   CVX_TRY(check_c(C, M));
   int rows = cvx_stream_rows_per_block(M, C, 16);
-  hipLaunchKernelGGL(bn_silu_apply_kernel, dim3(blocks_for(M, rows)), dim3(256), 0, st, y, M, C, hw, a, out, res, rows);
+  hipLaunchKernelGGL(bn_silu_apply_kernel, dim3(blocks_for(M, rows)), dim3(256), fold_ws_bytes(C) + 2 * C * 4, st, y, M, C, hw, a, out, res,
+                     xhat, rows);
   CVX_HIP(hipGetLastError());
   return 0;
 }
-int cvx_bn_bwd_reduce(const half_t* y, long long M, int C, int hw, const BnCoef& k, const ViewDesc& gout, long long* part, hipStream_t st) {
+int cvx_bn_stats_f32(const float* y, long long M, int C, long long* part, hipStream_t st) {
   CVX_TRY(check_c(C, M));
   int rows = cvx_stream_rows_per_block(M, C, 32);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks_for(M, rows)), dim3(256), 0, st, y, M, C, hw, k, gout, part, rows);
+  hipLaunchKernelGGL(bn_stats_f32_kernel, dim3(blocks_for(M, rows)), dim3(256), 0, st, y, M, C, part, rows);
   CVX_HIP(hipGetLastError());
   return 0;
 }
-int cvx_bn_bwd_apply(const half_t* y, long long M, int C, int hw, const BnCoef& k, const long long* part, float inv_scale, float* dgamma,
+int cvx_bn_bwd_reduce(const half_t* xhat, long long M, int C, int hw, const BnCoef& k, const ViewDesc& gout, long long* part, hipStream_t st) {
+  CVX_TRY(check_c(C, M));
+  int rows = cvx_stream_rows_per_block(M, C, 32);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks_for(M, rows)), dim3(256), 0, st, xhat, M, C, hw, k, gout, part, rows);
+  CVX_HIP(hipGetLastError());
+  return 0;
+}
+int cvx_bn_bwd_apply(const half_t* xhat, long long M, int C, int hw, const BnCoef& k, const long long* part, float inv_scale, float* dgamma,
                      float* dbeta, const ViewDesc& gout, half_t* dy, const ViewDesc& gres, int res_accumulate, hipStream_t st) {
   CVX_TRY(check_c(C, M));
   int rows = cvx_stream_rows_per_block(M, C, 32);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(M, rows)), dim3(256), 0, st, y, M, C, hw, k, part, inv_scale, dgamma, dbeta, gout,
-                     dy, gres, res_accumulate, rows);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(M, rows)), dim3(256), fold_ws_bytes(C), st, xhat, M, C, hw, k, part, inv_scale, dgamma,
+                     dbeta, gout, dy, gres, res_accumulate, rows);
   CVX_HIP(hipGetLastError());
   return 0;
 }
@@ -407,7 +374,7 @@ int cvx_colsum(long long M, int C, int hw, const ViewDesc& g, long long* part, f
   CVX_TRY(check_c(C, M));
   int rows = cvx_stream_rows_per_block(M, C, 32);
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3(blocks_for(M, rows)), dim3(256), 0, st, M, C, hw, g, part, rows);
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(1), dim3(256), 0, st, part, C, inv_scale, dbias);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(1), dim3(256), fold_ws_bytes(C), st, part, C, inv_scale, dbias);
   CVX_HIP(hipGetLastError());
   return 0;
 }

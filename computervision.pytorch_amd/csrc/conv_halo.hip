@@ -281,7 +281,7 @@ int launch_halo_hv(const ConvParams& p, hipStream_t stream, int gy) {
   CVX_TRY(cvx_lds_optin((const void*)conv_halo_kernel<WM, WN, MT, NTW, CIN, HV>, G::LDS_BYTES, &optin_mask));
   // persistent: as many workgroups as fit on the 256 CUs at once (LDS-limited, at most CVX_HALO_OCC per CU), split
   // over the gy channel blocks; each walks the tile list with that stride (HV tiles per workgroup and trip)
-  static const int occ_cap = getenv("CVX_HALO_OCC") ? atoi(getenv("CVX_HALO_OCC")) : 4;
+  static const int occ_cap = cvx_tune_int("CVX_HALO_OCC", 4);
   int per_cu = (160 * 1024) / G::LDS_BYTES;
   per_cu = per_cu < 1 ? 1 : (per_cu > occ_cap ? occ_cap : per_cu);
   if (HV == 2 && per_cu > 2) per_cu = 2;  // 8 waves each
@@ -302,7 +302,7 @@ int launch_halo_c(const ConvParams& p, hipStream_t stream, int gy) {
   } else {
     // two tile streams per workgroup when only ONE single-stream workgroup would fit a CU (heavy weight slices) and the
     // two-stream layout does; register budget halves (256 per wave), so only the moderate register tiles
-    static const bool hv2 = !(getenv("CVX_HALO_HV") && atoi(getenv("CVX_HALO_HV")) == 1);
+    static const bool hv2 = cvx_tune_int("CVX_HALO_HV", 2) != 1;
     if constexpr (G2::LDS_BYTES <= 160 * 1024 && 2 * G1::LDS_BYTES > 160 * 1024 && MT * NTW <= 8 && NTW <= 4) {
       if (hv2) return launch_halo_hv<WM, WN, MT, NTW, CIN, 2>(p, stream, gy);
     }
@@ -339,7 +339,7 @@ int launch_m(int NT, const ConvParams& p, hipStream_t st, int gy, int l2) {
 }  // namespace
 
 bool cvx_conv_halo_supported(const ConvParams& p) {
-  static const bool off = getenv("CVX_NO_HALO") != nullptr;
+  static const bool off = cvx_tune_set("CVX_NO_HALO");
   if (off || !p.zeros) return false;
   if (!(p.Cin == 16 || p.Cin == 32 || p.Cin == 64 || p.Cin == 80 || p.Cin == 128 || p.Cin == 144)) return false;
   if (p.IS != 1 || p.OS != 1 || p.oph != 0 || p.opw != 0) return false;
@@ -350,7 +350,7 @@ bool cvx_conv_halo_supported(const ConvParams& p) {
 
 // largest number of 16-channel tiles per workgroup whose weights (tiles*16 x 9*Cin fp16) stay within the LDS budget
 static int halo_tile_cap(int cin) {
-  static const int kb = getenv("CVX_HALO_WKB") ? atoi(getenv("CVX_HALO_WKB")) : 88;
+  static const int kb = cvx_tune_int("CVX_HALO_WKB", 88);
   int cap = (kb * 1024) / (16 * 9 * cin * 2);
   return cap < 1 ? 1 : (cap > 8 ? 8 : cap);
 }

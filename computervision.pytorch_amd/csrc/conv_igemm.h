@@ -6,7 +6,7 @@
 #include "cvx_common.h"
 
 enum {
-  CVX_EPI_RAW_STATS = 0,    // train fwd: raw conv output fp16 + per-block (sum, sumsq) partials
+  CVX_EPI_RAW_STATS = 0,    // train fwd: raw conv output FP32 (out32) + per-channel (sum, sumsq) into the fixed-point replica slabs
   CVX_EPI_AFFINE_SILU = 1,  // eval fwd: y*scale+shift -> SiLU (+residual) -> fp16
   CVX_EPI_BIAS_F32 = 2,     // head output: +bias -> fp32
   CVX_EPI_PLAIN = 3,        // dgrad: fp16 store (optionally accumulate into the destination)
@@ -50,9 +50,9 @@ struct ConvParams {
   const float* scale;  // AFFINE_SILU
   const float* shift;  // AFFINE_SILU
   const float* bias;   // BIAS_F32
-  long long* stats;    // RAW_STATS: [stats_replicas][Cout][2] fixed-point (cvx_fix_atomic_add), must be zero on entry
+  long long* stats;    // RAW_STATS: [stats_replicas][Cout][2] fixed-point values of CVX_FIX_WORDS words (cvx_fix_atomic_add), zero on entry
   int stats_replicas;
-  const half_t* zeros; // >= 16 zero bytes in device memory: DMA source for padding (second-generation kernel); null -> generation one
+  const half_t* zeros; // >= 16 zero bytes in device memory, 16-byte aligned: DMA source for padding
   int dbg;             // timing experiments only (CVX_DBG): 1 = halo kernel streams the weights once, 2 = no MFMA; results are WRONG
   unsigned long long* clk;  // tuning aid (cvx_debug_clock_buffer): thread 0 of every block stores 100 MHz timestamps, 8 slots per block
   int halo_taps_ok;    // 1 when the tap table is a 3x3 neighbourhood (all |dh|,|dw| <= 1): the LDS halo-tile kernel may be used
@@ -87,11 +87,9 @@ extern unsigned long long* g_cvx_clk;
 // share of the chip a persistent conv launch should size its grid for: 1 = all CUs, n = 1/n of them (set by the engine
 // around launches on concurrent lanes, so that side-by-side persistent kernels do not queue behind each other)
 extern int g_cvx_grid_div;
-// Launches the kernel; returns the number of M-blocks (= stats partial count) through *m_blocks.
+// Validates and dispatches to one of the kernels below (m_blocks: legacy out-parameter, always 0).
 int cvx_conv_igemm_launch(const ConvParams& p, hipStream_t stream, int* m_blocks);
-// Number of M-blocks the launcher will use for M output pixels.
-int cvx_conv_igemm_mblocks(long long M);
-// second generation (LDS-DMA ring, conv_igemm_dma.hip); cvx_conv_igemm_launch forwards to it when p.zeros is set
+// LDS-DMA ring kernel (conv_igemm_dma.hip): every shape the two persistent kernels do not take
 int cvx_conv_igemm_dma_launch(const ConvParams& p, hipStream_t stream);
 // 3x3 stride-1 halo-tile kernel (conv_halo.hip)
 bool cvx_conv_halo_supported(const ConvParams& p);

@@ -227,8 +227,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
       for (int i = 0; i < MT; ++i) {
         if (pvalid[i]) {
           if (n0 < p.Cout) {
-            h4 v = {(half_t)acc[i][j][0], (half_t)acc[i][j][1], (half_t)acc[i][j][2], (half_t)acc[i][j][3]};
-            *reinterpret_cast<h4*>(p.out16 + out_off[i] + n0) = v;
+            *reinterpret_cast<f4*>(p.out32 + out_off[i] + n0) = acc[i][j];  // fp32, see conv_tile_common.h
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -254,7 +253,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < WM; ++w) v += sStat[(w * BN + ch) * 2 + which];
-        cvx_fix_atomic_add(&p.stats[((long long)(blockIdx.x % p.stats_replicas) * p.Cout + n) * 2 + which], v);
+        cvx_fix_atomic_add(p.stats, ((long long)(blockIdx.x % p.stats_replicas) * p.Cout + n) * 2 + which, v);
       }
     }
     clk_mark(p, 4);
@@ -299,10 +298,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
   clk_mark(p, 4);
 }
 
-int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
+int env_int(const char* name, int dflt) { return cvx_tune_int(name, dflt); }
 
 template <int WM, int WN, int MT, int NTW, int STAGES>
 int launch_st(const ConvParams& p, hipStream_t stream, dim3 grid) {

@@ -151,7 +151,7 @@ int launch_pw(const ConvParams& p, hipStream_t stream, int gy) {
     const int n_wave_tiles = (int)((M + MT * 16 - 1) / (MT * 16));
     static unsigned long long optin_mask = 0;  // per device (cvx_lds_optin)
     CVX_TRY(cvx_lds_optin((const void*)conv_pw_kernel<MT, NTW, NSTEPS>, G::LDS_BYTES, &optin_mask));
-    static const int occ_cap = getenv("CVX_PW_OCC") ? atoi(getenv("CVX_PW_OCC")) : 4;
+    static const int occ_cap = cvx_tune_int("CVX_PW_OCC", 4);
     int per_cu = (160 * 1024) / G::LDS_BYTES;
     per_cu = per_cu < 1 ? 1 : (per_cu > occ_cap ? occ_cap : per_cu);
     int gx = (256 * per_cu) / gy / (g_cvx_grid_div > 0 ? g_cvx_grid_div : 1);
@@ -179,7 +179,7 @@ int launch_pw_n(int NT, const ConvParams& p, hipStream_t st, int gy) {
 }  // namespace
 
 bool cvx_conv_pw_supported(const ConvParams& p) {
-  static const bool off = getenv("CVX_NO_PW") != nullptr;
+  static const bool off = cvx_tune_set("CVX_NO_PW");
   if (off || !p.zeros || !p.pointwise) return false;
   if (p.IS != 1 || p.OS != 1 || p.oph != 0 || p.opw != 0 || p.ntaps != 1) return false;
   if (p.OH2 != p.IH || p.OW2 != p.IW || p.OWr != p.IW) return false;
@@ -199,7 +199,7 @@ int cvx_conv_pw_launch(const ConvParams& p, hipStream_t stream) {
       break;
     }
   // channel tiles per workgroup: fewest channel blocks whose weights (NT*16 x NS*32 fp16 = NT*NS KiB) fit the budget
-  static const int kb = getenv("CVX_PW_WKB") ? atoi(getenv("CVX_PW_WKB")) : 64;
+  static const int kb = cvx_tune_int("CVX_PW_WKB", 64);
   const int tiles = (p.Cout + 15) / 16;
   int cap = kb / NS;
   cap = cap < 1 ? 1 : (cap > 8 ? 8 : cap);

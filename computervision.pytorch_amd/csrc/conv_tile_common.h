@@ -50,7 +50,7 @@ __device__ __forceinline__ void wait_steps_ahead(int ahead) {
 
 // Epilogue for a block tile of WM x (MT sub-tiles of 16 pixels) by WN x (NTW sub-tiles of 16 channels).
 // Lane (fr, fq) holds pixel fr of sub-tile i and channels 4*fq..4*fq+3 of sub-tile j in acc[i][j].
-// RAW_STATS mode only stores the fp16 outputs and adds the lane's values into st1/st2 (per-lane running sums of y and
+// RAW_STATS mode only stores the raw fp32 outputs and adds the lane's values into st1/st2 (per-lane running sums of y and
 // y^2 for its 4 channels of every j); a persistent workgroup calls this once per tile and stats_flush once at the end.
 template <int WM, int WN, int MT, int NTW>
 __device__ __forceinline__ void epilogue_tile(const ConvParams& p, f4 (&acc)[MT][NTW], const long long (&out_off)[MT],
@@ -66,8 +66,7 @@ __device__ __forceinline__ void epilogue_tile(const ConvParams& p, f4 (&acc)[MT]
       if (!pvalid[i]) continue;
       f4 v = acc[i][j];
       if (p.epi == CVX_EPI_RAW_STATS) {
-        h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-        *reinterpret_cast<h4*>(p.out16 + out_off[i] + n0) = o;
+        *reinterpret_cast<f4*>(p.out32 + out_off[i] + n0) = v;  // fp32: normalisation reads the un-rounded accumulators
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           st1[j][r] += v[r];
@@ -130,7 +129,7 @@ __device__ __forceinline__ void stats_flush(const ConvParams& p, const f4 (&st1)
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < WM; ++w) v += sStat[(w * BN + ch) * 2 + which];
-      cvx_fix_atomic_add(&p.stats[((long long)(blockIdx.x % p.stats_replicas) * p.Cout + n) * 2 + which], v);
+      cvx_fix_atomic_add(p.stats, ((long long)(blockIdx.x % p.stats_replicas) * p.Cout + n) * 2 + which, v);
     }
   }
 }

@@ -217,7 +217,7 @@ int pick_tiles(int c) {
 }  // namespace
 
 bool cvx_conv_wgrad_halo_supported(const WgradParams& p) {
-  static const bool off = getenv("CVX_NO_WGRAD_HALO") != nullptr;
+  static const bool off = cvx_tune_set("CVX_NO_WGRAD_HALO");
   return !off && p.std3x3 && p.stride == 1 && p.ntaps == 9 && p.Cin >= 16 && p.IH == p.OH && p.IW == p.OW;
 }
 

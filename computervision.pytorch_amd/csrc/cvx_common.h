@@ -40,6 +40,20 @@ void cvx_set_error(const std::string& msg);
 
 static inline int cvx_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// Tuning knobs (tile thresholds, ring depths, occupancy caps ...) are environment variables ONLY in a -DCVX_TUNING build;
+// the release library ignores the environment entirely, so a stray variable can change neither numerics nor speed.
+#ifdef CVX_TUNING
+#include <cstdlib>
+static inline int cvx_tune_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+static inline bool cvx_tune_set(const char* name) { return getenv(name) != nullptr; }
+#else
+static inline int cvx_tune_int(const char*, int dflt) { return dflt; }
+static inline bool cvx_tune_set(const char*) { return false; }
+#endif
+
 // Opt-in to more than 64 KB of dynamic LDS for a kernel.  The attribute is per device: one bit per device ordinal in the
 // caller's static mask, so a process that drives several GPUs (one engine each) opts in on each of them.
 inline int cvx_lds_optin(const void* kernel, int bytes, unsigned long long* done_mask) {
@@ -82,13 +96,24 @@ __device__ __forceinline__ float cvx_wave_sum64(float v) {
   v += __shfl_xor(v, 32);
   return v;
 }
-// Deterministic cross-workgroup sums: partial sums are converted to 64-bit fixed point (2^-30 resolution,
-// +-8.6e9 range) and added with integer atomics, so the total does not depend on arrival order.
-#define CVX_FIX_SCALE 1073741824.0f
-__device__ __forceinline__ void cvx_fix_atomic_add(long long* dst, float v) {
-  atomicAdd(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__float2ll_rn(v * CVX_FIX_SCALE));
+// Deterministic cross-workgroup sums: every logical value is TWO 64-bit integer words that only ever see integer
+// atomic adds, so the total does not depend on arrival order.  Word 0 holds round(v * 2^6) (range +-1.4e17: a sum of
+// squares of fp16-bounded values over 1e7 rows fits), word 1 the exact remainder in units of 2^-40 (|remainder| <=
+// 2^33 per add: no overflow below 2^30 adds).  One word at 2^-30 -- the first version -- wrapped silently once a sum of
+// squares passed 8.6e9 (stem at batch 32 with pre-BN RMS > 51).
+#define CVX_FIX_WORDS 2
+__device__ __forceinline__ void cvx_fix_atomic_add(long long* slab, long long idx, float v) {
+  const float s = v * 64.0f;                       // exact (power of two)
+  const float c = rintf(s);                        // |s| >= 2^24: s is an integer already, c == s
+  const long long coarse = __float2ll_rn(c);
+  const long long fine = __float2ll_rn((s - c) * 17179869184.0f);  // (s - c) in [-0.5, 0.5], exact; * 2^34
+  unsigned long long* d = reinterpret_cast<unsigned long long*>(slab + idx * CVX_FIX_WORDS);
+  atomicAdd(d, (unsigned long long)coarse);
+  if (fine != 0) atomicAdd(d + 1, (unsigned long long)fine);
 }
-__device__ __forceinline__ double cvx_fix_to_double(long long v) { return (double)v * (1.0 / 1073741824.0); }
+__device__ __forceinline__ double cvx_fix_to_double(long long coarse, long long fine) {
+  return (double)coarse * (1.0 / 64.0) + (double)fine * (1.0 / 1099511627776.0);
+}
 
 __device__ __forceinline__ float cvx_wave_max64(float v) {
   for (int o = 1; o < 64; o <<= 1) v = fmaxf(v, __shfl_xor(v, o));

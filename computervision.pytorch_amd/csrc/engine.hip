@@ -11,11 +11,12 @@
 #include "bn_act.h"
 #include "conv_igemm.h"
 #include "misc_ops.h"
+#include "stem.h"
 
 // events that only order this process's own streams on one device: no timing, no system-scope fence (the marker packet
 // between two main-chain kernels costs ~6.5 us with the default flags -- 53 of them per backward pass)
 static unsigned cvx_event_flags() {
-  static const bool sysfence = getenv("CVX_EVENT_SYSFENCE") != nullptr;
+  static const bool sysfence = cvx_tune_set("CVX_EVENT_SYSFENCE");
   return hipEventDisableTiming | (sysfence ? 0u : hipEventDisableSystemFence);
 }
 
@@ -51,8 +52,9 @@ struct ConvRt {
   // backward plan
   int in_accum = 0, res_accum = 0;
   int slab_blk0 = 0, slab_blk1 = 0;  // reducer workgroups [blk0, blk1) of this op in the slab block table
+  bool stem = false;  // 3 -> Cout 3x3 stride-2 conv on the caller's fp32 images: stem.hip
   // per-batch
-  half_t* ybuf = nullptr;
+  half_t* ybuf = nullptr;   // xhat = (y - mean) * invstd of the training forward, fp16 (operand of the BN backward passes)
   half_t* dybuf = nullptr;  // gradient w.r.t. the raw conv output (kept per layer: the weight-gradient runs on a side stream)
   float *mean = nullptr, *invstd = nullptr, *scale = nullptr, *shift = nullptr;
   long long *stat_fwd = nullptr, *stat_bwd = nullptr;  // fixed-point replica slabs [R][C][2]
@@ -104,12 +106,9 @@ struct cvx_engine {
   long long stat_half = 0;           // entries per half
   hipStream_t side = nullptr;    // weight gradients run here, concurrently with the data-gradient chain
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  // execution lanes (cvx_op_desc.lane): independent tails of the op list, each on its own stream
-  enum { MAX_LANES = 4 };
-  hipStream_t lane_stream[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_lane_fork = nullptr, ev_lane_join[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
-  int n_lanes = 1;         // 1 + highest lane in use
-  int first_lane_op = -1;  // index of the first op with lane > 0 (all later ops have lane > 0)
+  float* ytmp = nullptr;              // raw fp32 conv output of the layer in flight (training forward), shared by all layers
+  const float* last_images = nullptr;  // the caller's images of the last training forward (the stem's weight gradient reads them)
+  int64_t plan_generation = 0;         // bumped whenever plan_batch re-allocates: captured hipGraphs hold raw buffer pointers
   float* slabs = nullptr;
   SlabDesc* d_slab = nullptr;
   BlockRef* d_slab_blocks = nullptr;
@@ -241,6 +240,13 @@ int build_static(cvx_engine* e) {
     ConvRt& c = e->conv[i];
     const int T = o.k * o.k;
     CVX_CHECK(T <= CVX_MAX_TAPS, "kernel too large");
+    if (o.in.buf == e->image_buf) {
+      // the image is read as the caller's NCHW fp32 tensor by the fp32 stem kernels; no fp16 NHWC copy of it exists
+      CVX_CHECK(o.w_cin == 3 && o.k == 3 && o.stride == 2 && o.pad == 1 && o.dil == 1 && o.act == CVX_ACT_BN_SILU && !o.needs_dgrad &&
+                    o.res.buf < 0 && o.out.c % 16 == 0 && o.out.c <= 80 && o.ih % 2 == 0 && o.iw % 2 == 0,
+                "the op that reads the image must be the 3 -> 16..80 channel 3x3 stride-2 BN+SiLU stem (stem.hip)");
+      c.stem = true;
+    }
     CVX_CHECK(o.in.c % 8 == 0 && o.out.c % 8 == 0 && o.in.coff % 8 == 0 && o.out.coff % 8 == 0, "conv views must be 8-channel aligned");
     CVX_CHECK(o.w_cin <= o.in.c && o.w_cin > o.in.c - 8, "w_cin vs view channels");
     c.cin_g = o.in.c;
@@ -362,10 +368,14 @@ int plan_batch(cvx_engine* e, int B, bool training) {
   free_pool(e->batch_allocs);
   e->batch_bytes = 0;
   e->planned_batch = 0;
+  e->plan_generation++;  // every per-batch buffer moves: a hipGraph captured against the old plan must be dropped
+  e->fwd_train_done = false;
   void* p = nullptr;
-  for (Buf& b : e->bufs) {
+  long long ytmp_elems = 0;
+  for (size_t bi = 0; bi < e->bufs.size(); ++bi) {
+    Buf& b = e->bufs[bi];
     b.act = b.grad = nullptr;
-    if (b.d.kind != CVX_BUF_ACT_F16) continue;
+    if (b.d.kind != CVX_BUF_ACT_F16 || (int)bi == e->image_buf) continue;
     long long bytes = (long long)B * b.d.h * b.d.w * b.d.c * 2;
     CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, bytes));
     b.act = (half_t*)p;
@@ -404,19 +414,20 @@ int plan_batch(cvx_engine* e, int B, bool training) {
       c.ybuf = (half_t*)p;
       CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, M * C * 2));
       c.dybuf = (half_t*)p;
+      if (!c.stem) ytmp_elems = std::max(ytmp_elems, M * C);
     }
     c.stat_fwd = (long long*)nullptr + stat_floats;  // offset for now, rebased below
-    stat_floats += (long long)CVX_STAT_REPLICAS * C * 2;
+    stat_floats += (long long)CVX_STAT_REPLICAS * C * CVX_STAT_WORDS;
     if (training) {
       int co_b, j_b;
       wgrad_tile(C, &co_b, &j_b);
       const int Jtot = c.ntaps * c.cin_pad16;
       const long long tiles = (long long)cvx_cdiv(C, co_b) * cvx_cdiv(Jtot, j_b);
-      static const long long blk_target = getenv("CVX_WGRAD_BLOCKS") ? atoll(getenv("CVX_WGRAD_BLOCKS")) : 2048;
+      static const long long blk_target = cvx_tune_int("CVX_WGRAD_BLOCKS", 2048);
       long long ns = std::min<long long>(std::max<long long>(1, M / 256), std::max<long long>(1, blk_target / tiles));
       const long long slab_elems = (long long)C * Jtot;
-      static const long long slab_cap_mb = getenv("CVX_SLAB_MB") ? atoll(getenv("CVX_SLAB_MB")) : 8;
-      static const long long ns_cap = getenv("CVX_NSPLIT_CAP") ? atoll(getenv("CVX_NSPLIT_CAP")) : 512;
+      static const long long slab_cap_mb = cvx_tune_int("CVX_SLAB_MB", 8);
+      static const long long ns_cap = cvx_tune_int("CVX_NSPLIT_CAP", 512);
       ns = std::min(ns, std::max<long long>(1, (slab_cap_mb << 20) / (slab_elems * 4)));
       ns = std::min<long long>(ns, ns_cap);
       {  // 3x3 stride-1 layers take the register-tile kernel: few, fat workgroups per pixel split
@@ -430,12 +441,14 @@ int plan_batch(cvx_engine* e, int B, bool training) {
         probe.IW = o.iw;
         probe.OH = o.oh;
         probe.OW = o.ow;
-        if (cvx_conv_wgrad_halo_supported(probe)) {
+        if (c.stem) {
+          ns = cvx_stem_wgrad_splits(M);
+        } else if (cvx_conv_wgrad_halo_supported(probe)) {
           int gx, gy;
           cvx_conv_wgrad_halo_grid(C, c.cin_g, &gx, &gy);
           const long long ptiles = cvx_conv_wgrad_halo_tiles(B, o.oh, o.ow);
-          static const long long wh_blocks = getenv("CVX_WH_BLOCKS") ? atoll(getenv("CVX_WH_BLOCKS")) : 128;  // measured: 128 beats 64/256/512 (slab volume vs. parallelism)
-          static const long long wh_slab_mb = getenv("CVX_WH_SLAB_MB") ? atoll(getenv("CVX_WH_SLAB_MB")) : 16;
+          static const long long wh_blocks = cvx_tune_int("CVX_WH_BLOCKS", 128);  // measured: 128 beats 64/256/512 (slab volume vs. parallelism)
+          static const long long wh_slab_mb = cvx_tune_int("CVX_WH_SLAB_MB", 16);
           ns = std::max<long long>(1, wh_blocks / ((long long)gx * gy));
           ns = std::min(ns, ptiles);
           ns = std::min(ns, std::max<long long>(1, (wh_slab_mb << 20) / (slab_elems * 4)));
@@ -453,7 +466,7 @@ int plan_batch(cvx_engine* e, int B, bool training) {
       sd.Cin_pad = c.cin_pad16;
       sd.lanes = cvx_slab_lanes(sd.nsplit);
       const long long total = (long long)sd.rows * sd.Cin;
-      static const int tail_ops = getenv("CVX_SLAB_TAIL") ? atoi(getenv("CVX_SLAB_TAIL")) : 2;
+      static const int tail_ops = cvx_tune_int("CVX_SLAB_TAIL", 2);
       if ((int)sdescs.size() == tail_ops && tail_ops > 0) {  // this is the first conv op outside the tail
         e->slab_tail_blocks = (int)sblocks.size();
         e->slab_tail_op = (int)i;
@@ -463,6 +476,11 @@ int plan_batch(cvx_engine* e, int B, bool training) {
       c.slab_blk1 = (int)sblocks.size();
       sdescs.push_back(sd);
     }
+  }
+  e->ytmp = nullptr;
+  if (training && ytmp_elems > 0) {
+    CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, ytmp_elems * 4));
+    e->ytmp = (float*)p;
   }
   CVX_TRY(upload(e, e->batch_allocs, e->batch_bytes, &e->d_fold, folds));
   e->n_fold = (int)folds.size();
@@ -543,7 +561,7 @@ extern "C" int cvx_engine_create(cvx_engine** out, const cvx_buf_desc* bufs, int
     // reason it matters -- a priority class of its own keeps it off the main stream's hardware queue.  (With the default
     // round-robin mapping onto 4 hardware queues, a process that had created other streams first, e.g. RCCL's, got main
     // and side on ONE queue: the weight gradients ran serialised, 8.8 instead of 7.4 ms/step.)  CVX_SIDE_PRIO=0: plain stream.
-    static const bool side_prio = !(getenv("CVX_SIDE_PRIO") && atoi(getenv("CVX_SIDE_PRIO")) == 0);
+    static const bool side_prio = cvx_tune_int("CVX_SIDE_PRIO", 1) != 0;
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     hipError_t side_rc = side_prio ? hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio_least)
@@ -560,29 +578,7 @@ extern "C" int cvx_engine_create(cvx_engine** out, const cvx_buf_desc* bufs, int
         cvx_set_error("cvx_engine_create: could not create events");
         rc = -1;
       }
-    // execution lanes: validate (lane ops form the tail of the op list) and create their streams
-    // Measured on MI355X (bench.py): the three Detect levels on three streams are SLOWER than one stream (7.66 vs 7.42
-    // ms/step; grids sized for 1/2 or 1/3 of the chip: 7.72 / 7.91) -- the persistent conv kernels already fill the CUs and
-    // the weight-gradient stream fills the gaps -- so lanes are honoured only on request (CVX_LANES=1).
-    static const bool no_lanes = getenv("CVX_LANES") == nullptr;
-    for (size_t i = 0; rc == 0 && i < e->ops.size(); ++i) {
-      int lane = no_lanes ? 0 : e->ops[i].lane;
-      e->ops[i].lane = lane;
-      if (lane < 0 || lane >= cvx_engine::MAX_LANES || (lane == 0 && e->first_lane_op >= 0)) {
-        cvx_set_error("cvx_engine_create: lanes must be 0..3 and lane ops must follow every lane-0 op");
-        rc = -1;
-      }
-      if (lane > 0 && e->first_lane_op < 0) e->first_lane_op = (int)i;
-      if (lane + 1 > e->n_lanes) e->n_lanes = lane + 1;
-    }
-    if (rc == 0 && e->n_lanes > 1) {
-      if (hipEventCreateWithFlags(&e->ev_lane_fork, cvx_event_flags()) != hipSuccess) rc = -1;
-      for (int l = 1; rc == 0 && l < e->n_lanes; ++l)
-        if (hipStreamCreateWithFlags(&e->lane_stream[l], hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&e->ev_lane_join[l], cvx_event_flags()) != hipSuccess)
-          rc = -1;
-      if (rc != 0) cvx_set_error("cvx_engine_create: could not create the lane streams / events");
-    }
+    for (cvx_op_desc& o : e->ops) o.lane = 0;  // reserved field (measured: the three Detect levels on own streams were slower)
   }
   if (rc != 0) {
     free_pool(e->static_allocs);
@@ -607,14 +603,6 @@ extern "C" int cvx_engine_destroy(cvx_engine* e) {
   if (e->ev_mid) (void)hipEventDestroy(e->ev_mid);
   for (hipEvent_t ev : e->ev_seg)
     if (ev) (void)hipEventDestroy(ev);
-  for (int l = 1; l < cvx_engine::MAX_LANES; ++l) {
-    if (e->lane_stream[l]) {
-      (void)hipStreamSynchronize(e->lane_stream[l]);
-      (void)hipStreamDestroy(e->lane_stream[l]);
-    }
-    if (e->ev_lane_join[l]) (void)hipEventDestroy(e->ev_lane_join[l]);
-  }
-  if (e->ev_lane_fork) (void)hipEventDestroy(e->ev_lane_fork);
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   free_pool(e->batch_allocs);
   free_pool(e->static_allocs);
@@ -663,31 +651,8 @@ extern "C" int cvx_engine_debug_copy(cvx_engine* e, int32_t buf, int32_t which, 
   return 0;
 }
 
-namespace {
-// lanes start after everything queued on the main stream so far ...
-int lanes_fork(cvx_engine* e) {
-  if (e->n_lanes <= 1) return 0;
-  CVX_HIP(hipEventRecord(e->ev_lane_fork, e->stream));
-  for (int l = 1; l < e->n_lanes; ++l) CVX_HIP(hipStreamWaitEvent(e->lane_stream[l], e->ev_lane_fork, 0));
-  return 0;
-}
-// ... and the main stream continues once every lane has drained
-int lanes_join(cvx_engine* e) {
-  if (e->n_lanes <= 1) return 0;
-  for (int l = 1; l < e->n_lanes; ++l) {
-    CVX_HIP(hipEventRecord(e->ev_lane_join[l], e->lane_stream[l]));
-    CVX_HIP(hipStreamWaitEvent(e->stream, e->ev_lane_join[l], 0));
-  }
-  return 0;
-}
-inline hipStream_t op_stream(const cvx_engine* e, const cvx_op_desc& o) {
-  static const int div = getenv("CVX_LANE_DIV") ? atoi(getenv("CVX_LANE_DIV")) : 0;  // 0: one share per lane
-  g_cvx_grid_div = o.lane > 0 ? (div > 0 ? div : e->n_lanes - 1) : 1;
-  return o.lane > 0 ? e->lane_stream[o.lane] : e->stream;
-}
-}  // namespace
-
 extern "C" int64_t cvx_engine_workspace_bytes(const cvx_engine* e) { return e ? e->batch_bytes + e->static_bytes : 0; }
+extern "C" int64_t cvx_engine_plan_generation(const cvx_engine* e) { return e ? e->plan_generation : -1; }
 
 extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t batch, int32_t training, float* pred) {
   CVX_CHECK(e && images && pred && batch > 0, "bad arguments");
@@ -698,12 +663,13 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
   const int B = batch;
   // fp32 master -> fp16 shadows (forward layout + transposed layout for the data gradient)
   const Buf& ib = e->bufs[e->image_buf];
+  CVX_CHECK(((uintptr_t)images % 8) == 0, "images must be 8-byte aligned");
   if (training) CVX_HIP(hipMemsetAsync(e->stat_region, 0, (size_t)e->stat_half * 8, st));
   {
-    ProfScope ps(e, PROF_MISC, 0, 6.0 * e->n_params + (double)B * ib.d.h * ib.d.w * (12 + 16));
+    ProfScope ps(e, PROF_MISC, 0, 6.0 * e->n_params);
     CVX_TRY(cvx_pack_weights(e->params, e->shadow, e->d_pack, e->d_pack_blocks, e->n_pack_blocks, st));
-    CVX_TRY(cvx_image_to_nhwc8(images, B, ib.d.h, ib.d.w, ib.act, st));
   }
+  e->last_images = training ? images : nullptr;
   const Buf& pb = e->bufs[e->pred_buf];
   const long long A = (long long)pb.d.h * pb.d.w;
   if (!training) CVX_TRY(cvx_bn_fold_all(e->d_fold, e->n_fold, e->params, e->stats, e->bn_eps, st));  // eval: running stats -> scale/shift
@@ -711,8 +677,6 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
   for (size_t i = 0; i < e->ops.size(); ++i) {
     const cvx_op_desc& o = e->ops[i];
     e->cur_op = (int)i;
-    if ((int)i == e->first_lane_op) CVX_TRY(lanes_fork(e));  // the Detect levels run side by side from here on
-    hipStream_t st = op_stream(e, o);
     if (o.type == CVX_OP_MAXPOOL5) {
       ProfScope ps(e, PROF_MISC, 0, 4.0 * B * o.ih * o.iw * o.in.c, st);
       CVX_TRY(cvx_maxpool5_fwd(make_view(e, o.in, false), make_view(e, o.out, false), B, o.ih, o.iw, o.in.c,
@@ -725,10 +689,29 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
       continue;
     }
     ConvRt& c = e->conv[i];
-    ConvParams cp;
-    fill_conv_fwd(e, (int)i, B, &cp);
     const long long M = (long long)B * o.oh * o.ow;
     const int C = o.out.c;
+    if (c.stem) {  // fp32, straight from the caller's NCHW images: statistics pass + recompute/normalise pass (stem.hip)
+      const StemParams sp{images, B, ib.d.h, ib.d.w, o.oh, o.ow, e->params + o.w_off, C};
+      const double img_bytes = 12.0 * B * ib.d.h * ib.d.w;
+      ViewDesc outv = make_view(e, o.out, false);
+      if (training) {
+        {
+          ProfScope ps(e, PROF_CONV_FWD, conv_flops(o, B), img_bytes, st);
+          CVX_TRY(cvx_stem_stats(sp, c.stat_fwd, st));
+        }
+        ProfScope ps(e, PROF_CONV_FWD, conv_flops(o, B), img_bytes + 4.0 * M * C, st);
+        BnTrainArgs ta{c.stat_fwd,           e->params + o.gamma_off, e->params + o.beta_off, c.mean, c.invstd, e->stats + o.rmean_off,
+                       e->stats + o.rvar_off, e->bn_eps,       e->bn_momentum};
+        CVX_TRY(cvx_stem_apply_train(sp, ta, outv, c.ybuf, st));
+      } else {
+        ProfScope ps(e, PROF_CONV_FWD, conv_flops(o, B), img_bytes + 2.0 * M * C, st);
+        CVX_TRY(cvx_stem_apply_eval(sp, c.scale, c.shift, outv, st));
+      }
+      continue;
+    }
+    ConvParams cp;
+    fill_conv_fwd(e, (int)i, B, &cp);
     if (o.act == CVX_ACT_BIAS) {
       cp.epi = CVX_EPI_BIAS_F32;
       cp.bias = e->params + o.bias_off;
@@ -743,20 +726,20 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
     ViewDesc resv = make_view(e, o.res, false);
     if (training) {
       cp.epi = CVX_EPI_RAW_STATS;
-      cp.out16 = c.ybuf;
+      cp.out32 = e->ytmp;  // raw fp32 output: lives until the normalisation pass right below, then the next layer reuses it
       cp.out_ld = C;
       cp.out_bstride = (long long)o.oh * o.ow * C;
       cp.stats = c.stat_fwd;
       cp.stats_replicas = CVX_STAT_REPLICAS;
       int P = 0;
       {
-        ProfScope ps(e, PROF_CONV_FWD, conv_flops(o, B), conv_bytes(o, B), st);
+        ProfScope ps(e, PROF_CONV_FWD, conv_flops(o, B), conv_bytes(o, B) + 2.0 * M * C, st);
         CVX_TRY(cvx_conv_igemm_launch(cp, st, &P));
       }
-      ProfScope ps(e, PROF_BN_FWD, 0, (resv.p ? 6.0 : 4.0) * M * C, st);
+      ProfScope ps(e, PROF_BN_FWD, 0, (resv.p ? 10.0 : 8.0) * M * C, st);
       BnTrainArgs ta{c.stat_fwd,           e->params + o.gamma_off, e->params + o.beta_off, c.mean, c.invstd, e->stats + o.rmean_off,
                      e->stats + o.rvar_off, e->bn_eps,       e->bn_momentum};
-      CVX_TRY(cvx_bn_silu_apply(c.ybuf, M, C, o.oh * o.ow, ta, outv, resv, st));
+      CVX_TRY(cvx_bn_silu_apply(e->ytmp, M, C, o.oh * o.ow, ta, outv, resv, c.ybuf, st));
     } else {
       // scale / shift were folded for every layer at once before the op loop (cvx_bn_fold_all)
       cp.epi = CVX_EPI_AFFINE_SILU;
@@ -772,7 +755,6 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
       CVX_TRY(cvx_conv_igemm_launch(cp, st, nullptr));
     }
   }
-  CVX_TRY(lanes_join(e));
   e->cur_op = -1;
   e->fwd_train_done = training != 0;
   e->last_batch = B;
@@ -782,6 +764,8 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
 // ---- backward pass state shared by the whole-pass and the segmented entry points ----
 struct PendingWgrad {
   WgradParams wp;
+  bool stem;
+  StemParams sp;
   double flops, bytes;
   int op;
 };
@@ -789,7 +773,7 @@ struct cvx_bw_state {
   half_t* dpred = nullptr;
   float inv_scale = 1.f;
   int B = 0;
-  bool active = false, lanes_open = false;
+  bool active = false;
   int wg_batch = 1;
   int next_op = -1;  // next op (descending) the segmented interface expects
   std::vector<PendingWgrad> pending;
@@ -804,14 +788,14 @@ namespace {
 // weight gradients go to the side stream in batches: one event record on the producing stream per batch
 int flush_wgrads(cvx_engine* e, hipEvent_t ev, hipStream_t producer) {
   cvx_bw_state& w = bw_of(e);
-  static const bool skip_wgrad = getenv("CVX_DBG_SKIP_WGRAD") != nullptr;  // timing experiment only: WRONG gradients
   if (w.pending.empty()) return 0;
   CVX_HIP(hipEventRecord(ev, producer));
   CVX_HIP(hipStreamWaitEvent(e->side, ev, 0));
   for (const PendingWgrad& g : w.pending) {
     e->cur_op = g.op;
     ProfScope ps(e, PROF_CONV_WGRAD, g.flops, g.bytes, e->side);
-    if (!skip_wgrad) CVX_TRY(cvx_conv_wgrad_launch(g.wp, e->side));
+    if (g.stem) CVX_TRY(cvx_stem_wgrad(g.sp, g.wp.dy, g.wp.slabs, g.wp.nsplit, e->side));
+    else CVX_TRY(cvx_conv_wgrad_launch(g.wp, e->side));
   }
   w.pending.clear();
   return 0;
@@ -831,17 +815,12 @@ int backward_begin(cvx_engine* e, const void* dpred_f16, float loss_scale) {
   w.pending.clear();
   w.active = true;
   w.next_op = (int)e->ops.size() - 1;
-  static const int wg_batch_env = getenv("CVX_WGRAD_BATCH") ? atoi(getenv("CVX_WGRAD_BATCH")) : 3;
-  w.wg_batch = (e->first_lane_op >= 0 || wg_batch_env < 1) ? 1 : wg_batch_env;  // lanes: every op has its own producer stream
+  static const int wg_batch_env = cvx_tune_int("CVX_WGRAD_BATCH", 3);
+  w.wg_batch = wg_batch_env < 1 ? 1 : wg_batch_env;
   CVX_HIP(hipMemsetAsync(e->stat_region + e->stat_half, 0, (size_t)e->stat_half * 8, st));
   // fork: the side stream (weight gradients) starts after everything already queued on the main stream
   CVX_HIP(hipEventRecord(e->ev_fork, st));
   CVX_HIP(hipStreamWaitEvent(e->side, e->ev_fork, 0));
-  w.lanes_open = false;
-  if (e->first_lane_op >= 0) {  // the op list ends with the lane ops: the backward pass starts with them
-    CVX_TRY(lanes_fork(e));
-    w.lanes_open = true;
-  }
   return 0;
 }
 
@@ -853,11 +832,7 @@ int backward_op(cvx_engine* e, int i) {
   const long long A = (long long)pb.d.h * pb.d.w;
   const cvx_op_desc& o = e->ops[i];
   e->cur_op = i;
-  if (w.lanes_open && o.lane == 0) {  // first main-chain op: its gradient inputs were written on the lanes
-    CVX_TRY(lanes_join(e));
-    w.lanes_open = false;
-  }
-    hipStream_t st = op_stream(e, o);
+    hipStream_t st = e->stream;
     if (o.type == CVX_OP_MAXPOOL5) {
       ProfScope ps(e, PROF_MISC, 0, 7.0 * B * o.ih * o.iw * o.in.c, st);
       CVX_TRY(cvx_maxpool5_bwd(make_view(e, o.out, true), make_view(e, o.in, true), B, o.ih, o.iw, o.in.c, e->pool[i].idx,
@@ -883,7 +858,7 @@ int backward_op(cvx_engine* e, int i) {
     } else {
       ViewDesc gout = make_view(e, o.out, true);
       ViewDesc gres = make_view(e, o.res, true);
-      BnCoef k{c.mean, c.invstd, e->params + o.gamma_off, e->params + o.beta_off};
+      BnCoef k{c.invstd, e->params + o.gamma_off, e->params + o.beta_off};
       ProfScope ps(e, PROF_BN_BWD, 0, (gres.p ? 14.0 : 10.0) * M * C, st);
       CVX_TRY(cvx_bn_bwd_reduce(c.ybuf, M, C, hw, k, gout, c.stat_bwd, st));
       CVX_TRY(cvx_bn_bwd_apply(c.ybuf, M, C, hw, k, c.stat_bwd, w.inv_scale, e->grads + o.gamma_off, e->grads + o.beta_off, gout, c.dybuf,
@@ -898,7 +873,7 @@ int backward_op(cvx_engine* e, int i) {
     if (o.needs_dgrad) {
       ViewDesc gin = make_view(e, o.in, true);
       // the phases of a strided data gradient differ only in tap subset and output phase: one launch (blockIdx.z)
-      static const bool merge_off = getenv("CVX_NO_PHASE_MERGE") != nullptr;
+      static const bool merge_off = cvx_tune_set("CVX_NO_PHASE_MERGE");
       bool merged = !merge_off && c.ndg > 1 && c.ndg <= 4;
       for (int q = 0; q < c.ndg && merged; ++q)
         if (c.dg[q].OH2 <= 0 || c.dg[q].OW2 <= 0 || c.dg[q].ntaps <= 0) merged = false;
@@ -958,7 +933,7 @@ int backward_op(cvx_engine* e, int i) {
     }
     // ---- weight gradient -> fp32 slabs ----
     {
-      ViewDesc xin = make_view(e, o.in, false);
+      ViewDesc xin = c.stem ? ViewDesc{nullptr, 0, 0} : make_view(e, o.in, false);
       WgradParams wp;
       memset(&wp, 0, sizeof(wp));
       wp.x = xin.p;
@@ -981,10 +956,15 @@ int backward_op(cvx_engine* e, int i) {
       wp.nsplit = c.nsplit;
       wp.cin_pad16 = c.cin_pad16;
       wp.std3x3 = c.std3x3;
-      w.pending.push_back({wp, conv_flops(o, B), conv_bytes(o, B) + 4.0 * c.nsplit * C * c.ntaps * c.cin_pad16, i});
-      if ((int)w.pending.size() >= w.wg_batch || i == 0 || i == e->slab_tail_op ||
-          (w.lanes_open && e->ops[i].lane != (i > 0 ? e->ops[i - 1].lane : 0)))
-        CVX_TRY(flush_wgrads(e, c.ev_dy, st));
+      PendingWgrad pw{wp, c.stem, StemParams{}, conv_flops(o, B), conv_bytes(o, B) + 4.0 * c.nsplit * C * c.ntaps * c.cin_pad16, i};
+      if (c.stem) {
+        const Buf& ib = e->bufs[e->image_buf];
+        CVX_CHECK(e->last_images, "the stem's weight gradient needs the images of the training forward");
+        pw.sp = StemParams{e->last_images, B, ib.d.h, ib.d.w, o.oh, o.ow, e->params + o.w_off, C};
+        pw.bytes = 12.0 * B * ib.d.h * ib.d.w + 2.0 * M * C + 4.0 * c.nsplit * C * 144;
+      }
+      w.pending.push_back(pw);
+      if ((int)w.pending.size() >= w.wg_batch || i == 0 || i == e->slab_tail_op) CVX_TRY(flush_wgrads(e, c.ev_dy, st));
       if (i == e->slab_tail_op) CVX_HIP(hipEventRecord(e->ev_mid, e->side));  // every weight gradient outside the tail is queued
     }
   return 0;
@@ -999,7 +979,6 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
   const float inv_scale = w.inv_scale;
   for (int i = (int)e->ops.size() - 1; i >= 0; --i) CVX_TRY(backward_op(e, i));
   w.active = false;
-  if (w.lanes_open) CVX_TRY(lanes_join(e));
   CVX_TRY(flush_wgrads(e, e->ev_fork, st));  // (non-conv first ops: nothing pending in practice)
   e->cur_op = -1;
   double slab_bytes = 0;
@@ -1037,10 +1016,6 @@ extern "C" int cvx_engine_backward_range(cvx_engine* e, int32_t op_hi, int32_t o
   CVX_CHECK(op_hi == w.next_op && op_lo >= 0 && op_lo <= op_hi, "ranges must tile the op list from the last op down to 0");
   for (int i = op_hi; i >= op_lo; --i) CVX_TRY(backward_op(e, i));
   w.next_op = op_lo - 1;
-  if (w.lanes_open && (op_lo == 0 || e->ops[op_lo - 1].lane == 0)) {
-    CVX_TRY(lanes_join(e));
-    w.lanes_open = false;
-  }
   CVX_TRY(flush_wgrads(e, e->ev_fork, e->stream));  // every weight gradient of the range is queued on the side stream
   return 0;
 }

@@ -571,3 +571,50 @@ extern "C" int cvx_loss_v8_strided(const float* pred, int32_t pred_ld, int32_t B
   CVX_HIP(hipGetLastError());
   return 0;
 }
+
+// Inspection of the last cvx_loss_v8* call that used `workspace` (same batch / anchors / max_targets): per anchor the
+// index of the assigned target row (-1 = background) and its normalised target score
+// (TaskAlignedAssigner outputs target_gt_idx / fg_mask / target_scores, core/utils/bboxes.py:330-345).
+extern "C" int cvx_loss_v8_assignment(const void* workspace, int32_t B, int32_t A, int32_t max_targets, int32_t* gt_index, float* norm_score,
+                                      void* hip_stream) {
+  CVX_CHECK(workspace && gt_index && norm_score && B > 0 && A > 0, "bad arguments");
+  char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  Ws w;
+  carve(base, B, A, max_targets, &w);
+  hipStream_t st = (hipStream_t)hip_stream;
+  CVX_HIP(hipMemcpyAsync(gt_index, w.gt_idx, (size_t)B * A * 4, hipMemcpyDeviceToDevice, st));
+  CVX_HIP(hipMemcpyAsync(norm_score, w.norm, (size_t)B * A * 4, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+// ---- yolo8_collate dict -> target rows ----------------------------------------------------------------------
+// batch_idx (N), cls (N), bboxes (N,4) -> rows [batch_idx, cls, cx, cy, w, h] grouped by image, the relative order inside
+// an image kept (what Loss.preprocess does row by row, core/algorithms/yolo_v8.py:51-65).  Rank = number of rows that
+// must precede: O(N^2) compares, N is a few hundred at most.
+namespace {
+__global__ __launch_bounds__(256) void pack_targets_kernel(const float* bi, const float* cls, const float* box, int N, float* out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const float b = bi[i];
+  int rank = 0;
+  for (int j = 0; j < N; ++j) {
+    const float bj = bi[j];
+    rank += (bj < b || (bj == b && j < i)) ? 1 : 0;
+  }
+  float* o = out + (long long)rank * 6;
+  o[0] = b;
+  o[1] = cls[i];
+  o[2] = box[i * 4 + 0];
+  o[3] = box[i * 4 + 1];
+  o[4] = box[i * 4 + 2];
+  o[5] = box[i * 4 + 3];
+}
+}  // namespace
+
+extern "C" int cvx_pack_targets(const float* batch_idx, const float* cls, const float* bboxes, int32_t n, float* rows, void* hip_stream) {
+  if (n <= 0) return 0;
+  CVX_CHECK(batch_idx && cls && bboxes && rows, "null arguments");
+  hipLaunchKernelGGL(pack_targets_kernel, dim3(cvx_cdiv(n, 256)), dim3(256), 0, (hipStream_t)hip_stream, batch_idx, cls, bboxes, n, rows);
+  CVX_HIP(hipGetLastError());
+  return 0;
+}

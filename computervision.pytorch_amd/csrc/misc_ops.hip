@@ -6,17 +6,6 @@ namespace {
 
 __device__ __forceinline__ long long voff(const ViewDesc& v, int b, long long pix) { return (long long)b * v.bstride + pix * v.ld; }
 
-// ---- NCHW fp32 image -> NHWC fp16 with C padded 3 -> 8 (16 B per pixel) -----------------------
-__global__ void image_to_nhwc8_kernel(const float* img, int B, int HW, half_t* out) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  long long n = (long long)B * HW;
-  if (i >= n) return;
-  long long b = i / HW, pix = i - b * HW;
-  const float* src = img + b * 3 * HW + pix;
-  h8 o = {(half_t)src[0], (half_t)src[HW], (half_t)src[2LL * HW], (half_t)0, (half_t)0, (half_t)0, (half_t)0, (half_t)0};
-  *reinterpret_cast<h8*>(out + i * 8) = o;
-}
-
 // ---- max pool 5x5 s1 p2 ------------------------------------------------------------------------
 __global__ void maxpool5_fwd_kernel(ViewDesc in, ViewDesc out, int B, int H, int W, int CG, uint8_t* idx) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -321,9 +310,6 @@ int launch1d(K kern, long long n, hipStream_t st, Args... args) {
 
 }  // namespace
 
-int cvx_image_to_nhwc8(const float* img, int B, int H, int W, half_t* out, hipStream_t st) {
-  return launch1d(image_to_nhwc8_kernel, (long long)B * H * W, st, img, B, H * W, out);
-}
 int cvx_maxpool5_fwd(const ViewDesc& in, const ViewDesc& out, int B, int H, int W, int C, uint8_t* idx, hipStream_t st) {
   CVX_CHECK(C % 8 == 0, "maxpool5: C % 8");
   return launch1d(maxpool5_fwd_kernel, (long long)B * H * W * (C / 8), st, in, out, B, H, W, C / 8, idx);

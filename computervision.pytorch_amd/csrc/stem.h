@@ -1,0 +1,21 @@
+// FP32 stem convolution (3 -> Cout, 3x3 / stride 2 / pad 1) straight from NCHW fp32 images: see stem.hip.
+#pragma once
+#include "bn_act.h"
+
+struct StemParams {
+  const float* img;  // (B, 3, H, W) fp32, NCHW, H and W even
+  int B, H, W, OH, OW;
+  const float* w;    // fp32 master weights [Cout][kh][kw][ci]
+  int Cout;          // 16, 32, 48, 64 or 80
+};
+
+// pass 1 (train): per-channel (sum, sumsq) of the raw conv output into the fixed-point replica slabs (zero on entry)
+int cvx_stem_stats(const StemParams& p, long long* stats, hipStream_t st);
+// pass 2 (train): recompute, (y-mean)*invstd -> xhat fp16 [M][Cout], silu(gamma*xhat+beta) -> out view; block 0 publishes
+// mean / invstd and updates the running statistics
+int cvx_stem_apply_train(const StemParams& p, const BnTrainArgs& a, const ViewDesc& out, half_t* xhat, hipStream_t st);
+// eval: silu(y*scale+shift) -> out view (scale / shift = folded running statistics)
+int cvx_stem_apply_eval(const StemParams& p, const float* scale, const float* shift, const ViewDesc& out, hipStream_t st);
+// weight gradient from dy fp16 [M][Cout] into fp32 slabs [nsplit][Cout][9 * 16]; nsplit = cvx_stem_wgrad_splits(M)
+int cvx_stem_wgrad_splits(long long M);
+int cvx_stem_wgrad(const StemParams& p, const half_t* dy, float* slabs, int nsplit, hipStream_t st);

@@ -1,0 +1,313 @@
+// The stem convolution (3 -> Cout, 3x3, stride 2, pad 1: model.0 of every YOLOv8 scale) in FP32, straight from the
+// caller's NCHW fp32 images (gfx950).
+//
+// Why a kernel of its own: K = 27 wastes an MFMA K-step, the layer is purely HBM-bound, and its arithmetic decides the
+// forward error of the whole network -- the image has a large mean, so rounding the image, the stem weights or the raw
+// stem output to fp16 costs more than all later layers together.  Here nothing is rounded before
+// the BatchNorm: images and master weights are read as fp32, 27 FMAs per output value on the vector ALUs
+// (432 per pixel at 16 channels: ~3 GFLOP per 32-image batch, far below the memory time), and training mode runs TWO
+// passes over the images -- statistics, then recompute + normalise + SiLU -- instead of storing the raw output:
+//   pass 1  stem_stats   images (157 MB at batch 32)                      -> per-channel (sum, sumsq), fixed-point slabs
+//   pass 2  stem_apply   images again                                     -> xhat fp16 (backward operand) + activation fp16
+// i.e. 0.52 GB where NCHW->NHWC8 conversion + MFMA conv + BN/SiLU pass moved 0.89 GB.  Eval mode is pass 2 alone with the
+// folded running statistics.  The weight gradient (stem_wgrad) reads the fp32 images too: 4 x 27 accumulators per lane,
+// lane = pixel, wave = 4 output channels, fixed-order reductions into the engine's fp32 gradient slabs.
+#include "stem.h"
+
+#include "bn_common.h"
+
+namespace {
+using namespace cvx_bn;
+
+constexpr int KT = 27;  // (kh*3 + kw)*3 + ci
+
+struct PixelId {
+  int b, oy, ox;
+};
+__device__ __forceinline__ PixelId pixel_of(const StemParams& p, long long m) {
+  const unsigned mu = (unsigned)m;  // M < 2^31 (launcher)
+  const unsigned t = mu / (unsigned)p.OW;
+  const int ox = (int)(mu - t * (unsigned)p.OW);
+  const int b = (int)(t / (unsigned)p.OH);
+  const int oy = (int)(t - (unsigned)b * (unsigned)p.OH);
+  return PixelId{b, oy, ox};
+}
+
+// the 3x3x3 input window of output pixel (oy, ox): columns 2ox-1, 2ox, 2ox+1 of rows 2oy-1 .. 2oy+1 (H, W even: only
+// the top row and the left column can fall outside).  One 8-byte load covers (2ox, 2ox+1); consecutive lanes read
+// consecutive 8-byte pairs, the left neighbour is a second (cache-resident) 4-byte load.
+__device__ __forceinline__ void load_window(const StemParams& p, const PixelId& id, float (&x)[KT]) {
+  const long long plane = (long long)p.H * p.W;
+  const float* img = p.img + (long long)id.b * 3 * plane;
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int iy = 2 * id.oy - 1 + kh;
+    const bool rok = iy >= 0;  // iy <= 2*OH - 1 + 1 - 1 = H - 1 always
+    const int iyc = rok ? iy : 0;
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci) {
+      const float* row = img + ci * plane + (long long)iyc * p.W + 2 * id.ox;
+      const float2 c = *reinterpret_cast<const float2*>(row);
+      const float l = id.ox > 0 ? row[-1] : 0.f;
+      x[(kh * 3 + 0) * 3 + ci] = rok ? l : 0.f;
+      x[(kh * 3 + 1) * 3 + ci] = rok ? c.x : 0.f;
+      x[(kh * 3 + 2) * 3 + ci] = rok ? c.y : 0.f;
+    }
+  }
+}
+
+// weights fp32 [Cout][kh][kw][ci] (the master layout) -> LDS [27][Cout]: a lane group reads 16 consecutive channels of
+// one k as four broadcast ds_read_b128
+__device__ __forceinline__ void stage_weights(const StemParams& p, float* sW) {
+  for (int i = threadIdx.x; i < KT * p.Cout; i += blockDim.x) {
+    const int co = i / KT, k = i - co * KT;
+    sW[k * p.Cout + co] = p.w[i];
+  }
+}
+
+// 16 output channels [g*16, g*16+16) of one pixel; the same instruction order in every pass (bit-identical recompute)
+__device__ __forceinline__ void conv16(const float (&x)[KT], const float* sW, int Cout, int g, float (&acc)[16]) {
+#pragma unroll
+  for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+#pragma unroll
+  for (int k = 0; k < KT; ++k) {
+    const f4* w4 = reinterpret_cast<const f4*>(sW + k * Cout + g * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f4 w = w4[q];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[q * 4 + r] = fmaf(x[k], w[r], acc[q * 4 + r]);
+    }
+  }
+}
+
+// ---- pass 1: batch statistics ------------------------------------------------------------------------------
+template <int NG>
+__global__ __launch_bounds__(256) void stem_stats_kernel(const StemParams p, long long M, long long* stats) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sW = smem;                 // [27][Cout]
+  float* sred = smem + KT * p.Cout;  // [4 waves][2][Cout]
+  stage_weights(p, sW);
+  __syncthreads();
+  float s1[NG][16], s2[NG][16];
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int c = 0; c < 16; ++c) s1[g][c] = s2[g][c] = 0.f;
+  for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long long)gridDim.x * 256) {
+    asm volatile("" ::: "memory");  // keeps the compiler from hoisting all 27 x Cout LDS weights into registers (spills)
+    const PixelId id = pixel_of(p, m);
+    float x[KT];
+    load_window(p, id, x);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      float acc[16];
+      conv16(x, sW, p.Cout, g, acc);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        s1[g][c] += acc[c];
+        s2[g][c] = fmaf(acc[c], acc[c], s2[g][c]);
+      }
+    }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const float a = cvx_wave_sum64(s1[g][c]), b = cvx_wave_sum64(s2[g][c]);
+      if (lane == 0) {
+        sred[(wave * 2 + 0) * p.Cout + g * 16 + c] = a;
+        sred[(wave * 2 + 1) * p.Cout + g * 16 + c] = b;
+      }
+    }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 2 * p.Cout; t += 256) {
+    const int which = t / p.Cout, c = t - which * p.Cout;
+    const float v = (sred[(0 * 2 + which) * p.Cout + c] + sred[(1 * 2 + which) * p.Cout + c]) +
+                    (sred[(2 * 2 + which) * p.Cout + c] + sred[(3 * 2 + which) * p.Cout + c]);
+    cvx_fix_atomic_add(stats, ((long long)(blockIdx.x % CVX_STAT_REPLICAS) * p.Cout + c) * 2 + which, v);
+  }
+}
+
+// ---- pass 2: recompute, normalise from the fp32 values, SiLU, store ---------------------------------------------
+template <int NG, bool TRAIN>
+__global__ __launch_bounds__(256) void stem_apply_kernel(const StemParams p, long long M, BnTrainArgs a, const float* scale,
+                                                         const float* shift, ViewDesc out, half_t* xhat) {
+  extern __shared__ __attribute__((aligned(16))) long long ws[];  // [fold workspace (train)] | 4 x Cout coefficients | weights
+  float* sA = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (TRAIN ? fold_ws_bytes(p.Cout) : 0));
+  float* sB = sA + p.Cout;   // train: (mean, invstd, gamma, beta); eval: (scale, shift, -, -)
+  float* sG = sB + p.Cout;
+  float* sBe = sG + p.Cout;
+  float* sW = sBe + p.Cout;
+  if (TRAIN) {
+    fold_replicas(a.stats, p.Cout, ws);
+    for (int c = threadIdx.x; c < p.Cout; c += 256) {
+      double var;
+      const BnMoments mo = moments_of(ws, p.Cout, c, M, a.eps, &var);
+      sA[c] = mo.mean;
+      sB[c] = mo.invstd;
+      sG[c] = a.gamma[c];
+      sBe[c] = a.beta[c];
+      if (blockIdx.x == 0) {
+        const double cnt = (double)M;
+        const double mu = reinterpret_cast<const double*>(ws)[c] / cnt;
+        a.mean[c] = mo.mean;
+        a.invstd[c] = mo.invstd;
+        const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+        a.rmean[c] = (float)((1.0 - a.momentum) * (double)a.rmean[c] + a.momentum * mu);
+        a.rvar[c] = (float)((1.0 - a.momentum) * (double)a.rvar[c] + a.momentum * unbiased);
+      }
+    }
+  } else {
+    for (int c = threadIdx.x; c < p.Cout; c += 256) {
+      sA[c] = scale[c];
+      sB[c] = shift[c];
+    }
+  }
+  stage_weights(p, sW);
+  __syncthreads();
+  const int ohw = p.OH * p.OW;
+  for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long long)gridDim.x * 256) {
+    asm volatile("" ::: "memory");  // keeps the compiler from hoisting all 27 x Cout LDS weights into registers (spills)
+    const PixelId id = pixel_of(p, m);
+    float x[KT];
+    load_window(p, id, x);
+    half_t* o = out.p + (long long)id.b * out.bstride + ((long long)id.oy * p.OW + id.ox) * out.ld;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      float acc[16];
+      conv16(x, sW, p.Cout, g, acc);
+      h8 av[2], xv[2];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const int ch = g * 16 + c;
+        float z;
+        if (TRAIN) {
+          const float xh = (acc[c] - sA[ch]) * sB[ch];
+          xv[c >> 3][c & 7] = (half_t)xh;
+          z = fmaf(xh, sG[ch], sBe[ch]);
+        } else {
+          z = fmaf(acc[c], sA[ch], sB[ch]);
+        }
+        av[c >> 3][c & 7] = (half_t)cvx_silu(z);
+      }
+      *reinterpret_cast<h8*>(o + g * 16) = av[0];
+      *reinterpret_cast<h8*>(o + g * 16 + 8) = av[1];
+      if (TRAIN) {
+        half_t* xo = xhat + m * p.Cout + g * 16;
+        *reinterpret_cast<h8*>(xo) = xv[0];
+        *reinterpret_cast<h8*>(xo + 8) = xv[1];
+      }
+    }
+  }
+  (void)ohw;
+}
+
+// ---- weight gradient: dW[co][tap][ci] = sum over pixels of dy[pixel][co] * x[pixel][tap][ci] -------------------------
+// blockIdx.y = slice of 16 output channels; wave w of a workgroup owns channels slice*16 + 4w .. +3; all four waves walk
+// the same pixels (lane = pixel).  Slab layout = the engine's [split][Cout][9 taps * 16 (padded ci)] fp32.
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemParams p, long long M, const half_t* dy, float* slabs) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int co0 = blockIdx.y * 16 + wave * 4;
+  float acc[4][KT];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < KT; ++k) acc[c][k] = 0.f;
+  for (long long m = (long long)blockIdx.x * 64 + lane; m < M; m += (long long)gridDim.x * 64) {
+    asm volatile("" ::: "memory");  // keeps the compiler from hoisting all 27 x Cout LDS weights into registers (spills)
+    const PixelId id = pixel_of(p, m);
+    float x[KT];
+    load_window(p, id, x);
+    const h4 g = *reinterpret_cast<const h4*>(dy + m * p.Cout + co0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float gc = (float)g[c];
+#pragma unroll
+      for (int k = 0; k < KT; ++k) acc[c][k] = fmaf(gc, x[k], acc[c][k]);
+    }
+  }
+  float* slab = slabs + (long long)blockIdx.x * p.Cout * 144;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      const float v = cvx_wave_sum64(acc[c][k]);
+      if (lane == 0) slab[(co0 + c) * 144 + (k / 3) * 16 + (k % 3)] = v;
+    }
+}
+
+int stem_grid(long long M, int per_block) {
+  long long blocks = (M + per_block - 1) / per_block;
+  const long long cap = 256 * 8;  // persistent: grid-stride over the pixels, 8 workgroups per CU at most
+  return (int)(blocks < cap ? blocks : cap);
+}
+
+int check(const StemParams& p) {
+  CVX_CHECK(p.img && p.w, "stem: null pointers");
+  CVX_CHECK(p.H % 2 == 0 && p.W % 2 == 0 && p.OH == p.H / 2 && p.OW == p.W / 2, "stem: even input sizes, output = input / 2");
+  CVX_CHECK(p.Cout % 16 == 0 && p.Cout >= 16 && p.Cout <= 80, "stem: 16..80 output channels in multiples of 16");
+  CVX_CHECK((long long)p.B * p.OH * p.OW < (1LL << 31), "stem: too many output pixels");
+  CVX_CHECK(((uintptr_t)p.img % 8) == 0, "stem: images must be 8-byte aligned");
+  return 0;
+}
+
+}  // namespace
+
+int cvx_stem_stats(const StemParams& p, long long* stats, hipStream_t st) {
+  CVX_TRY(check(p));
+  const long long M = (long long)p.B * p.OH * p.OW;
+  const int lds = (KT + 8) * p.Cout * 4;
+  const dim3 grid(stem_grid(M, 256));
+  switch (p.Cout / 16) {
+    case 1: hipLaunchKernelGGL(stem_stats_kernel<1>, grid, dim3(256), lds, st, p, M, stats); break;
+    case 2: hipLaunchKernelGGL(stem_stats_kernel<2>, grid, dim3(256), lds, st, p, M, stats); break;
+    case 3: hipLaunchKernelGGL(stem_stats_kernel<3>, grid, dim3(256), lds, st, p, M, stats); break;
+    case 4: hipLaunchKernelGGL(stem_stats_kernel<4>, grid, dim3(256), lds, st, p, M, stats); break;
+    default: hipLaunchKernelGGL(stem_stats_kernel<5>, grid, dim3(256), lds, st, p, M, stats); break;
+  }
+  CVX_HIP(hipGetLastError());
+  return 0;
+}
+
+template <bool TRAIN>
+static int launch_apply(const StemParams& p, const BnTrainArgs& a, const float* scale, const float* shift, const ViewDesc& out,
+                        half_t* xhat, hipStream_t st) {
+  const long long M = (long long)p.B * p.OH * p.OW;
+  const int lds = (TRAIN ? fold_ws_bytes(p.Cout) : 0) + (4 + KT) * p.Cout * 4;
+  const dim3 grid(stem_grid(M, 256));
+  switch (p.Cout / 16) {
+    case 1: hipLaunchKernelGGL((stem_apply_kernel<1, TRAIN>), grid, dim3(256), lds, st, p, M, a, scale, shift, out, xhat); break;
+    case 2: hipLaunchKernelGGL((stem_apply_kernel<2, TRAIN>), grid, dim3(256), lds, st, p, M, a, scale, shift, out, xhat); break;
+    case 3: hipLaunchKernelGGL((stem_apply_kernel<3, TRAIN>), grid, dim3(256), lds, st, p, M, a, scale, shift, out, xhat); break;
+    case 4: hipLaunchKernelGGL((stem_apply_kernel<4, TRAIN>), grid, dim3(256), lds, st, p, M, a, scale, shift, out, xhat); break;
+    default: hipLaunchKernelGGL((stem_apply_kernel<5, TRAIN>), grid, dim3(256), lds, st, p, M, a, scale, shift, out, xhat); break;
+  }
+  CVX_HIP(hipGetLastError());
+  return 0;
+}
+
+int cvx_stem_apply_train(const StemParams& p, const BnTrainArgs& a, const ViewDesc& out, half_t* xhat, hipStream_t st) {
+  CVX_TRY(check(p));
+  CVX_CHECK(out.p && xhat && ((uintptr_t)out.p % 16) == 0 && out.ld % 8 == 0, "stem: output view");
+  return launch_apply<true>(p, a, nullptr, nullptr, out, xhat, st);
+}
+
+int cvx_stem_apply_eval(const StemParams& p, const float* scale, const float* shift, const ViewDesc& out, hipStream_t st) {
+  CVX_TRY(check(p));
+  CVX_CHECK(out.p && scale && shift && ((uintptr_t)out.p % 16) == 0 && out.ld % 8 == 0, "stem: output view");
+  BnTrainArgs none{};
+  return launch_apply<false>(p, none, scale, shift, out, nullptr, st);
+}
+
+int cvx_stem_wgrad_splits(long long M) { return stem_grid(M, 64 * 16) < 512 ? stem_grid(M, 64 * 16) : 512; }
+
+int cvx_stem_wgrad(const StemParams& p, const half_t* dy, float* slabs, int nsplit, hipStream_t st) {
+  CVX_TRY(check(p));
+  const long long M = (long long)p.B * p.OH * p.OW;
+  CVX_CHECK(dy && slabs && nsplit >= 1 && nsplit == cvx_stem_wgrad_splits(M), "stem wgrad: split count must come from cvx_stem_wgrad_splits");
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nsplit, p.Cout / 16), dim3(256), 0, st, p, M, dy, slabs);
+  CVX_HIP(hipGetLastError());
+  return 0;
+}

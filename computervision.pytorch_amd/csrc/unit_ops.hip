@@ -1,0 +1,135 @@
+// Single-op C-ABI entry points over the streaming kernels (BatchNorm+SiLU passes, SPPF pool, nearest upsample, fp32 stem):
+// the same kernels the engine launches, on caller-owned dense NHWC tensors -- for unit parity tests and for host code
+// that wants one op.  They allocate their small statistic slabs themselves and synchronise before returning.
+#include <vector>
+
+#include "../../include/cvx_engine.h"
+#include "misc_ops.h"
+#include "stem.h"
+
+namespace {
+
+struct Scratch {  // RAII device allocation (zeroed)
+  void* p = nullptr;
+  int alloc(size_t bytes) {
+    CVX_HIP(hipMalloc(&p, bytes));
+    CVX_HIP(hipMemset(p, 0, bytes));
+    return 0;
+  }
+  ~Scratch() {
+    if (p) (void)hipFree(p);
+  }
+};
+size_t slab_bytes(int C) { return (size_t)CVX_STAT_REPLICAS * C * CVX_STAT_WORDS * 8; }
+ViewDesc dense(const void* p, int hw, int C) { return ViewDesc{(half_t*)p, (long long)hw * C, C}; }
+
+}  // namespace
+
+extern "C" int cvx_bn_silu_train_nhwc(const float* y_f32, int32_t batch, int32_t hw, int32_t c, const float* gamma, const float* beta, float eps,
+                                      float momentum, float* running_mean, float* running_var, const void* res_f16, void* out_f16,
+                                      void* xhat_f16, float* mean, float* invstd, void* hip_stream) {
+  CVX_CHECK(y_f32 && gamma && beta && running_mean && running_var && out_f16 && xhat_f16 && mean && invstd && batch > 0 && hw > 0, "bad arguments");
+  hipStream_t st = (hipStream_t)hip_stream;
+  const long long M = (long long)batch * hw;
+  Scratch slab;
+  CVX_TRY(slab.alloc(slab_bytes(c)));
+  CVX_TRY(cvx_bn_stats_f32(y_f32, M, c, (long long*)slab.p, st));
+  BnTrainArgs ta{(const long long*)slab.p, gamma, beta, mean, invstd, running_mean, running_var, eps, momentum};
+  CVX_TRY(cvx_bn_silu_apply(y_f32, M, c, hw, ta, dense(out_f16, hw, c), res_f16 ? dense(res_f16, hw, c) : ViewDesc{nullptr, 0, 0},
+                            (half_t*)xhat_f16, st));
+  CVX_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+extern "C" int cvx_bn_silu_bwd_nhwc(const void* xhat_f16, const void* gout_f16, int32_t batch, int32_t hw, int32_t c, const float* gamma,
+                                    const float* beta, const float* invstd, float inv_scale, float* dgamma, float* dbeta, void* dy_f16,
+                                    void* gres_f16, int32_t res_accumulate, void* hip_stream) {
+  CVX_CHECK(xhat_f16 && gout_f16 && gamma && beta && invstd && dgamma && dbeta && dy_f16 && batch > 0 && hw > 0, "bad arguments");
+  hipStream_t st = (hipStream_t)hip_stream;
+  const long long M = (long long)batch * hw;
+  Scratch slab;
+  CVX_TRY(slab.alloc(slab_bytes(c)));
+  BnCoef k{invstd, gamma, beta};
+  const ViewDesc g = dense(gout_f16, hw, c);
+  CVX_TRY(cvx_bn_bwd_reduce((const half_t*)xhat_f16, M, c, hw, k, g, (long long*)slab.p, st));
+  CVX_TRY(cvx_bn_bwd_apply((const half_t*)xhat_f16, M, c, hw, k, (const long long*)slab.p, inv_scale, dgamma, dbeta, g, (half_t*)dy_f16,
+                           gres_f16 ? dense(gres_f16, hw, c) : ViewDesc{nullptr, 0, 0}, res_accumulate, st));
+  CVX_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+extern "C" int cvx_maxpool5_nhwc(const void* x_f16, int32_t batch, int32_t h, int32_t w, int32_t c, void* out_f16, uint8_t* argmax,
+                                 void* hip_stream) {
+  CVX_CHECK(x_f16 && out_f16 && batch > 0 && c % 8 == 0, "bad arguments (channels in multiples of 8)");
+  CVX_TRY(cvx_maxpool5_fwd(dense(x_f16, h * w, c), dense(out_f16, h * w, c), batch, h, w, c, argmax, (hipStream_t)hip_stream));
+  CVX_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
+  return 0;
+}
+extern "C" int cvx_maxpool5_bwd_nhwc(const void* gout_f16, const uint8_t* argmax, int32_t batch, int32_t h, int32_t w, int32_t c,
+                                     void* gin_f16, int32_t accumulate, void* hip_stream) {
+  CVX_CHECK(gout_f16 && argmax && gin_f16 && batch > 0 && c % 8 == 0, "bad arguments (channels in multiples of 8)");
+  CVX_TRY(cvx_maxpool5_bwd(dense(gout_f16, h * w, c), dense(gin_f16, h * w, c), batch, h, w, c, argmax, accumulate, (hipStream_t)hip_stream));
+  CVX_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
+  return 0;
+}
+extern "C" int cvx_upsample2_nhwc(const void* x_f16, int32_t batch, int32_t h, int32_t w, int32_t c, void* out_f16, void* hip_stream) {
+  CVX_CHECK(x_f16 && out_f16 && batch > 0 && c % 8 == 0, "bad arguments (channels in multiples of 8)");
+  CVX_TRY(cvx_upsample2_fwd(dense(x_f16, h * w, c), dense(out_f16, 4 * h * w, c), batch, h, w, c, (hipStream_t)hip_stream));
+  CVX_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
+  return 0;
+}
+extern "C" int cvx_upsample2_bwd_nhwc(const void* gout_f16, int32_t batch, int32_t h, int32_t w, int32_t c, void* gin_f16, int32_t accumulate,
+                                      void* hip_stream) {
+  CVX_CHECK(gout_f16 && gin_f16 && batch > 0 && c % 8 == 0, "bad arguments (channels in multiples of 8)");
+  CVX_TRY(cvx_upsample2_bwd(dense(gout_f16, 4 * h * w, c), dense(gin_f16, h * w, c), batch, h, w, c, accumulate, (hipStream_t)hip_stream));
+  CVX_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
+  return 0;
+}
+
+// ---- fp32 stem --------------------------------------------------------------------------------------------
+extern "C" int cvx_stem_train_nchw(const float* images, int32_t batch, int32_t h, int32_t w, const float* weight, int32_t cout,
+                                   const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                                   float* running_var, void* out_f16, void* xhat_f16, float* mean, float* invstd, void* hip_stream) {
+  CVX_CHECK(images && weight && gamma && beta && running_mean && running_var && out_f16 && xhat_f16 && mean && invstd, "null arguments");
+  hipStream_t st = (hipStream_t)hip_stream;
+  const StemParams sp{images, batch, h, w, h / 2, w / 2, weight, cout};
+  Scratch slab;
+  CVX_TRY(slab.alloc(slab_bytes(cout)));
+  CVX_TRY(cvx_stem_stats(sp, (long long*)slab.p, st));
+  BnTrainArgs ta{(const long long*)slab.p, gamma, beta, mean, invstd, running_mean, running_var, eps, momentum};
+  CVX_TRY(cvx_stem_apply_train(sp, ta, dense(out_f16, (h / 2) * (w / 2), cout), (half_t*)xhat_f16, st));
+  CVX_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+extern "C" int cvx_stem_eval_nchw(const float* images, int32_t batch, int32_t h, int32_t w, const float* weight, int32_t cout,
+                                  const float* scale, const float* shift, void* out_f16, void* hip_stream) {
+  CVX_CHECK(images && weight && scale && shift && out_f16, "null arguments");
+  const StemParams sp{images, batch, h, w, h / 2, w / 2, weight, cout};
+  CVX_TRY(cvx_stem_apply_eval(sp, scale, shift, dense(out_f16, (h / 2) * (w / 2), cout), (hipStream_t)hip_stream));
+  CVX_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
+  return 0;
+}
+extern "C" int cvx_stem_wgrad_nchw(const float* images, int32_t batch, int32_t h, int32_t w, const void* dy_f16, int32_t cout, float* dw,
+                                   void* hip_stream) {
+  CVX_CHECK(images && dy_f16 && dw, "null arguments");
+  hipStream_t st = (hipStream_t)hip_stream;
+  const StemParams sp{images, batch, h, w, h / 2, w / 2, dw /* unused by the gradient kernel, must be non-null */, cout};
+  const long long M = (long long)batch * (h / 2) * (w / 2);
+  const int ns = cvx_stem_wgrad_splits(M);
+  Scratch slabs, dsd, dbl;
+  CVX_TRY(slabs.alloc((size_t)ns * cout * 144 * 4));
+  CVX_TRY(cvx_stem_wgrad(sp, (const half_t*)dy_f16, (float*)slabs.p, ns, st));
+  // fold the split slabs with the engine's reducer: [Cout*9 rows][3 of 16 padded columns] -> dw [Cout][3][3][3]
+  SlabDesc sd{0, 0, ns, cout * 9, 3, 16, cvx_slab_lanes(ns)};
+  std::vector<BlockRef> blocks;
+  const long long total = (long long)sd.rows * sd.Cin;
+  for (long long s0 = 0; s0 < total; s0 += 256 / sd.lanes) blocks.push_back(BlockRef{0, (int)s0});
+  CVX_TRY(dsd.alloc(sizeof(sd)));
+  CVX_TRY(dbl.alloc(blocks.size() * sizeof(BlockRef)));
+  CVX_HIP(hipMemcpy(dsd.p, &sd, sizeof(sd), hipMemcpyHostToDevice));
+  CVX_HIP(hipMemcpy(dbl.p, blocks.data(), blocks.size() * sizeof(BlockRef), hipMemcpyHostToDevice));
+  CVX_HIP(hipMemsetAsync(dw, 0, (size_t)cout * 27 * 4, st));
+  CVX_TRY(cvx_reduce_slabs((const float*)slabs.p, dw, 1.0f, (const SlabDesc*)dsd.p, (const BlockRef*)dbl.p, (int)blocks.size(), st));
+  CVX_HIP(hipStreamSynchronize(st));
+  return 0;
+}

@@ -57,7 +57,13 @@ class Engine:
             pred = torch.empty(b, self.graph.anchors, no, device=images.device, dtype=torch.float32)
         self._use_current_stream()
         L.check(self.lib.cvx_engine_forward(self.handle, L.ptr(images), b, 1 if training else 0, L.ptr(pred)), "cvx_engine_forward")
+        # the fp32 stem reads the caller's tensor directly, and its weight gradient reads it again in the backward pass
+        self._images = images if training else None
         return pred
+
+    def plan_generation(self) -> int:
+        """Counts re-allocations of the per-batch buffers (a captured hipGraph is stale once this changes)."""
+        return int(self.lib.cvx_engine_plan_generation(self.handle))
 
     def _use_current_stream(self):
         """Enqueue on torch's current stream of this device (it may be a stream under hipGraph capture)."""
@@ -168,7 +174,18 @@ class V8LossOp:
         L.check(self.lib.cvx_loss_v8_strided(L.ptr(pred), ld, B, A, self.nc, L.ptr(targets) if n else C.c_void_p(0), n, cap, lv, st, nl,
                                              self.gains[0], self.gains[1], self.gains[2], float(loss_scale), L.ptr(items), L.ptr(dpred),
                                              L.ptr(self._ws), self._ws.numel(), L.stream_ptr(pred.device)), "cvx_loss_v8")
+        self._last_shape = (B, A, cap)
         return items, dpred
+
+    def assignment(self, B: int, A: int, n_targets: int):
+        """Per-anchor result of the task-aligned assigner of the LAST call: (target row index or -1, normalised target score)."""
+        assert self._ws is not None and self._last_shape == (B, A, max(n_targets, 1)), "call the loss first (same shapes)"
+        dev = self._ws.device
+        idx = torch.empty(B, A, dtype=torch.int32, device=dev)
+        norm = torch.empty(B, A, dtype=torch.float32, device=dev)
+        L.check(self.lib.cvx_loss_v8_assignment(L.ptr(self._ws), B, A, max(n_targets, 1), L.ptr(idx), L.ptr(norm), L.stream_ptr(dev)),
+                "cvx_loss_v8_assignment")
+        return idx.long(), norm
 
 
 def adam_step(params, grads, exp_avg, exp_avg_sq, lr, betas, eps, step, found_inf=None, zero_grad=True):

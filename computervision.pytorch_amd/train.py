@@ -22,13 +22,24 @@ from .model import PredList, Yolo8
 
 def flatten_targets(batch: Dict[str, torch.Tensor], device) -> torch.Tensor:
     """yolo8_collate dict (core/data/collate.py:25-29) -> (N, 6) [batch_idx, cls, cx, cy, w, h] on `device`,
-    grouped by image in stable order (what Loss.preprocess does row by row, yolo_v8.py:51-65)."""
-    bi = batch["batch_idx"].reshape(-1, 1).float()
-    if bi.numel() == 0:
+    grouped by image in stable order (what Loss.preprocess does row by row, yolo_v8.py:51-65).
+
+    Device-resident dicts go through ``cvx_pack_targets`` (one small HIP kernel, no ATen sort/index/cat on the hot path);
+    host dicts -- what a DataLoader hands over -- are ordered on the host and shipped with one copy."""
+    n = int(batch["batch_idx"].numel())
+    device = torch.device(device)
+    if n == 0:
         return torch.zeros(0, 6, device=device)
-    t = torch.cat((bi, batch["cls"].reshape(-1, 1).float(), batch["bboxes"].reshape(-1, 4).float()), 1).to(device)
+    bi, cls, box = batch["batch_idx"].reshape(-1), batch["cls"].reshape(-1), batch["bboxes"].reshape(-1, 4)
+    if bi.is_cuda and device.type == "cuda":
+        bi, cls, box = (t if t.dtype == torch.float32 and t.is_contiguous() else t.float().contiguous() for t in (bi, cls, box))
+        rows = torch.empty(n, 6, device=device)
+        lib = L.load()
+        L.check(lib.cvx_pack_targets(L.ptr(bi), L.ptr(cls), L.ptr(box), n, L.ptr(rows), L.stream_ptr(device)), "cvx_pack_targets")
+        return rows
+    t = torch.cat((bi.reshape(-1, 1).float().cpu(), cls.reshape(-1, 1).float().cpu(), box.float().cpu()), 1)
     order = torch.sort(t[:, 0], stable=True).indices
-    return t[order].contiguous()
+    return t[order].contiguous().to(device, non_blocking=True)
 
 
 class _LossFn(torch.autograd.Function):
@@ -104,26 +115,38 @@ class FlatAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None, zero_grad: bool = False, grad_scale: float = 1.0):
         self._ensure_state()
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_lr()               # a scheduler (or GradScaler.step -> optimizer.step) may have changed param_groups["lr"]
         g = self.param_groups[0]
-        self._step += 1
+        self._step += 1                  # host mirror only; the authoritative count lives in the device state
         adam_step_dev(self.model.flat_params, self.model.flat_grads, self._m, self._v, g["betas"], g["eps"], self._state, self.found_inf,
                       zero_grad, grad_scale)
 
     def zero_grad(self, set_to_none: bool = True):
         self.model.flat_grads.zero_()
 
+    def device_step(self) -> int:
+        """Steps actually applied: read from the device state (overflow-skipped steps and graph replays are counted there)."""
+        return self._step if self._state is None else int(self._state[1].item())
+
     def state_dict(self):
-        return {"step": self._step, "exp_avg": self._m, "exp_avg_sq": self._v, "param_groups": [
+        return {"step": self.device_step(), "exp_avg": self._m, "exp_avg_sq": self._v, "param_groups": [
             {k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
 
     def load_state_dict(self, sd):
+        for g, s in zip(self.param_groups, sd.get("param_groups", [])):
+            g.update(s)
         self._step = int(sd["step"])
         self._ensure_state()
+        # rebuild the device state unconditionally: [lr, step, -, -] (the derived factors are recomputed by the next step)
+        self._state.copy_(torch.tensor([self.param_groups[0]["lr"], float(self._step), 0.0, 0.0]))
+        self._lr_on_device = self.param_groups[0]["lr"]
         if sd.get("exp_avg") is not None:
             self._m.copy_(sd["exp_avg"])
             self._v.copy_(sd["exp_avg_sq"])
-        for g, s in zip(self.param_groups, sd.get("param_groups", [])):
-            g.update(s)
+        else:
+            self._m.zero_()
+            self._v.zero_()
 
 
 class DynamicLossScale:
@@ -139,6 +162,7 @@ class DynamicLossScale:
         self.scale = float(init_scale)
         self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, int(growth_interval)
         self.min_scale, self.max_scale = float(min_scale), float(max_scale)
+        self.device = torch.device(device)
         self.found_inf = torch.zeros(1, dtype=torch.int32, device=device)
         self._host = torch.zeros(1, dtype=torch.int32).pin_memory() if torch.device(device).type == "cuda" else torch.zeros(1, dtype=torch.int32)
         self._event = None
@@ -168,9 +192,10 @@ class DynamicLossScale:
     def end_step(self):
         """After the optimiser step was queued: ship the flag to the host without waiting for it."""
         if self._event is None:                      # one verdict in flight at a time
-            self._host.copy_(self.found_inf, non_blocking=True)
-            self._event = torch.cuda.Event()
-            self._event.record()
+            with torch.cuda.device(self.device):   # the copy and the event belong to the scaler's device, whatever is current
+                self._host.copy_(self.found_inf, non_blocking=True)
+                self._event = torch.cuda.Event()
+                self._event.record(torch.cuda.current_stream(self.device))
 
     def state_dict(self):
         return {"scale": self.scale, "good_steps": self._good}
@@ -218,10 +243,15 @@ class FusedTrainStep:
         a new (batch, size, target-count) signature is run eagerly once (plans workspaces) and then captured."""
         dev = self.model.flat_params.device
         n_t = int(batch["batch_idx"].numel())
-        key = (tuple(images.shape), n_t)
+        eng = self.model.engine_for(int(images.shape[2]), int(images.shape[3]))
+        # the graph holds raw engine buffer addresses: a re-plan (other batch size through the same engine, e.g. an eval
+        # pass or predict() between two train steps) bumps the engine's plan generation and invalidates it
+        key = (tuple(images.shape), n_t, id(eng), eng.plan_generation())
         self.optimizer.sync_lr()
         if key != self._graph_key:
+            self._graph = None
             items = self._eager(images, batch)               # warm-up: allocations, attribute opt-ins, first plan
+            key = key[:3] + (eng.plan_generation(),)         # the warm-up itself may have planned
             self._sx = images.detach().clone()
             self._sb = {k: v.detach().to(dev).clone() for k, v in batch.items()}
             torch.cuda.synchronize(dev)
@@ -235,7 +265,7 @@ class FusedTrainStep:
             self._sb[k].copy_(v, non_blocking=True)
         self._graph.replay()
         self.optimizer._step += 1
-        return self._sitems
+        return self._sitems.clone()                          # the static buffer is overwritten by the next replay
 
     def _eager(self, images: torch.Tensor, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         m, crit = self.model, self.criterion

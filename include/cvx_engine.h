@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define CVX_ABI_VERSION 2
+#define CVX_ABI_VERSION 3
 
 const char* cvx_last_error(void);
 int cvx_abi_version(void);
@@ -53,17 +53,15 @@ typedef struct {
   int64_t gamma_off, beta_off; /* BN affine (param arena) */
   int64_t bias_off;            /* CVX_ACT_BIAS */
   int64_t rmean_off, rvar_off; /* BN running statistics (stats arena) */
-  /* Execution lane: 0 = the main chain; 1..3 = independent tails of the op list (the three Detect levels) that the
-   * engine runs on their own HIP streams, forked after the last lane-0 op of the forward pass and joined before the
-   * caller's next work (backward: forked first, joined before the first lane-0 op).  Lane ops must follow all lane-0 ops. */
-  int32_t lane;
+  int32_t lane; /* reserved (ignored): independent tails on own HIP streams measured slower than one stream */
   int32_t reserved_;
 } cvx_op_desc;
 
 typedef struct cvx_engine cvx_engine;
 
-/* Builds an engine for a fixed input size.  `image_buf` is the index of the NHWC fp16 buffer
- * (c == 8, channels 3..7 zero) the engine fills from the caller's NCHW fp32 images.
+/* Builds an engine for a fixed input size.  `image_buf` is the index of the buffer-table entry (c == 8) that stands for
+ * the caller's NCHW fp32 images; exactly one op may read it: the 3 -> 16..80 channel 3x3 stride-2 BN+SiLU stem, which runs
+ * in fp32 straight from the caller's tensor (no fp16 copy of the image is made).
  * Replaces: Yolo8.__init__ graph construction, core/models/yolov8/yolo_v8.py:17-62. */
 int cvx_engine_create(cvx_engine** out, const cvx_buf_desc* bufs, int32_t nbufs, const cvx_op_desc* ops, int32_t nops,
                       int32_t image_buf, int32_t pred_buf, int32_t device, void* hip_stream);
@@ -79,9 +77,11 @@ int cvx_engine_set_stream(cvx_engine* e, void* hip_stream);
 /* BatchNorm hyper-parameters (core/models/yolov8/torch_utils.py:17-19: eps 1e-3, momentum 0.03). */
 int cvx_engine_set_bn(cvx_engine* e, float eps, float momentum);
 
-/* Forward pass.  images: (B,3,H,W) fp32 NCHW in [0,1]; pred: (B, A, no) fp32, anchors of the three
+/* Forward pass.  images: (B,3,H,W) fp32 NCHW in [0,1], 8-byte aligned; pred: (B, A, no) fp32, anchors of the three
  * levels concatenated (80x80, 40x40, 20x20 order), channels = [64 DFL logits | nc class logits].
- * training != 0: batch statistics + running-stat update, activations kept for backward.
+ * training != 0: batch statistics + running-stat update, activations kept for backward; `images` must stay valid and
+ * unchanged until the backward pass of this forward has been enqueued AND has finished (the stem's weight gradient
+ * reads it).
  * Replaces: Yolo8.forward, core/models/yolov8/yolo_v8.py:78-107 (+ Conv/C2f/SPPF/Detect in modules.py). */
 int cvx_engine_forward(cvx_engine* e, const float* images, int32_t batch, int32_t training, float* pred);
 
@@ -127,6 +127,10 @@ int cvx_debug_clock_buffer(void* buf);
 
 /* Bytes of device memory the engine currently owns (workspaces). */
 int64_t cvx_engine_workspace_bytes(const cvx_engine* e);
+/* Counts re-plans: a forward with a different batch size (or the first training forward after eval-only ones) frees and
+ * re-allocates every per-batch buffer.  A caller that captured launches into a hipGraph must drop the graph when this
+ * number changes -- the graph holds the old buffer addresses. */
+int64_t cvx_engine_plan_generation(const cvx_engine* e);
 
 /* Copies one level of pred into an NCHW fp32 tensor (B, no, H, W) -- the reference's output format
  * (core/models/yolov8/modules.py:431-433) -- and the inverse for incoming NCHW gradients. */
@@ -153,6 +157,15 @@ int cvx_loss_v8_strided(const float* pred, int32_t pred_ld, int32_t batch, int32
                         int32_t n_targets, int32_t max_targets_per_image, const int32_t* level_hw, const float* strides, int32_t n_levels,
                         float gain_box, float gain_cls, float gain_dfl, float loss_scale, float* loss_items, void* dpred_f16,
                         void* workspace, int64_t workspace_bytes, void* hip_stream);
+
+/* Per-anchor assignment of the last cvx_loss_v8* call made with this workspace and the same (batch, anchors,
+ * max_targets): index of the assigned target row (-1: background) and its normalised target score (device arrays of
+ * batch*anchors).  Replaces: reading TaskAlignedAssigner's target_gt_idx / fg_mask / target_scores, bboxes.py:330-345. */
+int cvx_loss_v8_assignment(const void* workspace, int32_t batch, int32_t anchors, int32_t max_targets_per_image, int32_t* gt_index,
+                           float* norm_score, void* hip_stream);
+/* yolo8_collate's dict (core/data/collate.py:25-29; fp32 device arrays batch_idx (n), cls (n), bboxes (n,4)) -> the
+ * (n,6) target rows cvx_loss_v8 reads, grouped by image in stable order.  Replaces: Loss.preprocess, yolo_v8.py:51-65. */
+int cvx_pack_targets(const float* batch_idx, const float* cls, const float* bboxes, int32_t n, float* rows, void* hip_stream);
 
 /* ---- optimiser ------------------------------------------------------------------------------------
  * torch.optim.Adam semantics (core/trainer/lr_scheduler.py:37-43): lr, betas, eps, no weight decay;
@@ -199,6 +212,40 @@ int64_t cvx_conv2d_wgrad_workspace_bytes(int32_t batch, int32_t oh, int32_t ow, 
 int cvx_conv2d_wgrad_nhwc(const void* x_f16, const void* dy_f16, int32_t batch, int32_t ih, int32_t iw, int32_t cin, int32_t cout,
                           int32_t k, int32_t stride, int32_t pad, int32_t dil, float* dw, void* workspace, int64_t workspace_bytes,
                           void* hip_stream);
+
+
+/* ---- streaming ops on dense NHWC fp16 tensors (the kernels the engine runs between the convolutions) ----------------
+ * Train-mode BatchNorm + SiLU.  y: raw conv output FP32 (B*hw, C); statistics are taken from it, running statistics
+ * updated (momentum, unbiased variance); out = silu(gamma*xhat+beta) (+res) fp16, xhat = (y-mean)*invstd fp16 (the
+ * operand of the backward op), mean / invstd (C) returned.  C multiple of 8, <= 1024.
+ * Replaces: Conv.forward's bn + act, core/models/yolov8/modules.py:29-30 (eps / momentum: torch_utils.py:17-19). */
+int cvx_bn_silu_train_nhwc(const float* y_f32, int32_t batch, int32_t hw, int32_t c, const float* gamma, const float* beta, float eps,
+                           float momentum, float* running_mean, float* running_var, const void* res_f16, void* out_f16, void* xhat_f16,
+                           float* mean, float* invstd, void* hip_stream);
+/* Its backward: dy (gradient w.r.t. the raw conv output) from gout (gradient w.r.t. out); dgamma / dbeta are ACCUMULATED
+ * (scaled by inv_scale); gres (optional) receives the residual branch's gradient = gout (+= when res_accumulate). */
+int cvx_bn_silu_bwd_nhwc(const void* xhat_f16, const void* gout_f16, int32_t batch, int32_t hw, int32_t c, const float* gamma,
+                         const float* beta, const float* invstd, float inv_scale, float* dgamma, float* dbeta, void* dy_f16, void* gres_f16,
+                         int32_t res_accumulate, void* hip_stream);
+/* 5x5 / stride 1 / pad 2 max pool (SPPF, core/models/yolov8/modules.py:312-318) and its backward; argmax (optional in
+ * the forward): one byte per element, the window tap 0..24 of the first maximum in row-major scan order. */
+int cvx_maxpool5_nhwc(const void* x_f16, int32_t batch, int32_t h, int32_t w, int32_t c, void* out_f16, uint8_t* argmax, void* hip_stream);
+int cvx_maxpool5_bwd_nhwc(const void* gout_f16, const uint8_t* argmax, int32_t batch, int32_t h, int32_t w, int32_t c, void* gin_f16,
+                          int32_t accumulate, void* hip_stream);
+/* nearest-neighbour x2 upsample (nn.Upsample(scale_factor=2), core/models/yolov8/yolo_v8.py:39,41) and its backward */
+int cvx_upsample2_nhwc(const void* x_f16, int32_t batch, int32_t h, int32_t w, int32_t c, void* out_f16, void* hip_stream);
+int cvx_upsample2_bwd_nhwc(const void* gout_f16, int32_t batch, int32_t h, int32_t w, int32_t c, void* gin_f16, int32_t accumulate,
+                           void* hip_stream);
+/* The stem (model.0: Conv(3, c, 3, 2), core/models/yolov8/yolo_v8.py:28) in fp32 from NCHW fp32 images: weight fp32
+ * [cout][kh][kw][ci]; train = batch statistics + running update, eval = folded scale / shift; wgrad: dw [cout][3][3][3]
+ * (overwritten) from dy fp16 (B, h/2, w/2, cout). */
+int cvx_stem_train_nchw(const float* images, int32_t batch, int32_t h, int32_t w, const float* weight, int32_t cout, const float* gamma,
+                        const float* beta, float eps, float momentum, float* running_mean, float* running_var, void* out_f16,
+                        void* xhat_f16, float* mean, float* invstd, void* hip_stream);
+int cvx_stem_eval_nchw(const float* images, int32_t batch, int32_t h, int32_t w, const float* weight, int32_t cout, const float* scale,
+                       const float* shift, void* out_f16, void* hip_stream);
+int cvx_stem_wgrad_nchw(const float* images, int32_t batch, int32_t h, int32_t w, const void* dy_f16, int32_t cout, float* dw,
+                        void* hip_stream);
 
 #ifdef __cplusplus
 }

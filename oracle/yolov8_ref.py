@@ -188,9 +188,10 @@ def trainable_keys(sd: Dict[str, torch.Tensor]) -> List[str]:
 # ----------------------------------------------------------------------------------------------
 # fp16-STORAGE emulation.  The reference's GPU path runs under torch.cuda.amp.autocast()
 # (core/trainer/yolo8_train.py:98-104): conv operands and activations are fp16, accumulation fp32.
-# With FP16_STORAGE[0] = True the oracle rounds exactly those tensors (weights, conv outputs, activations)
-# to fp16 and back, everything else stays fp32 -- this is what an fp16-storage engine must reproduce,
-# while the plain fp32 run is the reference's CPU path.  Casts are differentiable (straight-through).
+# With FP16_STORAGE[0] = True the oracle rounds exactly the tensors the MI355X engine rounds -- the weights of the MFMA
+# convolutions and every stored activation -- and nothing else: the stem (model.0) runs in fp32 from the fp32 image, and
+# the BatchNorm normalises the un-rounded fp32 conv output (the engine keeps it in fp32 until the normalisation pass).
+# The plain fp32 run is the reference's CPU path.  Casts are differentiable (straight-through).
 FP16_STORAGE = [False]
 
 
@@ -200,19 +201,10 @@ def _q(t: torch.Tensor) -> torch.Tensor:
 
 def _unit(x, sd, p, k, s, training):
     """Conv2d(no bias, 'same' pad) -> BatchNorm -> SiLU   (modules.py:29-30)."""
-    y = F.conv2d(x, _q(sd[p + ".conv.weight"]), None, s, k // 2)
-    if FP16_STORAGE[0] and training:
-        # batch statistics come from the fp32 accumulators, normalisation reads the fp16-rounded tensor
-        mean, var = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=False)
-        n = y.numel() / y.shape[1]
-        with torch.no_grad():
-            sd[p + ".bn.running_mean"].mul_(1 - BN_MOMENTUM).add_(mean.detach(), alpha=BN_MOMENTUM)
-            sd[p + ".bn.running_var"].mul_(1 - BN_MOMENTUM).add_(var.detach() * (n / max(n - 1, 1)), alpha=BN_MOMENTUM)
-        y = (_q(y) - mean[None, :, None, None]) * torch.rsqrt(var + BN_EPS)[None, :, None, None]
-        y = y * sd[p + ".bn.weight"][None, :, None, None] + sd[p + ".bn.bias"][None, :, None, None]
-    else:
-        y = F.batch_norm(y, sd[p + ".bn.running_mean"], sd[p + ".bn.running_var"], sd[p + ".bn.weight"],
-                         sd[p + ".bn.bias"], training, BN_MOMENTUM, BN_EPS)
+    w = sd[p + ".conv.weight"]
+    y = F.conv2d(x, w if p == "model.0" else _q(w), None, s, k // 2)
+    y = F.batch_norm(y, sd[p + ".bn.running_mean"], sd[p + ".bn.running_var"], sd[p + ".bn.weight"],
+                     sd[p + ".bn.bias"], training, BN_MOMENTUM, BN_EPS)
     if training:
         sd[p + ".bn.num_batches_tracked"] += 1
     return _q(F.silu(y))
@@ -272,7 +264,6 @@ def forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, model_type: str = "n",
     """
     a = arch(model_type, nc)
     saved = {}
-    x = _q(x)
     for idx, kind, kw in a["layers"]:
         p = f"model.{idx}"
         if kind == "conv":

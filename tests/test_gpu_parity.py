@@ -1,16 +1,17 @@
 """GPU (MI355X): the HIP path, called through the C ABI, against the CPU oracle and the golden fixtures.
 
 Tolerances (stated once, used below):
-* integer / index work (NMS kept indices, rows): bit-exact;
-* fp32 kernels given identical inputs (loss values, weight-gradient GEMM): 1e-5 relative;
+* integer / index work (NMS kept indices, rows, task-aligned assignment): bit-exact;
+* fp32 kernels given identical inputs (loss values, weight-gradient GEMM, fp32 stem): 1e-5 relative;
 * fp16-storage kernels given identical inputs: 5e-4 relative L2 (one fp16 rounding of the output);
-* whole-network forward vs the FP32 oracle: <= 2e-3 relative L2 on the head output.  The engine stores
-  weights / activations in fp16 like the reference's CUDA autocast path; the oracle run with the same three
-  tensors rounded to fp16 (``O.FP16_STORAGE``) must agree to <= 1.5e-3 (the two runs round at slightly different
-  points of the accumulation, and a flipped fp16 rounding propagates like the rounding itself); the fp32 number
-  is what fp16 storage costs on this 60-conv random-init network (~1e-3 at 640x640);
+* whole-network forward vs the reference's FP32 CPU outputs (fixtures captured from the reference itself):
+  **<= 1e-3 relative L2 per Detect level** -- the bar BASELINE.json's north_star states ("CPU-reference parity within 1e-3
+  rel on logits").  The engine stores MFMA weights and activations in fp16 like the reference's CUDA autocast path; the stem
+  runs in fp32 and every BatchNorm normalises the fp32 accumulators, which is what it took to get below the bar (DESIGN.md
+  section 2 has the ablation).  ``LEVEL_TOL`` below; the measured numbers are printed by the tests (pytest -s);
 * parameter gradients: backward kernels fed the oracle's d(loss)/d(pred): <= 6e-2 global relative L2 vs fp32 (the
-  fp16-storage emulation of the oracle itself deviates by ~4e-2); fully end to end (own loss, discrete assignment): <= 1.2e-1.
+  fp16-storage emulation of the oracle itself deviates by ~4e-2); fully end to end (own loss, discrete assignment): <= 1.2e-1;
+  per-layer activation gradients vs the fp16-storage emulation: see test_per_layer_backward_parity.
 """
 import numpy as np
 import pytest
@@ -31,9 +32,22 @@ def dev():
     return torch.device("cuda:0")
 
 
+LEVEL_TOL = 1e-3     # north_star: logits within 1e-3 rel of the reference's CPU path, per Detect level
+
+
 def rel(a, b):
     a, b = a.double().flatten().cpu(), b.double().flatten().cpu()
     return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def level_report(tag, outs, refs):
+    """rel-L2 per level (whole (B, 64+nc, H, W) tensor, and its box / class halves separately) -- printed, returned."""
+    r = [rel(o, t) for o, t in zip(outs, refs)]
+    rb = [rel(o[:, :64], t[:, :64]) for o, t in zip(outs, refs)]
+    rc = [rel(o[:, 64:], t[:, 64:]) for o, t in zip(outs, refs)]
+    print(f"[parity] {tag}: level rel-L2 " + " ".join(f"{v:.2e}" for v in r) + " | box " + " ".join(f"{v:.2e}" for v in rb) +
+          " | cls " + " ".join(f"{v:.2e}" for v in rc))
+    return r
 
 
 def new_model(dev, seed=0, scale="n"):
@@ -106,6 +120,154 @@ def test_conv_epilogues_affine_silu_and_bias(dev):
     assert rel(out32.permute(0, 3, 1, 2), conv + sh[None, :, None, None]) < 1e-5
 
 
+# ---- streaming kernels, one by one, vs plain torch fp32 --------------------------------------------------------------
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("B,H,W,C,res", [(2, 16, 16, 16, False), (3, 9, 7, 80, True), (1, 40, 40, 144, False), (2, 5, 5, 256, True),
+                                          (4, 20, 20, 64, True), (1, 3, 3, 640, False)])
+def test_bn_silu_train_and_backward_unit(dev, B, H, W, C, res):
+    """bn_silu_apply / bn_bwd_reduce / bn_bwd_apply (bn_act.hip) against torch autograd of
+    silu(batch_norm(y)) (+ residual) in fp32 (modules.py:29-30, 134-135)."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(B * 100 + C)
+    y = (torch.randn(B, C, H, W, generator=g) * (torch.rand(C, generator=g) * 3 + 0.2).view(1, C, 1, 1) + torch.randn(C, generator=g).view(1, C, 1, 1) * 2)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    r16 = torch.randn(B, C, H, W, generator=g).half()
+    gout16 = torch.randn(B, C, H, W, generator=g).half()
+    rm0, rv0 = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    # reference
+    yr, gr, br = y.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rr = r16.float().requires_grad_(True)
+    rm, rv = rm0.clone(), rv0.clone()
+    out = F.silu(F.batch_norm(yr, rm, rv, gr, br, True, 0.03, 1e-3))
+    if res:
+        out = out + rr
+    out.backward(gout16.float())
+    # engine kernels
+    st = L.stream_ptr(dev)
+    yd = _nhwc(y).to(dev)
+    gd, bd, rmd, rvd = gamma.to(dev), beta.to(dev), rm0.clone().to(dev), rv0.clone().to(dev)
+    resd = _nhwc(r16).to(dev) if res else None
+    outd = torch.empty(B, H, W, C, dtype=torch.float16, device=dev)
+    xh = torch.empty_like(outd)
+    mean, invstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    L.check(lib.cvx_bn_silu_train_nhwc(L.ptr(yd), B, H * W, C, L.ptr(gd), L.ptr(bd), 1e-3, 0.03, L.ptr(rmd), L.ptr(rvd), L.ptr(resd),
+                                       L.ptr(outd), L.ptr(xh), L.ptr(mean), L.ptr(invstd), st), "bn fwd")
+    assert rel(outd.float().permute(0, 3, 1, 2), out.detach()) < 5e-4
+    y64 = y.double()
+    n = y64.numel() / C
+    mu64, var64 = y64.mean((0, 2, 3)), y64.var((0, 2, 3), unbiased=False)
+    np.testing.assert_allclose(mean.cpu().numpy(), mu64.numpy(), rtol=1e-5, atol=1e-6)
+    # E[y^2] - E[y]^2 from fp32 block partial sums: the cases with |mean| ~ 30 sigma lose ~900 x 6e-8 of the variance
+    np.testing.assert_allclose(invstd.cpu().numpy(), (var64 + 1e-3).rsqrt().numpy(), rtol=1e-4)
+    # running statistics: momentum 0.03, unbiased variance (fp64 reference: torch's fp32 variance itself is off by ~3e-5)
+    np.testing.assert_allclose(rmd.cpu().numpy(), (0.97 * rm0.double() + 0.03 * mu64).numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rvd.cpu().numpy(), (0.97 * rv0.double() + 0.03 * var64 * n / (n - 1)).numpy(), rtol=1e-4, atol=1e-6)
+    xh_ref = (y - y.mean((0, 2, 3), keepdim=True)) * (y.var((0, 2, 3), unbiased=False, keepdim=True) + 1e-3).rsqrt()
+    assert rel(xh.float().permute(0, 3, 1, 2), xh_ref) < 5e-4
+    goutd = _nhwc(gout16).to(dev)
+    dgam, dbet = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    dy = torch.empty_like(outd)
+    gres = torch.full((B, H, W, C), 0.5, dtype=torch.float16, device=dev) if res else None
+    L.check(lib.cvx_bn_silu_bwd_nhwc(L.ptr(xh), L.ptr(goutd), B, H * W, C, L.ptr(gd), L.ptr(bd), L.ptr(invstd), 1.0, L.ptr(dgam), L.ptr(dbet),
+                                     L.ptr(dy), L.ptr(gres), 1, st), "bn bwd")
+    # dy is stored in fp16 and computed from the fp16 xhat: one rounding of the operand, one of the result
+    assert rel(dy.float().permute(0, 3, 1, 2), yr.grad) < 2e-3
+    assert rel(dgam, gr.grad) < 1e-3 and rel(dbet, br.grad) < 1e-3
+    if res:                                              # residual branch: gradient passes through, accumulated onto 0.5
+        assert rel(gres.float().permute(0, 3, 1, 2), rr.grad + 0.5) < 5e-4
+
+
+def test_bn_statistics_do_not_overflow_at_large_magnitudes(dev):
+    """Sums of squares far beyond the +-8.6e9 range of the first fixed-point format: pre-BN values
+    of magnitude 3e3 over 400k rows -> sum of squares ~4e12 per channel."""
+    lib = L.load()
+    B, H, W, C = 4, 320, 320, 16
+    g = torch.Generator().manual_seed(1)
+    y = torch.randn(B, H, W, C, generator=g) * 3000.0 + 500.0
+    yd = y.to(dev)
+    out, xh = torch.empty(B, H, W, C, dtype=torch.float16, device=dev), torch.empty(B, H, W, C, dtype=torch.float16, device=dev)
+    mean, invstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    ones, zeros = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    L.check(lib.cvx_bn_silu_train_nhwc(L.ptr(yd), B, H * W, C, L.ptr(ones), L.ptr(zeros), 1e-3, 0.03, L.ptr(rm), L.ptr(rv), None, L.ptr(out),
+                                       L.ptr(xh), L.ptr(mean), L.ptr(invstd), L.stream_ptr(dev)), "bn fwd")
+    y64 = y.double().reshape(-1, C)
+    np.testing.assert_allclose(mean.cpu().numpy(), y64.mean(0).numpy(), rtol=1e-5)
+    np.testing.assert_allclose(invstd.cpu().numpy(), (y64.var(0, unbiased=False) + 1e-3).rsqrt().numpy(), rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 20, 20, 128), (1, 5, 7, 8), (3, 4, 4, 256), (1, 33, 2, 16)])
+def test_maxpool5_and_upsample2_units(dev, B, H, W, C):
+    """SPPF's 5x5/s1/p2 max pool (modules.py:312-318) and nn.Upsample(x2, nearest) (yolo_v8.py:39), forward and backward,
+    against torch (exact: the ops only move fp16 values; ties resolved like torch's first-max scan)."""
+    lib = L.load()
+    st = L.stream_ptr(dev)
+    g = torch.Generator().manual_seed(H * W + C)
+    x16 = (torch.randint(-8, 9, (B, C, H, W), generator=g).float() / 4).half()     # many exact ties
+    go16 = torch.randn(B, C, H, W, generator=g).half()
+    xr = x16.float().requires_grad_(True)
+    ref = F.max_pool2d(xr, 5, 1, 2)
+    ref.backward(go16.float())
+    xd = _nhwc(x16).to(dev)
+    out = torch.empty_like(xd)
+    idx = torch.empty(B, H, W, C, dtype=torch.uint8, device=dev)
+    L.check(lib.cvx_maxpool5_nhwc(L.ptr(xd), B, H, W, C, L.ptr(out), L.ptr(idx), st), "pool")
+    assert torch.equal(out.float().permute(0, 3, 1, 2).cpu(), ref.detach())
+    gin = torch.empty_like(xd)
+    L.check(lib.cvx_maxpool5_bwd_nhwc(L.ptr(_nhwc(go16).to(dev)), L.ptr(idx), B, H, W, C, L.ptr(gin), 0, st), "pool bwd")
+    assert rel(gin.float().permute(0, 3, 1, 2), xr.grad) < 5e-4            # up to 25 fp16 terms summed in fp32, rounded once
+    # upsample
+    up = torch.empty(B, 2 * H, 2 * W, C, dtype=torch.float16, device=dev)
+    L.check(lib.cvx_upsample2_nhwc(L.ptr(xd), B, H, W, C, L.ptr(up), st), "up")
+    assert torch.equal(up.float().permute(0, 3, 1, 2).cpu(), F.interpolate(x16.float(), scale_factor=2.0, mode="nearest"))
+    gu16 = torch.randn(B, C, 2 * H, 2 * W, generator=g).half()
+    xr2 = x16.float().requires_grad_(True)
+    F.interpolate(xr2, scale_factor=2.0, mode="nearest").backward(gu16.float())
+    gin2 = torch.full((B, H, W, C), 1.0, dtype=torch.float16, device=dev)
+    L.check(lib.cvx_upsample2_bwd_nhwc(L.ptr(_nhwc(gu16).to(dev)), B, H, W, C, L.ptr(gin2), 1, st), "up bwd")
+    assert rel(gin2.float().permute(0, 3, 1, 2), xr2.grad + 1.0) < 5e-4
+
+
+@pytest.mark.parametrize("B,H,W,Co", [(2, 64, 64, 16), (1, 32, 96, 32), (3, 16, 16, 48), (1, 128, 128, 80)])
+def test_fp32_stem_unit(dev, B, H, W, Co):
+    """stem.hip (model.0 = Conv(3, c, 3, 2), yolo_v8.py:28) against torch fp32: train pass (batch statistics, running
+    update, xhat), eval pass (folded scale / shift) and the weight gradient."""
+    lib = L.load()
+    st = L.stream_ptr(dev)
+    g = torch.Generator().manual_seed(Co + H)
+    x = torch.rand(B, 3, H, W, generator=g)
+    w = (torch.rand(Co, 3, 3, 3, generator=g) - 0.5) * 0.4
+    gamma, beta = torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g) * 0.3
+    wr = w.clone().requires_grad_(True)
+    y = F.conv2d(x, wr, None, 2, 1)
+    rm, rv = torch.zeros(Co), torch.full((Co,), 0.9)
+    ref = F.silu(F.batch_norm(y, rm, rv, gamma, beta, True, 0.03, 1e-3))
+    xd, wd = x.to(dev), w.permute(0, 2, 3, 1).contiguous().to(dev)          # [cout][kh][kw][ci]
+    out = torch.empty(B, H // 2, W // 2, Co, dtype=torch.float16, device=dev)
+    xh = torch.empty_like(out)
+    mean, invstd = torch.empty(Co, device=dev), torch.empty(Co, device=dev)
+    rmd, rvd = torch.zeros(Co, device=dev), torch.full((Co,), 0.9, device=dev)
+    gd, bd = gamma.to(dev), beta.to(dev)
+    L.check(lib.cvx_stem_train_nchw(L.ptr(xd), B, H, W, L.ptr(wd), Co, L.ptr(gd), L.ptr(bd), 1e-3, 0.03, L.ptr(rmd), L.ptr(rvd), L.ptr(out),
+                                    L.ptr(xh), L.ptr(mean), L.ptr(invstd), st), "stem train")
+    assert rel(out.float().permute(0, 3, 1, 2), ref.detach()) < 5e-4          # one fp16 rounding of the stored activation
+    np.testing.assert_allclose(mean.cpu().numpy(), y.detach().mean((0, 2, 3)).numpy(), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(rmd.cpu().numpy(), rm.numpy(), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(rvd.cpu().numpy(), rv.numpy(), rtol=2e-5, atol=1e-6)
+    sc, sh = torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g)
+    scd, shd = sc.to(dev), sh.to(dev)
+    L.check(lib.cvx_stem_eval_nchw(L.ptr(xd), B, H, W, L.ptr(wd), Co, L.ptr(scd), L.ptr(shd), L.ptr(out), st), "stem eval")
+    assert rel(out.float().permute(0, 3, 1, 2), F.silu(y.detach() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))) < 5e-4
+    dy16 = torch.randn(B, Co, H // 2, W // 2, generator=g).half()
+    y.backward(dy16.float())
+    dw = torch.empty(Co, 3, 3, 3, device=dev)
+    L.check(lib.cvx_stem_wgrad_nchw(L.ptr(xd), B, H, W, L.ptr(_nhwc(dy16).to(dev)), Co, L.ptr(dw), st), "stem wgrad")
+    assert rel(dw.permute(0, 3, 1, 2), wr.grad) < 1e-5
+
+
 # ---- whole network -----------------------------------------------------------------------------------------
 def test_forward_matches_golden_and_oracle(dev, gold):
     g = gold("yolov8n_fwd_128.npz")
@@ -114,18 +276,18 @@ def test_forward_matches_golden_and_oracle(dev, gold):
     with torch.no_grad():
         outs = m(x.to(dev))
     assert [tuple(o.shape) for o in outs] == [(2, 144, 16, 16), (2, 144, 8, 8), (2, 144, 4, 4)]
-    for i, o in enumerate(outs):                                  # reference's own (fp32 CPU) outputs
-        assert rel(o, torch.from_numpy(g[f"train{i}"])) < 2e-3, i
+    r = level_report("128x128 fixture vs reference fp32", outs, [torch.from_numpy(g[f"train{i}"]) for i in range(3)])
+    assert max(r) < LEVEL_TOL, r                                  # the reference's own (fp32 CPU) outputs
     with fp16_storage():
         sd = O.init_state_dict("n", 80, seed=0)
         emu = O.forward(sd, x, "n", 80, training=True)
-    for i, o in enumerate(outs):                                  # same arithmetic, fp16 storage emulated
-        assert rel(o, emu[i].detach()) < 1.5e-3, i
+    r = level_report("128x128 fixture vs fp16-storage emulation", outs, [e.detach() for e in emu])
+    assert max(r) < LEVEL_TOL, r                                  # same arithmetic, rounding points emulated on the CPU
     # BN running statistics after one training forward (momentum 0.03, unbiased variance)
     for k in g.files:
         if k.startswith("bn:"):
-            # the stem's statistics see one fp16 rounding; the deepest head BN sees 30 layers of them
-            assert rel(m.state_dict()[k[3:]], torch.from_numpy(g[k])) < (2e-3 if "model.0." in k else 2e-2), k
+            # the stem runs in fp32 (statistics to fp32 round-off); the deepest head BN sees 30 layers of fp16 activations
+            assert rel(m.state_dict()[k[3:]], torch.from_numpy(g[k])) < (1e-5 if "model.0." in k else 2e-2), k
     assert int(m.state_dict()["model.0.bn.num_batches_tracked"]) == 2
     # eval mode: (y, feats); compare the head logits and the decoded output
     m.eval()
@@ -140,9 +302,11 @@ def test_forward_640_subsample(dev, gold):
     m = new_model(dev).train()
     with torch.no_grad():
         outs = m(synth.images(1, 640, 640, seed=1).to(dev))
+    r = level_report("640x640 sub-sample vs reference fp32", [o.flatten()[::97].reshape(1, -1, 1, 1) for o in outs],
+                     [torch.from_numpy(g[f"lvl{i}"]).reshape(1, -1, 1, 1) for i in range(3)])
     for i, o in enumerate(outs):
         ref = torch.from_numpy(g[f"lvl{i}"])
-        assert rel(o.flatten()[::97], ref) < 2e-3, i
+        assert rel(o.flatten()[::97], ref) < LEVEL_TOL, (i, r)
         assert abs(float(o.norm()) / float(g["norms"][i]) - 1) < 1e-3
 
 
@@ -151,10 +315,9 @@ def test_model_scale_s_runs_and_matches_oracle(dev):
     m = new_model(dev, scale="s").train()
     with torch.no_grad():
         outs = m(x.to(dev))
-    with fp16_storage():
-        ref = O.forward(O.init_state_dict("s", 80, seed=0), x, "s", 80, training=True)
-    for o, r in zip(outs, ref):
-        assert rel(o, r.detach()) < 2e-3
+    ref32 = O.forward(O.init_state_dict("s", 80, seed=0), x, "s", 80, training=True)
+    r = level_report("YOLOv8-s 128x128 vs oracle fp32", outs, [t.detach() for t in ref32])
+    assert max(r) < LEVEL_TOL, r
 
 
 def test_non_square_input_matches_oracle(dev):
@@ -164,10 +327,9 @@ def test_non_square_input_matches_oracle(dev):
     with torch.no_grad():
         outs = m(x.to(dev))
     assert [tuple(o.shape) for o in outs] == [(3, 144, 12, 20), (3, 144, 6, 10), (3, 144, 3, 5)]
-    with fp16_storage():
-        ref = O.forward(O.init_state_dict("n", 80, seed=0), x, "n", 80, training=True)
-    for o, r in zip(outs, ref):
-        assert rel(o, r.detach()) < 2e-3
+    ref32 = O.forward(O.init_state_dict("n", 80, seed=0), x, "n", 80, training=True)
+    r = level_report("96x160 vs oracle fp32", outs, [t.detach() for t in ref32])
+    assert max(r) < 1.3e-3, r          # 3 x 5 cells at stride 32: 45 samples per BatchNorm channel at the deepest level
     # and a fused training step on it stays finite (data / weight gradients at the same odd tile edges)
     from computervision.pytorch_amd.train import FlatAdam, FusedTrainStep, V8DetectionLoss
     from configs import Yolo8DetConfig
@@ -235,15 +397,65 @@ def test_loss_edge_cases(dev):
     np.testing.assert_allclose(it2.cpu().numpy(), it.cpu().numpy(), rtol=1e-6)
 
 
+def _logit(p):
+    return torch.log(p) - torch.log1p(-p)
+
+
 def test_assigner_fixture_through_the_loss(dev, gold):
-    """The reference-captured TAL fixture: feed logits whose sigmoid / DFL expectation reproduce its
-    scores and boxes, then check the loss the HIP path derives from its assignment equals the oracle's."""
+    """The reference-captured TaskAlignedAssigner case (tests/golden/tal_assign.npz: padded target rows, two heavily
+    overlapping targets -> anchors claimed twice) through the HIP loss: logits are built whose sigmoid / DFL expectation
+    reproduce the fixture's scores and boxes, then the per-anchor assignment of ``loss_v8.hip`` is read back and compared
+    with the reference's fg_mask / target_gt_idx BIT-EXACTLY, its normalised target scores and classes to fp32 round-off."""
+    g = gold("tal_assign.npz")
+    pd_scores, pd_bboxes, anc = (torch.from_numpy(g[k]) for k in ("pd_scores", "pd_bboxes", "anc"))
+    gt_labels, gt_bboxes = torch.from_numpy(g["gt_labels"]), torch.from_numpy(g["gt_bboxes"])
+    B, A, nc = pd_scores.shape
+    G = gt_bboxes.shape[1]
+    hw, strides = [(16, 16), (8, 8), (4, 4)], (8.0, 16.0, 32.0)
+    stride_t = torch.cat([torch.full((h * w,), s) for (h, w), s in zip(hw, strides)])
+    # DFL logits whose softmax expectation is the fixture's ltrb distance (two neighbouring bins carry the mass)
+    ltrb = torch.cat((anc[None] - pd_bboxes[..., :2], pd_bboxes[..., 2:] - anc[None]), -1) / stride_t[None, :, None]
+    assert float(ltrb.min()) >= 0 and float(ltrb.max()) < 15
+    lo = ltrb.floor()
+    frac = (ltrb - lo).double()
+    box = torch.full((B, A, 4, 16), -80.0, dtype=torch.float64)
+    box.scatter_(3, lo.long().unsqueeze(-1), torch.log1p(-frac).unsqueeze(-1).clamp_min(-80.0))
+    box.scatter_(3, (lo.long() + 1).unsqueeze(-1), torch.log(frac.clamp_min(1e-35)).unsqueeze(-1).clamp_min(-80.0))
+    pred = torch.cat((box.reshape(B, A, 64).float(), _logit(pd_scores.double()).float()), 2).contiguous()
+    # every fixture row as a target (zero rows included: the kernel must treat them like the reference's padding)
+    wh = 128.0
+    rows = []
+    for b in range(B):
+        for k in range(G):
+            x1, y1, x2, y2 = gt_bboxes[b, k].tolist()
+            rows.append([b, float(gt_labels[b, k, 0]), (x1 + x2) / 2 / wh, (y1 + y2) / 2 / wh, (x2 - x1) / wh, (y2 - y1) / wh])
+    targets = torch.tensor(rows, dtype=torch.float32, device=dev)
+    op = E.V8LossOp(nc)
+    op(pred.to(dev), targets, hw, strides, 1.0)
+    gt_index, norm = op.assignment(B, A, len(rows))
+    gt_index, norm = gt_index.cpu(), norm.cpu()
+    fg_ref, idx_ref = torch.from_numpy(g["fg"]), torch.from_numpy(g["gt_idx"])
+    fg = gt_index >= 0
+    assert torch.equal(fg, fg_ref), f"fg mask differs at {int((fg != fg_ref).sum())} anchors"
+    local = gt_index - torch.arange(B).view(B, 1) * G                 # target row -> index inside its image
+    assert torch.equal(local[fg], idx_ref[fg])
+    assert int(fg.sum()) > 20 and bool((idx_ref[fg_ref] < G).all())
+    np.testing.assert_allclose(norm[fg].numpy(), g["t_scores_sum"][fg_ref.numpy()], rtol=2e-5, atol=1e-7)
+    cls_of = gt_labels[..., 0].long()
+    assert torch.equal(cls_of.gather(1, local.clamp_min(0))[fg], torch.from_numpy(g["t_cls"])[fg])
+
+
+def test_pack_targets_kernel(dev):
+    """cvx_pack_targets == the host ordering (stable sort by image) of the yolo8_collate dict."""
     from computervision.pytorch_amd.train import flatten_targets
-    pred, batch, hw = _loss_case(2, 128, 11)
-    it_ref, _, aux = _oracle_loss(pred, batch, hw)
-    it, _ = E.V8LossOp(80)(pred.to(dev), flatten_targets(batch, dev), hw, (8, 16, 32), 1.0)
-    np.testing.assert_allclose(it.cpu().numpy(), it_ref.numpy(), rtol=2e-5)
-    assert int(aux["fg_mask"].sum()) > 10
+    gen = torch.Generator().manual_seed(3)
+    n = 777
+    batch = {"batch_idx": torch.randint(0, 9, (n,), generator=gen).float(), "cls": torch.randint(0, 80, (n, 1), generator=gen).float(),
+             "bboxes": torch.rand(n, 4, generator=gen)}
+    host = flatten_targets(batch, "cpu")
+    devd = flatten_targets({k: v.to(dev) for k, v in batch.items()}, dev)
+    assert torch.equal(devd.cpu(), host)
+    assert flatten_targets({"batch_idx": torch.zeros(0), "cls": torch.zeros(0, 1), "bboxes": torch.zeros(0, 4)}, dev).shape == (0, 6)
 
 
 # ---- full train step -----------------------------------------------------------------------------------------
