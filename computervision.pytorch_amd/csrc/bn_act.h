@@ -2,7 +2,11 @@
 #pragma once
 #include "cvx_common.h"
 #define CVX_BN_MAX_C 1024    // widest BatchNorm the streaming passes hold coefficients for (YOLOv8-m: 576, -x: 640)
-#define CVX_STAT_REPLICAS 16  // replica slabs the reduction kernels scatter their atomics over
+// Replica slabs the reduction kernels scatter their atomics over, by channel count.  Every consumer block folds all R
+// replicas of all C channels first, so R * C is held at ~512: 16 replicas up to 32 channels, 2 from 256 channels on (the
+// fold used to be 131 KB per block at 256 channels -- more than the block's share of the tensor on the 20x20 layers).
+__host__ __device__ constexpr int cvx_stat_replicas(int C) { return C <= 32 ? 16 : C <= 64 ? 8 : C <= 128 ? 4 : 2; }
+#define CVX_STAT_REPLICAS_MAX 16
 #define CVX_STAT_WORDS (2 * CVX_FIX_WORDS)  // 64-bit words per channel and replica: (value 0, value 1) x (coarse, fine)
 
 // fp16 NHWC channel-slice view: element (b, pix, c) at p[b*bstride + pix*ld + c]

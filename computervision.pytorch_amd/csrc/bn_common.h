@@ -15,7 +15,7 @@ __device__ __forceinline__ long long view_off(const ViewDesc& v, long long m, in
 // LDS bytes fold_replicas needs for C channels: [C][2 values][CVX_FIX_WORDS] 64-bit accumulators, reused for the result
 __host__ __device__ constexpr int fold_ws_bytes(int C) { return C * 2 * CVX_FIX_WORDS * 8; }
 
-// Sums the CVX_STAT_REPLICAS fixed-point slabs [R][C][2][CVX_FIX_WORDS] and leaves the two per-channel totals as doubles
+// Sums the cvx_stat_replicas(C) fixed-point slabs [R][C][2][CVX_FIX_WORDS] and leaves the two per-channel totals as doubles
 // in ws: value q of channel c at ((double*)ws)[q * C + c].  All 256 threads load slab entries in parallel (one round of
 // independent, coalesced 16-byte loads) and add them with INTEGER LDS atomics: exact and order-independent, and the
 // block pays one memory latency instead of R dependent ones.  Every thread of the 256-thread block must call it; it ends
@@ -24,7 +24,7 @@ __device__ __forceinline__ void fold_replicas(const long long* part, int C, long
   const int nacc = C * 2 * CVX_FIX_WORDS;
   for (int i = threadIdx.x; i < nacc; i += 256) ws[i] = 0;
   __syncthreads();
-  const int total = CVX_STAT_REPLICAS * C * 2;  // (replica, channel, value) entries of two 64-bit words (coarse, fine)
+  const int total = cvx_stat_replicas(C) * C * 2;  // (replica, channel, value) entries of two 64-bit words (coarse, fine)
   for (int e = threadIdx.x; e < total; e += 256) {
     const longlong2 q = *reinterpret_cast<const longlong2*>(part + (long long)e * CVX_FIX_WORDS);
     const int cv = e % (C * 2);  // channel * 2 + value
@@ -71,7 +71,7 @@ __device__ __forceinline__ void block_channel_sums(float (&v)[NV][8], int C, int
     for (int j = threadIdx.x; j < NV * C; j += 256) {
       const int c = j / NV, q = j - c * NV;
       const float acc = (sred[(0 * C + c) * NV + q] + sred[(1 * C + c) * NV + q]) + (sred[(2 * C + c) * NV + q] + sred[(3 * C + c) * NV + q]);
-      cvx_fix_atomic_add(part, ((long long)(blockIdx.x % CVX_STAT_REPLICAS) * C + c) * 2 + q, acc);
+      cvx_fix_atomic_add(part, ((long long)(blockIdx.x % cvx_stat_replicas(C)) * C + c) * 2 + q, acc);
     }
     return;
   }
@@ -89,7 +89,7 @@ __device__ __forceinline__ void block_channel_sums(float (&v)[NV][8], int C, int
     const int g = c >> 3, i = c & 7;
     float acc = 0.f;
     for (int r = 0; r < RP; ++r) acc += sred[(size_t)(r * CG + g) * (NV * 8) + q * 8 + i];
-    cvx_fix_atomic_add(part, ((long long)(blockIdx.x % CVX_STAT_REPLICAS) * C + c) * 2 + q, acc);
+    cvx_fix_atomic_add(part, ((long long)(blockIdx.x % cvx_stat_replicas(C)) * C + c) * 2 + q, acc);
   }
 }
 

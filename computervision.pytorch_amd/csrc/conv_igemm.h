@@ -4,6 +4,7 @@
 // `bstride` (both in elements), so channel slices of concat buffers are read and written in place.
 #pragma once
 #include "cvx_common.h"
+#include "bn_act.h"  // cvx_stat_replicas
 
 enum {
   CVX_EPI_RAW_STATS = 0,    // train fwd: raw conv output FP32 (out32) + per-channel (sum, sumsq) into the fixed-point replica slabs
@@ -80,7 +81,6 @@ inline bool cvx_halo_pack_taps(const ConvTap* t, int n, unsigned long long* pos,
   }
   return true;
 }
-#define CVX_STAT_REPLICAS 16
 
 // tuning aid: when set (cvx_debug_clock_buffer), the DMA-ring and halo kernels store per-block phase timestamps there
 extern unsigned long long* g_cvx_clk;

@@ -105,6 +105,8 @@ struct cvx_engine {
   long long* stat_region = nullptr;  // [fwd slabs | bwd slabs] of every conv op, zeroed once per pass
   long long stat_half = 0;           // entries per half
   hipStream_t side = nullptr;    // weight gradients run here, concurrently with the data-gradient chain
+  hipStream_t red = nullptr;     // gradient-slab reduction (whole-pass backward): off the main chain as well
+  hipEvent_t ev_red = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   float* ytmp = nullptr;              // raw fp32 conv output of the layer in flight (training forward), shared by all layers
   const float* last_images = nullptr;  // the caller's images of the last training forward (the stem's weight gradient reads them)
@@ -417,7 +419,7 @@ int plan_batch(cvx_engine* e, int B, bool training) {
       if (!c.stem) ytmp_elems = std::max(ytmp_elems, M * C);
     }
     c.stat_fwd = (long long*)nullptr + stat_floats;  // offset for now, rebased below
-    stat_floats += (long long)CVX_STAT_REPLICAS * C * CVX_STAT_WORDS;
+    stat_floats += (long long)cvx_stat_replicas(C) * C * CVX_STAT_WORDS;
     if (training) {
       int co_b, j_b;
       wgrad_tile(C, &co_b, &j_b);
@@ -566,7 +568,10 @@ extern "C" int cvx_engine_create(cvx_engine** out, const cvx_buf_desc* bufs, int
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     hipError_t side_rc = side_prio ? hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio_least)
                                    : hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
-    if (side_rc != hipSuccess ||
+    if (side_rc == hipSuccess)
+      side_rc = side_prio ? hipStreamCreateWithPriority(&e->red, hipStreamNonBlocking, prio_least)
+                          : hipStreamCreateWithFlags(&e->red, hipStreamNonBlocking);
+    if (side_rc != hipSuccess || hipEventCreateWithFlags(&e->ev_red, cvx_event_flags()) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_fork, cvx_event_flags()) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_join, cvx_event_flags()) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_mid, cvx_event_flags()) != hipSuccess) {
@@ -598,6 +603,11 @@ extern "C" int cvx_engine_destroy(cvx_engine* e) {
   }
   for (auto& c : e->conv)
     if (c.ev_dy) (void)hipEventDestroy(c.ev_dy);
+  if (e->red) {
+    (void)hipStreamSynchronize(e->red);
+    (void)hipStreamDestroy(e->red);
+  }
+  if (e->ev_red) (void)hipEventDestroy(e->ev_red);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->ev_mid) (void)hipEventDestroy(e->ev_mid);
@@ -730,7 +740,7 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
       cp.out_ld = C;
       cp.out_bstride = (long long)o.oh * o.ow * C;
       cp.stats = c.stat_fwd;
-      cp.stats_replicas = CVX_STAT_REPLICAS;
+      cp.stats_replicas = cvx_stat_replicas(C);
       int P = 0;
       {
         ProfScope ps(e, PROF_CONV_FWD, conv_flops(o, B), conv_bytes(o, B) + 2.0 * M * C, st);
@@ -984,18 +994,24 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
   double slab_bytes = 0;
   for (size_t i = 0; i < e->ops.size(); ++i)
     if (e->ops[i].type == CVX_OP_CONV) slab_bytes += 4.0 * e->conv[i].nsplit * e->ops[i].out.c * e->conv[i].ntaps * e->conv[i].cin_pad16;
+  // The slab reduction runs on a stream of its own, in two parts: everything but the first (tail) ops as soon as THEIR weight
+  // gradients are done -- concurrently with the end of the main chain and with the tail's weight gradients on the side
+  // stream -- then the tail.  The main stream only waits for the second part.
   const int tail = e->slab_tail_op >= 0 ? e->slab_tail_blocks : 0;
-  if (tail > 0) {  // part 1: all ops but the tail -- overlaps the tail's weight gradients still running on the side stream
-    CVX_HIP(hipStreamWaitEvent(st, e->ev_mid, 0));
-    ProfScope ps(e, PROF_SLAB_REDUCE, 0, slab_bytes + 8.0 * e->n_params);
-    CVX_TRY(cvx_reduce_slabs(e->slabs, e->grads, inv_scale, e->d_slab, e->d_slab_blocks + tail, e->n_slab_blocks - tail, st));
+  hipStream_t rs = e->red;
+  if (tail > 0) {
+    CVX_HIP(hipStreamWaitEvent(rs, e->ev_mid, 0));
+    ProfScope ps(e, PROF_SLAB_REDUCE, 0, slab_bytes + 8.0 * e->n_params, rs);
+    CVX_TRY(cvx_reduce_slabs(e->slabs, e->grads, inv_scale, e->d_slab, e->d_slab_blocks + tail, e->n_slab_blocks - tail, rs));
   }
-  CVX_HIP(hipEventRecord(e->ev_join, e->side));  // join: the (rest of the) slab reduction needs every weight-gradient slab
-  CVX_HIP(hipStreamWaitEvent(st, e->ev_join, 0));
+  CVX_HIP(hipEventRecord(e->ev_join, e->side));  // the (rest of the) slab reduction needs every weight-gradient slab
+  CVX_HIP(hipStreamWaitEvent(rs, e->ev_join, 0));
   {
-    ProfScope ps(e, PROF_SLAB_REDUCE, 0, tail > 0 ? 0.0 : slab_bytes + 8.0 * e->n_params);
-    CVX_TRY(cvx_reduce_slabs(e->slabs, e->grads, inv_scale, e->d_slab, e->d_slab_blocks, tail > 0 ? tail : e->n_slab_blocks, st));
+    ProfScope ps(e, PROF_SLAB_REDUCE, 0, tail > 0 ? 0.0 : slab_bytes + 8.0 * e->n_params, rs);
+    CVX_TRY(cvx_reduce_slabs(e->slabs, e->grads, inv_scale, e->d_slab, e->d_slab_blocks, tail > 0 ? tail : e->n_slab_blocks, rs));
   }
+  CVX_HIP(hipEventRecord(e->ev_red, rs));
+  CVX_HIP(hipStreamWaitEvent(st, e->ev_red, 0));
   return 0;
 }
 

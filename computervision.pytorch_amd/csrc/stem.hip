@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void stem_stats_kernel(const StemParams p, lon
     const int which = t / p.Cout, c = t - which * p.Cout;
     const float v = (sred[(0 * 2 + which) * p.Cout + c] + sred[(1 * 2 + which) * p.Cout + c]) +
                     (sred[(2 * 2 + which) * p.Cout + c] + sred[(3 * 2 + which) * p.Cout + c]);
-    cvx_fix_atomic_add(stats, ((long long)(blockIdx.x % CVX_STAT_REPLICAS) * p.Cout + c) * 2 + which, v);
+    cvx_fix_atomic_add(stats, ((long long)(blockIdx.x % cvx_stat_replicas(p.Cout)) * p.Cout + c) * 2 + which, v);
   }
 }
 
@@ -215,18 +215,30 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemParams p, lon
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int k = 0; k < KT; ++k) acc[c][k] = 0.f;
-  for (long long m = (long long)blockIdx.x * 64 + lane; m < M; m += (long long)gridDim.x * 64) {
-    asm volatile("" ::: "memory");  // keeps the compiler from hoisting all 27 x Cout LDS weights into registers (spills)
-    const PixelId id = pixel_of(p, m);
-    float x[KT];
-    load_window(p, id, x);
-    const h4 g = *reinterpret_cast<const h4*>(dy + m * p.Cout + co0);
+  // the loop is latency-bound (19 loads, then 108 FMAs per pixel): WG_UNR pixels per lane are in flight per trip
+  constexpr int WG_UNR = 3;
+  const long long stride = (long long)gridDim.x * 64;
+  for (long long m0 = (long long)blockIdx.x * 64 + lane; m0 < M; m0 += stride * WG_UNR) {
+    asm volatile("" ::: "memory");
+    float x[WG_UNR][KT];
+    h4 g[WG_UNR];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float gc = (float)g[c];
-#pragma unroll
-      for (int k = 0; k < KT; ++k) acc[c][k] = fmaf(gc, x[k], acc[c][k]);
+    for (int u = 0; u < WG_UNR; ++u) {
+      const long long m = m0 + u * stride;
+      const bool ok = m < M;
+      const long long mm = ok ? m : m0;  // clamped address, zero gradient: contributes nothing
+      load_window(p, pixel_of(p, mm), x[u]);
+      g[u] = *reinterpret_cast<const h4*>(dy + mm * p.Cout + co0);
+      if (!ok) g[u] = h4{(half_t)0, (half_t)0, (half_t)0, (half_t)0};
     }
+#pragma unroll
+    for (int u = 0; u < WG_UNR; ++u)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float gc = (float)g[u][c];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) acc[c][k] = fmaf(gc, x[u][k], acc[c][k]);
+      }
   }
   float* slab = slabs + (long long)blockIdx.x * p.Cout * 144;
 #pragma unroll

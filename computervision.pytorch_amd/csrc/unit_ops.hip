@@ -20,7 +20,7 @@ struct Scratch {  // RAII device allocation (zeroed)
     if (p) (void)hipFree(p);
   }
 };
-size_t slab_bytes(int C) { return (size_t)CVX_STAT_REPLICAS * C * CVX_STAT_WORDS * 8; }
+size_t slab_bytes(int C) { return (size_t)cvx_stat_replicas(C) * C * CVX_STAT_WORDS * 8; }
 ViewDesc dense(const void* p, int hw, int C) { return ViewDesc{(half_t*)p, (long long)hw * C, C}; }
 
 }  // namespace
