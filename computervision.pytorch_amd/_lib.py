@@ -82,6 +82,7 @@ PROTOTYPES = {
     "cvx_decode": (_I32, [_P, _I32, _I32, _I32, C.POINTER(_I32), C.POINTER(_F), _I32, _P, _P]),
     "cvx_nms_workspace_bytes": (_I64, [_I32, _I32]),
     "cvx_nms": (_I32, [_P, _I32, _I32, _I32, _F, _F, _I32, _P, _P, _P, _P, _I64, _P]),
+    "cvx_nms_variant": (_I32, [_P, _I32, _I32, _I32, _F, _F, _I32, _I32, _P, _P, _P, _P, _I64, _P]),
     "cvx_conv2d_nhwc": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P]),
     "cvx_conv2d_dgrad_nhwc": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "cvx_conv2d_wgrad_workspace_bytes": (_I64, [_I32, _I32, _I32, _I32, _I32, _I32]),

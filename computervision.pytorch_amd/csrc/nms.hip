@@ -3,10 +3,13 @@
 //   cvx_decode : pred (B,A,no) -> y (B,4+nc,A)                  core/models/yolov8/modules.py:434-446
 //   cvx_nms    : y -> kept rows + anchor indices                core/utils/ultralytics_ops.py:131-264
 //
-// NMS semantics are those of oracle/nms_ref.py (torchvision batched_nms restated): candidates with
-// best-class score > conf, ordered by (score desc, anchor index asc), greedy suppression inside a
-// class when inter/(area_i+area_j-inter) > iou_thres, evaluated in fp32 with the same operation order
-// (explicit round-to-nearest intrinsics: no FMA contraction), first max_det survivors.
+// NMS semantics are those of oracle/nms_ref.py (torchvision 0.14.1 batched_nms restated): candidates with
+// best-class score > conf, ordered by (score desc, anchor index asc), greedy suppression when
+// inter/(area_i+area_j-inter) > iou_thres, evaluated in fp32 with the same operation order (explicit
+// round-to-nearest intrinsics: no FMA contraction), first max_det survivors.  Both strategies of the library:
+// VANILLA (boxes interact inside a class only) and OFFSET (_batched_nms_coordinate_trick: every box shifted by
+// cls * (max coordinate + 1) in fp32, class-agnostic pass over the shifted, re-rounded boxes), plus the library's own
+// switch between them by candidate count.
 //
 // One workgroup per image: the (score,index) keys are sorted with an in-LDS bitonic network
 // (<= 16384 candidates = 128 KB of the CU's 160 KB LDS), the suppression matrix is built as 64-bit
@@ -78,6 +81,7 @@ __device__ __forceinline__ bool iou_gt(const float4& a, float area_a, const floa
 
 struct NmsWs {
   float4* box;              // [B][cap] sorted boxes (xyxy)
+  float4* boxs;             // [B][cap] the boxes the suppression test sees (class-shifted in OFFSET mode)
   float* score;             // [B][cap]
   int* cls;                 // [B][cap]
   int* aidx;                // [B][cap]
@@ -85,12 +89,13 @@ struct NmsWs {
 };
 
 __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* y, int A, int nc, float conf_thres, float iou_thres, int max_det, int cap,
-                                                          NmsWs ws, float* out_rows, int* out_index, int* counts) {
+                                                          int variant, NmsWs ws, float* out_rows, int* out_index, int* counts) {
   extern __shared__ unsigned long long keys[];  // cap2 entries (power of two >= candidates)
   __shared__ int s_n;
   __shared__ unsigned long long s_removed[NMS_CAP / 64];
   __shared__ int s_keep[1024];
   __shared__ int s_nkeep;
+  __shared__ float s_wmax[NMS_THREADS / 64];
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* yb = y + (long long)b * (4 + nc) * A;
   if (tid == 0) {
@@ -134,7 +139,11 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* y, int A,
     }
   }
   // ---- 3. gather sorted candidates ----
+  // torchvision 0.14.1 batched_nms: vanilla when boxes.numel() = 4 n exceeds 20000 (CUDA tensor) / 4000 (CPU tensor)
+  const bool offset_mode = variant == CVX_NMS_OFFSET || (variant == CVX_NMS_TV0141_CUDA && 4 * n <= 20000) ||
+                           (variant == CVX_NMS_TV0141_CPU && 4 * n <= 4000);
   float4* box = ws.box + (long long)b * cap;
+  float4* boxs = ws.boxs + (long long)b * cap;
   float* score = ws.score + (long long)b * cap;
   int* cls = ws.cls + (long long)b * cap;
   int* aidx = ws.aidx + (long long)b * cap;
@@ -157,6 +166,30 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* y, int A,
     aidx[i] = a;
   }
   __syncthreads();
+  // ---- 3b. the boxes the suppression test sees: shifted by cls * (boxes.max() + 1), fp32, in OFFSET mode ----
+  {
+    float m = -INFINITY;
+    if (offset_mode)
+      for (int i = tid; i < n; i += NMS_THREADS) {
+        const float4 bx = box[i];
+        m = fmaxf(fmaxf(m, fmaxf(bx.x, bx.y)), fmaxf(bx.z, bx.w));
+      }
+    m = cvx_wave_max64(m);
+    if ((tid & 63) == 0) s_wmax[tid >> 6] = m;
+    __syncthreads();
+    float mx = s_wmax[0];
+    for (int w = 1; w < NMS_THREADS / 64; ++w) mx = fmaxf(mx, s_wmax[w]);
+    const float unit = __fadd_rn(mx, 1.0f);
+    for (int i = tid; i < n; i += NMS_THREADS) {
+      float4 bx = box[i];
+      if (offset_mode) {
+        const float off = __fmul_rn((float)cls[i], unit);
+        bx = make_float4(__fadd_rn(bx.x, off), __fadd_rn(bx.y, off), __fadd_rn(bx.z, off), __fadd_rn(bx.w, off));
+      }
+      boxs[i] = bx;
+    }
+  }
+  __syncthreads();
   // ---- 4. suppression matrix: bit j of row i set when j > i, same class, IoU > thr ----
   const int nw = (n + 63) / 64;
   unsigned long long* mat = ws.mat + (long long)b * cap * (cap / 64);
@@ -164,13 +197,13 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* y, int A,
     int i = (int)(t / nw), wj = (int)(t - (long long)i * nw);
     unsigned long long bits = 0;
     if (wj * 64 + 63 > i) {
-      float4 bi = box[i];
+      float4 bi = boxs[i];
       float ai = __fmul_rn(__fsub_rn(bi.z, bi.x), __fsub_rn(bi.w, bi.y));
       int ci = cls[i];
       int j0 = max(wj * 64, i + 1), j1 = min(n, wj * 64 + 64);
       for (int j = j0; j < j1; ++j) {
-        if (cls[j] != ci) continue;
-        float4 bj = box[j];
+        if (!offset_mode && cls[j] != ci) continue;
+        float4 bj = boxs[j];
         float aj = __fmul_rn(__fsub_rn(bj.z, bj.x), __fsub_rn(bj.w, bj.y));
         if (iou_gt(bi, ai, bj, aj, iou_thres)) bits |= 1ull << (j - wj * 64);
       }
@@ -250,12 +283,20 @@ extern "C" int cvx_decode_strided(const float* pred, int32_t pred_ld, int32_t B,
 
 extern "C" int64_t cvx_nms_workspace_bytes(int32_t B, int32_t A) {
   long long cap = cap_for(A);
-  return al(B * cap * 16) + 3 * al(B * cap * 4) + al((long long)B * cap * (cap / 64) * 8) + 1024;
+  return 2 * al(B * cap * 16) + 3 * al(B * cap * 4) + al((long long)B * cap * (cap / 64) * 8) + 1024;
 }
 
 extern "C" int cvx_nms(const float* y, int32_t B, int32_t A, int32_t nc, float conf_thres, float iou_thres, int32_t max_det, float* out_rows,
                        int32_t* out_index, int32_t* counts, void* workspace, int64_t workspace_bytes, void* hip_stream) {
+  return cvx_nms_variant(y, B, A, nc, conf_thres, iou_thres, max_det, CVX_NMS_TV0141_CUDA, out_rows, out_index, counts, workspace,
+                         workspace_bytes, hip_stream);
+}
+
+extern "C" int cvx_nms_variant(const float* y, int32_t B, int32_t A, int32_t nc, float conf_thres, float iou_thres, int32_t max_det,
+                               int32_t variant, float* out_rows, int32_t* out_index, int32_t* counts, void* workspace,
+                               int64_t workspace_bytes, void* hip_stream) {
   CVX_CHECK(y && out_rows && out_index && counts && workspace, "null arguments");
+  CVX_CHECK(variant >= CVX_NMS_TV0141_CUDA && variant <= CVX_NMS_VANILLA, "unknown batched_nms variant");
   CVX_CHECK(conf_thres >= 0.f && conf_thres <= 1.f && iou_thres >= 0.f && iou_thres <= 1.f, "thresholds must lie in [0,1]");
   CVX_CHECK(max_det >= 1 && max_det <= 1024, "max_det must lie in [1,1024]");
   CVX_CHECK(A <= NMS_CAP, "cvx_nms: more than 16384 anchors per image is not supported by the in-LDS sort");
@@ -265,6 +306,8 @@ extern "C" int cvx_nms(const float* y, int32_t B, int32_t A, int32_t nc, float c
   NmsWs ws;
   long long off = 0;
   ws.box = (float4*)(base + off);
+  off += al(B * cap * 16);
+  ws.boxs = (float4*)(base + off);
   off += al(B * cap * 16);
   ws.score = (float*)(base + off);
   off += al(B * cap * 4);
@@ -279,7 +322,7 @@ extern "C" int cvx_nms(const float* y, int32_t B, int32_t A, int32_t nc, float c
     attr_set = true;
   }
   hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(NMS_THREADS), (size_t)cap * 8, (hipStream_t)hip_stream, y, A, nc, conf_thres, iou_thres, max_det,
-                     (int)cap, ws, out_rows, out_index, counts);
+                     (int)cap, (int)variant, ws, out_rows, out_index, counts);
   CVX_HIP(hipGetLastError());
   return 0;
 }

@@ -224,8 +224,13 @@ def decode(pred: torch.Tensor, nc: int, level_hw, strides) -> torch.Tensor:
 _nms_ws = {}
 
 
-def nms(y: torch.Tensor, conf_thres: float, iou_thres: float, max_det: int = 300):
-    """y (B, 4+nc, A) fp32 -> (rows (B,max_det,6), anchor_index (B,max_det) int32, counts (B,) int32), all on device."""
+NMS_VARIANTS = {"tv0141_cuda": 0, "tv0141_cpu": 1, "offset": 2, "vanilla": 3}
+
+
+def nms(y: torch.Tensor, conf_thres: float, iou_thres: float, max_det: int = 300, variant: str = "tv0141_cuda"):
+    """y (B, 4+nc, A) fp32 -> (rows (B,max_det,6), anchor_index (B,max_det) int32, counts (B,) int32), all on device.
+    ``variant``: torchvision 0.14.1 ``batched_nms`` strategy (include/cvx_engine.h); the default is the library's own
+    switch for CUDA tensors, i.e. what the reference's GPU predict path runs."""
     lib = L.load()
     _need_gpu(y, "y")
     if not (0 <= conf_thres <= 1 and 0 <= iou_thres <= 1):
@@ -240,6 +245,6 @@ def nms(y: torch.Tensor, conf_thres: float, iou_thres: float, max_det: int = 300
     rows = torch.zeros(B, max_det, 6, dtype=torch.float32, device=y.device)
     index = torch.zeros(B, max_det, dtype=torch.int32, device=y.device)
     counts = torch.zeros(B, dtype=torch.int32, device=y.device)
-    L.check(lib.cvx_nms(L.ptr(y), B, A, nc, conf_thres, iou_thres, max_det, L.ptr(rows), L.ptr(index), L.ptr(counts), L.ptr(ws), ws.numel(),
-                        L.stream_ptr(y.device)), "cvx_nms")
+    L.check(lib.cvx_nms_variant(L.ptr(y), B, A, nc, conf_thres, iou_thres, max_det, NMS_VARIANTS[variant], L.ptr(rows), L.ptr(index),
+                                L.ptr(counts), L.ptr(ws), ws.numel(), L.stream_ptr(y.device)), "cvx_nms")
     return rows, index, counts

@@ -139,6 +139,21 @@ class ParamLayout:
             c0 += co
         return spec
 
+    # -- reference-keyed dicts <-> flat arenas (checkpoints, tests) ------------------------------------
+    def views(self, arena, which: str = "param"):
+        """{state_dict key: strided view of `arena`} for the slots of one arena ("param" or "stat")."""
+        import torch
+        return {k: torch.as_strided(arena, sl.shape, sl.strides, sl.offset) for k, sl in self.slots.items() if sl.arena == which}
+
+    def scatter(self, tensors, which: str = "param"):
+        """Flat arena (zero padding) holding `tensors` (reference keys, logical shapes) in the engine's layout."""
+        import torch
+        arena = torch.zeros(self.n_params if which == "param" else self.n_stats)
+        for k, v in self.views(arena, which).items():
+            if k in tensors:
+                v.copy_(tensors[k])
+        return arena
+
     def _plan(self):
         A = self._add_conv
         c64, c128, c256, c512, c1024 = self.c64, self.c128, self.c256, self.c512, self.c1024

@@ -39,3 +39,25 @@ def nms_pred(seed: int = 7, b: int = 2, a: int = 8400, nc: int = 80, hot: int = 
         idx = rng.choice(a, hot, replace=False)
         pred[i, 4 + rng.integers(0, 6, hot), idx] = np.round(rng.uniform(0.2, 0.95, hot), 2)
     return pred
+
+
+def nms_pred_borderline(seed: int = 3, a: int = 2048, nc: int = 80, pairs: int = 600, iou: float = 0.7) -> np.ndarray:
+    """(1, 4+nc, A) predictions made of box PAIRS whose IoU sits within ~1e-6 of ``iou`` (the second box is the first one
+    shifted along x by w * (1 - iou) / (1 + iou), plus sub-pixel jitter), all in high class indices: the case where
+    torchvision's coordinate-offset ``batched_nms`` (boxes re-rounded after adding cls * (max + 1)) and its per-class
+    variant can disagree."""
+    rng = np.random.default_rng(seed)
+    pred = np.zeros((1, 4 + nc, a), np.float32)
+    pred[0, 2:4] = 1.0
+    pred[0, 4:] = rng.uniform(0, 0.05, (nc, a))
+    slots = rng.choice(a // 2, pairs, replace=False) * 2
+    for k, s0 in enumerate(slots):
+        w, h = rng.uniform(40, 160, 2)
+        cx, cy = rng.uniform(100, 540, 2)
+        dx = w * (1 - iou) / (1 + iou) + rng.uniform(-2e-4, 2e-4)
+        c = int(rng.integers(nc // 2, nc))
+        s = float(np.round(rng.uniform(0.3, 0.9), 3))
+        for j, (x, sc) in enumerate(((cx, s), (cx + dx, s - 0.01))):
+            pred[0, 0:4, s0 + j] = (x, cy, w, h)
+            pred[0, 4 + c, s0 + j] = sc
+    return pred

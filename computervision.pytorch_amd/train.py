@@ -297,7 +297,6 @@ class FusedTrainStep:
         """Backward in `n_buckets` op ranges (head first).  As soon as a range's gradients are final, its slice of the flat
         gradient arena is SUM-all-reduced (RCCL) on a side HIP stream while the main stream runs the next range; the mean's
         1/world is folded into the Adam kernel.  BASELINE.json north_star: exchange overlapped with the backward pass."""
-        import torch.distributed as dist
         m = self.model
         g = m.flat_grads
         if self._side is None:
@@ -309,19 +308,42 @@ class FusedTrainStep:
             self._buckets = eng.grad_buckets(m.layout, self.n_buckets)
             self._buckets_key = key
         cur = torch.cuda.current_stream(g.device)
-        eng.backward_begin(dpred, loss_scale)
-        for op_hi, op_lo, p0, p1 in self._buckets:
-            eng.backward_range(op_hi, op_lo)
-            eng.grads_ready(op_hi, op_lo, self._side)          # side stream: waits for the range, folds its slabs
-            with torch.cuda.stream(self._side):
-                dist.all_reduce(g[p0:p1], group=self.pg)       # ordered after the fold on the same stream
-        eng.backward_end()
+        backward_with_overlapped_exchange(eng, self._buckets, g, dpred, loss_scale, self.pg, self._side)
         cur.wait_stream(self._side)
 
     def _allreduce(self, g: torch.Tensor):
         if self._side is None and g.is_cuda:
             self._side = torch.cuda.Stream(device=g.device)
         allreduce_mean_flat(g, self.world, self.pg, self.n_buckets, self._side, average=False)
+
+
+def backward_with_overlapped_exchange(eng, buckets, g: torch.Tensor, dpred, loss_scale: float, group=None, side_stream=None):
+    """The bucket loop of the data-parallel step, engine-agnostic: ``eng`` provides the segmented backward of
+    include/cvx_engine.h (``backward_begin / backward_range(op_hi, op_lo) / grads_ready(op_hi, op_lo, stream) / backward_end``),
+    ``buckets`` = ``graph.grad_buckets`` = op ranges in backward order with their contiguous slice [p0, p1) of the flat
+    gradient arena ``g``.  Each slice is SUM-all-reduced as soon as its range has run -- on ``side_stream`` (HIP: RCCL,
+    overlapping the next range on the current stream) or inline (CPU tensors: the gloo tests drive exactly this loop with a
+    fake engine).  The caller folds the mean's 1/world into the optimiser step."""
+    import torch.distributed as dist
+    eng.backward_begin(dpred, loss_scale)
+    for op_hi, op_lo, p0, p1 in buckets:
+        eng.backward_range(op_hi, op_lo)
+        eng.grads_ready(op_hi, op_lo, side_stream)               # side stream: waits for the range, folds its slabs
+        if side_stream is not None:
+            with torch.cuda.stream(side_stream):
+                dist.all_reduce(g[p0:p1], group=group)            # ordered after the fold on the same stream
+        else:
+            dist.all_reduce(g[p0:p1], group=group)
+    eng.backward_end()
+
+
+def broadcast_bn_statistics(model: Yolo8, group=None, src: int = 0):
+    """BatchNorm running statistics are per rank (the reference has no SyncBN) and drift apart; before a checkpoint is
+    written every rank takes rank ``src``'s, so that a resumed job starts from ONE consistent model."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(model.flat_stats, src=src, group=group)
+        dist.broadcast(model._flat["nbt"], src=src, group=group)
 
 
 def bucket_bounds(n: int, n_buckets: int):

@@ -185,7 +185,7 @@ int cvx_adam_step_dev(float* params, float* grads, float* exp_avg, float* exp_av
  * cvx_decode: pred (B,A,no) -> y (B, 4+nc, A) fp32 [cx,cy,w,h (pixels), class scores]
  *   Replaces: Detect eval branch, core/models/yolov8/modules.py:434-446.
  * cvx_nms: y -> per image up to max_det rows [x1,y1,x2,y2,conf,cls] + the anchor index of each row;
- *   counts[b] = rows kept.  Semantics = oracle/nms_ref.py (torchvision batched_nms restated).
+ *   counts[b] = rows kept.  Semantics = oracle/nms_ref.py (torchvision 0.14.1 batched_nms restated, both strategies).
  *   Replaces: non_max_suppression, core/utils/ultralytics_ops.py:131-264. */
 int cvx_decode(const float* pred, int32_t batch, int32_t anchors, int32_t nc, const int32_t* level_hw, const float* strides,
                int32_t n_levels, float* y, void* hip_stream);
@@ -193,9 +193,18 @@ int cvx_decode(const float* pred, int32_t batch, int32_t anchors, int32_t nc, co
  * class columns padded to the next multiple of 8; the padding is never read. */
 int cvx_decode_strided(const float* pred, int32_t pred_ld, int32_t batch, int32_t anchors, int32_t nc, const int32_t* level_hw,
                        const float* strides, int32_t n_levels, float* y, void* hip_stream);
+enum { CVX_NMS_TV0141_CUDA = 0, /* torchvision 0.14.1's own switch for CUDA tensors: coordinate trick up to 5000 candidates */
+       CVX_NMS_TV0141_CPU = 1,  /* ... for CPU tensors: up to 1000 candidates */
+       CVX_NMS_OFFSET = 2,      /* _batched_nms_coordinate_trick: boxes + cls*(max+1), one class-agnostic pass */
+       CVX_NMS_VANILLA = 3 };   /* _batched_nms_vanilla: per-class passes on the unshifted boxes */
 int64_t cvx_nms_workspace_bytes(int32_t batch, int32_t anchors);
 int cvx_nms(const float* y, int32_t batch, int32_t anchors, int32_t nc, float conf_thres, float iou_thres, int32_t max_det,
             float* out_rows, int32_t* out_index, int32_t* counts, void* workspace, int64_t workspace_bytes, void* hip_stream);
+/* cvx_nms = cvx_nms_variant(CVX_NMS_TV0141_CUDA): what the reference's GPU predict path executes through
+ * torchvision.ops.batched_nms (core/utils/ultralytics_ops.py:247). */
+int cvx_nms_variant(const float* y, int32_t batch, int32_t anchors, int32_t nc, float conf_thres, float iou_thres, int32_t max_det,
+                    int32_t variant, float* out_rows, int32_t* out_index, int32_t* counts, void* workspace, int64_t workspace_bytes,
+                    void* hip_stream);
 
 /* ---- single-op entry points (unit tests and other model families reuse them) -----------------------
  * NHWC fp16 convolution, weights [cout][kh][kw][cin] fp16.  mode 0: out fp16 = conv; mode 1: out fp16 =

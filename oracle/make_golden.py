@@ -223,6 +223,84 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "yolov8n_fwd_640_sub.npz"), norms=norms, **sub)
     report["forward640"] = "allclose; norms " + str(norms.tolist())
 
+    # ---- 7. data-parallel simulation: the REFERENCE run shard by shard, gradients averaged ----------
+    # N ranks = N sequential shards of one global batch with identical weights; every shard normalises its loss by its
+    # own target_scores_sum and batch size (core/algorithms/yolo_v8.py:109,124) and uses its own BN batch statistics; the
+    # exchange must deliver the MEAN over shards of the per-shard gradients (not the single-process full-batch gradient).
+    g = torch.Generator().manual_seed(21)
+    xg = torch.rand(8, 3, 96, 96, generator=g)
+    bg = synth.targets(8, seed=22)
+    dp = {"x": xg.numpy(), "batch_idx": bg["batch_idx"].numpy(), "cls": bg["cls"].numpy(), "bboxes": bg["bboxes"].numpy()}
+    keys = O.trainable_keys(O.init_state_dict("n", 80, seed=0))
+    probe = ("model.0.conv.weight", "model.9.cv2.bn.weight", "model.15.cv2.conv.weight", "model.22.cv2.0.2.weight", "model.22.cv3.0.2.bias")
+    for world in (1, 2, 4, 8):
+        per = 8 // world
+        acc = None
+        for r in range(world):
+            torch.manual_seed(0)
+            cfg, algo_cls, _ = builder.export_from_registry("yolo8_det")
+            algo = algo_cls(cfg, torch.device("cpu"))
+            model, _ = algo.build_model()
+            crit = algo.build_loss(model)
+            model.train()
+            sel = (bg["batch_idx"] >= r * per) & (bg["batch_idx"] < (r + 1) * per)
+            sb = {"batch_idx": bg["batch_idx"][sel] - r * per, "cls": bg["cls"][sel], "bboxes": bg["bboxes"][sel]}
+            loss, _ = crit(model(xg[r * per:(r + 1) * per].clone()), sb)
+            loss.backward()
+            named = dict(model.named_parameters())
+            gr = {k: (named[k].grad.detach().clone() if named[k].grad is not None else torch.zeros_like(named[k])) for k in keys}
+            # the oracle must give the same shard gradients (it is what the CPU gloo test of the exchange runs per rank)
+            mine = O.train_step(O.init_state_dict("n", 80, seed=0), xg[r * per:(r + 1) * per].clone(), sb, {})[2]
+            for k in keys:
+                assert float((gr[k] - mine[k]).norm() / (gr[k].norm() + 1e-12)) < 2e-4, (world, r, k)
+            acc = gr if acc is None else {k: acc[k] + gr[k] for k in keys}
+        mean = {k: acc[k] / world for k in keys}
+        flat = torch.cat([mean[k].flatten() for k in keys])
+        dp[f"w{world}_norm"] = np.array(float(flat.norm()))
+        dp[f"w{world}_sub"] = flat[::211].numpy().copy()
+        for k in probe:
+            dp[f"w{world}:{k}"] = mean[k].numpy().copy()
+    dp["keys"] = np.array(keys)
+    np.savez_compressed(os.path.join(GOLD, "dp_sim_96.npz"), **dp)
+    report["dp_sim"] = {f"world{w}": float(dp[f"w{w}_norm"]) for w in (1, 2, 4, 8)}
+
+    # ---- 8. YOLOv8-s (BASELINE config 3's per-rank model): init sums, train forward, loss, gradient norms -------------
+    torch.manual_seed(0)
+    cfg, algo_cls, _ = builder.export_from_registry("yolo8_det")
+    cfg.arch.model_type = "s"
+    algo = algo_cls(cfg, torch.device("cpu"))
+    model, _ = algo.build_model()
+    crit = algo.build_loss(model)
+    s_sd = O.init_state_dict("s", 80, seed=0)
+    ref_sd = model.state_dict()
+    assert list(ref_sd.keys()) == list(s_sd.keys())
+    for k in ref_sd:
+        assert torch.equal(ref_sd[k], s_sd[k]), f"YOLOv8-s init mismatch {k}"
+    g = torch.Generator().manual_seed(31)
+    xs = torch.rand(2, 3, 160, 160, generator=g)
+    bs_ = synth.targets(2, seed=32)
+    model.train()
+    preds = model(xs.clone())
+    loss, items = crit(preds, {k: v.clone() for k, v in bs_.items()})
+    loss.backward()
+    named = dict(model.named_parameters())
+    skeys = O.trainable_keys(s_sd)
+    my_loss, my_items, my_grads, my_feats = O.train_step(s_sd, xs.clone(), bs_, {}, "s", 80, 1e-3)
+    assert torch.allclose(loss.detach(), my_loss, rtol=1e-5)
+    for r_, m_ in zip(preds, my_feats):
+        assert torch.allclose(r_, m_.detach(), rtol=1e-5, atol=1e-5)
+    for k in skeys:
+        if named[k].grad is not None:
+            assert float((named[k].grad - my_grads[k]).norm() / (named[k].grad.norm() + 1e-12)) < 2e-4, k
+    np.savez_compressed(
+        os.path.join(GOLD, "yolov8s_train_160.npz"), x=xs.numpy(), batch_idx=bs_["batch_idx"].numpy(), cls=bs_["cls"].numpy(),
+        bboxes=bs_["bboxes"].numpy(), train0=preds[0].detach().numpy(), train1=preds[1].detach().numpy(), train2=preds[2].detach().numpy(),
+        loss=np.array(float(loss)), items=items.numpy().copy(), keys=np.array(skeys),
+        grad_norms=np.array([float(named[k].grad.norm()) if named[k].grad is not None else 0.0 for k in skeys]),
+        g_headb=named["model.22.cv3.0.2.bias"].grad.numpy().copy(), g_stem=named["model.0.conv.weight"].grad.numpy().copy(),
+        n_params=np.array(sum(p_.numel() for p_ in model.parameters())))
+    report["yolov8s"] = dict(loss=float(loss), params=int(sum(p_.numel() for p_ in model.parameters())))
+
     # ---- 6. NMS tail fixture (oracle-generated; upstream parity unpinned) ----------------------
     pred = synth.nms_pred(7)
     res = nms_ref.non_max_suppression(pred, 0.25, 0.7, 300)

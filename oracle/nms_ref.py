@@ -5,16 +5,22 @@ PARITY UNPINNED UPSTREAM: the suppression arithmetic of the reference lives in
 dependency that is neither vendored under /root/reference nor installed in this image (README.md:8
 names torchvision 0.14.1; requirements.txt leaves it unpinned) and the reference holds no test or
 golden vector at that boundary.  This file therefore *restates* torchvision-0.14.1's published
-algorithm and is itself the bit-exact reference for the HIP NMS indices:
+algorithm (torchvision/ops/boxes.py ``batched_nms`` + csrc/ops/{cpu,cuda}/nms_kernel) and is itself
+the bit-exact reference for the HIP NMS indices.  Both strategies of 0.14.1 are restated:
 
-* candidates sorted by score, descending; ties broken by the lower original anchor index
-  (``torch.argsort(descending=True)`` at ultralytics_ops.py:240 is unstable, so the reference leaves
-  tie order undefined -- we define it);
-* greedy: walk the sorted list, keep a box unless an earlier kept box OF THE SAME CLASS has
-  ``inter / (area_i + area_j - inter) > iou_thres`` (fp32, evaluated in exactly this operation order;
-  torchvision csrc/ops/cpu/nms_kernel.cpp); this is ``_batched_nms_vanilla`` semantics -- the
-  coordinate-offset variant differs only by fp32 rounding of the shifted coordinates;
-* kept boxes returned in descending-score order, truncated to ``max_det``.
+* ``offset``  = ``_batched_nms_coordinate_trick``: every box is shifted by ``cls * (boxes.max() + 1)`` (fp32) and ONE
+  class-agnostic greedy pass runs over the shifted boxes -- areas and intersections are computed from the shifted,
+  re-rounded coordinates, which can flip a borderline ``IoU > thr``;
+* ``vanilla`` = ``_batched_nms_vanilla``: one greedy pass per class on the unshifted boxes, survivors re-sorted by score;
+* ``tv0141_cuda`` / ``tv0141_cpu`` = the library's own switch: vanilla when ``boxes.numel()`` exceeds 20000 (CUDA tensors,
+  i.e. more than 5000 boxes -- the reference's predict path keeps the tensor on the GPU) or 4000 (CPU), else the
+  coordinate trick.  With conf 0.25 an image has a few hundred candidates: 0.14.1 takes the OFFSET path there.
+
+Common to both: candidates sorted by score, descending; ties broken by the lower original anchor index
+(``torch.argsort(descending=True)`` at ultralytics_ops.py:240 and the sort inside ``nms`` are unstable, so the reference
+leaves tie order undefined -- we define it); a box is suppressed when ``inter / (area_i + area_j - inter) > iou_thres``
+evaluated in fp32 in exactly this operation order; kept boxes are returned in descending-score order, truncated to
+``max_det``.
 
 Everything around that call is reference Python (ultralytics_ops.py:131-264, 360-375;
 core/algorithms/yolo_v8.py:210-242; core/utils/image_process.py:69-97) and is restated line by
@@ -32,8 +38,9 @@ def xywh2xyxy(b: np.ndarray) -> np.ndarray:
     return np.concatenate((b[..., 0:2] - half, b[..., 0:2] + half), -1)
 
 
-def greedy_nms_per_class(boxes: np.ndarray, cls: np.ndarray, iou_thres: float) -> np.ndarray:
-    """boxes (n,4) xyxy fp32 already in descending-score order -> kept positions (ascending)."""
+def _greedy(boxes: np.ndarray, same: "np.ndarray | None", iou_thres: float) -> np.ndarray:
+    """torchvision nms kernel on boxes (n,4) xyxy fp32 already in descending-score order -> kept positions (ascending).
+    ``same`` (optional, (n,) ints): only boxes with equal entries interact."""
     n = boxes.shape[0]
     x1, y1, x2, y2 = (boxes[:, i].astype(np.float32) for i in range(4))
     area = (x2 - x1) * (y2 - y1)
@@ -45,7 +52,7 @@ def greedy_nms_per_class(boxes: np.ndarray, cls: np.ndarray, iou_thres: float) -
             continue
         keep.append(i)
         j = np.arange(i + 1, n)
-        j = j[(~dead[j]) & (cls[j] == cls[i])]
+        j = j[~dead[j]] if same is None else j[(~dead[j]) & (same[j] == same[i])]
         if j.size == 0:
             continue
         w = np.maximum(np.float32(0), np.minimum(x2[i], x2[j]) - np.maximum(x1[i], x1[j]))
@@ -57,8 +64,35 @@ def greedy_nms_per_class(boxes: np.ndarray, cls: np.ndarray, iou_thres: float) -
     return np.asarray(keep, dtype=np.int64)
 
 
+def greedy_nms_per_class(boxes: np.ndarray, cls: np.ndarray, iou_thres: float) -> np.ndarray:
+    """``_batched_nms_vanilla``: per-class greedy passes on the unshifted boxes (input in descending-score order, so the
+    union of the per-class survivors in input order IS the final descending-score order)."""
+    return _greedy(boxes, cls, iou_thres)
+
+
+def greedy_nms_offset(boxes: np.ndarray, cls: np.ndarray, iou_thres: float) -> np.ndarray:
+    """``_batched_nms_coordinate_trick``: boxes + cls * (boxes.max() + 1) in fp32, one class-agnostic pass."""
+    if boxes.shape[0] == 0:
+        return np.zeros((0,), np.int64)
+    boxes = boxes.astype(np.float32)
+    off = cls.astype(np.float32) * (boxes.max() + np.float32(1))
+    return _greedy(boxes + off[:, None], None, iou_thres)
+
+
+VARIANTS = ("tv0141_cuda", "tv0141_cpu", "offset", "vanilla")
+
+
+def batched_nms(boxes: np.ndarray, cls: np.ndarray, iou_thres: float, variant: str = "tv0141_cuda") -> np.ndarray:
+    """torchvision 0.14.1 ``batched_nms`` on score-sorted boxes -> kept positions, ascending = descending score."""
+    assert variant in VARIANTS, variant
+    if variant.startswith("tv0141"):
+        limit = 20000 if variant.endswith("cuda") else 4000
+        variant = "vanilla" if boxes.size > limit else "offset"
+    return greedy_nms_per_class(boxes, cls, iou_thres) if variant == "vanilla" else greedy_nms_offset(boxes, cls, iou_thres)
+
+
 def non_max_suppression(pred: np.ndarray, conf_thres: float = 0.25, iou_thres: float = 0.7,
-                        max_det: int = 300, max_nms: int = 30000):
+                        max_det: int = 300, max_nms: int = 30000, variant: str = "tv0141_cuda"):
     """pred (B, 4+nc, A) fp32 [cx,cy,w,h, cls scores] -> per image (rows (k,6), anchor_idx (k,)).
 
     rows = [x1,y1,x2,y2,conf,cls] as ultralytics_ops.py:225-226,248; anchor_idx = the column of
@@ -80,7 +114,7 @@ def non_max_suppression(pred: np.ndarray, conf_thres: float = 0.25, iou_thres: f
         box, conf, cls, cand = box[sel], conf[sel], cls[sel], cand[sel]
         order = np.lexsort((cand, -conf.astype(np.float64)))[:max_nms]      # desc score, asc index
         box, conf, cls, cand = box[order], conf[order], cls[order], cand[order]
-        keep = greedy_nms_per_class(box, cls, iou_thres)[:max_det]
+        keep = batched_nms(box, cls, iou_thres, variant)[:max_det]
         rows = np.concatenate((box[keep], conf[keep, None], cls[keep, None].astype(np.float32)), 1)
         out.append((rows.astype(np.float32), cand[keep].astype(np.int64)))
     return out

@@ -155,3 +155,28 @@ def test_fp16_storage_emulation_gap(gold):
     keys = list(g32)
     gap = rel(torch.cat([g16[k].flatten() for k in keys]), torch.cat([g32[k].flatten() for k in keys]))
     assert 1e-2 < gap < 8e-2, gap
+
+
+def test_nms_variants_of_torchvision_0141():
+    """The two batched_nms strategies of torchvision 0.14.1 (oracle/nms_ref.py): identical on ordinary inputs, measurably
+    different on borderline IoUs in high class indices (the shifted coordinates are re-rounded); the library's switch takes
+    the coordinate-offset path below 5000 (CUDA) / 1000 (CPU) candidates.  PARITY UNPINNED: torchvision itself is absent."""
+    import numpy as np
+    from oracle import nms_ref, synth
+    pred = synth.nms_pred(7, b=1)
+    van = nms_ref.non_max_suppression(pred, 0.25, 0.7, 300, variant="vanilla")[0][1]
+    off = nms_ref.non_max_suppression(pred, 0.25, 0.7, 300, variant="offset")[0][1]
+    assert np.array_equal(van, off)
+    hard = synth.nms_pred_borderline(3)
+    van = nms_ref.non_max_suppression(hard, 0.25, 0.7, 1024, variant="vanilla")[0][1]
+    off = nms_ref.non_max_suppression(hard, 0.25, 0.7, 1024, variant="offset")[0][1]
+    only_v, only_o = len(set(van) - set(off)), len(set(off) - set(van))
+    assert only_v > 50 and only_o > 50, (only_v, only_o)        # ~140 / ~130 of ~900 kept boxes differ on this fixture
+    # the switch: 1200 candidates -> offset on CUDA tensors (4*1200 <= 20000), vanilla on CPU tensors (4*1200 > 4000)
+    assert np.array_equal(nms_ref.non_max_suppression(hard, 0.25, 0.7, 1024, variant="tv0141_cuda")[0][1], off)
+    assert np.array_equal(nms_ref.non_max_suppression(hard, 0.25, 0.7, 1024, variant="tv0141_cpu")[0][1], van)
+    # greedy invariants of both: no kept pair of one class overlaps above the threshold (on the boxes the variant sees)
+    rows = nms_ref.non_max_suppression(hard, 0.25, 0.7, 1024, variant="vanilla")[0][0]
+    for c in np.unique(rows[:, 5]):
+        r = rows[rows[:, 5] == c]
+        assert len(nms_ref.greedy_nms_per_class(r[:, :4], r[:, 5], 0.7)) == len(r)
