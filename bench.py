@@ -3,17 +3,19 @@ on N MI355X of one node.  `python bench.py --gpus N --steps K --warmup W`; for N
 under torch.distributed.run (one rank per GPU, RCCL gradient all-reduce).  Rank 0 prints ONE JSON line.
 
 * workload = BASELINE.json configs[1]: YOLOv8-n, batch 32 per GPU, 640x640 synthetic images (U[0,1), seed 1),
-  3 synthetic boxes per image, random-init weights (seed 0); inputs are resident in HBM before the timed region;
-* `roofline`: the dominant kernel family on the critical path is the implicit-GEMM convolution -- the forward and
-  data-gradient launches of conv_halo_kernel (3x3 stride 1), conv_pw_kernel (1x1) and conv_igemm_dma_kernel (the
-  rest).  YOLOv8-n's layers have 16..256 channels: their arithmetic intensity (48..290 FLOP/B) is below the MI355X
-  ridge (2516.6 TF/s / 8 TB/s = 315 FLOP/B), so HBM is the binding roof: achieved = algorithmic bytes per launch
-  (fp16 input view + output + weights) / average launch duration, measured with HIP events on
-  the engine's launch stream (cvx_engine_profile) in a window right after the timed steps; peak = 8 TB/s.  The MFMA
-  view of the same launches is reported beside it.  `traffic` = HBM bytes per launch from rocprofv3 PMC passes
-  (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_conv_traffic_v8.json, tools/pmc_traffic.py -- counters cannot be read from
-  inside this process).
-  The other kernel classes are reported alongside under "kernel_classes";
+  3 synthetic boxes per image, random-init weights (seed 0); inputs are resident in HBM before the timed region
+  (`--model s` = the per-rank workload of configs[2]);
+* `roofline` (the contract roof is MFMA fp16 dense, 2516.6 TFLOP/s): the dominant kernel family on
+  the critical path is the implicit-GEMM convolution -- the forward and data-gradient launches of conv_halo_kernel (3x3
+  stride 1), conv_pw_kernel (1x1), conv_igemm_dma_kernel (the rest) and the fp32 stem.  `achieved` = their algorithmic
+  FLOPs (2 x MACs of every launch) / their summed launch duration, measured live with HIP events on the
+  engine's launch stream (cvx_engine_profile) in a window right after the timed steps; `frac` = achieved / peak.
+  `hbm_view` is the same launches against the 8 TB/s roof (algorithmic bytes: fp16 input view + output + weights per launch,
+  DESIGN.md section 4) -- every YOLOv8-n layer has 16..256 channels, below the 315 FLOP/B ridge, so this is the nearer roof.
+  `traffic` = HBM bytes per launch of that family from rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE,
+  tools/pmc_traffic.py): counters cannot be read inside this process, so the JSON under profiles/ carries the SHA-256 of the
+  library it was measured on and is REFUSED (traffic = null) when it does not match the library that is running;
+  `whole_step` = images/s x 26.140262 GFLOP / 2516.6 TF, the section-8(d) figure for the whole train step;
 * `cpu_baseline`: the CPU oracle (torch-CPU fp32 restatement of the reference, kind "port") timed on this
   host's cores on a bounded sample (batch 8 train steps), rank 0, N = 1 only.
 """
@@ -30,9 +32,28 @@ sys.path.insert(0, ROOT)
 
 MFMA_FP16_PEAK_TFLOPS = 2516.6                  # MI355X dense fp16
 HBM_PEAK_GBS = 8000.0
-TRAIN_GFLOP_PER_IMG = 26.140262                 # 3*F - 2*MAC0, YOLOv8-n 640x640
-FWD_GFLOP_PER_IMG = 8.742912
-TRAFFIC_FILE = "r01_conv_traffic_v8.json"       # PMC passes of the build this file was committed with (tools/pmc_traffic.py)
+GFLOP = {"n": (8.742912, 26.140262), "s": (28.601549, 85.627699)}   # (forward, train step) per image, SURVEY section 8(d)
+TRAFFIC_FILES = ("r02_conv_traffic.json",)      # newest first; PMC passes of a build, keyed by that build's library hash
+
+
+def lib_sha256():
+    import hashlib
+    from computervision.pytorch_amd import _lib
+    return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
+
+
+def measured_traffic(model, batch):
+    """HBM bytes per conv launch from the committed PMC passes -- only if they were taken on THIS build of the library."""
+    sha = lib_sha256()
+    for name in TRAFFIC_FILES:
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        t = json.load(open(path))
+        if t.get("lib_sha256") == sha and t.get("model", "n") == model and t.get("batch", 32) == batch:
+            return round(t["hbm_bytes_per_launch"]), f"profiles/{name} (library {sha[:12]})"
+        return None, f"profiles/{name} was measured on library {str(t.get('lib_sha256'))[:12]}, running {sha[:12]}: refused"
+    return None, "no PMC passes committed for this round yet"
 
 
 def usable_cores() -> int:
@@ -158,6 +179,7 @@ def main():
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
+        fwd_gf, train_gf = GFLOP.get(args.model, (float('nan'), float('nan')))
         value = B * world * args.steps / elapsed
         conv = {k: prof[k] for k in ("conv_fwd", "conv_dgrad")}
         conv_ms = sum(v["ms"] for v in conv.values())
@@ -166,10 +188,7 @@ def main():
         achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         conv_by = sum(v["bytes"] for v in conv.values())
         conv_gbs = conv_by / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0
-        traffic = None                                   # measured HBM bytes per launch of the same kernel family (PMC passes)
-        tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
-        if os.path.exists(tpath) and B == 32 and args.model == "n":
-            traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
+        traffic, traffic_note = measured_traffic(args.model, B)
         classes = {}
         for k, v in prof.items():
             if v["launches"] == 0:
@@ -179,25 +198,27 @@ def main():
                           "tflops": round(v["flops"] / sec / 1e12, 2) if v["flops"] else None,
                           "algorithmic_gbs": round(v["bytes"] / sec / 1e9, 1)}
         out = {
-            "metric": "images/sec 640x640 YOLOv8-n train step", "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
+            "metric": f"images/sec 640x640 YOLOv8-{args.model} train step", "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"YOLOv8-{args.model} train step (fwd + v8 loss + bwd + Adam), batch {B}/GPU, 640x640, nc=80, random init",
                        "global_batch": B * world, "parallelism": f"dp{world}", "loss_scale": cfg.engine.loss_scale,
                        "launch": "hipGraph replay" if use_graph else "eager"},
-            "roofline": {"bound": "hbm",
-                         "kernel": "implicit-GEMM convolution: conv_halo_kernel + conv_pw_kernel + conv_igemm_dma_kernel, forward + data-gradient launches",
-                         "achieved": round(conv_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(conv_gbs / HBM_PEAK_GBS, 5),
-                         "traffic": traffic,
+            "roofline": {"bound": "mfma",
+                         "kernel": "implicit-GEMM convolution, forward + data-gradient launches: conv_halo_kernel + conv_pw_kernel + "
+                                   "conv_igemm_dma_kernel (+ the fp32 stem passes)",
+                         "achieved": round(achieved, 3), "peak": MFMA_FP16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / MFMA_FP16_PEAK_TFLOPS, 5), "traffic": traffic, "traffic_source": traffic_note,
+                         "algorithmic_flops_per_launch": round(conv_fl / max(conv_launches, 1)),
                          "algorithmic_bytes_per_launch": round(conv_by / max(conv_launches, 1)),
                          "avg_launch_us": round(conv_ms * 1e3 / max(conv_launches, 1), 3), "launches_per_step": conv_launches // prof_steps,
-                         "mfma_view": {"achieved_tflops": round(achieved, 3), "peak_tflops": MFMA_FP16_PEAK_TFLOPS,
-                                       "frac": round(achieved / MFMA_FP16_PEAK_TFLOPS, 5), "algorithmic_flops_per_step": conv_fl / prof_steps}},
-            "whole_step": {"train_tflops": round(value / world * TRAIN_GFLOP_PER_IMG / 1e3, 3),
-                           "frac_of_mfma_peak": round(value / world * TRAIN_GFLOP_PER_IMG / 1e3 / MFMA_FP16_PEAK_TFLOPS, 5)},
+                         "hbm_view": {"achieved_gbs": round(conv_gbs, 1), "peak_gbs": HBM_PEAK_GBS, "frac": round(conv_gbs / HBM_PEAK_GBS, 5)}},
+            "whole_step": {"train_tflops": round(value / world * train_gf / 1e3, 3),
+                           "frac_of_mfma_peak": round(value / world * train_gf / 1e3 / MFMA_FP16_PEAK_TFLOPS, 5),
+                           "gflop_per_image": train_gf},
             "forward_eval": {"ms_per_batch": round(eval_ms, 4), "images_per_sec": round(B / eval_ms * 1e3, 1),
-                             "tflops": round(B * FWD_GFLOP_PER_IMG / eval_ms, 2),
-                             "frac_of_mfma_peak": round(B * FWD_GFLOP_PER_IMG / eval_ms / MFMA_FP16_PEAK_TFLOPS, 5),
+                             "tflops": round(B * fwd_gf / eval_ms, 2),
+                             "frac_of_mfma_peak": round(B * fwd_gf / eval_ms / MFMA_FP16_PEAK_TFLOPS, 5),
                              "note": "per GPU; eval-mode forward of the same batch, folded BN + SiLU in the conv epilogues"},
             "kernel_classes": classes,
             "loss_items_last_step": loss_items,

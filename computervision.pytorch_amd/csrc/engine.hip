@@ -274,10 +274,9 @@ int build_static(cvx_engine* e) {
     sh = (sh + 7) & ~7LL;
     pd.dg_off = -1;
     if (o.needs_dgrad) {
-      CVX_CHECK(o.w_cin == o.in.c, "dgrad needs unpadded input channels");
-      pd.dg_off = sh;
+      pd.dg_off = sh;  // [Cin_pad][T][Cout]: the rows of padded input channels are never written and stay zero (memset below)
       c.sh_dg = sh;
-      sh += (long long)pd.Cin * T * pd.Cout;
+      sh += (long long)pd.Cin_pad * T * pd.Cout;
       sh = (sh + 7) & ~7LL;
       // data-gradient tap classes: one per output phase of the forward stride
       const int S = o.stride;

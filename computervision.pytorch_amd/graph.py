@@ -82,6 +82,7 @@ class ParamLayout:
         self.head_in = (self.c256, self.c512, self.c1024)
         self.c_box = max(16, self.head_in[0] // 4, REG_MAX * 4)        # modules.py:422
         self.c_cls = max(self.head_in[0], nc)
+        self.c_cls_eng = (self.c_cls + 7) & ~7        # hidden width of the class branch as the engine runs it (zero-padded)
         self.no = nc + 4 * REG_MAX
         self.nc_pad = (nc + 7) & ~7                    # class columns of the engine's pred buffer
         self.no_pad = self.nc_pad + 4 * REG_MAX
@@ -107,19 +108,19 @@ class ParamLayout:
     def _add_conv(self, name: str, prefixes, couts, cin, k, bn=True) -> ConvSpec:
         spec = ConvSpec(list(prefixes), list(couts), cin, k, bn)
         ct = spec.cout
-        # the head's class conv has nc output rows; the engine's kernels work on 8-channel groups, so its arena block is
-        # padded with zero rows (weights, bias and gradients stay zero; the state_dict views cover the real rows only)
-        ce = ct if bn else (ct + 7) & ~7
-        if bn and ct % 8:
-            raise ValueError(f"{name}: {ct} output channels -- the MI355X engine needs BatchNorm layers in multiples of 8 "
-                             f"(class counts in (64, 100] must be multiples of 8 for this model scale)")
+        # the engine's kernels work on 8-channel groups: an arena block whose channel count is not a multiple of 8 (the head's
+        # class convs: nc outputs, and their c3 = max(ch0, nc) wide hidden layers when nc > ch0) is padded with zero rows.
+        # Padded channels are inert: zero weights -> zero conv output -> zero normalised value -> silu(beta = 0) = 0, the next
+        # layer's weights for them are zero as well, and every gradient that reaches them is zero, so Adam never moves them.
+        # The state_dict views cover the real rows only.
+        ce = (ct + 7) & ~7
         spec.cout_eng = ce
         spec.w_off = self._take("param", ce * k * k * cin)
         if bn:
-            spec.gamma_off = self._take("param", ct)
-            spec.beta_off = self._take("param", ct)
-            spec.rmean_off = self._take("stat", ct)
-            spec.rvar_off = self._take("stat", ct)
+            spec.gamma_off = self._take("param", ce)
+            spec.beta_off = self._take("param", ce)
+            spec.rmean_off = self._take("stat", ce)
+            spec.rvar_off = self._take("stat", ce)
         else:
             spec.bias_off = self._take("param", ce)
         self.convs[name] = spec
@@ -318,7 +319,7 @@ def build_yolov8_graph(lay: ParamLayout, H: int, W: int) -> Graph:
     pred = buf(g.anchors, 1, lay.no_pad, L.BUF_PRED_F32)
     g.pred_buf = pred
     a_off = 0
-    cb, cc = lay.c_box, lay.c_cls
+    cb, cc = lay.c_box, lay.c_cls_eng
     for lvl, (src, (hh, ww)) in enumerate(zip((View(b15, 0, c256), View(b18, 0, c512), View(b21, 0, c1024)), g.level_hw)):
         h1 = buf(hh, ww, cb + cc)
         hb = buf(hh, ww, cb)
@@ -357,7 +358,7 @@ def grad_buckets(g: Graph, lay: ParamLayout, n_buckets: int, tail_modules: int =
         if o["type"] == L.OP_CONV:
             spec = lay.convs[o["name"]]
             start = spec.w_off
-            end = ((spec.beta_off + spec.cout if spec.bn else spec.bias_off + spec.cout_eng) + 3) & ~3
+            end = ((spec.beta_off if spec.bn else spec.bias_off) + spec.cout_eng + 3) & ~3
             mods[-1][2] = start if mods[-1][2] is None else min(mods[-1][2], start)
             mods[-1][3] = end if mods[-1][3] is None else max(mods[-1][3], end)
     merged = []

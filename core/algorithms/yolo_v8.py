@@ -82,9 +82,19 @@ class YOLOv8:
             img = cv2.resize(img, (W, H), interpolation=cv2.INTER_CUBIC)
         x = torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1).float().div(255.0).unsqueeze(0)
         boxes, scores, classes = self.predict_tensor(model, x, h, w)
+        bgr = cv2.imread(image_path, cv2.IMREAD_COLOR | cv2.IMREAD_IGNORE_ORIENTATION)
         if boxes.shape[0] == 0:
             print("No object detected")
-        elif print_on:
-            for b, s, c in zip(boxes, scores, classes):
-                print(f"class {int(c)} score {float(s):.3f} box {b.tolist()}")
-        return boxes, scores, classes
+            return bgr                                  # the reference returns the untouched BGR image (yolo_v8.py:193-195)
+        # the reference returns the image with the detections drawn on it (show_detection_results, visualize.py:15)
+        for b, s_, c in zip(boxes, scores, classes):
+            x1, y1, x2, y2 = (int(round(float(v))) for v in b)
+            cv2.rectangle(bgr, (x1, y1), (x2, y2), (0, 255, 0), 2)
+            cv2.putText(bgr, f"{int(c)}: {float(s_):.2f}", (x1, max(y1 - 4, 10)), cv2.FONT_HERSHEY_SIMPLEX, 0.5, (0, 255, 0), 1)
+            if print_on:
+                print(f"class {int(c)} score {float(s_):.3f} box {[float(v) for v in b]}")
+        if save_result:
+            import os
+            os.makedirs(self.cfg.decode.test_results, exist_ok=True)
+            cv2.imwrite(os.path.join(self.cfg.decode.test_results, os.path.basename(image_path)), bgr)
+        return bgr

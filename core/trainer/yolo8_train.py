@@ -10,7 +10,7 @@ import torch
 from computervision.pytorch_amd.train import DynamicLossScale, FlatAdam, FusedTrainStep
 from configs import Yolo8DetConfig
 from core.algorithms.yolo_v8 import YOLOv8
-from core.trainer.base import BaseTrainer
+from core.trainer.base import BaseTrainer, LinearWarmup
 from registry import trainer_registry
 
 
@@ -66,7 +66,14 @@ class Yolo8Trainer(BaseTrainer):
         self.optimizer = get_optimizer(self.optimizer_name, self.model, self.initial_lr)
 
     def set_lr_scheduler(self):
-        self.lr_scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=self.milestones, gamma=self.gamma)
+        """EnhancedMultiStepLR over ITERATION milestones + LinearWarmup (reference yolo8_train.py:76-88,
+        lr_scheduler.py:87-91: an empty milestone list means 'never')."""
+        milestones = list(self.milestones) or [int(1e8), int(1e8) + 1]
+        self.lr_scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=milestones, gamma=self.gamma,
+                                                                 last_epoch=self.last_iter if self.last_iter > 0 else -1)
+        if self.warmup_iters > 0:
+            self.warmup_scheduler = LinearWarmup(self.optimizer, warmup_period=self.warmup_iters,
+                                                 last_step=self.last_iter if self.last_iter > 0 else -1)
 
     def set_criterion(self):
         self.criterion = self.model_algorithm.build_loss(model=self.model)

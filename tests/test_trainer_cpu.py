@@ -1,0 +1,80 @@
+"""CPU: the trainer's schedule and checkpoint semantics (reference core/trainer/base.py:121-122,180-191,261-292,
+core/trainer/warm_up.py, core/utils/ckpt.py) -- no engine call is made here."""
+import torch
+
+from core.trainer.base import LinearWarmup
+from core.utils.ckpt import CheckPoint
+
+
+class _Opt(torch.optim.SGD):
+    pass
+
+
+def _sched(lr=1e-3, milestones=(6, 9), warm=4):
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = _Opt([{"params": [p], "initial_lr": lr}], lr=lr)
+    sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=list(milestones), gamma=0.1)
+    return p, opt, sch, LinearWarmup(opt, warm)
+
+
+def test_linear_warmup_dampens_the_multistep_schedule_per_iteration():
+    """lr_t = initial * gamma^(milestones passed) * min(1, (t + 1) / warmup) -- pytorch_warmup semantics as used by the
+    reference: scheduler.step() inside warmup.dampening() once per iteration."""
+    _, opt, sch, warm = _sched()
+    lrs = [opt.param_groups[0]["lr"]]
+    for _ in range(11):
+        with warm.dampening():
+            sch.step()
+        lrs.append(opt.param_groups[0]["lr"])
+    want = [1e-3 * (0.1 ** ((t >= 6) + (t >= 9))) * min(1.0, (t + 1) / 4) for t in range(12)]
+    assert all(abs(a - b) < 1e-12 for a, b in zip(lrs, want)), (lrs, want)
+
+
+def test_iteration_milestones_and_constant_lr_without_warmup():
+    """Milestones in epochs become (m + 1) * len(loader) iterations; without warm-up the scheduler never steps (the
+    reference's quirk, base.py:261-263)."""
+    from configs import Yolo8DetConfig
+    from core.trainer.base import BaseTrainer
+
+    class T(BaseTrainer):
+        def set_model_algorithm(self):
+            pass
+
+        def load_data(self):
+            self.train_dataloader = [None] * 7
+
+        def initialize_model(self):
+            self.p = torch.nn.Parameter(torch.zeros(1))
+
+        def set_optimizer(self):
+            self.optimizer = _Opt([{"params": [self.p], "initial_lr": 1e-3}], lr=1e-3)
+
+        def set_criterion(self):
+            pass
+
+    cfg = Yolo8DetConfig()
+    cfg.train.milestones = [1, 3]
+    t = T(cfg, "cpu")
+    assert t.milestones == [14, 28] and t.last_iter == 0 and t.warmup_scheduler is None
+
+
+def test_checkpoint_round_trip_in_the_reference_format(tmp_path):
+    model = torch.nn.Linear(3, 2)
+    p, opt, sch, warm = _sched()
+    for _ in range(3):
+        with warm.dampening():
+            sch.step()
+    path = str(tmp_path / "ck.pth")
+    CheckPoint.save(model, path, optimizer=opt, scheduler=sch, warm_up=warm)
+    obj = torch.load(path, weights_only=False)
+    assert set(obj) == {"model", "optimizer", "scheduler", "warm_up"} and set(obj["model"]) == {"weight", "bias"}
+    m2 = torch.nn.Linear(3, 2)
+    _, opt2, sch2, warm2 = _sched()
+    CheckPoint.load(path, "cpu", m2, optimizer=opt2, scheduler=sch2, warm_up=warm2)
+    assert torch.equal(m2.weight, model.weight) and sch2.last_epoch == sch.last_epoch and warm2.last_step == warm.last_step
+    bare = str(tmp_path / "bare.pth")
+    CheckPoint.save(model, bare)
+    m3 = torch.nn.Linear(3, 2)
+    CheckPoint.load_pure(bare, "cpu", m3)
+    CheckPoint.load_pure(path, "cpu", m3)                       # either format
+    assert torch.equal(m3.bias, model.bias)

@@ -2,6 +2,9 @@
 
     python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
 
+The JSON records the SHA-256 of the library the passes ran on (the in-tree libcvx_engine.so at the time this tool runs:
+run it on the GPU box right after the passes); bench.py refuses the figure when it does not match the running library.
+
 One timed step (between two Adam launches) is summed.  Correction as MI355X_MICROARCH.md (section HBM) prescribes for gfx950:
 bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB counters; FETCH_SIZE tallies 128-byte requests at 64 bytes).
 """
@@ -10,9 +13,9 @@ import csv
 import json
 import sys
 
-FAMILIES = ("conv_halo_kernel", "conv_pw_kernel", "conv_igemm_dma_kernel", "conv_wgrad_halo_kernel", "conv_wgrad_kernel", "bn_bwd_reduce",
+FAMILIES = ("conv_halo_kernel", "conv_pw_kernel", "conv_igemm_dma_kernel", "stem_stats_kernel", "stem_apply_kernel", "stem_wgrad_kernel", "conv_wgrad_halo_kernel", "conv_wgrad_kernel", "bn_bwd_reduce",
             "bn_bwd_apply", "bn_silu_apply", "reduce_slabs")
-CONV = ("conv_halo_kernel", "conv_pw_kernel", "conv_igemm_dma_kernel")
+CONV = ("conv_halo_kernel", "conv_pw_kernel", "conv_igemm_dma_kernel", "stem_stats_kernel", "stem_apply_kernel")
 
 
 def family(name):
@@ -45,7 +48,11 @@ def main():
                "hbm_bytes": (2 * fetch[k][0] + write[k][0]) * 1024} for k in fetch}
     n = sum(fam[k]["launches"] for k in CONV)
     tot = sum(fam[k]["hbm_bytes"] for k in CONV)
-    out = {"source": "rocprofv3 --pmc FETCH_SIZE --kernel-trace / --pmc WRITE_SIZE --kernel-trace (separate passes) -- python bench.py "
+    import hashlib
+    import os
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "computervision.pytorch_amd", "lib", "libcvx_engine.so")
+    out = {"lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(), "model": "n", "batch": 32,
+           "source": "rocprofv3 --pmc FETCH_SIZE --kernel-trace / --pmc WRITE_SIZE --kernel-trace (separate passes) -- python bench.py "
                      "--no-cpu-baseline --steps 3 --warmup 2 --profile-steps 1; one timed step",
            "correction": "bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB counters), MI355X_MICROARCH.md section HBM",
            "conv_family": list(CONV), "launches_per_step": n, "hbm_bytes_per_step": tot, "hbm_bytes_per_launch": tot / n,
