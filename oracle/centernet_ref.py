@@ -1,0 +1,313 @@
+"""CPU oracle for CenterNet (DLA-34) inference + heat-map decode -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+SURVEY.md section 8 row a18 / (f)1, BASELINE.json configs[3].  A torch-CPU fp32 restatement, functional over a flat
+``state_dict`` with the reference's keys (``backbone.base...``, ``backbone.dla_up...``, ``backbone.<head>...``), of
+
+* the DLA-34 network (core/models/centernet_model.py:9-379): 7x7 stem, BasicBlock trees with Root aggregation, 2x2 max-pool
+  down-sampling, IDAUp / DLAUp with depthwise ConvTranspose2d up-sampling, three heads, NHWC output (:371-379);
+* the decode tail (core/algorithms/centernet.py:271-338): sigmoid, the 3x3 max-pool that the reference applies to the
+  NHWC tensor as if it were NCHW -- the window spans (x, class) for a fixed row y, reproduced as is --, global top-K,
+  gather, clamp, score mask, class-agnostic DIoU-NMS (core/utils/nms.py:9-31, core/utils/iou.py:8-64), letterbox
+  inverse (core/utils/image_process.py:100-129).
+
+Parity pin: ``oracle/make_golden.py`` imports the real reference in the build container and asserts that this file
+reproduces its seed-0 initialisation bit for bit, its forward to fp32 round-off and its decode exactly, then writes
+``tests/golden/centernet_*.npz``.  ``torch.topk``'s order among equal scores is implementation-defined; the oracle defines
+it as (score descending, flat index ascending) -- the fixtures contain no ties among the kept scores.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+LEVELS = (1, 1, 1, 2, 2, 1)                      # dla34 (centernet_model.py:342-344)
+CHANNELS = (16, 32, 64, 128, 256, 512)
+HEAD_CONV = 256                                   # centernet_model.py:312
+BN_EPS = 1e-5                                     # nn.BatchNorm2d defaults
+BN_MOMENTUM = 0.1
+
+
+# ----------------------------------------------------------------------------------------------
+# architecture walk: one description drives the initialiser, the forward and (in the product) the engine graph
+# ----------------------------------------------------------------------------------------------
+def tree_plan(prefix, levels, cin, cout, stride, level_root, root_dim=0):
+    """Tree.__init__ (centernet_model.py:98-136) as data."""
+    if root_dim == 0:
+        root_dim = 2 * cout
+    if level_root:
+        root_dim += cin
+    t = dict(prefix=prefix, levels=levels, cin=cin, cout=cout, stride=stride, level_root=level_root, root_dim=root_dim,
+             project=cin != cout)
+    if levels == 1:
+        t["tree1"] = dict(kind="block", prefix=prefix + ".tree1", cin=cin, cout=cout, stride=stride)
+        t["tree2"] = dict(kind="block", prefix=prefix + ".tree2", cin=cout, cout=cout, stride=1)
+    else:
+        t["tree1"] = tree_plan(prefix + ".tree1", levels - 1, cin, cout, stride, False, 0)
+        t["tree2"] = tree_plan(prefix + ".tree2", levels - 1, cout, cout, 1, False, root_dim + cout)
+    t["kind"] = "tree"
+    return t
+
+
+def dla_up_plan():
+    """DLAUp.__init__ with its in-place list updates (centernet_model.py:282-296) -> [(out_dim, in_channels, up_factors)]."""
+    channels = list(CHANNELS[2:])
+    in_ch = list(CHANNELS[2:])
+    scales = [1, 2, 4, 8]
+    idas = []
+    for i in range(len(channels) - 1):
+        j = -i - 2
+        idas.append((channels[j], list(in_ch[j:]), [s // scales[j] for s in scales[j:]]))
+        scales[j + 1:] = [scales[j]] * len(scales[j + 1:])
+        in_ch[j + 1:] = [channels[j]] * len(in_ch[j + 1:])
+    return idas
+
+
+def _emit_conv(out, key, cout, cin_per_group, k, bias, gen):
+    w = torch.empty(cout, cin_per_group, k, k)
+    torch.nn.init.kaiming_uniform_(w, a=math.sqrt(5), generator=gen)
+    out[key + ".weight"] = w
+    if bias:
+        bound = 1.0 / math.sqrt(cin_per_group * k * k)
+        b = torch.empty(cout)
+        torch.nn.init.uniform_(b, -bound, bound, generator=gen)
+        out[key + ".bias"] = b
+
+
+def _emit_bn(out, key, c):
+    out[key + ".weight"] = torch.ones(c)
+    out[key + ".bias"] = torch.zeros(c)
+    out[key + ".running_mean"] = torch.zeros(c)
+    out[key + ".running_var"] = torch.ones(c)
+    out[key + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+
+
+def _emit_block(out, p, gen):
+    _emit_conv(out, p["prefix"] + ".conv1", p["cout"], p["cin"], 3, False, gen)
+    _emit_bn(out, p["prefix"] + ".bn1", p["cout"])
+    _emit_conv(out, p["prefix"] + ".conv2", p["cout"], p["cout"], 3, False, gen)
+    _emit_bn(out, p["prefix"] + ".bn2", p["cout"])
+
+
+def _emit_tree(out, t, gen):
+    for sub in (t["tree1"], t["tree2"]):
+        (_emit_block if sub["kind"] == "block" else _emit_tree)(out, sub, gen)
+    if t["levels"] == 1:
+        _emit_conv(out, t["prefix"] + ".root.conv", t["cout"], t["root_dim"], 1, False, gen)
+        _emit_bn(out, t["prefix"] + ".root.bn", t["cout"])
+    if t["project"]:
+        _emit_conv(out, t["prefix"] + ".project.0", t["cout"], t["cin"], 1, False, gen)
+        _emit_bn(out, t["prefix"] + ".project.1", t["cout"])
+
+
+def trees():
+    b = "backbone.base."
+    c = CHANNELS
+    return [tree_plan(b + "level_2", LEVELS[2], c[1], c[2], 2, False), tree_plan(b + "level_3", LEVELS[3], c[2], c[3], 2, True),
+            tree_plan(b + "level_4", LEVELS[4], c[3], c[4], 2, True), tree_plan(b + "level_5", LEVELS[5], c[4], c[5], 2, True)]
+
+
+def init_state_dict(nc: int = 80, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    """The reference's ``CenterNet(cfg)`` under ``torch.manual_seed(seed)``: same draws in the same (construction) order --
+    torch's default Conv2d / ConvTranspose2d initialisation; the unused classifier ``base.final`` (512 -> 1000, with bias)
+    draws too and is part of the ``state_dict``."""
+    gen = torch.Generator().manual_seed(seed)
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    b = "backbone.base."
+    c = CHANNELS
+    _emit_conv(sd, b + "base_layer.0", c[0], 3, 7, False, gen)
+    _emit_bn(sd, b + "base_layer.1", c[0])
+    _emit_conv(sd, b + "level_0.0", c[0], c[0], 3, False, gen)
+    _emit_bn(sd, b + "level_0.1", c[0])
+    _emit_conv(sd, b + "level_1.0", c[1], c[0], 3, False, gen)
+    _emit_bn(sd, b + "level_1.1", c[1])
+    for t in trees():
+        _emit_tree(sd, t, gen)
+    _emit_conv(sd, b + "final", 1000, c[5], 1, True, gen)
+    for i, (out_dim, in_ch, ups) in enumerate(dla_up_plan()):
+        p = f"backbone.dla_up.ida_{i}."
+        for k, (ci, f) in enumerate(zip(in_ch, ups)):
+            if ci != out_dim:
+                _emit_conv(sd, p + f"proj_{k}.0", out_dim, ci, 1, False, gen)
+                _emit_bn(sd, p + f"proj_{k}.1", out_dim)
+            if f != 1:
+                _emit_conv(sd, p + f"up_{k}", out_dim, 1, 2 * f, False, gen)        # ConvTranspose2d weight (C, 1, 2f, 2f)
+        for k in range(1, len(in_ch)):
+            _emit_conv(sd, p + f"node_{k}.0", out_dim, 2 * out_dim, 3, False, gen)
+            _emit_bn(sd, p + f"node_{k}.1", out_dim)
+    for head, classes in (("heatmap", nc), ("wh", 2), ("reg", 2)):
+        _emit_conv(sd, f"backbone.{head}.0", HEAD_CONV, c[2], 3, True, gen)
+        _emit_conv(sd, f"backbone.{head}.2", classes, HEAD_CONV, 1, True, gen)
+    return sd
+
+
+# ----------------------------------------------------------------------------------------------
+# forward
+# ----------------------------------------------------------------------------------------------
+def _bn(x, sd, key, training):
+    if training:
+        sd[key + ".num_batches_tracked"] += 1
+    return F.batch_norm(x, sd[key + ".running_mean"], sd[key + ".running_var"], sd[key + ".weight"], sd[key + ".bias"],
+                        training, BN_MOMENTUM, BN_EPS)
+
+
+def _block(x, sd, p, residual, training):
+    """BasicBlock.forward (centernet_model.py:20-27): the residual is added BEFORE the ReLU."""
+    pre = p["prefix"]
+    y = F.relu(_bn(F.conv2d(x, sd[pre + ".conv1.weight"], None, p["stride"], 1), sd, pre + ".bn1", training))
+    y = _bn(F.conv2d(y, sd[pre + ".conv2.weight"], None, 1, 1), sd, pre + ".bn2", training)
+    return F.relu(y + residual)
+
+
+def _tree(x, sd, t, training, residual=None, children=None):
+    """Tree.forward (centernet_model.py:138-152)."""
+    children = [] if children is None else children
+    pre = t["prefix"]
+    bottom = F.max_pool2d(x, 2, 2) if t["stride"] > 1 else x
+    if t["project"]:
+        residual = _bn(F.conv2d(bottom, sd[pre + ".project.0.weight"]), sd, pre + ".project.1", training)
+    else:
+        residual = bottom
+    if t["level_root"]:
+        children.append(bottom)
+    if t["levels"] == 1:
+        x1 = _block(x, sd, t["tree1"], residual, training)
+        x2 = _block(x1, sd, t["tree2"], x1, training)
+        cat = torch.cat([x2, x1, *children], 1)
+        return F.relu(_bn(F.conv2d(cat, sd[pre + ".root.conv.weight"]), sd, pre + ".root.bn", training))   # root_residual False
+    x1 = _tree(x, sd, t["tree1"], training, residual=residual)
+    children.append(x1)
+    return _tree(x1, sd, t["tree2"], training, children=children)
+
+
+def _ida(layers, sd, p, out_dim, in_ch, ups, training):
+    """IDAUp.forward (centernet_model.py:268-279)."""
+    layers = list(layers)
+    for k, (ci, f) in enumerate(zip(in_ch, ups)):
+        l = layers[k]
+        if ci != out_dim:
+            l = F.relu(_bn(F.conv2d(l, sd[p + f"proj_{k}.0.weight"]), sd, p + f"proj_{k}.1", training))
+        if f != 1:
+            l = F.conv_transpose2d(l, sd[p + f"up_{k}.weight"], None, stride=f, padding=f // 2, groups=out_dim)
+        layers[k] = l
+    x, ys = layers[0], []
+    for k in range(1, len(layers)):
+        x = F.relu(_bn(F.conv2d(torch.cat([x, layers[k]], 1), sd[p + f"node_{k}.0.weight"], None, 1, 1), sd, p + f"node_{k}.1", training))
+        ys.append(x)
+    return x, ys
+
+
+def forward(sd, x: torch.Tensor, nc: int = 80, training: bool = False) -> torch.Tensor:
+    """CenterNet.forward (centernet_model.py:371-379): (B,3,H,W) -> (B, H/4, W/4, nc + 4) = [heatmap | wh | reg] heads, NHWC."""
+    b = "backbone.base."
+    x = F.relu(_bn(F.conv2d(x, sd[b + "base_layer.0.weight"], None, 1, 3), sd, b + "base_layer.1", training))
+    x = F.relu(_bn(F.conv2d(x, sd[b + "level_0.0.weight"], None, 1, 1), sd, b + "level_0.1", training))
+    x = F.relu(_bn(F.conv2d(x, sd[b + "level_1.0.weight"], None, 2, 1), sd, b + "level_1.1", training))
+    ys = []
+    for t in trees():
+        x = _tree(x, sd, t, training)
+        ys.append(x)
+    layers = list(ys)                                              # DLAUp.forward (centernet_model.py:298-305)
+    for i, (out_dim, in_ch, ups) in enumerate(dla_up_plan()):
+        x, y = _ida(layers[-i - 2:], sd, f"backbone.dla_up.ida_{i}.", out_dim, in_ch, ups, training)
+        layers[-i - 1:] = y
+    outs = []
+    for head in ("heatmap", "wh", "reg"):
+        h = F.relu(F.conv2d(x, sd[f"backbone.{head}.0.weight"], sd[f"backbone.{head}.0.bias"], 1, 1))
+        outs.append(F.conv2d(h, sd[f"backbone.{head}.2.weight"], sd[f"backbone.{head}.2.bias"]))
+    return torch.cat(outs, 1).permute(0, 2, 3, 1)
+
+
+# ----------------------------------------------------------------------------------------------
+# decode
+# ----------------------------------------------------------------------------------------------
+IOU_EPS = 1e-6                                    # core/utils/iou.py:5
+
+
+def box_diou(b1: torch.Tensor, b2: torch.Tensor) -> torch.Tensor:
+    """core/utils/iou.py:8-64, xyxy boxes, fp32, the reference's operation order."""
+    a1 = (b1[..., 2] - b1[..., 0]) * (b1[..., 3] - b1[..., 1])
+    a2 = (b2[..., 2] - b2[..., 0]) * (b2[..., 3] - b2[..., 1])
+    wh = torch.clamp(torch.minimum(b1[..., 2:4], b2[..., 2:4]) - torch.maximum(b1[..., 0:2], b2[..., 0:2]), min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    iou = inter / torch.clamp(a1 + a2 - inter, min=IOU_EPS)
+    c1, c2 = (b1[..., 0:2] + b1[..., 2:4]) / 2, (b2[..., 0:2] + b2[..., 2:4]) / 2
+    enc = torch.clamp(torch.maximum(b1[..., 2:4], b2[..., 2:4]) - torch.minimum(b1[..., 0:2], b2[..., 0:2]), min=0)
+    c_sq = torch.sum(torch.pow(enc, 2), dim=-1)
+    d_sq = torch.sum(torch.pow(c1 - c2, 2), dim=-1)
+    return iou - d_sq / torch.clamp(c_sq, min=IOU_EPS)
+
+
+def diou_nms(boxes: torch.Tensor, scores: torch.Tensor, thr: float) -> torch.Tensor:
+    """core/utils/nms.py:9-31: greedy, class-agnostic; a box survives a kept box when DIoU <= thr.  Ties in the score sort:
+    lower index first."""
+    order = torch.sort(scores, descending=True, stable=True).indices
+    alive = torch.ones(order.numel(), dtype=torch.bool)
+    keep = []
+    for pos in range(order.numel()):
+        if not alive[pos]:
+            continue
+        i = int(order[pos])
+        keep.append(i)
+        rest = order[pos + 1:]
+        if rest.numel():
+            alive[pos + 1:] &= box_diou(boxes[i], boxes[rest]) <= thr
+    return torch.tensor(keep, dtype=torch.long)
+
+
+def suppress_and_topk(pred: torch.Tensor, nc: int, k: int):
+    """sigmoid -> the reference's (x, class)-window 3x3 max-pool -> top-k over H*W*C per image
+    (centernet.py:279-281,313-336).  Returns scores (B,k), flat indices (B,k) into (H, W, C)."""
+    heat = torch.sigmoid(pred[..., :nc])                                             # (B, H, W, C)
+    hmax = F.max_pool2d(heat, 3, 1, 1)      # on a (B,H,W,C) tensor: "channels" = H, the window runs over (W, C)
+    heat = heat * (heat == hmax).float()
+    B = heat.shape[0]
+    flat = heat.reshape(B, -1)
+    order = torch.sort(flat, dim=1, descending=True, stable=True).indices[:, :k]   # (score desc, index asc)
+    return flat.gather(1, order), order
+
+
+def decode(pred: torch.Tensor, nc: int, input_hw, image_hw, k: int = 100, conf: float = 0.1, nms_thr: float = 0.5,
+           use_nms: bool = True):
+    """CenterNetA.decode_boxes (centernet.py:271-311) for ONE image (the reference flattens the batch before the score mask
+    and the NMS, so per-image semantics hold for B = 1 only): -> boxes (n,4) xyxy in original-image pixels, scores, classes,
+    and the positions (0..k-1) of the survivors in the top-k list."""
+    assert pred.shape[0] == 1
+    _, H, W, _ = pred.shape
+    scores, inds = suppress_and_topk(pred, nc, k)
+    cls = inds % nc
+    pixel = torch.div(inds, nc, rounding_mode="floor")
+    ys, xs = torch.div(pixel, W, rounding_mode="floor"), pixel % W
+    pix = (ys * W + xs).long()
+    feat = pred.reshape(1, H * W, nc + 4)
+    reg = feat[..., nc:nc + 2].gather(1, pix.unsqueeze(2).expand(-1, -1, 2))         # the reference reads offsets from the "wh" head
+    wh = feat[..., nc + 2:].gather(1, pix.unsqueeze(2).expand(-1, -1, 2))            # ... and sizes from the "reg" head
+    xs = xs.float() + reg[..., 0]
+    ys = ys.float() + reg[..., 1]
+    bb = torch.cat((xs.unsqueeze(-1), ys.unsqueeze(-1), wh), -1)
+    bb[..., ::2] /= W
+    bb[..., 1::2] /= H
+    bb = torch.clamp(bb, min=0, max=1)
+    bb = torch.cat((bb[..., 0:1] - bb[..., 2:3] / 2, bb[..., 1:2] - bb[..., 3:4] / 2, bb[..., 0:1] + bb[..., 2:3] / 2,
+                    bb[..., 1:2] + bb[..., 3:4] / 2), -1)
+    mask = scores >= conf
+    pos = torch.nonzero(mask[0]).flatten()
+    bb, sc, cl = bb[mask], scores[mask], cls[mask]
+    if use_nms and bb.shape[0] > 0:
+        keep = diou_nms(bb, sc, nms_thr)
+        bb, sc, cl, pos = bb[keep], sc[keep], cl[keep], pos[keep]
+    h, w = image_hw                                                 # reverse_letter_box (image_process.py:100-129), xyxy input
+    out = bb.clone()
+    out[..., ::2] *= input_hw[1]
+    out[..., 1::2] *= input_hw[0]
+    scale = max(h / input_hw[0], w / input_hw[1])
+    top = (input_hw[0] - h / scale) // 2
+    left = (input_hw[1] - w / scale) // 2
+    out[..., 0] -= left
+    out[..., 2] -= left
+    out[..., 1] -= top
+    out[..., 3] -= top
+    out *= scale
+    return out, sc, cl, pos

@@ -301,6 +301,60 @@ def main():
         n_params=np.array(sum(p_.numel() for p_ in model.parameters())))
     report["yolov8s"] = dict(loss=float(loss), params=int(sum(p_.numel() for p_ in model.parameters())))
 
+    # ---- 9. CenterNet DLA-34 (BASELINE config 4): init, forward, decode ------------------------------------
+    from oracle import centernet_ref as C
+    torch.manual_seed(0)
+    ccfg, calgo_cls, _ = builder.export_from_registry("centernet")
+    ccfg.dataset.num_classes = 80
+    ccfg.arch.input_size = (3, 128, 128)
+    calgo = calgo_cls(ccfg, torch.device("cpu"))
+    cmodel, cname = calgo.build_model()
+    ref_sd = cmodel.state_dict()
+    my_sd = C.init_state_dict(80, seed=0)
+    assert list(ref_sd.keys()) == list(my_sd.keys()), [(a_, b_) for a_, b_ in zip(ref_sd, my_sd) if a_ != b_][:5]
+    for k in ref_sd:
+        assert ref_sd[k].shape == my_sd[k].shape and torch.equal(ref_sd[k], my_sd[k]), f"CenterNet init mismatch {k}"
+    csums = {k: [float(v.double().sum()), float(v.double().abs().sum())] for k, v in ref_sd.items()}
+    with open(os.path.join(GOLD, "centernet_seed0_init_sums.json"), "w") as f:
+        json.dump(csums, f)
+    g = torch.Generator().manual_seed(41)
+    xc = torch.rand(2, 3, 128, 128, generator=g)
+    cmodel.train()
+    ref_tr = cmodel(xc.clone()).detach()
+    sd_t = {k: v.clone() for k, v in my_sd.items()}
+    my_tr = C.forward(sd_t, xc.clone(), 80, training=True)
+    assert torch.allclose(ref_tr, my_tr, rtol=1e-4, atol=1e-5), float((ref_tr - my_tr).abs().max())
+    for k, v in cmodel.state_dict().items():                    # BN running statistics after one train-mode forward
+        assert torch.allclose(v.float(), sd_t[k].float(), rtol=1e-4, atol=1e-6), k
+    cmodel.eval()
+    with torch.no_grad():
+        ref_ev = cmodel(xc.clone())
+        my_ev = C.forward(sd_t, xc.clone(), 80, training=False)
+    assert torch.allclose(ref_ev, my_ev, rtol=1e-4, atol=1e-5), float((ref_ev - my_ev).abs().max())
+    # decode: the network output of image 0, and a synthetic head output with real peaks
+    gs = torch.Generator().manual_seed(42)
+    synth_pred = torch.cat((torch.randn(1, 32, 32, 80, generator=gs) * 2.5 - 3.0, torch.rand(1, 32, 32, 2, generator=gs),
+                            torch.rand(1, 32, 32, 2, generator=gs) * 12 + 1), -1)
+    dec = {}
+    for tag, pr, hw in (("net", ref_ev[0:1].clone(), (96, 128)), ("synth", synth_pred, (375, 500))):
+        rb, rs, rc = calgo.decode_boxes(pr.clone(), hw[0], hw[1])
+        mb, ms, mc, mpos = C.decode(pr.clone(), 80, (128, 128), hw, k=ccfg.decode.max_boxes_per_img, conf=ccfg.decode.score_threshold,
+                                    nms_thr=ccfg.decode.nms_threshold, use_nms=ccfg.decode.use_nms)
+        assert rb.shape[0] == mb.shape[0] and rb.shape[0] > 3, (tag, rb.shape, mb.shape)
+        assert np.array_equal(rc, mc.numpy()) and np.allclose(rs, ms.numpy(), rtol=0, atol=0), tag
+        assert np.allclose(rb, mb.numpy(), rtol=1e-6, atol=1e-5), tag
+        dec[tag + "_pred"] = pr.numpy().copy()
+        dec[tag + "_hw"] = np.array(hw)
+        dec[tag + "_boxes"], dec[tag + "_scores"], dec[tag + "_classes"], dec[tag + "_pos"] = rb, rs, rc, mpos.numpy()
+    np.savez_compressed(os.path.join(GOLD, "centernet_fwd_128.npz"), x=xc.numpy(), eval_sub=ref_ev.flatten()[::7].numpy().copy(),
+                        train_sub=ref_tr.flatten()[::7].numpy().copy(), eval_norm=np.array(float(ref_ev.norm())),
+                        bn_rm=cmodel.state_dict()["backbone.dla_up.ida_2.node_3.1.running_mean"].numpy().copy(),
+                        bn_rv=cmodel.state_dict()["backbone.base.level_5.root.bn.running_var"].numpy().copy(),
+                        k=np.array(ccfg.decode.max_boxes_per_img), conf=np.array(ccfg.decode.score_threshold),
+                        nms_thr=np.array(ccfg.decode.nms_threshold), **dec)
+    report["centernet"] = dict(init="bit-exact, %d tensors" % len(ref_sd), params=int(sum(p_.numel() for p_ in cmodel.parameters())),
+                               decode={t: int(dec[t + "_boxes"].shape[0]) for t in ("net", "synth")})
+
     # ---- 6. NMS tail fixture (oracle-generated; upstream parity unpinned) ----------------------
     pred = synth.nms_pred(7)
     res = nms_ref.non_max_suppression(pred, 0.25, 0.7, 300)
