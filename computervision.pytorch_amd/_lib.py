@@ -33,13 +33,14 @@ class OpDesc(C.Structure):
         ("act", C.c_int32), ("needs_dgrad", C.c_int32), ("w_cin", C.c_int32),
         ("w_off", C.c_int64), ("gamma_off", C.c_int64), ("beta_off", C.c_int64), ("bias_off", C.c_int64),
         ("rmean_off", C.c_int64), ("rvar_off", C.c_int64),
-        ("lane", C.c_int32), ("reserved_", C.c_int32),
+        ("lane", C.c_int32), ("flags", C.c_int32),
     ]
 
 
 BUF_ACT_F16, BUF_PRED_F32 = 0, 1
-OP_CONV, OP_MAXPOOL5, OP_UPSAMPLE2 = 1, 2, 3
-ACT_BN_SILU, ACT_BIAS = 1, 2
+OP_CONV, OP_MAXPOOL5, OP_UPSAMPLE2, OP_MAXPOOL2, OP_DWCONVT, OP_COPY = 1, 2, 3, 4, 5, 6
+ACT_BN_SILU, ACT_BIAS, ACT_BN_RELU, ACT_BN_LINEAR, ACT_BIAS_RELU = 1, 2, 3, 4, 5
+OPF_RES_PRE_ACT = 1
 
 _P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -83,6 +84,8 @@ PROTOTYPES = {
     "cvx_nms_workspace_bytes": (_I64, [_I32, _I32]),
     "cvx_nms": (_I32, [_P, _I32, _I32, _I32, _F, _F, _I32, _P, _P, _P, _P, _I64, _P]),
     "cvx_nms_variant": (_I32, [_P, _I32, _I32, _I32, _F, _F, _I32, _I32, _P, _P, _P, _P, _I64, _P]),
+    "cvx_centernet_decode_workspace_bytes": (_I64, [_I32, _I32, _I32, _I32]),
+    "cvx_centernet_decode": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _F, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "cvx_conv2d_nhwc": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P]),
     "cvx_conv2d_dgrad_nhwc": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "cvx_conv2d_wgrad_workspace_bytes": (_I64, [_I32, _I32, _I32, _I32, _I32, _I32]),

@@ -42,7 +42,8 @@ struct BnFoldDesc {
   long long rmean_off, rvar_off;  // ... into the statistics arena
   float* scale;                   // outputs (C floats each)
   float* shift;
-  int C, pad_;
+  int C;
+  int bias_only;                  // 1: no BatchNorm -- scale = 1, shift = params[beta_off] (a conv bias feeding an activation)
 };
 int cvx_bn_fold_all(const BnFoldDesc* descs, int n, const float* params, const float* stats, float eps, hipStream_t st);
 int cvx_bn_fold(int n, const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps, float* scale, float* shift,

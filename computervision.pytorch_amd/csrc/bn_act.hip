@@ -33,6 +33,11 @@ __global__ void bn_fold_kernel(int n, const float* gamma, const float* beta, con
 __global__ __launch_bounds__(256) void bn_fold_all_kernel(const BnFoldDesc* descs, const float* params, const float* stats, float eps) {
   const BnFoldDesc d = descs[blockIdx.x];
   for (int i = threadIdx.x; i < d.C; i += 256) {
+    if (d.bias_only) {
+      d.scale[i] = 1.f;
+      d.shift[i] = params[d.beta_off + i];
+      continue;
+    }
     const float sc = params[d.gamma_off + i] / sqrtf(stats[d.rvar_off + i] + eps);
     d.scale[i] = sc;
     d.shift[i] = params[d.beta_off + i] - stats[d.rmean_off + i] * sc;

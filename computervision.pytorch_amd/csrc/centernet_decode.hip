@@ -1,0 +1,241 @@
+// CenterNet heat-map decode on gfx950: sigmoid -> the reference's 3x3 max-pool over (x, class) -> global top-K ->
+// gather + box arithmetic -> score mask -> class-agnostic DIoU-NMS.
+//
+// Reference (file:line under the reference tree): CenterNetA.decode_boxes / _suppress_redundant_centers / _top_k,
+// core/algorithms/centernet.py:271-338; diou_nms, core/utils/nms.py:9-31; box_iou / box_diou, core/utils/iou.py:8-64.
+// Kept quirks: the reference max-pools the NHWC tensor as if it were NCHW, so the 3x3 window spans (x-1..x+1, c-1..c+1)
+// inside one row y (centernet.py:279-280,324); it reads the centre offsets from the "wh" head's two channels and the sizes
+// from the "reg" head's (:276-277); the letterbox inverse stays on the host (a handful of scalars per image).
+// Tie order of the top-K (torch.topk leaves it undefined): score descending, flat (y, x, c) index ascending, as
+// oracle/centernet_ref.py defines it.  All box arithmetic in fp32 with explicit round-to-nearest intrinsics (no FMA
+// contraction): identical operation order to the reference's torch ops.
+//
+//   K1 peak_scores   one thread per (b, y, x, c): window max on the LOGITS (sigmoid is monotone: the arg-max is the same,
+//                    and `heat == hmax` is evaluated on the two sigmoid values exactly as the reference does) -> fp32 scores
+//   K2 select        one 1024-thread workgroup per image: 3-pass radix select of the K-th largest score (LDS histograms),
+//                    collection of the candidates, in-LDS bitonic sort, boxes, mask, greedy DIoU-NMS by one wave
+#include <cstring>
+
+#include "../../include/cvx_engine.h"
+#include "cvx_common.h"
+
+namespace {
+
+constexpr int SEL_THREADS = 1024;
+constexpr int CAND_CAP = 2048;  // top-K candidates incl. score ties the LDS sort holds
+constexpr int MAX_K = 256;
+
+__device__ __forceinline__ float sigmoid_ref(float x) {  // 1 / (1 + exp(-x)) in fp32, the reference's torch.sigmoid arithmetic
+  return __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x)));
+}
+
+__global__ __launch_bounds__(256) void peak_scores_kernel(const float* pred, int ld, int B, int H, int W, int C, float* scores) {
+  const long long n = (long long)B * H * W * C;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % C);
+  const long long pix = i / C;  // b*H*W + y*W + x
+  const int x = (int)(pix % W);
+  const float* row = pred + pix * ld;
+  const float v = row[c];
+  float m = v;
+#pragma unroll
+  for (int dx = -1; dx <= 1; ++dx) {
+    if ((unsigned)(x + dx) >= (unsigned)W) continue;
+    const float* r = row + (long long)dx * ld;
+#pragma unroll
+    for (int dc = -1; dc <= 1; ++dc)
+      if ((unsigned)(c + dc) < (unsigned)C) m = fmaxf(m, r[c + dc]);
+  }
+  const float s = sigmoid_ref(v);
+  scores[i] = (m == v || sigmoid_ref(m) == s) ? s : 0.f;
+}
+
+struct DecodeOut {
+  float* boxes;  // [B][K][4] xyxy in [0, 1]
+  float* scores;
+  int* classes;
+  int* topk_index;  // [B][K] flat (y*W + x)*C + c of every top-K entry (before mask / NMS)
+  int* keep;        // [B][K] positions (0..K-1) in the top-K list of the survivors, descending score
+  int* counts;      // [B] survivors; -1: more than CAND_CAP candidates tie at the K-th score
+};
+
+__device__ __forceinline__ float diou(const float4& a, const float4& b) {  // core/utils/iou.py:8-64
+  const float eps = 1e-6f;
+  const float a1 = __fmul_rn(__fsub_rn(a.z, a.x), __fsub_rn(a.w, a.y));
+  const float a2 = __fmul_rn(__fsub_rn(b.z, b.x), __fsub_rn(b.w, b.y));
+  const float iw = fmaxf(__fsub_rn(fminf(a.z, b.z), fmaxf(a.x, b.x)), 0.f);
+  const float ih = fmaxf(__fsub_rn(fminf(a.w, b.w), fmaxf(a.y, b.y)), 0.f);
+  const float inter = __fmul_rn(iw, ih);
+  const float iou = __fdiv_rn(inter, fmaxf(__fsub_rn(__fadd_rn(a1, a2), inter), eps));
+  const float cx1 = __fdiv_rn(__fadd_rn(a.x, a.z), 2.f), cy1 = __fdiv_rn(__fadd_rn(a.y, a.w), 2.f);
+  const float cx2 = __fdiv_rn(__fadd_rn(b.x, b.z), 2.f), cy2 = __fdiv_rn(__fadd_rn(b.y, b.w), 2.f);
+  const float ew = fmaxf(__fsub_rn(fmaxf(a.z, b.z), fminf(a.x, b.x)), 0.f);
+  const float eh = fmaxf(__fsub_rn(fmaxf(a.w, b.w), fminf(a.y, b.y)), 0.f);
+  const float c_sq = __fadd_rn(__fmul_rn(ew, ew), __fmul_rn(eh, eh));
+  const float dx = __fsub_rn(cx1, cx2), dy = __fsub_rn(cy1, cy2);
+  const float d_sq = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+  return __fsub_rn(iou, __fdiv_rn(d_sq, fmaxf(c_sq, eps)));
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void select_kernel(const float* pred, int ld, int H, int W, int C, int reg_off, int wh_off,
+                                                             const float* scores, int K, float conf, float nms_thr, int use_nms,
+                                                             DecodeOut o) {
+  __shared__ unsigned hist[2048];
+  __shared__ unsigned long long cand[CAND_CAP];
+  __shared__ unsigned s_prefix, s_remaining, s_ncand;
+  __shared__ float4 s_box[MAX_K];
+  __shared__ unsigned char s_alive[MAX_K];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const long long N = (long long)H * W * C;
+  const float* sc = scores + (long long)b * N;
+  const unsigned* key = reinterpret_cast<const unsigned*>(sc);  // scores are >= 0: the bit patterns order like the values
+
+  // ---- 1. radix select: bit pattern T of the K-th largest score (11 + 11 + 10 bits, most significant first) ----
+  if (tid == 0) {
+    s_prefix = 0;
+    s_remaining = (unsigned)K;
+  }
+  const int shifts[3] = {21, 10, 0};
+  const int widths[3] = {11, 11, 10};
+  unsigned known_mask = 0;
+  for (int pass = 0; pass < 3; ++pass) {
+    for (int i = tid; i < 2048; i += SEL_THREADS) hist[i] = 0;
+    __syncthreads();
+    const unsigned prefix = s_prefix;
+    const int sh = shifts[pass];
+    const unsigned mask = (1u << widths[pass]) - 1;
+    for (long long i = tid; i < N; i += SEL_THREADS) {
+      const unsigned k = key[i];
+      if ((k & known_mask) == prefix) atomicAdd(&hist[(k >> sh) & mask], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {  // walk the bins from the top: the bin that holds the remaining-th largest
+      unsigned rem = s_remaining;
+      int bin = (int)mask;
+      for (; bin > 0; --bin) {
+        if (hist[bin] >= rem) break;
+        rem -= hist[bin];
+      }
+      s_remaining = rem;
+      s_prefix = prefix | ((unsigned)bin << sh);
+    }
+    __syncthreads();
+    known_mask |= mask << sh;
+  }
+  const unsigned T = s_prefix;  // K-th largest score; s_remaining of the elements equal to T belong to the top K
+  // ---- 2. candidates: every element > T, and the elements == T (ordered by index by the sort below) ----
+  if (tid == 0) s_ncand = 0;
+  __syncthreads();
+  for (long long i = tid; i < N; i += SEL_THREADS) {
+    const unsigned k = key[i];
+    if (k >= T && k != 0) {  // zero = suppressed / never a detection (conf > 0): a top-K that reaches into the zeros is cut short
+      const unsigned slot = atomicAdd(&s_ncand, 1u);
+      if (slot < CAND_CAP) cand[slot] = ((unsigned long long)(0xFFFFFFFFu - k) << 32) | (unsigned)i;
+    }
+  }
+  __syncthreads();
+  const unsigned ncand = s_ncand;
+  if (ncand > CAND_CAP) {  // more ties at the K-th score than the sort holds (only a flat heat-map does this)
+    if (tid == 0) o.counts[b] = -1;
+    return;
+  }
+  unsigned cap2 = 1;
+  while (cap2 < ncand) cap2 <<= 1;
+  for (unsigned i = ncand + tid; i < cap2; i += SEL_THREADS) cand[i] = ~0ull;
+  __syncthreads();
+  for (unsigned k = 2; k <= cap2; k <<= 1)
+    for (unsigned j = k >> 1; j > 0; j >>= 1) {
+      for (unsigned i = tid; i < cap2; i += SEL_THREADS) {
+        const unsigned l = i ^ j;
+        if (l > i) {
+          const unsigned long long x = cand[i], z = cand[l];
+          const bool up = (i & k) == 0;
+          if ((x > z) == up) {
+            cand[i] = z;
+            cand[l] = x;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  // ---- 3. the K winners: class, pixel, box (centernet.py:282-297) ----
+  const int kk = min(K, (int)ncand);
+  if (tid < kk) {
+    const unsigned idx = (unsigned)(cand[tid] & 0xFFFFFFFFu);
+    const int c = (int)(idx % (unsigned)C);
+    const unsigned pix = idx / (unsigned)C;
+    const int y = (int)(pix / (unsigned)W), x = (int)(pix % (unsigned)W);
+    const float* row = pred + ((long long)b * H * W + pix) * ld;
+    const float score = sc[idx];
+    float cx = __fadd_rn((float)x, row[reg_off]), cy = __fadd_rn((float)y, row[reg_off + 1]);
+    float bw = row[wh_off], bh = row[wh_off + 1];
+    cx = fminf(fmaxf(__fdiv_rn(cx, (float)W), 0.f), 1.f);
+    bw = fminf(fmaxf(__fdiv_rn(bw, (float)W), 0.f), 1.f);
+    cy = fminf(fmaxf(__fdiv_rn(cy, (float)H), 0.f), 1.f);
+    bh = fminf(fmaxf(__fdiv_rn(bh, (float)H), 0.f), 1.f);
+    const float hw2 = __fdiv_rn(bw, 2.f), hh2 = __fdiv_rn(bh, 2.f);
+    const float4 bx = make_float4(__fsub_rn(cx, hw2), __fsub_rn(cy, hh2), __fadd_rn(cx, hw2), __fadd_rn(cy, hh2));
+    s_box[tid] = bx;
+    s_alive[tid] = score >= conf ? 1 : 0;
+    float* ob = o.boxes + ((long long)b * K + tid) * 4;
+    ob[0] = bx.x;
+    ob[1] = bx.y;
+    ob[2] = bx.z;
+    ob[3] = bx.w;
+    o.scores[(long long)b * K + tid] = score;
+    o.classes[(long long)b * K + tid] = c;
+    o.topk_index[(long long)b * K + tid] = (int)idx;
+  }
+  if (tid >= kk && tid < K) {  // fewer than K non-zero peaks: the rest of the list is empty
+    float* ob = o.boxes + ((long long)b * K + tid) * 4;
+    ob[0] = ob[1] = ob[2] = ob[3] = 0.f;
+    o.scores[(long long)b * K + tid] = 0.f;
+    o.classes[(long long)b * K + tid] = 0;
+    o.topk_index[(long long)b * K + tid] = -1;
+  }
+  __syncthreads();
+  // ---- 4. score mask + greedy DIoU-NMS in list order (core/utils/nms.py:9-31), one wave ----
+  if (tid < 64) {
+    int nkeep = 0;
+    for (int i = 0; i < kk; ++i) {
+      if (!s_alive[i]) continue;  // wave-uniform (LDS)
+      if (tid == 0) o.keep[(long long)b * K + nkeep] = i;
+      ++nkeep;
+      if (use_nms) {
+        const float4 bi = s_box[i];
+        for (int j = i + 1 + tid; j < kk; j += 64)
+          if (s_alive[j] && !(diou(bi, s_box[j]) <= nms_thr)) s_alive[j] = 0;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (tid == 0) o.counts[b] = nkeep;
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t cvx_centernet_decode_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t nc) {
+  return (int64_t)B * H * W * nc * 4 + 256;
+}
+
+extern "C" int cvx_centernet_decode(const float* pred, int32_t pred_ld, int32_t B, int32_t H, int32_t W, int32_t nc, int32_t reg_col,
+                                    int32_t wh_col, int32_t K, float conf, float nms_thr, int32_t use_nms, float* boxes, float* scores,
+                                    int32_t* classes, int32_t* topk_index, int32_t* keep, int32_t* counts, void* workspace,
+                                    int64_t workspace_bytes, void* hip_stream) {
+  CVX_CHECK(pred && boxes && scores && classes && topk_index && keep && counts && workspace, "null arguments");
+  CVX_CHECK(B > 0 && H > 0 && W > 0 && nc > 0 && K >= 1 && K <= MAX_K, "bad sizes (1 <= K <= 256)");
+  CVX_CHECK((long long)H * W * nc < (1LL << 31) && (long long)H * W * nc >= K, "heat-map size");
+  CVX_CHECK(pred_ld >= nc && reg_col >= 0 && reg_col + 2 <= pred_ld && wh_col >= 0 && wh_col + 2 <= pred_ld, "column offsets");
+  CVX_CHECK(workspace_bytes >= cvx_centernet_decode_workspace_bytes(B, H, W, nc), "workspace too small");
+  hipStream_t st = (hipStream_t)hip_stream;
+  float* ws = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  const long long n = (long long)B * H * W * nc;
+  hipLaunchKernelGGL(peak_scores_kernel, dim3(cvx_cdiv(n, 256)), dim3(256), 0, st, pred, pred_ld, B, H, W, nc, ws);
+  DecodeOut o{boxes, scores, classes, topk_index, keep, counts};
+  hipLaunchKernelGGL(select_kernel, dim3(B), dim3(SEL_THREADS), 0, st, pred, pred_ld, H, W, nc, reg_col, wh_col, ws, K, conf, nms_thr, use_nms, o);
+  CVX_HIP(hipGetLastError());
+  return 0;
+}

@@ -8,7 +8,7 @@
 
 enum {
   CVX_EPI_RAW_STATS = 0,    // train fwd: raw conv output FP32 (out32) + per-channel (sum, sumsq) into the fixed-point replica slabs
-  CVX_EPI_AFFINE_SILU = 1,  // eval fwd: y*scale+shift -> SiLU (+residual) -> fp16
+  CVX_EPI_AFFINE_SILU = 1,  // eval fwd: act(y*scale+shift [+res]) [+res] -> fp16; act / residual order: ConvParams::act_kind, res_pre
   CVX_EPI_BIAS_F32 = 2,     // head output: +bias -> fp32
   CVX_EPI_PLAIN = 3,        // dgrad: fp16 store (optionally accumulate into the destination)
 };
@@ -49,6 +49,8 @@ struct ConvParams {
   long long res_bstride;
   int res_ld;
   const float* scale;  // AFFINE_SILU
+  int act_kind;        // AFFINE_SILU: 0 SiLU (YOLO), 1 ReLU, 2 none (DLA / heads)
+  int res_pre;         // AFFINE_SILU: 1 = the residual is added BEFORE the activation (DLA BasicBlock), 0 = after (YOLO Bottleneck)
   const float* shift;  // AFFINE_SILU
   const float* bias;   // BIAS_F32
   long long* stats;    // RAW_STATS: [stats_replicas][Cout][2] fixed-point values of CVX_FIX_WORDS words (cvx_fix_atomic_add), zero on entry

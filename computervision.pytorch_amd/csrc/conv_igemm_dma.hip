@@ -272,11 +272,27 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
         f4 sc = *reinterpret_cast<const f4*>(p.scale + n0);
         f4 sh = *reinterpret_cast<const f4*>(p.shift + n0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = cvx_silu(v[r] * sc[r] + sh[r]);
+        for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[r] + sh[r];
+        f4 rv = {0.f, 0.f, 0.f, 0.f};
         if (p.res) {
           h4 rr = *reinterpret_cast<const h4*>(p.res + res_off[i] + n0);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+          for (int r = 0; r < 4; ++r) rv[r] = (float)rr[r];
+        }
+        if (p.res_pre) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += rv[r];
+        }
+        if (p.act_kind == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = cvx_silu(v[r]);
+        } else if (p.act_kind == 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (!p.res_pre) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += rv[r];
         }
       } else if (p.epi == CVX_EPI_BIAS_F32) {
         f4 bb = *reinterpret_cast<const f4*>(p.bias + n0);

@@ -108,8 +108,10 @@ struct cvx_engine {
   hipStream_t red = nullptr;     // gradient-slab reduction (whole-pass backward): off the main chain as well
   hipEvent_t ev_red = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool image_nhwc = false;            // a non-stem op reads the image: keep an NHWC fp16 copy (channels padded to 8)
   float* ytmp = nullptr;              // raw fp32 conv output of the layer in flight (training forward), shared by all layers
   const float* last_images = nullptr;  // the caller's images of the last training forward (the stem's weight gradient reads them)
+  bool inference_only = false;         // the graph holds ops / epilogues without a backward pass (DLA-34): eval forward only
   int64_t plan_generation = 0;         // bumped whenever plan_batch re-allocates: captured hipGraphs hold raw buffer pointers
   float* slabs = nullptr;
   SlabDesc* d_slab = nullptr;
@@ -238,16 +240,25 @@ int build_static(cvx_engine* e) {
   for (int i = 0; i < nops; ++i) {
     const cvx_op_desc& o = e->ops[i];
     CVX_CHECK(o.in.buf >= 0 && o.in.buf < (int)e->bufs.size() && o.out.buf >= 0 && o.out.buf < (int)e->bufs.size(), "op view buffer index");
-    if (o.type != CVX_OP_CONV) continue;
+    CVX_CHECK(o.type >= CVX_OP_CONV && o.type <= CVX_OP_COPY, "unknown op type");
+    if (o.type >= CVX_OP_MAXPOOL2 || (o.type == CVX_OP_CONV && o.act >= CVX_ACT_BN_RELU)) e->inference_only = true;
+    if (o.type != CVX_OP_CONV) {
+      CVX_CHECK(o.in.c % 8 == 0 && o.in.coff % 8 == 0 && o.out.coff % 8 == 0 && o.in.c == o.out.c, "pool / resample / copy views: equal, 8-aligned channel slices");
+      continue;
+    }
     ConvRt& c = e->conv[i];
     const int T = o.k * o.k;
     CVX_CHECK(T <= CVX_MAX_TAPS, "kernel too large");
     if (o.in.buf == e->image_buf) {
-      // the image is read as the caller's NCHW fp32 tensor by the fp32 stem kernels; no fp16 NHWC copy of it exists
-      CVX_CHECK(o.w_cin == 3 && o.k == 3 && o.stride == 2 && o.pad == 1 && o.dil == 1 && o.act == CVX_ACT_BN_SILU && !o.needs_dgrad &&
-                    o.res.buf < 0 && o.out.c % 16 == 0 && o.out.c <= 80 && o.ih % 2 == 0 && o.iw % 2 == 0,
-                "the op that reads the image must be the 3 -> 16..80 channel 3x3 stride-2 BN+SiLU stem (stem.hip)");
-      c.stem = true;
+      // YOLO stem: read as the caller's NCHW fp32 tensor by the fp32 stem kernels; no fp16 NHWC copy of the image exists.
+      // Any other first layer (DLA's 7x7): inference-only, through an NHWC fp16 copy with the channels padded to 8.
+      c.stem = o.w_cin == 3 && o.k == 3 && o.stride == 2 && o.pad == 1 && o.dil == 1 && o.act == CVX_ACT_BN_SILU && !o.needs_dgrad &&
+               o.res.buf < 0 && o.out.c % 16 == 0 && o.out.c <= 80 && o.ih % 2 == 0 && o.iw % 2 == 0;
+      if (!c.stem) {
+        CVX_CHECK(o.w_cin == 3 && !o.needs_dgrad, "an op that reads the image needs 3 stored input channels and no data gradient");
+        e->inference_only = true;
+        e->image_nhwc = true;
+      }
     }
     CVX_CHECK(o.in.c % 8 == 0 && o.out.c % 8 == 0 && o.in.coff % 8 == 0 && o.out.coff % 8 == 0, "conv views must be 8-channel aligned");
     CVX_CHECK(o.w_cin <= o.in.c && o.w_cin > o.in.c - 8, "w_cin vs view channels");
@@ -335,6 +346,7 @@ int build_static(cvx_engine* e) {
       }
     }
   }
+  if (e->inference_only) return 0;  // no backward pass exists for these graphs
   // ---- backward write/accumulate plan -----------------------------------------------------
   std::vector<std::vector<char>> written(e->bufs.size());
   for (size_t b = 0; b < e->bufs.size(); ++b) written[b].assign(e->bufs[b].d.c, 0);
@@ -376,7 +388,7 @@ int plan_batch(cvx_engine* e, int B, bool training) {
   for (size_t bi = 0; bi < e->bufs.size(); ++bi) {
     Buf& b = e->bufs[bi];
     b.act = b.grad = nullptr;
-    if (b.d.kind != CVX_BUF_ACT_F16 || (int)bi == e->image_buf) continue;
+    if (b.d.kind != CVX_BUF_ACT_F16 || ((int)bi == e->image_buf && !e->image_nhwc)) continue;
     long long bytes = (long long)B * b.d.h * b.d.w * b.d.c * 2;
     CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, bytes));
     b.act = (half_t*)p;
@@ -409,7 +421,10 @@ int plan_batch(cvx_engine* e, int B, bool training) {
     c.invstd = c.mean + C;
     c.scale = c.invstd + C;
     c.shift = c.scale + C;
-    if (o.act == CVX_ACT_BN_SILU) folds.push_back(BnFoldDesc{o.gamma_off, o.beta_off, o.rmean_off, o.rvar_off, c.scale, c.shift, C, 0});
+    if (o.act == CVX_ACT_BN_SILU || o.act == CVX_ACT_BN_RELU || o.act == CVX_ACT_BN_LINEAR)
+      folds.push_back(BnFoldDesc{o.gamma_off, o.beta_off, o.rmean_off, o.rvar_off, c.scale, c.shift, C, 0});
+    else if (o.act == CVX_ACT_BIAS_RELU)
+      folds.push_back(BnFoldDesc{0, o.bias_off, 0, 0, c.scale, c.shift, C, 1});
     if (training && o.act == CVX_ACT_BN_SILU) {
       CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, M * C * 2));
       c.ybuf = (half_t*)p;
@@ -624,9 +639,10 @@ extern "C" int cvx_engine_bind(cvx_engine* e, float* params, float* grads, int64
   CVX_CHECK(e && params && stats, "null arguments");
   CVX_CHECK(((uintptr_t)params % 16) == 0 && ((uintptr_t)grads % 16) == 0, "arenas must be 16-byte aligned");
   for (const cvx_op_desc& o : e->ops) {
+    if (o.type == CVX_OP_DWCONVT) CVX_CHECK(o.w_off >= 0 && o.w_off + (int64_t)o.out.c * 4 * o.stride * o.stride <= n_params, "dwconvt weight offset");
     if (o.type != CVX_OP_CONV) continue;
     CVX_CHECK(o.w_off >= 0 && o.w_off + (int64_t)o.out.c * o.k * o.k * o.w_cin <= n_params, "weight offset out of range");
-    if (o.act == CVX_ACT_BN_SILU) {
+    if (o.act == CVX_ACT_BN_SILU || o.act == CVX_ACT_BN_RELU || o.act == CVX_ACT_BN_LINEAR) {
       CVX_CHECK(o.gamma_off >= 0 && o.gamma_off + o.out.c <= n_params && o.beta_off >= 0 && o.beta_off + o.out.c <= n_params, "bn offsets");
       CVX_CHECK(o.rmean_off >= 0 && o.rmean_off + o.out.c <= n_stats && o.rvar_off >= 0 && o.rvar_off + o.out.c <= n_stats, "stat offsets");
       CVX_CHECK(o.gamma_off % 4 == 0 && o.beta_off % 4 == 0 && o.rmean_off % 4 == 0 && o.rvar_off % 4 == 0, "bn offsets must be 4-aligned");
@@ -666,6 +682,7 @@ extern "C" int64_t cvx_engine_plan_generation(const cvx_engine* e) { return e ? 
 extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t batch, int32_t training, float* pred) {
   CVX_CHECK(e && images && pred && batch > 0, "bad arguments");
   CVX_CHECK(e->params, "cvx_engine_bind was not called");
+  CVX_CHECK(!(training && e->inference_only), "this graph holds inference-only ops: training-mode forward is not available");
   CVX_HIP(hipSetDevice(e->device));
   CVX_TRY(plan_batch(e, batch, training != 0));
   hipStream_t st = e->stream;
@@ -679,6 +696,7 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
     CVX_TRY(cvx_pack_weights(e->params, e->shadow, e->d_pack, e->d_pack_blocks, e->n_pack_blocks, st));
   }
   e->last_images = training ? images : nullptr;
+  if (e->image_nhwc) CVX_TRY(cvx_image_to_nhwc8(images, B, ib.d.h, ib.d.w, ib.act, st));
   const Buf& pb = e->bufs[e->pred_buf];
   const long long A = (long long)pb.d.h * pb.d.w;
   if (!training) CVX_TRY(cvx_bn_fold_all(e->d_fold, e->n_fold, e->params, e->stats, e->bn_eps, st));  // eval: running stats -> scale/shift
@@ -695,6 +713,21 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
     if (o.type == CVX_OP_UPSAMPLE2) {
       ProfScope ps(e, PROF_MISC, 0, 10.0 * B * o.ih * o.iw * o.in.c, st);
       CVX_TRY(cvx_upsample2_fwd(make_view(e, o.in, false), make_view(e, o.out, false), B, o.ih, o.iw, o.in.c, st));
+      continue;
+    }
+    if (o.type == CVX_OP_MAXPOOL2) {
+      ProfScope ps(e, PROF_MISC, 0, 2.5 * B * o.ih * o.iw * o.in.c, st);
+      CVX_TRY(cvx_maxpool2(make_view(e, o.in, false), make_view(e, o.out, false), B, o.oh, o.ow, o.in.c, st));
+      continue;
+    }
+    if (o.type == CVX_OP_DWCONVT) {
+      ProfScope ps(e, PROF_MISC, 0, 2.0 * B * (o.ih * o.iw + o.oh * o.ow) * o.in.c, st);
+      CVX_TRY(cvx_dwconvt(make_view(e, o.in, false), make_view(e, o.out, false), e->params + o.w_off, B, o.ih, o.iw, o.in.c, o.stride, st));
+      continue;
+    }
+    if (o.type == CVX_OP_COPY) {
+      ProfScope ps(e, PROF_MISC, 0, 4.0 * B * o.ih * o.iw * o.in.c, st);
+      CVX_TRY(cvx_copy_slice(make_view(e, o.in, false), make_view(e, o.out, false), B, o.ih * o.iw, o.in.c, st));
       continue;
     }
     ConvRt& c = e->conv[i];
@@ -752,6 +785,8 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
     } else {
       // scale / shift were folded for every layer at once before the op loop (cvx_bn_fold_all)
       cp.epi = CVX_EPI_AFFINE_SILU;
+      cp.act_kind = o.act == CVX_ACT_BN_SILU ? 0 : (o.act == CVX_ACT_BN_LINEAR ? 2 : 1);
+      cp.res_pre = (o.flags & CVX_OPF_RES_PRE_ACT) ? 1 : 0;
       cp.scale = c.scale;
       cp.shift = c.shift;
       cp.out16 = outv.p;

@@ -2,6 +2,12 @@
 #pragma once
 #include "bn_act.h"
 
+int cvx_image_to_nhwc8(const float* img_nchw, int B, int H, int W, half_t* out, hipStream_t st);
+// 2x2 / stride 2 max pool, depthwise ConvTranspose2d (kernel 2f, stride f, padding f/2; w fp32 [C][2f][2f]), channel-slice copy
+int cvx_maxpool2(const ViewDesc& in, const ViewDesc& out, int B, int OH, int OW, int C, hipStream_t st);
+int cvx_dwconvt(const ViewDesc& in, const ViewDesc& out, const float* w, int B, int IH, int IW, int C, int f, hipStream_t st);
+int cvx_copy_slice(const ViewDesc& in, const ViewDesc& out, int B, int HW, int C, hipStream_t st);
+
 // 5x5 / stride 1 / pad 2 max pool on channel-slice views; idx (optional, train) records the argmax
 // tap (0..24, first max in row-major window order as torch does) per output element: [B*H*W][C] bytes.
 int cvx_maxpool5_fwd(const ViewDesc& in, const ViewDesc& out, int B, int H, int W, int C, uint8_t* idx, hipStream_t st);

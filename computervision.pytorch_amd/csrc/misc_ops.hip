@@ -6,6 +6,89 @@ namespace {
 
 __device__ __forceinline__ long long voff(const ViewDesc& v, int b, long long pix) { return (long long)b * v.bstride + pix * v.ld; }
 
+// ---- NCHW fp32 image -> NHWC fp16 with C padded 3 -> 8 (16 B per pixel): first layers other than the YOLO stem ----
+__global__ void image_to_nhwc8_kernel(const float* img, int B, int HW, half_t* out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long n = (long long)B * HW;
+  if (i >= n) return;
+  long long b = i / HW, pix = i - b * HW;
+  const float* src = img + b * 3 * HW + pix;
+  h8 o = {(half_t)src[0], (half_t)src[HW], (half_t)src[2LL * HW], (half_t)0, (half_t)0, (half_t)0, (half_t)0, (half_t)0};
+  *reinterpret_cast<h8*>(out + i * 8) = o;
+}
+
+// ---- max pool 2x2 stride 2 (DLA Tree.downsample, centernet_model.py:128-129) ----
+__global__ void maxpool2_kernel(ViewDesc in, ViewDesc out, int B, int OH, int OW, int CG) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long n = (long long)B * OH * OW * CG;
+  if (i >= n) return;
+  int cg = (int)(i % CG);
+  long long t = i / CG;
+  int w = (int)(t % OW);
+  t /= OW;
+  int h = (int)(t % OH);
+  int b = (int)(t / OH);
+  const int IW = 2 * OW;
+  h8 v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    v[q] = *reinterpret_cast<const h8*>(in.p + voff(in, b, (long long)(2 * h + (q >> 1)) * IW + 2 * w + (q & 1)) + cg * 8);
+  h8 o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = (half_t)fmaxf(fmaxf((float)v[0][k], (float)v[1][k]), fmaxf((float)v[2][k], (float)v[3][k]));
+  *reinterpret_cast<h8*>(out.p + voff(out, b, (long long)h * OW + w) + cg * 8) = o;
+}
+
+// ---- depthwise ConvTranspose2d, kernel 2f, stride f, padding f/2 (IDAUp.up_i, centernet_model.py:256): every output pixel
+// receives exactly 2 x 2 taps.  w: fp32 [C][2f][2f] (the master tensor), out = sum_{ky,kx} in[(oy + p - ky) / f][..] * w[c][ky][kx] ----
+__global__ void dwconvt_kernel(ViewDesc in, ViewDesc out, const float* w, int B, int IH, int IW, int CG, int f) {
+  const int OH = IH * f, OW = IW * f, K = 2 * f, P = f / 2;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long n = (long long)B * OH * OW * CG;
+  if (i >= n) return;
+  int cg = (int)(i % CG);
+  long long t = i / CG;
+  int ox = (int)(t % OW);
+  t /= OW;
+  int oy = (int)(t % OH);
+  int b = (int)(t / OH);
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  const int ky0 = (oy + P) % f, kx0 = (ox + P) % f;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int ky = ky0 + a * f;
+    const int iy = (oy + P - ky) / f;  // exact
+    if (ky >= K || iy < 0 || iy >= IH) continue;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int kx = kx0 + c * f;
+      const int ix = (ox + P - kx) / f;
+      if (kx >= K || ix < 0 || ix >= IW) continue;
+      const h8 v = *reinterpret_cast<const h8*>(in.p + voff(in, b, (long long)iy * IW + ix) + cg * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] = fmaf((float)v[k], w[((long long)(cg * 8 + k) * K + ky) * K + kx], acc[k]);
+    }
+  }
+  h8 o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = (half_t)acc[k];
+  *reinterpret_cast<h8*>(out.p + voff(out, b, (long long)oy * OW + ox) + cg * 8) = o;
+}
+
+// ---- channel-slice copy (a tensor that must also live in a second concat buffer) ----
+__global__ void copy_slice_kernel(ViewDesc in, ViewDesc out, int B, int HW, int CG) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long n = (long long)B * HW * CG;
+  if (i >= n) return;
+  int cg = (int)(i % CG);
+  long long t = i / CG;
+  int pix = (int)(t % HW);
+  int b = (int)(t / HW);
+  *reinterpret_cast<h8*>(out.p + voff(out, b, pix) + cg * 8) = *reinterpret_cast<const h8*>(in.p + voff(in, b, pix) + cg * 8);
+}
+
 // ---- max pool 5x5 s1 p2 ------------------------------------------------------------------------
 __global__ void maxpool5_fwd_kernel(ViewDesc in, ViewDesc out, int B, int H, int W, int CG, uint8_t* idx) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -310,6 +393,19 @@ int launch1d(K kern, long long n, hipStream_t st, Args... args) {
 
 }  // namespace
 
+int cvx_image_to_nhwc8(const float* img, int B, int H, int W, half_t* out, hipStream_t st) {
+  return launch1d(image_to_nhwc8_kernel, (long long)B * H * W, st, img, B, H * W, out);
+}
+int cvx_maxpool2(const ViewDesc& in, const ViewDesc& out, int B, int OH, int OW, int C, hipStream_t st) {
+  return launch1d(maxpool2_kernel, (long long)B * OH * OW * (C / 8), st, in, out, B, OH, OW, C / 8);
+}
+int cvx_dwconvt(const ViewDesc& in, const ViewDesc& out, const float* w, int B, int IH, int IW, int C, int f, hipStream_t st) {
+  CVX_CHECK(f >= 2 && f % 2 == 0, "dwconvt: stride must be even (kernel 2f, padding f/2)");
+  return launch1d(dwconvt_kernel, (long long)B * IH * f * IW * f * (C / 8), st, in, out, w, B, IH, IW, C / 8, f);
+}
+int cvx_copy_slice(const ViewDesc& in, const ViewDesc& out, int B, int HW, int C, hipStream_t st) {
+  return launch1d(copy_slice_kernel, (long long)B * HW * (C / 8), st, in, out, B, HW, C / 8);
+}
 int cvx_maxpool5_fwd(const ViewDesc& in, const ViewDesc& out, int B, int H, int W, int C, uint8_t* idx, hipStream_t st) {
   CVX_CHECK(C % 8 == 0, "maxpool5: C % 8");
   return launch1d(maxpool5_fwd_kernel, (long long)B * H * W * (C / 8), st, in, out, B, H, W, C / 8, idx);

@@ -248,3 +248,29 @@ def nms(y: torch.Tensor, conf_thres: float, iou_thres: float, max_det: int = 300
     L.check(lib.cvx_nms_variant(L.ptr(y), B, A, nc, conf_thres, iou_thres, max_det, NMS_VARIANTS[variant], L.ptr(rows), L.ptr(index),
                                 L.ptr(counts), L.ptr(ws), ws.numel(), L.stream_ptr(y.device)), "cvx_nms")
     return rows, index, counts
+
+
+_cn_ws = {}
+
+
+def centernet_decode(pred: torch.Tensor, h: int, w: int, nc: int, reg_col: int, wh_col: int, k: int = 100, conf: float = 0.1,
+                     nms_thr: float = 0.5, use_nms: bool = True):
+    """pred (B, h*w, ld) fp32 head tensor -> dict(boxes (B,k,4) xyxy in [0,1], scores, classes, topk_index, keep, counts), on device
+    (cvx_centernet_decode, include/cvx_engine.h)."""
+    lib = L.load()
+    _need_gpu(pred, "pred")
+    pred = pred.contiguous().float()
+    B, hw, ld = pred.shape
+    assert hw == h * w
+    need = int(lib.cvx_centernet_decode_workspace_bytes(B, h, w, nc))
+    ws = _cn_ws.get(pred.device)
+    if ws is None or ws.numel() < need:
+        ws = _cn_ws[pred.device] = torch.empty(need, dtype=torch.uint8, device=pred.device)
+    dev = pred.device
+    out = dict(boxes=torch.zeros(B, k, 4, device=dev), scores=torch.zeros(B, k, device=dev),
+               classes=torch.zeros(B, k, dtype=torch.int32, device=dev), topk_index=torch.zeros(B, k, dtype=torch.int32, device=dev),
+               keep=torch.zeros(B, k, dtype=torch.int32, device=dev), counts=torch.zeros(B, dtype=torch.int32, device=dev))
+    L.check(lib.cvx_centernet_decode(L.ptr(pred), ld, B, h, w, nc, reg_col, wh_col, k, float(conf), float(nms_thr), 1 if use_nms else 0,
+                                     L.ptr(out["boxes"]), L.ptr(out["scores"]), L.ptr(out["classes"]), L.ptr(out["topk_index"]),
+                                     L.ptr(out["keep"]), L.ptr(out["counts"]), L.ptr(ws), ws.numel(), L.stream_ptr(dev)), "cvx_centernet_decode")
+    return out

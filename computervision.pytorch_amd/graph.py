@@ -220,6 +220,7 @@ class Graph:
             for f in ("w_off", "gamma_off", "beta_off", "bias_off", "rmean_off", "rvar_off"):
                 setattr(d, f, o.get(f, 0))
             d.lane = o.get("lane", 0)
+            d.flags = o.get("flags", 0)
         return bufs, ops
 
 

@@ -37,8 +37,17 @@ typedef struct {
   int32_t pix_off; /* first pixel row (PRED buffers: anchor offset of the level), else 0 */
 } cvx_view;
 
-enum { CVX_OP_CONV = 1, CVX_OP_MAXPOOL5 = 2, CVX_OP_UPSAMPLE2 = 3 };
-enum { CVX_ACT_BN_SILU = 1, CVX_ACT_BIAS = 2 };
+enum { CVX_OP_CONV = 1, CVX_OP_MAXPOOL5 = 2, CVX_OP_UPSAMPLE2 = 3,
+       /* inference-only ops (DLA-34 / CenterNet, core/models/centernet_model.py): */
+       CVX_OP_MAXPOOL2 = 4, /* 2x2 stride-2 max pool (Tree.downsample, :128-129) */
+       CVX_OP_DWCONVT = 5,  /* depthwise ConvTranspose2d, kernel 2*stride, padding stride/2 (IDAUp.up_i, :256); w_off -> fp32 [C][2f][2f] */
+       CVX_OP_COPY = 6 };   /* channel-slice copy (a tensor that lives in two concat buffers) */
+enum { CVX_ACT_BN_SILU = 1, CVX_ACT_BIAS = 2,
+       /* inference-only epilogues (folded BatchNorm): */
+       CVX_ACT_BN_RELU = 3,   /* Conv + BN + ReLU */
+       CVX_ACT_BN_LINEAR = 4, /* Conv + BN (Tree.project) */
+       CVX_ACT_BIAS_RELU = 5 }; /* Conv + bias + ReLU, fp16 output (head 3x3, :314-318) */
+#define CVX_OPF_RES_PRE_ACT 1 /* cvx_op_desc.flags: the residual is added before the activation (BasicBlock, :20-27) */
 
 typedef struct {
   int32_t type;
@@ -54,12 +63,15 @@ typedef struct {
   int64_t bias_off;            /* CVX_ACT_BIAS */
   int64_t rmean_off, rvar_off; /* BN running statistics (stats arena) */
   int32_t lane; /* reserved (ignored): independent tails on own HIP streams measured slower than one stream */
-  int32_t reserved_;
+  int32_t flags; /* CVX_OPF_* */
 } cvx_op_desc;
 
 typedef struct cvx_engine cvx_engine;
 
-/* Builds an engine for a fixed input size.  `image_buf` is the index of the buffer-table entry (c == 8) that stands for
+/* A graph that contains an inference-only op or epilogue can only run cvx_engine_forward(training = 0); there the op that
+ * reads `image_buf` may be any convolution with 3 stored input channels (the image is converted to NHWC fp16, 8 channels).
+ *
+ * Builds an engine for a fixed input size.  `image_buf` is the index of the buffer-table entry (c == 8) that stands for
  * the caller's NCHW fp32 images; exactly one op may read it: the 3 -> 16..80 channel 3x3 stride-2 BN+SiLU stem, which runs
  * in fp32 straight from the caller's tensor (no fp16 copy of the image is made).
  * Replaces: Yolo8.__init__ graph construction, core/models/yolov8/yolo_v8.py:17-62. */
@@ -205,6 +217,20 @@ int cvx_nms(const float* y, int32_t batch, int32_t anchors, int32_t nc, float co
 int cvx_nms_variant(const float* y, int32_t batch, int32_t anchors, int32_t nc, float conf_thres, float iou_thres, int32_t max_det,
                     int32_t variant, float* out_rows, int32_t* out_index, int32_t* counts, void* workspace, int64_t workspace_bytes,
                     void* hip_stream);
+
+/* ---- CenterNet heat-map decode (BASELINE.json configs[3]) -----------------------------------------------------
+ * pred: (B, H*W, pred_ld) fp32 head tensor, heat-map logits in columns [0, nc), the two channels the reference reads as
+ * centre offsets at reg_col (its "wh" head), the two it reads as sizes at wh_col (its "reg" head).  Per image: sigmoid,
+ * the reference's 3x3 max-pool over (x, class), top-K (score desc, flat index asc), boxes = clamp([x+dx, y+dy, w, h] / (W, H))
+ * as xyxy in [0, 1], mask score >= conf, class-agnostic greedy DIoU-NMS (a box survives a kept one when DIoU <= nms_thr).
+ * Outputs: boxes (B,K,4), scores (B,K), classes (B,K), topk_index (B,K) = (y*W+x)*nc+c (-1: fewer than K peaks) for the whole
+ * top-K list; keep (B,K) = list positions of the survivors in descending score; counts (B) = survivors (-1: more than 2048
+ * scores tie at the K-th value).  The letterbox inverse (a few scalars per image) stays with the caller.
+ * Replaces: CenterNetA.decode_boxes, core/algorithms/centernet.py:271-338; diou_nms, core/utils/nms.py:9-31. */
+int64_t cvx_centernet_decode_workspace_bytes(int32_t batch, int32_t h, int32_t w, int32_t nc);
+int cvx_centernet_decode(const float* pred, int32_t pred_ld, int32_t batch, int32_t h, int32_t w, int32_t nc, int32_t reg_col, int32_t wh_col,
+                         int32_t k, float conf, float nms_thr, int32_t use_nms, float* boxes, float* scores, int32_t* classes,
+                         int32_t* topk_index, int32_t* keep, int32_t* counts, void* workspace, int64_t workspace_bytes, void* hip_stream);
 
 /* ---- single-op entry points (unit tests and other model families reuse them) -----------------------
  * NHWC fp16 convolution, weights [cout][kh][kw][cin] fp16.  mode 0: out fp16 = conv; mode 1: out fp16 =

@@ -146,6 +146,19 @@ def init_state_dict(nc: int = 80, seed: int = 0) -> "OrderedDict[str, torch.Tens
 # ----------------------------------------------------------------------------------------------
 # forward
 # ----------------------------------------------------------------------------------------------
+# fp16-STORAGE emulation (as in oracle/yolov8_ref.py): with FP16_STORAGE[0] = True every convolution sees its input and its
+# weights rounded to fp16 -- exactly what the MI355X engine's MFMA kernels read -- and accumulates in fp32.
+FP16_STORAGE = [False]
+
+
+def _q(t):
+    return t.half().float() if FP16_STORAGE[0] else t
+
+
+def _conv(x, w, b=None, stride=1, pad=0):
+    return F.conv2d(_q(x), _q(w), b, stride, pad)
+
+
 def _bn(x, sd, key, training):
     if training:
         sd[key + ".num_batches_tracked"] += 1
@@ -156,8 +169,8 @@ def _bn(x, sd, key, training):
 def _block(x, sd, p, residual, training):
     """BasicBlock.forward (centernet_model.py:20-27): the residual is added BEFORE the ReLU."""
     pre = p["prefix"]
-    y = F.relu(_bn(F.conv2d(x, sd[pre + ".conv1.weight"], None, p["stride"], 1), sd, pre + ".bn1", training))
-    y = _bn(F.conv2d(y, sd[pre + ".conv2.weight"], None, 1, 1), sd, pre + ".bn2", training)
+    y = F.relu(_bn(_conv(x, sd[pre + ".conv1.weight"], None, p["stride"], 1), sd, pre + ".bn1", training))
+    y = _bn(_conv(y, sd[pre + ".conv2.weight"], None, 1, 1), sd, pre + ".bn2", training)
     return F.relu(y + residual)
 
 
@@ -167,7 +180,7 @@ def _tree(x, sd, t, training, residual=None, children=None):
     pre = t["prefix"]
     bottom = F.max_pool2d(x, 2, 2) if t["stride"] > 1 else x
     if t["project"]:
-        residual = _bn(F.conv2d(bottom, sd[pre + ".project.0.weight"]), sd, pre + ".project.1", training)
+        residual = _bn(_conv(bottom, sd[pre + ".project.0.weight"]), sd, pre + ".project.1", training)
     else:
         residual = bottom
     if t["level_root"]:
@@ -176,7 +189,7 @@ def _tree(x, sd, t, training, residual=None, children=None):
         x1 = _block(x, sd, t["tree1"], residual, training)
         x2 = _block(x1, sd, t["tree2"], x1, training)
         cat = torch.cat([x2, x1, *children], 1)
-        return F.relu(_bn(F.conv2d(cat, sd[pre + ".root.conv.weight"]), sd, pre + ".root.bn", training))   # root_residual False
+        return F.relu(_bn(_conv(cat, sd[pre + ".root.conv.weight"]), sd, pre + ".root.bn", training))   # root_residual False
     x1 = _tree(x, sd, t["tree1"], training, residual=residual)
     children.append(x1)
     return _tree(x1, sd, t["tree2"], training, children=children)
@@ -188,13 +201,13 @@ def _ida(layers, sd, p, out_dim, in_ch, ups, training):
     for k, (ci, f) in enumerate(zip(in_ch, ups)):
         l = layers[k]
         if ci != out_dim:
-            l = F.relu(_bn(F.conv2d(l, sd[p + f"proj_{k}.0.weight"]), sd, p + f"proj_{k}.1", training))
+            l = F.relu(_bn(_conv(l, sd[p + f"proj_{k}.0.weight"]), sd, p + f"proj_{k}.1", training))
         if f != 1:
-            l = F.conv_transpose2d(l, sd[p + f"up_{k}.weight"], None, stride=f, padding=f // 2, groups=out_dim)
+            l = F.conv_transpose2d(_q(l), sd[p + f"up_{k}.weight"], None, stride=f, padding=f // 2, groups=out_dim)
         layers[k] = l
     x, ys = layers[0], []
     for k in range(1, len(layers)):
-        x = F.relu(_bn(F.conv2d(torch.cat([x, layers[k]], 1), sd[p + f"node_{k}.0.weight"], None, 1, 1), sd, p + f"node_{k}.1", training))
+        x = F.relu(_bn(_conv(torch.cat([x, layers[k]], 1), sd[p + f"node_{k}.0.weight"], None, 1, 1), sd, p + f"node_{k}.1", training))
         ys.append(x)
     return x, ys
 
@@ -202,9 +215,9 @@ def _ida(layers, sd, p, out_dim, in_ch, ups, training):
 def forward(sd, x: torch.Tensor, nc: int = 80, training: bool = False) -> torch.Tensor:
     """CenterNet.forward (centernet_model.py:371-379): (B,3,H,W) -> (B, H/4, W/4, nc + 4) = [heatmap | wh | reg] heads, NHWC."""
     b = "backbone.base."
-    x = F.relu(_bn(F.conv2d(x, sd[b + "base_layer.0.weight"], None, 1, 3), sd, b + "base_layer.1", training))
-    x = F.relu(_bn(F.conv2d(x, sd[b + "level_0.0.weight"], None, 1, 1), sd, b + "level_0.1", training))
-    x = F.relu(_bn(F.conv2d(x, sd[b + "level_1.0.weight"], None, 2, 1), sd, b + "level_1.1", training))
+    x = F.relu(_bn(_conv(x, sd[b + "base_layer.0.weight"], None, 1, 3), sd, b + "base_layer.1", training))
+    x = F.relu(_bn(_conv(x, sd[b + "level_0.0.weight"], None, 1, 1), sd, b + "level_0.1", training))
+    x = F.relu(_bn(_conv(x, sd[b + "level_1.0.weight"], None, 2, 1), sd, b + "level_1.1", training))
     ys = []
     for t in trees():
         x = _tree(x, sd, t, training)
@@ -215,8 +228,8 @@ def forward(sd, x: torch.Tensor, nc: int = 80, training: bool = False) -> torch.
         layers[-i - 1:] = y
     outs = []
     for head in ("heatmap", "wh", "reg"):
-        h = F.relu(F.conv2d(x, sd[f"backbone.{head}.0.weight"], sd[f"backbone.{head}.0.bias"], 1, 1))
-        outs.append(F.conv2d(h, sd[f"backbone.{head}.2.weight"], sd[f"backbone.{head}.2.bias"]))
+        h = F.relu(_conv(x, sd[f"backbone.{head}.0.weight"], sd[f"backbone.{head}.0.bias"], 1, 1))
+        outs.append(_conv(h, sd[f"backbone.{head}.2.weight"], sd[f"backbone.{head}.2.bias"]))
     return torch.cat(outs, 1).permute(0, 2, 3, 1)
 
 

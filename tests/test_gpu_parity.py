@@ -861,3 +861,126 @@ def test_other_class_counts_match_the_oracle(dev, nc):
     with torch.no_grad():
         y, _ = m2(x.to(dev))
     assert tuple(y.shape) == (2, 4 + nc, 336) and bool(torch.isfinite(y).all())
+
+
+# ---- CenterNet DLA-34 inference + heat-map decode (BASELINE config 4) ------------------------------------------
+def _centernet(dev, nc=80):
+    from computervision.pytorch_amd.dla import CenterNetDLA34
+    torch.manual_seed(0)
+    return CenterNetDLA34(nc).to(dev).eval()
+
+
+def test_centernet_state_dict_is_the_references(dev):
+    """Same keys, order and shapes as the reference's CenterNet(cfg).state_dict(), and -- under the same seed -- the same
+    values bit for bit (oracle.init_state_dict is asserted equal to the reference's in oracle/make_golden.py section 9)."""
+    from oracle import centernet_ref as C
+    m = _centernet(dev)
+    ref = C.init_state_dict(80, seed=0)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(ref.keys()) and len(sd) == 326
+    for k, v in ref.items():
+        assert sd[k].shape == v.shape and torch.equal(sd[k].cpu(), v), k
+    assert sum(p.numel() for p in m.parameters()) == 18474476
+
+
+def test_centernet_forward_matches_the_oracle(dev, gold):
+    """DLA-34 eval forward on the engine vs the fp32 oracle (pinned to the reference), with BatchNorm running statistics that
+    normalise (calibrated on the batch: at the constructor's mean 0 / var 1 a 40-layer ReLU chain decays to nothing and every
+    output is its head bias).  Per head: relative L2 of the logits / regressions <= 3e-3 (fp16 weights and activations,
+    fp32 accumulation; the 7x7 stem reads the image as fp16)."""
+    from oracle import centernet_ref as C
+    g = gold("centernet_fwd_128.npz")
+    x = torch.from_numpy(g["x"])
+    sd = C.init_state_dict(80, seed=0)
+    old = C.BN_MOMENTUM
+    C.BN_MOMENTUM = 1.0                                               # running statistics := this batch's statistics
+    try:
+        C.forward(sd, x, 80, training=True)
+    finally:
+        C.BN_MOMENTUM = old
+    with torch.no_grad():
+        ref = C.forward(sd, x, 80, training=False)
+    m = _centernet(dev)
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        out = m(x.to(dev)).cpu()
+    assert tuple(out.shape) == (2, 32, 32, 84)
+    parts = {"heatmap": slice(0, 80), "wh": slice(80, 82), "reg": slice(82, 84)}
+    C.FP16_STORAGE[0] = True
+    try:
+        with torch.no_grad():
+            emu = C.forward(sd, x, 80, training=False)
+    finally:
+        C.FP16_STORAGE[0] = False
+    errs = {k: rel(out[..., sl], ref[..., sl]) for k, sl in parts.items()}
+    errs_emu = {k: rel(out[..., sl], emu[..., sl]) for k, sl in parts.items()}
+    print("[parity] CenterNet DLA-34 128x128 eval vs oracle fp32: " + " ".join(f"{k} {v:.2e}" for k, v in errs.items()) +
+          " | vs fp16-storage emulation: " + " ".join(f"{k} {v:.2e}" for k, v in errs_emu.items()))
+    # same arithmetic (fp16 conv operands, fp32 accumulation) emulated on the CPU: only the summation order differs, and a
+    # rounding that flips propagates like the rounding itself (3.8e-3 / 4.5e-3 / 4.8e-3 measured on this random-init network,
+    # whose calibrated BatchNorms have folded scales up to 6)
+    assert max(errs_emu.values()) < 8e-3, errs_emu
+    # against fp32: what fp16 operands cost on this 50-conv ReLU network at random init (the emulation itself is 1.1e-2 /
+    # 1.3e-2 / 1.4e-2 away from fp32 on this input)
+    assert max(errs.values()) < 2.5e-2, errs
+    # the reference's own eval output at the constructor's statistics (fixture): bias-dominated, must agree as well
+    m2 = _centernet(dev)
+    sd0 = C.init_state_dict(80, seed=0)
+    C.forward(sd0, x, 80, training=True)
+    m2.load_state_dict(sd0)
+    with torch.no_grad():
+        out0 = m2(x.to(dev)).cpu()
+    assert rel(out0.flatten()[::7], torch.from_numpy(g["eval_sub"])) < 3e-3         # bias-dominated outputs
+    with pytest.raises(L.CvxError):
+        m.train()(x.to(dev))                                          # inference-only this round: loud, no fallback
+
+
+@pytest.mark.parametrize("tag", ["synth", "net"])
+def test_centernet_decode_matches_the_reference_fixture(dev, gold, tag):
+    """cvx_centernet_decode on head tensors whose decode the REFERENCE itself produced (fixture): classes exact, scores
+    bit-exact, boxes to fp32 round-off, survivors of the DIoU-NMS identical.  'synth' has real peaks; 'net' is a random-init
+    network output (scores ~0.5 everywhere, 100 of 100 kept)."""
+    import builder
+    g = gold("centernet_fwd_128.npz")
+    cfg, algo_cls, _ = builder.export_from_registry("centernet")
+    cfg.dataset.num_classes = 80
+    cfg.arch.input_size = (3, 128, 128)
+    algo = algo_cls(cfg, dev)
+    pred = torch.from_numpy(g[tag + "_pred"]).to(dev)
+    h, w = (int(v) for v in g[tag + "_hw"])
+    boxes, scores, classes = algo.decode_boxes(pred, h, w)
+    assert np.array_equal(classes, g[tag + "_classes"])              # same peaks, same order, same DIoU-NMS survivors
+    # scores: the reference's torch.sigmoid and the device's 1 / (1 + expf(-x)) agree to the last bit on 98 of the 100 'net'
+    # scores and on all 'synth' ones; the rest differ by one unit in the last place of expf
+    ulp = np.abs(scores.view(np.int32).astype(np.int64) - g[tag + "_scores"].view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1 and (ulp == 0).mean() >= 0.9, (int(ulp.max()), float((ulp == 0).mean()))
+    np.testing.assert_allclose(boxes, g[tag + "_boxes"], rtol=1e-6, atol=1e-5)
+
+
+def test_centernet_full_size_properties(dev):
+    """BASELINE config 4's size (512x512; batch 8 here, 64 in bench.py): finite outputs, per-image independence of forward and
+    decode (image b of a batch == the same image alone, bit for bit: eval BatchNorm, per-image decode), sparse heat-maps."""
+    import builder
+    m = _centernet(dev)
+    x = synth.images(8, 512, 512, seed=3).to(dev)
+    with torch.no_grad():
+        raw = m.forward_raw(x)
+        one = m.forward_raw(x[5:6])
+    assert bool(torch.isfinite(raw).all()) and torch.equal(raw[5:6], one)
+    cfg, algo_cls, _ = builder.export_from_registry("centernet")
+    cfg.dataset.num_classes = 80
+    cfg.arch.input_size = (3, 512, 512)
+    algo = algo_cls(cfg, dev)
+    d_all, d_one = algo.decode_raw(raw, 128, 128), algo.decode_raw(one, 128, 128)
+    n = int(d_one["counts"][0])
+    assert n == int(d_all["counts"][5]) and n >= 0
+    assert torch.equal(d_all["topk_index"][5], d_one["topk_index"][0]) and torch.equal(d_all["keep"][5, :n], d_one["keep"][0, :n])
+    # a heat-map with 7 peaks only: the top-100 list is cut short, exactly those 7 come back
+    sparse = torch.full((1, 128 * 128, 96), -200.0, device=dev)      # sigmoid(-200) == 0 exactly in fp32
+    sparse[..., 80:] = 0.5
+    peaks = [(3, 5, 7), (100, 64, 0), (127, 127, 79), (64, 64, 40), (10, 120, 33), (90, 2, 1), (50, 77, 60)]
+    for y, x_, c in peaks:
+        sparse[0, y * 128 + x_, c] = 2.0 + 0.01 * c
+    d = algo.decode_raw(sparse, 128, 128)
+    assert int(d["counts"][0]) == 7 and sorted(d["topk_index"][0, :7].tolist()) == sorted((y * 128 + x_) * 80 + c for y, x_, c in peaks)
+    assert d["topk_index"][0, 7:].tolist() == [-1] * 93

@@ -180,3 +180,30 @@ def test_nms_variants_of_torchvision_0141():
     for c in np.unique(rows[:, 5]):
         r = rows[rows[:, 5] == c]
         assert len(nms_ref.greedy_nms_per_class(r[:, :4], r[:, 5], 0.7)) == len(r)
+
+
+# ---- CenterNet (DLA-34) oracle vs the fixtures captured from the reference (oracle/make_golden.py section 9) ---------------
+def test_centernet_oracle_init_forward_decode(gold):
+    from oracle import centernet_ref as C
+    sd = C.init_state_dict(80, seed=0)
+    sums = json.load(open(os.path.join(GOLD, "centernet_seed0_init_sums.json")))
+    assert list(sums.keys()) == list(sd.keys()) and len(sd) == 326
+    for k, (s, a) in sums.items():
+        v = sd[k].double()
+        assert float(v.sum()) == s and float(v.abs().sum()) == a, k
+    g = gold("centernet_fwd_128.npz")
+    x = torch.from_numpy(g["x"])
+    tr = C.forward(sd, x, 80, training=True)                       # also moves the BN running statistics, as the fixture run did
+    np.testing.assert_allclose(tr.detach().flatten()[::7].numpy(), g["train_sub"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(sd["backbone.dla_up.ida_2.node_3.1.running_mean"].numpy(), g["bn_rm"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(sd["backbone.base.level_5.root.bn.running_var"].numpy(), g["bn_rv"], rtol=1e-4, atol=1e-6)
+    with torch.no_grad():
+        ev = C.forward(sd, x, 80, training=False)
+    np.testing.assert_allclose(ev.flatten()[::7].numpy(), g["eval_sub"], rtol=1e-4, atol=1e-5)
+    for tag in ("net", "synth"):
+        pred = torch.from_numpy(g[tag + "_pred"])
+        boxes, scores, classes, pos = C.decode(pred, 80, (128, 128), tuple(int(v) for v in g[tag + "_hw"]), k=int(g["k"]), conf=float(g["conf"]),
+                                               nms_thr=float(g["nms_thr"]))
+        assert np.array_equal(classes.numpy(), g[tag + "_classes"]) and np.array_equal(scores.numpy(), g[tag + "_scores"])
+        np.testing.assert_allclose(boxes.numpy(), g[tag + "_boxes"], rtol=1e-6, atol=1e-5)
+        assert np.array_equal(pos.numpy(), g[tag + "_pos"])
