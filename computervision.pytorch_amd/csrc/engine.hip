@@ -428,8 +428,10 @@ int plan_batch(cvx_engine* e, int B, bool training) {
     if (training && o.act == CVX_ACT_BN_SILU) {
       CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, M * C * 2));
       c.ybuf = (half_t*)p;
-      CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, M * C * 2));
-      c.dybuf = (half_t*)p;
+      if (!c.stem) {  // the stem's dy is never materialised (cvx_stem_backward)
+        CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, M * C * 2));
+        c.dybuf = (half_t*)p;
+      }
       if (!c.stem) ytmp_elems = std::max(ytmp_elems, M * C);
     }
     c.stat_fwd = (long long*)nullptr + stat_floats;  // offset for now, rebased below
@@ -810,6 +812,11 @@ struct PendingWgrad {
   WgradParams wp;
   bool stem;
   StemParams sp;
+  ViewDesc gout;             // stem: fused BN-apply + weight gradient (cvx_stem_backward) reads gout / xhat instead of dy
+  BnCoef coef;
+  const long long* part;
+  float inv_scale;
+  float *dgamma, *dbeta;
   double flops, bytes;
   int op;
 };
@@ -837,9 +844,15 @@ int flush_wgrads(cvx_engine* e, hipEvent_t ev, hipStream_t producer) {
   CVX_HIP(hipStreamWaitEvent(e->side, ev, 0));
   for (const PendingWgrad& g : w.pending) {
     e->cur_op = g.op;
+    if (g.stem) {
+      // the last op of the pass: the main stream has nothing else left, while the side stream still holds the previous
+      // layers' weight gradients -- the fused stem backward runs on the producer (main) stream, beside them
+      ProfScope ps(e, PROF_CONV_WGRAD, g.flops, g.bytes, producer);
+      CVX_TRY(cvx_stem_backward(g.sp, g.wp.dy /* = xhat */, g.gout, g.coef, g.part, g.inv_scale, g.dgamma, g.dbeta, g.wp.slabs, g.wp.nsplit, producer));
+      continue;
+    }
     ProfScope ps(e, PROF_CONV_WGRAD, g.flops, g.bytes, e->side);
-    if (g.stem) CVX_TRY(cvx_stem_wgrad(g.sp, g.wp.dy, g.wp.slabs, g.wp.nsplit, e->side));
-    else CVX_TRY(cvx_conv_wgrad_launch(g.wp, e->side));
+    CVX_TRY(cvx_conv_wgrad_launch(g.wp, e->side));
   }
   w.pending.clear();
   return 0;
@@ -903,10 +916,12 @@ int backward_op(cvx_engine* e, int i) {
       ViewDesc gout = make_view(e, o.out, true);
       ViewDesc gres = make_view(e, o.res, true);
       BnCoef k{c.invstd, e->params + o.gamma_off, e->params + o.beta_off};
-      ProfScope ps(e, PROF_BN_BWD, 0, (gres.p ? 14.0 : 10.0) * M * C, st);
+      ProfScope ps(e, PROF_BN_BWD, 0, (c.stem ? 4.0 : (gres.p ? 14.0 : 10.0)) * M * C, st);
       CVX_TRY(cvx_bn_bwd_reduce(c.ybuf, M, C, hw, k, gout, c.stat_bwd, st));
-      CVX_TRY(cvx_bn_bwd_apply(c.ybuf, M, C, hw, k, c.stat_bwd, w.inv_scale, e->grads + o.gamma_off, e->grads + o.beta_off, gout, c.dybuf,
-                               gres, c.res_accum, st));
+      // the stem's "apply" half is fused into its weight gradient (cvx_stem_backward, queued below): dy is never materialised
+      if (!c.stem)
+        CVX_TRY(cvx_bn_bwd_apply(c.ybuf, M, C, hw, k, c.stat_bwd, w.inv_scale, e->grads + o.gamma_off, e->grads + o.beta_off, gout, c.dybuf,
+                                 gres, c.res_accum, st));
       dyv.p = c.dybuf;
       dyv.ld = C;
       dyv.bstride = (long long)hw * C;
@@ -1000,16 +1015,25 @@ int backward_op(cvx_engine* e, int i) {
       wp.nsplit = c.nsplit;
       wp.cin_pad16 = c.cin_pad16;
       wp.std3x3 = c.std3x3;
-      PendingWgrad pw{wp, c.stem, StemParams{}, conv_flops(o, B), conv_bytes(o, B) + 4.0 * c.nsplit * C * c.ntaps * c.cin_pad16, i};
+      PendingWgrad pw{wp, c.stem, StemParams{}, ViewDesc{nullptr, 0, 0}, BnCoef{nullptr, nullptr, nullptr}, nullptr, 0.f, nullptr, nullptr,
+                      conv_flops(o, B), conv_bytes(o, B) + 4.0 * c.nsplit * C * c.ntaps * c.cin_pad16, i};
       if (c.stem) {
         const Buf& ib = e->bufs[e->image_buf];
         CVX_CHECK(e->last_images, "the stem's weight gradient needs the images of the training forward");
         pw.sp = StemParams{e->last_images, B, ib.d.h, ib.d.w, o.oh, o.ow, e->params + o.w_off, C};
-        pw.bytes = 12.0 * B * ib.d.h * ib.d.w + 2.0 * M * C + 4.0 * c.nsplit * C * 144;
+        pw.bytes = 12.0 * B * ib.d.h * ib.d.w + 4.0 * M * C + 4.0 * c.nsplit * C * 144;
+        pw.wp.dy = c.ybuf;  // xhat
+        pw.gout = make_view(e, o.out, true);
+        pw.coef = BnCoef{c.invstd, e->params + o.gamma_off, e->params + o.beta_off};
+        pw.part = c.stat_bwd;
+        pw.inv_scale = w.inv_scale;
+        pw.dgamma = e->grads + o.gamma_off;
+        pw.dbeta = e->grads + o.beta_off;
       }
       w.pending.push_back(pw);
-      if ((int)w.pending.size() >= w.wg_batch || i == 0 || i == e->slab_tail_op) CVX_TRY(flush_wgrads(e, c.ev_dy, st));
-      if (i == e->slab_tail_op) CVX_HIP(hipEventRecord(e->ev_mid, e->side));  // every weight gradient outside the tail is queued
+      // batches of wg_batch layers share one event record -- except at the end of the pass: the last layers' weight
+      // gradients are the largest and form the tail of the step, they start the moment their dy exists
+      if ((int)w.pending.size() >= w.wg_batch || i <= e->slab_tail_op || e->slab_tail_op < 0) CVX_TRY(flush_wgrads(e, c.ev_dy, st));
     }
   return 0;
 }
@@ -1021,29 +1045,47 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
   cvx_bw_state& w = bw_of(e);
   hipStream_t st = e->stream;
   const float inv_scale = w.inv_scale;
-  for (int i = (int)e->ops.size() - 1; i >= 0; --i) CVX_TRY(backward_op(e, i));
+  // The gradient slabs are folded into the arena on a stream of their own, in chunks of a few layers: a chunk is reduced as
+  // soon as its weight gradients have been queued on the side stream, i.e. DURING the backward pass, where the main chain is
+  // latency-bound and leaves HBM bandwidth unused -- not at its end, where the stem's gradient kernels need all of it (one
+  // reduction of everything at the end moved 0.4 GB beside them).  The main stream only waits for the last, tiny chunk.
+  hipStream_t rs = e->red;
+  static const int chunk_convs = cvx_tune_int("CVX_SLAB_CHUNK", 6);
+  double slab_bytes = 0;
+  int chunk_hi = -1, in_chunk = 0;  // conv ops [i, chunk_hi] whose slabs are not reduced yet
+  auto reduce_chunk = [&](int lo, int hi, bool first) -> int {
+    const int blk0 = e->conv[lo].slab_blk0, blk1 = e->conv[hi].slab_blk1;
+    if (blk1 <= blk0) return 0;
+    ProfScope ps(e, PROF_SLAB_REDUCE, 0, first ? slab_bytes + 8.0 * e->n_params : 0.0, rs);
+    return cvx_reduce_slabs(e->slabs, e->grads, inv_scale, e->d_slab, e->d_slab_blocks + blk0, blk1 - blk0, rs);
+  };
+  for (size_t i = 0; i < e->ops.size(); ++i)
+    if (e->ops[i].type == CVX_OP_CONV) slab_bytes += 4.0 * e->conv[i].nsplit * e->ops[i].out.c * e->conv[i].ntaps * e->conv[i].cin_pad16;
+  bool first = true;
+  int lo_conv = -1;
+  for (int i = (int)e->ops.size() - 1; i >= 0; --i) {
+    CVX_TRY(backward_op(e, i));
+    if (e->ops[i].type != CVX_OP_CONV) continue;
+    if (chunk_hi < 0) chunk_hi = i;
+    lo_conv = i;
+    ++in_chunk;
+    if (in_chunk >= chunk_convs && w.pending.empty() && i > 1) {  // every weight gradient of [i, chunk_hi] is on the side stream
+      CVX_HIP(hipEventRecord(e->ev_mid, e->side));
+      CVX_HIP(hipStreamWaitEvent(rs, e->ev_mid, 0));
+      CVX_TRY(reduce_chunk(i, chunk_hi, first));
+      first = false;
+      chunk_hi = -1;
+      in_chunk = 0;
+    }
+  }
   w.active = false;
   CVX_TRY(flush_wgrads(e, e->ev_fork, st));  // (non-conv first ops: nothing pending in practice)
   e->cur_op = -1;
-  double slab_bytes = 0;
-  for (size_t i = 0; i < e->ops.size(); ++i)
-    if (e->ops[i].type == CVX_OP_CONV) slab_bytes += 4.0 * e->conv[i].nsplit * e->ops[i].out.c * e->conv[i].ntaps * e->conv[i].cin_pad16;
-  // The slab reduction runs on a stream of its own, in two parts: everything but the first (tail) ops as soon as THEIR weight
-  // gradients are done -- concurrently with the end of the main chain and with the tail's weight gradients on the side
-  // stream -- then the tail.  The main stream only waits for the second part.
-  const int tail = e->slab_tail_op >= 0 ? e->slab_tail_blocks : 0;
-  hipStream_t rs = e->red;
-  if (tail > 0) {
-    CVX_HIP(hipStreamWaitEvent(rs, e->ev_mid, 0));
-    ProfScope ps(e, PROF_SLAB_REDUCE, 0, slab_bytes + 8.0 * e->n_params, rs);
-    CVX_TRY(cvx_reduce_slabs(e->slabs, e->grads, inv_scale, e->d_slab, e->d_slab_blocks + tail, e->n_slab_blocks - tail, rs));
-  }
-  CVX_HIP(hipEventRecord(e->ev_join, e->side));  // the (rest of the) slab reduction needs every weight-gradient slab
+  CVX_HIP(hipEventRecord(e->ev_join, e->side));  // the last chunk needs the remaining weight-gradient slabs ...
   CVX_HIP(hipStreamWaitEvent(rs, e->ev_join, 0));
-  {
-    ProfScope ps(e, PROF_SLAB_REDUCE, 0, tail > 0 ? 0.0 : slab_bytes + 8.0 * e->n_params, rs);
-    CVX_TRY(cvx_reduce_slabs(e->slabs, e->grads, inv_scale, e->d_slab, e->d_slab_blocks, tail > 0 ? tail : e->n_slab_blocks, rs));
-  }
+  CVX_HIP(hipEventRecord(e->ev_fork, st));       // ... including the stem's, produced on the main stream (cvx_stem_backward)
+  CVX_HIP(hipStreamWaitEvent(rs, e->ev_fork, 0));
+  if (chunk_hi >= 0) CVX_TRY(reduce_chunk(lo_conv, chunk_hi, first));
   CVX_HIP(hipEventRecord(e->ev_red, rs));
   CVX_HIP(hipStreamWaitEvent(st, e->ev_red, 0));
   return 0;

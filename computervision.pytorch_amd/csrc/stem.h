@@ -19,3 +19,7 @@ int cvx_stem_apply_eval(const StemParams& p, const float* scale, const float* sh
 // weight gradient from dy fp16 [M][Cout] into fp32 slabs [nsplit][Cout][9 * 16]; nsplit = cvx_stem_wgrad_splits(M)
 int cvx_stem_wgrad_splits(long long M);
 int cvx_stem_wgrad(const StemParams& p, const half_t* dy, float* slabs, int nsplit, hipStream_t st);
+// fused tail of the backward pass: BN backward "apply" (dy formed in registers from xhat / gout and the folded sums of
+// bn_bwd_reduce in `part`) + weight gradient; accumulates dgamma / dbeta; dy itself is never stored
+int cvx_stem_backward(const StemParams& p, const half_t* xhat, const ViewDesc& gout, const BnCoef& k, const long long* part, float inv_scale,
+                      float* dgamma, float* dbeta, float* slabs, int nsplit, hipStream_t st);

@@ -250,6 +250,145 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemParams p, lon
     }
 }
 
+// ---- fused backward of the stem: BatchNorm backward "apply" + weight gradient in one pass ------------------------------
+// The stem's dy (gradient w.r.t. its raw conv output) has exactly one consumer, the weight gradient (there is no data
+// gradient into the image), and both kernels sit at the very end of the backward pass where nothing overlaps them.  Here
+// dy = gamma * invstd * (dz - c1 - xhat * c2), dz = gout * silu'(gamma * xhat + beta), is formed in registers from xhat and
+// gout and goes straight into the 4 x 27 accumulators: dy is never written or re-read (0.21 GB at batch 32) and the step's
+// tail is one kernel shorter.  c1 / c2 come from the replica slabs bn_bwd_reduce filled (folded by every block, as in
+// bn_bwd_apply); block (0, 0) accumulates dgamma / dbeta.
+__global__ __launch_bounds__(256) void stem_bwd_kernel(const StemParams p, long long M, const half_t* xhat, ViewDesc gout, BnCoef k,
+                                                       const long long* part, float inv_scale, float* dgamma, float* dbeta, float* slabs,
+                                                       int tiles_x, int tiles_y, int total_tiles) {
+  // Workgroup = one 8 x 32 tile of output pixels at a time (grid-stride over the tiles): the 17 x 65 x 3 fp32 input window of
+  // the tile is staged in LDS ONCE (coalesced loads; even / odd columns kept apart so that the stride-2 window reads are
+  // conflict-free) and read by all four waves (4 output channels each) -- the first version let every wave fetch its pixels'
+  // windows from global memory itself: 4 x redundant L1 traffic, 1.4 TB/s.
+  constexpr int TH = 8, TW = 32, WR = 2 * TH + 1, WE = TW + 1, WO = TW;  // window rows; even-index / odd-index columns per row
+  constexpr int ROWP = WE + WO + 1;                                      // floats per (channel, row): [even | odd | pad]
+  extern __shared__ __attribute__((aligned(16))) long long ws[];  // fold workspace | 5 x Cout coefficients | window
+  float* sG = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + fold_ws_bytes(p.Cout));
+  float* sB = sG + p.Cout;
+  float* sK1 = sB + p.Cout;
+  float* sK2 = sK1 + p.Cout;
+  float* sGi = sK2 + p.Cout;
+  float* sX = sGi + p.Cout;  // [3][WR][ROWP]
+  fold_replicas(part, p.Cout, ws);
+  {
+    const double* s0 = reinterpret_cast<const double*>(ws);
+    const double* s1 = s0 + p.Cout;
+    const double cnt = (double)M;
+    for (int c = threadIdx.x; c < p.Cout; c += 256) {
+      const float g = k.gamma[c];
+      sG[c] = g;
+      sB[c] = k.beta[c];
+      sK1[c] = (float)(s0[c] / cnt);
+      sK2[c] = (float)(s1[c] / cnt);
+      sGi[c] = g * k.invstd[c];
+      if (blockIdx.x == 0 && blockIdx.y == 0) {
+        dgamma[c] += (float)(s1[c] * inv_scale);
+        dbeta[c] += (float)(s0[c] * inv_scale);
+      }
+    }
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int co0 = blockIdx.y * 16 + wave * 4;
+  float ga[4], be[4], k1[4], k2[4], gi[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    ga[c] = sG[co0 + c];
+    be[c] = sB[co0 + c];
+    k1[c] = sK1[co0 + c];
+    k2[c] = sK2[co0 + c];
+    gi[c] = sGi[co0 + c];
+  }
+  float acc[4][KT];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) acc[c][kk] = 0.f;
+  const long long plane = (long long)p.H * p.W;
+  const int lx = lane & 31, ly = lane >> 5;  // a wave covers two tile rows per group
+  for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    const int tx = tile % tiles_x;
+    const int t2 = tile / tiles_x;
+    const int ty = t2 % tiles_y;
+    const int b = t2 / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    // xhat / gout of the wave's 4 channels, one pixel group (2 rows x 32 columns) at a time, the next group's in flight
+    auto load_group = [&](int q, h4& xq, h4& gq, bool& okq) {
+      const int oy = oy0 + q * 2 + ly, ox = ox0 + lx;
+      okq = oy < p.OH && ox < p.OW;
+      const long long pix = okq ? (long long)oy * p.OW + ox : 0;
+      xq = *reinterpret_cast<const h4*>(xhat + ((long long)b * p.OH * p.OW + pix) * p.Cout + co0);
+      gq = *reinterpret_cast<const h4*>(gout.p + (long long)b * gout.bstride + pix * gout.ld + co0);
+    };
+    h4 xn, gn;
+    bool okn;
+    load_group(0, xn, gn, okn);
+    // stage the input window: rows 2*oy0-1 .. 2*oy0+2*TH-1, columns 2*ox0-1 .. 2*ox0+2*TW-1 (window index j = col - (2*ox0-1))
+    const float* img = p.img + (long long)b * 3 * plane;
+    __syncthreads();  // the previous tile's window is no longer read
+    {
+      constexpr int NE = 3 * WR * (WE + WO), NST = (NE + 255) / 256;
+      float v[NST];
+      int dst[NST];
+#pragma unroll
+      for (int it = 0; it < NST; ++it) {  // every load is issued before the first LDS store waits for one
+        const int e = it * 256 + threadIdx.x;
+        const int j = e % (WE + WO);
+        const int t3 = e / (WE + WO);
+        const int r = t3 % WR, ci = t3 / WR;
+        const int iy = 2 * oy0 - 1 + r, ix = 2 * ox0 - 1 + j;
+        const bool in = e < NE && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        v[it] = in ? img[ci * plane + (long long)iy * p.W + ix] : 0.f;
+        dst[it] = e < NE ? (ci * WR + r) * ROWP + ((j & 1) ? WE + (j >> 1) : (j >> 1)) : -1;
+      }
+#pragma unroll
+      for (int it = 0; it < NST; ++it)
+        if (dst[it] >= 0) sX[dst[it]] = v[it];
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+      const h4 xq = xn, gq = gn;
+      const bool okq = okn;
+      if (q < 3) load_group(q + 1, xn, gn, okn);
+      float dyc[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float xv = (float)xq[c];
+        const float dz = (float)gq[c] * cvx_silu_grad(xv * ga[c] + be[c]);
+        dyc[c] = okq ? (float)(half_t)(gi[c] * (dz - k1[c] - xv * k2[c])) : 0.f;  // rounded to fp16 once, as bn_bwd_apply stores it
+      }
+      const float* rowq = sX + (2 * (q * 2 + ly)) * ROWP;  // window row of kh = 0
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) {
+          const float* row = rowq + (ci * WR + kh) * ROWP;
+          // window columns j = 2*lx + kw: kw = 0 -> even[lx], kw = 1 -> odd[lx], kw = 2 -> even[lx + 1]
+          const float x0 = row[lx], x1 = row[WE + lx], x2 = row[lx + 1];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            acc[c][(kh * 3 + 0) * 3 + ci] = fmaf(dyc[c], x0, acc[c][(kh * 3 + 0) * 3 + ci]);
+            acc[c][(kh * 3 + 1) * 3 + ci] = fmaf(dyc[c], x1, acc[c][(kh * 3 + 1) * 3 + ci]);
+            acc[c][(kh * 3 + 2) * 3 + ci] = fmaf(dyc[c], x2, acc[c][(kh * 3 + 2) * 3 + ci]);
+          }
+        }
+    }
+  }
+  float* slab = slabs + (long long)blockIdx.x * p.Cout * 144;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) {
+      const float v = cvx_wave_sum64(acc[c][kk]);
+      if (lane == 0) slab[(co0 + c) * 144 + (kk / 3) * 16 + (kk % 3)] = v;
+    }
+}
+
 int stem_grid(long long M, int per_block) {
   long long blocks = (M + per_block - 1) / per_block;
   const long long cap = 256 * 8;  // persistent: grid-stride over the pixels, 8 workgroups per CU at most
@@ -320,6 +459,20 @@ int cvx_stem_wgrad(const StemParams& p, const half_t* dy, float* slabs, int nspl
   const long long M = (long long)p.B * p.OH * p.OW;
   CVX_CHECK(dy && slabs && nsplit >= 1 && nsplit == cvx_stem_wgrad_splits(M), "stem wgrad: split count must come from cvx_stem_wgrad_splits");
   hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nsplit, p.Cout / 16), dim3(256), 0, st, p, M, dy, slabs);
+  CVX_HIP(hipGetLastError());
+  return 0;
+}
+
+int cvx_stem_backward(const StemParams& p, const half_t* xhat, const ViewDesc& gout, const BnCoef& k, const long long* part, float inv_scale,
+                      float* dgamma, float* dbeta, float* slabs, int nsplit, hipStream_t st) {
+  CVX_TRY(check(p));
+  const long long M = (long long)p.B * p.OH * p.OW;
+  CVX_CHECK(xhat && gout.p && part && dgamma && dbeta && slabs && nsplit == cvx_stem_wgrad_splits(M), "stem backward: bad arguments");
+  CVX_CHECK(gout.ld % 4 == 0 && ((uintptr_t)gout.p % 8) == 0, "stem backward: gradient view alignment");
+  const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + 7) / 8;
+  const int lds = fold_ws_bytes(p.Cout) + 5 * p.Cout * 4 + 3 * 17 * 66 * 4;
+  hipLaunchKernelGGL(stem_bwd_kernel, dim3(nsplit, p.Cout / 16), dim3(256), lds, st, p, M, xhat, gout, k, part, inv_scale, dgamma, dbeta, slabs,
+                     tiles_x, tiles_y, tiles_x * tiles_y * p.B);
   CVX_HIP(hipGetLastError());
   return 0;
 }

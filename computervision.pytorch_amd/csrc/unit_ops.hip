@@ -133,3 +133,35 @@ extern "C" int cvx_stem_wgrad_nchw(const float* images, int32_t batch, int32_t h
   CVX_HIP(hipStreamSynchronize(st));
   return 0;
 }
+
+// the stem's whole backward pass (BatchNorm + SiLU backward and the weight gradient, fused as in the engine): gout = gradient
+// w.r.t. the stem's activation, fp16 (B, h/2, w/2, cout); xhat / invstd from cvx_stem_train_nchw; dgamma / dbeta accumulated
+extern "C" int cvx_stem_backward_nchw(const float* images, int32_t batch, int32_t h, int32_t w, const void* xhat_f16, const void* gout_f16,
+                                      int32_t cout, const float* gamma, const float* beta, const float* invstd, float inv_scale, float* dgamma,
+                                      float* dbeta, float* dw, void* hip_stream) {
+  CVX_CHECK(images && xhat_f16 && gout_f16 && gamma && beta && invstd && dgamma && dbeta && dw, "null arguments");
+  hipStream_t st = (hipStream_t)hip_stream;
+  const StemParams sp{images, batch, h, w, h / 2, w / 2, dw, cout};
+  const int hw = (h / 2) * (w / 2);
+  const long long M = (long long)batch * hw;
+  const int ns = cvx_stem_wgrad_splits(M);
+  Scratch part, slabs, dsd, dbl;
+  CVX_TRY(part.alloc(slab_bytes(cout)));
+  CVX_TRY(slabs.alloc((size_t)ns * cout * 144 * 4));
+  BnCoef k{invstd, gamma, beta};
+  const ViewDesc g = dense(gout_f16, hw, cout);
+  CVX_TRY(cvx_bn_bwd_reduce((const half_t*)xhat_f16, M, cout, hw, k, g, (long long*)part.p, st));
+  CVX_TRY(cvx_stem_backward(sp, (const half_t*)xhat_f16, g, k, (const long long*)part.p, inv_scale, dgamma, dbeta, (float*)slabs.p, ns, st));
+  SlabDesc sd{0, 0, ns, cout * 9, 3, 16, cvx_slab_lanes(ns)};
+  std::vector<BlockRef> blocks;
+  const long long total = (long long)sd.rows * sd.Cin;
+  for (long long s0 = 0; s0 < total; s0 += 256 / sd.lanes) blocks.push_back(BlockRef{0, (int)s0});
+  CVX_TRY(dsd.alloc(sizeof(sd)));
+  CVX_TRY(dbl.alloc(blocks.size() * sizeof(BlockRef)));
+  CVX_HIP(hipMemcpy(dsd.p, &sd, sizeof(sd), hipMemcpyHostToDevice));
+  CVX_HIP(hipMemcpy(dbl.p, blocks.data(), blocks.size() * sizeof(BlockRef), hipMemcpyHostToDevice));
+  CVX_HIP(hipMemsetAsync(dw, 0, (size_t)cout * 27 * 4, st));
+  CVX_TRY(cvx_reduce_slabs((const float*)slabs.p, dw, inv_scale, (const SlabDesc*)dsd.p, (const BlockRef*)dbl.p, (int)blocks.size(), st));
+  CVX_HIP(hipStreamSynchronize(st));
+  return 0;
+}

@@ -281,6 +281,13 @@ int cvx_stem_eval_nchw(const float* images, int32_t batch, int32_t h, int32_t w,
                        const float* shift, void* out_f16, void* hip_stream);
 int cvx_stem_wgrad_nchw(const float* images, int32_t batch, int32_t h, int32_t w, const void* dy_f16, int32_t cout, float* dw,
                         void* hip_stream);
+/* The stem's backward pass as the engine runs it: BatchNorm + SiLU backward fused with the weight gradient (the gradient of
+ * the raw conv output is formed in registers and never stored).  gout: gradient w.r.t. the stem's activation, fp16
+ * (B, h/2, w/2, cout); xhat / invstd from cvx_stem_train_nchw; dgamma / dbeta accumulated, dw [cout][3][3][3] overwritten,
+ * all scaled by inv_scale. */
+int cvx_stem_backward_nchw(const float* images, int32_t batch, int32_t h, int32_t w, const void* xhat_f16, const void* gout_f16, int32_t cout,
+                           const float* gamma, const float* beta, const float* invstd, float inv_scale, float* dgamma, float* dbeta, float* dw,
+                           void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -262,10 +262,21 @@ def test_fp32_stem_unit(dev, B, H, W, Co):
     L.check(lib.cvx_stem_eval_nchw(L.ptr(xd), B, H, W, L.ptr(wd), Co, L.ptr(scd), L.ptr(shd), L.ptr(out), st), "stem eval")
     assert rel(out.float().permute(0, 3, 1, 2), F.silu(y.detach() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))) < 5e-4
     dy16 = torch.randn(B, Co, H // 2, W // 2, generator=g).half()
-    y.backward(dy16.float())
+    y.backward(dy16.float(), retain_graph=True)
     dw = torch.empty(Co, 3, 3, 3, device=dev)
     L.check(lib.cvx_stem_wgrad_nchw(L.ptr(xd), B, H, W, L.ptr(_nhwc(dy16).to(dev)), Co, L.ptr(dw), st), "stem wgrad")
     assert rel(dw.permute(0, 3, 1, 2), wr.grad) < 1e-5
+    # the fused backward the engine runs: BatchNorm + SiLU backward and the weight gradient in one pass, from gout
+    L.check(lib.cvx_stem_train_nchw(L.ptr(xd), B, H, W, L.ptr(wd), Co, L.ptr(gd), L.ptr(bd), 1e-3, 0.03, L.ptr(rmd), L.ptr(rvd), L.ptr(out),
+                                    L.ptr(xh), L.ptr(mean), L.ptr(invstd), st), "stem train")
+    wr2, gr2, br2 = w.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref2 = F.silu(F.batch_norm(F.conv2d(x, wr2, None, 2, 1), None, None, gr2, br2, True, 0.03, 1e-3))
+    ref2.backward(dy16.float())
+    dgam, dbet = torch.zeros(Co, device=dev), torch.zeros(Co, device=dev)
+    L.check(lib.cvx_stem_backward_nchw(L.ptr(xd), B, H, W, L.ptr(xh), L.ptr(_nhwc(dy16).to(dev)), Co, L.ptr(gd), L.ptr(bd), L.ptr(invstd), 1.0,
+                                       L.ptr(dgam), L.ptr(dbet), L.ptr(dw), st), "stem backward")
+    assert rel(dgam, gr2.grad) < 1e-3 and rel(dbet, br2.grad) < 1e-3
+    assert rel(dw.permute(0, 3, 1, 2), wr2.grad) < 3e-3       # dy passes through one fp16 rounding (as bn_bwd_apply stores it) and xhat is fp16
 
 
 # ---- whole network -----------------------------------------------------------------------------------------
