@@ -78,72 +78,127 @@ __device__ __forceinline__ float diou(const float4& a, const float4& b) {  // co
   return __fsub_rn(iou, __fdiv_rn(d_sq, fmaxf(c_sq, eps)));
 }
 
-__global__ __launch_bounds__(SEL_THREADS) void select_kernel(const float* pred, int ld, int H, int W, int C, int reg_off, int wh_off,
-                                                             const float* scores, int K, float conf, float nms_thr, int use_nms,
-                                                             DecodeOut o) {
-  __shared__ unsigned hist[2048];
-  __shared__ unsigned long long cand[CAND_CAP];
-  __shared__ unsigned s_prefix, s_remaining, s_ncand;
-  __shared__ float4 s_box[MAX_K];
-  __shared__ unsigned char s_alive[MAX_K];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const long long N = (long long)H * W * C;
-  const float* sc = scores + (long long)b * N;
-  const unsigned* key = reinterpret_cast<const unsigned*>(sc);  // scores are >= 0: the bit patterns order like the values
+// Sorted top-K of n non-negative floats (their bit patterns, `key`) by (value descending, index ascending); zeros never
+// qualify.  3-pass radix select of the K-th largest value (LDS histograms), collection of every element >= it, in-LDS
+// bitonic sort of 64-bit (inverted value, idx0 + i) keys.  Returns the number of sorted candidates left in cand[] (the
+// first min(K, that) are the answer), or -1 when more than CAND_CAP elements tie at the K-th value.  All threads call it.
+struct SelShared {
+  unsigned hist[2048];
+  unsigned long long cand[CAND_CAP];
+  unsigned prefix, remaining, ncand;
+};
 
-  // ---- 1. radix select: bit pattern T of the K-th largest score (11 + 11 + 10 bits, most significant first) ----
+__device__ int topk_sorted(const unsigned* key, long long n, unsigned idx0, int K, SelShared& sh) {
+  const int tid = threadIdx.x;
   if (tid == 0) {
-    s_prefix = 0;
-    s_remaining = (unsigned)K;
+    sh.prefix = 0;
+    sh.remaining = (unsigned)K;
   }
   const int shifts[3] = {21, 10, 0};
   const int widths[3] = {11, 11, 10};
   unsigned known_mask = 0;
   for (int pass = 0; pass < 3; ++pass) {
-    for (int i = tid; i < 2048; i += SEL_THREADS) hist[i] = 0;
+    for (int i = tid; i < 2048; i += SEL_THREADS) sh.hist[i] = 0;
     __syncthreads();
-    const unsigned prefix = s_prefix;
-    const int sh = shifts[pass];
+    const unsigned prefix = sh.prefix;
+    const int sft = shifts[pass];
     const unsigned mask = (1u << widths[pass]) - 1;
-    for (long long i = tid; i < N; i += SEL_THREADS) {
+    for (long long i = tid; i < n; i += SEL_THREADS) {
       const unsigned k = key[i];
-      if ((k & known_mask) == prefix) atomicAdd(&hist[(k >> sh) & mask], 1u);
+      if ((k & known_mask) == prefix) atomicAdd(&sh.hist[(k >> sft) & mask], 1u);
     }
     __syncthreads();
     if (tid == 0) {  // walk the bins from the top: the bin that holds the remaining-th largest
-      unsigned rem = s_remaining;
+      unsigned rem = sh.remaining;
       int bin = (int)mask;
       for (; bin > 0; --bin) {
-        if (hist[bin] >= rem) break;
-        rem -= hist[bin];
+        if (sh.hist[bin] >= rem) break;
+        rem -= sh.hist[bin];
       }
-      s_remaining = rem;
-      s_prefix = prefix | ((unsigned)bin << sh);
+      sh.remaining = rem;
+      sh.prefix = prefix | ((unsigned)bin << sft);
     }
     __syncthreads();
-    known_mask |= mask << sh;
+    known_mask |= mask << sft;
   }
-  const unsigned T = s_prefix;  // K-th largest score; s_remaining of the elements equal to T belong to the top K
-  // ---- 2. candidates: every element > T, and the elements == T (ordered by index by the sort below) ----
-  if (tid == 0) s_ncand = 0;
+  const unsigned T = sh.prefix;  // K-th largest value (0 when fewer than K elements are non-zero)
+  if (tid == 0) sh.ncand = 0;
   __syncthreads();
-  for (long long i = tid; i < N; i += SEL_THREADS) {
+  for (long long i = tid; i < n; i += SEL_THREADS) {
     const unsigned k = key[i];
     if (k >= T && k != 0) {  // zero = suppressed / never a detection (conf > 0): a top-K that reaches into the zeros is cut short
-      const unsigned slot = atomicAdd(&s_ncand, 1u);
-      if (slot < CAND_CAP) cand[slot] = ((unsigned long long)(0xFFFFFFFFu - k) << 32) | (unsigned)i;
+      const unsigned slot = atomicAdd(&sh.ncand, 1u);
+      if (slot < CAND_CAP) sh.cand[slot] = ((unsigned long long)(0xFFFFFFFFu - k) << 32) | (idx0 + (unsigned)i);
     }
   }
   __syncthreads();
-  const unsigned ncand = s_ncand;
-  if (ncand > CAND_CAP) {  // more ties at the K-th score than the sort holds (only a flat heat-map does this)
+  const unsigned ncand = sh.ncand;
+  if (ncand > CAND_CAP) return -1;
+  unsigned cap2 = 1;
+  while (cap2 < ncand) cap2 <<= 1;
+  for (unsigned i = ncand + tid; i < cap2; i += SEL_THREADS) sh.cand[i] = ~0ull;
+  __syncthreads();
+  for (unsigned k = 2; k <= cap2; k <<= 1)
+    for (unsigned j = k >> 1; j > 0; j >>= 1) {
+      for (unsigned i = tid; i < cap2; i += SEL_THREADS) {
+        const unsigned l = i ^ j;
+        if (l > i) {
+          const unsigned long long x = sh.cand[i], z = sh.cand[l];
+          const bool up = (i & k) == 0;
+          if ((x > z) == up) {
+            sh.cand[i] = z;
+            sh.cand[l] = x;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  return (int)ncand;
+}
+
+// K2a: grid (B, S).  Slice s of an image's H*W*C scores -> its own sorted top-K, as 64-bit keys in slice_top[b][s][K]
+// (~0 = empty, first word ~0 of slot 0 with the second = 0 marks "too many ties").  The global top-K under the strict
+// (score, index) order is a subset of the union of the per-slice top-Ks.
+__global__ __launch_bounds__(SEL_THREADS) void select_slice_kernel(const float* scores, long long N, int S, int K,
+                                                                   unsigned long long* slice_top) {
+  __shared__ SelShared sh;
+  const int b = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
+  const long long per = (N + S - 1) / S;
+  const long long i0 = (long long)sl * per;
+  const long long n = i0 < N ? (N - i0 < per ? N - i0 : per) : 0;
+  const unsigned* key = reinterpret_cast<const unsigned*>(scores + (long long)b * N + i0);
+  const int nc = topk_sorted(key, n, (unsigned)i0, K, sh);
+  unsigned long long* out = slice_top + ((long long)b * S + sl) * K;
+  for (int i = tid; i < K; i += SEL_THREADS) out[i] = (nc >= 0 && i < nc) ? sh.cand[i] : ~0ull;
+  if (nc < 0 && tid == 0) out[0] = 0xFFFFFFFF00000000ull;  // overflow marker (a real key never has an all-ones value word)
+}
+
+// K2b: one workgroup per image: merge the S slice lists (one more bitonic sort of S*K keys), boxes, mask, DIoU-NMS.
+__global__ __launch_bounds__(SEL_THREADS) void finish_kernel(const float* pred, int ld, int H, int W, int C, int reg_off, int wh_off,
+                                                             const float* scores, const unsigned long long* slice_top, int S, int K,
+                                                             float conf, float nms_thr, int use_nms, DecodeOut o) {
+  __shared__ unsigned long long cand[CAND_CAP];
+  __shared__ float4 s_box[MAX_K];
+  __shared__ unsigned char s_alive[MAX_K];
+  __shared__ int s_over;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const long long N = (long long)H * W * C;
+  const float* sc = scores + (long long)b * N;
+  const int total = S * K;
+  unsigned cap2 = 1;
+  while ((int)cap2 < total) cap2 <<= 1;
+  if (tid == 0) s_over = 0;
+  __syncthreads();
+  for (unsigned i = tid; i < cap2; i += SEL_THREADS) {
+    const unsigned long long v = (int)i < total ? slice_top[(long long)b * total + i] : ~0ull;
+    if (v == 0xFFFFFFFF00000000ull) s_over = 1;
+    cand[i] = v;
+  }
+  __syncthreads();
+  if (s_over) {
     if (tid == 0) o.counts[b] = -1;
     return;
   }
-  unsigned cap2 = 1;
-  while (cap2 < ncand) cap2 <<= 1;
-  for (unsigned i = ncand + tid; i < cap2; i += SEL_THREADS) cand[i] = ~0ull;
-  __syncthreads();
   for (unsigned k = 2; k <= cap2; k <<= 1)
     for (unsigned j = k >> 1; j > 0; j >>= 1) {
       for (unsigned i = tid; i < cap2; i += SEL_THREADS) {
@@ -159,6 +214,9 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const float* pred, 
       }
       __syncthreads();
     }
+  int ncand = 0;  // valid keys come first after the sort
+  for (int i = 0; i < K && i < total; ++i)
+    if (cand[i] != ~0ull) ++ncand;
   // ---- 3. the K winners: class, pixel, box (centernet.py:282-297) ----
   const int kk = min(K, (int)ncand);
   if (tid < kk) {
@@ -217,8 +275,14 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const float* pred, 
 
 }  // namespace
 
+static int slices_for(int K) {  // slices per image whose K-lists fit the merge sort together
+  int S = 16;
+  while (S > 1 && S * K > CAND_CAP) S >>= 1;
+  return S;
+}
+
 extern "C" int64_t cvx_centernet_decode_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t nc) {
-  return (int64_t)B * H * W * nc * 4 + 256;
+  return ((int64_t)B * H * W * nc + 64) * 4 + (int64_t)B * CAND_CAP * 8 + 512;
 }
 
 extern "C" int cvx_centernet_decode(const float* pred, int32_t pred_ld, int32_t B, int32_t H, int32_t W, int32_t nc, int32_t reg_col,
@@ -235,7 +299,11 @@ extern "C" int cvx_centernet_decode(const float* pred, int32_t pred_ld, int32_t 
   const long long n = (long long)B * H * W * nc;
   hipLaunchKernelGGL(peak_scores_kernel, dim3(cvx_cdiv(n, 256)), dim3(256), 0, st, pred, pred_ld, B, H, W, nc, ws);
   DecodeOut o{boxes, scores, classes, topk_index, keep, counts};
-  hipLaunchKernelGGL(select_kernel, dim3(B), dim3(SEL_THREADS), 0, st, pred, pred_ld, H, W, nc, reg_col, wh_col, ws, K, conf, nms_thr, use_nms, o);
+  const int S = slices_for(K);
+  unsigned long long* slice_top = reinterpret_cast<unsigned long long*>(ws + ((n + 63) & ~63LL));
+  hipLaunchKernelGGL(select_slice_kernel, dim3(B, S), dim3(SEL_THREADS), 0, st, ws, (long long)H * W * nc, S, K, slice_top);
+  hipLaunchKernelGGL(finish_kernel, dim3(B), dim3(SEL_THREADS), 0, st, pred, pred_ld, H, W, nc, reg_col, wh_col, ws, slice_top, S, K, conf, nms_thr,
+                     use_nms, o);
   CVX_HIP(hipGetLastError());
   return 0;
 }

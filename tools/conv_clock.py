@@ -67,6 +67,9 @@ def main():
         c = c[c[:, 0] != 0]
         mhz = float(np.median((c[:, 6] - c[:, 5]) / np.maximum(c[:, 4] - c[:, 0], 1)) * 100.0)
         c = c[:, :5].astype(np.float64)
+        if c.shape[0] == 0:
+            print(f"{B}x{H}x{W} {Ci}->{Co} k{k}s{s}: no stamps (kernel without clock marks)")
+            continue
         t0 = c[:, 0].min()
         c = (c - t0) / 100.0                      # microseconds
         start = c[:, 0]
