@@ -1295,10 +1295,16 @@ extern "C" int cvx_conv2d_nhwc(const void* x_f16, int32_t batch, int32_t ih, int
     cp.scale = scale_or_bias;
     cp.shift = shift;
     cp.out16 = (half_t*)out;
-  } else {
+  } else if (mode == 2) {
     cp.epi = CVX_EPI_BIAS_F32;
     cp.bias = scale_or_bias;
     cp.out32 = (float*)out;
+  } else {  // mode 3: the training epilogue -- raw fp32 output + per-channel (sum, sumsq) into `shift` viewed as the replica slabs
+    CVX_CHECK(shift, "mode 3 needs the statistics slab (cvx_stat_replicas(cout) * cout * 4 64-bit words, zeroed) in `shift`");
+    cp.epi = CVX_EPI_RAW_STATS;
+    cp.out32 = (float*)out;
+    cp.stats = (long long*)shift;
+    cp.stats_replicas = cvx_stat_replicas(cout);
   }
   int rc = cvx_conv_igemm_launch(cp, st, nullptr);
   (void)hipStreamSynchronize(st);

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Round evidence on the GPU box (run from the repo root through gpurun): rocprofv3 kernel statistics, the two PMC passes for
+# HBM traffic, the bench lines.  Outputs under gpurun_out/profiles_rNN/ -- copy what is to be judged into profiles/.
+#   tools/collect_profiles.sh r02
+set -e
+R=${1:-r02}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/profiles_$R
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${R}_bench_under_rocprof.json 2> $OUT/stats.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $ROOT/bench.py --no-cpu-baseline --steps 3 --warmup 2 --profile-steps 1 > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $ROOT/bench.py --no-cpu-baseline --steps 3 --warmup 2 --profile-steps 1 > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cn -- python $ROOT/bench.py --workload centernet --steps 5 --warmup 2 > $OUT/${R}_bench_centernet_under_rocprof.json 2> $OUT/stats_cn.err
+cd $ROOT
+cp $(ls $OUT/stats/*/*_kernel_stats.csv | head -1) $OUT/${R}_bench_kernel_stats.csv
+cp $(ls $OUT/stats_cn/*/*_kernel_stats.csv | head -1) $OUT/${R}_bench_centernet_kernel_stats.csv
+python tools/pmc_traffic.py $(ls $OUT/pmc_fetch/*/*_counter_collection.csv | head -1) $(ls $OUT/pmc_write/*/*_counter_collection.csv | head -1) $OUT/${R}_conv_traffic.json
+python bench.py --steps 30 --warmup 5 > $OUT/${R}_bench.json 2> $OUT/bench.err
+python bench.py --workload centernet --steps 10 --warmup 2 > $OUT/${R}_bench_centernet.json 2>> $OUT/bench.err
+python bench.py --model s --steps 20 --warmup 3 --no-cpu-baseline > $OUT/${R}_bench_yolov8s.json 2>> $OUT/bench.err
+python tools/op_profile.py 5 > $OUT/${R}_op_profile.txt 2>> $OUT/bench.err
+rm -rf $OUT/stats $OUT/stats_cn $OUT/pmc_fetch $OUT/pmc_write
+ls -la $OUT

@@ -46,8 +46,13 @@ def main():
         Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
         out = torch.empty(B, Ho, Wo, Co, dtype=torch.float16, device=dev)
 
+        mode = int(os.environ.get("CONV_CLOCK_MODE", "0"))           # 3: training epilogue (raw fp32 + statistics)
+        out32 = torch.empty(B, Ho, Wo, Co, dtype=torch.float32, device=dev) if mode == 3 else None
+        slab = torch.zeros(16 * Co * 4, dtype=torch.int64, device=dev)
+
         def run():
-            L.check(lib.cvx_conv2d_nhwc(L.ptr(x), B, H, W, Ci, L.ptr(w), Co, k, s, k // 2, 1, 0, None, None, L.ptr(out), L.stream_ptr(dev)), "conv")
+            L.check(lib.cvx_conv2d_nhwc(L.ptr(x), B, H, W, Ci, L.ptr(w), Co, k, s, k // 2, 1, mode, None, L.ptr(slab) if mode == 3 else None,
+                                        L.ptr(out32 if mode == 3 else out), L.stream_ptr(dev)), "conv")
         for _ in range(5):
             run()
         torch.cuda.synchronize()
