@@ -851,6 +851,9 @@ int flush_wgrads(cvx_engine* e, hipEvent_t ev, hipStream_t producer) {
       CVX_TRY(cvx_stem_backward(g.sp, g.wp.dy /* = xhat */, g.gout, g.coef, g.part, g.inv_scale, g.dgamma, g.dbeta, g.wp.slabs, g.wp.nsplit, producer));
       continue;
     }
+    // tuning build only (cvx_tune_int is a constant in the release library): time the main stream without its competitor
+    static const bool skip = cvx_tune_int("CVX_TUNE_SKIP_WGRAD", 0) != 0;
+    if (skip) continue;
     ProfScope ps(e, PROF_CONV_WGRAD, g.flops, g.bytes, e->side);
     CVX_TRY(cvx_conv_wgrad_launch(g.wp, e->side));
   }
