@@ -668,7 +668,19 @@ extern "C" int cvx_engine_set_bn(cvx_engine* e, float eps, float momentum) {
 }
 
 extern "C" int cvx_engine_debug_copy(cvx_engine* e, int32_t buf, int32_t which, void* dst, int64_t bytes) {
-  CVX_CHECK(e && dst && buf >= 0 && buf < (int)e->bufs.size(), "bad arguments");
+  CVX_CHECK(e && dst && buf >= 0, "bad arguments");
+  if (which == 2 || which == 3) {  // per-layer operands of the backward pass: `buf` is an op index
+    CVX_CHECK(buf < (int)e->ops.size() && e->ops[buf].type == CVX_OP_CONV, "which 2/3: `buf` must be the index of a conv op");
+    const ConvRt& c = e->conv[buf];
+    const cvx_op_desc& o = e->ops[buf];
+    const half_t* src = which == 2 ? c.ybuf : c.dybuf;
+    CVX_CHECK(src && e->planned_batch > 0 && e->planned_train, "no training plan, or the op keeps no such tensor");
+    const int64_t want = (int64_t)e->planned_batch * o.oh * o.ow * o.out.c * 2;
+    CVX_CHECK(bytes == want, "size mismatch: the tensor holds " + std::to_string(want) + " bytes");
+    CVX_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDefault, e->stream));
+    return 0;
+  }
+  CVX_CHECK(buf < (int)e->bufs.size(), "bad arguments");
   const Buf& b = e->bufs[buf];
   const half_t* src = which ? b.grad : b.act;
   CVX_CHECK(src && e->planned_batch > 0, "buffer not allocated (no forward yet, or eval-only plan)");
@@ -920,7 +932,8 @@ int backward_op(cvx_engine* e, int i) {
       ViewDesc gres = make_view(e, o.res, true);
       BnCoef k{c.invstd, e->params + o.gamma_off, e->params + o.beta_off};
       ProfScope ps(e, PROF_BN_BWD, 0, (c.stem ? 4.0 : (gres.p ? 14.0 : 10.0)) * M * C, st);
-      CVX_TRY(cvx_bn_bwd_reduce(c.ybuf, M, C, hw, k, gout, c.stat_bwd, st));
+      static const bool tune_skip_reduce = cvx_tune_int("CVX_TUNE_SKIP_BN_REDUCE", 0) != 0;  // tuning build: timing without the pass (wrong results)
+      if (!tune_skip_reduce) CVX_TRY(cvx_bn_bwd_reduce(c.ybuf, M, C, hw, k, gout, c.stat_bwd, st));
       // the stem's "apply" half is fused into its weight gradient (cvx_stem_backward, queued below): dy is never materialised
       if (!c.stem)
         CVX_TRY(cvx_bn_bwd_apply(c.ybuf, M, C, hw, k, c.stat_bwd, w.inv_scale, e->grads + o.gamma_off, e->grads + o.beta_off, gout, c.dybuf,

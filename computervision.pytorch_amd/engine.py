@@ -103,6 +103,13 @@ class Engine:
         L.check(self.lib.cvx_engine_debug_copy(self.handle, buf, 1 if grad else 0, L.ptr(out), out.numel() * 2), "cvx_engine_debug_copy")
         return out
 
+    def read_layer(self, op: int, batch: int, what: str = "xhat") -> torch.Tensor:
+        """Debug: a conv op's normalised output (``xhat``) or the gradient w.r.t. its raw output (``dy``), NHWC fp16."""
+        o = self.graph.ops[op]
+        out = torch.empty(batch, o["oh"], o["ow"], o["out"][2], dtype=torch.float16, device=self.device)
+        L.check(self.lib.cvx_engine_debug_copy(self.handle, op, 2 if what == "xhat" else 3, L.ptr(out), out.numel() * 2), "cvx_engine_debug_copy")
+        return out
+
     PROFILE_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn_silu_fwd", "bn_silu_bwd", "misc", "slab_reduce")
 
     def profile(self, enable: bool):

@@ -103,7 +103,9 @@ int cvx_engine_forward(cvx_engine* e, const float* images, int32_t batch, int32_
 int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float loss_scale);
 
 /* Debug/inspection: copies activation (which=0) or gradient (which=1) buffer `buf` of the last planned
- * batch, NHWC fp16, into dst (device or host memory, `bytes` must equal batch*h*w*c*2). */
+ * batch, NHWC fp16, into dst (device or host memory, `bytes` must equal batch*h*w*c*2).  which=2 / 3: `buf` is the index
+ * of a conv op and the tensor is its normalised output xhat = (y-mean)*invstd / the gradient w.r.t. its raw output,
+ * dense (batch, oh, ow, cout) fp16 -- the per-layer operands of the backward pass (training plans only). */
 int cvx_engine_debug_copy(cvx_engine* e, int32_t buf, int32_t which, void* dst, int64_t bytes);
 
 /* Segmented backward for data-parallel training: the same pass as cvx_engine_backward, cut into op ranges so that the
