@@ -59,4 +59,17 @@ int cvx_bn_bwd_reduce(const half_t* xhat, long long M, int C, int hw, const BnCo
 int cvx_bn_bwd_apply(const half_t* xhat, long long M, int C, int hw, const BnCoef& k, const long long* part, float inv_scale, float* dgamma,
                      float* dbeta, const ViewDesc& gout, half_t* dy, const ViewDesc& gres, int res_accumulate, hipStream_t st);
 // part: replica slabs [R][C][2], zero on entry
+// ... of several tensors that are views of one allocation, in two launches: descs / blocks live in device memory
+struct ColsumDesc {
+  long long off, bstride;  // element (b, pix, c) of the tensor at base[off + b*bstride + pix*ld + c]
+  long long M;             // rows = batch * hw
+  int ld, hw, C, rows_per_block;
+  long long* part;         // replica slabs [R][C][2] fixed-point values, zero on entry
+  long long dbias_off;     // grads[dbias_off + c] += column sum * inv_scale
+};
+struct ColsumBlock {
+  int desc, block;         // workgroup -> (tensor, row chunk of rows_per_block rows)
+};
+int cvx_colsum_multi(const half_t* base, const ColsumDesc* descs, int ndesc, int max_c, const ColsumBlock* blocks, int nblocks, float inv_scale,
+                     float* grads, hipStream_t st);
 int cvx_colsum(long long M, int C, int hw, const ViewDesc& g, long long* part, float inv_scale, float* dbias, hipStream_t st);

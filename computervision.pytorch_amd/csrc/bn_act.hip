@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const half_t* xhat, 
       one(v, g);
     }
   }
-  block_channel_sums<2>(acc, C, CG, cg, active, sacc, part);
+  block_channel_sums<2>(acc, C, CG, cg, active, sacc, part, blockIdx.x);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const half_t* xhat, long long M, int C, int hw, BnCoef k, const long long* part,
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void bn_stats_f32_kernel(const float* y, long 
       }
     }
   }
-  block_channel_sums<2>(acc, C, CG, cg, active, sacc, part);
+  block_channel_sums<2>(acc, C, CG, cg, active, sacc, part, blockIdx.x);
 }
 
 // column sums of a [M][C] fp16 view (bias gradient of the head's 1x1 output convs)
@@ -303,7 +303,51 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(long long M, int C, 
       for (int i = 0; i < 8; ++i) acc[0][i] += (float)v[i];
     }
   }
-  block_channel_sums<1>(acc, C, CG, cg, active, sacc, part);
+  block_channel_sums<1>(acc, C, CG, cg, active, sacc, part, blockIdx.x);
+}
+
+// every bias gradient of the network in two launches (the head's six 1x1 output convs: twelve launches one by one, at the
+// very start of the backward pass): block -> (tensor, row chunk) through a table, one finalize block per tensor
+__global__ __launch_bounds__(256) void colsum_multi_reduce_kernel(const half_t* base, const ColsumDesc* descs, const ColsumBlock* blocks) {
+  __shared__ float sacc[256 * 8];
+  const ColsumBlock br = blocks[blockIdx.x];
+  const ColsumDesc d = descs[br.desc];
+  const ViewDesc g{const_cast<half_t*>(base) + d.off, d.bstride, d.ld};
+  const int C = d.C, hw = d.hw;
+  const int CG = C >> 3;
+  const int RP = 256 / CG;
+  const int cg = threadIdx.x % CG, r = threadIdx.x / CG;
+  const bool active = r < RP;
+  float acc[1][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[0][i] = 0.f;
+  if (active) {
+    const long long m0 = (long long)br.block * d.rows_per_block;
+    const long long m1 = min(d.M, m0 + d.rows_per_block);
+    long long m = m0 + r;
+    for (; m + (long long)(UNR - 1) * RP < m1; m += (long long)UNR * RP) {
+      h8 v[UNR];
+#pragma unroll
+      for (int q = 0; q < UNR; ++q) v[q] = *reinterpret_cast<const h8*>(g.p + view_off(g, m + q * RP, hw) + cg * 8);
+#pragma unroll
+      for (int q = 0; q < UNR; ++q)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[0][i] += (float)v[q][i];
+    }
+    for (; m < m1; m += RP) {
+      h8 v = *reinterpret_cast<const h8*>(g.p + view_off(g, m, hw) + cg * 8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[0][i] += (float)v[i];
+    }
+  }
+  block_channel_sums<1>(acc, C, CG, cg, active, sacc, d.part, br.block);
+}
+__global__ __launch_bounds__(256) void colsum_multi_finalize_kernel(const ColsumDesc* descs, float inv_scale, float* grads) {
+  extern __shared__ __attribute__((aligned(16))) long long ws[];
+  const ColsumDesc d = descs[blockIdx.x];
+  fold_replicas(d.part, d.C, ws);
+  const double* s0 = reinterpret_cast<const double*>(ws);
+  for (int c = threadIdx.x; c < d.C; c += 256) grads[d.dbias_off + c] += (float)(s0[c] * inv_scale);
 }
 
 }  // namespace
@@ -372,6 +416,15 @@ int cvx_bn_bwd_apply(const half_t* xhat, long long M, int C, int hw, const BnCoe
   int rows = cvx_stream_rows_per_block(M, C, 32);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(M, rows)), dim3(256), fold_ws_bytes(C), st, xhat, M, C, hw, k, part, inv_scale, dgamma,
                      dbeta, gout, dy, gres, res_accumulate, rows);
+  CVX_HIP(hipGetLastError());
+  return 0;
+}
+int cvx_colsum_multi(const half_t* base, const ColsumDesc* descs, int ndesc, int max_c, const ColsumBlock* blocks, int nblocks, float inv_scale,
+                     float* grads, hipStream_t st) {
+  if (ndesc <= 0 || nblocks <= 0) return 0;
+  CVX_TRY(check_c(max_c));
+  hipLaunchKernelGGL(colsum_multi_reduce_kernel, dim3(nblocks), dim3(256), 0, st, base, descs, blocks);
+  hipLaunchKernelGGL(colsum_multi_finalize_kernel, dim3(ndesc), dim3(256), fold_ws_bytes(max_c), st, descs, inv_scale, grads);
   CVX_HIP(hipGetLastError());
   return 0;
 }

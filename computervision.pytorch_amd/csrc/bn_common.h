@@ -54,8 +54,10 @@ __device__ __forceinline__ void fold_replicas(const long long* part, int C, long
 // LDS slot; NV*C threads add the four wave slots in fixed order and issue ONE fixed-point atomic add per value.
 // Channel-group counts that do not divide 64 (C = 80, 144: Detect head) take the parked-partials column walk instead.
 // part: replica slabs [R][C][2] fixed-point values; NV = 1 fills value 0 only.
+// rep_block: the block's ordinal among the blocks that feed `part` (picks the replica slab)
 template <int NV>
-__device__ __forceinline__ void block_channel_sums(float (&v)[NV][8], int C, int CG, int cg, bool active, float* sred, long long* part) {
+__device__ __forceinline__ void block_channel_sums(float (&v)[NV][8], int C, int CG, int cg, bool active, float* sred, long long* part,
+                                                   int rep_block) {
   const bool pow2 = (64 % CG) == 0;
   if (pow2) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -71,7 +73,7 @@ __device__ __forceinline__ void block_channel_sums(float (&v)[NV][8], int C, int
     for (int j = threadIdx.x; j < NV * C; j += 256) {
       const int c = j / NV, q = j - c * NV;
       const float acc = (sred[(0 * C + c) * NV + q] + sred[(1 * C + c) * NV + q]) + (sred[(2 * C + c) * NV + q] + sred[(3 * C + c) * NV + q]);
-      cvx_fix_atomic_add(part, ((long long)(blockIdx.x % cvx_stat_replicas(C)) * C + c) * 2 + q, acc);
+      cvx_fix_atomic_add(part, ((long long)(rep_block % cvx_stat_replicas(C)) * C + c) * 2 + q, acc);
     }
     return;
   }
@@ -89,7 +91,7 @@ __device__ __forceinline__ void block_channel_sums(float (&v)[NV][8], int C, int
     const int g = c >> 3, i = c & 7;
     float acc = 0.f;
     for (int r = 0; r < RP; ++r) acc += sred[(size_t)(r * CG + g) * (NV * 8) + q * 8 + i];
-    cvx_fix_atomic_add(part, ((long long)(blockIdx.x % cvx_stat_replicas(C)) * C + c) * 2 + q, acc);
+    cvx_fix_atomic_add(part, ((long long)(rep_block % cvx_stat_replicas(C)) * C + c) * 2 + q, acc);
   }
 }
 

@@ -119,6 +119,9 @@ struct cvx_engine {
   int n_slab_blocks = 0;
   // the slab reduction runs in two parts: everything but the first `tail` conv ops as soon as THEIR weight gradients are
   // done (overlapping the last, largest-image weight gradients on the side stream), then the rest
+  ColsumDesc* d_colsum = nullptr;    // bias gradients of every conv+bias op in one reduction (cvx_colsum_multi)
+  ColsumBlock* d_colsum_blocks = nullptr;
+  int n_colsum = 0, n_colsum_blocks = 0, colsum_max_c = 0;
   BnFoldDesc* d_fold = nullptr;  // eval-mode BN fold table (one entry per BN conv), rebuilt with the batch plan
   int n_fold = 0;
   int slab_tail_blocks = 0;  // reducer workgroups of the first ops (the tail of the backward pass)
@@ -512,6 +515,35 @@ int plan_batch(cvx_engine* e, int B, bool training) {
     c.stat_fwd = e->stat_region + off;
     c.stat_bwd = e->stat_region + stat_floats + off;
   }
+  e->n_colsum = e->n_colsum_blocks = e->colsum_max_c = 0;
+  if (training) {
+    const Buf& pb = e->bufs[e->pred_buf];
+    const long long A = (long long)pb.d.h * pb.d.w;
+    std::vector<ColsumDesc> cds;
+    std::vector<ColsumBlock> cbs;
+    for (size_t i = 0; i < e->ops.size(); ++i) {
+      const cvx_op_desc& o = e->ops[i];
+      if (o.type != CVX_OP_CONV || o.act != CVX_ACT_BIAS) continue;
+      ColsumDesc d;
+      d.off = (long long)o.out.pix_off * pb.d.c + o.out.coff;
+      d.bstride = A * pb.d.c;
+      d.ld = pb.d.c;
+      d.hw = o.oh * o.ow;
+      d.M = (long long)B * d.hw;
+      d.C = o.out.c;
+      d.rows_per_block = cvx_stream_rows_per_block(d.M, d.C, 32);
+      d.part = e->conv[i].stat_bwd;
+      d.dbias_off = o.bias_off;
+      const int nb = (int)((d.M + d.rows_per_block - 1) / d.rows_per_block);
+      for (int b = 0; b < nb; ++b) cbs.push_back(ColsumBlock{(int)cds.size(), b});
+      if (d.C > e->colsum_max_c) e->colsum_max_c = d.C;
+      cds.push_back(d);
+    }
+    CVX_TRY(upload(e, e->batch_allocs, e->batch_bytes, &e->d_colsum, cds));
+    CVX_TRY(upload(e, e->batch_allocs, e->batch_bytes, &e->d_colsum_blocks, cbs));
+    e->n_colsum = (int)cds.size();
+    e->n_colsum_blocks = (int)cbs.size();
+  }
   if (training) {
     CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, slab_total * 4));
     e->slabs = (float*)p;
@@ -890,6 +922,14 @@ int backward_begin(cvx_engine* e, const void* dpred_f16, float loss_scale) {
   static const int wg_batch_env = cvx_tune_int("CVX_WGRAD_BATCH", 3);
   w.wg_batch = wg_batch_env < 1 ? 1 : wg_batch_env;
   CVX_HIP(hipMemsetAsync(e->stat_region + e->stat_half, 0, (size_t)e->stat_half * 8, st));
+  if (e->n_colsum > 0) {  // every bias gradient (the head's 1x1 output convs) at once: column sums of dpred
+    double by = 0;
+    for (size_t i = 0; i < e->ops.size(); ++i)
+      if (e->ops[i].type == CVX_OP_CONV && e->ops[i].act == CVX_ACT_BIAS) by += 2.0 * w.B * e->ops[i].oh * e->ops[i].ow * e->ops[i].out.c;
+    e->cur_op = -1;
+    ProfScope ps(e, PROF_MISC, 0, by, st);
+    CVX_TRY(cvx_colsum_multi(w.dpred, e->d_colsum, e->n_colsum, e->colsum_max_c, e->d_colsum_blocks, e->n_colsum_blocks, w.inv_scale, e->grads, st));
+  }
   // fork: the side stream (weight gradients) starts after everything already queued on the main stream
   CVX_HIP(hipEventRecord(e->ev_fork, st));
   CVX_HIP(hipStreamWaitEvent(e->side, e->ev_fork, 0));
@@ -925,8 +965,7 @@ int backward_op(cvx_engine* e, int i) {
       dyv.p = w.dpred + (long long)o.out.pix_off * pb.d.c + o.out.coff;
       dyv.ld = pb.d.c;
       dyv.bstride = A * pb.d.c;
-      ProfScope ps(e, PROF_MISC, 0, 2.0 * M * C, st);
-      CVX_TRY(cvx_colsum(M, C, hw, dyv, c.stat_bwd, w.inv_scale, e->grads + o.bias_off, st));
+      // (the bias gradient = column sums of dy went out with all the others in backward_begin: cvx_colsum_multi)
     } else {
       ViewDesc gout = make_view(e, o.out, true);
       ViewDesc gres = make_view(e, o.res, true);
