@@ -106,6 +106,12 @@ struct cvx_engine {
   long long stat_half = 0;           // entries per half
   hipStream_t side = nullptr;    // weight gradients run here, concurrently with the data-gradient chain
   hipStream_t red = nullptr;     // gradient-slab reduction (whole-pass backward): off the main chain as well
+  // ops with cvx_op_desc.lane >= 2 (Detect levels 1 and 2: short, latency-bound chains, independent of level 0's) run on
+  // this stream, beside the main chain, between one fork and one join per pass
+  hipStream_t lane = nullptr;
+  hipEvent_t ev_lane_fork = nullptr, ev_lane_join = nullptr;
+  bool use_lanes = false;
+  float* ytmp_lane = nullptr;         // raw fp32 conv output of the lane's layer in flight
   hipEvent_t ev_red = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool image_nhwc = false;            // a non-stem op reads the image: keep an NHWC fp16 copy (channels padded to 8)
@@ -381,13 +387,14 @@ int plan_batch(cvx_engine* e, int B, bool training) {
   if (e->planned_batch == B && (e->planned_train || !training)) return 0;
   CVX_HIP(hipStreamSynchronize(e->stream));
   if (e->side) CVX_HIP(hipStreamSynchronize(e->side));
+  if (e->lane) CVX_HIP(hipStreamSynchronize(e->lane));
   free_pool(e->batch_allocs);
   e->batch_bytes = 0;
   e->planned_batch = 0;
   e->plan_generation++;  // every per-batch buffer moves: a hipGraph captured against the old plan must be dropped
   e->fwd_train_done = false;
   void* p = nullptr;
-  long long ytmp_elems = 0;
+  long long ytmp_elems = 0, ytmp_lane_elems = 0;
   for (size_t bi = 0; bi < e->bufs.size(); ++bi) {
     Buf& b = e->bufs[bi];
     b.act = b.grad = nullptr;
@@ -436,6 +443,7 @@ int plan_batch(cvx_engine* e, int B, bool training) {
         c.dybuf = (half_t*)p;
       }
       if (!c.stem) ytmp_elems = std::max(ytmp_elems, M * C);
+      if (e->use_lanes && o.lane >= 2) ytmp_lane_elems = std::max(ytmp_lane_elems, M * C);
     }
     c.stat_fwd = (long long*)nullptr + stat_floats;  // offset for now, rebased below
     stat_floats += (long long)cvx_stat_replicas(C) * C * CVX_STAT_WORDS;
@@ -502,6 +510,11 @@ int plan_batch(cvx_engine* e, int B, bool training) {
   if (training && ytmp_elems > 0) {
     CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, ytmp_elems * 4));
     e->ytmp = (float*)p;
+  }
+  e->ytmp_lane = nullptr;
+  if (training && ytmp_lane_elems > 0) {
+    CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, ytmp_lane_elems * 4));
+    e->ytmp_lane = (float*)p;
   }
   CVX_TRY(upload(e, e->batch_allocs, e->batch_bytes, &e->d_fold, folds));
   e->n_fold = (int)folds.size();
@@ -614,8 +627,15 @@ extern "C" int cvx_engine_create(cvx_engine** out, const cvx_buf_desc* bufs, int
     static const bool side_prio = cvx_tune_int("CVX_SIDE_PRIO", 1) != 0;
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    hipError_t side_rc = side_prio ? hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio_least)
-                                   : hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
+    hipError_t side_rc;
+    static const int side_cus = cvx_tune_int("CVX_SIDE_CUS", 0);  // tuning build: confine the weight-gradient stream to the first n CUs
+    if (side_cus > 0) {
+      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int c = 0; c < side_cus && c < 256; ++c) mask[c >> 5] |= 1u << (c & 31);
+      side_rc = hipExtStreamCreateWithCUMask(&e->side, 8, mask);
+    } else
+      side_rc = side_prio ? hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio_least)
+                          : hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
     if (side_rc == hipSuccess)
       side_rc = side_prio ? hipStreamCreateWithPriority(&e->red, hipStreamNonBlocking, prio_least)
                           : hipStreamCreateWithFlags(&e->red, hipStreamNonBlocking);
@@ -631,7 +651,24 @@ extern "C" int cvx_engine_create(cvx_engine** out, const cvx_buf_desc* bufs, int
         cvx_set_error("cvx_engine_create: could not create events");
         rc = -1;
       }
-    for (cvx_op_desc& o : e->ops) o.lane = 0;  // reserved field (measured: the three Detect levels on own streams were slower)
+    // lanes: a HIGH-priority stream, i.e. a priority class (and hardware queue) of its own -- plain extra streams can land on
+    // the main or the side stream's hardware queue and serialise with it (that is what made per-level streams slower before)
+    static const bool lanes_on = cvx_tune_int("CVX_LANES", 1) != 0;
+    bool any_lane = false;
+    for (cvx_op_desc& o : e->ops) {
+      if (!lanes_on || e->inference_only) o.lane = 0;
+      any_lane = any_lane || o.lane >= 2;
+    }
+    if (rc == 0 && any_lane) {
+      if (hipStreamCreateWithPriority(&e->lane, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
+          hipEventCreateWithFlags(&e->ev_lane_fork, cvx_event_flags()) == hipSuccess &&
+          hipEventCreateWithFlags(&e->ev_lane_join, cvx_event_flags()) == hipSuccess) {
+        e->use_lanes = true;
+      } else {
+        (void)hipGetLastError();
+        for (cvx_op_desc& o : e->ops) o.lane = 0;
+      }
+    }
   }
   if (rc != 0) {
     free_pool(e->static_allocs);
@@ -651,6 +688,12 @@ extern "C" int cvx_engine_destroy(cvx_engine* e) {
   }
   for (auto& c : e->conv)
     if (c.ev_dy) (void)hipEventDestroy(c.ev_dy);
+  if (e->lane) {
+    (void)hipStreamSynchronize(e->lane);
+    (void)hipStreamDestroy(e->lane);
+  }
+  if (e->ev_lane_fork) (void)hipEventDestroy(e->ev_lane_fork);
+  if (e->ev_lane_join) (void)hipEventDestroy(e->ev_lane_join);
   if (e->red) {
     (void)hipStreamSynchronize(e->red);
     (void)hipStreamDestroy(e->red);
@@ -747,9 +790,24 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
   const long long A = (long long)pb.d.h * pb.d.w;
   if (!training) CVX_TRY(cvx_bn_fold_all(e->d_fold, e->n_fold, e->params, e->stats, e->bn_eps, st));  // eval: running stats -> scale/shift
 
+  const hipStream_t main_st = st;
+  bool lane_forked = false, lane_used = false;
   for (size_t i = 0; i < e->ops.size(); ++i) {
     const cvx_op_desc& o = e->ops[i];
     e->cur_op = (int)i;
+    // lanes (Detect levels 1, 2 beside level 0): fork where the first op of ANY lane comes up -- everything the lanes read
+    // exists by then --, the lane stream joins back after the last op
+    st = main_st;
+    if (e->use_lanes && o.lane >= 1 && !lane_forked) {
+      CVX_HIP(hipEventRecord(e->ev_lane_fork, main_st));
+      lane_forked = true;
+    }
+    if (e->use_lanes && o.lane >= 2) {
+      if (!lane_used) CVX_HIP(hipStreamWaitEvent(e->lane, e->ev_lane_fork, 0));
+      lane_used = true;
+      st = e->lane;
+    }
+    float* const ytmp = st == main_st ? e->ytmp : e->ytmp_lane;
     if (o.type == CVX_OP_MAXPOOL5) {
       ProfScope ps(e, PROF_MISC, 0, 4.0 * B * o.ih * o.iw * o.in.c, st);
       CVX_TRY(cvx_maxpool5_fwd(make_view(e, o.in, false), make_view(e, o.out, false), B, o.ih, o.iw, o.in.c,
@@ -814,7 +872,7 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
     ViewDesc resv = make_view(e, o.res, false);
     if (training) {
       cp.epi = CVX_EPI_RAW_STATS;
-      cp.out32 = e->ytmp;  // raw fp32 output: lives until the normalisation pass right below, then the next layer reuses it
+      cp.out32 = ytmp;  // raw fp32 output: lives until the normalisation pass right below, then the next layer (of this stream) reuses it
       cp.out_ld = C;
       cp.out_bstride = (long long)o.oh * o.ow * C;
       cp.stats = c.stat_fwd;
@@ -827,7 +885,7 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
       ProfScope ps(e, PROF_BN_FWD, 0, (resv.p ? 10.0 : 8.0) * M * C, st);
       BnTrainArgs ta{c.stat_fwd,           e->params + o.gamma_off, e->params + o.beta_off, c.mean, c.invstd, e->stats + o.rmean_off,
                      e->stats + o.rvar_off, e->bn_eps,       e->bn_momentum};
-      CVX_TRY(cvx_bn_silu_apply(e->ytmp, M, C, o.oh * o.ow, ta, outv, resv, c.ybuf, st));
+      CVX_TRY(cvx_bn_silu_apply(ytmp, M, C, o.oh * o.ow, ta, outv, resv, c.ybuf, st));
     } else {
       // scale / shift were folded for every layer at once before the op loop (cvx_bn_fold_all)
       cp.epi = CVX_EPI_AFFINE_SILU;
@@ -844,6 +902,10 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
       ProfScope ps(e, PROF_CONV_FWD, conv_flops(o, B), conv_bytes(o, B), st);
       CVX_TRY(cvx_conv_igemm_launch(cp, st, nullptr));
     }
+  }
+  if (lane_used) {
+    CVX_HIP(hipEventRecord(e->ev_lane_join, e->lane));
+    CVX_HIP(hipStreamWaitEvent(main_st, e->ev_lane_join, 0));
   }
   e->cur_op = -1;
   e->fwd_train_done = training != 0;
@@ -871,6 +933,8 @@ struct cvx_bw_state {
   bool active = false;
   int wg_batch = 1;
   int next_op = -1;  // next op (descending) the segmented interface expects
+  bool lane_pending = false;       // kernels queued on the lane stream since the last join
+  hipStream_t pending_stream = nullptr;  // stream that produced the dy tensors of `pending`
   std::vector<PendingWgrad> pending;
 };
 static cvx_bw_state& bw_of(cvx_engine* e) {
@@ -905,6 +969,16 @@ int flush_wgrads(cvx_engine* e, hipEvent_t ev, hipStream_t producer) {
   return 0;
 }
 
+int join_lane(cvx_engine* e) {
+  cvx_bw_state& w = bw_of(e);
+  if (!w.lane_pending) return 0;
+  if (!w.pending.empty() && w.pending_stream == e->lane) CVX_TRY(flush_wgrads(e, e->ev_lane_fork, e->lane));
+  CVX_HIP(hipEventRecord(e->ev_lane_join, e->lane));
+  CVX_HIP(hipStreamWaitEvent(e->stream, e->ev_lane_join, 0));
+  w.lane_pending = false;
+  return 0;
+}
+
 int backward_begin(cvx_engine* e, const void* dpred_f16, float loss_scale) {
   CVX_CHECK(e && dpred_f16, "bad arguments");
   CVX_CHECK(e->fwd_train_done, "cvx_engine_backward needs a preceding training-mode forward");
@@ -933,6 +1007,9 @@ int backward_begin(cvx_engine* e, const void* dpred_f16, float loss_scale) {
   // fork: the side stream (weight gradients) starts after everything already queued on the main stream
   CVX_HIP(hipEventRecord(e->ev_fork, st));
   CVX_HIP(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+  if (e->use_lanes) CVX_HIP(hipStreamWaitEvent(e->lane, e->ev_fork, 0));
+  w.lane_pending = false;
+  w.pending_stream = nullptr;
   return 0;
 }
 
@@ -945,6 +1022,15 @@ int backward_op(cvx_engine* e, int i) {
   const cvx_op_desc& o = e->ops[i];
   e->cur_op = i;
     hipStream_t st = e->stream;
+    if (e->use_lanes && o.lane >= 2) {
+      st = e->lane;
+      w.lane_pending = true;
+    } else if (w.lane_pending && o.lane == 0) {
+      CVX_TRY(join_lane(e));  // the first op after the head: it consumes gradients the lanes wrote
+    }
+    // weight gradients wait for ONE event per batch, recorded on the stream that produced their dy: a batch never mixes streams
+    if (!w.pending.empty() && w.pending_stream != st) CVX_TRY(flush_wgrads(e, e->ev_lane_fork, w.pending_stream));
+    w.pending_stream = st;
     if (o.type == CVX_OP_MAXPOOL5) {
       ProfScope ps(e, PROF_MISC, 0, 7.0 * B * o.ih * o.iw * o.in.c, st);
       CVX_TRY(cvx_maxpool5_bwd(make_view(e, o.out, true), make_view(e, o.in, true), B, o.ih, o.iw, o.in.c, e->pool[i].idx,
@@ -1134,6 +1220,7 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
     }
   }
   w.active = false;
+  CVX_TRY(join_lane(e));
   CVX_TRY(flush_wgrads(e, e->ev_fork, st));  // (non-conv first ops: nothing pending in practice)
   e->cur_op = -1;
   CVX_HIP(hipEventRecord(e->ev_join, e->side));  // the last chunk needs the remaining weight-gradient slabs ...
@@ -1163,6 +1250,7 @@ extern "C" int cvx_engine_backward_range(cvx_engine* e, int32_t op_hi, int32_t o
   CVX_CHECK(op_hi == w.next_op && op_lo >= 0 && op_lo <= op_hi, "ranges must tile the op list from the last op down to 0");
   for (int i = op_hi; i >= op_lo; --i) CVX_TRY(backward_op(e, i));
   w.next_op = op_lo - 1;
+  CVX_TRY(join_lane(e));                             // (a range that ends inside the head)
   CVX_TRY(flush_wgrads(e, e->ev_fork, e->stream));  // every weight gradient of the range is queued on the side stream
   return 0;
 }
