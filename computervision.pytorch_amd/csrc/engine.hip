@@ -109,7 +109,7 @@ struct cvx_engine {
   // ops with cvx_op_desc.lane >= 2 (Detect levels 1 and 2: short, latency-bound chains, independent of level 0's) run on
   // this stream, beside the main chain, between one fork and one join per pass
   hipStream_t lane = nullptr;
-  hipEvent_t ev_lane_fork = nullptr, ev_lane_join = nullptr;
+  hipEvent_t ev_lane_fork = nullptr, ev_lane_join = nullptr, ev_pack = nullptr;
   bool use_lanes = false;
   float* ytmp_lane = nullptr;         // raw fp32 conv output of the lane's layer in flight
   hipEvent_t ev_red = nullptr;
@@ -659,13 +659,17 @@ extern "C" int cvx_engine_create(cvx_engine** out, const cvx_buf_desc* bufs, int
       if (!lanes_on || e->inference_only) o.lane = 0;
       any_lane = any_lane || o.lane >= 2;
     }
-    if (rc == 0 && any_lane) {
+    const bool stem_first = !e->ops.empty() && e->ops[0].type == CVX_OP_CONV && e->conv[0].stem;  // the weight packing can run beside it
+    if (rc == 0 && (any_lane || (lanes_on && stem_first))) {
       if (hipStreamCreateWithPriority(&e->lane, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
           hipEventCreateWithFlags(&e->ev_lane_fork, cvx_event_flags()) == hipSuccess &&
-          hipEventCreateWithFlags(&e->ev_lane_join, cvx_event_flags()) == hipSuccess) {
-        e->use_lanes = true;
+          hipEventCreateWithFlags(&e->ev_lane_join, cvx_event_flags()) == hipSuccess &&
+          hipEventCreateWithFlags(&e->ev_pack, cvx_event_flags()) == hipSuccess) {
+        e->use_lanes = any_lane;
       } else {
         (void)hipGetLastError();
+        if (e->lane) (void)hipStreamDestroy(e->lane);
+        e->lane = nullptr;
         for (cvx_op_desc& o : e->ops) o.lane = 0;
       }
     }
@@ -694,6 +698,7 @@ extern "C" int cvx_engine_destroy(cvx_engine* e) {
   }
   if (e->ev_lane_fork) (void)hipEventDestroy(e->ev_lane_fork);
   if (e->ev_lane_join) (void)hipEventDestroy(e->ev_lane_join);
+  if (e->ev_pack) (void)hipEventDestroy(e->ev_pack);
   if (e->red) {
     (void)hipStreamSynchronize(e->red);
     (void)hipStreamDestroy(e->red);
@@ -780,21 +785,35 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
   const Buf& ib = e->bufs[e->image_buf];
   CVX_CHECK(((uintptr_t)images % 8) == 0, "images must be 8-byte aligned");
   if (training) CVX_HIP(hipMemsetAsync(e->stat_region, 0, (size_t)e->stat_half * 8, st));
+  // fp16 weight shadows: the fp32 stem does not need them, so they are prepared on the lane stream BESIDE it (33 us off the main chain); the first op after the stem waits for them
+  const bool prep_beside_stem = e->lane && !e->ops.empty() && e->ops[0].type == CVX_OP_CONV && e->conv[0].stem && !e->profile;
+  hipStream_t prep = st;
+  if (prep_beside_stem) {
+    CVX_HIP(hipEventRecord(e->ev_pack, st));  // the caller's parameter update precedes on this stream
+    CVX_HIP(hipStreamWaitEvent(e->lane, e->ev_pack, 0));
+    prep = e->lane;
+  }
   {
-    ProfScope ps(e, PROF_MISC, 0, 6.0 * e->n_params);
-    CVX_TRY(cvx_pack_weights(e->params, e->shadow, e->d_pack, e->d_pack_blocks, e->n_pack_blocks, st));
+    ProfScope ps(e, PROF_MISC, 0, 6.0 * e->n_params, prep);
+    CVX_TRY(cvx_pack_weights(e->params, e->shadow, e->d_pack, e->d_pack_blocks, e->n_pack_blocks, prep));
   }
   e->last_images = training ? images : nullptr;
   if (e->image_nhwc) CVX_TRY(cvx_image_to_nhwc8(images, B, ib.d.h, ib.d.w, ib.act, st));
   const Buf& pb = e->bufs[e->pred_buf];
   const long long A = (long long)pb.d.h * pb.d.w;
-  if (!training) CVX_TRY(cvx_bn_fold_all(e->d_fold, e->n_fold, e->params, e->stats, e->bn_eps, st));  // eval: running stats -> scale/shift
+  if (!training) CVX_TRY(cvx_bn_fold_all(e->d_fold, e->n_fold, e->params, e->stats, e->bn_eps, st));  // eval: running stats -> scale/shift (the stem's too)
+  bool prep_pending = prep_beside_stem;
+  if (prep_beside_stem) CVX_HIP(hipEventRecord(e->ev_pack, e->lane));
 
   const hipStream_t main_st = st;
   bool lane_forked = false, lane_used = false;
   for (size_t i = 0; i < e->ops.size(); ++i) {
     const cvx_op_desc& o = e->ops[i];
     e->cur_op = (int)i;
+    if (prep_pending && i > 0) {
+      CVX_HIP(hipStreamWaitEvent(main_st, e->ev_pack, 0));
+      prep_pending = false;
+    }
     // lanes (Detect levels 1, 2 beside level 0): fork where the first op of ANY lane comes up -- everything the lanes read
     // exists by then --, the lane stream joins back after the last op
     st = main_st;
