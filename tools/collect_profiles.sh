@@ -16,6 +16,7 @@ cd $ROOT
 cp $(ls $OUT/stats/*/*_kernel_stats.csv | head -1) $OUT/${R}_bench_kernel_stats.csv
 cp $(ls $OUT/stats_cn/*/*_kernel_stats.csv | head -1) $OUT/${R}_bench_centernet_kernel_stats.csv
 python tools/pmc_traffic.py $(ls $OUT/pmc_fetch/*/*_counter_collection.csv | head -1) $(ls $OUT/pmc_write/*/*_counter_collection.csv | head -1) $OUT/${R}_conv_traffic.json
+cp $OUT/${R}_conv_traffic.json profiles/${R}_conv_traffic.json   # bench.py quotes it when its lib_sha256 is the running library's
 python bench.py --steps 30 --warmup 5 > $OUT/${R}_bench.json 2> $OUT/bench.err
 python bench.py --workload centernet --steps 10 --warmup 2 > $OUT/${R}_bench_centernet.json 2>> $OUT/bench.err
 python bench.py --model s --steps 20 --warmup 3 --no-cpu-baseline > $OUT/${R}_bench_yolov8s.json 2>> $OUT/bench.err
