@@ -38,7 +38,7 @@ class OpDesc(C.Structure):
 
 
 BUF_ACT_F16, BUF_PRED_F32 = 0, 1
-OP_CONV, OP_MAXPOOL5, OP_UPSAMPLE2, OP_MAXPOOL2, OP_DWCONVT, OP_COPY = 1, 2, 3, 4, 5, 6
+OP_CONV, OP_MAXPOOL5, OP_UPSAMPLE2, OP_MAXPOOL2, OP_DWCONVT, OP_COPY, OP_MAXPOOL3S2, OP_AVGPOOL, OP_RESIZE = 1, 2, 3, 4, 5, 6, 7, 8, 9
 ACT_BN_SILU, ACT_BIAS, ACT_BN_RELU, ACT_BN_LINEAR, ACT_BIAS_RELU = 1, 2, 3, 4, 5
 OPF_RES_PRE_ACT = 1
 
@@ -94,6 +94,7 @@ PROTOTYPES = {
     "cvx_bn_silu_bwd_nhwc": (_I32, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _F, _P, _P, _P, _P, _I32, _P]),
     "cvx_maxpool5_nhwc": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _P, _P]),
     "cvx_maxpool5_bwd_nhwc": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _P, _I32, _P]),
+    "cvx_resize_bilinear_rows_to_nchw": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "cvx_upsample2_nhwc": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _P]),
     "cvx_upsample2_bwd_nhwc": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _I32, _P]),
     "cvx_stem_train_nchw": (_I32, [_P, _I32, _I32, _I32, _P, _I32, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),

@@ -249,7 +249,7 @@ int build_static(cvx_engine* e) {
   for (int i = 0; i < nops; ++i) {
     const cvx_op_desc& o = e->ops[i];
     CVX_CHECK(o.in.buf >= 0 && o.in.buf < (int)e->bufs.size() && o.out.buf >= 0 && o.out.buf < (int)e->bufs.size(), "op view buffer index");
-    CVX_CHECK(o.type >= CVX_OP_CONV && o.type <= CVX_OP_COPY, "unknown op type");
+    CVX_CHECK(o.type >= CVX_OP_CONV && o.type <= CVX_OP_RESIZE, "unknown op type");
     if (o.type >= CVX_OP_MAXPOOL2 || (o.type == CVX_OP_CONV && o.act >= CVX_ACT_BN_RELU)) e->inference_only = true;
     if (o.type != CVX_OP_CONV) {
       CVX_CHECK(o.in.c % 8 == 0 && o.in.coff % 8 == 0 && o.out.coff % 8 == 0 && o.in.c == o.out.c, "pool / resample / copy views: equal, 8-aligned channel slices");
@@ -853,6 +853,23 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
     if (o.type == CVX_OP_COPY) {
       ProfScope ps(e, PROF_MISC, 0, 4.0 * B * o.ih * o.iw * o.in.c, st);
       CVX_TRY(cvx_copy_slice(make_view(e, o.in, false), make_view(e, o.out, false), B, o.ih * o.iw, o.in.c, st));
+      continue;
+    }
+    if (o.type == CVX_OP_MAXPOOL3S2) {
+      ProfScope ps(e, PROF_MISC, 0, 2.0 * B * (o.ih * o.iw + o.oh * o.ow) * o.in.c, st);
+      CVX_CHECK(o.oh == (o.ih - 1) / 2 + 1 && o.ow == (o.iw - 1) / 2 + 1, "maxpool3s2: output size must be floor((i - 1) / 2) + 1");
+      CVX_TRY(cvx_maxpool3s2(make_view(e, o.in, false), make_view(e, o.out, false), B, o.ih, o.iw, o.in.c, st));
+      continue;
+    }
+    if (o.type == CVX_OP_AVGPOOL) {
+      ProfScope ps(e, PROF_MISC, 0, 2.0 * B * o.ih * o.iw * o.in.c, st);
+      CVX_CHECK(o.oh == 1 && o.ow == 1, "avgpool: global pooling only (1x1 output)");
+      CVX_TRY(cvx_avgpool_global(make_view(e, o.in, false), make_view(e, o.out, false), B, o.ih * o.iw, o.in.c, st));
+      continue;
+    }
+    if (o.type == CVX_OP_RESIZE) {
+      ProfScope ps(e, PROF_MISC, 0, 2.0 * B * (o.ih * o.iw + o.oh * o.ow) * o.in.c, st);
+      CVX_TRY(cvx_resize_bilinear(make_view(e, o.in, false), make_view(e, o.out, false), B, o.ih, o.iw, o.oh, o.ow, o.in.c, st));
       continue;
     }
     ConvRt& c = e->conv[i];

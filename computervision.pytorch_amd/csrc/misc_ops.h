@@ -7,6 +7,12 @@ int cvx_image_to_nhwc8(const float* img_nchw, int B, int H, int W, half_t* out, 
 int cvx_maxpool2(const ViewDesc& in, const ViewDesc& out, int B, int OH, int OW, int C, hipStream_t st);
 int cvx_dwconvt(const ViewDesc& in, const ViewDesc& out, const float* w, int B, int IH, int IW, int C, int f, hipStream_t st);
 int cvx_copy_slice(const ViewDesc& in, const ViewDesc& out, int B, int HW, int C, hipStream_t st);
+// DeepLabv3+ (inference): 3x3 / stride 2 / pad 1 max pool, global average pool -> (B, 1, 1, C), bilinear resize with
+// align_corners = False on fp16 NHWC views, and fp32 rows (B, IH*IW, ld) -> NCHW fp32 (B, C, OH, OW)
+int cvx_maxpool3s2(const ViewDesc& in, const ViewDesc& out, int B, int IH, int IW, int C, hipStream_t st);
+int cvx_avgpool_global(const ViewDesc& in, const ViewDesc& out, int B, int HW, int C, hipStream_t st);
+int cvx_resize_bilinear(const ViewDesc& in, const ViewDesc& out, int B, int IH, int IW, int OH, int OW, int C, hipStream_t st);
+int cvx_resize_bilinear_f32_nchw(const float* in, int ld, int B, int C, int IH, int IW, int OH, int OW, float* out, hipStream_t st);
 
 // 5x5 / stride 1 / pad 2 max pool on channel-slice views; idx (optional, train) records the argmax
 // tap (0..24, first max in row-major window order as torch does) per output element: [B*H*W][C] bytes.

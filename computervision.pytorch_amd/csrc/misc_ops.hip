@@ -39,6 +39,129 @@ __global__ void maxpool2_kernel(ViewDesc in, ViewDesc out, int B, int OH, int OW
   *reinterpret_cast<h8*>(out.p + voff(out, b, (long long)h * OW + w) + cg * 8) = o;
 }
 
+// ---- max pool 3x3 stride 2 pad 1 (ResNet stem, core/models/resnet.py:163) ----
+__global__ void maxpool3s2_kernel(ViewDesc in, ViewDesc out, int B, int IH, int IW, int OH, int OW, int CG) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long n = (long long)B * OH * OW * CG;
+  if (i >= n) return;
+  int cg = (int)(i % CG);
+  long long t = i / CG;
+  int w = (int)(t % OW);
+  t /= OW;
+  int h = (int)(t % OH);
+  int b = (int)(t / OH);
+  float best[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) best[k] = -INFINITY;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int hh = 2 * h - 1 + dy;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int ww = 2 * w - 1 + dx;
+      if (hh < 0 || hh >= IH || ww < 0 || ww >= IW) continue;
+      const h8 v = *reinterpret_cast<const h8*>(in.p + voff(in, b, (long long)hh * IW + ww) + cg * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) best[k] = fmaxf(best[k], (float)v[k]);
+    }
+  }
+  h8 o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = (half_t)best[k];
+  *reinterpret_cast<h8*>(out.p + voff(out, b, (long long)h * OW + w) + cg * 8) = o;
+}
+
+// ---- global average pool (ASPPPooling's AdaptiveAvgPool2d(1), core/models/deeplabv3plus.py:30): one workgroup per
+// (image, 8-channel group), fp32 sums in a fixed order ----
+__global__ __launch_bounds__(256) void avgpool_global_kernel(ViewDesc in, ViewDesc out, int HW, int CG) {
+  __shared__ float red[256 * 8];
+  const int b = blockIdx.x / CG, cg = blockIdx.x - b * CG;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  for (int pix = threadIdx.x; pix < HW; pix += 256) {
+    const h8 v = *reinterpret_cast<const h8*>(in.p + voff(in, b, pix) + cg * 8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += (float)v[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = acc[k];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] += red[(threadIdx.x + s) * 8 + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    h8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (half_t)(red[k] / (float)HW);
+    *reinterpret_cast<h8*>(out.p + voff(out, b, 0) + cg * 8) = o;
+  }
+}
+
+// ---- bilinear resize, align_corners = False (F.interpolate(..., mode="bilinear"), deeplabv3plus.py:38,117-122,147):
+// src = (dst + 0.5) * (in / out) - 0.5, clamped at 0; a 1x1 input degenerates to a broadcast ----
+__device__ __forceinline__ void bilinear_src(int d, float scale, int in_size, int* i0, int* i1, float* lam) {
+  float s = ((float)d + 0.5f) * scale - 0.5f;
+  if (s < 0.f) s = 0.f;
+  int a = (int)s;
+  if (a > in_size - 1) a = in_size - 1;
+  *i0 = a;
+  *i1 = a + (a < in_size - 1 ? 1 : 0);
+  *lam = s - (float)a;
+}
+__global__ void resize_bilinear_kernel(ViewDesc in, ViewDesc out, int B, int IH, int IW, int OH, int OW, int CG, float sh, float sw) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long n = (long long)B * OH * OW * CG;
+  if (i >= n) return;
+  int cg = (int)(i % CG);
+  long long t = i / CG;
+  int w = (int)(t % OW);
+  t /= OW;
+  int h = (int)(t % OH);
+  int b = (int)(t / OH);
+  int y0, y1, x0, x1;
+  float ly, lx;
+  bilinear_src(h, sh, IH, &y0, &y1, &ly);
+  bilinear_src(w, sw, IW, &x0, &x1, &lx);
+  const h8 v00 = *reinterpret_cast<const h8*>(in.p + voff(in, b, (long long)y0 * IW + x0) + cg * 8);
+  const h8 v01 = *reinterpret_cast<const h8*>(in.p + voff(in, b, (long long)y0 * IW + x1) + cg * 8);
+  const h8 v10 = *reinterpret_cast<const h8*>(in.p + voff(in, b, (long long)y1 * IW + x0) + cg * 8);
+  const h8 v11 = *reinterpret_cast<const h8*>(in.p + voff(in, b, (long long)y1 * IW + x1) + cg * 8);
+  h8 o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float top = (float)v00[k] * (1.f - lx) + (float)v01[k] * lx;
+    const float bot = (float)v10[k] * (1.f - lx) + (float)v11[k] * lx;
+    o[k] = (half_t)(top * (1.f - ly) + bot * ly);
+  }
+  *reinterpret_cast<h8*>(out.p + voff(out, b, (long long)h * OW + w) + cg * 8) = o;
+}
+// fp32 rows (B, IH*IW, ld) -> NCHW fp32 (B, C, OH, OW): the segmentation logits back at input resolution (deeplabv3plus.py:147)
+__global__ void resize_bilinear_f32_nchw_kernel(const float* in, int ld, int B, int C, int IH, int IW, int OH, int OW, float sh, float sw,
+                                                float* out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long n = (long long)B * C * OH * OW;
+  if (i >= n) return;
+  int w = (int)(i % OW);
+  long long t = i / OW;
+  int h = (int)(t % OH);
+  t /= OH;
+  int c = (int)(t % C);
+  int b = (int)(t / C);
+  int y0, y1, x0, x1;
+  float ly, lx;
+  bilinear_src(h, sh, IH, &y0, &y1, &ly);
+  bilinear_src(w, sw, IW, &x0, &x1, &lx);
+  const float* base = in + (long long)b * IH * IW * ld + c;
+  const float v00 = base[((long long)y0 * IW + x0) * ld], v01 = base[((long long)y0 * IW + x1) * ld];
+  const float v10 = base[((long long)y1 * IW + x0) * ld], v11 = base[((long long)y1 * IW + x1) * ld];
+  const float top = v00 * (1.f - lx) + v01 * lx, bot = v10 * (1.f - lx) + v11 * lx;
+  out[i] = top * (1.f - ly) + bot * ly;
+}
+
 // ---- depthwise ConvTranspose2d, kernel 2f, stride f, padding f/2 (IDAUp.up_i, centernet_model.py:256): every output pixel
 // receives exactly 2 x 2 taps.  w: fp32 [C][2f][2f] (the master tensor), out = sum_{ky,kx} in[(oy + p - ky) / f][..] * w[c][ky][kx] ----
 __global__ void dwconvt_kernel(ViewDesc in, ViewDesc out, const float* w, int B, int IH, int IW, int CG, int f) {
@@ -398,6 +521,27 @@ int cvx_image_to_nhwc8(const float* img, int B, int H, int W, half_t* out, hipSt
 }
 int cvx_maxpool2(const ViewDesc& in, const ViewDesc& out, int B, int OH, int OW, int C, hipStream_t st) {
   return launch1d(maxpool2_kernel, (long long)B * OH * OW * (C / 8), st, in, out, B, OH, OW, C / 8);
+}
+int cvx_maxpool3s2(const ViewDesc& in, const ViewDesc& out, int B, int IH, int IW, int C, hipStream_t st) {
+  CVX_CHECK(C % 8 == 0, "maxpool3s2: C % 8");
+  const int OH = (IH - 1) / 2 + 1, OW = (IW - 1) / 2 + 1;  // floor((I + 2 - 3) / 2) + 1
+  return launch1d(maxpool3s2_kernel, (long long)B * OH * OW * (C / 8), st, in, out, B, IH, IW, OH, OW, C / 8);
+}
+int cvx_avgpool_global(const ViewDesc& in, const ViewDesc& out, int B, int HW, int C, hipStream_t st) {
+  CVX_CHECK(C % 8 == 0 && HW > 0, "avgpool_global: C % 8");
+  hipLaunchKernelGGL(avgpool_global_kernel, dim3(B * (C / 8)), dim3(256), 0, st, in, out, HW, C / 8);
+  CVX_HIP(hipGetLastError());
+  return 0;
+}
+int cvx_resize_bilinear(const ViewDesc& in, const ViewDesc& out, int B, int IH, int IW, int OH, int OW, int C, hipStream_t st) {
+  CVX_CHECK(C % 8 == 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0, "resize_bilinear: C % 8 / sizes");
+  return launch1d(resize_bilinear_kernel, (long long)B * OH * OW * (C / 8), st, in, out, B, IH, IW, OH, OW, C / 8, (float)IH / (float)OH,
+                  (float)IW / (float)OW);
+}
+int cvx_resize_bilinear_f32_nchw(const float* in, int ld, int B, int C, int IH, int IW, int OH, int OW, float* out, hipStream_t st) {
+  CVX_CHECK(in && out && C > 0 && C <= ld && IH > 0 && IW > 0 && OH > 0 && OW > 0, "resize_bilinear_f32_nchw: bad arguments");
+  return launch1d(resize_bilinear_f32_nchw_kernel, (long long)B * C * OH * OW, st, in, ld, B, C, IH, IW, OH, OW, (float)IH / (float)OH,
+                  (float)IW / (float)OW, out);
 }
 int cvx_dwconvt(const ViewDesc& in, const ViewDesc& out, const float* w, int B, int IH, int IW, int C, int f, hipStream_t st) {
   CVX_CHECK(f >= 2 && f % 2 == 0, "dwconvt: stride must be even (kernel 2f, padding f/2)");

@@ -72,6 +72,12 @@ extern "C" int cvx_maxpool5_bwd_nhwc(const void* gout_f16, const uint8_t* argmax
   CVX_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
   return 0;
 }
+extern "C" int cvx_resize_bilinear_rows_to_nchw(const float* rows_f32, int32_t ld, int32_t batch, int32_t c, int32_t ih, int32_t iw, int32_t oh,
+                                                int32_t ow, float* out_nchw, void* hip_stream) {
+  CVX_CHECK(rows_f32 && out_nchw && batch > 0, "bad arguments");
+  CVX_TRY(cvx_resize_bilinear_f32_nchw(rows_f32, ld, batch, c, ih, iw, oh, ow, out_nchw, (hipStream_t)hip_stream));
+  return 0;  // asynchronous on the caller's stream, like the engine's forward it follows
+}
 extern "C" int cvx_upsample2_nhwc(const void* x_f16, int32_t batch, int32_t h, int32_t w, int32_t c, void* out_f16, void* hip_stream) {
   CVX_CHECK(x_f16 && out_f16 && batch > 0 && c % 8 == 0, "bad arguments (channels in multiples of 8)");
   CVX_TRY(cvx_upsample2_fwd(dense(x_f16, h * w, c), dense(out_f16, 4 * h * w, c), batch, h, w, c, (hipStream_t)hip_stream));

@@ -41,7 +41,11 @@ enum { CVX_OP_CONV = 1, CVX_OP_MAXPOOL5 = 2, CVX_OP_UPSAMPLE2 = 3,
        /* inference-only ops (DLA-34 / CenterNet, core/models/centernet_model.py): */
        CVX_OP_MAXPOOL2 = 4, /* 2x2 stride-2 max pool (Tree.downsample, :128-129) */
        CVX_OP_DWCONVT = 5,  /* depthwise ConvTranspose2d, kernel 2*stride, padding stride/2 (IDAUp.up_i, :256); w_off -> fp32 [C][2f][2f] */
-       CVX_OP_COPY = 6 };   /* channel-slice copy (a tensor that lives in two concat buffers) */
+       CVX_OP_COPY = 6,     /* channel-slice copy (a tensor that lives in two concat buffers) */
+       /* inference-only ops (DeepLabv3+ / ResNet, core/models/deeplabv3plus.py, core/models/resnet.py): */
+       CVX_OP_MAXPOOL3S2 = 7, /* 3x3 stride-2 pad-1 max pool (resnet.py:163) */
+       CVX_OP_AVGPOOL = 8,    /* global average pool -> (B, 1, 1, C) (ASPPPooling, deeplabv3plus.py:30) */
+       CVX_OP_RESIZE = 9 };   /* bilinear resize (ih, iw) -> (oh, ow), align_corners = False (deeplabv3plus.py:38,117-122) */
 enum { CVX_ACT_BN_SILU = 1, CVX_ACT_BIAS = 2,
        /* inference-only epilogues (folded BatchNorm): */
        CVX_ACT_BN_RELU = 3,   /* Conv + BN + ReLU */
@@ -270,6 +274,11 @@ int cvx_bn_silu_bwd_nhwc(const void* xhat_f16, const void* gout_f16, int32_t bat
 int cvx_maxpool5_nhwc(const void* x_f16, int32_t batch, int32_t h, int32_t w, int32_t c, void* out_f16, uint8_t* argmax, void* hip_stream);
 int cvx_maxpool5_bwd_nhwc(const void* gout_f16, const uint8_t* argmax, int32_t batch, int32_t h, int32_t w, int32_t c, void* gin_f16,
                           int32_t accumulate, void* hip_stream);
+/* Bilinear resize (align_corners = False) of fp32 rows (batch, ih*iw, ld) -- e.g. a PRED buffer holding segmentation logits --
+ * into an NCHW fp32 tensor (batch, c, oh, ow).  Asynchronous on hip_stream.
+ * Replaces: F.interpolate(x, size=input_shape, mode="bilinear", align_corners=False), core/models/deeplabv3plus.py:147. */
+int cvx_resize_bilinear_rows_to_nchw(const float* rows_f32, int32_t ld, int32_t batch, int32_t c, int32_t ih, int32_t iw, int32_t oh, int32_t ow,
+                                     float* out_nchw, void* hip_stream);
 /* nearest-neighbour x2 upsample (nn.Upsample(scale_factor=2), core/models/yolov8/yolo_v8.py:39,41) and its backward */
 int cvx_upsample2_nhwc(const void* x_f16, int32_t batch, int32_t h, int32_t w, int32_t c, void* out_f16, void* hip_stream);
 int cvx_upsample2_bwd_nhwc(const void* gout_f16, int32_t batch, int32_t h, int32_t w, int32_t c, void* gin_f16, int32_t accumulate,

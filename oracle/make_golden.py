@@ -355,6 +355,53 @@ def main():
     report["centernet"] = dict(init="bit-exact, %d tensors" % len(ref_sd), params=int(sum(p_.numel() for p_ in cmodel.parameters())),
                                decode={t: int(dec[t + "_boxes"].shape[0]) for t in ("net", "synth")})
 
+    # ---- 10. DeepLabv3+ ResNet-101: init, eval forward on a calibrated network ---------------------------------
+    from oracle import deeplab_ref as D
+    dcfg, dalgo_cls, _ = builder.export_from_registry("deeplabv3plus")
+    torch.manual_seed(0)
+    dmodel, _ = dalgo_cls(dcfg, torch.device("cpu")).build_model()
+    ref_sd = dmodel.state_dict()
+    my_sd = D.init_state_dict(dcfg.dataset.num_classes, seed=0)
+    assert list(ref_sd.keys()) == list(my_sd.keys()), [(a_, b_) for a_, b_ in zip(ref_sd, my_sd) if a_ != b_][:5]
+    for k in ref_sd:
+        assert ref_sd[k].shape == my_sd[k].shape and torch.equal(ref_sd[k], my_sd[k]), f"DeepLab init mismatch {k}"
+    dsums = {k: [float(v.double().sum()), float(v.double().abs().sum())] for k, v in ref_sd.items() if not k.endswith("num_batches_tracked")}
+    with open(os.path.join(GOLD, "deeplab_seed0_init_sums.json"), "w") as f:
+        json.dump(dsums, f)
+    # Forward fixture on a well-conditioned network.  (i) With unit BN weights everywhere a random-init ResNet-101 is chaotic:
+    # every residual branch is as large as the stream it joins, and a perturbation of 5e-4 (one fp16 rounding) grows to 40 %
+    # over the 33 blocks in the reference's own arithmetic with fp16 operands -- no implementation can be compared on it.
+    # The last BatchNorm of every block gets weight 0.1 (torchvision's zero_init_residual idea, resnet.py:180-185, not
+    # quite zero so that the branches still matter): 4e-3 instead.  (ii) In eval mode the untouched running statistics (0 / 1)
+    # leave the network un-normalised: they are calibrated with ONE train-mode pass at momentum 1 (running := batch
+    # statistics); the eval-mode forward of another batch is the fixture.
+    GAMMA3 = 0.1
+    with torch.no_grad():
+        for k_, v_ in dmodel.named_parameters():
+            if k_.endswith(".bn3.weight"):
+                v_.fill_(GAMMA3)
+    g = torch.Generator().manual_seed(51)
+    xcal, xd = torch.rand(2, 3, 193, 225, generator=g), torch.rand(2, 3, 193, 225, generator=g)
+    for m_ in dmodel.modules():
+        if isinstance(m_, torch.nn.BatchNorm2d):
+            m_.momentum = 1.0
+    dmodel.train()
+    with torch.no_grad():
+        dmodel(xcal)
+    dmodel.eval()
+    with torch.no_grad():
+        ref_out = dmodel(xd.clone())
+    cal_sd = {k: v.clone() for k, v in dmodel.state_dict().items()}
+    with torch.no_grad():
+        my_out, my_rows = D.forward(cal_sd, xd.clone(), dcfg.dataset.num_classes, return_rows=True)
+    assert torch.allclose(ref_out, my_out, rtol=1e-4, atol=1e-4 * float(ref_out.abs().max())), float((ref_out - my_out).abs().max())
+    stats = {k: v.numpy().copy() for k, v in cal_sd.items() if k.endswith("running_mean") or k.endswith("running_var")}
+    np.savez_compressed(os.path.join(GOLD, "deeplab_fwd_193x225.npz"), x=xd.numpy(), rows=my_rows.numpy().copy(),
+                        out_sub=ref_out.flatten()[::11].numpy().copy(), out_norm=np.array(float(ref_out.norm())), bn3_gamma=np.array(GAMMA3),
+                        stat_keys=np.array(list(stats.keys())), stat_vals=np.concatenate([v.ravel() for v in stats.values()]))
+    report["deeplab"] = dict(init="bit-exact, %d tensors" % len(ref_sd), params=int(sum(p_.numel() for p_ in dmodel.parameters())),
+                             out_absmax=float(ref_out.abs().max()), rows_shape=list(my_rows.shape))
+
     # ---- 6. NMS tail fixture (oracle-generated; upstream parity unpinned) ----------------------
     pred = synth.nms_pred(7)
     res = nms_ref.non_max_suppression(pred, 0.25, 0.7, 300)

@@ -1044,3 +1044,63 @@ def test_centernet_full_size_properties(dev):
     d = algo.decode_raw(sparse, 128, 128)
     assert int(d["counts"][0]) == 7 and sorted(d["topk_index"][0, :7].tolist()) == sorted((y * 128 + x_) * 80 + c for y, x_, c in peaks)
     assert d["topk_index"][0, 7:].tolist() == [-1] * 93
+
+
+# ---- DeepLabv3+ ResNet-101, inference --------------------------------------------------------------------
+def _deeplab(dev, gold_file=None):
+    from computervision.pytorch_amd.deeplab import DeepLabV3PlusR101
+    torch.manual_seed(0)
+    m = DeepLabV3PlusR101(21)
+    if gold_file is not None:                              # the calibrated running statistics of the fixture run
+        sd = m.state_dict()
+        keys, vals, off = [str(k) for k in gold_file["stat_keys"]], gold_file["stat_vals"], 0
+        with torch.no_grad():
+            for k in sd:                                   # residual branches scaled down, as in the fixture run (make_golden.py, section 10)
+                if k.endswith(".bn3.weight"):
+                    sd[k].fill_(float(gold_file["bn3_gamma"]))
+            for k in keys:
+                n = sd[k].numel()
+                sd[k].copy_(torch.from_numpy(vals[off:off + n].copy()))
+                off += n
+    return m.to(dev).eval()
+
+
+def test_deeplab_state_dict_is_the_references(dev):
+    """674 keys in the reference's order, seed-0 values bit-identical to DeeplabV3Plus(21, 16, pretrained_backbone=False)
+    (resnet.py:150-178, deeplabv3plus.py:99-110) -- the oracle's init is pinned to the reference's in make_golden.py."""
+    from oracle import deeplab_ref as D
+    m = _deeplab(dev)
+    ref = D.init_state_dict(21, seed=0)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(ref.keys()) and len(sd) == 674
+    for k, v in ref.items():
+        assert sd[k].shape == v.shape and torch.equal(sd[k].cpu(), v), k
+
+
+def test_deeplab_forward_matches_the_reference_fixture(dev, gold):
+    """Eval forward of the calibrated random-init network on the fixture batch (2 x 3 x 193 x 225, odd sizes as the
+    reference's 513): logits at the decoder's resolution and the final NCHW tensor against the REAL reference's outputs.
+    104 convolutions with fp16 operands in a row: the yardstick is what the fp16-operand emulation of the oracle gives on the
+    CPU against the reference (printed); the engine must be within 1.5x of it."""
+    from oracle import deeplab_ref as D
+    g = gold("deeplab_fwd_193x225.npz")
+    m = _deeplab(dev, g)
+    x = torch.from_numpy(g["x"]).to(dev)
+    out = m(x)
+    rows = m.last_rows[..., :21].reshape(2, 49, 57, 21).float().cpu()
+    ref_rows = torch.from_numpy(g["rows"])
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    D.FP16_STORAGE[0] = True
+    try:
+        with torch.no_grad():
+            emu_out, emu_rows = D.forward(sd, x.cpu(), 21, return_rows=True)
+    finally:
+        D.FP16_STORAGE[0] = False
+    e_ref, e_emu, emu_ref = rel(rows, ref_rows), rel(rows, emu_rows), rel(emu_rows, ref_rows)
+    print(f"deeplab rows: engine vs reference {e_ref:.3e}, engine vs fp16 emulation {e_emu:.3e}, emulation vs reference {emu_ref:.3e}")
+    assert e_emu < 1.5e-2 and e_ref < max(1.5 * emu_ref, 1e-2)
+    assert tuple(out.shape) == (2, 21, 193, 225)
+    assert rel(out.flatten()[::11].cpu(), torch.from_numpy(g["out_sub"])) < max(1.5 * emu_ref, 1e-2)
+    # argmax agreement (what the plugin's post-processing consumes, segmentation_2d.py:28)
+    agree = (out.argmax(1).cpu() == emu_out.argmax(1)).float().mean().item()
+    assert agree > 0.97, agree

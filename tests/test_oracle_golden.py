@@ -207,3 +207,39 @@ def test_centernet_oracle_init_forward_decode(gold):
         assert np.array_equal(classes.numpy(), g[tag + "_classes"]) and np.array_equal(scores.numpy(), g[tag + "_scores"])
         np.testing.assert_allclose(boxes.numpy(), g[tag + "_boxes"], rtol=1e-6, atol=1e-5)
         assert np.array_equal(pos.numpy(), g[tag + "_pos"])
+
+
+def _deeplab_fixture_state(gold_file):
+    """seed-0 initialisation + the calibrated running statistics the fixture carries"""
+    from oracle import deeplab_ref as D
+    sd = D.init_state_dict(21, seed=0)
+    for k in sd:                                              # the fixture network: residual branches scaled down (make_golden.py, section 10)
+        if k.endswith(".bn3.weight"):
+            sd[k] = torch.full_like(sd[k], float(gold_file["bn3_gamma"]))
+    keys, vals, off = [str(k) for k in gold_file["stat_keys"]], gold_file["stat_vals"], 0
+    for k in keys:
+        n = sd[k].numel()
+        sd[k] = torch.from_numpy(vals[off:off + n].copy())
+        off += n
+    assert off == len(vals)
+    return sd
+
+
+def test_deeplab_oracle_init_and_forward(gold):
+    """oracle/deeplab_ref.py against what the real reference produced (oracle/make_golden.py section 10): the seed-0
+    state_dict (674 tensors, checksums) and the eval-mode forward of the calibrated network."""
+    from oracle import deeplab_ref as D
+    sd0 = D.init_state_dict(21, seed=0)
+    sums = json.load(open(os.path.join(GOLD, "deeplab_seed0_init_sums.json")))
+    assert len(sd0) == 674 and [k for k in sd0 if not k.endswith("num_batches_tracked")] == list(sums.keys())
+    for k, (s, a) in sums.items():
+        v = sd0[k].double()
+        np.testing.assert_allclose([float(v.sum()), float(v.abs().sum())], [s, a], rtol=1e-12, atol=1e-12, err_msg=k)
+    g = gold("deeplab_fwd_193x225.npz")
+    sd = _deeplab_fixture_state(g)
+    with torch.no_grad():
+        out, rows = D.forward(sd, torch.from_numpy(g["x"]), 21, return_rows=True)
+    scale = float(np.abs(g["rows"]).max())
+    np.testing.assert_allclose(rows.numpy(), g["rows"], rtol=1e-4, atol=1e-4 * scale)
+    np.testing.assert_allclose(out.flatten()[::11].numpy(), g["out_sub"], rtol=1e-4, atol=1e-4 * scale)
+    assert abs(float(out.norm()) - float(g["out_norm"])) < 1e-4 * float(g["out_norm"])
