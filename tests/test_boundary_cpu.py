@@ -151,3 +151,20 @@ def test_engine_refuses_cpu_device():
     from computervision.pytorch_amd.graph import ParamLayout, build_yolov8_graph
     with pytest.raises(CvxError):
         Engine(build_yolov8_graph(ParamLayout("n", 80), 64, 64), torch.device("cpu"))
+
+
+def test_deeplab_plugin_surface_cpu():
+    """deeplabv3plus resolves through the reference's registry contract; the model holds the reference's 674 state_dict entries
+    (58.75 M parameters) and refuses to run without the MI355X engine; the VOC palette is the reference's."""
+    from computervision.pytorch_amd import _lib as L
+    from core.algorithms.segmentation_2d import voc_colormap
+    cfg, algo_cls, trainer_cls = builder.export_from_registry("deeplabv3plus")
+    assert cfg.dataset.num_classes == 21 and cfg.arch.input_size == (3, 513, 513) and cfg.arch.output_stride == 16
+    algo = algo_cls(cfg, torch.device("cpu"))
+    model, name = algo.build_model()
+    assert name == "deeplabv3plus" and len(model.state_dict()) == 674
+    assert sum(p.numel() for p in model.parameters()) == 58753973
+    cm = voc_colormap()
+    assert cm[0] == (0, 0, 0) and cm[1] == (128, 0, 0) and cm[15] == (192, 128, 128) and cm[20] == (0, 64, 128) and len(cm) == 21
+    with pytest.raises(L.CvxError):
+        model.eval()(torch.zeros(1, 3, 65, 65))

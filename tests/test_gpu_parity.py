@@ -1104,3 +1104,33 @@ def test_deeplab_forward_matches_the_reference_fixture(dev, gold):
     # argmax agreement (what the plugin's post-processing consumes, segmentation_2d.py:28)
     agree = (out.argmax(1).cpu() == emu_out.argmax(1)).float().mean().item()
     assert agree > 0.97, agree
+
+
+def test_deeplab_full_size_through_the_plugin_api(dev):
+    """export_from_registry("deeplabv3plus") at the reference's 513 x 513 (odd sizes all the way down: 257, 129, 65, 33):
+    logits shape, finiteness, determinism, the colour post-processing (segmentation_2d.py:20-30) and the training guard."""
+    import builder
+    from computervision.pytorch_amd import _lib as LL
+    cfg, algo_cls, trainer_cls = builder.export_from_registry("deeplabv3plus")
+    algo = algo_cls(cfg, dev)
+    torch.manual_seed(0)
+    model, name = algo.build_model()
+    assert name == "deeplabv3plus"
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            if k.endswith(".bn3.weight"):
+                v.fill_(0.1)
+    model = model.to(dev).eval()
+    x = synth.images(2, 513, 513, seed=3).to(dev)
+    out = model(x)
+    assert tuple(out.shape) == (2, 21, 513, 513) and out.dtype == torch.float32 and torch.isfinite(out).all()
+    assert torch.equal(out, model(x))
+    col = algo.predict_tensor(model, x)
+    assert tuple(col.shape) == (2, 513, 513, 3) and int(col.max()) <= 192
+    model.train()
+    with pytest.raises(LL.CvxError):
+        model(x)
+    with pytest.raises(LL.CvxError):
+        algo.build_loss()
+    with pytest.raises(LL.CvxError):
+        trainer_cls(cfg, dev).train()
