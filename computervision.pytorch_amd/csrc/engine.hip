@@ -136,6 +136,7 @@ struct cvx_engine {
   hipEvent_t ev_seg[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // segmented backward: (main, side) pairs
   int ev_seg_next = 0;
   bool fwd_train_done = false;
+  bool bwd_slabs_clean = false;  // the backward statistic slabs were zeroed by the training forward and not used since
   int last_batch = 0;
   float* last_pred = nullptr;
   // per-kernel-class profiling with HIP events on the launch stream (bench.py's roofline object)
@@ -784,7 +785,10 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
   // fp32 master -> fp16 shadows (forward layout + transposed layout for the data gradient)
   const Buf& ib = e->bufs[e->image_buf];
   CVX_CHECK(((uintptr_t)images % 8) == 0, "images must be 8-byte aligned");
-  if (training) CVX_HIP(hipMemsetAsync(e->stat_region, 0, (size_t)e->stat_half * 8, st));
+  if (training) {  // forward AND backward statistic slabs in one fill (the backward's own fill sat at the head of its critical path)
+    CVX_HIP(hipMemsetAsync(e->stat_region, 0, (size_t)e->stat_half * 16, st));
+    e->bwd_slabs_clean = true;
+  }
   // fp16 weight shadows: the fp32 stem does not need them, so they are prepared on the lane stream BESIDE it (33 us off the main chain); the first op after the stem waits for them
   static const int pack_lane = cvx_tune_int("CVX_PACK_LANE", 1);  // bit 0: training forward, bit 1: eval forward (measured: +0.02 ms there)
   const bool prep_beside_stem = e->lane && !e->ops.empty() && e->ops[0].type == CVX_OP_CONV && e->conv[0].stem && !e->profile &&
@@ -1033,7 +1037,8 @@ int backward_begin(cvx_engine* e, const void* dpred_f16, float loss_scale) {
   w.next_op = (int)e->ops.size() - 1;
   static const int wg_batch_env = cvx_tune_int("CVX_WGRAD_BATCH", 3);
   w.wg_batch = wg_batch_env < 1 ? 1 : wg_batch_env;
-  CVX_HIP(hipMemsetAsync(e->stat_region + e->stat_half, 0, (size_t)e->stat_half * 8, st));
+  if (!e->bwd_slabs_clean) CVX_HIP(hipMemsetAsync(e->stat_region + e->stat_half, 0, (size_t)e->stat_half * 8, st));  // (a second backward on one forward)
+  e->bwd_slabs_clean = false;
   if (e->n_colsum > 0) {  // every bias gradient (the head's 1x1 output convs) at once: column sums of dpred
     double by = 0;
     for (size_t i = 0; i < e->ops.size(); ++i)

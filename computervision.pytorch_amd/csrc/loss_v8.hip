@@ -551,8 +551,15 @@ extern "C" int cvx_loss_v8_strided(const float* pred, int32_t pred_ld, int32_t B
   const int n_lb = (int)((BA + 15) / 16);
   half_t* dpred = (half_t*)dpred_f16;
 
-  CVX_HIP(hipMemsetAsync(w.img_start, 0, B * 4, st));
-  CVX_HIP(hipMemsetAsync(w.img_end, 0, B * 4, st));
+  {  // img_start | img_end are carved back to back: one fill
+    char *a = (char*)w.img_start, *b = (char*)w.img_end;
+    if (b > a && b - a <= 4096) {
+      CVX_HIP(hipMemsetAsync(a, 0, (size_t)(b - a) + (size_t)B * 4, st));
+    } else {
+      CVX_HIP(hipMemsetAsync(w.img_start, 0, B * 4, st));
+      CVX_HIP(hipMemsetAsync(w.img_end, 0, B * 4, st));
+    }
+  }
   if (N > 0) {
     hipLaunchKernelGGL(tgt_prep_kernel, dim3(cvx_cdiv(N, 128)), dim3(128), 0, st, targets, N, B, img_w, img_h, w.gtbox, w.gtlabel, w.gtb,
                        w.gtvalid, w.img_start, w.img_end);
