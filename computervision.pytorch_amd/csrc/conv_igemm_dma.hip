@@ -368,6 +368,11 @@ int cvx_conv_igemm_dma_launch(const ConvParams& p, hipStream_t stream) {
   static const long long t128 = env_int("CVX_T128", 128 * 1024), t64 = env_int("CVX_T64", 64 * 1024);
   int BM = 128;
   if (M < t128) BM = (M >= t64) ? 64 : 32;
+  // heavy weights (>= 512 K elements: ResNet / DLA layers with 256+ channels in 3x3, 1024+ in 1x1): every workgroup streams the
+  // whole [BN][K] weight block from L2, so 32-row tiles re-read it M/32 times -- the L2->LDS path, not the MFMAs, was the limit
+  // (DeepLabv3+ ASPP: 6.4 GB per launch); 64 rows from 8 K pixels on (DeepLabv3+ forward 11.85 -> 10.27 ms)
+  static const long long heavy = env_int("CVX_HEAVY_W", 512 * 1024), t64h = env_int("CVX_T64_HEAVY", 8192);
+  if (BM == 32 && (long long)p.ntaps * p.Cin * p.Cout >= heavy && M >= t64h) BM = 64;
   if (BM == 32) {
     // 2x2 waves: BN = 32 * NTW
     int pairs = (tiles + 1) / 2;
