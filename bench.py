@@ -242,6 +242,84 @@ def deeplab_main(args):
         dist.destroy_process_group()
 
 
+YOLOV7_GFLOP_PER_IMG = 105.8    # YOLOv7-l @ 640x640 (probe at nc = 80; the VOC head is 0.3 % smaller)
+
+
+def yolov7_main(args):
+    """images/sec of YOLOv7-l INFERENCE (engine forward + anchor decode + per-class NMS) on synthetic 640x640 batches of 32; one
+    process per GPU, images sharded with no exchange."""
+    rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    import torch.distributed as dist
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29535")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    import builder
+    from computervision.pytorch_amd import synth
+    cfg, algo_cls, _ = builder.export_from_registry("yolo7")
+    cfg.train.pretrained = False
+    algo = algo_cls(cfg, dev)
+    torch.manual_seed(0)
+    model, _ = algo.build_model()
+    model = model.to(dev).eval()
+    B = args.batch
+    H, W = cfg.arch.input_size[1:]
+    x = synth.images(B, H, W, seed=1 + rank).to(dev)
+
+    def step():
+        with torch.no_grad():
+            rows = model.forward_rows(x)
+            dec, y = algo.decode_rows(model, rows)
+            return algo.nms_device(y, dec, 0.6)      # (untrained logits ~ 0: objectness * class = 0.25 everywhere -- nothing passes)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(max(args.warmup, 1)):
+        out = step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    eng = model._last_engine
+    eng.profile(True)
+    for _ in range(3):
+        step()
+    sync()
+    prof = eng.profile_read()
+    eng.profile(False)
+    if rank == 0:
+        value = B * world * args.steps / elapsed
+        conv = prof["conv_fwd"]
+        tf = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+        print(json.dumps({
+            "metric": "images/sec 640x640 YOLOv7-l inference + decode + NMS", "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"YOLOv7-l (nc 20) eval forward + anchor decode + per-class NMS, batch {B}/GPU, {H}x{W}, random init",
+                       "global_batch": B * world, "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "kernel": "implicit-GEMM convolution forward launches (conv_halo / conv_pw / conv_igemm_dma)",
+                         "achieved": round(tf, 3), "peak": MFMA_FP16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_FP16_PEAK_TFLOPS, 5),
+                         "traffic": None, "avg_launch_us": round(conv["ms"] * 1e3 / max(conv["launches"], 1), 3),
+                         "launches_per_step": conv["launches"] // 3},
+            "whole_step": {"tflops": round(value / world * YOLOV7_GFLOP_PER_IMG / 1e3, 3),
+                           "frac_of_mfma_peak": round(value / world * YOLOV7_GFLOP_PER_IMG / 1e3 / MFMA_FP16_PEAK_TFLOPS, 5)},
+            "kernel_classes": {k: {"ms_per_step": round(v["ms"] / 3, 4), "launches_per_step": v["launches"] // 3} for k, v in prof.items() if v["launches"]},
+            "engine_workspace_gib": round(eng.workspace_bytes() / 2 ** 30, 3)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -253,13 +331,15 @@ def main():
     ap.add_argument("--graph", type=int, default=0, help="1: replay the step as a hipGraph (N=1 only); 0: eager stream launches (default: "
                     "measured faster -- the side-stream weight gradients overlap better than as graph branches)")
     ap.add_argument("--profile-steps", type=int, default=10, help="steps of the per-kernel HIP-event window after the timed region")
-    ap.add_argument("--workload", default="yolov8_train", choices=["yolov8_train", "centernet", "deeplab"],
+    ap.add_argument("--workload", default="yolov8_train", choices=["yolov8_train", "centernet", "deeplab", "yolov7"],
                     help="centernet: BASELINE.json configs[3] -- CenterNet DLA-34 (nc 80) 512x512 inference + heat-map decode, batch 64 per GPU")
     args = ap.parse_args()
     if args.workload == "centernet":
         return centernet_main(args)
     if args.workload == "deeplab":
         return deeplab_main(args)
+    if args.workload == "yolov7":
+        return yolov7_main(args)
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))

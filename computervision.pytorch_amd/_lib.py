@@ -81,6 +81,7 @@ PROTOTYPES = {
     "cvx_adam_step_dev": (_I32, [_P, _P, _P, _P, _I64, _F, _F, _F, _P, _P, _I32, _F, _P]),
     "cvx_engine_set_stream": (_I32, [_P, _P]),
     "cvx_decode": (_I32, [_P, _I32, _I32, _I32, C.POINTER(_I32), C.POINTER(_F), _I32, _P, _P]),
+    "cvx_yolo7_decode": (_I32, [_P, _I32, _I32, _I32, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
     "cvx_nms_workspace_bytes": (_I64, [_I32, _I32]),
     "cvx_nms": (_I32, [_P, _I32, _I32, _I32, _F, _F, _I32, _P, _P, _P, _P, _I64, _P]),
     "cvx_nms_variant": (_I32, [_P, _I32, _I32, _I32, _F, _F, _I32, _I32, _P, _P, _P, _P, _I64, _P]),

@@ -116,6 +116,10 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* y, int A,
     }
   }
   __syncthreads();
+  if (s_n > cap) {  // more candidates than the in-LDS sort holds (only possible beyond 16384 anchors): signalled, never truncated silently
+    if (tid == 0) counts[b] = -1;
+    return;
+  }
   const int n = min(s_n, cap);
   int cap2 = 1;
   while (cap2 < n) cap2 <<= 1;
@@ -299,7 +303,6 @@ extern "C" int cvx_nms_variant(const float* y, int32_t B, int32_t A, int32_t nc,
   CVX_CHECK(variant >= CVX_NMS_TV0141_CUDA && variant <= CVX_NMS_VANILLA, "unknown batched_nms variant");
   CVX_CHECK(conf_thres >= 0.f && conf_thres <= 1.f && iou_thres >= 0.f && iou_thres <= 1.f, "thresholds must lie in [0,1]");
   CVX_CHECK(max_det >= 1 && max_det <= 1024, "max_det must lie in [1,1024]");
-  CVX_CHECK(A <= NMS_CAP, "cvx_nms: more than 16384 anchors per image is not supported by the in-LDS sort");
   CVX_CHECK(workspace_bytes >= cvx_nms_workspace_bytes(B, A), "workspace too small");
   const long long cap = cap_for(A);
   char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
@@ -323,6 +326,85 @@ extern "C" int cvx_nms_variant(const float* y, int32_t B, int32_t A, int32_t nc,
   }
   hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(NMS_THREADS), (size_t)cap * 8, (hipStream_t)hip_stream, y, A, nc, conf_thres, iou_thres, max_det,
                      (int)cap, (int)variant, ws, out_rows, out_index, counts);
+  CVX_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- YOLOv7 anchor decode (core/algorithms/yolo_v7.py:246-343) ------------------------------------------------------------
+// pred: fp32 rows (B, sum_l H_l*W_l, ld), a row = one pixel of one level (levels in the order of the network's outputs,
+// coarsest first), columns a*(5+nc)+k for anchor a = 0..2.  dec: (B, 3*sum_l H_l*W_l, 5+nc) in the reference's order -- level,
+// then anchor, then pixel -- with normalised (cx, cy, w, h), objectness and class probabilities.  y (optional): the same
+// candidates as (B, 4+nc, 3*sum) channel-major [cx, cy, w, h, obj*cls_k] -- the input format of cvx_nms_variant.
+namespace {
+struct Y7Levels {
+  int n;
+  int row0[5];   // first pred row of level l (row0[n] = total rows)
+  int w[4], h[4];
+  float aw[4][3], ah[4][3];  // anchors scaled to the level's grid (anchor / stride)
+};
+__global__ void yolo7_decode_kernel(const float* pred, int ld, int B, int nc, Y7Levels L, float* dec, float* y) {
+  const int attrs = 5 + nc;
+  const long long R = L.row0[L.n];  // rows per image
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * 3 * R) return;
+  const int b = (int)(i / (3 * R));
+  long long r = i - (long long)b * 3 * R;  // reference anchor index inside the image
+  int l = 0;
+  while (l + 1 < L.n && r >= 3LL * L.row0[l + 1]) ++l;
+  const int hw = L.row0[l + 1] - L.row0[l];
+  const long long rl = r - 3LL * L.row0[l];
+  const int a = (int)(rl / hw), pix = (int)(rl - (long long)a * hw);
+  const int gy = pix / L.w[l], gx = pix - gy * L.w[l];
+  const float* p = pred + ((long long)b * R + L.row0[l] + pix) * ld + a * attrs;
+  float* d = dec + i * attrs;
+  auto sg = [](float v) { return 1.f / (1.f + expf(-v)); };
+  const float sx = sg(p[0]), sy = sg(p[1]), sw = sg(p[2]), sh = sg(p[3]), obj = sg(p[4]);
+  const float cx = (sx * 2.f - 0.5f + (float)gx) / (float)L.w[l], cy = (sy * 2.f - 0.5f + (float)gy) / (float)L.h[l];
+  const float tw = sw * 2.f, th = sh * 2.f;
+  const float bw = tw * tw * L.aw[l][a] / (float)L.w[l], bh = th * th * L.ah[l][a] / (float)L.h[l];
+  d[0] = cx;
+  d[1] = cy;
+  d[2] = bw;
+  d[3] = bh;
+  d[4] = obj;
+  const long long A3 = 3 * R;
+  float* yb = y ? y + (long long)b * (4 + nc) * A3 + r : nullptr;
+  if (yb) {
+    yb[0] = cx;
+    yb[A3] = cy;
+    yb[2 * A3] = bw;
+    yb[3 * A3] = bh;
+  }
+  for (int k = 0; k < nc; ++k) {
+    const float c = sg(p[5 + k]);
+    d[5 + k] = c;
+    if (yb) yb[(long long)(4 + k) * A3] = obj * c;
+  }
+}
+}  // namespace
+
+extern "C" int cvx_yolo7_decode(const float* pred, int32_t pred_ld, int32_t B, int32_t nc, const int32_t* level_hw, const float* anchors_wh,
+                                int32_t n_levels, int32_t input_h, int32_t input_w, float* dec, float* y, void* hip_stream) {
+  CVX_CHECK(pred && level_hw && anchors_wh && dec && n_levels >= 1 && n_levels <= 4 && B > 0 && nc > 0, "bad arguments");
+  CVX_CHECK(pred_ld >= 3 * (5 + nc), "pred_ld must cover 3 * (5 + nc) columns");
+  Y7Levels L;
+  memset(&L, 0, sizeof(L));
+  L.n = n_levels;
+  int off = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    L.row0[l] = off;
+    L.h[l] = level_hw[2 * l];
+    L.w[l] = level_hw[2 * l + 1];
+    off += L.h[l] * L.w[l];
+    const float stride_h = (float)input_h / (float)L.h[l], stride_w = (float)input_w / (float)L.w[l];  // yolo_v7.py:259-260
+    for (int a = 0; a < 3; ++a) {
+      L.aw[l][a] = anchors_wh[(l * 3 + a) * 2] / stride_w;
+      L.ah[l][a] = anchors_wh[(l * 3 + a) * 2 + 1] / stride_h;
+    }
+  }
+  L.row0[n_levels] = off;
+  const long long n = (long long)B * 3 * off;
+  hipLaunchKernelGGL(yolo7_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, pred, pred_ld, B, nc, L, dec, y);
   CVX_HIP(hipGetLastError());
   return 0;
 }

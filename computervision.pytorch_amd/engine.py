@@ -257,6 +257,24 @@ def nms(y: torch.Tensor, conf_thres: float, iou_thres: float, max_det: int = 300
     return rows, index, counts
 
 
+def yolo7_decode(rows: torch.Tensor, nc: int, level_hw, anchors_wh, input_hw, want_nms_input: bool = True):
+    """rows (B, sum h*w, ld) fp32 head rows of the YOLOv7 graph -> (dec (B, 3*sum, 5+nc), y (B, 4+nc, 3*sum) or None), on device
+    (cvx_yolo7_decode, include/cvx_engine.h).  ``anchors_wh``: per level three (w, h) pairs in input pixels."""
+    lib = L.load()
+    _need_gpu(rows, "rows")
+    rows = rows.contiguous().float()
+    B, R, ld = rows.shape
+    assert R == sum(h * w for h, w in level_hw)
+    dev = rows.device
+    dec = torch.empty(B, 3 * R, 5 + nc, dtype=torch.float32, device=dev)
+    y = torch.empty(B, 4 + nc, 3 * R, dtype=torch.float32, device=dev) if want_nms_input else None
+    lv = (C.c_int32 * (2 * len(level_hw)))(*[int(v) for hw in level_hw for v in hw])
+    an = (C.c_float * (6 * len(level_hw)))(*[float(v) for lvl in anchors_wh for wh in lvl for v in wh])
+    L.check(lib.cvx_yolo7_decode(L.ptr(rows), ld, B, nc, lv, an, len(level_hw), int(input_hw[0]), int(input_hw[1]), L.ptr(dec), L.ptr(y),
+                                 L.stream_ptr(dev)), "cvx_yolo7_decode")
+    return dec, y
+
+
 _cn_ws = {}
 
 

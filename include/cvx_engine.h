@@ -203,7 +203,7 @@ int cvx_adam_step_dev(float* params, float* grads, float* exp_avg, float* exp_av
  * cvx_decode: pred (B,A,no) -> y (B, 4+nc, A) fp32 [cx,cy,w,h (pixels), class scores]
  *   Replaces: Detect eval branch, core/models/yolov8/modules.py:434-446.
  * cvx_nms: y -> per image up to max_det rows [x1,y1,x2,y2,conf,cls] + the anchor index of each row;
- *   counts[b] = rows kept.  Semantics = oracle/nms_ref.py (torchvision 0.14.1 batched_nms restated, both strategies).
+ *   counts[b] = rows kept (-1: more candidates than the 16384 the in-LDS sort holds -- raise conf_thres).  Semantics = oracle/nms_ref.py (torchvision 0.14.1 batched_nms restated, both strategies).
  *   Replaces: non_max_suppression, core/utils/ultralytics_ops.py:131-264. */
 int cvx_decode(const float* pred, int32_t batch, int32_t anchors, int32_t nc, const int32_t* level_hw, const float* strides,
                int32_t n_levels, float* y, void* hip_stream);
@@ -211,6 +211,15 @@ int cvx_decode(const float* pred, int32_t batch, int32_t anchors, int32_t nc, co
  * class columns padded to the next multiple of 8; the padding is never read. */
 int cvx_decode_strided(const float* pred, int32_t pred_ld, int32_t batch, int32_t anchors, int32_t nc, const int32_t* level_hw,
                        const float* strides, int32_t n_levels, float* y, void* hip_stream);
+/* YOLOv7 anchor decode.  pred: fp32 rows (batch, sum_l h_l*w_l, pred_ld) as the engine's YOLOv7 graph writes them (one row per
+ * pixel, levels in the order of the network's outputs, columns a*(5+nc)+k for anchor a); anchors_wh: n_levels x 3 x (w, h) in
+ * input pixels, already selected through anchors_mask.  dec: (batch, 3*sum, 5+nc) = the reference's `decoded_outputs`
+ * (normalised cx, cy, w, h, objectness, class probabilities; level, anchor, pixel order).  y (optional): the same candidates as
+ * (batch, 4+nc, 3*sum) channel-major [cx, cy, w, h, objectness*class_k] -- what cvx_nms_variant(CVX_NMS_VANILLA) takes, i.e. the
+ * per-class greedy NMS of YOLOv7._nms with score = objectness * best class probability.
+ * Replaces: YOLOv7.decode_box, core/algorithms/yolo_v7.py:234-346. */
+int cvx_yolo7_decode(const float* pred, int32_t pred_ld, int32_t batch, int32_t nc, const int32_t* level_hw, const float* anchors_wh,
+                     int32_t n_levels, int32_t input_h, int32_t input_w, float* dec, float* y, void* hip_stream);
 enum { CVX_NMS_TV0141_CUDA = 0, /* torchvision 0.14.1's own switch for CUDA tensors: coordinate trick up to 5000 candidates */
        CVX_NMS_TV0141_CPU = 1,  /* ... for CPU tensors: up to 1000 candidates */
        CVX_NMS_OFFSET = 2,      /* _batched_nms_coordinate_trick: boxes + cls*(max+1), one class-agnostic pass */

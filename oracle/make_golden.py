@@ -402,6 +402,82 @@ def main():
     report["deeplab"] = dict(init="bit-exact, %d tensors" % len(ref_sd), params=int(sum(p_.numel() for p_ in dmodel.parameters())),
                              out_absmax=float(ref_out.abs().max()), rows_shape=list(my_rows.shape))
 
+    # ---- 11. YOLOv7-l: init, eval forward on a calibrated network, decode, NMS bookkeeping ------------
+    from oracle import yolov7_ref as Y7
+    ycfg, yalgo_cls, _ = builder.export_from_registry("yolo7")
+    ycfg.train.pretrained = False                                # (the default loads saves/yolov7_weights.pth)
+    torch.manual_seed(0)
+    yalgo = yalgo_cls(ycfg, torch.device("cpu"))
+    ymodel, _ = yalgo.build_model()
+    ref_sd = ymodel.state_dict()
+    nc7 = ycfg.dataset.num_classes
+    my_sd = Y7.init_state_dict(nc7, seed=0)
+    assert list(ref_sd.keys()) == list(my_sd.keys())
+    for k in ref_sd:
+        assert ref_sd[k].shape == my_sd[k].shape and torch.equal(ref_sd[k], my_sd[k]), f"YOLOv7 init mismatch {k}"
+    ysums = {k: [float(v.double().sum()), float(v.double().abs().sum())] for k, v in ref_sd.items() if not k.endswith("num_batches_tracked")}
+    with open(os.path.join(GOLD, "yolov7_seed0_init_sums.json"), "w") as f:
+        json.dump(ysums, f)
+    # N(0, 0.02) weights under untouched running statistics let the signal die out layer by layer: calibrate the BatchNorms
+    # with one train-mode pass at momentum 1, then the eval forward of another batch is the fixture; the head biases get a
+    # spread so that objectness / class scores are not all 0.5
+    g = torch.Generator().manual_seed(61)
+    HW7 = (160, 224)
+    xcal, x7 = torch.rand(2, 3, *HW7, generator=g), torch.rand(2, 3, *HW7, generator=g)
+    with torch.no_grad():
+        for hk in ("yolo_head_P3", "yolo_head_P4", "yolo_head_P5"):
+            getattr(ymodel, hk).bias.copy_(torch.randn(3 * (5 + nc7), generator=g) * 1.5 - 1.0)
+    for m_ in ymodel.modules():
+        if isinstance(m_, torch.nn.BatchNorm2d):
+            m_.momentum = 1.0
+    ymodel.train()
+    with torch.no_grad():
+        ymodel(xcal)
+    ymodel.eval()
+    with torch.no_grad():
+        ref7 = ymodel(x7.clone())
+    cal7 = {k: v.clone() for k, v in ymodel.state_dict().items()}
+    with torch.no_grad():
+        my7 = Y7.forward(cal7, x7.clone())
+    for a_, b_ in zip(ref7, my7):
+        assert torch.allclose(a_, b_, rtol=1e-4, atol=1e-5 * float(a_.abs().max())), float((a_ - b_).abs().max())
+    # decode: the tensor decode_box hands to _nms (captured), then _nms itself with torchvision's nms replaced by the
+    # oracle's greedy restatement -- everything around the suppression primitive is the reference's own code
+    yalgo.input_image_size = list(HW7)
+    captured = {}
+    yalgo._nms = lambda pred, *a_: captured.setdefault("dec", pred)
+    yalgo.decode_box(ref7, HW7[0], HW7[1])
+    del yalgo._nms
+    my_dec = Y7.decode(ref7, nc7, HW7)
+    assert torch.equal(captured["dec"], my_dec), float((captured["dec"] - my_dec).abs().max())
+    import core.algorithms.yolo_v7 as ref_y7mod
+    from oracle import nms_ref as _nr
+
+    def _tv_nms(boxes, scores, iou_threshold):
+        o_ = np.argsort(-scores.numpy(), kind="stable")
+        return torch.from_numpy(o_[_nr._greedy(boxes.numpy()[o_], None, iou_threshold)].copy())
+
+    ref_y7mod.nms = _tv_nms
+    yalgo.letterbox_image = False
+    conf7, thr7 = ycfg.decode.conf_threshold, ycfg.decode.nms_threshold
+    ref_nms = yalgo._nms(captured["dec"].clone(), HW7, [1, 1], conf7)
+    my_nms = Y7.nms(my_dec, nc7, conf7, thr7)
+    n_det = []
+    for r_, (m_rows, m_idx) in zip(ref_nms, my_nms):
+        assert (r_ is None) == (m_rows is None)
+        if r_ is not None:
+            assert r_.shape == m_rows.shape and np.allclose(r_, m_rows, rtol=1e-5, atol=1e-6), float(np.abs(r_ - m_rows).max())
+            n_det.append(int(r_.shape[0]))
+    assert sum(n_det) > 10, n_det
+    stats7 = {k: v.numpy().copy() for k, v in cal7.items() if k.endswith("running_mean") or k.endswith("running_var")}
+    np.savez_compressed(os.path.join(GOLD, "yolov7_fwd_160x224.npz"), x=x7.numpy(), out0=ref7[0].numpy().copy(), out1=ref7[1].numpy().copy(),
+                        out2_sub=ref7[2].flatten()[::5].numpy().copy(), dec_sub=my_dec.flatten()[::7].numpy().copy(), conf=np.array(conf7),
+                        nms_thr=np.array(thr7), keep0=my_nms[0][1], keep1=my_nms[1][1], rows0=my_nms[0][0], rows1=my_nms[1][0],
+                        head_bias=np.stack([cal7[h_ + ".bias"].numpy() for h_ in ("yolo_head_P3", "yolo_head_P4", "yolo_head_P5")]),
+                        stat_keys=np.array(list(stats7.keys())), stat_vals=np.concatenate([v.ravel() for v in stats7.values()]))
+    report["yolov7"] = dict(init="bit-exact, %d tensors" % len(ref_sd), params=int(sum(p_.numel() for p_ in ymodel.parameters())),
+                            detections=n_det, out_absmax=[float(o_.abs().max()) for o_ in ref7])
+
     # ---- 6. NMS tail fixture (oracle-generated; upstream parity unpinned) ----------------------
     pred = synth.nms_pred(7)
     res = nms_ref.non_max_suppression(pred, 0.25, 0.7, 300)

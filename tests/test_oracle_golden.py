@@ -243,3 +243,45 @@ def test_deeplab_oracle_init_and_forward(gold):
     np.testing.assert_allclose(rows.numpy(), g["rows"], rtol=1e-4, atol=1e-4 * scale)
     np.testing.assert_allclose(out.flatten()[::11].numpy(), g["out_sub"], rtol=1e-4, atol=1e-4 * scale)
     assert abs(float(out.norm()) - float(g["out_norm"])) < 1e-4 * float(g["out_norm"])
+
+
+def _yolov7_fixture_state(g):
+    from oracle import yolov7_ref as Y
+    sd = Y.init_state_dict(20, seed=0)
+    for i, h in enumerate(("yolo_head_P3", "yolo_head_P4", "yolo_head_P5")):
+        sd[h + ".bias"] = torch.from_numpy(g["head_bias"][i].copy())
+    keys, vals, off = [str(k) for k in g["stat_keys"]], g["stat_vals"], 0
+    for k in keys:
+        n = sd[k].numel()
+        sd[k] = torch.from_numpy(vals[off:off + n].copy())
+        off += n
+    assert off == len(vals)
+    return sd
+
+
+def test_yolov7_oracle_init_forward_decode_nms(gold):
+    """oracle/yolov7_ref.py against what the real reference produced (oracle/make_golden.py section 11): seed-0 state_dict
+    checksums (558 tensors), eval forward of the calibrated network, the decoded tensor and the per-class NMS result."""
+    from oracle import yolov7_ref as Y
+    sd0 = Y.init_state_dict(20, seed=0)
+    sums = json.load(open(os.path.join(GOLD, "yolov7_seed0_init_sums.json")))
+    assert len(sd0) == 558 and [k for k in sd0 if not k.endswith("num_batches_tracked")] == list(sums.keys())
+    for k, (s_, a_) in sums.items():
+        v = sd0[k].double()
+        np.testing.assert_allclose([float(v.sum()), float(v.abs().sum())], [s_, a_], rtol=1e-12, atol=1e-12, err_msg=k)
+    g = gold("yolov7_fwd_160x224.npz")
+    sd = _yolov7_fixture_state(g)
+    with torch.no_grad():
+        outs = Y.forward(sd, torch.from_numpy(g["x"]))
+    np.testing.assert_allclose(outs[0].numpy(), g["out0"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(outs[1].numpy(), g["out1"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(outs[2].flatten()[::5].numpy(), g["out2_sub"], rtol=1e-4, atol=1e-4)
+    dec = Y.decode(outs, 20, (160, 224))
+    np.testing.assert_allclose(dec.flatten()[::7].numpy(), g["dec_sub"], rtol=1e-4, atol=1e-5)
+    res = Y.nms(dec, 20, float(g["conf"]), float(g["nms_thr"]))
+    for b in range(2):
+        rows, keep = res[b]
+        # logits 1e-5 away from the fixture's can move a borderline candidate: sets agree but for a handful
+        common = len(set(keep.tolist()) & set(g[f"keep{b}"].tolist()))
+        assert common >= 0.98 * len(g[f"keep{b}"]) and abs(len(keep) - len(g[f"keep{b}"])) <= 0.02 * len(keep)
+        assert rows.shape[1] == 7 and np.all(np.diff(rows[:, 6]) >= 0)
