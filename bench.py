@@ -320,6 +320,81 @@ def yolov7_main(args):
         dist.destroy_process_group()
 
 
+SSD_GFLOP_PER_IMG = 62.8        # SSD300 VGG16 @ 300x300 (probe)
+
+
+def ssd_main(args):
+    """images/sec of SSD300 (VGG16-BN) INFERENCE (engine forward + NCHW-order head tensors + softmax / prior decode) on synthetic
+    300x300 batches of 32; one process per GPU, images sharded with no exchange.  (At random init no class score passes the 0.7
+    threshold, so the per-class NMS launches are skipped, as they would be on background images.)"""
+    rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    import torch.distributed as dist
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29536")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    import builder
+    from computervision.pytorch_amd import synth
+    cfg, algo_cls, _ = builder.export_from_registry("ssd")
+    algo = algo_cls(cfg, dev)
+    torch.manual_seed(0)
+    model, _ = algo.build_model()
+    model = model.to(dev).eval()
+    B = args.batch
+    x = synth.images(B, 300, 300, seed=1 + rank).to(dev)
+
+    def step():
+        with torch.no_grad():
+            return algo.decode_device(model(x))
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    eng = model._last_engine
+    eng.profile(True)
+    for _ in range(3):
+        step()
+    sync()
+    prof = eng.profile_read()
+    eng.profile(False)
+    if rank == 0:
+        value = B * world * args.steps / elapsed
+        conv = prof["conv_fwd"]
+        tf = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+        print(json.dumps({
+            "metric": "images/sec 300x300 SSD300-VGG16 inference + decode", "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"SSD300 VGG16-BN (nc 20) eval forward + softmax / prior decode (+ per-class NMS when a score passes), batch {B}/GPU, "
+                                   "300x300, random init", "global_batch": B * world, "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "kernel": "implicit-GEMM convolution forward launches (conv_halo / conv_pw / conv_igemm_dma)",
+                         "achieved": round(tf, 3), "peak": MFMA_FP16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_FP16_PEAK_TFLOPS, 5),
+                         "traffic": None, "avg_launch_us": round(conv["ms"] * 1e3 / max(conv["launches"], 1), 3),
+                         "launches_per_step": conv["launches"] // 3},
+            "whole_step": {"tflops": round(value / world * SSD_GFLOP_PER_IMG / 1e3, 3),
+                           "frac_of_mfma_peak": round(value / world * SSD_GFLOP_PER_IMG / 1e3 / MFMA_FP16_PEAK_TFLOPS, 5)},
+            "kernel_classes": {k: {"ms_per_step": round(v["ms"] / 3, 4), "launches_per_step": v["launches"] // 3} for k, v in prof.items() if v["launches"]},
+            "engine_workspace_gib": round(eng.workspace_bytes() / 2 ** 30, 3)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -331,7 +406,7 @@ def main():
     ap.add_argument("--graph", type=int, default=0, help="1: replay the step as a hipGraph (N=1 only); 0: eager stream launches (default: "
                     "measured faster -- the side-stream weight gradients overlap better than as graph branches)")
     ap.add_argument("--profile-steps", type=int, default=10, help="steps of the per-kernel HIP-event window after the timed region")
-    ap.add_argument("--workload", default="yolov8_train", choices=["yolov8_train", "centernet", "deeplab", "yolov7"],
+    ap.add_argument("--workload", default="yolov8_train", choices=["yolov8_train", "centernet", "deeplab", "yolov7", "ssd"],
                     help="centernet: BASELINE.json configs[3] -- CenterNet DLA-34 (nc 80) 512x512 inference + heat-map decode, batch 64 per GPU")
     args = ap.parse_args()
     if args.workload == "centernet":
@@ -340,6 +415,8 @@ def main():
         return deeplab_main(args)
     if args.workload == "yolov7":
         return yolov7_main(args)
+    if args.workload == "ssd":
+        return ssd_main(args)
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))

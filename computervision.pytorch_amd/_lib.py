@@ -38,9 +38,10 @@ class OpDesc(C.Structure):
 
 
 BUF_ACT_F16, BUF_PRED_F32 = 0, 1
-OP_CONV, OP_MAXPOOL5, OP_UPSAMPLE2, OP_MAXPOOL2, OP_DWCONVT, OP_COPY, OP_MAXPOOL3S2, OP_AVGPOOL, OP_RESIZE = 1, 2, 3, 4, 5, 6, 7, 8, 9
-ACT_BN_SILU, ACT_BIAS, ACT_BN_RELU, ACT_BN_LINEAR, ACT_BIAS_RELU = 1, 2, 3, 4, 5
+OP_CONV, OP_MAXPOOL5, OP_UPSAMPLE2, OP_MAXPOOL2, OP_DWCONVT, OP_COPY, OP_MAXPOOL3S2, OP_AVGPOOL, OP_RESIZE, OP_MAXPOOL3S1, OP_L2NORM = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
+ACT_BN_SILU, ACT_BIAS, ACT_BN_RELU, ACT_BN_LINEAR, ACT_BIAS_RELU, ACT_BIAS_LINEAR = 1, 2, 3, 4, 5, 6
 OPF_RES_PRE_ACT = 1
+OPF_CONV_BIAS = 2
 
 _P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -82,6 +83,8 @@ PROTOTYPES = {
     "cvx_engine_set_stream": (_I32, [_P, _P]),
     "cvx_decode": (_I32, [_P, _I32, _I32, _I32, C.POINTER(_I32), C.POINTER(_F), _I32, _P, _P]),
     "cvx_yolo7_decode": (_I32, [_P, _I32, _I32, _I32, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
+    "cvx_ssd_decode": (_I32, [_P, _P, _P, _I32, _I32, _I32, _F, _F, _P, _P, _P]),
+    "cvx_pred_cols_to_nchw": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I64, _I64, _P]),
     "cvx_nms_workspace_bytes": (_I64, [_I32, _I32]),
     "cvx_nms": (_I32, [_P, _I32, _I32, _I32, _F, _F, _I32, _P, _P, _P, _P, _I64, _P]),
     "cvx_nms_variant": (_I32, [_P, _I32, _I32, _I32, _F, _F, _I32, _I32, _P, _P, _P, _P, _I64, _P]),

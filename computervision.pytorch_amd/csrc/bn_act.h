@@ -44,6 +44,7 @@ struct BnFoldDesc {
   float* shift;
   int C;
   int bias_only;                  // 1: no BatchNorm -- scale = 1, shift = params[beta_off] (a conv bias feeding an activation)
+  long long cbias_off;            // >= 0: the conv has a bias of its own in front of the BatchNorm (VGG-BN): shift += scale * bias
 };
 int cvx_bn_fold_all(const BnFoldDesc* descs, int n, const float* params, const float* stats, float eps, hipStream_t st);
 int cvx_bn_fold(int n, const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps, float* scale, float* shift,

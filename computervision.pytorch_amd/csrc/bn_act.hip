@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256) void bn_fold_all_kernel(const BnFoldDesc* desc
     }
     const float sc = params[d.gamma_off + i] / sqrtf(stats[d.rvar_off + i] + eps);
     d.scale[i] = sc;
-    d.shift[i] = params[d.beta_off + i] - stats[d.rmean_off + i] * sc;
+    const float cb = d.cbias_off >= 0 ? params[d.cbias_off + i] : 0.f;  // bn(conv + b) = sc * conv + (beta + sc * (b - mean))
+    d.shift[i] = params[d.beta_off + i] + (cb - stats[d.rmean_off + i]) * sc;
   }
 }
 

@@ -250,7 +250,7 @@ int build_static(cvx_engine* e) {
   for (int i = 0; i < nops; ++i) {
     const cvx_op_desc& o = e->ops[i];
     CVX_CHECK(o.in.buf >= 0 && o.in.buf < (int)e->bufs.size() && o.out.buf >= 0 && o.out.buf < (int)e->bufs.size(), "op view buffer index");
-    CVX_CHECK(o.type >= CVX_OP_CONV && o.type <= CVX_OP_RESIZE, "unknown op type");
+    CVX_CHECK(o.type >= CVX_OP_CONV && o.type <= CVX_OP_L2NORM, "unknown op type");
     if (o.type >= CVX_OP_MAXPOOL2 || (o.type == CVX_OP_CONV && o.act >= CVX_ACT_BN_RELU)) e->inference_only = true;
     if (o.type != CVX_OP_CONV) {
       CVX_CHECK(o.in.c % 8 == 0 && o.in.coff % 8 == 0 && o.out.coff % 8 == 0 && o.in.c == o.out.c, "pool / resample / copy views: equal, 8-aligned channel slices");
@@ -433,9 +433,10 @@ int plan_batch(cvx_engine* e, int B, bool training) {
     c.scale = c.invstd + C;
     c.shift = c.scale + C;
     if (o.act == CVX_ACT_BN_SILU || o.act == CVX_ACT_BN_RELU || o.act == CVX_ACT_BN_LINEAR)
-      folds.push_back(BnFoldDesc{o.gamma_off, o.beta_off, o.rmean_off, o.rvar_off, c.scale, c.shift, C, 0});
-    else if (o.act == CVX_ACT_BIAS_RELU)
-      folds.push_back(BnFoldDesc{0, o.bias_off, 0, 0, c.scale, c.shift, C, 1});
+      folds.push_back(BnFoldDesc{o.gamma_off, o.beta_off, o.rmean_off, o.rvar_off, c.scale, c.shift, C, 0,
+                                 (o.flags & CVX_OPF_CONV_BIAS) ? (long long)o.bias_off : -1LL});
+    else if (o.act == CVX_ACT_BIAS_RELU || o.act == CVX_ACT_BIAS_LINEAR)
+      folds.push_back(BnFoldDesc{0, o.bias_off, 0, 0, c.scale, c.shift, C, 1, -1LL});
     if (training && o.act == CVX_ACT_BN_SILU) {
       CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, M * C * 2));
       c.ybuf = (half_t*)p;
@@ -846,7 +847,7 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
     }
     if (o.type == CVX_OP_MAXPOOL2) {
       ProfScope ps(e, PROF_MISC, 0, 2.5 * B * o.ih * o.iw * o.in.c, st);
-      CVX_TRY(cvx_maxpool2(make_view(e, o.in, false), make_view(e, o.out, false), B, o.oh, o.ow, o.in.c, st));
+      CVX_TRY(cvx_maxpool2(make_view(e, o.in, false), make_view(e, o.out, false), B, o.ih, o.iw, o.oh, o.ow, o.in.c, st));
       continue;
     }
     if (o.type == CVX_OP_DWCONVT) {
@@ -862,7 +863,18 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
     if (o.type == CVX_OP_MAXPOOL3S2) {
       ProfScope ps(e, PROF_MISC, 0, 2.0 * B * (o.ih * o.iw + o.oh * o.ow) * o.in.c, st);
       CVX_CHECK(o.oh == (o.ih - 1) / 2 + 1 && o.ow == (o.iw - 1) / 2 + 1, "maxpool3s2: output size must be floor((i - 1) / 2) + 1");
-      CVX_TRY(cvx_maxpool3s2(make_view(e, o.in, false), make_view(e, o.out, false), B, o.ih, o.iw, o.in.c, st));
+      CVX_TRY(cvx_maxpool3(make_view(e, o.in, false), make_view(e, o.out, false), B, o.ih, o.iw, o.in.c, 2, st));
+      continue;
+    }
+    if (o.type == CVX_OP_MAXPOOL3S1) {
+      ProfScope ps(e, PROF_MISC, 0, 4.0 * B * o.ih * o.iw * o.in.c, st);
+      CVX_CHECK(o.oh == o.ih && o.ow == o.iw, "maxpool3s1: same-size output");
+      CVX_TRY(cvx_maxpool3(make_view(e, o.in, false), make_view(e, o.out, false), B, o.ih, o.iw, o.in.c, 1, st));
+      continue;
+    }
+    if (o.type == CVX_OP_L2NORM) {
+      ProfScope ps(e, PROF_MISC, 0, 4.0 * B * o.ih * o.iw * o.in.c, st);
+      CVX_TRY(cvx_l2norm(make_view(e, o.in, false), make_view(e, o.out, false), e->params + o.gamma_off, B, o.ih * o.iw, o.in.c, st));
       continue;
     }
     if (o.type == CVX_OP_AVGPOOL) {
@@ -931,7 +943,7 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
     } else {
       // scale / shift were folded for every layer at once before the op loop (cvx_bn_fold_all)
       cp.epi = CVX_EPI_AFFINE_SILU;
-      cp.act_kind = o.act == CVX_ACT_BN_SILU ? 0 : (o.act == CVX_ACT_BN_LINEAR ? 2 : 1);
+      cp.act_kind = o.act == CVX_ACT_BN_SILU ? 0 : ((o.act == CVX_ACT_BN_LINEAR || o.act == CVX_ACT_BIAS_LINEAR) ? 2 : 1);
       cp.res_pre = (o.flags & CVX_OPF_RES_PRE_ACT) ? 1 : 0;
       cp.scale = c.scale;
       cp.shift = c.shift;

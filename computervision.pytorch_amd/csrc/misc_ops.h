@@ -4,12 +4,14 @@
 
 int cvx_image_to_nhwc8(const float* img_nchw, int B, int H, int W, half_t* out, hipStream_t st);
 // 2x2 / stride 2 max pool, depthwise ConvTranspose2d (kernel 2f, stride f, padding f/2; w fp32 [C][2f][2f]), channel-slice copy
-int cvx_maxpool2(const ViewDesc& in, const ViewDesc& out, int B, int OH, int OW, int C, hipStream_t st);
+int cvx_maxpool2(const ViewDesc& in, const ViewDesc& out, int B, int IH, int IW, int OH, int OW, int C, hipStream_t st);  // floor or ceil mode
+// L2Normalize over channels with a learned per-channel scale (SSD conv4_3)
+int cvx_l2norm(const ViewDesc& in, const ViewDesc& out, const float* weight, int B, int HW, int C, hipStream_t st);
 int cvx_dwconvt(const ViewDesc& in, const ViewDesc& out, const float* w, int B, int IH, int IW, int C, int f, hipStream_t st);
 int cvx_copy_slice(const ViewDesc& in, const ViewDesc& out, int B, int HW, int C, hipStream_t st);
 // DeepLabv3+ (inference): 3x3 / stride 2 / pad 1 max pool, global average pool -> (B, 1, 1, C), bilinear resize with
 // align_corners = False on fp16 NHWC views, and fp32 rows (B, IH*IW, ld) -> NCHW fp32 (B, C, OH, OW)
-int cvx_maxpool3s2(const ViewDesc& in, const ViewDesc& out, int B, int IH, int IW, int C, hipStream_t st);
+int cvx_maxpool3(const ViewDesc& in, const ViewDesc& out, int B, int IH, int IW, int C, int stride, hipStream_t st);  // 3x3, pad 1, stride 1 | 2
 int cvx_avgpool_global(const ViewDesc& in, const ViewDesc& out, int B, int HW, int C, hipStream_t st);
 int cvx_resize_bilinear(const ViewDesc& in, const ViewDesc& out, int B, int IH, int IW, int OH, int OW, int C, hipStream_t st);
 int cvx_resize_bilinear_f32_nchw(const float* in, int ld, int B, int C, int IH, int IW, int OH, int OW, float* out, hipStream_t st);
@@ -25,6 +27,8 @@ int cvx_upsample2_bwd(const ViewDesc& gout, const ViewDesc& gin, int B, int H, i
 
 // copy pred (B, A, no) fp32 level slice -> NCHW fp32 (B, no, H, W)   (API-compat outputs)
 int cvx_pred_to_nchw(const float* pred, int B, int A, int no, int a_off, int H, int W, float* out, hipStream_t st);
+int cvx_pred_cols_to_nchw_launch(const float* rows, int ld, int col0, int C, int B, int A, int a_off, int HW, float* out, long long out_bstride,
+                                 long long out_off, hipStream_t st);
 int cvx_nchw_to_pred_f16(const float* g_nchw, int B, int A, int no, int a_off, int H, int W, float scale, half_t* dpred, hipStream_t st);
 
 // ---- table-driven multi-tensor kernels ---------------------------------------------------------

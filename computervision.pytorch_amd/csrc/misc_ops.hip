@@ -18,7 +18,7 @@ __global__ void image_to_nhwc8_kernel(const float* img, int B, int HW, half_t* o
 }
 
 // ---- max pool 2x2 stride 2 (DLA Tree.downsample, centernet_model.py:128-129) ----
-__global__ void maxpool2_kernel(ViewDesc in, ViewDesc out, int B, int OH, int OW, int CG) {
+__global__ void maxpool2_kernel(ViewDesc in, ViewDesc out, int B, int IH, int IW, int OH, int OW, int CG) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long n = (long long)B * OH * OW * CG;
   if (i >= n) return;
@@ -28,19 +28,25 @@ __global__ void maxpool2_kernel(ViewDesc in, ViewDesc out, int B, int OH, int OW
   t /= OW;
   int h = (int)(t % OH);
   int b = (int)(t / OH);
-  const int IW = 2 * OW;
-  h8 v[4];
+  float best[8];
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
-    v[q] = *reinterpret_cast<const h8*>(in.p + voff(in, b, (long long)(2 * h + (q >> 1)) * IW + 2 * w + (q & 1)) + cg * 8);
+  for (int k = 0; k < 8; ++k) best[k] = -INFINITY;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int hh = 2 * h + (q >> 1), ww = 2 * w + (q & 1);
+    if (hh >= IH || ww >= IW) continue;  // ceil_mode: the last window of an odd size is clipped
+    const h8 v = *reinterpret_cast<const h8*>(in.p + voff(in, b, (long long)hh * IW + ww) + cg * 8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) best[k] = fmaxf(best[k], (float)v[k]);
+  }
   h8 o;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) o[k] = (half_t)fmaxf(fmaxf((float)v[0][k], (float)v[1][k]), fmaxf((float)v[2][k], (float)v[3][k]));
+  for (int k = 0; k < 8; ++k) o[k] = (half_t)best[k];
   *reinterpret_cast<h8*>(out.p + voff(out, b, (long long)h * OW + w) + cg * 8) = o;
 }
 
 // ---- max pool 3x3 stride 2 pad 1 (ResNet stem, core/models/resnet.py:163) ----
-__global__ void maxpool3s2_kernel(ViewDesc in, ViewDesc out, int B, int IH, int IW, int OH, int OW, int CG) {
+__global__ void maxpool3_kernel(ViewDesc in, ViewDesc out, int B, int IH, int IW, int OH, int OW, int CG, int stride) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long n = (long long)B * OH * OW * CG;
   if (i >= n) return;
@@ -55,10 +61,10 @@ __global__ void maxpool3s2_kernel(ViewDesc in, ViewDesc out, int B, int IH, int 
   for (int k = 0; k < 8; ++k) best[k] = -INFINITY;
 #pragma unroll
   for (int dy = 0; dy < 3; ++dy) {
-    const int hh = 2 * h - 1 + dy;
+    const int hh = stride * h - 1 + dy;
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
-      const int ww = 2 * w - 1 + dx;
+      const int ww = stride * w - 1 + dx;
       if (hh < 0 || hh >= IH || ww < 0 || ww >= IW) continue;
       const h8 v = *reinterpret_cast<const h8*>(in.p + voff(in, b, (long long)hh * IW + ww) + cg * 8);
 #pragma unroll
@@ -69,6 +75,32 @@ __global__ void maxpool3s2_kernel(ViewDesc in, ViewDesc out, int B, int IH, int 
 #pragma unroll
   for (int k = 0; k < 8; ++k) o[k] = (half_t)best[k];
   *reinterpret_cast<h8*>(out.p + voff(out, b, (long long)h * OW + w) + cg * 8) = o;
+}
+
+// ---- L2Normalize (core/models/ssd_model.py:113-128): x / (sqrt(sum_c x^2) + 1e-10) * weight[c]; one wave per pixel ----
+__global__ __launch_bounds__(256) void l2norm_kernel(ViewDesc in, ViewDesc out, const float* weight, long long npix, int hw, int C) {
+  const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pix >= npix) return;
+  const int lane = threadIdx.x & 63;
+  const int b = (int)(pix / hw);
+  const long long p = pix - (long long)b * hw;
+  const half_t* src = in.p + voff(in, b, p);
+  float ss = 0.f;
+  for (int c = lane * 8; c < C; c += 512) {
+    const h8 v = *reinterpret_cast<const h8*>(src + c);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ss += (float)v[k] * (float)v[k];
+  }
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  const float inv = 1.f / (sqrtf(ss) + 1e-10f);
+  half_t* dst = out.p + voff(out, b, p);
+  for (int c = lane * 8; c < C; c += 512) {
+    const h8 v = *reinterpret_cast<const h8*>(src + c);
+    h8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (half_t)(weight[c + k] * ((float)v[k] * inv));
+    *reinterpret_cast<h8*>(dst + c) = o;
+  }
 }
 
 // ---- global average pool (ASPPPooling's AdaptiveAvgPool2d(1), core/models/deeplabv3plus.py:30): one workgroup per
@@ -519,13 +551,21 @@ int launch1d(K kern, long long n, hipStream_t st, Args... args) {
 int cvx_image_to_nhwc8(const float* img, int B, int H, int W, half_t* out, hipStream_t st) {
   return launch1d(image_to_nhwc8_kernel, (long long)B * H * W, st, img, B, H * W, out);
 }
-int cvx_maxpool2(const ViewDesc& in, const ViewDesc& out, int B, int OH, int OW, int C, hipStream_t st) {
-  return launch1d(maxpool2_kernel, (long long)B * OH * OW * (C / 8), st, in, out, B, OH, OW, C / 8);
+int cvx_maxpool2(const ViewDesc& in, const ViewDesc& out, int B, int IH, int IW, int OH, int OW, int C, hipStream_t st) {
+  CVX_CHECK((OH == IH / 2 || OH == (IH + 1) / 2) && (OW == IW / 2 || OW == (IW + 1) / 2), "maxpool2: output size must be floor or ceil of half the input");
+  return launch1d(maxpool2_kernel, (long long)B * OH * OW * (C / 8), st, in, out, B, IH, IW, OH, OW, C / 8);
 }
-int cvx_maxpool3s2(const ViewDesc& in, const ViewDesc& out, int B, int IH, int IW, int C, hipStream_t st) {
-  CVX_CHECK(C % 8 == 0, "maxpool3s2: C % 8");
-  const int OH = (IH - 1) / 2 + 1, OW = (IW - 1) / 2 + 1;  // floor((I + 2 - 3) / 2) + 1
-  return launch1d(maxpool3s2_kernel, (long long)B * OH * OW * (C / 8), st, in, out, B, IH, IW, OH, OW, C / 8);
+int cvx_l2norm(const ViewDesc& in, const ViewDesc& out, const float* weight, int B, int HW, int C, hipStream_t st) {
+  CVX_CHECK(C % 8 == 0 && weight, "l2norm: C % 8 / weight");
+  const long long npix = (long long)B * HW;
+  hipLaunchKernelGGL(l2norm_kernel, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, st, in, out, weight, npix, HW, C);
+  CVX_HIP(hipGetLastError());
+  return 0;
+}
+int cvx_maxpool3(const ViewDesc& in, const ViewDesc& out, int B, int IH, int IW, int C, int stride, hipStream_t st) {
+  CVX_CHECK(C % 8 == 0 && (stride == 1 || stride == 2), "maxpool3: C % 8, stride 1 or 2");
+  const int OH = (IH - 1) / stride + 1, OW = (IW - 1) / stride + 1;  // floor((I + 2 - 3) / stride) + 1
+  return launch1d(maxpool3_kernel, (long long)B * OH * OW * (C / 8), st, in, out, B, IH, IW, OH, OW, C / 8, stride);
 }
 int cvx_avgpool_global(const ViewDesc& in, const ViewDesc& out, int B, int HW, int C, hipStream_t st) {
   CVX_CHECK(C % 8 == 0 && HW > 0, "avgpool_global: C % 8");
@@ -565,6 +605,20 @@ int cvx_upsample2_fwd(const ViewDesc& in, const ViewDesc& out, int B, int H, int
 int cvx_upsample2_bwd(const ViewDesc& gout, const ViewDesc& gin, int B, int H, int W, int C, int accumulate, hipStream_t st) {
   CVX_CHECK(C % 8 == 0, "upsample2_bwd: C % 8");
   return launch1d(upsample2_bwd_kernel, (long long)B * H * W * (C / 8), st, gout, gin, B, H, W, C / 8, accumulate);
+}
+__global__ void pred_cols_to_nchw_kernel(const float* rows, int ld, int col0, int C, int B, int A, int a_off, int HW, float* out,
+                                         long long out_bstride, long long out_off) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * C * HW) return;
+  const int pix = (int)(i % HW);
+  long long t = i / HW;
+  const int c = (int)(t % C);
+  const int b = (int)(t / C);
+  out[(long long)b * out_bstride + out_off + (long long)c * HW + pix] = rows[((long long)b * A + a_off + pix) * ld + col0 + c];
+}
+int cvx_pred_cols_to_nchw_launch(const float* rows, int ld, int col0, int C, int B, int A, int a_off, int HW, float* out, long long out_bstride,
+                                 long long out_off, hipStream_t st) {
+  return launch1d(pred_cols_to_nchw_kernel, (long long)B * C * HW, st, rows, ld, col0, C, B, A, a_off, HW, out, out_bstride, out_off);
 }
 int cvx_pred_to_nchw(const float* pred, int B, int A, int no, int a_off, int H, int W, float* out, hipStream_t st) {
   return launch1d(pred_to_nchw_kernel, (long long)B * no * H * W, st, pred, B, A, no, a_off, H * W, out);

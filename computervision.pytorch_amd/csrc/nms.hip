@@ -89,7 +89,9 @@ struct NmsWs {
 };
 
 __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* y, int A, int nc, float conf_thres, float iou_thres, int max_det, int cap,
-                                                          int variant, NmsWs ws, float* out_rows, int* out_index, int* counts) {
+                                                          int variant_flags, NmsWs ws, float* out_rows, int* out_index, int* counts) {
+  const int variant = variant_flags & 0xff;
+  const bool xyxy = (variant_flags & CVX_NMS_BOXES_XYXY) != 0;
   extern __shared__ unsigned long long keys[];  // cap2 entries (power of two >= candidates)
   __shared__ int s_n;
   __shared__ unsigned long long s_removed[NMS_CAP / 64];
@@ -154,8 +156,12 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* y, int A,
   for (int i = tid; i < n; i += NMS_THREADS) {
     int a = (int)(keys[i] & 0xFFFFFFFFu);
     float cx = yb[a], cy = yb[(long long)A + a], w = yb[2LL * A + a], h = yb[3LL * A + a];
-    float hw = __fmul_rn(w, 0.5f), hh = __fmul_rn(h, 0.5f);
-    box[i] = make_float4(__fsub_rn(cx, hw), __fsub_rn(cy, hh), __fadd_rn(cx, hw), __fadd_rn(cy, hh));
+    if (xyxy) {  // CVX_NMS_BOXES_XYXY: rows 0..3 already hold corners (SSD's clipped decode): taken as they are
+      box[i] = make_float4(cx, cy, w, h);
+    } else {
+      float hw = __fmul_rn(w, 0.5f), hh = __fmul_rn(h, 0.5f);
+      box[i] = make_float4(__fsub_rn(cx, hw), __fsub_rn(cy, hh), __fadd_rn(cx, hw), __fadd_rn(cy, hh));
+    }
     float best = -1.f;
     int bc = 0;
     for (int c = 0; c < nc; ++c) {
@@ -300,7 +306,8 @@ extern "C" int cvx_nms_variant(const float* y, int32_t B, int32_t A, int32_t nc,
                                int32_t variant, float* out_rows, int32_t* out_index, int32_t* counts, void* workspace,
                                int64_t workspace_bytes, void* hip_stream) {
   CVX_CHECK(y && out_rows && out_index && counts && workspace, "null arguments");
-  CVX_CHECK(variant >= CVX_NMS_TV0141_CUDA && variant <= CVX_NMS_VANILLA, "unknown batched_nms variant");
+  CVX_CHECK((variant & 0xff) >= CVX_NMS_TV0141_CUDA && (variant & 0xff) <= CVX_NMS_VANILLA && (variant & ~(0xff | CVX_NMS_BOXES_XYXY)) == 0,
+            "unknown batched_nms variant");
   CVX_CHECK(conf_thres >= 0.f && conf_thres <= 1.f && iou_thres >= 0.f && iou_thres <= 1.f, "thresholds must lie in [0,1]");
   CVX_CHECK(max_det >= 1 && max_det <= 1024, "max_det must lie in [1,1024]");
   CVX_CHECK(workspace_bytes >= cvx_nms_workspace_bytes(B, A), "workspace too small");
@@ -405,6 +412,46 @@ extern "C" int cvx_yolo7_decode(const float* pred, int32_t pred_ld, int32_t B, i
   L.row0[n_levels] = off;
   const long long n = (long long)B * 3 * off;
   hipLaunchKernelGGL(yolo7_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, pred, pred_ld, B, nc, L, dec, y);
+  CVX_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- SSD decode (core/algorithms/ssd.py:236-325): softmax over the class scores, prior-box regression decode with
+// variances (0.1, 0.2), corners clipped to [0, 1].  One thread per prior. ----
+namespace {
+__global__ void ssd_decode_kernel(const float* loc, const float* conf, const float* priors, int B, int A, int nc1, float v0, float v1,
+                                  float* boxes, float* prob) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * A) return;
+  const int a = (int)(i % A);
+  const float* l = loc + i * 4;
+  const float4 pr = *reinterpret_cast<const float4*>(priors + (long long)a * 4);
+  const float aw = pr.z - pr.x, ah = pr.w - pr.y;
+  const float acx = 0.5f * (pr.z + pr.x), acy = 0.5f * (pr.w + pr.y);
+  const float cx = l[0] * aw * v0 + acx, cy = l[1] * ah * v0 + acy;
+  const float w = expf(l[2] * v1) * aw, h = expf(l[3] * v1) * ah;
+  float4 o = make_float4(cx - 0.5f * w, cy - 0.5f * h, cx + 0.5f * w, cy + 0.5f * h);
+  o.x = fminf(fmaxf(o.x, 0.f), 1.f);
+  o.y = fminf(fmaxf(o.y, 0.f), 1.f);
+  o.z = fminf(fmaxf(o.z, 0.f), 1.f);
+  o.w = fminf(fmaxf(o.w, 0.f), 1.f);
+  *reinterpret_cast<float4*>(boxes + i * 4) = o;
+  const float* c = conf + i * nc1;
+  float m = c[0];
+  for (int k = 1; k < nc1; ++k) m = fmaxf(m, c[k]);
+  float sum = 0.f;
+  for (int k = 0; k < nc1; ++k) sum += expf(c[k] - m);
+  float* p = prob + i * nc1;
+  for (int k = 0; k < nc1; ++k) p[k] = expf(c[k] - m) / sum;
+}
+}  // namespace
+
+extern "C" int cvx_ssd_decode(const float* loc, const float* conf, const float* priors, int32_t B, int32_t A, int32_t num_classes_plus_bg,
+                              float variance_xy, float variance_wh, float* boxes, float* prob, void* hip_stream) {
+  CVX_CHECK(loc && conf && priors && boxes && prob && B > 0 && A > 0 && num_classes_plus_bg > 1, "bad arguments");
+  const long long n = (long long)B * A;
+  hipLaunchKernelGGL(ssd_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, loc, conf, priors, B, A,
+                     num_classes_plus_bg, variance_xy, variance_wh, boxes, prob);
   CVX_HIP(hipGetLastError());
   return 0;
 }

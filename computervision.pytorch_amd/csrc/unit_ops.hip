@@ -78,6 +78,11 @@ extern "C" int cvx_resize_bilinear_rows_to_nchw(const float* rows_f32, int32_t l
   CVX_TRY(cvx_resize_bilinear_f32_nchw(rows_f32, ld, batch, c, ih, iw, oh, ow, out_nchw, (hipStream_t)hip_stream));
   return 0;  // asynchronous on the caller's stream, like the engine's forward it follows
 }
+extern "C" int cvx_pred_cols_to_nchw(const float* rows, int32_t ld, int32_t col0, int32_t c, int32_t batch, int32_t anchors, int32_t a_off,
+                                     int32_t hw, float* out, int64_t out_bstride, int64_t out_off, void* hip_stream) {
+  CVX_CHECK(rows && out && batch > 0 && c > 0 && col0 >= 0 && col0 + c <= ld && a_off >= 0 && a_off + hw <= anchors, "bad arguments");
+  return cvx_pred_cols_to_nchw_launch(rows, ld, col0, c, batch, anchors, a_off, hw, out, out_bstride, out_off, (hipStream_t)hip_stream);
+}
 extern "C" int cvx_upsample2_nhwc(const void* x_f16, int32_t batch, int32_t h, int32_t w, int32_t c, void* out_f16, void* hip_stream) {
   CVX_CHECK(x_f16 && out_f16 && batch > 0 && c % 8 == 0, "bad arguments (channels in multiples of 8)");
   CVX_TRY(cvx_upsample2_fwd(dense(x_f16, h * w, c), dense(out_f16, 4 * h * w, c), batch, h, w, c, (hipStream_t)hip_stream));

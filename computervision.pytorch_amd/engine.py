@@ -234,7 +234,7 @@ _nms_ws = {}
 NMS_VARIANTS = {"tv0141_cuda": 0, "tv0141_cpu": 1, "offset": 2, "vanilla": 3}
 
 
-def nms(y: torch.Tensor, conf_thres: float, iou_thres: float, max_det: int = 300, variant: str = "tv0141_cuda"):
+def nms(y: torch.Tensor, conf_thres: float, iou_thres: float, max_det: int = 300, variant: str = "tv0141_cuda", boxes_xyxy: bool = False):
     """y (B, 4+nc, A) fp32 -> (rows (B,max_det,6), anchor_index (B,max_det) int32, counts (B,) int32), all on device.
     ``variant``: torchvision 0.14.1 ``batched_nms`` strategy (include/cvx_engine.h); the default is the library's own
     switch for CUDA tensors, i.e. what the reference's GPU predict path runs."""
@@ -252,7 +252,7 @@ def nms(y: torch.Tensor, conf_thres: float, iou_thres: float, max_det: int = 300
     rows = torch.zeros(B, max_det, 6, dtype=torch.float32, device=y.device)
     index = torch.zeros(B, max_det, dtype=torch.int32, device=y.device)
     counts = torch.zeros(B, dtype=torch.int32, device=y.device)
-    L.check(lib.cvx_nms_variant(L.ptr(y), B, A, nc, conf_thres, iou_thres, max_det, NMS_VARIANTS[variant], L.ptr(rows), L.ptr(index),
+    L.check(lib.cvx_nms_variant(L.ptr(y), B, A, nc, conf_thres, iou_thres, max_det, NMS_VARIANTS[variant] | (0x100 if boxes_xyxy else 0), L.ptr(rows), L.ptr(index),
                                 L.ptr(counts), L.ptr(ws), ws.numel(), L.stream_ptr(y.device)), "cvx_nms")
     return rows, index, counts
 
@@ -273,6 +273,19 @@ def yolo7_decode(rows: torch.Tensor, nc: int, level_hw, anchors_wh, input_hw, wa
     L.check(lib.cvx_yolo7_decode(L.ptr(rows), ld, B, nc, lv, an, len(level_hw), int(input_hw[0]), int(input_hw[1]), L.ptr(dec), L.ptr(y),
                                  L.stream_ptr(dev)), "cvx_yolo7_decode")
     return dec, y
+
+
+def ssd_decode(loc: torch.Tensor, conf: torch.Tensor, priors: torch.Tensor, variances=(0.1, 0.2)):
+    """loc (B, A, 4), conf (B, A, nc+1) fp32 (the SSD model's outputs), priors (A, 4) -> (boxes (B, A, 4) clipped corners,
+    prob (B, A, nc+1) softmax), on device (cvx_ssd_decode, include/cvx_engine.h)."""
+    lib = L.load()
+    _need_gpu(loc, "loc")
+    loc, conf, priors = loc.contiguous().float(), conf.contiguous().float(), priors.contiguous().float()
+    B, A, _ = loc.shape
+    boxes, prob = torch.empty_like(loc), torch.empty_like(conf)
+    L.check(lib.cvx_ssd_decode(L.ptr(loc), L.ptr(conf), L.ptr(priors), B, A, conf.shape[2], float(variances[0]), float(variances[1]), L.ptr(boxes),
+                               L.ptr(prob), L.stream_ptr(loc.device)), "cvx_ssd_decode")
+    return boxes, prob
 
 
 _cn_ws = {}

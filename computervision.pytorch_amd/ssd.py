@@ -1,0 +1,311 @@
+"""SSD300 (VGG16-BN) on the MI355X engine -- INFERENCE path.
+
+Mirrors ``core/models/ssd_model.py:6-191`` of the reference as an engine graph:
+
+* VGG16 with BatchNorm: ``Conv2d(bias=True) + BatchNorm2d + ReLU`` is one convolution launch -- the running statistics AND the
+  convolution's own bias folded into the epilogue (``CVX_OPF_CONV_BIAS``); the 2x2 pools (the third with ``ceil_mode``), the
+  3x3 / stride-1 pool5, the dilated conv6 (rate 6, a tap table of the generic kernel) and conv7 (bias + ReLU epilogues);
+* ``L2Normalize`` on conv4_3 (one wave per pixel); ``ExtraLayer``: eight convolutions with bias and, as in the reference's
+  ``forward`` (ssd_model.py:90-110), NO activation between them;
+* the six (loc, conf) 3x3 heads write fp32 rows (B, 1940, [loc 24 | conf 128]); ``forward`` returns the reference's tensors
+  (B, 8732, 4) and (B, 8732, 21) -- flattened in NCHW order per level, as the reference does (no permute, :177-183).
+
+``state_dict``: the reference's 136 keys / shapes / order, bit-identical to ``SSD(cfg)`` under the same global seed (torch's
+default initialisation in the reference's construction order: loc_i / conf_i alternately).  Training (MultiBoxLossV2) is not built.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, List
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .engine import Engine
+from .graph import Graph, TensorSlot
+
+VGG_PARAMS = (64, 64, "M", 128, 128, "M", 256, 256, 256, "C", 512, 512, 512, "M", 512, 512, 512)
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+ASPECT_RATIOS = ([1, 2, 0.5], [1, 2, 0.5, 3, 1.0 / 3], [1, 2, 0.5, 3, 1.0 / 3], [1, 2, 0.5, 3, 1.0 / 3], [1, 2, 0.5], [1, 2, 0.5])
+FEATURE_CHANNELS = (512, 1024, 512, 256, 256, 256)
+BOXES_PER_PIXEL = tuple(len(a) + 1 for a in ASPECT_RATIOS)
+EXTRAS = (("conv1", 256, 1024, 1, 1, 0), ("conv2", 512, 256, 3, 2, 1), ("conv3", 128, 512, 1, 1, 0), ("conv4", 256, 128, 3, 2, 1),
+          ("conv5", 128, 256, 1, 1, 0), ("conv6", 256, 128, 3, 1, 0), ("conv7", 128, 256, 1, 1, 0), ("conv8", 256, 128, 3, 1, 0))
+LOC_COLS = 24                                    # widest loc head (6 boxes x 4); the conf heads start at this column
+
+
+def vgg_plan():
+    """backbone.layers as data (ssd_model.py:9-38): (index, 'conv', cout, cin, k, pad, dil, bn_index | None) or (index, 'M' | 'C' | 'P5')."""
+    plan, idx, cin = [], 0, 3
+    for v in VGG_PARAMS:
+        if v in ("M", "C"):
+            plan.append((idx, v))
+            idx += 1
+        else:
+            plan.append((idx, "conv", v, cin, 3, 1, 1, idx + 1))
+            idx += 3
+            cin = v
+    plan += [(idx, "P5"), (idx + 1, "conv", 1024, cin, 3, 6, 6, None), (idx + 3, "conv", 1024, 1024, 1, 0, 1, None)]
+    return plan
+
+
+class SsdLayout:
+    """Arena offsets for every tensor of the reference's SSD ``state_dict`` (same keys, shapes, order)."""
+
+    def __init__(self, nc: int = 20):
+        self.nc = nc
+        self.conf_cols = max((n * (nc + 1) + 7) & ~7 for n in BOXES_PER_PIXEL)
+        self.pred_ld = LOC_COLS + self.conf_cols
+        self.slots: "OrderedDict[str, TensorSlot]" = OrderedDict()
+        self.nbt_keys: List[str] = []
+        self.convs: Dict[str, dict] = {}
+        self.construction: List[str] = []
+        self._p = self._s = 0
+        for item in vgg_plan():
+            if item[1] != "conv":
+                continue
+            idx, _, cout, cin, k, pad, dil, bn = item
+            spec = self.conv(f"backbone.layers.{idx}", cout, cin, k, pad=pad, dil=dil)
+            if bn is not None:
+                self.bn(f"backbone.layers.{bn}", cout, spec)
+        self.l2_off = self._take("param", 512)
+        self.slots["l2_norm.weight"] = TensorSlot("param", self.l2_off, (512,), (1,))
+        for name, cout, cin, k, s, p in EXTRAS:
+            self.conv(f"extras.{name}", cout, cin, k, stride=s, pad=p)
+        heads = [(f"locs.{i}", n * 4, c) for i, (c, n) in enumerate(zip(FEATURE_CHANNELS, BOXES_PER_PIXEL))]
+        heads += [(f"confs.{i}", n * (nc + 1), c) for i, (c, n) in enumerate(zip(FEATURE_CHANNELS, BOXES_PER_PIXEL))]
+        for key, cout, cin in heads:                              # state_dict order: every loc head, then every conf head
+            self.conv(key, cout, cin, 3, pad=1, construct=False)
+        for i in range(6):                                        # construction order: loc_i, conf_i alternately (:131-162)
+            self.construction += [f"locs.{i}", f"confs.{i}"]
+        self.n_params = (self._p + 3) & ~3
+        self.n_stats = (self._s + 3) & ~3
+
+    def _take(self, arena, n):
+        if arena == "param":
+            off, self._p = self._p, (self._p + n + 3) & ~3
+        else:
+            off, self._s = self._s, (self._s + n + 3) & ~3
+        return off
+
+    def conv(self, key, cout, cin, k, stride=1, pad=0, dil=1, construct=True):
+        ce = (cout + 7) & ~7
+        spec = dict(cout=cout, cout_eng=ce, cin=cin, k=k, stride=stride, pad=pad, dil=dil, w_off=self._take("param", ce * k * k * cin),
+                    bias_off=self._take("param", ce))
+        self.slots[key + ".weight"] = TensorSlot("param", spec["w_off"], (cout, cin, k, k), (k * k * cin, 1, k * cin, cin))
+        self.slots[key + ".bias"] = TensorSlot("param", spec["bias_off"], (cout,), (1,))
+        self.convs[key] = spec
+        if construct:
+            self.construction.append(key)
+        return spec
+
+    def bn(self, key, c, spec):
+        spec.update(gamma_off=self._take("param", c), beta_off=self._take("param", c), rmean_off=self._take("stat", c),
+                    rvar_off=self._take("stat", c))
+        self.slots[key + ".weight"] = TensorSlot("param", spec["gamma_off"], (c,), (1,))
+        self.slots[key + ".bias"] = TensorSlot("param", spec["beta_off"], (c,), (1,))
+        self.slots[key + ".running_mean"] = TensorSlot("stat", spec["rmean_off"], (c,), (1,), False)
+        self.slots[key + ".running_var"] = TensorSlot("stat", spec["rvar_off"], (c,), (1,), False)
+        self.slots[key + ".num_batches_tracked"] = TensorSlot("nbt", len(self.nbt_keys), (), (), False)
+        self.nbt_keys.append(key + ".num_batches_tracked")
+
+
+def conv_out(n, k, stride, pad, dil=1):
+    return (n + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+def build_ssd_graph(lay: SsdLayout, H: int, W: int) -> Graph:
+    if (H, W) != (300, 300):
+        raise ValueError("the SSD graph is built for 300 x 300 inputs (the reference's ExtraLayer type '300')")
+    g = Graph()
+
+    def buf(h, w, ch, kind=L.BUF_ACT_F16):
+        g.bufs.append((h, w, ch, kind))
+        return len(g.bufs) - 1
+
+    def V(b, off, ch, pix=0):
+        return (b, off, ch, pix)
+
+    def conv(key, vin, vout, hin, win, act, flags=0):
+        s = lay.convs[key]
+        ho, wo = conv_out(hin, s["k"], s["stride"], s["pad"], s["dil"]), conv_out(win, s["k"], s["stride"], s["pad"], s["dil"])
+        op = dict(type=L.OP_CONV, name=key, out=vout, ih=hin, iw=win, oh=ho, ow=wo, k=s["k"], stride=s["stride"], pad=s["pad"], dil=s["dil"], act=act,
+                  needs_dgrad=0, w_cin=s["cin"], w_off=s["w_off"], gamma_off=s.get("gamma_off", 0), beta_off=s.get("beta_off", 0),
+                  bias_off=s["bias_off"], rmean_off=s.get("rmean_off", 0), rvar_off=s.get("rvar_off", 0), flags=flags)
+        op["in"] = vin
+        g.ops.append(op)
+        return ho, wo
+
+    def simple(kind, name, vin, vout, ih, iw, oh, ow, **kw):
+        op = dict(type=kind, name=name, out=vout, ih=ih, iw=iw, oh=oh, ow=ow, **kw)
+        op["in"] = vin
+        g.ops.append(op)
+
+    img = buf(H, W, 8)
+    g.image_buf = img
+    cur, h, w, c = V(img, 0, 8), H, W, 8
+    sources = []
+    for item in vgg_plan():
+        kind = item[1]
+        if kind in ("M", "C"):
+            oh, ow = ((h + 1) // 2, (w + 1) // 2) if kind == "C" else (h // 2, w // 2)
+            nxt = V(buf(oh, ow, c), 0, c)
+            simple(L.OP_MAXPOOL2, f"backbone.layers.{item[0]}", cur, nxt, h, w, oh, ow)
+            cur, h, w = nxt, oh, ow
+        elif kind == "P5":
+            nxt = V(buf(h, w, c), 0, c)
+            simple(L.OP_MAXPOOL3S1, f"backbone.layers.{item[0]}", cur, nxt, h, w, h, w)
+            cur = nxt
+        else:
+            idx, _, cout, cin, k, pad, dil, bn = item
+            nxt = V(buf(h, w, cout), 0, cout)
+            if bn is not None:
+                conv(f"backbone.layers.{idx}", cur, nxt, h, w, L.ACT_BN_RELU, flags=L.OPF_CONV_BIAS)
+            else:
+                conv(f"backbone.layers.{idx}", cur, nxt, h, w, L.ACT_BIAS_RELU)
+            cur, c = nxt, cout
+            if bn == 31:                                          # conv4_3 + BN + ReLU = layers[32]: the first source (ssd_model.py:52)
+                normed = V(buf(h, w, c), 0, c)
+                simple(L.OP_L2NORM, "l2_norm", cur, normed, h, w, h, w, gamma_off=lay.l2_off)
+                sources.append((normed, h, w, c))
+    sources.append((cur, h, w, c))
+    e, eh, ew = cur, h, w
+    for j, (name, cout, cin, k, s, p) in enumerate(EXTRAS):       # no activation between the extra convolutions (ssd_model.py:90-110)
+        oh, ow = conv_out(eh, k, s, p), conv_out(ew, k, s, p)
+        nxt = V(buf(oh, ow, cout), 0, cout)
+        conv(f"extras.{name}", e, nxt, eh, ew, L.ACT_BIAS_LINEAR)
+        e, eh, ew = nxt, oh, ow
+        if j % 2 == 1:
+            sources.append((e, eh, ew, cout))
+    g.level_hw = [(hh, ww) for _, hh, ww, _ in sources]
+    g.anchors = sum(a * b for a, b in g.level_hw)
+    pred = buf(g.anchors, 1, lay.pred_ld, L.BUF_PRED_F32)
+    g.pred_buf = pred
+    a_off = 0
+    for i, (src, hh, ww, _) in enumerate(sources):
+        conv(f"locs.{i}", src, V(pred, 0, lay.convs[f"locs.{i}"]["cout_eng"], a_off), hh, ww, L.ACT_BIAS)
+        conv(f"confs.{i}", src, V(pred, LOC_COLS, lay.convs[f"confs.{i}"]["cout_eng"], a_off), hh, ww, L.ACT_BIAS)
+        a_off += hh * ww
+    return g
+
+
+class _Holder(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise L.CvxError("parameter holder: the engine executes the whole graph (call the SSD model)")
+
+
+class SSD300VGG(nn.Module):
+    """``SSD(cfg)`` of the reference (ssd_model.py:131-191) on the engine: ``model.eval(); model(x)`` returns
+    (loc (B, 8732, 4), conf (B, 8732, nc + 1)) fp32."""
+
+    def __init__(self, num_classes: int = 20):
+        super().__init__()
+        self.layout = lay = SsdLayout(num_classes)
+        self.num_classes = num_classes
+        self._flat = {"param": torch.zeros(lay.n_params), "stat": torch.zeros(lay.n_stats), "nbt": torch.zeros(len(lay.nbt_keys), dtype=torch.long)}
+        self._engines: Dict = {}
+        self._build_tree()
+        self._attach_views()
+        self._init_like_reference()
+        self.last_rows = None
+
+    def _build_tree(self):
+        for key in self.layout.slots:
+            mod = self
+            for name in key.split(".")[:-1]:
+                if name not in mod._modules:
+                    mod.add_module(name, _Holder())
+                mod = mod._modules[name]
+
+    def _attach_views(self):
+        for key, sl in self.layout.slots.items():
+            mod = self
+            parts = key.split(".")
+            for name in parts[:-1]:
+                mod = mod._modules[name]
+            if sl.arena == "nbt":
+                mod._buffers[parts[-1]] = self._flat["nbt"][sl.offset]
+                continue
+            view = torch.as_strided(self._flat[sl.arena], sl.shape, sl.strides, sl.offset)
+            if sl.trainable:
+                mod._parameters[parts[-1]] = nn.Parameter(view, requires_grad=False)
+            else:
+                mod._buffers[parts[-1]] = view
+
+    def _apply(self, fn, recurse=True):
+        for k in ("param", "stat", "nbt"):
+            t_ = fn(self._flat[k])
+            if k != "nbt" and t_.dtype != torch.float32:
+                raise L.CvxError("the engine keeps fp32 master parameters; half()/bfloat16() are not supported (compute is fp16 inside)")
+            self._flat[k] = t_.long().contiguous() if k == "nbt" else t_.contiguous()
+        self._attach_views()
+        self._engines.clear()
+        return self
+
+    def _init_like_reference(self):
+        lay = self.layout
+        sd = dict(self.named_parameters())
+        sd.update(dict(self.named_buffers()))
+        with torch.no_grad():
+            for key in lay.construction:
+                sl = lay.slots[key + ".weight"]
+                w = torch.empty(sl.shape)
+                nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+                sd[key + ".weight"].copy_(w)
+                bb = torch.empty(lay.slots[key + ".bias"].shape)
+                bound = 1.0 / math.sqrt(sl.shape[1] * sl.shape[2] * sl.shape[3])
+                nn.init.uniform_(bb, -bound, bound)
+                sd[key + ".bias"].copy_(bb)
+            for key, sl in lay.slots.items():
+                stem, leaf = key.rsplit(".", 1)
+                if (stem + ".running_mean") in lay.slots:
+                    if leaf in ("weight", "running_var"):
+                        sd[key].fill_(1.0)
+                    elif leaf in ("bias", "running_mean"):
+                        sd[key].zero_()
+            sd["l2_norm.weight"].fill_(20.0)
+            self._flat["nbt"].zero_()
+
+    def engine_for(self, h: int, w: int) -> Engine:
+        dev = self._flat["param"].device
+        key = (h, w, dev)
+        eng = self._engines.get(key)
+        if eng is None:
+            if dev.type != "cuda":
+                raise L.CvxError("SSD300VGG runs on an MI355X only: move the model with .to('cuda') first (there is no CPU fallback)")
+            eng = Engine(build_ssd_graph(self.layout, h, w), dev)
+            eng.set_bn(BN_EPS, BN_MOMENTUM)
+            self._engines[key] = eng
+        eng.bind(self._flat["param"], None, self._flat["stat"])
+        return eng
+
+    def forward_rows(self, x: torch.Tensor) -> torch.Tensor:
+        if self.training:
+            raise L.CvxError("SSD on the MI355X engine is inference-only this round: call model.eval() first")
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError("expected images of shape (B, 3, 300, 300)")
+        eng = self.engine_for(int(x.shape[2]), int(x.shape[3]))
+        self._last_engine = eng
+        return eng.forward(x, False)
+
+    def forward(self, x: torch.Tensor):
+        rows = self.forward_rows(x)
+        self.last_rows = rows
+        B = int(x.shape[0])
+        lay, lib, g = self.layout, L.load(), self._last_engine.graph
+        nc1 = self.num_classes + 1
+        tot = sum(hh * ww * n for (hh, ww), n in zip(g.level_hw, BOXES_PER_PIXEL))
+        loc = torch.empty(B, tot * 4, dtype=torch.float32, device=x.device)
+        conf = torch.empty(B, tot * nc1, dtype=torch.float32, device=x.device)
+        a_off = lo = co = 0
+        st = L.stream_ptr(x.device)
+        for (hh, ww), n in zip(g.level_hw, BOXES_PER_PIXEL):     # NCHW-order flattening per level, levels concatenated (ssd_model.py:177-183)
+            L.check(lib.cvx_pred_cols_to_nchw(L.ptr(rows), lay.pred_ld, 0, n * 4, B, g.anchors, a_off, hh * ww, L.ptr(loc), tot * 4, lo, st), "loc")
+            L.check(lib.cvx_pred_cols_to_nchw(L.ptr(rows), lay.pred_ld, LOC_COLS, n * nc1, B, g.anchors, a_off, hh * ww, L.ptr(conf), tot * nc1, co, st),
+                    "conf")
+            a_off += hh * ww
+            lo += hh * ww * n * 4
+            co += hh * ww * n * nc1
+        return loc.view(B, tot, 4), conf.view(B, tot, nc1)

@@ -1,0 +1,152 @@
+"""SSD algorithm wrapper -- the duck-typed interface of the reference's ``Ssd`` (core/algorithms/ssd.py:27-535) for the INFERENCE
+path: ``__init__(cfg, device)`` (prior boxes included), ``build_model() -> (nn.Module, name)``,
+``decode_boxes(preds, h, w, conf_threshold=None)``, ``predict``.  Network, softmax + box decode and the per-class NMS run on the
+MI355X engine (``computervision.pytorch_amd.ssd``, ``cvx_ssd_decode``, ``cvx_nms_variant``); ``build_loss`` (MultiBoxLossV2) raises.
+"""
+import numpy as np
+import torch
+
+from computervision.pytorch_amd import _lib as L
+from computervision.pytorch_amd import engine as _engine
+from computervision.pytorch_amd.ssd import SSD300VGG
+from configs import SsdConfig
+from registry import model_registry
+
+MAX_DET = 1024          # rows per image and class cvx_nms_variant returns
+
+
+@model_registry("ssd")
+class Ssd:
+    def __init__(self, cfg: SsdConfig, device):
+        self.cfg, self.device = cfg, device
+        self.input_image_size = cfg.arch.input_size[1:]
+        self.anchor_sizes, self.feature_shapes, self.aspect_ratios = cfg.arch.anchor_sizes, cfg.arch.feature_shapes, cfg.arch.aspect_ratios
+        self.anchors = self._get_ssd_anchors()
+        self.num_anchors = self.anchors.shape[0]
+        self.num_classes = cfg.dataset.num_classes
+        self.neg_pos_ratio = cfg.loss.neg_pos
+        self.variance = np.repeat(np.array(cfg.loss.variance, dtype=np.float32), 2, axis=0)
+        self.overlap_threshold = cfg.loss.overlap_threshold
+        self.conf_threshold = cfg.decode.confidence_threshold
+        self.nms_threshold = cfg.decode.nms_threshold
+        self.letterbox_image = cfg.decode.letterbox_image
+        self._priors_dev = None
+
+    def _get_ssd_anchors(self):
+        """Prior boxes (reference :482-535): per feature map a grid of centres, per centre one box per aspect ratio plus the
+        sqrt(min * max) square; corners normalised and clipped to [0, 1]; float32 (8732, 4)."""
+        image_h, image_w = self.input_image_size
+        out = []
+        for i, fh in enumerate(self.feature_shapes):
+            mn, mx = self.anchor_sizes[i], self.anchor_sizes[i + 1]
+            ws, hs = [], []
+            for ar in self.aspect_ratios[i]:
+                if ar == 1:
+                    ws += [mn, np.sqrt(mn * mx)]
+                    hs += [mn, np.sqrt(mn * mx)]
+                else:
+                    ws.append(mn * np.sqrt(ar))
+                    hs.append(mn / np.sqrt(ar))
+            half_w, half_h = np.array(ws) / 2.0, np.array(hs) / 2.0
+            step = [image_h / fh, image_w / fh]
+            gx, gy = np.meshgrid(np.linspace(0.5 * step[1], image_w - 0.5 * step[1], fh), np.linspace(0.5 * step[0], image_h - 0.5 * step[0], fh))
+            a = np.tile(np.concatenate((gx.reshape(-1, 1), gy.reshape(-1, 1)), 1), (1, (len(self.aspect_ratios[i]) + 1) * 2))
+            a[:, ::4] -= half_w
+            a[:, 1::4] -= half_h
+            a[:, 2::4] += half_w
+            a[:, 3::4] += half_h
+            a[:, ::2] /= image_w
+            a[:, 1::2] /= image_h
+            out.append(np.clip(a, 0.0, 1.0).reshape(-1, 4))
+        return np.concatenate(out, 0).astype(np.float32)
+
+    def build_model(self):
+        if self.cfg.arch.backbone != "vgg" or self.input_image_size[0] != 300:
+            raise L.CvxError("the MI355X engine builds SSD300 with the VGG16-BN backbone (the reference's configuration)")
+        if self.cfg.train.pretrained:
+            raise L.CvxError("train.pretrained needs a torchvision download; load a checkpoint with load_state_dict instead")
+        return SSD300VGG(self.num_classes), f"SSD{self.input_image_size[0]}_vgg"
+
+    def build_loss(self):
+        raise L.CvxError("SSD training (MultiBoxLossV2, core/loss/multi_box_loss.py) is not built on the MI355X engine yet: inference only")
+
+    # ---- decode ---------------------------------------------------------------------------------------
+    def decode_device(self, preds, conf_threshold=None):
+        """(loc, conf) on the device -> per image ((n, 6) tensor [x1, y1, x2, y2, label, conf], (n, 2) kept (prior, class column)):
+        classes ascending, scores descending inside a class, like the reference's loop (reference :246-274)."""
+        conf_thr = self.conf_threshold if conf_threshold is None else conf_threshold
+        loc, conf = preds
+        dev = loc.device
+        if self._priors_dev is None or self._priors_dev.device != dev:
+            self._priors_dev = torch.from_numpy(self.anchors).to(dev)
+        boxes, prob = _engine.ssd_decode(loc, conf, self._priors_dev, self.variance[::2].tolist())
+        B, A, _ = boxes.shape
+        bt = boxes.transpose(1, 2).contiguous()                                  # (B, 4, A): corner boxes, channel-major for cvx_nms
+        per_img = [([], []) for _ in range(B)]
+        for c in range(1, self.num_classes + 1):
+            if not bool((prob[:, :, c] > conf_thr).any()):
+                continue
+            y = torch.cat((bt, prob[:, :, c].unsqueeze(1)), 1)
+            rows, index, counts = _engine.nms(y, float(conf_thr), self.nms_threshold, max_det=MAX_DET, variant="vanilla", boxes_xyxy=True)
+            for b in range(B):
+                n = int(counts[b])
+                if n < 0 or n >= MAX_DET:
+                    raise L.CvxError(f"more than {MAX_DET} detections of one class in one image: raise decode.confidence_threshold")
+                if n == 0:
+                    continue
+                idx = index[b, :n].long()
+                per_img[b][0].append(torch.cat((rows[b, :n, :4], torch.full((n, 1), float(c - 1), device=dev), rows[b, :n, 4:5]), 1))
+                per_img[b][1].append(torch.stack((idx, torch.full_like(idx, c)), 1))
+        return [(torch.cat(r), torch.cat(p)) if r else (torch.zeros(0, 6, device=dev), torch.zeros(0, 2, dtype=torch.long, device=dev))
+                for r, p in per_img]
+
+    def decode_boxes(self, preds, h, w, conf_threshold=None):
+        results = []
+        for det, _ in self.decode_device(preds, conf_threshold):
+            o = det.cpu().numpy()
+            if len(o):
+                xy, wh = (o[:, 0:2] + o[:, 2:4]) / 2, o[:, 2:4] - o[:, 0:2]
+                o[:, :4] = self._correct_boxes(xy, wh, self.input_image_size, [h, w])
+            results.append(o if len(o) else [])
+        return results
+
+    def _correct_boxes(self, box_xy, box_wh, input_shape, image_shape):
+        """yolo_correct_boxes (core/utils/image_process.py:161-181)."""
+        xywh = np.concatenate([box_xy, box_wh], axis=-1)
+        if self.letterbox_image:
+            ih, iw = image_shape
+            h, w = input_shape
+            scale = max(ih / h, iw / w)
+            top, left = (h - ih / scale) // 2, (w - iw / scale) // 2
+            cx, cy, bw, bh = xywh[:, 0] * w - left, xywh[:, 1] * h - top, xywh[:, 2] * w, xywh[:, 3] * h
+            return np.stack([(cx - bw / 2) * scale, (cy - bh / 2) * scale, (cx + bw / 2) * scale, (cy + bh / 2) * scale], -1)
+        out = np.stack([xywh[:, 0] - xywh[:, 2] / 2, xywh[:, 1] - xywh[:, 3] / 2, xywh[:, 0] + xywh[:, 2] / 2, xywh[:, 1] + xywh[:, 3] / 2], -1)
+        out[:, ::2] *= image_shape[1]
+        out[:, 1::2] *= image_shape[0]
+        return out
+
+    def predict_tensor(self, model, images: torch.Tensor, h, w, conf_threshold=None):
+        model.eval()
+        with torch.no_grad():
+            return self.decode_boxes(model(images), h, w, conf_threshold)
+
+    def predict(self, model, image_path, print_on, save_result):
+        """Reference :69-100: read + letterbox to 300 x 300, forward, decode, draw.  Image I/O needs OpenCV (lazy import)."""
+        import cv2
+        img = cv2.cvtColor(cv2.imread(image_path), cv2.COLOR_BGR2RGB)
+        h, w = img.shape[:2]
+        H, W = self.input_image_size
+        if self.letterbox_image:
+            s = min(H / h, W / w)
+            nh, nw = int(h * s), int(w * s)
+            canvas = np.full((H, W, 3), 128, dtype=np.uint8)
+            canvas[(H - nh) // 2:(H - nh) // 2 + nh, (W - nw) // 2:(W - nw) // 2 + nw] = cv2.resize(img, (nw, nh))
+        else:
+            canvas = cv2.resize(img, (W, H))
+        x = torch.from_numpy(canvas.astype(np.float32) / 255.0).permute(2, 0, 1).unsqueeze(0).to(self.device)
+        results = self.predict_tensor(model, x, h, w)
+        out = cv2.cvtColor(img, cv2.COLOR_RGB2BGR)
+        for x1, y1, x2, y2, cls, sc in (results[0] if len(results[0]) else []):
+            cv2.rectangle(out, (int(x1), int(y1)), (int(x2), int(y2)), (0, 255, 0), 2)
+            cv2.putText(out, f"{int(cls)}:{sc:.2f}", (int(x1), max(int(y1) - 3, 0)), cv2.FONT_HERSHEY_SIMPLEX, 0.5, (0, 255, 0), 1)
+        return out

@@ -3,3 +3,4 @@ from .yolo8_train import Yolo8Trainer  # noqa: F401
 from .centernet_train import CenterNetTrainer  # noqa: F401
 from .segmentation_trainer import DeeplabV3PlusTrainer  # noqa: F401
 from .yolo7_train import Yolo7Trainer  # noqa: F401
+from .ssd_train import SsdTrainer  # noqa: F401

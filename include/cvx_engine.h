@@ -45,13 +45,19 @@ enum { CVX_OP_CONV = 1, CVX_OP_MAXPOOL5 = 2, CVX_OP_UPSAMPLE2 = 3,
        /* inference-only ops (DeepLabv3+ / ResNet, core/models/deeplabv3plus.py, core/models/resnet.py): */
        CVX_OP_MAXPOOL3S2 = 7, /* 3x3 stride-2 pad-1 max pool (resnet.py:163) */
        CVX_OP_AVGPOOL = 8,    /* global average pool -> (B, 1, 1, C) (ASPPPooling, deeplabv3plus.py:30) */
-       CVX_OP_RESIZE = 9 };   /* bilinear resize (ih, iw) -> (oh, ow), align_corners = False (deeplabv3plus.py:38,117-122) */
+       CVX_OP_RESIZE = 9,     /* bilinear resize (ih, iw) -> (oh, ow), align_corners = False (deeplabv3plus.py:38,117-122) */
+       /* inference-only ops (SSD / VGG, core/models/ssd_model.py): */
+       CVX_OP_MAXPOOL3S1 = 10, /* 3x3 stride-1 pad-1 max pool (VGG pool5, :30) */
+       CVX_OP_L2NORM = 11 };   /* x / (||x||_2 over channels + 1e-10) * weight[c] (L2Normalize, :113-128); gamma_off -> weight (C floats) */
+/* CVX_OP_MAXPOOL2 also serves ceil_mode = True (:18): oh = ceil(ih / 2), windows clipped at the border. */
 enum { CVX_ACT_BN_SILU = 1, CVX_ACT_BIAS = 2,
        /* inference-only epilogues (folded BatchNorm): */
        CVX_ACT_BN_RELU = 3,   /* Conv + BN + ReLU */
        CVX_ACT_BN_LINEAR = 4, /* Conv + BN (Tree.project) */
-       CVX_ACT_BIAS_RELU = 5 }; /* Conv + bias + ReLU, fp16 output (head 3x3, :314-318) */
+       CVX_ACT_BIAS_RELU = 5,   /* Conv + bias + ReLU, fp16 output (head 3x3, :314-318) */
+       CVX_ACT_BIAS_LINEAR = 6 }; /* Conv + bias, fp16 output, no activation (SSD ExtraLayer, ssd_model.py:90-110) */
 #define CVX_OPF_RES_PRE_ACT 1 /* cvx_op_desc.flags: the residual is added before the activation (BasicBlock, :20-27) */
+#define CVX_OPF_CONV_BIAS 2   /* a BN_* conv that also has a bias of its own at bias_off (VGG-BN: Conv2d(bias=True) + BatchNorm) */
 
 typedef struct {
   int32_t type;
@@ -211,6 +217,16 @@ int cvx_decode(const float* pred, int32_t batch, int32_t anchors, int32_t nc, co
  * class columns padded to the next multiple of 8; the padding is never read. */
 int cvx_decode_strided(const float* pred, int32_t pred_ld, int32_t batch, int32_t anchors, int32_t nc, const int32_t* level_hw,
                        const float* strides, int32_t n_levels, float* y, void* hip_stream);
+/* SSD decode: loc (batch, A, 4) regressions and conf (batch, A, nc+1) logits in the reference's output format, priors (A, 4)
+ * corner boxes -> boxes (batch, A, 4) clipped corners, prob (batch, A, nc+1) softmax.
+ * Replaces: torch.softmax + Ssd._parse_mbox_loc, core/algorithms/ssd.py:246-247,285-325. */
+int cvx_ssd_decode(const float* loc, const float* conf, const float* priors, int32_t batch, int32_t anchors, int32_t num_classes_plus_bg,
+                   float variance_xy, float variance_wh, float* boxes, float* prob, void* hip_stream);
+/* Column range [col0, col0 + c) of fp32 rows (batch, anchors, ld), pixels a_off .. a_off + h*w, as an NCHW block written at
+ * out[b * out_bstride + out_off + ch * h*w + pix]: SSD flattens its head maps in NCHW order and concatenates the levels
+ * (core/models/ssd_model.py:177-183).  Asynchronous on hip_stream. */
+int cvx_pred_cols_to_nchw(const float* rows, int32_t ld, int32_t col0, int32_t c, int32_t batch, int32_t anchors, int32_t a_off, int32_t hw,
+                          float* out, int64_t out_bstride, int64_t out_off, void* hip_stream);
 /* YOLOv7 anchor decode.  pred: fp32 rows (batch, sum_l h_l*w_l, pred_ld) as the engine's YOLOv7 graph writes them (one row per
  * pixel, levels in the order of the network's outputs, columns a*(5+nc)+k for anchor a); anchors_wh: n_levels x 3 x (w, h) in
  * input pixels, already selected through anchors_mask.  dec: (batch, 3*sum, 5+nc) = the reference's `decoded_outputs`
@@ -224,6 +240,7 @@ enum { CVX_NMS_TV0141_CUDA = 0, /* torchvision 0.14.1's own switch for CUDA tens
        CVX_NMS_TV0141_CPU = 1,  /* ... for CPU tensors: up to 1000 candidates */
        CVX_NMS_OFFSET = 2,      /* _batched_nms_coordinate_trick: boxes + cls*(max+1), one class-agnostic pass */
        CVX_NMS_VANILLA = 3 };   /* _batched_nms_vanilla: per-class passes on the unshifted boxes */
+#define CVX_NMS_BOXES_XYXY 0x100 /* OR-ed into `variant`: rows 0..3 of y are corner boxes already (no cx,cy,w,h conversion) */
 int64_t cvx_nms_workspace_bytes(int32_t batch, int32_t anchors);
 int cvx_nms(const float* y, int32_t batch, int32_t anchors, int32_t nc, float conf_thres, float iou_thres, int32_t max_det,
             float* out_rows, int32_t* out_index, int32_t* counts, void* workspace, int64_t workspace_bytes, void* hip_stream);

@@ -478,6 +478,75 @@ def main():
     report["yolov7"] = dict(init="bit-exact, %d tensors" % len(ref_sd), params=int(sum(p_.numel() for p_ in ymodel.parameters())),
                             detections=n_det, out_absmax=[float(o_.abs().max()) for o_ in ref7])
 
+    # ---- 12. SSD300 VGG16-BN: init, priors, eval forward on a calibrated network, decode ----------------------
+    from oracle import ssd_ref as SS
+    scfg, salgo_cls, _ = builder.export_from_registry("ssd")
+    torch.manual_seed(0)
+    salgo = salgo_cls(scfg, torch.device("cpu"))
+    smodel, sname = salgo.build_model()
+    ref_sd = smodel.state_dict()
+    ncs = scfg.dataset.num_classes
+    my_sd = SS.init_state_dict(ncs, seed=0)
+    assert list(ref_sd.keys()) == list(my_sd.keys())
+    for k in ref_sd:
+        assert ref_sd[k].shape == my_sd[k].shape and torch.equal(ref_sd[k], my_sd[k]), f"SSD init mismatch {k}"
+    ssums = {k: [float(v.double().sum()), float(v.double().abs().sum())] for k, v in ref_sd.items() if not k.endswith("num_batches_tracked")}
+    with open(os.path.join(GOLD, "ssd_seed0_init_sums.json"), "w") as f:
+        json.dump(ssums, f)
+    assert np.array_equal(SS.priors((300, 300)), salgo.anchors)
+    g = torch.Generator().manual_seed(71)
+    xcal = torch.rand(2, 3, 300, 300, generator=g)
+    xs_u8 = (torch.rand(2, 3, 300, 300, generator=g) * 255).round().to(torch.uint8)   # stored as bytes: x = u8 / 255
+    xs_ = xs_u8.float() / 255.0
+    for m_ in smodel.modules():
+        if isinstance(m_, torch.nn.BatchNorm2d):
+            m_.momentum = 1.0
+    smodel.train()
+    with torch.no_grad():
+        smodel(xcal)
+    smodel.eval()
+    with torch.no_grad():
+        rloc, rconf = smodel(xs_.clone())
+    cals = {k: v.clone() for k, v in smodel.state_dict().items()}
+    with torch.no_grad():
+        mloc, mconf = SS.forward(cals, xs_.clone(), ncs)
+    assert torch.allclose(rloc, mloc, rtol=1e-4, atol=1e-5) and torch.allclose(rconf, mconf, rtol=1e-4, atol=1e-5)
+    # decode on synthetic head outputs with real peaks (a random-init network's class scores never pass the 0.7 threshold);
+    # the reference's decode_boxes runs with torchvision's nms replaced by the oracle's greedy restatement, no letterbox
+    gs = torch.Generator().manual_seed(72)
+    sloc = torch.randn(2, 8732, 4, generator=gs)
+    sconf = torch.randn(2, 8732, ncs + 1, generator=gs)
+    hot = torch.randint(0, 8732, (2, 400), generator=gs)
+    hotc = torch.randint(1, ncs + 1, (2, 400), generator=gs)
+    for b_ in range(2):
+        sconf[b_, hot[b_], hotc[b_]] += 7.0 + torch.rand(400, generator=gs) * 3
+    sloc, sconf = sloc.half().float(), sconf.half().float()      # stored as fp16: the synthetic inputs ARE the rounded values
+    import core.algorithms.ssd as ref_ssdmod
+
+    def _tv_nms_s(boxes, scores, iou_threshold):
+        o_ = np.argsort(-scores.numpy(), kind="stable")
+        return torch.from_numpy(o_[_nr._greedy(boxes.numpy()[o_], None, iou_threshold)].copy())
+
+    ref_ssdmod.nms = _tv_nms_s
+    salgo.letterbox_image = False
+    ref_dec = salgo.decode_boxes((sloc.clone(), sconf.clone()), 1, 1)
+    my_dec = SS.decode(sloc, sconf, SS.priors((300, 300)), ncs, scfg.decode.confidence_threshold, scfg.decode.nms_threshold)
+    boxes0 = SS.parse_loc(sloc[0], SS.priors((300, 300)))
+    assert torch.equal(boxes0, salgo._parse_mbox_loc(sloc[0]))
+    nds = []
+    for r_, (m_rows, _p) in zip(ref_dec, my_dec):
+        r_ = np.asarray(r_, dtype=np.float32).reshape(-1, 6)
+        assert r_.shape == m_rows.shape and np.allclose(r_, m_rows, rtol=1e-5, atol=1e-6), (r_.shape, m_rows.shape)
+        nds.append(int(r_.shape[0]))
+    assert min(nds) > 50, nds
+    stats_s = {k: v.numpy().copy() for k, v in cals.items() if k.endswith("running_mean") or k.endswith("running_var")}
+    np.savez_compressed(os.path.join(GOLD, "ssd_fwd_300.npz"), x_u8=xs_u8.numpy(), loc=rloc.numpy().copy(), conf_sub=rconf.flatten()[::5].numpy().copy(),
+                        conf_norm=np.array(float(rconf.norm())), sloc=sloc.half().numpy(), sconf=sconf.half().numpy(), conf_thr=np.array(scfg.decode.confidence_threshold),
+                        nms_thr=np.array(scfg.decode.nms_threshold), rows0=my_dec[0][0], rows1=my_dec[1][0], pairs0=my_dec[0][1], pairs1=my_dec[1][1],
+                        stat_keys=np.array(list(stats_s.keys())), stat_vals=np.concatenate([v.ravel() for v in stats_s.values()]))
+    report["ssd"] = dict(init="bit-exact, %d tensors" % len(ref_sd), params=int(sum(p_.numel() for p_ in smodel.parameters())), name=sname,
+                         detections=nds, out_absmax=[float(rloc.abs().max()), float(rconf.abs().max())])
+
     # ---- 6. NMS tail fixture (oracle-generated; upstream parity unpinned) ----------------------
     pred = synth.nms_pred(7)
     res = nms_ref.non_max_suppression(pred, 0.25, 0.7, 300)

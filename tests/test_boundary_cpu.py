@@ -46,9 +46,16 @@ def test_export_from_registry_contract():
     assert algo.__name__ == "YOLOv8" and trainer.__name__ == "Yolo8Trainer"
     with pytest.raises(ValueError):
         builder.export_from_registry("resnet")                               # not in check.MODELS
-    with pytest.raises(KeyError):
-        builder.export_from_registry("ssd")                                  # whitelisted, path not built yet
     assert check.MODELS == ["yolo7", "yolo8_det", "ssd", "centernet", "deeplabv3plus"]
+    for name in check.MODELS:                                               # every whitelisted model resolves
+        c, a, t = builder.export_from_registry(name)
+        assert isinstance(a, type) and isinstance(t, type)
+    check.MODELS.append("whitelisted_but_unregistered")                     # builder.py:19-24: known name, no registry entry -> KeyError
+    try:
+        with pytest.raises(KeyError):
+            builder.export_from_registry("whitelisted_but_unregistered")
+    finally:
+        check.MODELS.pop()
 
 
 def test_config_fields_match_reference_defaults():
@@ -168,3 +175,17 @@ def test_deeplab_plugin_surface_cpu():
     assert cm[0] == (0, 0, 0) and cm[1] == (128, 0, 0) and cm[15] == (192, 128, 128) and cm[20] == (0, 64, 128) and len(cm) == 21
     with pytest.raises(L.CvxError):
         model.eval()(torch.zeros(1, 3, 65, 65))
+
+
+def test_ssd_plugin_surface_cpu(gold_dir=os.path.join(os.path.dirname(__file__), "golden")):
+    """ssd resolves through the registry; 136 state_dict entries / 26.29 M parameters; the prior boxes are the
+    reference's (8732 x 4, checked against the oracle, itself asserted equal to the reference's in make_golden.py); no CPU path."""
+    from oracle import ssd_ref as SS
+    cfg, algo_cls, _ = builder.export_from_registry("ssd")
+    algo = algo_cls(cfg, torch.device("cpu"))
+    assert algo.anchors.shape == (8732, 4) and algo.anchors.dtype.name == "float32"
+    assert (algo.anchors == SS.priors((300, 300))).all()
+    model, name = algo.build_model()
+    assert name == "SSD300_vgg" and len(model.state_dict()) == 136 and sum(p.numel() for p in model.parameters()) == 26293934
+    with pytest.raises(L.CvxError):
+        model.eval()(torch.zeros(1, 3, 300, 300))

@@ -1243,3 +1243,76 @@ def test_yolov7_full_size_through_the_plugin_api(dev):
         algo.build_loss()
     with pytest.raises(LL.CvxError):
         trainer_cls(cfg, dev).train()
+
+
+# ---- SSD300 VGG16-BN, inference + decode -----------------------------------------------------------------
+def _ssd(dev, g=None):
+    from computervision.pytorch_amd.ssd import SSD300VGG
+    torch.manual_seed(0)
+    m = SSD300VGG(20)
+    if g is not None:
+        sd = m.state_dict()
+        keys, vals, off = [str(k) for k in g["stat_keys"]], g["stat_vals"], 0
+        with torch.no_grad():
+            for k in keys:
+                n = sd[k].numel()
+                sd[k].copy_(torch.from_numpy(vals[off:off + n].copy()))
+                off += n
+    return m.to(dev).eval()
+
+
+def test_ssd_state_dict_is_the_references(dev):
+    from oracle import ssd_ref as SS
+    m = _ssd(dev)
+    ref = SS.init_state_dict(20, seed=0)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(ref.keys()) and len(sd) == 136
+    for k, v in ref.items():
+        assert sd[k].shape == v.shape and torch.equal(sd[k].cpu(), v), k
+
+
+def test_ssd_forward_and_decode_match_the_reference_fixture(dev, gold):
+    """Eval forward of the calibrated VGG16-BN SSD (conv bias folded with the BatchNorm, ceil-mode pool, dilated conv6,
+    L2Normalize, activation-free extras, NCHW-order flattening) against the REAL reference's (loc, conf); then softmax + prior
+    decode + per-class NMS on the reference's synthetic head tensors: boxes 1e-6 (expf), kept (prior, class) pairs and their
+    order identical."""
+    import builder
+    from oracle import ssd_ref as SS
+    g = gold("ssd_fwd_300.npz")
+    m = _ssd(dev, g)
+    x = (torch.from_numpy(g["x_u8"]).float() / 255.0).to(dev)
+    loc, conf = m(x)
+    assert tuple(loc.shape) == (2, 8732, 4) and tuple(conf.shape) == (2, 8732, 21)
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    SS.FP16_STORAGE[0] = True
+    try:
+        with torch.no_grad():
+            eloc, econf = SS.forward(sd, x.cpu(), 20)
+    finally:
+        SS.FP16_STORAGE[0] = False
+    rloc = torch.from_numpy(g["loc"])
+    e_ref = (rel(loc.cpu(), rloc), rel(conf.flatten()[::5].cpu(), torch.from_numpy(g["conf_sub"])))
+    emu_ref = (rel(eloc, rloc), rel(econf.flatten()[::5], torch.from_numpy(g["conf_sub"])))
+    print("ssd (loc, conf): engine vs reference", " ".join(f"{e:.3e}" for e in e_ref), "| fp16 emulation vs reference", " ".join(f"{e:.3e}" for e in emu_ref),
+          "| engine vs emulation", f"{rel(loc.cpu(), eloc):.3e} {rel(conf.cpu(), econf):.3e}")
+    assert all(e_ref[i] < max(1.5 * emu_ref[i], 2e-3) for i in range(2))
+    cfg, algo_cls, _ = builder.export_from_registry("ssd")
+    algo = algo_cls(cfg, dev)
+    sloc, sconf = torch.from_numpy(g["sloc"]).float().to(dev), torch.from_numpy(g["sconf"]).float().to(dev)
+    from computervision.pytorch_amd import engine as E
+    boxes, prob = E.ssd_decode(sloc, sconf, torch.from_numpy(algo.anchors).to(dev))
+    np.testing.assert_allclose(boxes.cpu().numpy(), torch.stack([SS.parse_loc(sloc[b].cpu(), algo.anchors) for b in range(2)]).numpy(), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(prob.cpu().numpy(), torch.softmax(sconf.cpu(), -1).numpy(), rtol=2e-6, atol=1e-9)
+    got = algo.decode_device((sloc, sconf))
+    for b in range(2):
+        rows, pairs = got[b]
+        # the class loop of the oracle on the device's own boxes / scores (expf differs from torch's in the last bit): identical
+        want_rows, want_pairs = SS.nms_per_class(boxes[b].cpu(), prob[b].cpu(), 20, float(g["conf_thr"]), float(g["nms_thr"]))
+        assert np.array_equal(pairs.cpu().numpy(), want_pairs), b
+        np.testing.assert_allclose(rows.cpu().numpy(), want_rows, rtol=1e-6, atol=1e-7)
+        # ... and against what the reference produced from torch's softmax: the same detections but for score ties at 1 ulp
+        ref_pairs = set(map(tuple, g[f"pairs{b}"].tolist()))
+        assert len(ref_pairs & set(map(tuple, want_pairs.tolist()))) >= 0.99 * len(ref_pairs) and abs(len(want_pairs) - len(ref_pairs)) <= 4
+    res = algo.decode_boxes((sloc, sconf), 240, 320)
+    assert len(res) == 2 and res[0].shape[1] == 6 and np.isfinite(res[0]).all()
+    assert algo.decode_boxes((loc, conf), 240, 320) == [[], []]              # the random-init network passes nothing at 0.7

@@ -285,3 +285,38 @@ def test_yolov7_oracle_init_forward_decode_nms(gold):
         common = len(set(keep.tolist()) & set(g[f"keep{b}"].tolist()))
         assert common >= 0.98 * len(g[f"keep{b}"]) and abs(len(keep) - len(g[f"keep{b}"])) <= 0.02 * len(keep)
         assert rows.shape[1] == 7 and np.all(np.diff(rows[:, 6]) >= 0)
+
+
+def _ssd_fixture_state(g):
+    from oracle import ssd_ref as SS
+    sd = SS.init_state_dict(20, seed=0)
+    keys, vals, off = [str(k) for k in g["stat_keys"]], g["stat_vals"], 0
+    for k in keys:
+        n = sd[k].numel()
+        sd[k] = torch.from_numpy(vals[off:off + n].copy())
+        off += n
+    assert off == len(vals)
+    return sd
+
+
+def test_ssd_oracle_init_forward_decode(gold):
+    """oracle/ssd_ref.py against what the real reference produced (oracle/make_golden.py section 12)."""
+    from oracle import ssd_ref as SS
+    sd0 = SS.init_state_dict(20, seed=0)
+    sums = json.load(open(os.path.join(GOLD, "ssd_seed0_init_sums.json")))
+    assert len(sd0) == 136 and [k for k in sd0 if not k.endswith("num_batches_tracked")] == list(sums.keys())
+    for k, (s_, a_) in sums.items():
+        v = sd0[k].double()
+        np.testing.assert_allclose([float(v.sum()), float(v.abs().sum())], [s_, a_], rtol=1e-12, atol=1e-12, err_msg=k)
+    g = gold("ssd_fwd_300.npz")
+    sd = _ssd_fixture_state(g)
+    x = torch.from_numpy(g["x_u8"]).float() / 255.0
+    with torch.no_grad():
+        loc, conf = SS.forward(sd, x, 20)
+    np.testing.assert_allclose(loc.numpy(), g["loc"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(conf.flatten()[::5].numpy(), g["conf_sub"], rtol=1e-4, atol=1e-5)
+    res = SS.decode(torch.from_numpy(g["sloc"]).float(), torch.from_numpy(g["sconf"]).float(), SS.priors((300, 300)), 20, float(g["conf_thr"]),
+                    float(g["nms_thr"]))
+    for b in range(2):
+        np.testing.assert_allclose(res[b][0], g[f"rows{b}"], rtol=1e-6, atol=1e-7)
+        assert np.array_equal(res[b][1], g[f"pairs{b}"])
