@@ -99,6 +99,10 @@ PROTOTYPES = {
     "cvx_maxpool5_nhwc": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _P, _P]),
     "cvx_maxpool5_bwd_nhwc": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _P, _I32, _P]),
     "cvx_resize_bilinear_rows_to_nchw": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),
+    "cvx_maxpool_nhwc": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),
+    "cvx_avgpool_global_nhwc": (_I32, [_P, _I32, _I32, _I32, _P, _P]),
+    "cvx_resize_bilinear_nhwc": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),
+    "cvx_l2norm_nhwc": (_I32, [_P, _P, _I32, _I32, _I32, _P, _P]),
     "cvx_upsample2_nhwc": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _P]),
     "cvx_upsample2_bwd_nhwc": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _I32, _P]),
     "cvx_stem_train_nchw": (_I32, [_P, _I32, _I32, _I32, _P, _I32, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),

@@ -83,6 +83,42 @@ extern "C" int cvx_pred_cols_to_nchw(const float* rows, int32_t ld, int32_t col0
   CVX_CHECK(rows && out && batch > 0 && c > 0 && col0 >= 0 && col0 + c <= ld && a_off >= 0 && a_off + hw <= anchors, "bad arguments");
   return cvx_pred_cols_to_nchw_launch(rows, ld, col0, c, batch, anchors, a_off, hw, out, out_bstride, out_off, (hipStream_t)hip_stream);
 }
+// ---- the inference-only pooling / resampling / normalisation ops of the DLA, ResNet / DeepLab and VGG / SSD graphs, one by one ----
+extern "C" int cvx_maxpool_nhwc(const void* x_f16, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t kernel, int32_t stride,
+                                int32_t ceil_mode, void* out_f16, void* hip_stream) {
+  CVX_CHECK(x_f16 && out_f16 && batch > 0 && c % 8 == 0, "bad arguments (channels in multiples of 8)");
+  hipStream_t st = (hipStream_t)hip_stream;
+  if (kernel == 2 && stride == 2) {
+    const int oh = ceil_mode ? (h + 1) / 2 : h / 2, ow = ceil_mode ? (w + 1) / 2 : w / 2;
+    CVX_TRY(cvx_maxpool2(dense(x_f16, h * w, c), dense(out_f16, oh * ow, c), batch, h, w, oh, ow, c, st));
+  } else if (kernel == 3 && (stride == 1 || stride == 2) && !ceil_mode) {
+    const int oh = (h - 1) / stride + 1, ow = (w - 1) / stride + 1;
+    CVX_TRY(cvx_maxpool3(dense(x_f16, h * w, c), dense(out_f16, oh * ow, c), batch, h, w, c, stride, st));
+  } else {
+    CVX_CHECK(false, "max pools built: 2x2 / stride 2 (floor or ceil mode), 3x3 / pad 1 / stride 1 or 2");
+  }
+  CVX_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+extern "C" int cvx_avgpool_global_nhwc(const void* x_f16, int32_t batch, int32_t hw, int32_t c, void* out_f16, void* hip_stream) {
+  CVX_CHECK(x_f16 && out_f16 && batch > 0 && c % 8 == 0, "bad arguments (channels in multiples of 8)");
+  CVX_TRY(cvx_avgpool_global(dense(x_f16, hw, c), dense(out_f16, 1, c), batch, hw, c, (hipStream_t)hip_stream));
+  CVX_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
+  return 0;
+}
+extern "C" int cvx_resize_bilinear_nhwc(const void* x_f16, int32_t batch, int32_t ih, int32_t iw, int32_t c, int32_t oh, int32_t ow,
+                                        void* out_f16, void* hip_stream) {
+  CVX_CHECK(x_f16 && out_f16 && batch > 0 && c % 8 == 0, "bad arguments (channels in multiples of 8)");
+  CVX_TRY(cvx_resize_bilinear(dense(x_f16, ih * iw, c), dense(out_f16, oh * ow, c), batch, ih, iw, oh, ow, c, (hipStream_t)hip_stream));
+  CVX_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
+  return 0;
+}
+extern "C" int cvx_l2norm_nhwc(const void* x_f16, const float* weight, int32_t batch, int32_t hw, int32_t c, void* out_f16, void* hip_stream) {
+  CVX_CHECK(x_f16 && weight && out_f16 && batch > 0 && c % 8 == 0, "bad arguments (channels in multiples of 8)");
+  CVX_TRY(cvx_l2norm(dense(x_f16, hw, c), dense(out_f16, hw, c), weight, batch, hw, c, (hipStream_t)hip_stream));
+  CVX_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
+  return 0;
+}
 extern "C" int cvx_upsample2_nhwc(const void* x_f16, int32_t batch, int32_t h, int32_t w, int32_t c, void* out_f16, void* hip_stream) {
   CVX_CHECK(x_f16 && out_f16 && batch > 0 && c % 8 == 0, "bad arguments (channels in multiples of 8)");
   CVX_TRY(cvx_upsample2_fwd(dense(x_f16, h * w, c), dense(out_f16, 4 * h * w, c), batch, h, w, c, (hipStream_t)hip_stream));

@@ -300,6 +300,19 @@ int cvx_bn_silu_bwd_nhwc(const void* xhat_f16, const void* gout_f16, int32_t bat
 int cvx_maxpool5_nhwc(const void* x_f16, int32_t batch, int32_t h, int32_t w, int32_t c, void* out_f16, uint8_t* argmax, void* hip_stream);
 int cvx_maxpool5_bwd_nhwc(const void* gout_f16, const uint8_t* argmax, int32_t batch, int32_t h, int32_t w, int32_t c, void* gin_f16,
                           int32_t accumulate, void* hip_stream);
+/* The inference-only pooling / resampling / normalisation kernels of the DLA, ResNet + DeepLab and VGG + SSD graphs on dense NHWC fp16
+ * tensors (unit parity tests, host code that wants one op); they synchronise before returning.
+ *   cvx_maxpool_nhwc: kernel 2 / stride 2 (ceil_mode 0 | 1: centernet_model.py:128, ssd_model.py:16-18), kernel 3 / pad 1 / stride 1 | 2
+ *     (ssd_model.py:30, resnet.py:163); output (batch, oh, ow, c) with torch's output-size rule.
+ *   cvx_avgpool_global_nhwc: (batch, hw, c) -> (batch, 1, c) mean in fp32 (deeplabv3plus.py:30).
+ *   cvx_resize_bilinear_nhwc: align_corners = False (deeplabv3plus.py:38,117-122).
+ *   cvx_l2norm_nhwc: x / (sqrt(sum_c x^2) + 1e-10) * weight[c] (ssd_model.py:113-128). */
+int cvx_maxpool_nhwc(const void* x_f16, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t kernel, int32_t stride, int32_t ceil_mode,
+                     void* out_f16, void* hip_stream);
+int cvx_avgpool_global_nhwc(const void* x_f16, int32_t batch, int32_t hw, int32_t c, void* out_f16, void* hip_stream);
+int cvx_resize_bilinear_nhwc(const void* x_f16, int32_t batch, int32_t ih, int32_t iw, int32_t c, int32_t oh, int32_t ow, void* out_f16,
+                             void* hip_stream);
+int cvx_l2norm_nhwc(const void* x_f16, const float* weight, int32_t batch, int32_t hw, int32_t c, void* out_f16, void* hip_stream);
 /* Bilinear resize (align_corners = False) of fp32 rows (batch, ih*iw, ld) -- e.g. a PRED buffer holding segmentation logits --
  * into an NCHW fp32 tensor (batch, c, oh, ow).  Asynchronous on hip_stream.
  * Replaces: F.interpolate(x, size=input_shape, mode="bilinear", align_corners=False), core/models/deeplabv3plus.py:147. */

@@ -231,6 +231,48 @@ def test_maxpool5_and_upsample2_units(dev, B, H, W, C):
     assert rel(gin2.float().permute(0, 3, 1, 2), xr2.grad + 1.0) < 5e-4
 
 
+@pytest.mark.parametrize("B,H,W,C", [(2, 75, 75, 16), (1, 38, 51, 8), (3, 7, 5, 64), (1, 1, 9, 24)])
+def test_inference_pool_resize_norm_units(dev, B, H, W, C):
+    """The pooling / resampling / normalisation kernels of the DLA, ResNet + DeepLab and VGG + SSD graphs against torch on odd
+    sizes: 2x2/2 max pool in floor and ceil mode (ssd_model.py:16-18), 3x3 pad-1 max pool at stride 1 and 2 (ssd_model.py:30,
+    resnet.py:163), global average pool, bilinear resize with align_corners=False up, down and from 1x1
+    (deeplabv3plus.py:38,117-122,147), L2Normalize (ssd_model.py:113-128).  Max pools exact; the others to one fp16 rounding."""
+    lib = L.load()
+    st = L.stream_ptr(dev)
+    g = torch.Generator().manual_seed(H * 131 + W * 7 + C)
+    x16 = torch.randn(B, C, H, W, generator=g).half()
+    xd = _nhwc(x16).to(dev)
+    xf = x16.float()
+
+    def run_pool(k, s, ceil, ref):
+        out = torch.empty(B, ref.shape[2], ref.shape[3], C, dtype=torch.float16, device=dev)
+        L.check(lib.cvx_maxpool_nhwc(L.ptr(xd), B, H, W, C, k, s, ceil, L.ptr(out), st), f"maxpool {k}/{s}/{ceil}")
+        assert torch.equal(out.float().permute(0, 3, 1, 2).cpu(), ref), (k, s, ceil)
+
+    if H >= 2 and W >= 2:
+        run_pool(2, 2, 0, F.max_pool2d(xf, 2, 2))
+    run_pool(2, 2, 1, F.max_pool2d(xf, 2, 2, ceil_mode=True))
+    run_pool(3, 1, 0, F.max_pool2d(xf, 3, 1, 1))
+    run_pool(3, 2, 0, F.max_pool2d(xf, 3, 2, 1))
+    avg = torch.empty(B, 1, 1, C, dtype=torch.float16, device=dev)
+    L.check(lib.cvx_avgpool_global_nhwc(L.ptr(xd), B, H * W, C, L.ptr(avg), st), "avgpool")
+    assert rel(avg.float().permute(0, 3, 1, 2).cpu(), F.adaptive_avg_pool2d(xf, 1)) < 1e-3
+    for (oh, ow) in ((2 * H + 1, 3 * W), (max(H // 2, 1), max(W // 3, 1)), (H, W), (4 * H - 3, 4 * W - 3)):
+        out = torch.empty(B, oh, ow, C, dtype=torch.float16, device=dev)
+        L.check(lib.cvx_resize_bilinear_nhwc(L.ptr(xd), B, H, W, C, oh, ow, L.ptr(out), st), "resize")
+        ref = F.interpolate(xf, size=(oh, ow), mode="bilinear", align_corners=False)
+        assert (out.float().permute(0, 3, 1, 2).cpu() - ref).abs().max() < 4e-3, (oh, ow)        # one fp16 rounding of values up to ~4
+    one = _nhwc(x16[:, :, :1, :1]).to(dev)
+    out = torch.empty(B, 5, 6, C, dtype=torch.float16, device=dev)
+    L.check(lib.cvx_resize_bilinear_nhwc(L.ptr(one), B, 1, 1, C, 5, 6, L.ptr(out), st), "broadcast")
+    assert torch.equal(out.cpu(), _nhwc(x16[:, :, :1, :1]).expand(B, 5, 6, C))
+    wgt = (torch.rand(C, generator=g) * 30 + 1).to(dev)
+    out = torch.empty_like(xd)
+    L.check(lib.cvx_l2norm_nhwc(L.ptr(xd), L.ptr(wgt), B, H * W, C, L.ptr(out), st), "l2norm")
+    ref = wgt.cpu().view(1, C, 1, 1) * (xf / (xf.pow(2).sum(1, keepdim=True).sqrt() + 1e-10))
+    assert rel(out.float().permute(0, 3, 1, 2).cpu(), ref) < 5e-4
+
+
 @pytest.mark.parametrize("B,H,W,Co", [(2, 64, 64, 16), (1, 32, 96, 32), (3, 16, 16, 48), (1, 128, 128, 80)])
 def test_fp32_stem_unit(dev, B, H, W, Co):
     """stem.hip (model.0 = Conv(3, c, 3, 2), yolo_v8.py:28) against torch fp32: train pass (batch statistics, running
