@@ -43,7 +43,7 @@ ACT_BN_SILU, ACT_BIAS, ACT_BN_RELU, ACT_BN_LINEAR, ACT_BIAS_RELU, ACT_BIAS_LINEA
 OPF_RES_PRE_ACT = 1
 OPF_CONV_BIAS = 2
 
-_P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+_P, _I32, _I64, _F, _U64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
 
 # name -> (restype, argtypes); every symbol include/cvx_engine.h declares
 PROTOTYPES = {
@@ -96,6 +96,13 @@ PROTOTYPES = {
     "cvx_conv2d_wgrad_nhwc": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _I64, _P]),
     "cvx_bn_silu_train_nhwc": (_I32, [_P, _I32, _I32, _I32, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
     "cvx_bn_silu_bwd_nhwc": (_I32, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _F, _P, _P, _P, _P, _I32, _P]),
+    "cvx_maxpool3_train_nhwc": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
+    "cvx_maxpool3_bwd_nhwc": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P]),
+    "cvx_avgpool_global_bwd_nhwc": (_I32, [_P, _I32, _I32, _I32, _P, _I32, _P]),
+    "cvx_resize_bilinear_bwd_nhwc": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P]),
+    "cvx_dropout_nhwc": (_I32, [_P, _I32, _I32, _I32, _F, _U64, _P, _I32, _P]),
+    "cvx_bn_act_train_nhwc": (_I32, [_P, _I32, _I32, _I32, _P, _P, _F, _F, _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P]),
+    "cvx_bn_act_bwd_nhwc": (_I32, [_P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _I32, _I32, _F, _P, _P, _P, _P, _I32, _P]),
     "cvx_maxpool5_nhwc": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _P, _P]),
     "cvx_maxpool5_bwd_nhwc": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _P, _I32, _P]),
     "cvx_resize_bilinear_rows_to_nchw": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),

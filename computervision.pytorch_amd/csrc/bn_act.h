@@ -1,7 +1,7 @@
 // BatchNorm + SiLU streaming passes (see bn_act.hip).
 #pragma once
 #include "cvx_common.h"
-#define CVX_BN_MAX_C 1024    // widest BatchNorm the streaming passes hold coefficients for (YOLOv8-m: 576, -x: 640)
+#define CVX_BN_MAX_C 2048    // widest BatchNorm the streaming passes hold coefficients for (one channel group of 8 per thread: ResNet-101 layer4)
 // Replica slabs the reduction kernels scatter their atomics over, by channel count.  Every consumer block folds all R
 // replicas of all C channels first, so R * C is held at ~512: 16 replicas up to 32 channels, 2 from 256 channels on (the
 // fold used to be 131 KB per block at 256 channels -- more than the block's share of the tensor on the 20x20 layers).
@@ -53,12 +53,22 @@ int cvx_bn_fold(int n, const float* gamma, const float* beta, const float* rmean
 // silu(gamma*xhat+beta) (+res) into the `out` view
 int cvx_bn_silu_apply(const float* y, long long M, int C, int hw, const BnTrainArgs& a, const ViewDesc& out, const ViewDesc& res,
                       half_t* xhat, hipStream_t st);
+// ... with the activation kind (0 SiLU, 1 ReLU, 2 none) and the position of the residual (res_pre: inside the activation,
+// ResNet's relu(bn(conv) + identity); else added to the activation's output, YOLO's x + cv2(cv1(x)))
+int cvx_bn_act_apply(const float* y, long long M, int C, int hw, const BnTrainArgs& a, const ViewDesc& out, const ViewDesc& res, int act,
+                     int res_pre, half_t* xhat, hipStream_t st);
+struct BnActKind {
+  int act, res_pre;
+  ViewDesc fout;  // ReLU: the layer's forward output (its sign is the backward mask)
+};
 // part (zero on entry) receives per-channel (sum y, sum y^2) of an fp32 [M][C] tensor -- the conv epilogues' job in the engine
 int cvx_bn_stats_f32(const float* y, long long M, int C, long long* part, hipStream_t st);
 // part: replica slabs [R][C][2] fixed-point values, zero on entry; receives (sum dz, sum dz*xhat)
-int cvx_bn_bwd_reduce(const half_t* xhat, long long M, int C, int hw, const BnCoef& k, const ViewDesc& gout, long long* part, hipStream_t st);
+int cvx_bn_bwd_reduce(const half_t* xhat, long long M, int C, int hw, const BnCoef& k, const ViewDesc& gout, const BnActKind& ak, long long* part,
+                      hipStream_t st);
+// gres receives the incoming gradient (res_pre: the pre-activation gradient dz), accumulated when res_accumulate
 int cvx_bn_bwd_apply(const half_t* xhat, long long M, int C, int hw, const BnCoef& k, const long long* part, float inv_scale, float* dgamma,
-                     float* dbeta, const ViewDesc& gout, half_t* dy, const ViewDesc& gres, int res_accumulate, hipStream_t st);
+                     float* dbeta, const ViewDesc& gout, const BnActKind& ak, half_t* dy, const ViewDesc& gres, int res_accumulate, hipStream_t st);
 // part: replica slabs [R][C][2], zero on entry
 // ... of several tensors that are views of one allocation, in two launches: descs / blocks live in device memory
 struct ColsumDesc {

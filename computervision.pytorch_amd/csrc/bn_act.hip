@@ -62,8 +62,18 @@ struct f8 {
 };
 __device__ __forceinline__ f8 load_f8(const float* p) { return f8{*reinterpret_cast<const f4*>(p), *reinterpret_cast<const f4*>(p + 4)}; }
 
-__global__ __launch_bounds__(256) void bn_silu_apply_kernel(const float* y, long long M, int C, int hw, BnTrainArgs a, ViewDesc out,
-                                                            ViewDesc res, half_t* xhat, int rows_per_block) {
+// activation kinds of the training passes (cvx_op_desc.act -> kind): 0 SiLU, 1 ReLU, 2 none
+template <int ACT>
+__device__ __forceinline__ float act_fwd(float z) {
+  if constexpr (ACT == 0) return cvx_silu(z);
+  if constexpr (ACT == 1) return fmaxf(z, 0.f);
+  return z;
+}
+
+// RES_PRE: the residual joins the pre-activation (ResNet Bottleneck: relu(bn(conv) + identity)), else it is added to the output
+template <int ACT, bool RES_PRE>
+__global__ __launch_bounds__(256) void bn_act_apply_kernel(const float* y, long long M, int C, int hw, BnTrainArgs a, ViewDesc out,
+                                                           ViewDesc res, half_t* xhat, int rows_per_block) {
   extern __shared__ __attribute__((aligned(16))) long long ws[];  // fold workspace | mean, invstd (2*C floats)
   float* s_mu = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + fold_ws_bytes(C));
   float* s_is = s_mu + C;
@@ -105,10 +115,13 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const float* y, long
     for (int i = 0; i < 8; ++i) {
       const float x = (v[i] - mu[i]) * is[i];
       xh[i] = (half_t)x;
-      f[i] = cvx_silu(x * ga[i] + be[i]);
+      if constexpr (RES_PRE)
+        f[i] = act_fwd<ACT>(x * ga[i] + be[i] + (float)rr[i]);
+      else
+        f[i] = act_fwd<ACT>(x * ga[i] + be[i]);
     }
     *reinterpret_cast<h8*>(xhat + m * C + cg * 8) = xh;
-    if (res.p) {
+    if (!RES_PRE && res.p) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) f[i] += (float)rr[i];
     }
@@ -121,7 +134,7 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const float* y, long
   long long m = m0 + r;
   for (; m + (long long)(UNR - 1) * RP < m1; m += (long long)UNR * RP) {
     f8 v[UNR];
-    h8 rr[UNR];
+    h8 rr[UNR] = {};
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       v[u] = load_f8(y + (m + u * RP) * C + cg * 8);
@@ -142,8 +155,19 @@ struct Coef8 {
   float a[8], b[8];
 };
 
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const half_t* xhat, long long M, int C, int hw, BnCoef k, ViewDesc gout, long long* part,
-                                                            int rows_per_block) {
+// dz = g * act'(pre).  SiLU: pre = gamma * xhat + beta is recomputed from the kept xhat.  ReLU: the mask is the sign of the
+// layer's own fp16 forward OUTPUT (`fout`): recomputing the pre-activation from the rounded xhat would flip the mask of
+// ~2e-4 of the elements (|pre| below the fp16 rounding of xhat), a 1 % gradient error per layer.  fout = relu(pre (+res)).
+template <int ACT>
+__device__ __forceinline__ float act_dz(float g, float xh, float ga, float be, float fo) {
+  if constexpr (ACT == 0) return g * cvx_silu_grad(xh * ga + be);
+  if constexpr (ACT == 1) return fo > 0.f ? g : 0.f;
+  return g;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const half_t* xhat, long long M, int C, int hw, BnCoef k, ViewDesc gout, ViewDesc fout,
+                                                            long long* part, int rows_per_block) {
   __shared__ float sacc[256 * 16];
   const int CG = C >> 3;
   const int RP = 256 / CG;
@@ -161,38 +185,43 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const half_t* xhat, 
     }
     const long long m0 = (long long)blockIdx.x * rows_per_block;
     const long long m1 = min(M, m0 + rows_per_block);
-    auto one = [&](const h8& v, const h8& g) {
+    auto one = [&](const h8& v, const h8& g, const h8& fo) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         float xh = (float)v[i];
-        float dz = (float)g[i] * cvx_silu_grad(xh * s.a[i] + s.b[i]);
+        float dz = act_dz<ACT>((float)g[i], xh, s.a[i], s.b[i], (float)fo[i]);
         acc[0][i] += dz;
         acc[1][i] += dz * xh;
       }
     };
     long long m = m0 + r;
     for (; m + (long long)(UNR - 1) * RP < m1; m += (long long)UNR * RP) {
-      h8 v[UNR], g[UNR];
+      h8 v[UNR], g[UNR], fo[UNR] = {};
 #pragma unroll
       for (int q = 0; q < UNR; ++q) {
         v[q] = *reinterpret_cast<const h8*>(xhat + (m + q * RP) * C + cg * 8);
         g[q] = *reinterpret_cast<const h8*>(gout.p + view_off(gout, m + q * RP, hw) + cg * 8);
+        if constexpr (ACT == 1) fo[q] = *reinterpret_cast<const h8*>(fout.p + view_off(fout, m + q * RP, hw) + cg * 8);
       }
 #pragma unroll
-      for (int q = 0; q < UNR; ++q) one(v[q], g[q]);
+      for (int q = 0; q < UNR; ++q) one(v[q], g[q], fo[q]);
     }
     for (; m < m1; m += RP) {
       h8 v = *reinterpret_cast<const h8*>(xhat + m * C + cg * 8);
       h8 g = *reinterpret_cast<const h8*>(gout.p + view_off(gout, m, hw) + cg * 8);
-      one(v, g);
+      h8 fo = {};
+      if constexpr (ACT == 1) fo = *reinterpret_cast<const h8*>(fout.p + view_off(fout, m, hw) + cg * 8);
+      one(v, g, fo);
     }
   }
   block_channel_sums<2>(acc, C, CG, cg, active, sacc, part, blockIdx.x);
 }
 
+// RES_PRE: the residual branch receives dz (the gradient of the shared pre-activation), else the incoming gradient g
+template <int ACT, bool RES_PRE>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const half_t* xhat, long long M, int C, int hw, BnCoef k, const long long* part,
-                                                           float inv_scale, float* dgamma, float* dbeta, ViewDesc gout, half_t* dy, ViewDesc gres,
-                                                           int res_accumulate, int rows_per_block) {
+                                                           float inv_scale, float* dgamma, float* dbeta, ViewDesc gout, ViewDesc fout, half_t* dy,
+                                                           ViewDesc gres, int res_accumulate, int rows_per_block) {
   extern __shared__ __attribute__((aligned(16))) long long ws[];
   fold_replicas(part, C, ws);
   const double* s0 = reinterpret_cast<const double*>(ws);
@@ -220,13 +249,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const half_t* xhat, l
   }
   const long long m0 = (long long)blockIdx.x * rows_per_block;
   const long long m1 = min(M, m0 + rows_per_block);
-  auto one = [&](long long m, const h8& v, h8 g, const h8& old) {
+  auto one = [&](long long m, const h8& v, h8 g, const h8& old, const h8& fo) {
     h8 o;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       float xh = (float)v[i];
-      float dz = (float)g[i] * cvx_silu_grad(xh * s.a[i] + s.b[i]);
+      float dz = act_dz<ACT>((float)g[i], xh, s.a[i], s.b[i], (float)fo[i]);
       o[i] = (half_t)(gi[i] * (dz - k1[i] - xh * k2[i]));
+      if constexpr (RES_PRE) g[i] = (half_t)dz;
     }
     *reinterpret_cast<h8*>(dy + m * C + cg * 8) = o;
     if (gres.p) {
@@ -240,22 +270,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const half_t* xhat, l
   const bool rd_old = gres.p && res_accumulate;
   long long m = m0 + r;
   for (; m + (long long)(UNR - 1) * RP < m1; m += (long long)UNR * RP) {
-    h8 v[UNR], g[UNR], old[UNR];
+    h8 v[UNR], g[UNR], old[UNR] = {}, fo[UNR] = {};
 #pragma unroll
     for (int q = 0; q < UNR; ++q) {
       v[q] = *reinterpret_cast<const h8*>(xhat + (m + q * RP) * C + cg * 8);
       g[q] = *reinterpret_cast<const h8*>(gout.p + view_off(gout, m + q * RP, hw) + cg * 8);
       if (rd_old) old[q] = *reinterpret_cast<const h8*>(gres.p + view_off(gres, m + q * RP, hw) + cg * 8);
+      if constexpr (ACT == 1) fo[q] = *reinterpret_cast<const h8*>(fout.p + view_off(fout, m + q * RP, hw) + cg * 8);
     }
 #pragma unroll
-    for (int q = 0; q < UNR; ++q) one(m + q * RP, v[q], g[q], old[q]);
+    for (int q = 0; q < UNR; ++q) one(m + q * RP, v[q], g[q], old[q], fo[q]);
   }
   for (; m < m1; m += RP) {
     h8 v = *reinterpret_cast<const h8*>(xhat + m * C + cg * 8);
     h8 g = *reinterpret_cast<const h8*>(gout.p + view_off(gout, m, hw) + cg * 8);
-    h8 old = {};
+    h8 old = {}, fo = {};
     if (rd_old) old = *reinterpret_cast<const h8*>(gres.p + view_off(gres, m, hw) + cg * 8);
-    one(m, v, g, old);
+    if constexpr (ACT == 1) fo = *reinterpret_cast<const h8*>(fout.p + view_off(fout, m, hw) + cg * 8);
+    one(m, v, g, old, fo);
   }
 }
 
@@ -371,7 +403,7 @@ int cvx_stream_rows_per_block(long long M, int C, int kb_per_block) {
 static int blocks_for(long long M, int rows) { return (int)((M + rows - 1) / rows); }
 
 static int check_c(int C, long long M = 0) {
-  CVX_CHECK(C % 8 == 0 && C >= 8 && C <= CVX_BN_MAX_C, "bn_act: C must be a multiple of 8 in [8, 1024]");
+  CVX_CHECK(C % 8 == 0 && C >= 8 && C <= CVX_BN_MAX_C, "bn_act: C must be a multiple of 8 in [8, 2048]");
   CVX_CHECK(M < (1LL << 32), "bn_act: more than 2^32 rows");
   return 0;
 }
@@ -388,14 +420,38 @@ int cvx_bn_fold(int n, const float* gamma, const float* beta, const float* rmean
   CVX_HIP(hipGetLastError());
   return 0;
 }
-int cvx_bn_silu_apply(const float* y, long long M, int C, int hw, const BnTrainArgs& a, const ViewDesc& out, const ViewDesc& res,
-                      half_t* xhat, hipStream_t st) {
+static int check_act(int act, int res_pre, bool has_res) {
+  CVX_CHECK(act >= 0 && act <= 2, "bn_act: activation kind must be 0 (SiLU), 1 (ReLU) or 2 (none)");
+  CVX_CHECK(!res_pre || has_res, "bn_act: res_pre without a residual");
+  CVX_CHECK(!(has_res && act == 0 && res_pre), "bn_act: SiLU with a pre-activation residual is not built");
+  CVX_CHECK(!(has_res && act == 1 && !res_pre), "bn_act: ReLU with a post-activation residual is not built (the backward mask is the output's sign)");
+  return 0;
+}
+int cvx_bn_act_apply(const float* y, long long M, int C, int hw, const BnTrainArgs& a, const ViewDesc& out, const ViewDesc& res, int act,
+                     int res_pre, half_t* xhat, hipStream_t st) {
   CVX_TRY(check_c(C, M));
+  CVX_TRY(check_act(act, res_pre, res.p != nullptr));
   int rows = cvx_stream_rows_per_block(M, C, 16);
-  hipLaunchKernelGGL(bn_silu_apply_kernel, dim3(blocks_for(M, rows)), dim3(256), fold_ws_bytes(C) + 2 * C * 4, st, y, M, C, hw, a, out, res,
-                     xhat, rows);
+  const dim3 grid(blocks_for(M, rows)), block(256);
+  const size_t lds = fold_ws_bytes(C) + 2 * C * 4;
+#define CVX_LAUNCH_APPLY(A, R) hipLaunchKernelGGL((bn_act_apply_kernel<A, R>), grid, block, lds, st, y, M, C, hw, a, out, res, xhat, rows)
+  if (act == 0)
+    CVX_LAUNCH_APPLY(0, false);
+  else if (act == 1 && res_pre)
+    CVX_LAUNCH_APPLY(1, true);
+  else if (act == 1)
+    CVX_LAUNCH_APPLY(1, false);
+  else if (res_pre)
+    CVX_LAUNCH_APPLY(2, true);
+  else
+    CVX_LAUNCH_APPLY(2, false);
+#undef CVX_LAUNCH_APPLY
   CVX_HIP(hipGetLastError());
   return 0;
+}
+int cvx_bn_silu_apply(const float* y, long long M, int C, int hw, const BnTrainArgs& a, const ViewDesc& out, const ViewDesc& res,
+                      half_t* xhat, hipStream_t st) {
+  return cvx_bn_act_apply(y, M, C, hw, a, out, res, 0, 0, xhat, st);
 }
 int cvx_bn_stats_f32(const float* y, long long M, int C, long long* part, hipStream_t st) {
   CVX_TRY(check_c(C, M));
@@ -404,19 +460,43 @@ int cvx_bn_stats_f32(const float* y, long long M, int C, long long* part, hipStr
   CVX_HIP(hipGetLastError());
   return 0;
 }
-int cvx_bn_bwd_reduce(const half_t* xhat, long long M, int C, int hw, const BnCoef& k, const ViewDesc& gout, long long* part, hipStream_t st) {
+int cvx_bn_bwd_reduce(const half_t* xhat, long long M, int C, int hw, const BnCoef& k, const ViewDesc& gout, const BnActKind& ak, long long* part,
+                      hipStream_t st) {
   CVX_TRY(check_c(C, M));
+  CVX_CHECK(ak.act >= 0 && ak.act <= 2 && (ak.act != 1 || ak.fout.p), "bn_bwd: ReLU needs the forward output view");
   int rows = cvx_stream_rows_per_block(M, C, 32);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks_for(M, rows)), dim3(256), 0, st, xhat, M, C, hw, k, gout, part, rows);
+  const dim3 grid(blocks_for(M, rows)), block(256);
+  if (ak.act == 0)
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<0>, grid, block, 0, st, xhat, M, C, hw, k, gout, ak.fout, part, rows);
+  else if (ak.act == 1)
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, block, 0, st, xhat, M, C, hw, k, gout, ak.fout, part, rows);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<2>, grid, block, 0, st, xhat, M, C, hw, k, gout, ak.fout, part, rows);
   CVX_HIP(hipGetLastError());
   return 0;
 }
 int cvx_bn_bwd_apply(const half_t* xhat, long long M, int C, int hw, const BnCoef& k, const long long* part, float inv_scale, float* dgamma,
-                     float* dbeta, const ViewDesc& gout, half_t* dy, const ViewDesc& gres, int res_accumulate, hipStream_t st) {
+                     float* dbeta, const ViewDesc& gout, const BnActKind& ak, half_t* dy, const ViewDesc& gres, int res_accumulate, hipStream_t st) {
   CVX_TRY(check_c(C, M));
+  CVX_TRY(check_act(ak.act, ak.res_pre, gres.p != nullptr));
+  CVX_CHECK(ak.act != 1 || ak.fout.p, "bn_bwd: ReLU needs the forward output view");
   int rows = cvx_stream_rows_per_block(M, C, 32);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(M, rows)), dim3(256), fold_ws_bytes(C), st, xhat, M, C, hw, k, part, inv_scale, dgamma,
-                     dbeta, gout, dy, gres, res_accumulate, rows);
+  const dim3 grid(blocks_for(M, rows)), block(256);
+  const size_t lds = fold_ws_bytes(C);
+#define CVX_LAUNCH_BWD(A, R)                                                                                                              \
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<A, R>), grid, block, lds, st, xhat, M, C, hw, k, part, inv_scale, dgamma, dbeta, gout, ak.fout, dy, gres, \
+                     res_accumulate, rows)
+  if (ak.act == 0)
+    CVX_LAUNCH_BWD(0, false);
+  else if (ak.act == 1 && ak.res_pre)
+    CVX_LAUNCH_BWD(1, true);
+  else if (ak.act == 1)
+    CVX_LAUNCH_BWD(1, false);
+  else if (ak.res_pre)
+    CVX_LAUNCH_BWD(2, true);
+  else
+    CVX_LAUNCH_BWD(2, false);
+#undef CVX_LAUNCH_BWD
   CVX_HIP(hipGetLastError());
   return 0;
 }

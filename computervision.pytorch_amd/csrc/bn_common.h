@@ -32,17 +32,17 @@ __device__ __forceinline__ void fold_replicas(const long long* part, int C, long
     atomicAdd(reinterpret_cast<unsigned long long*>(&ws[cv * 2 + 1]), (unsigned long long)q.y);
   }
   __syncthreads();
-  // convert in place: hold this thread's results in registers across the barrier (C <= 1024: at most 8 per thread)
-  double r[8];
+  // convert in place: hold this thread's results in registers across the barrier (C <= 2048: at most 16 per thread)
+  double r[16];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
+  for (int k = 0; k < 16; ++k) {
     const int cv = threadIdx.x + 256 * k;
     r[k] = cv < C * 2 ? cvx_fix_to_double(ws[cv * 2], ws[cv * 2 + 1]) : 0.0;
   }
   __syncthreads();
   double* out = reinterpret_cast<double*>(ws);
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
+  for (int k = 0; k < 16; ++k) {
     const int cv = threadIdx.x + 256 * k;
     if (cv < C * 2) out[(cv & 1) * C + (cv >> 1)] = r[k];
   }

@@ -135,6 +135,7 @@ struct cvx_engine {
   hipEvent_t ev_mid = nullptr;
   hipEvent_t ev_seg[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // segmented backward: (main, side) pairs
   int ev_seg_next = 0;
+  unsigned long long seed = 0, train_pass = 0;  // dropout: cvx_engine_set_seed, training forwards so far
   bool fwd_train_done = false;
   bool bwd_slabs_clean = false;  // the backward statistic slabs were zeroed by the training forward and not used since
   int last_batch = 0;
@@ -240,6 +241,13 @@ void wgrad_tile(int cout, int* co_b, int* j_b) {  // must mirror cvx_conv_wgrad_
   }
 }
 
+// activation kind of the BN passes / eval epilogue: 0 SiLU, 1 ReLU, 2 none
+int act_kind(const cvx_op_desc& o) { return o.act == CVX_ACT_BN_SILU ? 0 : ((o.act == CVX_ACT_BN_LINEAR || o.act == CVX_ACT_BIAS_LINEAR) ? 2 : 1); }
+float dropout_p(const cvx_op_desc& o) { return (float)o.k / 65536.f; }
+unsigned long long dropout_seed(const cvx_engine* e, int op) {
+  return e->seed * 0x9E3779B97F4A7C15ULL + (unsigned long long)e->train_pass * 1000003ULL + (unsigned long long)op;
+}
+
 int build_static(cvx_engine* e) {
   const int nops = (int)e->ops.size();
   e->conv.assign(nops, ConvRt());
@@ -250,8 +258,17 @@ int build_static(cvx_engine* e) {
   for (int i = 0; i < nops; ++i) {
     const cvx_op_desc& o = e->ops[i];
     CVX_CHECK(o.in.buf >= 0 && o.in.buf < (int)e->bufs.size() && o.out.buf >= 0 && o.out.buf < (int)e->bufs.size(), "op view buffer index");
-    CVX_CHECK(o.type >= CVX_OP_CONV && o.type <= CVX_OP_L2NORM, "unknown op type");
-    if (o.type >= CVX_OP_MAXPOOL2 || (o.type == CVX_OP_CONV && o.act >= CVX_ACT_BN_RELU)) e->inference_only = true;
+    CVX_CHECK(o.type >= CVX_OP_CONV && o.type <= CVX_OP_DROPOUT, "unknown op type");
+    // ops / epilogues without a backward pass: the DLA ops, L2Normalize, the conv + bias (+ ReLU) blocks with an fp16 output
+    if (o.type == CVX_OP_MAXPOOL2 || o.type == CVX_OP_DWCONVT || o.type == CVX_OP_COPY || o.type == CVX_OP_L2NORM ||
+        (o.type == CVX_OP_CONV && (o.act >= CVX_ACT_BIAS_RELU || (o.flags & CVX_OPF_CONV_BIAS))))
+      e->inference_only = true;
+    if (o.type == CVX_OP_CONV && o.res.buf >= 0 && o.act != CVX_ACT_BIAS) {
+      const bool pre = (o.flags & CVX_OPF_RES_PRE_ACT) != 0;
+      // the training passes hold relu(z + res) and silu(z) + res (bn_act.hip); the other two exist in the eval epilogue only
+      if ((o.act == CVX_ACT_BN_SILU && pre) || (o.act == CVX_ACT_BN_RELU && !pre)) e->inference_only = true;
+    }
+    if (o.type == CVX_OP_DROPOUT) CVX_CHECK(o.k >= 0 && o.k < 65536, "dropout: k = drop probability in units of 2^-16");
     if (o.type != CVX_OP_CONV) {
       CVX_CHECK(o.in.c % 8 == 0 && o.in.coff % 8 == 0 && o.out.coff % 8 == 0 && o.in.c == o.out.c, "pool / resample / copy views: equal, 8-aligned channel slices");
       continue;
@@ -264,9 +281,8 @@ int build_static(cvx_engine* e) {
       // Any other first layer (DLA's 7x7): inference-only, through an NHWC fp16 copy with the channels padded to 8.
       c.stem = o.w_cin == 3 && o.k == 3 && o.stride == 2 && o.pad == 1 && o.dil == 1 && o.act == CVX_ACT_BN_SILU && !o.needs_dgrad &&
                o.res.buf < 0 && o.out.c % 16 == 0 && o.out.c <= 80 && o.ih % 2 == 0 && o.iw % 2 == 0;
-      if (!c.stem) {
+      if (!c.stem) {  // any other first layer (ResNet's / DLA's 7x7): through an NHWC fp16 copy of the image, channels padded to 8
         CVX_CHECK(o.w_cin == 3 && !o.needs_dgrad, "an op that reads the image needs 3 stored input channels and no data gradient");
-        e->inference_only = true;
         e->image_nhwc = true;
       }
     }
@@ -356,6 +372,11 @@ int build_static(cvx_engine* e) {
       }
     }
   }
+  {  // a graph described without any data gradient (needs_dgrad = 0 throughout) was built for inference
+    bool any_dgrad = false;
+    for (int i = 0; i < nops; ++i) any_dgrad |= e->ops[i].type == CVX_OP_CONV && e->ops[i].needs_dgrad;
+    if (!any_dgrad && nops > 1) e->inference_only = true;
+  }
   if (e->inference_only) return 0;  // no backward pass exists for these graphs
   // ---- backward write/accumulate plan -----------------------------------------------------
   std::vector<std::vector<char>> written(e->bufs.size());
@@ -416,8 +437,8 @@ int plan_batch(cvx_engine* e, int B, bool training) {
   e->slab_tail_op = -1;
   for (size_t i = 0; i < e->ops.size(); ++i) {
     const cvx_op_desc& o = e->ops[i];
-    if (o.type == CVX_OP_MAXPOOL5) {
-      if (training) {
+    if (o.type == CVX_OP_MAXPOOL5 || o.type == CVX_OP_MAXPOOL3S2 || o.type == CVX_OP_MAXPOOL3S1) {
+      if (training) {  // argmax byte per output element: the operand of the backward gather
         CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, (long long)B * o.oh * o.ow * o.out.c));
         e->pool[i].idx = (uint8_t*)p;
       }
@@ -437,7 +458,7 @@ int plan_batch(cvx_engine* e, int B, bool training) {
                                  (o.flags & CVX_OPF_CONV_BIAS) ? (long long)o.bias_off : -1LL});
     else if (o.act == CVX_ACT_BIAS_RELU || o.act == CVX_ACT_BIAS_LINEAR)
       folds.push_back(BnFoldDesc{0, o.bias_off, 0, 0, c.scale, c.shift, C, 1, -1LL});
-    if (training && o.act == CVX_ACT_BN_SILU) {
+    if (training && (o.act == CVX_ACT_BN_SILU || o.act == CVX_ACT_BN_RELU || o.act == CVX_ACT_BN_LINEAR)) {
       CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, M * C * 2));
       c.ybuf = (half_t*)p;
       if (!c.stem) {  // the stem's dy is never materialised (cvx_stem_backward)
@@ -749,6 +770,12 @@ extern "C" int cvx_engine_set_bn(cvx_engine* e, float eps, float momentum) {
   return 0;
 }
 
+extern "C" int cvx_engine_set_seed(cvx_engine* e, uint64_t seed) {
+  CVX_CHECK(e, "null engine");
+  e->seed = seed;
+  return 0;
+}
+
 extern "C" int cvx_engine_debug_copy(cvx_engine* e, int32_t buf, int32_t which, void* dst, int64_t bytes) {
   CVX_CHECK(e && dst && buf >= 0, "bad arguments");
   if (which == 2 || which == 3) {  // per-layer operands of the backward pass: `buf` is an op index
@@ -805,6 +832,7 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
     CVX_TRY(cvx_pack_weights(e->params, e->shadow, e->d_pack, e->d_pack_blocks, e->n_pack_blocks, prep));
   }
   e->last_images = training ? images : nullptr;
+  if (training) e->train_pass++;  // dropout masks: one per (seed, training forward, op)
   if (e->image_nhwc) CVX_TRY(cvx_image_to_nhwc8(images, B, ib.d.h, ib.d.w, ib.act, st));
   const Buf& pb = e->bufs[e->pred_buf];
   const long long A = (long long)pb.d.h * pb.d.w;
@@ -863,13 +891,13 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
     if (o.type == CVX_OP_MAXPOOL3S2) {
       ProfScope ps(e, PROF_MISC, 0, 2.0 * B * (o.ih * o.iw + o.oh * o.ow) * o.in.c, st);
       CVX_CHECK(o.oh == (o.ih - 1) / 2 + 1 && o.ow == (o.iw - 1) / 2 + 1, "maxpool3s2: output size must be floor((i - 1) / 2) + 1");
-      CVX_TRY(cvx_maxpool3(make_view(e, o.in, false), make_view(e, o.out, false), B, o.ih, o.iw, o.in.c, 2, st));
+      CVX_TRY(cvx_maxpool3(make_view(e, o.in, false), make_view(e, o.out, false), B, o.ih, o.iw, o.in.c, 2, training ? e->pool[i].idx : nullptr, st));
       continue;
     }
     if (o.type == CVX_OP_MAXPOOL3S1) {
       ProfScope ps(e, PROF_MISC, 0, 4.0 * B * o.ih * o.iw * o.in.c, st);
       CVX_CHECK(o.oh == o.ih && o.ow == o.iw, "maxpool3s1: same-size output");
-      CVX_TRY(cvx_maxpool3(make_view(e, o.in, false), make_view(e, o.out, false), B, o.ih, o.iw, o.in.c, 1, st));
+      CVX_TRY(cvx_maxpool3(make_view(e, o.in, false), make_view(e, o.out, false), B, o.ih, o.iw, o.in.c, 1, training ? e->pool[i].idx : nullptr, st));
       continue;
     }
     if (o.type == CVX_OP_L2NORM) {
@@ -886,6 +914,12 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
     if (o.type == CVX_OP_RESIZE) {
       ProfScope ps(e, PROF_MISC, 0, 2.0 * B * (o.ih * o.iw + o.oh * o.ow) * o.in.c, st);
       CVX_TRY(cvx_resize_bilinear(make_view(e, o.in, false), make_view(e, o.out, false), B, o.ih, o.iw, o.oh, o.ow, o.in.c, st));
+      continue;
+    }
+    if (o.type == CVX_OP_DROPOUT) {  // eval: identity (p = 0 keeps every element at scale 1)
+      ProfScope ps(e, PROF_MISC, 0, 4.0 * B * o.ih * o.iw * o.in.c, st);
+      CVX_TRY(cvx_dropout(make_view(e, o.in, false), make_view(e, o.out, false), B, o.ih * o.iw, o.in.c, training ? dropout_p(o) : 0.f,
+                          dropout_seed(e, (int)i), 0, st));
       continue;
     }
     ConvRt& c = e->conv[i];
@@ -939,11 +973,11 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
       ProfScope ps(e, PROF_BN_FWD, 0, (resv.p ? 10.0 : 8.0) * M * C, st);
       BnTrainArgs ta{c.stat_fwd,           e->params + o.gamma_off, e->params + o.beta_off, c.mean, c.invstd, e->stats + o.rmean_off,
                      e->stats + o.rvar_off, e->bn_eps,       e->bn_momentum};
-      CVX_TRY(cvx_bn_silu_apply(ytmp, M, C, o.oh * o.ow, ta, outv, resv, c.ybuf, st));
+      CVX_TRY(cvx_bn_act_apply(ytmp, M, C, o.oh * o.ow, ta, outv, resv, act_kind(o), (o.flags & CVX_OPF_RES_PRE_ACT) ? 1 : 0, c.ybuf, st));
     } else {
       // scale / shift were folded for every layer at once before the op loop (cvx_bn_fold_all)
       cp.epi = CVX_EPI_AFFINE_SILU;
-      cp.act_kind = o.act == CVX_ACT_BN_SILU ? 0 : ((o.act == CVX_ACT_BN_LINEAR || o.act == CVX_ACT_BIAS_LINEAR) ? 2 : 1);
+      cp.act_kind = act_kind(o);
       cp.res_pre = (o.flags & CVX_OPF_RES_PRE_ACT) ? 1 : 0;
       cp.scale = c.scale;
       cp.shift = c.shift;
@@ -1097,6 +1131,30 @@ int backward_op(cvx_engine* e, int i) {
       CVX_TRY(cvx_upsample2_bwd(make_view(e, o.out, true), make_view(e, o.in, true), B, o.ih, o.iw, o.in.c, e->pool[i].in_accum, st));
       return 0;
     }
+    if (o.type == CVX_OP_MAXPOOL3S2 || o.type == CVX_OP_MAXPOOL3S1) {
+      ProfScope ps(e, PROF_MISC, 0, (2.0 * o.ih * o.iw + 3.0 * o.oh * o.ow) * B * o.in.c, st);
+      CVX_TRY(cvx_maxpool3_bwd(make_view(e, o.out, true), make_view(e, o.in, true), B, o.ih, o.iw, o.in.c, o.type == CVX_OP_MAXPOOL3S2 ? 2 : 1,
+                               e->pool[i].idx, e->pool[i].in_accum, st));
+      return 0;
+    }
+    if (o.type == CVX_OP_AVGPOOL) {
+      ProfScope ps(e, PROF_MISC, 0, (e->pool[i].in_accum ? 4.0 : 2.0) * B * o.ih * o.iw * o.in.c, st);
+      CVX_TRY(cvx_avgpool_global_bwd(make_view(e, o.out, true), make_view(e, o.in, true), B, o.ih * o.iw, o.in.c, e->pool[i].in_accum, st));
+      return 0;
+    }
+    if (o.type == CVX_OP_RESIZE) {
+      ProfScope ps(e, PROF_MISC, 0, 2.0 * B * (o.ih * o.iw + o.oh * o.ow) * o.in.c, st);
+      CVX_TRY(cvx_resize_bilinear_bwd(make_view(e, o.out, true), make_view(e, o.in, true), B, o.ih, o.iw, o.oh, o.ow, o.in.c, e->pool[i].in_accum,
+                                      st));
+      return 0;
+    }
+    if (o.type == CVX_OP_DROPOUT) {  // the forward's mask again, from the same (seed, pass, op)
+      ProfScope ps(e, PROF_MISC, 0, 4.0 * B * o.ih * o.iw * o.in.c, st);
+      CVX_TRY(cvx_dropout(make_view(e, o.out, true), make_view(e, o.in, true), B, o.ih * o.iw, o.in.c, dropout_p(o), dropout_seed(e, i),
+                          e->pool[i].in_accum, st));
+      return 0;
+    }
+    CVX_CHECK(o.type == CVX_OP_CONV, "op without a backward pass");
     ConvRt& c = e->conv[i];
     const long long M = (long long)B * o.oh * o.ow;
     const int C = o.out.c;
@@ -1111,12 +1169,13 @@ int backward_op(cvx_engine* e, int i) {
       ViewDesc gout = make_view(e, o.out, true);
       ViewDesc gres = make_view(e, o.res, true);
       BnCoef k{c.invstd, e->params + o.gamma_off, e->params + o.beta_off};
-      ProfScope ps(e, PROF_BN_BWD, 0, (c.stem ? 4.0 : (gres.p ? 14.0 : 10.0)) * M * C, st);
+      const BnActKind ak{act_kind(o), (o.flags & CVX_OPF_RES_PRE_ACT) ? 1 : 0, make_view(e, o.out, false)};
+      ProfScope ps(e, PROF_BN_BWD, 0, (c.stem ? 4.0 : (gres.p ? 14.0 : 10.0) + (ak.act == 1 ? 4.0 : 0.0)) * M * C, st);
       static const bool tune_skip_reduce = cvx_tune_int("CVX_TUNE_SKIP_BN_REDUCE", 0) != 0;  // tuning build: timing without the pass (wrong results)
-      if (!tune_skip_reduce) CVX_TRY(cvx_bn_bwd_reduce(c.ybuf, M, C, hw, k, gout, c.stat_bwd, st));
+      if (!tune_skip_reduce) CVX_TRY(cvx_bn_bwd_reduce(c.ybuf, M, C, hw, k, gout, ak, c.stat_bwd, st));
       // the stem's "apply" half is fused into its weight gradient (cvx_stem_backward, queued below): dy is never materialised
       if (!c.stem)
-        CVX_TRY(cvx_bn_bwd_apply(c.ybuf, M, C, hw, k, c.stat_bwd, w.inv_scale, e->grads + o.gamma_off, e->grads + o.beta_off, gout, c.dybuf,
+        CVX_TRY(cvx_bn_bwd_apply(c.ybuf, M, C, hw, k, c.stat_bwd, w.inv_scale, e->grads + o.gamma_off, e->grads + o.beta_off, gout, ak, c.dybuf,
                                  gres, c.res_accum, st));
       dyv.p = c.dybuf;
       dyv.ld = C;
@@ -1132,11 +1191,15 @@ int backward_op(cvx_engine* e, int i) {
       bool merged = !merge_off && c.ndg > 1 && c.ndg <= 4;
       for (int q = 0; q < c.ndg && merged; ++q)
         if (c.dg[q].OH2 <= 0 || c.dg[q].OW2 <= 0 || c.dg[q].ntaps <= 0) merged = false;
+      // stride > kernel (ResNet's 1x1 stride-2 downsample): input pixels of the tap-less phases receive no gradient -- the first
+      // writer of the slice zeroes it, the phases with taps then overwrite their own pixels
+      bool empty_phase = false;
+      for (int q = 0; q < c.ndg; ++q) empty_phase |= c.dg[q].OH2 > 0 && c.dg[q].OW2 > 0 && c.dg[q].ntaps == 0;
+      if (empty_phase && !c.in_accum) CVX_TRY(cvx_zero_slice(gin, B, o.ih * o.iw, o.in.c, st));
       for (int q = 0; q < c.ndg; ++q) {
         if (merged && q > 0) break;  // everything went out with phase 0
         const DgClass& dc = c.dg[q];
-        if (dc.OH2 <= 0 || dc.OW2 <= 0) return 0;
-        CVX_CHECK(dc.ntaps > 0, "dgrad phase without taps (stride > kernel) is not supported");
+        if (dc.OH2 <= 0 || dc.OW2 <= 0 || dc.ntaps == 0) continue;
         ConvParams cp;
         memset(&cp, 0, sizeof(cp));
         cp.in = dyv.p;

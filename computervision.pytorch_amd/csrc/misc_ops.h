@@ -11,7 +11,17 @@ int cvx_dwconvt(const ViewDesc& in, const ViewDesc& out, const float* w, int B, 
 int cvx_copy_slice(const ViewDesc& in, const ViewDesc& out, int B, int HW, int C, hipStream_t st);
 // DeepLabv3+ (inference): 3x3 / stride 2 / pad 1 max pool, global average pool -> (B, 1, 1, C), bilinear resize with
 // align_corners = False on fp16 NHWC views, and fp32 rows (B, IH*IW, ld) -> NCHW fp32 (B, C, OH, OW)
-int cvx_maxpool3(const ViewDesc& in, const ViewDesc& out, int B, int IH, int IW, int C, int stride, hipStream_t st);  // 3x3, pad 1, stride 1 | 2
+// 3x3, pad 1, stride 1 | 2; idx (optional): argmax byte per output element [B][OH*OW][C], the operand of the backward gather
+int cvx_maxpool3(const ViewDesc& in, const ViewDesc& out, int B, int IH, int IW, int C, int stride, uint8_t* idx, hipStream_t st);
+int cvx_maxpool3_bwd(const ViewDesc& gout, const ViewDesc& gin, int B, int IH, int IW, int C, int stride, const uint8_t* idx, int accumulate,
+                     hipStream_t st);
+int cvx_zero_slice(const ViewDesc& v, int B, int HW, int C, hipStream_t st);  // zero fill of a channel slice
+int cvx_avgpool_global_bwd(const ViewDesc& gout, const ViewDesc& gin, int B, int HW, int C, int accumulate, hipStream_t st);
+int cvx_resize_bilinear_bwd(const ViewDesc& gout, const ViewDesc& gin, int B, int IH, int IW, int OH, int OW, int C, int accumulate,
+                            hipStream_t st);
+// inverted dropout with a counter-based mask of (seed, element index): forward and backward are the same kernel (backward: in = gout,
+// out = gin, same seed); accumulate adds onto `out`
+int cvx_dropout(const ViewDesc& in, const ViewDesc& out, int B, int HW, int C, float p, unsigned long long seed, int accumulate, hipStream_t st);
 int cvx_avgpool_global(const ViewDesc& in, const ViewDesc& out, int B, int HW, int C, hipStream_t st);
 int cvx_resize_bilinear(const ViewDesc& in, const ViewDesc& out, int B, int IH, int IW, int OH, int OW, int C, hipStream_t st);
 int cvx_resize_bilinear_f32_nchw(const float* in, int ld, int B, int C, int IH, int IW, int OH, int OW, float* out, hipStream_t st);

@@ -46,7 +46,8 @@ __global__ void maxpool2_kernel(ViewDesc in, ViewDesc out, int B, int IH, int IW
 }
 
 // ---- max pool 3x3 stride 2 pad 1 (ResNet stem, core/models/resnet.py:163) ----
-__global__ void maxpool3_kernel(ViewDesc in, ViewDesc out, int B, int IH, int IW, int OH, int OW, int CG, int stride) {
+// idx (training): one byte per output element, the window tap dy*3+dx of the first maximum in row-major scan order (torch's rule)
+__global__ void maxpool3_kernel(ViewDesc in, ViewDesc out, int B, int IH, int IW, int OH, int OW, int CG, int stride, uint8_t* idx) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long n = (long long)B * OH * OW * CG;
   if (i >= n) return;
@@ -57,8 +58,13 @@ __global__ void maxpool3_kernel(ViewDesc in, ViewDesc out, int B, int IH, int IW
   int h = (int)(t % OH);
   int b = (int)(t / OH);
   float best[8];
+  int bi[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) best[k] = -INFINITY;
+  for (int k = 0; k < 8; ++k) {
+    best[k] = -INFINITY;
+    bi[k] = 0;
+  }
+  bool first = true;
 #pragma unroll
   for (int dy = 0; dy < 3; ++dy) {
     const int hh = stride * h - 1 + dy;
@@ -68,13 +74,141 @@ __global__ void maxpool3_kernel(ViewDesc in, ViewDesc out, int B, int IH, int IW
       if (hh < 0 || hh >= IH || ww < 0 || ww >= IW) continue;
       const h8 v = *reinterpret_cast<const h8*>(in.p + voff(in, b, (long long)hh * IW + ww) + cg * 8);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) best[k] = fmaxf(best[k], (float)v[k]);
+      for (int k = 0; k < 8; ++k) {
+        const float f = (float)v[k];
+        if (first || f > best[k]) {
+          best[k] = f;
+          bi[k] = dy * 3 + dx;
+        }
+      }
+      first = false;
     }
   }
   h8 o;
 #pragma unroll
   for (int k = 0; k < 8; ++k) o[k] = (half_t)best[k];
-  *reinterpret_cast<h8*>(out.p + voff(out, b, (long long)h * OW + w) + cg * 8) = o;
+  const long long pix = (long long)h * OW + w;
+  *reinterpret_cast<h8*>(out.p + voff(out, b, pix) + cg * 8) = o;
+  if (idx) {
+    unsigned long long pk = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pk |= (unsigned long long)(bi[k] & 0xff) << (8 * k);
+    *reinterpret_cast<unsigned long long*>(idx + (((long long)b * OH * OW + pix) * CG + cg) * 8) = pk;
+  }
+}
+
+// gradient of the 3x3 pad-1 max pool: a gather over the (at most 3 x 3 / stride^2) windows that hold the input pixel
+__global__ void maxpool3_bwd_kernel(ViewDesc gout, ViewDesc gin, int B, int IH, int IW, int OH, int OW, int CG, int stride, const uint8_t* idx,
+                                    int accumulate) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long n = (long long)B * IH * IW * CG;
+  if (i >= n) return;
+  int cg = (int)(i % CG);
+  long long t = i / CG;
+  int ww = (int)(t % IW);
+  t /= IW;
+  int hh = (int)(t % IH);
+  int b = (int)(t / IH);
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int nh = hh + 1 - dy;  // stride * h = hh + 1 - dy
+    if (nh < 0 || nh % stride != 0 || nh / stride >= OH) continue;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int nw = ww + 1 - dx;
+      if (nw < 0 || nw % stride != 0 || nw / stride >= OW) continue;
+      const long long pix = (long long)(nh / stride) * OW + nw / stride;
+      const unsigned long long pk = *reinterpret_cast<const unsigned long long*>(idx + (((long long)b * OH * OW + pix) * CG + cg) * 8);
+      const h8 g = *reinterpret_cast<const h8*>(gout.p + voff(gout, b, pix) + cg * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if ((int)((pk >> (8 * k)) & 0xff) == dy * 3 + dx) acc[k] += (float)g[k];
+    }
+  }
+  half_t* q = gin.p + voff(gin, b, (long long)hh * IW + ww) + cg * 8;
+  if (accumulate) {
+    const h8 old = *reinterpret_cast<const h8*>(q);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += (float)old[k];
+  }
+  h8 o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = (half_t)acc[k];
+  *reinterpret_cast<h8*>(q) = o;
+}
+
+__global__ void zero_slice_kernel(ViewDesc v, int B, int HW, int CG) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long n = (long long)B * HW * CG;
+  if (i >= n) return;
+  int cg = (int)(i % CG);
+  long long t = i / CG;
+  int pix = (int)(t % HW);
+  int b = (int)(t / HW);
+  const h8 z = {};
+  *reinterpret_cast<h8*>(v.p + voff(v, b, pix) + cg * 8) = z;
+}
+
+// gradient of the global average pool: every pixel of the map receives gout / HW
+__global__ void avgpool_global_bwd_kernel(ViewDesc gout, ViewDesc gin, int B, int HW, int CG, int accumulate) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long n = (long long)B * HW * CG;
+  if (i >= n) return;
+  int cg = (int)(i % CG);
+  long long t = i / CG;
+  int pix = (int)(t % HW);
+  int b = (int)(t / HW);
+  const h8 g = *reinterpret_cast<const h8*>(gout.p + voff(gout, b, 0) + cg * 8);
+  half_t* q = gin.p + voff(gin, b, pix) + cg * 8;
+  const float inv = 1.f / (float)HW;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = (float)g[k] * inv;
+  if (accumulate) {
+    const h8 old = *reinterpret_cast<const h8*>(q);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += (float)old[k];
+  }
+  h8 o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = (half_t)acc[k];
+  *reinterpret_cast<h8*>(q) = o;
+}
+
+// inverted dropout (nn.Dropout, deeplabv3plus.py:67): out = keep ? in / (1 - p) : 0 with keep drawn per element from a counter-based
+// hash of (seed, element index) -- the backward pass re-derives the same mask from the same seed instead of storing it.
+// (torch draws its mask from its own Philox stream: the two masks are different samples of the same distribution.)
+__device__ __forceinline__ unsigned dropout_hash(unsigned long long seed, unsigned long long i) {
+  unsigned long long z = seed + (i + 1) * 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return (unsigned)((z ^ (z >> 31)) >> 32);
+}
+__global__ void dropout_kernel(ViewDesc in, ViewDesc out, int B, int HW, int CG, unsigned thresh, float scale, unsigned long long seed, int accumulate) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long n = (long long)B * HW * CG;
+  if (i >= n) return;
+  int cg = (int)(i % CG);
+  long long t = i / CG;
+  int pix = (int)(t % HW);
+  int b = (int)(t / HW);
+  const h8 v = *reinterpret_cast<const h8*>(in.p + voff(in, b, pix) + cg * 8);
+  half_t* q = out.p + voff(out, b, pix) + cg * 8;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = dropout_hash(seed, (unsigned long long)i * 8 + k) >= thresh ? (float)v[k] * scale : 0.f;
+  if (accumulate) {
+    const h8 old = *reinterpret_cast<const h8*>(q);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += (float)old[k];
+  }
+  h8 o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = (half_t)acc[k];
+  *reinterpret_cast<h8*>(q) = o;
 }
 
 // ---- L2Normalize (core/models/ssd_model.py:113-128): x / (sqrt(sum_c x^2) + 1e-10) * weight[c]; one wave per pixel ----
@@ -170,6 +304,61 @@ __global__ void resize_bilinear_kernel(ViewDesc in, ViewDesc out, int B, int IH,
     o[k] = (half_t)(top * (1.f - ly) + bot * ly);
   }
   *reinterpret_cast<h8*>(out.p + voff(out, b, (long long)h * OW + w) + cg * 8) = o;
+}
+// gradient of the bilinear resize as a gather (deterministic, no atomics): input pixel (y, x) collects every output pixel whose
+// two source rows / columns include it.  The candidate range is a superset derived from src = (dst + 0.5) * scale - 0.5; each
+// candidate re-derives its (i0, i1, lambda) with the forward's arithmetic, so the weights are the forward's bit for bit.
+__device__ __forceinline__ void bilinear_dst_range(int s, float scale, int out_size, int* lo, int* hi) {
+  const float a = ((float)s - 0.5f) / scale - 0.5f, b = ((float)s + 1.5f) / scale - 0.5f;
+  int l = (int)floorf(a) - 1, h = (int)ceilf(b) + 1;
+  *lo = l < 0 ? 0 : l;
+  *hi = h > out_size - 1 ? out_size - 1 : h;
+}
+__global__ void resize_bilinear_bwd_kernel(ViewDesc gout, ViewDesc gin, int B, int IH, int IW, int OH, int OW, int CG, float sh, float sw,
+                                           int accumulate) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long n = (long long)B * IH * IW * CG;
+  if (i >= n) return;
+  int cg = (int)(i % CG);
+  long long t = i / CG;
+  int x = (int)(t % IW);
+  t /= IW;
+  int y = (int)(t % IH);
+  int b = (int)(t / IH);
+  int oy0, oy1, ox0, ox1;
+  bilinear_dst_range(y, sh, OH, &oy0, &oy1);
+  bilinear_dst_range(x, sw, OW, &ox0, &ox1);
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  for (int oy = oy0; oy <= oy1; ++oy) {
+    int y0, y1;
+    float ly;
+    bilinear_src(oy, sh, IH, &y0, &y1, &ly);
+    const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
+    if (wy == 0.f) continue;
+    for (int ox = ox0; ox <= ox1; ++ox) {
+      int x0, x1;
+      float lx;
+      bilinear_src(ox, sw, IW, &x0, &x1, &lx);
+      const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
+      if (wx == 0.f) continue;
+      const h8 g = *reinterpret_cast<const h8*>(gout.p + voff(gout, b, (long long)oy * OW + ox) + cg * 8);
+      const float wgt = wy * wx;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] = fmaf(wgt, (float)g[k], acc[k]);
+    }
+  }
+  half_t* q = gin.p + voff(gin, b, (long long)y * IW + x) + cg * 8;
+  if (accumulate) {
+    const h8 old = *reinterpret_cast<const h8*>(q);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += (float)old[k];
+  }
+  h8 o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = (half_t)acc[k];
+  *reinterpret_cast<h8*>(q) = o;
 }
 // fp32 rows (B, IH*IW, ld) -> NCHW fp32 (B, C, OH, OW): the segmentation logits back at input resolution (deeplabv3plus.py:147)
 __global__ void resize_bilinear_f32_nchw_kernel(const float* in, int ld, int B, int C, int IH, int IW, int OH, int OW, float sh, float sw,
@@ -562,10 +751,35 @@ int cvx_l2norm(const ViewDesc& in, const ViewDesc& out, const float* weight, int
   CVX_HIP(hipGetLastError());
   return 0;
 }
-int cvx_maxpool3(const ViewDesc& in, const ViewDesc& out, int B, int IH, int IW, int C, int stride, hipStream_t st) {
+int cvx_maxpool3(const ViewDesc& in, const ViewDesc& out, int B, int IH, int IW, int C, int stride, uint8_t* idx, hipStream_t st) {
   CVX_CHECK(C % 8 == 0 && (stride == 1 || stride == 2), "maxpool3: C % 8, stride 1 or 2");
   const int OH = (IH - 1) / stride + 1, OW = (IW - 1) / stride + 1;  // floor((I + 2 - 3) / stride) + 1
-  return launch1d(maxpool3_kernel, (long long)B * OH * OW * (C / 8), st, in, out, B, IH, IW, OH, OW, C / 8, stride);
+  return launch1d(maxpool3_kernel, (long long)B * OH * OW * (C / 8), st, in, out, B, IH, IW, OH, OW, C / 8, stride, idx);
+}
+int cvx_maxpool3_bwd(const ViewDesc& gout, const ViewDesc& gin, int B, int IH, int IW, int C, int stride, const uint8_t* idx, int accumulate,
+                     hipStream_t st) {
+  CVX_CHECK(C % 8 == 0 && (stride == 1 || stride == 2) && idx, "maxpool3_bwd: C % 8, stride 1 or 2, argmax bytes of the forward");
+  const int OH = (IH - 1) / stride + 1, OW = (IW - 1) / stride + 1;
+  return launch1d(maxpool3_bwd_kernel, (long long)B * IH * IW * (C / 8), st, gout, gin, B, IH, IW, OH, OW, C / 8, stride, idx, accumulate);
+}
+int cvx_zero_slice(const ViewDesc& v, int B, int HW, int C, hipStream_t st) {
+  CVX_CHECK(C % 8 == 0, "zero_slice: C % 8");
+  return launch1d(zero_slice_kernel, (long long)B * HW * (C / 8), st, v, B, HW, C / 8);
+}
+int cvx_avgpool_global_bwd(const ViewDesc& gout, const ViewDesc& gin, int B, int HW, int C, int accumulate, hipStream_t st) {
+  CVX_CHECK(C % 8 == 0 && HW > 0, "avgpool_global_bwd: C % 8");
+  return launch1d(avgpool_global_bwd_kernel, (long long)B * HW * (C / 8), st, gout, gin, B, HW, C / 8, accumulate);
+}
+int cvx_resize_bilinear_bwd(const ViewDesc& gout, const ViewDesc& gin, int B, int IH, int IW, int OH, int OW, int C, int accumulate,
+                            hipStream_t st) {
+  CVX_CHECK(C % 8 == 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0, "resize_bilinear_bwd: C % 8 / sizes");
+  return launch1d(resize_bilinear_bwd_kernel, (long long)B * IH * IW * (C / 8), st, gout, gin, B, IH, IW, OH, OW, C / 8, (float)IH / (float)OH,
+                  (float)IW / (float)OW, accumulate);
+}
+int cvx_dropout(const ViewDesc& in, const ViewDesc& out, int B, int HW, int C, float p, unsigned long long seed, int accumulate, hipStream_t st) {
+  CVX_CHECK(C % 8 == 0 && p >= 0.f && p < 1.f, "dropout: C % 8, p in [0, 1)");
+  const unsigned thresh = (unsigned)((double)p * 4294967296.0);
+  return launch1d(dropout_kernel, (long long)B * HW * (C / 8), st, in, out, B, HW, C / 8, thresh, 1.f / (1.f - p), seed, accumulate);
 }
 int cvx_avgpool_global(const ViewDesc& in, const ViewDesc& out, int B, int HW, int C, hipStream_t st) {
   CVX_CHECK(C % 8 == 0 && HW > 0, "avgpool_global: C % 8");

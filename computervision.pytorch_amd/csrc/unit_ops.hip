@@ -28,6 +28,12 @@ ViewDesc dense(const void* p, int hw, int C) { return ViewDesc{(half_t*)p, (long
 extern "C" int cvx_bn_silu_train_nhwc(const float* y_f32, int32_t batch, int32_t hw, int32_t c, const float* gamma, const float* beta, float eps,
                                       float momentum, float* running_mean, float* running_var, const void* res_f16, void* out_f16,
                                       void* xhat_f16, float* mean, float* invstd, void* hip_stream) {
+  return cvx_bn_act_train_nhwc(y_f32, batch, hw, c, gamma, beta, eps, momentum, running_mean, running_var, res_f16, 0, 0, out_f16, xhat_f16, mean,
+                               invstd, hip_stream);
+}
+extern "C" int cvx_bn_act_train_nhwc(const float* y_f32, int32_t batch, int32_t hw, int32_t c, const float* gamma, const float* beta, float eps,
+                                     float momentum, float* running_mean, float* running_var, const void* res_f16, int32_t act, int32_t res_pre,
+                                     void* out_f16, void* xhat_f16, float* mean, float* invstd, void* hip_stream) {
   CVX_CHECK(y_f32 && gamma && beta && running_mean && running_var && out_f16 && xhat_f16 && mean && invstd && batch > 0 && hw > 0, "bad arguments");
   hipStream_t st = (hipStream_t)hip_stream;
   const long long M = (long long)batch * hw;
@@ -35,8 +41,8 @@ extern "C" int cvx_bn_silu_train_nhwc(const float* y_f32, int32_t batch, int32_t
   CVX_TRY(slab.alloc(slab_bytes(c)));
   CVX_TRY(cvx_bn_stats_f32(y_f32, M, c, (long long*)slab.p, st));
   BnTrainArgs ta{(const long long*)slab.p, gamma, beta, mean, invstd, running_mean, running_var, eps, momentum};
-  CVX_TRY(cvx_bn_silu_apply(y_f32, M, c, hw, ta, dense(out_f16, hw, c), res_f16 ? dense(res_f16, hw, c) : ViewDesc{nullptr, 0, 0},
-                            (half_t*)xhat_f16, st));
+  CVX_TRY(cvx_bn_act_apply(y_f32, M, c, hw, ta, dense(out_f16, hw, c), res_f16 ? dense(res_f16, hw, c) : ViewDesc{nullptr, 0, 0}, act, res_pre,
+                           (half_t*)xhat_f16, st));
   CVX_HIP(hipStreamSynchronize(st));
   return 0;
 }
@@ -44,15 +50,23 @@ extern "C" int cvx_bn_silu_train_nhwc(const float* y_f32, int32_t batch, int32_t
 extern "C" int cvx_bn_silu_bwd_nhwc(const void* xhat_f16, const void* gout_f16, int32_t batch, int32_t hw, int32_t c, const float* gamma,
                                     const float* beta, const float* invstd, float inv_scale, float* dgamma, float* dbeta, void* dy_f16,
                                     void* gres_f16, int32_t res_accumulate, void* hip_stream) {
+  return cvx_bn_act_bwd_nhwc(xhat_f16, gout_f16, nullptr, batch, hw, c, gamma, beta, invstd, 0, 0, inv_scale, dgamma, dbeta, dy_f16, gres_f16,
+                             res_accumulate, hip_stream);
+}
+extern "C" int cvx_bn_act_bwd_nhwc(const void* xhat_f16, const void* gout_f16, const void* out_f16, int32_t batch, int32_t hw, int32_t c,
+                                   const float* gamma, const float* beta, const float* invstd, int32_t act, int32_t res_pre, float inv_scale,
+                                   float* dgamma, float* dbeta, void* dy_f16, void* gres_f16, int32_t res_accumulate, void* hip_stream) {
   CVX_CHECK(xhat_f16 && gout_f16 && gamma && beta && invstd && dgamma && dbeta && dy_f16 && batch > 0 && hw > 0, "bad arguments");
+  CVX_CHECK(act != 1 || out_f16, "ReLU: the forward output is needed (its sign is the mask)");
+  const BnActKind ak{act, res_pre, out_f16 ? dense(out_f16, hw, c) : ViewDesc{nullptr, 0, 0}};
   hipStream_t st = (hipStream_t)hip_stream;
   const long long M = (long long)batch * hw;
   Scratch slab;
   CVX_TRY(slab.alloc(slab_bytes(c)));
   BnCoef k{invstd, gamma, beta};
   const ViewDesc g = dense(gout_f16, hw, c);
-  CVX_TRY(cvx_bn_bwd_reduce((const half_t*)xhat_f16, M, c, hw, k, g, (long long*)slab.p, st));
-  CVX_TRY(cvx_bn_bwd_apply((const half_t*)xhat_f16, M, c, hw, k, (const long long*)slab.p, inv_scale, dgamma, dbeta, g, (half_t*)dy_f16,
+  CVX_TRY(cvx_bn_bwd_reduce((const half_t*)xhat_f16, M, c, hw, k, g, ak, (long long*)slab.p, st));
+  CVX_TRY(cvx_bn_bwd_apply((const half_t*)xhat_f16, M, c, hw, k, (const long long*)slab.p, inv_scale, dgamma, dbeta, g, ak, (half_t*)dy_f16,
                            gres_f16 ? dense(gres_f16, hw, c) : ViewDesc{nullptr, 0, 0}, res_accumulate, st));
   CVX_HIP(hipStreamSynchronize(st));
   return 0;
@@ -93,7 +107,7 @@ extern "C" int cvx_maxpool_nhwc(const void* x_f16, int32_t batch, int32_t h, int
     CVX_TRY(cvx_maxpool2(dense(x_f16, h * w, c), dense(out_f16, oh * ow, c), batch, h, w, oh, ow, c, st));
   } else if (kernel == 3 && (stride == 1 || stride == 2) && !ceil_mode) {
     const int oh = (h - 1) / stride + 1, ow = (w - 1) / stride + 1;
-    CVX_TRY(cvx_maxpool3(dense(x_f16, h * w, c), dense(out_f16, oh * ow, c), batch, h, w, c, stride, st));
+    CVX_TRY(cvx_maxpool3(dense(x_f16, h * w, c), dense(out_f16, oh * ow, c), batch, h, w, c, stride, nullptr, st));
   } else {
     CVX_CHECK(false, "max pools built: 2x2 / stride 2 (floor or ceil mode), 3x3 / pad 1 / stride 1 or 2");
   }
@@ -116,6 +130,45 @@ extern "C" int cvx_resize_bilinear_nhwc(const void* x_f16, int32_t batch, int32_
 extern "C" int cvx_l2norm_nhwc(const void* x_f16, const float* weight, int32_t batch, int32_t hw, int32_t c, void* out_f16, void* hip_stream) {
   CVX_CHECK(x_f16 && weight && out_f16 && batch > 0 && c % 8 == 0, "bad arguments (channels in multiples of 8)");
   CVX_TRY(cvx_l2norm(dense(x_f16, hw, c), dense(out_f16, hw, c), weight, batch, hw, c, (hipStream_t)hip_stream));
+  CVX_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
+  return 0;
+}
+// ---- their training forms: forward with the operand the backward needs, and the backward ----
+extern "C" int cvx_maxpool3_train_nhwc(const void* x_f16, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t stride, void* out_f16,
+                                       uint8_t* argmax, void* hip_stream) {
+  CVX_CHECK(x_f16 && out_f16 && argmax && batch > 0 && c % 8 == 0, "bad arguments (channels in multiples of 8)");
+  const int oh = (h - 1) / stride + 1, ow = (w - 1) / stride + 1;
+  CVX_TRY(cvx_maxpool3(dense(x_f16, h * w, c), dense(out_f16, oh * ow, c), batch, h, w, c, stride, argmax, (hipStream_t)hip_stream));
+  CVX_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
+  return 0;
+}
+extern "C" int cvx_maxpool3_bwd_nhwc(const void* gout_f16, const uint8_t* argmax, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t stride,
+                                     void* gin_f16, int32_t accumulate, void* hip_stream) {
+  CVX_CHECK(gout_f16 && argmax && gin_f16 && batch > 0 && c % 8 == 0, "bad arguments (channels in multiples of 8)");
+  const int oh = (h - 1) / stride + 1, ow = (w - 1) / stride + 1;
+  CVX_TRY(cvx_maxpool3_bwd(dense(gout_f16, oh * ow, c), dense(gin_f16, h * w, c), batch, h, w, c, stride, argmax, accumulate, (hipStream_t)hip_stream));
+  CVX_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
+  return 0;
+}
+extern "C" int cvx_avgpool_global_bwd_nhwc(const void* gout_f16, int32_t batch, int32_t hw, int32_t c, void* gin_f16, int32_t accumulate,
+                                           void* hip_stream) {
+  CVX_CHECK(gout_f16 && gin_f16 && batch > 0 && c % 8 == 0, "bad arguments (channels in multiples of 8)");
+  CVX_TRY(cvx_avgpool_global_bwd(dense(gout_f16, 1, c), dense(gin_f16, hw, c), batch, hw, c, accumulate, (hipStream_t)hip_stream));
+  CVX_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
+  return 0;
+}
+extern "C" int cvx_resize_bilinear_bwd_nhwc(const void* gout_f16, int32_t batch, int32_t ih, int32_t iw, int32_t c, int32_t oh, int32_t ow,
+                                            void* gin_f16, int32_t accumulate, void* hip_stream) {
+  CVX_CHECK(gout_f16 && gin_f16 && batch > 0 && c % 8 == 0, "bad arguments (channels in multiples of 8)");
+  CVX_TRY(cvx_resize_bilinear_bwd(dense(gout_f16, oh * ow, c), dense(gin_f16, ih * iw, c), batch, ih, iw, oh, ow, c, accumulate,
+                                  (hipStream_t)hip_stream));
+  CVX_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
+  return 0;
+}
+extern "C" int cvx_dropout_nhwc(const void* x_f16, int32_t batch, int32_t hw, int32_t c, float p, uint64_t seed, void* out_f16, int32_t accumulate,
+                                void* hip_stream) {
+  CVX_CHECK(x_f16 && out_f16 && batch > 0 && c % 8 == 0, "bad arguments (channels in multiples of 8)");
+  CVX_TRY(cvx_dropout(dense(x_f16, hw, c), dense(out_f16, hw, c), batch, hw, c, p, seed, accumulate, (hipStream_t)hip_stream));
   CVX_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
   return 0;
 }
@@ -197,7 +250,7 @@ extern "C" int cvx_stem_backward_nchw(const float* images, int32_t batch, int32_
   CVX_TRY(slabs.alloc((size_t)ns * cout * 144 * 4));
   BnCoef k{invstd, gamma, beta};
   const ViewDesc g = dense(gout_f16, hw, cout);
-  CVX_TRY(cvx_bn_bwd_reduce((const half_t*)xhat_f16, M, cout, hw, k, g, (long long*)part.p, st));
+  CVX_TRY(cvx_bn_bwd_reduce((const half_t*)xhat_f16, M, cout, hw, k, g, BnActKind{0, 0, ViewDesc{nullptr, 0, 0}}, (long long*)part.p, st));
   CVX_TRY(cvx_stem_backward(sp, (const half_t*)xhat_f16, g, k, (const long long*)part.p, inv_scale, dgamma, dbeta, (float*)slabs.p, ns, st));
   SlabDesc sd{0, 0, ns, cout * 9, 3, 16, cvx_slab_lanes(ns)};
   std::vector<BlockRef> blocks;

@@ -48,7 +48,10 @@ enum { CVX_OP_CONV = 1, CVX_OP_MAXPOOL5 = 2, CVX_OP_UPSAMPLE2 = 3,
        CVX_OP_RESIZE = 9,     /* bilinear resize (ih, iw) -> (oh, ow), align_corners = False (deeplabv3plus.py:38,117-122) */
        /* inference-only ops (SSD / VGG, core/models/ssd_model.py): */
        CVX_OP_MAXPOOL3S1 = 10, /* 3x3 stride-1 pad-1 max pool (VGG pool5, :30) */
-       CVX_OP_L2NORM = 11 };   /* x / (||x||_2 over channels + 1e-10) * weight[c] (L2Normalize, :113-128); gamma_off -> weight (C floats) */
+       CVX_OP_L2NORM = 11,     /* x / (||x||_2 over channels + 1e-10) * weight[c] (L2Normalize, :113-128); gamma_off -> weight (C floats) */
+       CVX_OP_DROPOUT = 12 };  /* nn.Dropout (deeplabv3plus.py:67): k = drop probability in units of 2^-16; identity in eval mode.
+                                  Training: inverted dropout, the mask a counter-based hash of (cvx_engine_set_seed, training pass, op,
+                                  element) -- a different draw than torch's Philox stream, the same distribution */
 /* CVX_OP_MAXPOOL2 also serves ceil_mode = True (:18): oh = ceil(ih / 2), windows clipped at the border. */
 enum { CVX_ACT_BN_SILU = 1, CVX_ACT_BIAS = 2,
        /* inference-only epilogues (folded BatchNorm): */
@@ -98,6 +101,8 @@ int cvx_engine_set_stream(cvx_engine* e, void* hip_stream);
 
 /* BatchNorm hyper-parameters (core/models/yolov8/torch_utils.py:17-19: eps 1e-3, momentum 0.03). */
 int cvx_engine_set_bn(cvx_engine* e, float eps, float momentum);
+/* Seed of the CVX_OP_DROPOUT masks (default 0).  Replaces: torch.manual_seed for the model's nn.Dropout layers. */
+int cvx_engine_set_seed(cvx_engine* e, uint64_t seed);
 
 /* Forward pass.  images: (B,3,H,W) fp32 NCHW in [0,1], 8-byte aligned; pred: (B, A, no) fp32, anchors of the three
  * levels concatenated (80x80, 40x40, 20x20 order), channels = [64 DFL logits | nc class logits].
@@ -285,7 +290,7 @@ int cvx_conv2d_wgrad_nhwc(const void* x_f16, const void* dy_f16, int32_t batch, 
 /* ---- streaming ops on dense NHWC fp16 tensors (the kernels the engine runs between the convolutions) ----------------
  * Train-mode BatchNorm + SiLU.  y: raw conv output FP32 (B*hw, C); statistics are taken from it, running statistics
  * updated (momentum, unbiased variance); out = silu(gamma*xhat+beta) (+res) fp16, xhat = (y-mean)*invstd fp16 (the
- * operand of the backward op), mean / invstd (C) returned.  C multiple of 8, <= 1024.
+ * operand of the backward op), mean / invstd (C) returned.  C multiple of 8, <= 2048.
  * Replaces: Conv.forward's bn + act, core/models/yolov8/modules.py:29-30 (eps / momentum: torch_utils.py:17-19). */
 int cvx_bn_silu_train_nhwc(const float* y_f32, int32_t batch, int32_t hw, int32_t c, const float* gamma, const float* beta, float eps,
                            float momentum, float* running_mean, float* running_var, const void* res_f16, void* out_f16, void* xhat_f16,
@@ -295,6 +300,18 @@ int cvx_bn_silu_train_nhwc(const float* y_f32, int32_t batch, int32_t hw, int32_
 int cvx_bn_silu_bwd_nhwc(const void* xhat_f16, const void* gout_f16, int32_t batch, int32_t hw, int32_t c, const float* gamma,
                          const float* beta, const float* invstd, float inv_scale, float* dgamma, float* dbeta, void* dy_f16, void* gres_f16,
                          int32_t res_accumulate, void* hip_stream);
+/* The same two passes for the other Conv + BatchNorm blocks of the reference (C up to 2048).  act: 0 SiLU, 1 ReLU, 2 none.
+ * res_pre = 1: the residual joins the PRE-activation, out = act(gamma*xhat + beta + res) (Bottleneck.forward, resnet.py:139-141:
+ * out += identity; out = relu(out)) and gres receives the pre-activation gradient dz; res_pre = 0: out = act(.) + res, gres
+ * receives gout.  ReLU's backward mask is the sign of the forward output `out_f16` (required for act = 1, else may be NULL);
+ * ReLU with a post-activation residual and SiLU with a pre-activation one are refused.
+ * Replaces: nn.BatchNorm2d + nn.ReLU in training mode (resnet.py:121-143, deeplabv3plus.py:19-27,63-68) and their autograd. */
+int cvx_bn_act_train_nhwc(const float* y_f32, int32_t batch, int32_t hw, int32_t c, const float* gamma, const float* beta, float eps,
+                          float momentum, float* running_mean, float* running_var, const void* res_f16, int32_t act, int32_t res_pre,
+                          void* out_f16, void* xhat_f16, float* mean, float* invstd, void* hip_stream);
+int cvx_bn_act_bwd_nhwc(const void* xhat_f16, const void* gout_f16, const void* out_f16, int32_t batch, int32_t hw, int32_t c,
+                        const float* gamma, const float* beta, const float* invstd, int32_t act, int32_t res_pre, float inv_scale,
+                        float* dgamma, float* dbeta, void* dy_f16, void* gres_f16, int32_t res_accumulate, void* hip_stream);
 /* 5x5 / stride 1 / pad 2 max pool (SPPF, core/models/yolov8/modules.py:312-318) and its backward; argmax (optional in
  * the forward): one byte per element, the window tap 0..24 of the first maximum in row-major scan order. */
 int cvx_maxpool5_nhwc(const void* x_f16, int32_t batch, int32_t h, int32_t w, int32_t c, void* out_f16, uint8_t* argmax, void* hip_stream);
@@ -318,6 +335,27 @@ int cvx_l2norm_nhwc(const void* x_f16, const float* weight, int32_t batch, int32
  * Replaces: F.interpolate(x, size=input_shape, mode="bilinear", align_corners=False), core/models/deeplabv3plus.py:147. */
 int cvx_resize_bilinear_rows_to_nchw(const float* rows_f32, int32_t ld, int32_t batch, int32_t c, int32_t ih, int32_t iw, int32_t oh, int32_t ow,
                                      float* out_nchw, void* hip_stream);
+/* Training forms of the ResNet / DeepLab pooling and resampling ops (dense NHWC fp16; they synchronise before returning):
+ *   cvx_maxpool3_train_nhwc: the 3x3 / pad 1 / stride 1 | 2 max pool that also stores `argmax` (one byte per OUTPUT element, the
+ *     window tap dy*3+dx of the first maximum in row-major scan order = torch's choice); cvx_maxpool3_bwd_nhwc routes gout through it
+ *     (resnet.py:163 + autograd);
+ *   cvx_avgpool_global_bwd_nhwc: gin (+)= gout / hw on every pixel (deeplabv3plus.py:30);
+ *   cvx_resize_bilinear_bwd_nhwc: the adjoint of cvx_resize_bilinear_nhwc (align_corners = False) as a deterministic gather
+ *     (deeplabv3plus.py:38,117-122);
+ *   cvx_dropout_nhwc: inverted dropout, out (+)= keep ? x / (1 - p) : 0, the mask a counter-based hash of (seed, element index) --
+ *     the same call with the same seed on the output gradient is its backward (deeplabv3plus.py:67).  The mask is NOT torch's
+ *     Philox sample: same distribution, different draw.
+ * accumulate != 0 adds onto the existing contents of the gradient tensor. */
+int cvx_maxpool3_train_nhwc(const void* x_f16, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t stride, void* out_f16, uint8_t* argmax,
+                            void* hip_stream);
+int cvx_maxpool3_bwd_nhwc(const void* gout_f16, const uint8_t* argmax, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t stride,
+                          void* gin_f16, int32_t accumulate, void* hip_stream);
+int cvx_avgpool_global_bwd_nhwc(const void* gout_f16, int32_t batch, int32_t hw, int32_t c, void* gin_f16, int32_t accumulate, void* hip_stream);
+int cvx_resize_bilinear_bwd_nhwc(const void* gout_f16, int32_t batch, int32_t ih, int32_t iw, int32_t c, int32_t oh, int32_t ow, void* gin_f16,
+                                 int32_t accumulate, void* hip_stream);
+int cvx_dropout_nhwc(const void* x_f16, int32_t batch, int32_t hw, int32_t c, float p, uint64_t seed, void* out_f16, int32_t accumulate,
+                     void* hip_stream);
+
 /* nearest-neighbour x2 upsample (nn.Upsample(scale_factor=2), core/models/yolov8/yolo_v8.py:39,41) and its backward */
 int cvx_upsample2_nhwc(const void* x_f16, int32_t batch, int32_t h, int32_t w, int32_t c, void* out_f16, void* hip_stream);
 int cvx_upsample2_bwd_nhwc(const void* gout_f16, int32_t batch, int32_t h, int32_t w, int32_t c, void* gin_f16, int32_t accumulate,

@@ -180,6 +180,57 @@ def test_bn_silu_train_and_backward_unit(dev, B, H, W, C, res):
         assert rel(gres.float().permute(0, 3, 1, 2), rr.grad + 0.5) < 5e-4
 
 
+@pytest.mark.parametrize("B,H,W,C,act,res_pre", [(2, 20, 20, 64, 1, 0), (2, 9, 11, 256, 1, 1), (1, 16, 16, 2048, 1, 1), (3, 7, 5, 1024, 2, 0),
+                                                   (2, 8, 8, 512, 2, 1), (16, 1, 1, 256, 1, 0)])
+def test_bn_act_train_and_backward_unit(dev, B, H, W, C, act, res_pre):
+    """The generalised BatchNorm passes (bn_act.hip): ReLU / no activation, the residual inside the activation (Bottleneck.forward,
+    resnet.py:139-141), up to 2048 channels (layer4) and down to a 1 x 1 map (ASPPPooling, deeplabv3plus.py:29-33), against torch
+    autograd in fp32."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(B * 100 + C + act)
+    y = (torch.randn(B, C, H, W, generator=g) * (torch.rand(C, generator=g) * 3 + 0.2).view(1, C, 1, 1) + torch.randn(C, generator=g).view(1, C, 1, 1) * 2)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    r16 = torch.randn(B, C, H, W, generator=g).half()
+    gout16 = torch.randn(B, C, H, W, generator=g).half()
+    rm0, rv0 = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    yr, gr, br = y.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rr = r16.float().requires_grad_(True)
+    z = F.batch_norm(yr, rm0.clone(), rv0.clone(), gr, br, True, 0.1, 1e-5)
+    if res_pre:
+        z = z + rr
+    out = F.relu(z) if act == 1 else z
+    out.backward(gout16.float())
+    st = L.stream_ptr(dev)
+    yd = _nhwc(y).to(dev)
+    gd, bd, rmd, rvd = gamma.to(dev), beta.to(dev), rm0.clone().to(dev), rv0.clone().to(dev)
+    resd = _nhwc(r16).to(dev) if res_pre else None
+    outd = torch.empty(B, H, W, C, dtype=torch.float16, device=dev)
+    xh = torch.empty_like(outd)
+    mean, invstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    L.check(lib.cvx_bn_act_train_nhwc(L.ptr(yd), B, H * W, C, L.ptr(gd), L.ptr(bd), 1e-5, 0.1, L.ptr(rmd), L.ptr(rvd), L.ptr(resd), act, res_pre,
+                                      L.ptr(outd), L.ptr(xh), L.ptr(mean), L.ptr(invstd), st), "bn fwd")
+    assert rel(outd.float().permute(0, 3, 1, 2), out.detach()) < 5e-4
+    y64 = y.double()
+    n = y64.numel() / C
+    mu64, var64 = y64.mean((0, 2, 3)), y64.var((0, 2, 3), unbiased=False)
+    np.testing.assert_allclose(rmd.cpu().numpy(), (0.9 * rm0.double() + 0.1 * mu64).numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rvd.cpu().numpy(), (0.9 * rv0.double() + 0.1 * var64 * n / (n - 1)).numpy(), rtol=1e-4, atol=1e-6)
+    goutd = _nhwc(gout16).to(dev)
+    dgam, dbet = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    dy = torch.empty_like(outd)
+    gres = torch.full((B, H, W, C), 0.5, dtype=torch.float16, device=dev) if res_pre else None
+    L.check(lib.cvx_bn_act_bwd_nhwc(L.ptr(xh), L.ptr(goutd), L.ptr(outd), B, H * W, C, L.ptr(gd), L.ptr(bd), L.ptr(invstd), act, res_pre, 1.0,
+                                    L.ptr(dgam), L.ptr(dbet), L.ptr(dy), L.ptr(gres), 1, st), "bn bwd")
+    assert rel(dy.float().permute(0, 3, 1, 2), yr.grad) < 2e-3
+    assert rel(dgam, gr.grad) < 1e-3 and rel(dbet, br.grad) < 1e-3
+    if res_pre:                                          # the identity branch receives the pre-activation gradient, accumulated onto 0.5
+        assert rel(gres.float().permute(0, 3, 1, 2), rr.grad + 0.5) < 5e-4
+    # refused combinations fail loudly
+    with pytest.raises(L.CvxError):
+        L.check(lib.cvx_bn_act_train_nhwc(L.ptr(yd), B, H * W, C, L.ptr(gd), L.ptr(bd), 1e-5, 0.1, L.ptr(rmd), L.ptr(rvd), L.ptr(outd), 1, 0,
+                                          L.ptr(outd), L.ptr(xh), L.ptr(mean), L.ptr(invstd), st), "bn fwd")
+
+
 def test_bn_statistics_do_not_overflow_at_large_magnitudes(dev):
     """Sums of squares far beyond the +-8.6e9 range of the first fixed-point format: pre-BN values
     of magnitude 3e3 over 400k rows -> sum of squares ~4e12 per channel."""
@@ -271,6 +322,71 @@ def test_inference_pool_resize_norm_units(dev, B, H, W, C):
     L.check(lib.cvx_l2norm_nhwc(L.ptr(xd), L.ptr(wgt), B, H * W, C, L.ptr(out), st), "l2norm")
     ref = wgt.cpu().view(1, C, 1, 1) * (xf / (xf.pow(2).sum(1, keepdim=True).sqrt() + 1e-10))
     assert rel(out.float().permute(0, 3, 1, 2).cpu(), ref) < 5e-4
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 33, 33, 16), (1, 38, 51, 8), (3, 7, 5, 64), (2, 1, 1, 24)])
+def test_training_pool_resize_dropout_units(dev, B, H, W, C):
+    """Backward kernels of the ResNet / DeepLab ops against torch autograd (fp32): 3x3 pad-1 max pool at stride 2 and 1 (ties
+    broken like torch: first maximum in scan order), global average pool, bilinear resize (align_corners = False) up, down,
+    identity and from 1 x 1, each also in accumulate mode; dropout: mask statistics, scale, and backward = same mask."""
+    lib = L.load()
+    st = L.stream_ptr(dev)
+    g = torch.Generator().manual_seed(H * 131 + W * 7 + C)
+    x16 = (torch.randint(-8, 9, (B, C, H, W), generator=g).float() / 4).half()     # many exact ties for the pools
+    xd = _nhwc(x16).to(dev)
+    base16 = torch.randn(B, C, H, W, generator=g).half()
+    for stride in (2, 1):
+        xr = x16.float().requires_grad_(True)
+        ref = F.max_pool2d(xr, 3, stride, 1)
+        oh, ow = ref.shape[2:]
+        go16 = torch.randn(B, C, oh, ow, generator=g).half()
+        ref.backward(go16.float())
+        out = torch.empty(B, oh, ow, C, dtype=torch.float16, device=dev)
+        am = torch.empty(B, oh, ow, C, dtype=torch.uint8, device=dev)
+        L.check(lib.cvx_maxpool3_train_nhwc(L.ptr(xd), B, H, W, C, stride, L.ptr(out), L.ptr(am), st), "maxpool3 train")
+        assert torch.equal(out.float().permute(0, 3, 1, 2).cpu(), ref.detach())
+        for acc in (0, 1):
+            gin = _nhwc(base16).to(dev).clone()
+            L.check(lib.cvx_maxpool3_bwd_nhwc(L.ptr(_nhwc(go16).to(dev)), L.ptr(am), B, H, W, C, stride, L.ptr(gin), acc, st), "maxpool3 bwd")
+            want = xr.grad + (base16.float() if acc else 0)
+            assert (gin.float().permute(0, 3, 1, 2).cpu() - want).abs().max() <= 2e-3 * max(1.0, float(want.abs().max()))
+    xf16 = torch.randn(B, C, H, W, generator=g).half()
+    # global average pool
+    xr = xf16.float().requires_grad_(True)
+    go16 = torch.randn(B, C, 1, 1, generator=g).half()
+    F.adaptive_avg_pool2d(xr, 1).backward(go16.float())
+    for acc in (0, 1):
+        gin = _nhwc(base16).to(dev).clone()
+        L.check(lib.cvx_avgpool_global_bwd_nhwc(L.ptr(_nhwc(go16).to(dev)), B, H * W, C, L.ptr(gin), acc, st), "avgpool bwd")
+        want = xr.grad + (base16.float() if acc else 0)
+        assert (gin.float().permute(0, 3, 1, 2).cpu() - want).abs().max() <= 2e-3 * max(1.0, float(want.abs().max()))
+    # bilinear resize
+    for (oh, ow) in ((2 * H + 1, 3 * W), (max(H // 2, 1), max(W // 3, 1)), (H, W), (4 * H - 3, 4 * W - 3), (33, 33)):
+        xr = xf16.float().requires_grad_(True)
+        go16 = torch.randn(B, C, oh, ow, generator=g).half()
+        F.interpolate(xr, size=(oh, ow), mode="bilinear", align_corners=False).backward(go16.float())
+        for acc in (0, 1):
+            gin = _nhwc(base16).to(dev).clone()
+            L.check(lib.cvx_resize_bilinear_bwd_nhwc(L.ptr(_nhwc(go16).to(dev)), B, H, W, C, oh, ow, L.ptr(gin), acc, st), "resize bwd")
+            want = xr.grad + (base16.float() if acc else 0)
+            assert (gin.float().permute(0, 3, 1, 2).cpu() - want).abs().max() <= 2e-3 * max(1.0, float(want.abs().max())), (oh, ow, acc)
+    # dropout
+    n = B * H * W * C
+    ones = torch.ones(B, H, W, C, dtype=torch.float16, device=dev)
+    out = torch.empty_like(ones)
+    L.check(lib.cvx_dropout_nhwc(L.ptr(ones), B, H * W, C, 0.1, 1234, L.ptr(out), 0, st), "dropout")
+    vals = out.float().cpu().flatten()
+    kept = vals > 0
+    assert torch.all((vals[kept] - 1 / 0.9).abs() < 1e-3)
+    assert abs(float(kept.float().mean()) - 0.9) < 4 * (0.09 / n) ** 0.5 + 1e-9
+    out2 = torch.empty_like(ones)
+    L.check(lib.cvx_dropout_nhwc(L.ptr(ones), B, H * W, C, 0.1, 1234, L.ptr(out2), 0, st), "dropout again")
+    assert torch.equal(out, out2)                                                       # same seed, same mask (what the backward relies on)
+    L.check(lib.cvx_dropout_nhwc(L.ptr(ones), B, H * W, C, 0.1, 1235, L.ptr(out2), 0, st), "dropout other seed")
+    assert n < 64 or not torch.equal(out, out2)
+    prev = out2.clone()
+    L.check(lib.cvx_dropout_nhwc(L.ptr(ones), B, H * W, C, 0.0, 7, L.ptr(out2), 1, st), "dropout p=0 accumulate")
+    assert torch.equal(out2, (prev.float() + 1).half())                                 # p = 0 keeps everything; accumulate adds
 
 
 @pytest.mark.parametrize("B,H,W,Co", [(2, 64, 64, 16), (1, 32, 96, 32), (3, 16, 16, 48), (1, 128, 128, 80)])
