@@ -39,6 +39,7 @@ class OpDesc(C.Structure):
 
 BUF_ACT_F16, BUF_PRED_F32 = 0, 1
 OP_CONV, OP_MAXPOOL5, OP_UPSAMPLE2, OP_MAXPOOL2, OP_DWCONVT, OP_COPY, OP_MAXPOOL3S2, OP_AVGPOOL, OP_RESIZE, OP_MAXPOOL3S1, OP_L2NORM = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
+OP_DROPOUT = 12
 ACT_BN_SILU, ACT_BIAS, ACT_BN_RELU, ACT_BN_LINEAR, ACT_BIAS_RELU, ACT_BIAS_LINEAR = 1, 2, 3, 4, 5, 6
 OPF_RES_PRE_ACT = 1
 OPF_CONV_BIAS = 2
@@ -96,6 +97,10 @@ PROTOTYPES = {
     "cvx_conv2d_wgrad_nhwc": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _I64, _P]),
     "cvx_bn_silu_train_nhwc": (_I32, [_P, _I32, _I32, _I32, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
     "cvx_bn_silu_bwd_nhwc": (_I32, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _F, _P, _P, _P, _P, _I32, _P]),
+    "cvx_engine_set_seed": (_I32, [_P, _U64]),
+    "cvx_seg_loss_workspace_bytes": (_I64, [_I32, _I32, _I32, _I32]),
+    "cvx_seg_loss": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I32, _F, _F, _I64, _F, _P, _P, _P, _P, _P]),
+    "cvx_resize_bilinear_nchw_grad_to_rows": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _P, _I32, _P]),
     "cvx_maxpool3_train_nhwc": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
     "cvx_maxpool3_bwd_nhwc": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P]),
     "cvx_avgpool_global_bwd_nhwc": (_I32, [_P, _I32, _I32, _I32, _P, _I32, _P]),

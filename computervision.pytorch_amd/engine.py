@@ -48,6 +48,12 @@ class Engine:
     def set_bn(self, eps: float, momentum: float):
         L.check(self.lib.cvx_engine_set_bn(self.handle, eps, momentum), "cvx_engine_set_bn")
 
+    def set_seed(self, seed: int):
+        """Seed of the graph's dropout masks (nn.Dropout layers of the reference model; torch.manual_seed there)."""
+        if seed != getattr(self, "_seed", None):
+            L.check(self.lib.cvx_engine_set_seed(self.handle, int(seed) & (2 ** 64 - 1)), "cvx_engine_set_seed")
+            self._seed = seed
+
     def forward(self, images: torch.Tensor, training: bool, pred: Optional[torch.Tensor] = None) -> torch.Tensor:
         _need_gpu(images, "images")
         images = images.contiguous().float()

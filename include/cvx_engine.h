@@ -335,6 +335,26 @@ int cvx_l2norm_nhwc(const void* x_f16, const float* weight, int32_t batch, int32
  * Replaces: F.interpolate(x, size=input_shape, mode="bilinear", align_corners=False), core/models/deeplabv3plus.py:147. */
 int cvx_resize_bilinear_rows_to_nchw(const float* rows_f32, int32_t ld, int32_t batch, int32_t c, int32_t ih, int32_t iw, int32_t oh, int32_t ow,
                                      float* out_nchw, void* hip_stream);
+/* Segmentation loss with its gradient, for the DeepLabv3+ step.  rows: the engine's fp32 logits rows (batch, ih*iw, ld) at decoder
+ * resolution; target: (batch, oh, ow) int64 class indices at label resolution (= the network input size).  Per label pixel the nc
+ * logits are interpolated bilinearly (align_corners = False, deeplabv3plus.py:147), then
+ *   mode 0: focal loss  alpha * (1 - pt)^gamma * ce, pt = exp(-ce), mean over ALL batch*oh*ow pixels (focal_loss.py:14-22;
+ *           ignored pixels contribute 0 to the sum and count in the mean, like the reference's .mean());
+ *   mode 1: cross-entropy, mean over the non-ignored pixels (nn.CrossEntropyLoss(reduction="mean"), segmentation_2d.py:61).
+ * loss_out: 1 float (device).  dpred: (batch, ih*iw, ld) fp16 = loss_scale * dLoss/drows (columns nc..ld-1 zero) -- the operand of
+ * cvx_engine_backward.  bad_target: 1 int32 (device), set non-zero when a label is neither ignore_index nor in [0, nc) (torch
+ * raises a device assert there; the pixel is skipped).  workspace: cvx_seg_loss_workspace_bytes() bytes.  Asynchronous on hip_stream.
+ * Replaces: F.interpolate + FocalLoss.forward / nn.CrossEntropyLoss + loss.backward() down to the classifier's output,
+ * core/trainer/segmentation_trainer.py:121-130. */
+int64_t cvx_seg_loss_workspace_bytes(int32_t batch, int32_t nc, int32_t oh, int32_t ow);
+int cvx_seg_loss(const float* rows_f32, int32_t ld, int32_t batch, int32_t nc, int32_t ih, int32_t iw, int32_t oh, int32_t ow,
+                 const int64_t* target, int32_t mode, float alpha, float gamma, int64_t ignore_index, float loss_scale, float* loss_out,
+                 void* dpred_f16, int32_t* bad_target, void* workspace, void* hip_stream);
+/* Adjoint of cvx_resize_bilinear_rows_to_nchw: a gradient w.r.t. the full-resolution logits (batch, nc, oh, ow) fp32 -> scale * the
+ * gradient w.r.t. the rows (batch, ih*iw, ld) fp16 (a deterministic gather).  For callers that compute their own loss on the
+ * model's NCHW output.  Asynchronous on hip_stream. */
+int cvx_resize_bilinear_nchw_grad_to_rows(const float* grad_nchw, int32_t batch, int32_t nc, int32_t ih, int32_t iw, int32_t oh, int32_t ow,
+                                          float scale, void* dpred_f16, int32_t ld, void* hip_stream);
 /* Training forms of the ResNet / DeepLab pooling and resampling ops (dense NHWC fp16; they synchronise before returning):
  *   cvx_maxpool3_train_nhwc: the 3x3 / pad 1 / stride 1 | 2 max pool that also stores `argmax` (one byte per OUTPUT element, the
  *     window tap dy*3+dx of the first maximum in row-major scan order = torch's choice); cvx_maxpool3_bwd_nhwc routes gout through it

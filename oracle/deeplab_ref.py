@@ -1,4 +1,4 @@
-"""CPU oracle for DeepLabv3+ (ResNet-101, output stride 16) inference -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+"""CPU oracle for DeepLabv3+ (ResNet-101, output stride 16), inference and one training step -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
 
 SURVEY.md section 8 row a19 / (f)2.  A torch-CPU fp32 restatement, functional over a flat ``state_dict`` with the
 reference's keys (``backbone.conv1...``, ``backbone.layerN.M...``, ``classifier.project...``, ``classifier.aspp...``,
@@ -11,9 +11,15 @@ reference's keys (``backbone.conv1...``, ``backbone.layerN.M...``, ``classifier.
   pooling; concat; 1x1 projection; Dropout = identity in eval), decoder (48-channel low-level projection, bilinear resize of
   the ASPP output, concat, 3x3, 1x1 + bias) and the final bilinear resize to the input size (``align_corners=False``).
 
+Training (``forward(train=True)``, ``focal_loss``, ``loss_and_grads``): the same graph with batch-statistics BatchNorm
+(running statistics updated in place, momentum 0.1, unbiased variance), ``Dropout(0.1)`` after the ASPP projection as a
+caller-supplied keep mask (deeplabv3plus.py:67), FocalLoss (core/loss/focal_loss.py:6-22) / nn.CrossEntropyLoss
+(core/algorithms/segmentation_2d.py:59-64); the gradients are torch autograd's over this restatement.
+
 Parity pin: ``oracle/make_golden.py`` imports the real reference in the build container and asserts that
-``init_state_dict`` reproduces ``DeeplabV3Plus(21, 16, pretrained_backbone=False)`` under seed 0 bit for bit and that
-``forward`` matches its eval-mode output to fp32 round-off, then writes ``tests/golden/deeplab_*``.
+``init_state_dict`` reproduces ``DeeplabV3Plus(21, 16, pretrained_backbone=False)`` under seed 0 bit for bit, that
+``forward`` matches its eval-mode output to fp32 round-off, and that ``loss_and_grads`` matches the loss and every parameter
+gradient of one reference training step (model.train(), FocalLoss(), loss.backward()), then writes ``tests/golden/deeplab_*``.
 """
 from __future__ import annotations
 
@@ -118,7 +124,14 @@ FP16_STORAGE = [False]
 
 
 def _q(t):
-    return t.half().float() if FP16_STORAGE[0] else t
+    if not FP16_STORAGE[0]:
+        return t
+    if t.requires_grad:                       # straight-through: the value is rounded, the gradient passes unrounded
+        return t + (t.detach().half().float() - t.detach())
+    return t.half().float()
+
+
+TRAIN = [False]                               # set by forward(train=True): batch statistics + running-statistics update
 
 
 def _conv_bn(sd, key, x, stride=1, dil=1, act=True, res=None):
@@ -126,15 +139,25 @@ def _conv_bn(sd, key, x, stride=1, dil=1, act=True, res=None):
     k = w.shape[-1]
     y = F.conv2d(_q(x), _q(w), None, stride, dil * (k // 2), dil)
     bk = _bn_key(key)
-    y = F.batch_norm(y, sd[bk + ".running_mean"], sd[bk + ".running_var"], sd[bk + ".weight"], sd[bk + ".bias"], False, 0.1, BN_EPS)
+    y = F.batch_norm(y, sd[bk + ".running_mean"], sd[bk + ".running_var"], sd[bk + ".weight"], sd[bk + ".bias"], TRAIN[0], 0.1, BN_EPS)
     if res is not None:
         y = y + res
     return _q(F.relu(y) if act else y)
 
 
-def forward(sd, x, nc: int = 21, return_rows: bool = False):
-    """Eval-mode forward: (B,3,H,W) fp32 -> (B,nc,H,W) fp32 logits (deeplabv3plus.py:142-148).  ``return_rows``: also the
-    logits at the decoder's resolution, NHWC (B, h, w, nc) -- what the engine's last convolution writes."""
+def forward(sd, x, nc: int = 21, return_rows: bool = False, train: bool = False, keep_mask=None, dropout_p: float = 0.1):
+    """(B,3,H,W) fp32 -> (B,nc,H,W) fp32 logits (deeplabv3plus.py:142-148).  ``return_rows``: also the logits at the decoder's
+    resolution, NHWC (B, h, w, nc) -- what the engine's last convolution writes.  ``train``: batch-statistics BatchNorm (the
+    running statistics in ``sd`` are updated in place) and dropout after the ASPP projection with ``keep_mask`` (B, 256, h, w)
+    of 0/1 -- None = no dropout (p = 0)."""
+    TRAIN[0] = bool(train)
+    try:
+        return _forward(sd, x, nc, return_rows, keep_mask if train else None, dropout_p)
+    finally:
+        TRAIN[0] = False
+
+
+def _forward(sd, x, nc, return_rows, keep_mask, dropout_p):
     H, W = x.shape[-2:]
     y = _conv_bn(sd, "backbone.conv1", x, stride=2)
     y = F.max_pool2d(y, 3, 2, 1)
@@ -154,9 +177,31 @@ def forward(sd, x, nc: int = 21, return_rows: bool = False):
     pooled = _conv_bn(sd, c + "aspp.convs.4.1", pooled)
     br.append(_q(F.interpolate(pooled, size=y.shape[-2:], mode="bilinear", align_corners=False)))
     a = _conv_bn(sd, c + "aspp.project.0", torch.cat(br, 1))
+    if keep_mask is not None:                                    # nn.Dropout(0.1) in training mode (deeplabv3plus.py:67)
+        a = _q(a * keep_mask / (1.0 - dropout_p))
     lowp = _conv_bn(sd, c + "project.0", low)
     a = _q(F.interpolate(a, size=lowp.shape[-2:], mode="bilinear", align_corners=False))
     h = _conv_bn(sd, c + "classifier.0", torch.cat([lowp, a], 1))
     logits = F.conv2d(_q(h), _q(sd[c + "classifier.3.weight"]), sd[c + "classifier.3.bias"])
     out = F.interpolate(logits, size=(H, W), mode="bilinear", align_corners=False)
     return (out, logits.permute(0, 2, 3, 1).contiguous()) if return_rows else out
+
+
+def focal_loss(logits, target, alpha: float = 0.25, gamma: float = 2.0, ignore_index: int = -100):
+    """FocalLoss.forward (core/loss/focal_loss.py:14-22), size_average=True."""
+    ce = F.cross_entropy(logits, target, ignore_index=ignore_index, reduction="none")
+    pt = torch.exp(-ce)
+    return (alpha * (1 - pt) ** gamma * ce).mean()
+
+
+def loss_and_grads(sd, x, target, nc: int = 21, loss_type: str = "focal", keep_mask=None, dropout_p: float = 0.1):
+    """One training step's loss and parameter gradients (segmentation_trainer.py:121-130 without the optimiser): returns
+    (loss, {key: grad}, rows (B, h, w, nc)); running statistics in ``sd`` are updated in place."""
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()
+              if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var"))}
+    work = dict(sd)
+    work.update(params)
+    out, rows = forward(work, x, nc, return_rows=True, train=True, keep_mask=keep_mask, dropout_p=dropout_p)
+    loss = focal_loss(out, target) if loss_type == "focal" else F.cross_entropy(out, target, reduction="mean")
+    loss.backward()
+    return loss.detach(), {k: p.grad for k, p in params.items()}, rows.detach()
