@@ -454,13 +454,15 @@ class _SegFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, images, anchor, model):
         ctx.model = model
+        ctx.set_materialize_grads(False)      # the fused SegLoss hands no gradient to the logits: then there is nothing to do here
         rows = model._run_forward(images, training=True)
         model.last_rows = rows
         return model.rows_to_nchw(rows, int(images.shape[2]), int(images.shape[3]))
 
     @staticmethod
     def backward(ctx, g):
-        ctx.model._backward_from_nchw(g)
+        if g is not None:
+            ctx.model._backward_from_nchw(g)
         return None, None, None
 
 
@@ -471,6 +473,7 @@ class _SegLossFn(torch.autograd.Function):
     def forward(ctx, logits, owner, rows, model, target, hw):
         loss, dpred = owner.op(rows, target, hw, model.loss_scale)
         ctx.model, ctx.dpred = model, dpred
+        model.last_dpred = dpred
         return loss.reshape(())
 
     @staticmethod
@@ -497,7 +500,12 @@ class SegLoss:
         self._dpred = None
         self._bad = None
 
-    def op(self, rows: torch.Tensor, target: torch.Tensor, hw, loss_scale: float, dpred: Optional[torch.Tensor] = None):
+    def bad_targets(self) -> bool:
+        """True when the last call saw a label that is neither ignore_index nor a class (synchronises)."""
+        return self._bad is not None and int(self._bad.item()) != 0
+
+    def op(self, rows: torch.Tensor, target: torch.Tensor, hw, loss_scale: float, dpred: Optional[torch.Tensor] = None,
+           check: Optional[bool] = None):
         """rows (B, lh*lw, ld) fp32, target (B, H, W) int64, hw = (lh, lw) -> (loss (1,), dpred (B, lh*lw, ld) fp16)."""
         if rows.device.type != "cuda":
             raise L.CvxError("SegLoss runs on an MI355X only (there is no CPU path)")
@@ -519,7 +527,7 @@ class SegLoss:
         L.check(lib.cvx_seg_loss(L.ptr(rows), ld, B, nc, lh, lw, H, W, L.ptr(target), self.mode, self.alpha, self.gamma, self.ignore_index,
                                  float(loss_scale), L.ptr(loss), L.ptr(dpred), L.ptr(self._bad), L.ptr(self._ws), L.stream_ptr(rows.device)),
                 "cvx_seg_loss")
-        if self.check_targets and int(self._bad.item()) != 0:
+        if (self.check_targets if check is None else check) and self.bad_targets():
             raise L.CvxError("SegLoss: a target label is neither ignore_index nor in [0, num_classes)")
         return loss, dpred
 
@@ -567,7 +575,7 @@ class SegTrainStep:
         scale = self.scaler.begin_step() if self.scaler is not None else m.loss_scale
         rows = m._run_forward(images, True, self._pred)
         crit.nc = m.num_classes
-        loss, dpred = crit.op(rows, targets, (lh, lw), scale, self._dpred)
+        loss, dpred = crit.op(rows, targets, (lh, lw), scale, self._dpred, check=False)   # no host sync in the step: crit.bad_targets() polls
         eng.backward(dpred, scale)
         if self.distributed and dev.type == "cuda":
             if self._side is None:

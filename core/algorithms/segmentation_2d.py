@@ -1,8 +1,7 @@
 """DeepLabv3+ algorithm wrapper -- the duck-typed interface of the reference's ``DeeplabV3PlusA``
-(core/algorithms/segmentation_2d.py:43-201) for the INFERENCE path: ``__init__(cfg, device)``,
-``build_model() -> (nn.Module, name)``, ``postprocess_seg2d`` (argmax -> colour map), ``predict``.  The network runs on the
-MI355X engine (``computervision.pytorch_amd.deeplab``); the loss (FocalLoss) and the training path are not built this round
-(``build_loss`` raises).
+(core/algorithms/segmentation_2d.py:43-201): ``__init__(cfg, device)``, ``build_model() -> (nn.Module, name)``,
+``build_loss()`` (FocalLoss / CrossEntropyLoss, :59-64, as the engine's fused ``SegLoss``), ``postprocess_seg2d`` (argmax ->
+colour map), ``predict``.  The network runs on the MI355X engine (``computervision.pytorch_amd.deeplab``).
 """
 import os
 
@@ -10,7 +9,7 @@ import numpy as np
 import torch
 
 from computervision.pytorch_amd import _lib as L
-from computervision.pytorch_amd.deeplab import DeepLabV3PlusR101
+from computervision.pytorch_amd.deeplab import DeepLabV3PlusR101, SegLoss
 from configs import DeeplabV3PlusConfig
 from registry import model_registry
 
@@ -57,7 +56,11 @@ class DeeplabV3PlusA:
         return DeepLabV3PlusR101(self.num_classes), "deeplabv3plus"
 
     def build_loss(self):
-        raise L.CvxError("DeepLabv3+ training (FocalLoss, core/loss/focal_loss.py) is not built on the MI355X engine yet: inference only")
+        """Reference :59-64: "ce" -> nn.CrossEntropyLoss(reduction="mean"), "focal" -> FocalLoss() (alpha 0.25, gamma 2,
+        ignore_index -100, mean over all pixels; core/loss/focal_loss.py:6-22)."""
+        if self.loss_type not in ("ce", "focal"):
+            raise L.CvxError(f"loss_type {self.loss_type!r}: the reference knows 'ce' and 'focal'")
+        return SegLoss(self.loss_type)
 
     def predict_tensor(self, model, images: torch.Tensor):
         """(B,3,H,W) normalised images on the device -> (B,H,W,3) class colours (the tensor part of ``predict``)."""

@@ -74,6 +74,80 @@ def _import_reference():
     return builder
 
 
+def deeplab_train_section(builder, report):
+    """10b. DeepLabv3+ training step (BASELINE configs[5]): the REAL reference model in train mode, FocalLoss(), loss.backward()
+    (core/trainer/segmentation_trainer.py:121-130 without the optimiser) -> loss, every parameter gradient, updated running
+    statistics.  Asserts the oracle's restatement (deeplab_ref.loss_and_grads) against all of them, then writes the fixture:
+    inputs, loss, logits rows, per-tensor gradient norms / sums, a handful of gradient tensors in full."""
+    from oracle import deeplab_ref as D
+    dcfg, dalgo_cls, _ = builder.export_from_registry("deeplabv3plus")
+    torch.manual_seed(0)
+    algo = dalgo_cls(dcfg, torch.device("cpu"))
+    dmodel, _ = algo.build_model()
+    crit = algo.build_loss()
+    assert type(crit).__name__ == "FocalLoss"
+    GAMMA3 = 0.1                                                 # conditioning of section 10 (unit bn3 weights make a random-init R101 chaotic)
+    with torch.no_grad():
+        for k_, v_ in dmodel.named_parameters():
+            if k_.endswith(".bn3.weight"):
+                v_.fill_(GAMMA3)
+    sd0 = {k: v.clone() for k, v in dmodel.state_dict().items()}
+    B, H, W = 2, 97, 129
+    g = torch.Generator().manual_seed(77)
+    x = torch.rand(B, 3, H, W, generator=g)
+    t = torch.randint(0, dcfg.dataset.num_classes, (B, H, W), generator=g)
+    t[torch.rand(B, H, W, generator=g) < 0.1] = -100             # FocalLoss's ignore_index
+    dmodel.train()
+    drop = [m_ for m_ in dmodel.modules() if isinstance(m_, torch.nn.Dropout)]
+    assert len(drop) == 1 and drop[0].p == 0.1
+    drop[0].p = 0.0                                              # the mask is a draw of the caller's RNG: the fixture runs without it
+    rows_ref = []
+    hook = dmodel.classifier.classifier.register_forward_hook(lambda m_, i_, o_: rows_ref.append(o_.detach()))
+    loss = crit(dmodel(x.clone()), t)
+    hook.remove()
+    loss.backward()
+    ref_grads = {k: p.grad.clone() for k, p in dmodel.named_parameters()}
+    ref_sd = dmodel.state_dict()
+    my_loss, my_grads, my_rows = D.loss_and_grads({k: v.clone() for k, v in sd0.items()}, x.clone(), t, dcfg.dataset.num_classes)
+    assert abs(float(my_loss) - float(loss)) < 1e-6 * abs(float(loss)), (float(my_loss), float(loss))
+    assert torch.allclose(my_rows, rows_ref[0].permute(0, 2, 3, 1), rtol=1e-4, atol=1e-5)
+    worst = 0.0
+    for k, gr in ref_grads.items():
+        e = float((my_grads[k] - gr).norm() / gr.norm().clamp_min(1e-30))
+        worst = max(worst, e)
+        assert e < 1e-4, (k, e)
+    # a second pass with dropout ON and the reference's own mask captured: pins the oracle's keep_mask semantics
+    drop[0].p = 0.1
+    masks = []
+    hk = drop[0].register_forward_hook(lambda m_, i_, o_: masks.append((o_ != 0) | (i_[0] == 0)))
+    dmodel.load_state_dict(sd0)
+    dmodel.zero_grad()
+    torch.manual_seed(123)
+    loss_d = crit(dmodel(x.clone()), t)
+    hk.remove()
+    loss_d.backward()
+    keep = masks[0].float()
+    my_loss_d, my_grads_d, _ = D.loss_and_grads({k: v.clone() for k, v in sd0.items()}, x.clone(), t, dcfg.dataset.num_classes, keep_mask=keep)
+    assert abs(float(my_loss_d) - float(loss_d)) < 1e-6 * abs(float(loss_d))
+    kd = "classifier.aspp.project.0.weight"
+    assert float((my_grads_d[kd] - dmodel.state_dict(keep_vars=True)[kd].grad).norm() / my_grads_d[kd].norm()) < 1e-4
+    full = ["classifier.classifier.3.weight", "classifier.classifier.3.bias", "classifier.classifier.1.weight", "classifier.aspp.convs.4.2.weight",
+            "classifier.project.1.bias", "backbone.layer4.2.bn3.weight", "backbone.layer3.11.bn2.bias", "backbone.layer2.0.downsample.1.weight",
+            "backbone.layer1.0.bn1.bias", "backbone.bn1.weight", "backbone.bn1.bias", "backbone.conv1.weight"]
+    keys = list(ref_grads.keys())
+    stat_keys = ["backbone.bn1.running_mean", "backbone.bn1.running_var", "backbone.layer4.2.bn3.running_var", "classifier.aspp.convs.4.2.running_mean",
+                 "classifier.classifier.1.running_var"]
+    np.savez_compressed(os.path.join(GOLD, "deeplab_train_97x129.npz"), x=x.numpy(), target=t.numpy().astype(np.int16), loss=np.array(float(loss)),
+                        loss_dropout=np.array(float(loss_d)), keep_mask=np.packbits(keep.numpy().astype(np.uint8)), keep_shape=np.array(keep.shape),
+                        rows=rows_ref[0].permute(0, 2, 3, 1).numpy().copy(), bn3_gamma=np.array(GAMMA3), grad_keys=np.array(keys),
+                        grad_norm=np.array([float(ref_grads[k].double().norm()) for k in keys]),
+                        grad_sum=np.array([float(ref_grads[k].double().sum()) for k in keys]),
+                        stat_keys=np.array(stat_keys), **{"g:" + k: ref_grads[k].numpy() for k in full},
+                        **{"s:" + k: ref_sd[k].numpy().copy() for k in stat_keys})
+    report["deeplab_train"] = dict(loss=float(loss), loss_dropout=float(loss_d), worst_grad_rel_oracle_vs_reference=worst, tensors=len(keys),
+                                   note="bn3.weight = 0.1; dropout p = 0 (second pass: p = 0.1 with the reference's captured mask)")
+
+
 def main():
     sys.path.insert(0, ROOT)
     from oracle import yolov8_ref as O
@@ -402,6 +476,8 @@ def main():
     report["deeplab"] = dict(init="bit-exact, %d tensors" % len(ref_sd), params=int(sum(p_.numel() for p_ in dmodel.parameters())),
                              out_absmax=float(ref_out.abs().max()), rows_shape=list(my_rows.shape))
 
+    deeplab_train_section(builder, report)
+
     # ---- 11. YOLOv7-l: init, eval forward on a calibrated network, decode, NMS bookkeeping ------------
     from oracle import yolov7_ref as Y7
     ycfg, yalgo_cls, _ = builder.export_from_registry("yolo7")
@@ -559,5 +635,25 @@ def main():
     print(json.dumps(report, indent=1))
 
 
+def only(section):
+    """python oracle/make_golden.py deeplab_train: regenerate one fixture, merge its entry into PIN_REPORT.json."""
+    sys.path.insert(0, ROOT)
+    import oracle  # noqa: the package stays importable after the reference takes over sys.path
+    os.makedirs(GOLD, exist_ok=True)
+    builder = _import_reference()
+    torch.set_num_threads(8)
+    report = {}
+    {"deeplab_train": deeplab_train_section}[section](builder, report)
+    path = os.path.join(GOLD, "PIN_REPORT.json")
+    full = json.load(open(path)) if os.path.exists(path) else {}
+    full.update(report)
+    with open(path, "w") as f:
+        json.dump(full, f, indent=1)
+    print(json.dumps(report, indent=1))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        only(sys.argv[1])
+        sys.exit(0)
     main()

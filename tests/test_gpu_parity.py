@@ -1285,13 +1285,66 @@ def test_deeplab_full_size_through_the_plugin_api(dev):
     assert torch.equal(out, model(x))
     col = algo.predict_tensor(model, x)
     assert tuple(col.shape) == (2, 513, 513, 3) and int(col.max()) <= 192
-    model.train()
+    assert type(algo.build_loss()).__name__ == "SegLoss"
+    cfg.loss.loss_type = "dice"
     with pytest.raises(LL.CvxError):
-        model(x)
-    with pytest.raises(LL.CvxError):
-        algo.build_loss()
-    with pytest.raises(LL.CvxError):
-        trainer_cls(cfg, dev).train()
+        algo_cls(cfg, dev).build_loss()
+
+
+def test_deeplab_trainer_at_full_size(dev):
+    """export_from_registry("deeplabv3plus") -> DeeplabV3PlusTrainer at the reference's 513 x 513 (BASELINE configs[5]; batch 4
+    here to keep the test short): a few fused steps of the reference's train_loop (segmentation_trainer.py:114-131) with dropout
+    active and GradScaler's initial scale; losses finite and falling on a repeated batch, every parameter tensor moved, BatchNorm
+    statistics updated, no overflow skip; then evaluate_loop's metrics (:133-159)."""
+    import builder
+    from core.trainer.segmentation_trainer import SyntheticSegmentationLoader
+    cfg, _, trainer_cls = builder.export_from_registry("deeplabv3plus")
+    cfg.train.batch_size = 4
+    torch.manual_seed(0)
+    loader = SyntheticSegmentationLoader(4, (513, 513), 21, length=2, seed=3)
+    tr = trainer_cls(cfg, dev, dataloader=loader)
+    assert tr.model.dropout_p == 0.1 and tr.model.loss_scale == 65536.0
+    p0 = tr.model.flat_params.clone()
+    rv0 = tr.model.flat_stats.clone()
+    batch = next(iter(loader))
+    tr.model.train()
+    losses = [float(tr.train_loop(batch, None)[0]) for _ in range(6)]
+    torch.cuda.synchronize()
+    assert all(np.isfinite(v) for v in losses), losses
+    assert losses[-1] < losses[0], losses
+    assert not tr.criterion.bad_targets()
+    tr._step.scaler.poll()
+    assert tr._step.scaler.skipped == 0 and tr.optimizer.device_step() == 6
+    moved = [k for k, v in tr.model.layout.views(tr.model.flat_params - p0).items() if float(v.abs().max()) == 0.0 and "classifier.3" not in k]
+    assert not moved, moved[:5]
+    assert not torch.equal(tr.model.flat_stats, rv0) and int(tr.model.state_dict()["backbone.bn1.num_batches_tracked"]) == 6
+    ev = tr.evaluate_loop()
+    assert set(ev) == {"Loss", "Overall Acc", "Mean Acc", "FreqW Acc", "Mean IoU"} and np.isfinite(ev["Loss"]) and 0.0 <= ev["Mean IoU"] <= 1.0
+
+
+def test_deeplab_torch_side_loss_reaches_the_same_gradients(dev, gold):
+    """The drop-in contract of the reference's loop: ``preds = model(images)`` is an ordinary (B, 21, H, W) tensor, and ANY torch
+    loss on it (here the reference's FocalLoss formula, focal_loss.py:14-22, written with torch ops) back-propagates into the engine
+    through the adjoint of the final resize.  Same parameter gradients as the fused SegLoss path, to fp16 rounding of the
+    logits gradient (the two paths round dLoss/drows to fp16 at the same point); dropout masks repeat with the seed."""
+    from computervision.pytorch_amd.deeplab import SegLoss
+    g = gold("deeplab_train_97x129.npz")
+    x, t = torch.from_numpy(g["x"]).to(dev), torch.from_numpy(g["target"].astype(np.int64)).to(dev)
+    grads = []
+    for path in ("fused", "torch"):
+        m = _deeplab_train_model(dev, g, dropout_p=0.1)
+        m.seed = 11
+        out = m(x)
+        if path == "fused":
+            loss = SegLoss("focal")(out, t)
+        else:
+            ce = F.cross_entropy(out, t, ignore_index=-100, reduction="none")
+            loss = (0.25 * (1 - torch.exp(-ce)) ** 2 * ce).mean()
+        loss.backward()
+        grads.append((float(loss.detach()), m.flat_grads.clone(), m.flat_stats.clone()))
+    assert abs(grads[0][0] - grads[1][0]) < 1e-5 * grads[0][0]
+    assert torch.equal(grads[0][2], grads[1][2])                       # identical forward passes (same dropout mask)
+    assert rel(grads[1][1], grads[0][1]) < 5e-3, rel(grads[1][1], grads[0][1])
 
 
 # ---- YOLOv7-l, inference + decode + NMS (SURVEY 8(f)3, row a16) -----------------------------------------------------------
@@ -1474,3 +1527,235 @@ def test_ssd_forward_and_decode_match_the_reference_fixture(dev, gold):
     res = algo.decode_boxes((sloc, sconf), 240, 320)
     assert len(res) == 2 and res[0].shape[1] == 6 and np.isfinite(res[0]).all()
     assert algo.decode_boxes((loc, conf), 240, 320) == [[], []]              # the random-init network passes nothing at 0.7
+
+
+# ---- DeepLabv3+ training (BASELINE configs[5]) ---------------------------------------------------------------
+@pytest.mark.parametrize("B,ih,iw,H,W,nc,mode", [(2, 25, 33, 97, 129, 21, 0), (1, 9, 9, 33, 33, 21, 1), (3, 17, 12, 65, 45, 5, 0), (2, 33, 33, 33, 33, 19, 1)])
+def test_seg_loss_kernel_against_torch(dev, B, ih, iw, H, W, nc, mode):
+    """cvx_seg_loss (loss_seg.hip) against torch autograd in fp32: F.interpolate(bilinear, align_corners=False) of the logits rows
+    (deeplabv3plus.py:147), then FocalLoss (focal_loss.py:14-22) or nn.CrossEntropyLoss(mean) (segmentation_2d.py:61), with ignored
+    pixels; the gradient w.r.t. the low-resolution rows comes back loss-scaled in fp16.  Also the bad-label flag and the adjoint
+    resize entry point on its own."""
+    from computervision.pytorch_amd.deeplab import SegLoss
+    lib = L.load()
+    g = torch.Generator().manual_seed(B * 1000 + H + nc)
+    ld = (nc + 7) & ~7
+    rows = torch.zeros(B, ih * iw, ld)
+    rows[..., :nc] = torch.randn(B, ih * iw, nc, generator=g) * 2
+    t = torch.randint(0, nc, (B, H, W), generator=g)
+    t[torch.rand(B, H, W, generator=g) < 0.15] = -100
+    rr = rows[..., :nc].reshape(B, ih, iw, nc).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    logits = F.interpolate(rr, size=(H, W), mode="bilinear", align_corners=False)
+    if mode == 0:
+        ce = F.cross_entropy(logits, t, ignore_index=-100, reduction="none")
+        ref = (0.25 * (1 - torch.exp(-ce)) ** 2 * ce).mean()
+    else:
+        ref = F.cross_entropy(logits, t, reduction="mean")
+    ref.backward()
+    want = rr.grad.permute(0, 2, 3, 1).reshape(B, ih * iw, nc)
+    crit = SegLoss("focal" if mode == 0 else "ce")
+    crit.nc = nc
+    scale = 65536.0
+    loss, dpred = crit.op(rows.to(dev), t.to(dev), (ih, iw), scale)
+    assert abs(float(loss) - float(ref)) < 2e-5 * abs(float(ref)), (float(loss), float(ref))
+    got = dpred.float().cpu() / scale
+    assert rel(got[..., :nc], want) < 1e-3, rel(got[..., :nc], want)               # one fp16 rounding of the scaled gradient
+    assert float(got[..., nc:].abs().max()) == 0.0 if ld > nc else True
+    # labels outside [0, nc) that are not the ignore index: flagged (torch asserts on the device), the pixel is skipped
+    tb = t.clone()
+    tb[0, 0, 0] = nc + 3
+    with pytest.raises(L.CvxError):
+        crit.op(rows.to(dev), tb.to(dev), (ih, iw), scale)
+    # the adjoint of the final resize alone (callers with their own loss on the NCHW logits)
+    gl = torch.randn(B, nc, H, W, generator=g)
+    rin = rr.detach().clone().requires_grad_(True)
+    F.interpolate(rin, size=(H, W), mode="bilinear", align_corners=False).backward(gl)
+    rr2 = rin.grad
+    d2 = torch.empty(B, ih * iw, ld, dtype=torch.float16, device=dev)
+    L.check(lib.cvx_resize_bilinear_nchw_grad_to_rows(L.ptr(gl.to(dev)), B, nc, ih, iw, H, W, 0.125, L.ptr(d2), ld, L.stream_ptr(dev)), "adjoint")
+    assert rel(d2.float().cpu()[..., :nc] * 8, rr2.permute(0, 2, 3, 1).reshape(B, ih * iw, nc)) < 1e-3
+
+
+def _deeplab_train_model(dev, g, dropout_p=0.0):
+    from computervision.pytorch_amd.deeplab import DeepLabV3PlusR101
+    torch.manual_seed(0)
+    m = DeepLabV3PlusR101(21, dropout_p=dropout_p)
+    with torch.no_grad():
+        for k, v in m.state_dict().items():
+            if k.endswith(".bn3.weight"):
+                v.fill_(float(g["bn3_gamma"]))              # the fixture's conditioning (make_golden.py, section 10b)
+    return m.to(dev).train()
+
+
+def test_deeplab_training_step_matches_the_reference_fixture(dev, gold):
+    """model.train(); loss = FocalLoss()(model(x), t); loss.backward() on the engine against the REAL reference's step on the
+    fixture batch (make_golden.py section 10b): loss value, logits rows, updated running statistics, and all 338 parameter gradients.
+    The gradients of a 100-layer ReLU network cannot agree to 1e-3 between an fp16-operand forward and an fp32 one: a forward
+    perturbation of 5e-3 flips the ReLU masks of ~0.4 % of the elements in every layer, and each flip changes that element's
+    gradient by 100 % -- the reference's own arithmetic with fp16-rounded operands (the oracle's emulation, run here) differs from
+    its fp32 gradients by ~14 %.  That difference is the yardstick: the engine must stay within 1.25x of it overall and per
+    tensor, and to 1e-2 on the classifier's last layers where no mask has intervened yet.  The exactness of the backward pass
+    itself is the business of test_deeplab_per_layer_backward_on_the_engines_own_operands."""
+    from computervision.pytorch_amd.deeplab import SegLoss
+    from oracle import deeplab_ref as D
+    g = gold("deeplab_train_97x129.npz")
+    m = _deeplab_train_model(dev, g)
+    sd0 = {k: v.cpu().clone() for k, v in m.state_dict().items()}
+    x, t = torch.from_numpy(g["x"]), torch.from_numpy(g["target"].astype(np.int64))
+    crit = SegLoss("focal")
+    out = m(x.to(dev))
+    assert tuple(out.shape) == (2, 21, 97, 129)
+    loss = crit(out, t.to(dev))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-4 * float(g["loss"]), (float(loss.detach()), float(g["loss"]))
+    # the yardstick, and the full fp32 gradients (the oracle is pinned to the fixture in tests/test_oracle_golden.py)
+    _, ref_grads, ref_rows = D.loss_and_grads({k: v.clone() for k, v in sd0.items()}, x, t)
+    D.FP16_STORAGE[0] = True
+    try:
+        _, emu_grads, emu_rows = D.loss_and_grads({k: v.clone() for k, v in sd0.items()}, x, t)
+    finally:
+        D.FP16_STORAGE[0] = False
+    lh, lw = m._last_engine.graph.level_hw[0]
+    rows = m.last_rows[..., :21].reshape(2, lh, lw, 21).cpu()
+    assert rel(ref_rows, torch.from_numpy(g["rows"])) < 1e-4          # (another CPU, another summation order)
+    e_rows, y_rows = rel(rows, ref_rows), rel(emu_rows, ref_rows)
+    assert e_rows < max(1.25 * y_rows, 1e-2), (e_rows, y_rows)
+    eg = {k: p.grad.cpu() for k, p in m.named_parameters()}
+    assert list(eg.keys()) == [str(k) for k in g["grad_keys"]]
+
+    def total(a, b):
+        num = sum(float((a[k].double() - b[k].double()).pow(2).sum()) for k in b)
+        return (num / sum(float(b[k].double().pow(2).sum()) for k in b)) ** 0.5
+
+    e_tot, y_tot = total(eg, ref_grads), total(emu_grads, ref_grads)
+    dot = sum(float((eg[k].double() * ref_grads[k].double()).sum()) for k in eg)
+    cos = dot / (sum(float(eg[k].double().pow(2).sum()) for k in eg) * sum(float(ref_grads[k].double().pow(2).sum()) for k in eg)) ** 0.5
+    print(f"deeplab train: loss {float(loss.detach()):.6f} (ref {float(g['loss']):.6f}); rows {e_rows:.2e} (yardstick {y_rows:.2e}); "
+          f"grads {e_tot:.3e} (yardstick {y_tot:.3e}), cosine {cos:.4f}")
+    assert e_tot < 1.25 * y_tot and cos > 0.985, (e_tot, y_tot, cos)
+    for k in eg:
+        e, y = rel(eg[k], ref_grads[k]), rel(emu_grads[k], ref_grads[k])
+        assert e < max(1.6 * y, 2e-2), (k, e, y)
+    for k in ("classifier.classifier.3.weight", "classifier.classifier.3.bias", "classifier.classifier.1.weight"):
+        assert rel(eg[k], torch.from_numpy(g["g:" + k])) < 1e-2, (k, rel(eg[k], torch.from_numpy(g["g:" + k])))
+    sdm = m.state_dict()
+    for k in [str(k) for k in g["stat_keys"]]:
+        assert rel(sdm[k].cpu(), torch.from_numpy(g["s:" + k])) < 2e-2, k
+    assert int(sdm["backbone.bn1.num_batches_tracked"]) == 1
+
+
+def test_deeplab_per_layer_backward_on_the_engines_own_operands(dev, gold):
+    """Every op of the DeepLabv3+ backward pass against fp64 on the ENGINE'S OWN operands (cvx_engine_debug_copy): for each
+    Conv + BatchNorm block its xhat, its fp16 output (ReLU mask), the gradient g arriving at its output and the gradient dy it hands
+    on -> dgamma / dbeta (2e-6), dy (one fp16 rounding), the weight gradient conv_wgrad(x, dy) incl. the 7x7 stem on the NHWC image
+    copy, the dilated 3x3 and the 1x1 stride-2 downsample (5e-4: fp32 MFMA accumulation of fp16 products); for each activation
+    buffer the gradient it ends up with = the sum over ALL its consumers (data gradients of convolutions, residual branches
+    taking dz, max pool / average pool / resize / dropout backward), each recomputed in fp64 from that consumer's own operands
+    (2e-3: one fp16 rounding per accumulation).  Together with the unit tests this pins the backward pass op by op, which
+    the end-to-end comparison (mask flips) cannot."""
+    from computervision.pytorch_amd.deeplab import SegLoss
+    g = gold("deeplab_train_97x129.npz")
+    m = _deeplab_train_model(dev, g, dropout_p=0.1)
+    m.seed = 5
+    x, t = torch.from_numpy(g["x"]), torch.from_numpy(g["target"].astype(np.int64))
+    B = x.shape[0]
+    crit = SegLoss("focal")
+    loss = crit(m(x.to(dev)), t.to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+    eng, lay, scale = m._last_engine, m.layout, m.loss_scale
+    gr = eng.graph
+    P, G = m.flat_params.double().cpu(), m.flat_grads.double().cpu()
+
+    def act(view, grad=False):                              # (B, h, w, c) fp64 slice of an engine buffer
+        b, off, c = view[0], view[1], view[2]
+        h, w, cc, _ = gr.bufs[b]
+        return eng.read_buffer(b, B, grad=grad).double().cpu().reshape(B, h, w, cc)[..., off:off + c]
+
+    nchw = lambda a: a.permute(0, 3, 1, 2).contiguous()     # noqa: E731
+    nhwc = lambda a: a.permute(0, 2, 3, 1).contiguous()     # noqa: E731
+    expect, unknown = {}, {}                                # buffer slice -> summed fp64 input-gradient contributions
+
+    def add(view, contrib):
+        key = (view[0], view[1], view[2])
+        expect[key] = contrib if key not in expect else expect[key] + contrib
+
+    lh, lw = gr.level_hw[0]
+    n_w = n_bn = 0
+    for i, o in enumerate(gr.ops):
+        typ = o["type"]
+        if typ == L.OP_CONV:
+            cs = lay.convs[o["name"]]
+            C, cin, k = cs["cout_eng"], cs["cin"], cs["k"]
+            xin = act(o["in"])[..., :cin]
+            wq = P[cs["w_off"]:cs["w_off"] + C * k * k * cin].reshape(C, k, k, cin).permute(0, 3, 1, 2).float().half().double()
+            if o["act"] == L.ACT_BIAS:
+                dy = m.last_dpred.double().cpu().reshape(B, lh, lw, C)      # the loss kernel's output: loss_scale * dLoss/drows
+                want_b = dy.reshape(-1, C).sum(0) / scale
+                assert rel(G[cs["bias_off"]:cs["bias_off"] + C][:lay.nc], want_b[:lay.nc]) < 1e-5, o["name"]
+            else:
+                xh = eng.read_layer(i, B, "xhat").double().cpu().reshape(-1, C)
+                dy = eng.read_layer(i, B, "dy").double().cpu().reshape(B, o["oh"], o["ow"], C)
+                gout = act(o["out"], grad=True).reshape(-1, C)
+                fo = act(o["out"]).reshape(-1, C)
+                dz = gout * (fo > 0) if o["act"] == L.ACT_BN_RELU else gout
+                ga = P[cs["gamma_off"]:cs["gamma_off"] + C]
+                want_g, want_b = (dz * xh).sum(0) / scale, dz.sum(0) / scale
+                got_g, got_b = G[cs["gamma_off"]:cs["gamma_off"] + C], G[cs["beta_off"]:cs["beta_off"] + C]
+                assert rel(got_g, want_g) < 2e-6 and rel(got_b, want_b) < 2e-6, (o["name"], rel(got_g, want_g), rel(got_b, want_b))
+                core = dz - dz.mean(0) - xh * (dz * xh).mean(0)
+                gi = (dy.reshape(-1, C) * core).sum(0) / (core * core).sum(0).clamp_min(1e-300)
+                rms = float(dy.pow(2).mean().sqrt())
+                e_dy = rel(dy.reshape(-1, C), core * gi)
+                assert e_dy < 1e-3 + 6e-8 / max(rms, 1e-30), (o["name"], e_dy, rms)
+                assert float((gi * ga).min()) >= 0.0, o["name"]          # gi = gamma * invstd: the sign of gamma
+                if "res" in o:                                            # Bottleneck: the identity branch receives dz (pre-activation residual)
+                    add(o["res"], dz.reshape(B, o["oh"], o["ow"], C))
+                n_bn += 1
+            # weight gradient on the layer's own operands
+            xr = nchw(xin).requires_grad_(o.get("needs_dgrad", 1) == 1)
+            wr = wq.clone().requires_grad_(True)
+            y = F.conv2d(xr, wr, None, o["stride"], o["pad"], o["dil"])
+            y.backward(nchw(dy))
+            got_w = G[cs["w_off"]:cs["w_off"] + C * k * k * cin].reshape(C, k, k, cin).permute(0, 3, 1, 2)
+            want_w = wr.grad / scale
+            if float(want_w.norm()) > 0:
+                assert rel(got_w, want_w) < 5e-4, (o["name"], rel(got_w, want_w))
+                n_w += 1
+            if xr.requires_grad:
+                add(o["in"], nhwc(xr.grad))
+            continue
+        xin = nchw(act(o["in"])).requires_grad_(True)
+        gout = nchw(act(o["out"], grad=True))
+        if typ == L.OP_MAXPOOL3S2:
+            y = F.max_pool2d(xin, 3, 2, 1)
+        elif typ == L.OP_AVGPOOL:
+            y = F.adaptive_avg_pool2d(xin, 1)
+        elif typ == L.OP_RESIZE:
+            y = F.interpolate(xin, size=(o["oh"], o["ow"]), mode="bilinear", align_corners=False)
+        elif typ == L.OP_DROPOUT:
+            out = nchw(act(o["out"]))
+            keep = (out != 0) | (xin.detach() == 0)
+            nz = xin.detach() != 0
+            frac = float((out[nz] == 0).double().mean())
+            assert 0.08 < frac < 0.12, frac                                                  # p = 0.1 of the non-zero elements dropped
+            assert rel(out, xin.detach() * keep / 0.9) < 1e-3                                # inverted scaling, one fp16 rounding
+            y = xin * keep / 0.9
+            unknown[(o["in"][0], o["in"][1], o["in"][2])] = nhwc(~nz)                         # the mask is not observable where the input is 0
+        else:
+            raise AssertionError(f"op type {typ} in the DeepLab graph")
+        y.backward(gout)
+        add(o["in"], nhwc(xin.grad))
+    assert n_w >= 100 and n_bn >= 100, (n_w, n_bn)
+    checked = 0
+    for (b, off, c), want in expect.items():
+        if b == gr.image_buf:
+            continue
+        got = act((b, off, c), grad=True)
+        if (b, off, c) in unknown:
+            want = torch.where(unknown[(b, off, c)], got, want)
+        rms = float(want.pow(2).mean().sqrt())
+        e = rel(got, want)
+        assert e < 2e-3 + 6e-8 / max(rms, 1e-30), (b, off, c, e, rms)
+        checked += 1
+    assert checked >= 100
