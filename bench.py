@@ -167,8 +167,7 @@ DEEPLAB_GFLOP_PER_IMG = 166.0   # DeepLabv3+ R101 @
 
 def deeplab_main(args):
     """images/sec of DeepLabv3+ ResNet-101 INFERENCE (engine forward + final bilinear resize to (B, 21, 513, 513)) on synthetic
-    513x513 batches of 16 (BASELINE.json configs[4] is the TRAIN step of this model: the training path is not built yet, this is
-    its forward half); one process per GPU, images sharded with no exchange."""
+    513x513 batches of 16 (the forward half of BASELINE.json configs[5]; `--workload deeplab_train` is the train step); one process per GPU, images sharded with no exchange."""
     rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     import torch.distributed as dist
     dev = torch.device("cuda", local_rank)
@@ -238,6 +237,87 @@ def deeplab_main(args):
                            "frac_of_mfma_peak": round(value / world * DEEPLAB_GFLOP_PER_IMG / 1e3 / MFMA_FP16_PEAK_TFLOPS, 5)},
             "kernel_classes": {k: {"ms_per_step": round(v["ms"] / 3, 4), "launches_per_step": v["launches"] // 3} for k, v in prof.items() if v["launches"]},
             "output_shape": list(out.shape), "engine_workspace_gib": round(eng.workspace_bytes() / 2 ** 30, 3)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def deeplab_train_main(args):
+    """images/sec of the DeepLabv3+ ResNet-101 TRAIN step (BASELINE.json configs[5]: 513x513, batch 16 per GPU, FocalLoss, Adam,
+    mixed precision): engine forward (batch-statistics BN, dropout) + cvx_seg_loss + engine backward + [RCCL gradient sum] + fused
+    Adam with the GradScaler check -- the reference's train_loop (segmentation_trainer.py:114-131).  One process per GPU, a batch per
+    rank, gradients summed over the ranks after the backward pass."""
+    rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    import torch.distributed as dist
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29536")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    import builder
+    from core.trainer.segmentation_trainer import SyntheticSegmentationLoader
+    cfg, _, trainer_cls = builder.export_from_registry("deeplabv3plus")
+    B = args.batch if args.batch != 32 else cfg.train.batch_size
+    cfg.train.batch_size = B
+    H, W = cfg.arch.input_size[1:]
+    torch.manual_seed(0)
+    tr = trainer_cls(cfg, dev, dataloader=SyntheticSegmentationLoader(B, (H, W), cfg.dataset.num_classes, length=1, seed=1 + rank))
+    tr.model.train()
+    images, targets = next(iter(tr.train_dataloader))
+    batch = (images.to(dev), targets.to(dev))
+
+    def step():
+        return tr.train_loop(batch, None)[0]
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(max(args.warmup, 1)):
+        loss = step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    eng = tr.model._last_engine
+    eng.profile(True)
+    for _ in range(2):
+        step()
+    sync()
+    prof = eng.profile_read()
+    eng.profile(False)
+    tr._step.scaler.poll()
+    if rank == 0:
+        value = B * world * args.steps / elapsed
+        classes = ("conv_fwd", "conv_dgrad", "conv_wgrad")
+        ms = sum(prof[k]["ms"] for k in classes)
+        fl = sum(prof[k]["flops"] for k in classes)
+        tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        launches = sum(prof[k]["launches"] for k in classes)
+        step_tf = value / world * 3 * DEEPLAB_GFLOP_PER_IMG / 1e3
+        print(json.dumps({
+            "metric": "images/sec 513x513 DeepLabv3+ R101 train", "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"DeepLabv3+ ResNet-101 (output stride 16, nc 21) train step (fwd + focal loss + bwd + Adam, dropout 0.1, dynamic "
+                                   f"loss scale), batch {B}/GPU, {H}x{W}, random init", "global_batch": B * world, "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "kernel": "implicit-GEMM convolution launches: forward, data gradient, weight gradient",
+                         "achieved": round(tf, 3), "peak": MFMA_FP16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_FP16_PEAK_TFLOPS, 5),
+                         "traffic": None, "avg_launch_us": round(ms * 1e3 / max(launches, 1), 3), "launches_per_step": launches // 2},
+            "whole_step": {"tflops": round(step_tf, 3), "frac_of_mfma_peak": round(step_tf / MFMA_FP16_PEAK_TFLOPS, 5),
+                           "note": "3 x the forward's 2*MAC count per image (forward + data gradient + weight gradient)"},
+            "kernel_classes": {k: {"ms_per_step": round(v["ms"] / 2, 4), "launches_per_step": v["launches"] // 2,
+                                   "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 and v["flops"] > 0 else None}
+                               for k, v in prof.items() if v["launches"]},
+            "loss": round(float(loss), 5), "loss_scale": tr._step.scaler.scale, "skipped_steps": tr._step.scaler.skipped,
+            "engine_workspace_gib": round(eng.workspace_bytes() / 2 ** 30, 3)}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -406,13 +486,15 @@ def main():
     ap.add_argument("--graph", type=int, default=0, help="1: replay the step as a hipGraph (N=1 only); 0: eager stream launches (default: "
                     "measured faster -- the side-stream weight gradients overlap better than as graph branches)")
     ap.add_argument("--profile-steps", type=int, default=10, help="steps of the per-kernel HIP-event window after the timed region")
-    ap.add_argument("--workload", default="yolov8_train", choices=["yolov8_train", "centernet", "deeplab", "yolov7", "ssd"],
+    ap.add_argument("--workload", default="yolov8_train", choices=["yolov8_train", "centernet", "deeplab", "deeplab_train", "yolov7", "ssd"],
                     help="centernet: BASELINE.json configs[3] -- CenterNet DLA-34 (nc 80) 512x512 inference + heat-map decode, batch 64 per GPU")
     args = ap.parse_args()
     if args.workload == "centernet":
         return centernet_main(args)
     if args.workload == "deeplab":
         return deeplab_main(args)
+    if args.workload == "deeplab_train":
+        return deeplab_train_main(args)
     if args.workload == "yolov7":
         return yolov7_main(args)
     if args.workload == "ssd":

@@ -5,7 +5,7 @@
 // Replica slabs the reduction kernels scatter their atomics over, by channel count.  Every consumer block folds all R
 // replicas of all C channels first, so R * C is held at ~512: 16 replicas up to 32 channels, 2 from 256 channels on (the
 // fold used to be 131 KB per block at 256 channels -- more than the block's share of the tensor on the 20x20 layers).
-__host__ __device__ constexpr int cvx_stat_replicas(int C) { return C <= 32 ? 16 : C <= 64 ? 8 : C <= 128 ? 4 : 2; }
+__host__ __device__ constexpr int cvx_stat_replicas(int C) { return C <= 32 ? 16 : C <= 64 ? 8 : C <= 128 ? 4 : C <= 256 ? 2 : 1; }
 #define CVX_STAT_REPLICAS_MAX 16
 #define CVX_STAT_WORDS (2 * CVX_FIX_WORDS)  // 64-bit words per channel and replica: (value 0, value 1) x (coarse, fine)
 

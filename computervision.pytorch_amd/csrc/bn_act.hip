@@ -390,6 +390,9 @@ int cvx_stream_rows_per_block(long long M, int C, int kb_per_block) {
   const int RP = 256 / CG;
   static const int kb_env = cvx_tune_int("CVX_BN_KB", 0);
   if (kb_env > 0) kb_per_block = kb_env;
+  // wide layers (ResNet's 512..2048 channels): every block folds R*C*32 bytes of statistic slabs before it streams, so its share of
+  // the tensor must be several times that -- at least 64 rows
+  if (C > 256 && kb_per_block < C / 8) kb_per_block = C / 8;
   long long target = ((long long)kb_per_block * 1024) / (2LL * C);
   if (target < RP) target = RP;
   long long rows = ((target + RP - 1) / RP) * RP;

@@ -121,6 +121,7 @@ struct WgradParams {
   int std3x3;     // 1 when taps[t] == (t/3-1, t%3-1, wtap t), t = 0..8: the register-tile kernel (conv_wgrad_halo.hip) applies
 };
 int cvx_conv_wgrad_launch(const WgradParams& p, hipStream_t stream);
+void cvx_conv_wgrad_tile(int cout, int jtot, int* co_b, int* j_b);  // (co, j) tile the generic kernel takes for a layer
 // 3x3 stride-1 kernel with the whole (co block x 9 taps x ci block) tile in registers (conv_wgrad_halo.hip)
 bool cvx_conv_wgrad_halo_supported(const WgradParams& p);
 void cvx_conv_wgrad_halo_grid(int cout, int cin, int* gx, int* gy);

@@ -178,18 +178,43 @@ void launch_cfg(const WgradParams& p, hipStream_t st) {
 
 }  // namespace
 
+// tile of the generic kernel for a layer (the engine sizes its pixel splits and slabs with it)
+void cvx_conv_wgrad_tile(int cout, int jtot, int* co_b, int* j_b) {
+  static const int wide = cvx_tune_int("CVX_WGRAD_WIDE", 1);
+  if (cout <= 16) {
+    *co_b = 16;
+    *j_b = 192;
+  } else if (cout <= 32) {
+    *co_b = 32;
+    *j_b = 128;
+  } else if (cout % 64 != 0 && (cout % 48 == 0 || cout <= 96)) {
+    *co_b = 48;
+    *j_b = 128;
+  } else if (wide && cout % 128 == 0 && jtot >= 512) {  // ResNet-sized layers: twice the arithmetic intensity per staged byte
+    *co_b = 128;
+    *j_b = 128;
+  } else {
+    *co_b = 64;
+    *j_b = 64;
+  }
+}
+
 int cvx_conv_wgrad_launch(const WgradParams& p, hipStream_t st) {
   CVX_CHECK(p.Cin % 8 == 0 && p.x_ld % 8 == 0 && p.dy_ld % 8 == 0 && p.Cout % 8 == 0, "wgrad: channels must be multiples of 8");
   CVX_CHECK(p.cin_pad16 % 16 == 0 && p.cin_pad16 >= p.Cin, "wgrad: cin_pad16");
   CVX_CHECK(p.nsplit >= 1 && p.ntaps >= 1 && p.ntaps <= CVX_MAX_TAPS, "wgrad: nsplit/ntaps");
   CVX_CHECK(((uintptr_t)p.x % 16) == 0 && ((uintptr_t)p.dy % 16) == 0, "wgrad: operands must be 16-byte aligned");
   if (cvx_conv_wgrad_halo_supported(p)) return cvx_conv_wgrad_halo_launch(p, st);
-  if (p.Cout <= 16)
+  int co_b, j_b;
+  cvx_conv_wgrad_tile(p.Cout, p.ntaps * p.cin_pad16, &co_b, &j_b);
+  if (co_b == 16)
     launch_cfg<1, 3, 1, 4>(p, st);
-  else if (p.Cout <= 32)
+  else if (co_b == 32)
     launch_cfg<2, 2, 1, 4>(p, st);
-  else if (p.Cout % 64 != 0 && (p.Cout % 48 == 0 || p.Cout <= 96))
+  else if (co_b == 48)
     launch_cfg<3, 2, 1, 4>(p, st);
+  else if (co_b == 128)
+    launch_cfg<4, 4, 2, 2>(p, st);
   else
     launch_cfg<2, 2, 2, 2>(p, st);
   CVX_HIP(hipGetLastError());

@@ -218,7 +218,10 @@ int pick_tiles(int c) {
 
 bool cvx_conv_wgrad_halo_supported(const WgradParams& p) {
   static const bool off = cvx_tune_set("CVX_NO_WGRAD_HALO");
-  return !off && p.std3x3 && p.stride == 1 && p.ntaps == 9 && p.Cin >= 16 && p.IH == p.OH && p.IW == p.OW;
+  // wide layers (Cin * Cout >= 256 * 256) take the generic kernel's 128 x 128 tile: 3-4x faster there (DeepLabv3+ R101: 256 -> 256 at
+  // 33 x 33: 260 -> 70 us, 304 -> 256 at 129 x 129: 3.1 -> 1.0 ms); the register-tile kernel is built for YOLO's narrow layers
+  static const int max_c = cvx_tune_int("CVX_WH_MAX_C", 65535);
+  return !off && p.std3x3 && p.stride == 1 && p.ntaps == 9 && p.Cin >= 16 && p.IH == p.OH && p.IW == p.OW && (long long)p.Cin * p.Cout <= max_c;
 }
 
 // workgroups per pixel split: gx channel blocks x gy (input-channel blocks x tap groups)

@@ -225,22 +225,6 @@ ViewDesc make_view(const cvx_engine* e, const cvx_view& v, bool grad) {
   return r;
 }
 
-void wgrad_tile(int cout, int* co_b, int* j_b) {  // must mirror cvx_conv_wgrad_launch
-  if (cout <= 16) {
-    *co_b = 16;
-    *j_b = 192;
-  } else if (cout <= 32) {
-    *co_b = 32;
-    *j_b = 128;
-  } else if (cout % 64 != 0 && (cout % 48 == 0 || cout <= 96)) {
-    *co_b = 48;
-    *j_b = 128;
-  } else {
-    *co_b = 64;
-    *j_b = 64;
-  }
-}
-
 // activation kind of the BN passes / eval epilogue: 0 SiLU, 1 ReLU, 2 none
 int act_kind(const cvx_op_desc& o) { return o.act == CVX_ACT_BN_SILU ? 0 : ((o.act == CVX_ACT_BN_LINEAR || o.act == CVX_ACT_BIAS_LINEAR) ? 2 : 1); }
 float dropout_p(const cvx_op_desc& o) { return (float)o.k / 65536.f; }
@@ -472,13 +456,17 @@ int plan_batch(cvx_engine* e, int B, bool training) {
     stat_floats += (long long)cvx_stat_replicas(C) * C * CVX_STAT_WORDS;
     if (training) {
       int co_b, j_b;
-      wgrad_tile(C, &co_b, &j_b);
       const int Jtot = c.ntaps * c.cin_pad16;
+      cvx_conv_wgrad_tile(C, Jtot, &co_b, &j_b);
       const long long tiles = (long long)cvx_cdiv(C, co_b) * cvx_cdiv(Jtot, j_b);
-      static const long long blk_target = cvx_tune_int("CVX_WGRAD_BLOCKS", 2048);
+      // the 128 x 128 tile (ResNet-sized layers) has few, fat tiles: it takes its parallelism from more pixel splits, and its slabs
+      // may grow accordingly (measured on DeepLabv3+ R101: 8 -> 64 MB of slabs per layer took the step from 48.6 to 38.5 ms)
+      static const long long blk_narrow = cvx_tune_int("CVX_WGRAD_BLOCKS", 2048), blk_wide = cvx_tune_int("CVX_WGRAD_BLOCKS_WIDE", 1024);
+      const long long blk_target = co_b == 128 ? blk_wide : blk_narrow;
       long long ns = std::min<long long>(std::max<long long>(1, M / 256), std::max<long long>(1, blk_target / tiles));
       const long long slab_elems = (long long)C * Jtot;
-      static const long long slab_cap_mb = cvx_tune_int("CVX_SLAB_MB", 8);
+      static const long long cap_narrow = cvx_tune_int("CVX_SLAB_MB", 8), cap_wide = cvx_tune_int("CVX_SLAB_MB_WIDE", 64);
+      const long long slab_cap_mb = co_b == 128 ? cap_wide : cap_narrow;
       static const long long ns_cap = cvx_tune_int("CVX_NSPLIT_CAP", 512);
       ns = std::min(ns, std::max<long long>(1, (slab_cap_mb << 20) / (slab_elems * 4)));
       ns = std::min<long long>(ns, ns_cap);
@@ -489,6 +477,7 @@ int plan_batch(cvx_engine* e, int B, bool training) {
         probe.stride = o.stride;
         probe.ntaps = c.ntaps;
         probe.Cin = c.cin_g;
+        probe.Cout = C;
         probe.IH = o.ih;
         probe.IW = o.iw;
         probe.OH = o.oh;

@@ -360,6 +360,41 @@ __global__ void resize_bilinear_bwd_kernel(ViewDesc gout, ViewDesc gin, int B, i
   for (int k = 0; k < 8; ++k) o[k] = (half_t)acc[k];
   *reinterpret_cast<h8*>(q) = o;
 }
+// ... from a 1 x 1 input (ASPPPooling's broadcast): the gradient is the sum over all output pixels -- one workgroup per (image, channel
+// group), fixed-order tree (the gather above would walk the whole map in every thread)
+__global__ __launch_bounds__(256) void resize_from_1x1_bwd_kernel(ViewDesc gout, ViewDesc gin, int HW, int CG, int accumulate) {
+  __shared__ float red[256 * 8];
+  const int b = blockIdx.x / CG, cg = blockIdx.x - b * CG;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  for (int pix = threadIdx.x; pix < HW; pix += 256) {
+    const h8 v = *reinterpret_cast<const h8*>(gout.p + voff(gout, b, pix) + cg * 8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += (float)v[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = acc[k];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] += red[(threadIdx.x + s) * 8 + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    half_t* q = gin.p + voff(gin, b, 0) + cg * 8;
+    h8 o;
+    if (accumulate) {
+      const h8 old = *reinterpret_cast<const h8*>(q);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) red[k] += (float)old[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (half_t)red[k];
+    *reinterpret_cast<h8*>(q) = o;
+  }
+}
 // fp32 rows (B, IH*IW, ld) -> NCHW fp32 (B, C, OH, OW): the segmentation logits back at input resolution (deeplabv3plus.py:147)
 __global__ void resize_bilinear_f32_nchw_kernel(const float* in, int ld, int B, int C, int IH, int IW, int OH, int OW, float sh, float sw,
                                                 float* out) {
@@ -773,6 +808,11 @@ int cvx_avgpool_global_bwd(const ViewDesc& gout, const ViewDesc& gin, int B, int
 int cvx_resize_bilinear_bwd(const ViewDesc& gout, const ViewDesc& gin, int B, int IH, int IW, int OH, int OW, int C, int accumulate,
                             hipStream_t st) {
   CVX_CHECK(C % 8 == 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0, "resize_bilinear_bwd: C % 8 / sizes");
+  if (IH == 1 && IW == 1) {
+    hipLaunchKernelGGL(resize_from_1x1_bwd_kernel, dim3(B * (C / 8)), dim3(256), 0, st, gout, gin, OH * OW, C / 8, accumulate);
+    CVX_HIP(hipGetLastError());
+    return 0;
+  }
   return launch1d(resize_bilinear_bwd_kernel, (long long)B * IH * IW * (C / 8), st, gout, gin, B, IH, IW, OH, OW, C / 8, (float)IH / (float)OH,
                   (float)IW / (float)OW, accumulate);
 }

@@ -107,7 +107,7 @@ def deeplab_train_section(builder, report):
     hook.remove()
     loss.backward()
     ref_grads = {k: p.grad.clone() for k, p in dmodel.named_parameters()}
-    ref_sd = dmodel.state_dict()
+    ref_sd = {k: v.clone() for k, v in dmodel.state_dict().items()}
     my_loss, my_grads, my_rows = D.loss_and_grads({k: v.clone() for k, v in sd0.items()}, x.clone(), t, dcfg.dataset.num_classes)
     assert abs(float(my_loss) - float(loss)) < 1e-6 * abs(float(loss)), (float(my_loss), float(loss))
     assert torch.allclose(my_rows, rows_ref[0].permute(0, 2, 3, 1), rtol=1e-4, atol=1e-5)

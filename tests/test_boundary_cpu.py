@@ -5,6 +5,7 @@ import os
 import re
 
 import pytest
+import numpy as np
 import torch
 
 import builder
@@ -175,6 +176,41 @@ def test_deeplab_plugin_surface_cpu():
     assert cm[0] == (0, 0, 0) and cm[1] == (128, 0, 0) and cm[15] == (192, 128, 128) and cm[20] == (0, 64, 128) and len(cm) == 21
     with pytest.raises(L.CvxError):
         model.eval()(torch.zeros(1, 3, 65, 65))
+    # training surface: the reference's loss choices (segmentation_2d.py:59-64), no CPU path for either the model or the loss
+    crit = algo.build_loss()
+    assert type(crit).__name__ == "SegLoss" and crit.mode == 0 and (crit.alpha, crit.gamma, crit.ignore_index) == (0.25, 2.0, -100)
+    cfg.loss.loss_type = "ce"
+    assert algo_cls(cfg, torch.device("cpu")).build_loss().mode == 1
+    with pytest.raises(L.CvxError):
+        model.train()(torch.zeros(2, 3, 65, 65))
+    with pytest.raises(L.CvxError):
+        crit.op(torch.zeros(1, 4, 24), torch.zeros(1, 8, 8, dtype=torch.long), (2, 2), 1.0)
+    assert all(p.requires_grad for p in model.parameters()) and model.loss_scale == 65536.0 and model.dropout_p == 0.1
+    g = model.flat_grads
+    model.attach_grads()
+    assert dict(model.named_parameters())["classifier.classifier.3.bias"].grad.data_ptr() == g[model.layout.convs["classifier.classifier.3"]["bias_off"]:].data_ptr()
+
+
+def test_segmentation_metrics_and_synthetic_loader():
+    """SegmentationMetrics (core/metrics/seg_metrics.py:4-44) on a hand-made confusion matrix, labels outside [0, nc) dropped;
+    the synthetic loader's batch contract (images in [0, 1), int64 targets with ignored pixels)."""
+    from core.trainer.segmentation_trainer import SegmentationMetrics, SyntheticSegmentationLoader
+    m = SegmentationMetrics(3)
+    gt = torch.tensor([[0, 0, 1, 1, 2, 2, -100, 255]])
+    pr = torch.tensor([[0, 1, 1, 1, 2, 0, 0, 1]])
+    m.add_batch(pr, gt)
+    r = m.get_results()
+    hist = np.array([[1, 1, 0], [0, 2, 0], [1, 0, 1]], dtype=float)
+    assert np.array_equal(m.confusion_matrix.numpy(), hist)
+    iu = np.diag(hist) / (hist.sum(1) + hist.sum(0) - np.diag(hist))
+    assert abs(r["Overall Acc"] - 4 / 6) < 1e-12 and abs(r["Mean IoU"] - iu.mean()) < 1e-12
+    assert abs(r["Mean Acc"] - np.mean(np.diag(hist) / hist.sum(1))) < 1e-12
+    assert abs(r["FreqW Acc"] - float((hist.sum(1) / hist.sum() * iu).sum())) < 1e-12
+    m.reset()
+    assert float(m.confusion_matrix.sum()) == 0
+    x, t = next(iter(SyntheticSegmentationLoader(2, (65, 97), 21, length=1, seed=4)))
+    assert tuple(x.shape) == (2, 3, 65, 97) and tuple(t.shape) == (2, 65, 97) and t.dtype == torch.long
+    assert 0 <= float(x.min()) and float(x.max()) < 1 and int(t.max()) <= 20 and int((t == -100).sum()) > 0 and int(t[t >= 0].min()) >= 0
 
 
 def test_ssd_plugin_surface_cpu(gold_dir=os.path.join(os.path.dirname(__file__), "golden")):

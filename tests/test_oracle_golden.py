@@ -245,6 +245,47 @@ def test_deeplab_oracle_init_and_forward(gold):
     assert abs(float(out.norm()) - float(g["out_norm"])) < 1e-4 * float(g["out_norm"])
 
 
+def test_deeplab_oracle_training_step(gold):
+    """oracle/deeplab_ref.loss_and_grads against the REAL reference's training step (make_golden.py section 10b: model.train(),
+    FocalLoss(), loss.backward()): loss, logits rows, norm and sum of every one of the 338 parameter gradients, a dozen gradient
+    tensors in full, updated running statistics; and the second pass with the reference's own dropout mask."""
+    from oracle import deeplab_ref as D
+    g = gold("deeplab_train_97x129.npz")
+    sd = D.init_state_dict(21, seed=0)
+    for k in sd:
+        if k.endswith(".bn3.weight"):
+            sd[k] = torch.full_like(sd[k], float(g["bn3_gamma"]))
+    x, t = torch.from_numpy(g["x"]), torch.from_numpy(g["target"].astype(np.int64))
+    assert int((t == -100).sum()) > 0 and int(t.max()) == 20
+    work = {k: v.clone() for k, v in sd.items()}
+    loss, grads, rows = D.loss_and_grads(work, x, t)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * float(g["loss"])
+    np.testing.assert_allclose(rows.numpy(), g["rows"], rtol=1e-3, atol=1e-4 * float(np.abs(g["rows"]).max()))
+    keys = [str(k) for k in g["grad_keys"]]
+    assert list(grads.keys()) == keys and len(keys) == 338
+    norms = np.array([float(grads[k].double().norm()) for k in keys])
+    np.testing.assert_allclose(norms, g["grad_norm"], rtol=2e-3)            # (fp32 convolutions on another CPU: other summation order)
+    sums = np.array([float(grads[k].double().sum()) for k in keys])
+    np.testing.assert_allclose(sums, g["grad_sum"], rtol=0, atol=5e-3 * float(np.abs(g["grad_norm"]).max()))
+    for name in g.files:
+        if name.startswith("g:"):
+            ref = torch.from_numpy(g[name])
+            assert float((grads[name[2:]] - ref).norm() / ref.norm()) < 2e-3, name
+        if name.startswith("s:"):
+            ref = torch.from_numpy(g[name])
+            assert float((work[name[2:]] - ref).norm() / ref.norm()) < 1e-4, name
+    keep = torch.from_numpy(np.unpackbits(g["keep_mask"])[:int(np.prod(g["keep_shape"]))].reshape(tuple(g["keep_shape"])).astype(np.float32))
+    assert 0.85 < float(keep.mean()) <= 0.95                                  # the reference's Dropout(0.1) mask (zeros of the ReLU count as kept)
+    loss_d, _, _ = D.loss_and_grads({k: v.clone() for k, v in sd.items()}, x, t, keep_mask=keep)
+    assert abs(float(loss_d) - float(g["loss_dropout"])) < 1e-5 * float(g["loss_dropout"])
+    # focal_loss against its definition on a tiny case (focal_loss.py:14-22): ignored pixels count in the mean
+    lg = torch.tensor([[[[2.0, 0.0]], [[0.0, 0.0]]]])
+    tt = torch.tensor([[[0, -100]]])
+    ce0 = float(np.log(1 + np.exp(-2.0)))
+    want = 0.25 * (1 - np.exp(-ce0)) ** 2 * ce0 / 2
+    assert abs(float(D.focal_loss(lg, tt)) - want) < 1e-7
+
+
 def _yolov7_fixture_state(g):
     from oracle import yolov7_ref as Y
     sd = Y.init_state_dict(20, seed=0)

@@ -1,7 +1,8 @@
-"""Per-op timing of the 640x640 batch-32 train step: joins cvx_engine_profile_dump records with the op list and prints,
-per (class, op), the mean time, algorithmic TF/s and GB/s, and the time the tighter of the two rooflines would allow.
+"""Per-op timing of a train step (YOLOv8-n 640x640 batch 32, or `deeplab`: DeepLabv3+ R101 513x513 batch 16): joins
+cvx_engine_profile_dump records with the op list and prints, per (class, op), the mean time, algorithmic TF/s and GB/s, and the
+time the tighter of the two rooflines would allow.
 
-    python tools/op_profile.py [steps] > gpurun_out/op_profile.txt
+    python tools/op_profile.py [steps] [yolov8|deeplab] > gpurun_out/op_profile.txt
 """
 import collections
 import csv
@@ -19,6 +20,8 @@ PEAK_TF, PEAK_GB = 2516.6, 8000.0
 
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    if len(sys.argv) > 2 and sys.argv[2] == "deeplab":
+        return report(*deeplab_step(), steps)
     from computervision.pytorch_amd.model import Yolo8
     from computervision.pytorch_amd.train import FlatAdam, FusedTrainStep, V8DetectionLoss
     from configs import Yolo8DetConfig
@@ -34,10 +37,29 @@ def main():
     for _ in range(3):
         step(x, batch)
     torch.cuda.synchronize()
-    eng = model._last_engine
+    report(model._last_engine, lambda: step(x, batch), steps)
+
+
+def deeplab_step():
+    import builder
+    from core.trainer.segmentation_trainer import SyntheticSegmentationLoader
+    dev = torch.device("cuda", 0)
+    cfg, _, trainer_cls = builder.export_from_registry("deeplabv3plus")
+    torch.manual_seed(0)
+    tr = trainer_cls(cfg, dev, dataloader=SyntheticSegmentationLoader(16, (513, 513), 21, length=1, seed=1))
+    tr.model.train()
+    images, targets = next(iter(tr.train_dataloader))
+    batch = (images.to(dev), targets.to(dev))
+    for _ in range(3):
+        tr.train_loop(batch, None)
+    torch.cuda.synchronize()
+    return tr.model._last_engine, lambda: tr.train_loop(batch, None)
+
+
+def report(eng, run, steps):
     eng.profile(True)
     for _ in range(steps):
-        step(x, batch)
+        run()
     torch.cuda.synchronize()
     path = os.path.join(ROOT, "gpurun_out", "op_profile.csv")
     os.makedirs(os.path.dirname(path), exist_ok=True)
@@ -52,7 +74,7 @@ def main():
     ops = eng.graph.ops
     tot = collections.defaultdict(float)
     ideal = collections.defaultdict(float)
-    print(f"{'class':10s} {'op':>3s} {'shape':40s} {'us':>8s} {'TF/s':>7s} {'GB/s':>7s} {'roof us':>8s} {'frac':>6s}")
+    print(f"{'class':10s} {'op':>3s} {'shape':58s} {'us':>8s} {'TF/s':>7s} {'GB/s':>7s} {'roof us':>8s} {'frac':>6s}")
     for (cls, op), (ms, fl, by, n) in agg.items():
         per = n // steps if n >= steps else 1          # dgrad of a stride-2 conv: 4 launches per step under one key
         us = ms * 1e3 / steps
@@ -62,12 +84,12 @@ def main():
         if op >= 0:
             o = ops[op]
             if o["type"] == 1:
-                shape = f"{o['name']:12s} {o['ih']}x{o['iw']} {o['w_cin']}->{o['out'][2]} k{o['k']}s{o['stride']}" + (" +res" if "res" in o else "")
+                shape = f"{o['name'][-28:]:12s} {o['ih']}x{o['iw']} {o['w_cin']}->{o['out'][2]} k{o['k']}s{o['stride']}" + (f"d{o['dil']}" if o.get("dil", 1) > 1 else "") + (" +res" if "res" in o else "")
             else:
-                shape = f"{o['name']:12s} {o['ih']}x{o['iw']} c{o['out'][2]}"
+                shape = f"{o['name'][-28:]:12s} {o['ih']}x{o['iw']} c{o['out'][2]}"
         tot[cls] += us
         ideal[cls] += roof
-        print(f"{CLASSES[cls]:10s} {op:3d} {shape:40s} {us:8.1f} {fl / us / 1e6:7.1f} {by / us / 1e3:7.0f} {roof:8.1f} {roof / us:6.2f}")
+        print(f"{CLASSES[cls]:10s} {op:3d} {shape:58s} {us:8.1f} {fl / us / 1e6:7.1f} {by / us / 1e3:7.0f} {roof:8.1f} {roof / us:6.2f}")
     print()
     for c in sorted(tot):
         print(f"{CLASSES[c]:12s} {tot[c]:8.1f} us   roofline {ideal[c]:8.1f} us   frac {ideal[c] / tot[c]:.3f}")
