@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CVX_LIB") or os.path.join(_HERE, "lib", "libcvx_engine.so")   # CVX_LIB: A/B runs of two builds on one box
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class CvxError(RuntimeError):

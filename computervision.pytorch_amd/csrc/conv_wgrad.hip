@@ -181,6 +181,7 @@ void launch_cfg(const WgradParams& p, hipStream_t st) {
 // tile of the generic kernel for a layer (the engine sizes its pixel splits and slabs with it)
 void cvx_conv_wgrad_tile(int cout, int jtot, int* co_b, int* j_b) {
   static const int wide = cvx_tune_int("CVX_WGRAD_WIDE", 1);
+  static const long long wide_min = cvx_tune_int("CVX_WGRAD_WIDE_MIN", 512 * 1024);  // below (YOLOv8-n's layers) the 64 x 64 tile measured 1 % faster
   if (cout <= 16) {
     *co_b = 16;
     *j_b = 192;
@@ -190,7 +191,7 @@ void cvx_conv_wgrad_tile(int cout, int jtot, int* co_b, int* j_b) {
   } else if (cout % 64 != 0 && (cout % 48 == 0 || cout <= 96)) {
     *co_b = 48;
     *j_b = 128;
-  } else if (wide && cout % 128 == 0 && jtot >= 512) {  // ResNet-sized layers: twice the arithmetic intensity per staged byte
+  } else if (wide && cout % 128 == 0 && jtot >= 512 && (long long)cout * jtot >= wide_min) {  // ResNet-sized layers: twice the arithmetic intensity per staged byte
     *co_b = 128;
     *j_b = 128;
   } else {

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define CVX_ABI_VERSION 3
+#define CVX_ABI_VERSION 4
 
 const char* cvx_last_error(void);
 int cvx_abi_version(void);
@@ -42,7 +42,7 @@ enum { CVX_OP_CONV = 1, CVX_OP_MAXPOOL5 = 2, CVX_OP_UPSAMPLE2 = 3,
        CVX_OP_MAXPOOL2 = 4, /* 2x2 stride-2 max pool (Tree.downsample, :128-129) */
        CVX_OP_DWCONVT = 5,  /* depthwise ConvTranspose2d, kernel 2*stride, padding stride/2 (IDAUp.up_i, :256); w_off -> fp32 [C][2f][2f] */
        CVX_OP_COPY = 6,     /* channel-slice copy (a tensor that lives in two concat buffers) */
-       /* inference-only ops (DeepLabv3+ / ResNet, core/models/deeplabv3plus.py, core/models/resnet.py): */
+       /* DeepLabv3+ / ResNet ops (core/models/deeplabv3plus.py, core/models/resnet.py), forward and backward: */
        CVX_OP_MAXPOOL3S2 = 7, /* 3x3 stride-2 pad-1 max pool (resnet.py:163) */
        CVX_OP_AVGPOOL = 8,    /* global average pool -> (B, 1, 1, C) (ASPPPooling, deeplabv3plus.py:30) */
        CVX_OP_RESIZE = 9,     /* bilinear resize (ih, iw) -> (oh, ow), align_corners = False (deeplabv3plus.py:38,117-122) */
@@ -54,9 +54,9 @@ enum { CVX_OP_CONV = 1, CVX_OP_MAXPOOL5 = 2, CVX_OP_UPSAMPLE2 = 3,
                                   element) -- a different draw than torch's Philox stream, the same distribution */
 /* CVX_OP_MAXPOOL2 also serves ceil_mode = True (:18): oh = ceil(ih / 2), windows clipped at the border. */
 enum { CVX_ACT_BN_SILU = 1, CVX_ACT_BIAS = 2,
-       /* inference-only epilogues (folded BatchNorm): */
-       CVX_ACT_BN_RELU = 3,   /* Conv + BN + ReLU */
-       CVX_ACT_BN_LINEAR = 4, /* Conv + BN (Tree.project) */
+       CVX_ACT_BN_RELU = 3,   /* Conv + BN + ReLU (trainable: batch statistics, backward) */
+       CVX_ACT_BN_LINEAR = 4, /* Conv + BN (Tree.project, ResNet downsample; trainable) */
+       /* inference-only epilogues: */
        CVX_ACT_BIAS_RELU = 5,   /* Conv + bias + ReLU, fp16 output (head 3x3, :314-318) */
        CVX_ACT_BIAS_LINEAR = 6 }; /* Conv + bias, fp16 output, no activation (SSD ExtraLayer, ssd_model.py:90-110) */
 #define CVX_OPF_RES_PRE_ACT 1 /* cvx_op_desc.flags: the residual is added before the activation (BasicBlock, :20-27) */
@@ -81,8 +81,11 @@ typedef struct {
 
 typedef struct cvx_engine cvx_engine;
 
-/* A graph that contains an inference-only op or epilogue can only run cvx_engine_forward(training = 0); there the op that
- * reads `image_buf` may be any convolution with 3 stored input channels (the image is converted to NHWC fp16, 8 channels).
+/* A graph that contains an inference-only op or epilogue (CVX_OP_MAXPOOL2, _DWCONVT, _COPY, _L2NORM; CVX_ACT_BIAS_RELU, _BIAS_LINEAR,
+ * CVX_OPF_CONV_BIAS; SiLU with a pre-activation residual, ReLU with a post-activation one), or none of whose convolutions asks for
+ * a data gradient, can only run cvx_engine_forward(training = 0).  The op that reads `image_buf` may be the YOLO stem (below) or any
+ * convolution with 3 stored input channels and needs_dgrad = 0 (the image is converted to NHWC fp16, 8 channels; its weight gradient
+ * reads that copy).
  *
  * Builds an engine for a fixed input size.  `image_buf` is the index of the buffer-table entry (c == 8) that stands for
  * the caller's NCHW fp32 images; exactly one op may read it: the 3 -> 16..80 channel 3x3 stride-2 BN+SiLU stem, which runs

@@ -1759,3 +1759,53 @@ def test_deeplab_per_layer_backward_on_the_engines_own_operands(dev, gold):
         assert e < 2e-3 + 6e-8 / max(rms, 1e-30), (b, off, c, e, rms)
         checked += 1
     assert checked >= 100
+
+
+def test_deeplab_step_with_gradient_exchange_and_loss_scaling(dev, gold):
+    """SegTrainStep: (a) with an RCCL group of size 1 the gradient exchange after the backward pass (4 slices of the flat arena on a
+    side stream, 1/world folded into Adam) gives exactly the plain step's losses and parameters; (b) GradScaler semantics: an
+    absurd initial scale overflows the fp16 gradients, the step is skipped on the device and the scale backs off until steps
+    go through; (c) the fused step repeats bit for bit from the same seed (dropout masks included)."""
+    import torch.distributed as dist
+    from computervision.pytorch_amd.deeplab import SegLoss, SegTrainStep
+    from computervision.pytorch_amd.train import DynamicLossScale, FlatAdam
+    g = gold("deeplab_train_97x129.npz")
+    x, t = torch.from_numpy(g["x"]).to(dev), torch.from_numpy(g["target"].astype(np.int64)).to(dev)
+    created = False
+    if not dist.is_initialized():
+        try:
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29613", rank=0, world_size=1, device_id=dev)
+            created = True
+        except Exception as exc:
+            pytest.skip(f"RCCL process group unavailable: {exc}")
+    try:
+        runs = []
+        for distributed in (False, True, True):
+            m = _deeplab_train_model(dev, g, dropout_p=0.1)
+            m.seed = 3
+            step = SegTrainStep(m, SegLoss("focal"), FlatAdam(m, lr=1e-3), scaler=DynamicLossScale(dev, init_scale=4096.0))
+            step.distributed = distributed
+            losses = [step(x, t).clone() for _ in range(3)]
+            torch.cuda.synchronize()
+            runs.append((torch.cat(losses).cpu(), m.flat_params.clone().cpu()))
+        assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+        assert torch.equal(runs[1][0], runs[2][0]) and torch.equal(runs[1][1], runs[2][1])
+        assert float(runs[0][0][-1]) < float(runs[0][0][0])
+    finally:
+        if created:
+            dist.destroy_process_group()
+    m = _deeplab_train_model(dev, g)
+    sc = DynamicLossScale(dev, init_scale=2.0 ** 40, growth_interval=1000)
+    opt = FlatAdam(m, lr=1e-3)
+    step = SegTrainStep(m, SegLoss("focal"), opt, scaler=sc)
+    p0 = m.flat_params.clone()
+    step(x, t)
+    torch.cuda.synchronize()
+    assert torch.equal(m.flat_params, p0)
+    sc.poll()
+    assert sc.scale == 2.0 ** 39 and sc.skipped == 1
+    for _ in range(60):
+        step(x, t)
+        torch.cuda.synchronize()
+    sc.poll()
+    assert sc.scale < 2.0 ** 34 and not torch.equal(m.flat_params, p0) and bool(torch.isfinite(m.flat_params).all())

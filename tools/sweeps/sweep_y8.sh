@@ -1,0 +1,8 @@
+#!/bin/bash
+# A/B of knobs on the YOLOv8-n train step (tuning library)
+run() { echo "== $*"; env "$@" CVX_LIB=build/libcvx_tuning.so python bench.py --no-cpu-baseline --steps 60 --warmup 10 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"; }
+run CVX_WGRAD_WIDE=0
+run CVX_WGRAD_WIDE=1
+run CVX_WGRAD_WIDE=0
+run CVX_WGRAD_WIDE=1
