@@ -97,6 +97,8 @@ PROTOTYPES = {
     "cvx_conv2d_wgrad_nhwc": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _I64, _P]),
     "cvx_bn_silu_train_nhwc": (_I32, [_P, _I32, _I32, _I32, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
     "cvx_bn_silu_bwd_nhwc": (_I32, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _F, _P, _P, _P, _P, _I32, _P]),
+    "cvx_letterbox_geometry": (_I32, [_I32, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
+    "cvx_letterbox_u8_to_nchw": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _I32, _I32, _P]),
     "cvx_engine_set_seed": (_I32, [_P, _U64]),
     "cvx_seg_loss_workspace_bytes": (_I64, [_I32, _I32, _I32, _I32]),
     "cvx_seg_loss": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I32, _F, _F, _I64, _F, _P, _P, _P, _P, _P]),

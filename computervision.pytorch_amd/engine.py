@@ -318,3 +318,27 @@ def centernet_decode(pred: torch.Tensor, h: int, w: int, nc: int, reg_col: int, 
                                      L.ptr(out["boxes"]), L.ptr(out["scores"]), L.ptr(out["classes"]), L.ptr(out["topk_index"]),
                                      L.ptr(out["keep"]), L.ptr(out["counts"]), L.ptr(ws), ws.numel(), L.stream_ptr(dev)), "cvx_centernet_decode")
     return out
+
+
+def letterbox_geometry(h: int, w: int, H: int, W: int):
+    """(new_h, new_w, top, left, scale) of the reference's letter_box (core/utils/image_process.py:56-62); host arithmetic of the library."""
+    import ctypes as C
+    lib = L.load()
+    nh, nw, top, left, sc = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_double()
+    L.check(lib.cvx_letterbox_geometry(h, w, H, W, C.byref(nh), C.byref(nw), C.byref(top), C.byref(left), C.byref(sc)), "cvx_letterbox_geometry")
+    return nh.value, nw.value, top.value, left.value, sc.value
+
+
+def letterbox_u8(image_u8: torch.Tensor, out_chw: torch.Tensor, letterbox: bool = True, swap_rb: bool = False) -> torch.Tensor:
+    """uint8 (h, w, 3) device image -> out_chw (3, H, W) fp32 (a slot of the batch tensor): letter_box + to_tensor in one launch."""
+    _need_gpu(image_u8, "image")
+    if image_u8.dtype != torch.uint8 or image_u8.dim() != 3 or image_u8.shape[2] != 3:
+        raise ValueError("image must be a uint8 (h, w, 3) tensor")
+    if out_chw.dtype != torch.float32 or out_chw.dim() != 3 or out_chw.shape[0] != 3 or not out_chw.is_contiguous():
+        raise ValueError("out must be a contiguous float32 (3, H, W) tensor")
+    image_u8 = image_u8.contiguous()
+    lib = L.load()
+    L.check(lib.cvx_letterbox_u8_to_nchw(L.ptr(image_u8), int(image_u8.shape[0]), int(image_u8.shape[1]), 1 if letterbox else 0, 1 if swap_rb else 0,
+                                         L.ptr(out_chw), int(out_chw.shape[1]), int(out_chw.shape[2]), L.stream_ptr(image_u8.device)),
+            "cvx_letterbox_u8_to_nchw")
+    return out_chw

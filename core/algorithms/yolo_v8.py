@@ -72,15 +72,12 @@ class YOLOv8:
         img = cv2.cvtColor(cv2.imread(image_path, cv2.IMREAD_COLOR | cv2.IMREAD_IGNORE_ORIENTATION), cv2.COLOR_BGR2RGB)
         h, w, _ = img.shape
         H, W = self.input_image_size
-        if self.letterbox_image:
-            scale = min(H / h, W / w)
-            nh, nw = int(h * scale), int(w * scale)
-            img = cv2.resize(img, (nw, nh), interpolation=cv2.INTER_NEAREST)
-            top, left = (H - nh) // 2, (W - nw) // 2
-            img = cv2.copyMakeBorder(img, top, H - nh - top, left, W - nw - left, cv2.BORDER_CONSTANT, value=(128, 128, 128))
+        if self.letterbox_image:                        # letter_box + to_tensor on the GPU (one kernel; image_process.py:48-66)
+            from core.utils.image_process import letter_box
+            x, _, _ = letter_box(img, (H, W), device=self.device)
         else:
             img = cv2.resize(img, (W, H), interpolation=cv2.INTER_CUBIC)
-        x = torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1).float().div(255.0).unsqueeze(0)
+            x = torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1).float().div(255.0).unsqueeze(0)
         boxes, scores, classes = self.predict_tensor(model, x, h, w)
         bgr = cv2.imread(image_path, cv2.IMREAD_COLOR | cv2.IMREAD_IGNORE_ORIENTATION)
         if boxes.shape[0] == 0:

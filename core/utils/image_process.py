@@ -1,0 +1,35 @@
+"""Input side of the detection path: the reference's ``letter_box`` + ``TF.to_tensor``
+(core/utils/image_process.py:29-66) as one HIP kernel on images that are already in device memory, and the batch assembly
+``torch.stack`` does in the reference's collate functions (core/data/collate.py:9,24).  Image FILE I/O (cv2.imread) stays with the
+caller, as in the reference."""
+from typing import Sequence, Tuple
+
+import numpy as np
+import torch
+
+from computervision.pytorch_amd.engine import letterbox_geometry, letterbox_u8
+
+
+def letter_box(image, size, device=None, swap_rb: bool = False):
+    """``letter_box`` (reference :48-66) fused with ``TF.to_tensor``: uint8 (h, w, 3) numpy array or tensor -> ((1, 3, H, W) fp32
+    tensor in [0, 1] on the device, scale, [top, bottom, left, right])."""
+    img = torch.as_tensor(np.ascontiguousarray(image) if isinstance(image, np.ndarray) else image)
+    if device is not None:
+        img = img.to(device, non_blocking=True)
+    h, w = int(img.shape[0]), int(img.shape[1])
+    H, W = size
+    new_h, new_w, top, left, scale = letterbox_geometry(h, w, H, W)
+    out = torch.empty(1, 3, H, W, device=img.device)
+    letterbox_u8(img, out[0], letterbox=True, swap_rb=swap_rb)
+    return out, scale, [top, H - new_h - top, left, W - new_w - left]
+
+
+def images_to_batch(images: Sequence, size: Tuple[int, int], device, letterbox: bool = True, swap_rb: bool = False) -> torch.Tensor:
+    """A list of uint8 (h_i, w_i, 3) images of any sizes -> the (B, 3, H, W) fp32 network input, one kernel per image writing
+    straight into its slot of the batch tensor (no per-image tensors, no ``torch.stack``)."""
+    H, W = size
+    batch = torch.empty(len(images), 3, H, W, device=device)
+    for i, im in enumerate(images):
+        img = torch.as_tensor(np.ascontiguousarray(im) if isinstance(im, np.ndarray) else im).to(device, non_blocking=True)
+        letterbox_u8(img, batch[i], letterbox=letterbox, swap_rb=swap_rb)
+    return batch

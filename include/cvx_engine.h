@@ -199,6 +199,18 @@ int cvx_loss_v8_assignment(const void* workspace, int32_t batch, int32_t anchors
  * (n,6) target rows cvx_loss_v8 reads, grouped by image in stable order.  Replaces: Loss.preprocess, yolo_v8.py:51-65. */
 int cvx_pack_targets(const float* batch_idx, const float* cls, const float* bboxes, int32_t n, float* rows, void* hip_stream);
 
+/* ---- input side: letterbox pre-processing -------------------------------
+ * cvx_letterbox_u8_to_nchw: uint8 (h, w, 3) HWC image in DEVICE memory -> one (3, H, W) fp32 image of the network's input batch
+ * (out_chw = batch tensor + b*3*H*W), values in [0, 1].  letterbox != 0: the reference's letter_box -- aspect-preserving
+ * cv2.resize(INTER_NEAREST) to (int(h*s), int(w*s)), s = min(H/h, W/w), centred on a (128,128,128) canvas; letterbox == 0: plain
+ * nearest resize to (H, W) (the reference uses INTER_CUBIC there: not built).  swap_rb: BGR source -> RGB planes (cv2.cvtColor).
+ * Asynchronous on hip_stream.  cvx_letterbox_geometry: the same size / padding arithmetic on the host (the decode side needs it).
+ * Replaces: letter_box + TF.to_tensor in read_image_and_convert_to_tensor, core/utils/image_process.py:29-66 (image file I/O stays
+ * with the caller). */
+int cvx_letterbox_geometry(int32_t h, int32_t w, int32_t H, int32_t W, int32_t* new_h, int32_t* new_w, int32_t* top, int32_t* left, double* scale);
+int cvx_letterbox_u8_to_nchw(const uint8_t* image_hwc, int32_t h, int32_t w, int32_t letterbox, int32_t swap_rb, float* out_chw, int32_t H,
+                             int32_t W, void* hip_stream);
+
 /* ---- optimiser ------------------------------------------------------------------------------------
  * torch.optim.Adam semantics (core/trainer/lr_scheduler.py:37-43): lr, betas, eps, no weight decay;
  * `step` counts from 1.  found_inf (device int32, may be NULL): when non-zero the update is skipped

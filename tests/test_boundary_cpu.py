@@ -225,3 +225,28 @@ def test_ssd_plugin_surface_cpu(gold_dir=os.path.join(os.path.dirname(__file__),
     assert name == "SSD300_vgg" and len(model.state_dict()) == 136 and sum(p.numel() for p in model.parameters()) == 26293934
     with pytest.raises(L.CvxError):
         model.eval()(torch.zeros(1, 3, 300, 300))
+
+
+def test_letterbox_geometry_and_oracle():
+    """cvx_letterbox_geometry (host arithmetic of the library, no GPU needed) against the reference's letter_box lines
+    (core/utils/image_process.py:56-62) restated in oracle/letterbox_ref.py, over a grid of odd sizes; the oracle's nearest resize
+    and padding on a hand-checkable image; no CPU path for the pixel kernel."""
+    from computervision.pytorch_amd.engine import letterbox_geometry, letterbox_u8
+    from oracle import letterbox_ref as LB
+    for (h, w) in [(480, 640), (375, 500), (1080, 1920), (1, 1), (333, 77), (640, 640), (641, 639), (2000, 3), (7, 1999)]:
+        for (H, W) in [(640, 640), (300, 300), (513, 513), (512, 384)]:
+            nh, nw, top, left, sc = LB.geometry(h, w, H, W)
+            if nh <= 0 or nw <= 0:
+                with pytest.raises(L.CvxError):
+                    letterbox_geometry(h, w, H, W)
+                continue
+            assert letterbox_geometry(h, w, H, W) == (nh, nw, top, left, sc), (h, w, H, W)
+    img = np.arange(2 * 3 * 3, dtype=np.uint8).reshape(2, 3, 3)                 # 2 x 3 image -> 4 x 6 inside a 6 x 6 canvas
+    out, scale, pads = LB.letter_box(img, (6, 6))
+    assert scale == 2.0 and pads == [1, 1, 0, 0] and out.shape == (6, 6, 3)
+    assert (out[0] == 128).all() and (out[5] == 128).all()
+    assert np.array_equal(out[1:5, :, 0], np.repeat(np.repeat(img[:, :, 0], 2, 0), 2, 1))
+    t = LB.to_tensor(out)
+    assert t.dtype == np.float32 and t.shape == (3, 6, 6) and t[0, 0, 0] == np.float32(128) / np.float32(255)
+    with pytest.raises(CvxError):
+        letterbox_u8(torch.zeros(4, 4, 3, dtype=torch.uint8), torch.zeros(3, 8, 8))

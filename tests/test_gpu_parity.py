@@ -1809,3 +1809,31 @@ def test_deeplab_step_with_gradient_exchange_and_loss_scaling(dev, gold):
         torch.cuda.synchronize()
     sc.poll()
     assert sc.scale < 2.0 ** 34 and not torch.equal(m.flat_params, p0) and bool(torch.isfinite(m.flat_params).all())
+
+
+# ---- input side: letterbox pre-processing ------------------------------------------------------------------
+@pytest.mark.parametrize("h,w,H,W", [(480, 640, 640, 640), (375, 500, 640, 640), (1080, 1920, 640, 640), (333, 77, 300, 300), (97, 129, 513, 513),
+                                     (640, 640, 640, 640), (3, 5, 64, 96), (2000, 31, 512, 384)])
+def test_letterbox_kernel_is_bit_exact(dev, h, w, H, W):
+    """cvx_letterbox_u8_to_nchw against oracle/letterbox_ref.py (letter_box + TF.to_tensor, image_process.py:41-66): byte and index
+    work -> bit-exact, up- and down-scaling, odd sizes, BGR -> RGB swap, the batch-slot form (images_to_batch) and the plain nearest
+    resize (letterbox = 0)."""
+    from computervision.pytorch_amd.engine import letterbox_u8
+    from core.utils.image_process import images_to_batch, letter_box
+    from oracle import letterbox_ref as LB
+    rng = np.random.default_rng(h * 7 + w)
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    ref_img, ref_scale, ref_pads = LB.letter_box(img, (H, W))
+    want = torch.from_numpy(LB.to_tensor(ref_img))
+    x, scale, pads = letter_box(img, (H, W), device=dev)
+    assert scale == ref_scale and pads == ref_pads and tuple(x.shape) == (1, 3, H, W)
+    assert torch.equal(x[0].cpu(), want)
+    xs, _, _ = letter_box(img[:, :, ::-1], (H, W), device=dev, swap_rb=True)
+    assert torch.equal(xs[0].cpu(), want)
+    other = rng.integers(0, 256, (w + 1, h + 2, 3), dtype=np.uint8)
+    batch = images_to_batch([img, other, img], (H, W), dev)
+    assert torch.equal(batch[0].cpu(), want) and torch.equal(batch[2].cpu(), want)
+    assert torch.equal(batch[1].cpu(), torch.from_numpy(LB.to_tensor(LB.letter_box(other, (H, W))[0])))
+    plain = torch.empty(3, H, W, device=dev)
+    letterbox_u8(torch.from_numpy(img).to(dev), plain, letterbox=False)
+    assert torch.equal(plain.cpu(), torch.from_numpy(LB.to_tensor(LB.resize_nearest(img, H, W))))
