@@ -327,6 +327,10 @@ int build_static(cvx_engine* e) {
     }
     const int total = pd.Cout * T * pd.Cin_pad;
     for (int s0 = 0; s0 < total; s0 += 1024) pblocks.push_back(BlockRef{(int)packs.size(), s0});
+    if (pd.dg_off >= 0) {  // transposed copy: 32 x 32 (co, ci) tiles per tap, encoded as negative starts (pack_weights_kernel)
+      const int ntile = T * ((pd.Cout + 31) / 32) * ((pd.Cin + 31) / 32);
+      for (int q = 0; q < ntile; ++q) pblocks.push_back(BlockRef{(int)packs.size(), -(q + 1)});
+    }
     packs.push_back(pd);
   }
   e->shadow_elems = sh;

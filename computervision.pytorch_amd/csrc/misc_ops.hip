@@ -654,9 +654,35 @@ __global__ void nchw_to_pred_f16_kernel(const float* g, int B, int A, int no, in
 }
 
 // ---- weight shadow packing ------------------------------------------------------------------------
+// block kinds of one launch: start >= 0 -- 1024 consecutive elements of the forward layout [Cout][T][Cin_pad] (fp32 -> fp16, padded
+// input channels zero); start < 0 -- tile -(start + 1) of the transposed data-gradient layout [Cin][T][Cout]: a 32 x 32 (co, ci) tile of
+// one tap goes through LDS so that both the fp32 reads (along ci) and the fp16 writes (along co) are contiguous (the element-wise
+// scatter it replaces wrote 2 bytes per cache line: 0.8 ms for ResNet-101's 59 M parameters).
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* master, half_t* shadow, const PackDesc* descs, const BlockRef* blocks) {
+  __shared__ float tile[32][33];
   const BlockRef br = blocks[blockIdx.x];
   const PackDesc d = descs[br.desc];
+  if (br.start < 0) {
+    const int lin = -(br.start + 1);
+    const int tci = (d.Cin + 31) / 32, tco = (d.Cout + 31) / 32;
+    const int t = lin / (tco * tci), rem = lin - t * (tco * tci);
+    const int co0 = (rem / tci) * 32, ci0 = (rem % tci) * 32;
+    const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = r0 + 8 * k;  // co within the tile
+      const int co = co0 + r, ci = ci0 + c;
+      tile[r][c] = (co < d.Cout && ci < d.Cin) ? master[d.src_off + ((long long)co * d.T + t) * d.Cin + ci] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = r0 + 8 * k;  // ci within the tile
+      const int ci = ci0 + r, co = co0 + c;
+      if (ci < d.Cin && co < d.Cout) shadow[d.dg_off + ((long long)ci * d.T + t) * d.Cout + co] = (half_t)tile[c][r];
+    }
+    return;
+  }
   const int total = d.Cout * d.T * d.Cin_pad;
   for (int k = 0; k < 4; ++k) {
     int e = br.start + k * 256 + threadIdx.x;
@@ -665,10 +691,6 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* master, 
     int row = e / d.Cin_pad;  // co*T + t
     float v = ci < d.Cin ? master[d.src_off + (long long)row * d.Cin + ci] : 0.f;
     shadow[d.fwd_off + e] = (half_t)v;
-    if (d.dg_off >= 0 && ci < d.Cin) {
-      int t = row % d.T, co = row / d.T;
-      shadow[d.dg_off + ((long long)ci * d.T + t) * d.Cout + co] = (half_t)v;
-    }
   }
 }
 
