@@ -105,6 +105,7 @@ PROTOTYPES = {
     "cvx_resize_bilinear_nchw_grad_to_rows": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _P, _I32, _P]),
     "cvx_maxpool3_train_nhwc": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
     "cvx_maxpool3_bwd_nhwc": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P]),
+    "cvx_maxpool2_bwd_nhwc": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P]),
     "cvx_avgpool_global_bwd_nhwc": (_I32, [_P, _I32, _I32, _I32, _P, _I32, _P]),
     "cvx_resize_bilinear_bwd_nhwc": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P]),
     "cvx_dropout_nhwc": (_I32, [_P, _I32, _I32, _I32, _F, _U64, _P, _I32, _P]),

@@ -158,9 +158,12 @@ struct Coef8 {
 // dz = g * act'(pre).  SiLU: pre = gamma * xhat + beta is recomputed from the kept xhat.  ReLU: the mask is the sign of the
 // layer's own fp16 forward OUTPUT (`fout`): recomputing the pre-activation from the rounded xhat would flip the mask of
 // ~2e-4 of the elements (|pre| below the fp16 rounding of xhat), a 1 % gradient error per layer.  fout = relu(pre (+res)).
+// SiLU with a pre-activation residual (YOLOv7's RepConv, yolov7_model.py: silu(bn(conv3x3) + bn(conv1x1))): `fo` carries the residual
+// VALUE (the other branch's output) instead, and pre = gamma * xhat + beta + residual.
 template <int ACT>
 __device__ __forceinline__ float act_dz(float g, float xh, float ga, float be, float fo) {
   if constexpr (ACT == 0) return g * cvx_silu_grad(xh * ga + be);
+  if constexpr (ACT == 3) return g * cvx_silu_grad(xh * ga + be + fo);  // kernel-internal kind: SiLU whose pre-activation holds a residual
   if constexpr (ACT == 1) return fo > 0.f ? g : 0.f;
   return g;
 }
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const half_t* xhat, 
       for (int q = 0; q < UNR; ++q) {
         v[q] = *reinterpret_cast<const h8*>(xhat + (m + q * RP) * C + cg * 8);
         g[q] = *reinterpret_cast<const h8*>(gout.p + view_off(gout, m + q * RP, hw) + cg * 8);
-        if constexpr (ACT == 1) fo[q] = *reinterpret_cast<const h8*>(fout.p + view_off(fout, m + q * RP, hw) + cg * 8);
+        if constexpr (ACT == 1 || ACT == 3) fo[q] = *reinterpret_cast<const h8*>(fout.p + view_off(fout, m + q * RP, hw) + cg * 8);
       }
 #pragma unroll
       for (int q = 0; q < UNR; ++q) one(v[q], g[q], fo[q]);
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const half_t* xhat, 
       h8 v = *reinterpret_cast<const h8*>(xhat + m * C + cg * 8);
       h8 g = *reinterpret_cast<const h8*>(gout.p + view_off(gout, m, hw) + cg * 8);
       h8 fo = {};
-      if constexpr (ACT == 1) fo = *reinterpret_cast<const h8*>(fout.p + view_off(fout, m, hw) + cg * 8);
+      if constexpr (ACT == 1 || ACT == 3) fo = *reinterpret_cast<const h8*>(fout.p + view_off(fout, m, hw) + cg * 8);
       one(v, g, fo);
     }
   }
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const half_t* xhat, l
       v[q] = *reinterpret_cast<const h8*>(xhat + (m + q * RP) * C + cg * 8);
       g[q] = *reinterpret_cast<const h8*>(gout.p + view_off(gout, m + q * RP, hw) + cg * 8);
       if (rd_old) old[q] = *reinterpret_cast<const h8*>(gres.p + view_off(gres, m + q * RP, hw) + cg * 8);
-      if constexpr (ACT == 1) fo[q] = *reinterpret_cast<const h8*>(fout.p + view_off(fout, m + q * RP, hw) + cg * 8);
+      if constexpr (ACT == 1 || ACT == 3) fo[q] = *reinterpret_cast<const h8*>(fout.p + view_off(fout, m + q * RP, hw) + cg * 8);
     }
 #pragma unroll
     for (int q = 0; q < UNR; ++q) one(m + q * RP, v[q], g[q], old[q], fo[q]);
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const half_t* xhat, l
     h8 g = *reinterpret_cast<const h8*>(gout.p + view_off(gout, m, hw) + cg * 8);
     h8 old = {}, fo = {};
     if (rd_old) old = *reinterpret_cast<const h8*>(gres.p + view_off(gres, m, hw) + cg * 8);
-    if constexpr (ACT == 1) fo = *reinterpret_cast<const h8*>(fout.p + view_off(fout, m, hw) + cg * 8);
+    if constexpr (ACT == 1 || ACT == 3) fo = *reinterpret_cast<const h8*>(fout.p + view_off(fout, m, hw) + cg * 8);
     one(m, v, g, old, fo);
   }
 }
@@ -426,7 +429,6 @@ int cvx_bn_fold(int n, const float* gamma, const float* beta, const float* rmean
 static int check_act(int act, int res_pre, bool has_res) {
   CVX_CHECK(act >= 0 && act <= 2, "bn_act: activation kind must be 0 (SiLU), 1 (ReLU) or 2 (none)");
   CVX_CHECK(!res_pre || has_res, "bn_act: res_pre without a residual");
-  CVX_CHECK(!(has_res && act == 0 && res_pre), "bn_act: SiLU with a pre-activation residual is not built");
   CVX_CHECK(!(has_res && act == 1 && !res_pre), "bn_act: ReLU with a post-activation residual is not built (the backward mask is the output's sign)");
   return 0;
 }
@@ -438,7 +440,9 @@ int cvx_bn_act_apply(const float* y, long long M, int C, int hw, const BnTrainAr
   const dim3 grid(blocks_for(M, rows)), block(256);
   const size_t lds = fold_ws_bytes(C) + 2 * C * 4;
 #define CVX_LAUNCH_APPLY(A, R) hipLaunchKernelGGL((bn_act_apply_kernel<A, R>), grid, block, lds, st, y, M, C, hw, a, out, res, xhat, rows)
-  if (act == 0)
+  if (act == 0 && res_pre)
+    CVX_LAUNCH_APPLY(0, true);
+  else if (act == 0)
     CVX_LAUNCH_APPLY(0, false);
   else if (act == 1 && res_pre)
     CVX_LAUNCH_APPLY(1, true);
@@ -467,9 +471,12 @@ int cvx_bn_bwd_reduce(const half_t* xhat, long long M, int C, int hw, const BnCo
                       hipStream_t st) {
   CVX_TRY(check_c(C, M));
   CVX_CHECK(ak.act >= 0 && ak.act <= 2 && (ak.act != 1 || ak.fout.p), "bn_bwd: ReLU needs the forward output view");
+  CVX_CHECK(!(ak.act == 0 && ak.res_pre) || ak.fout.p, "bn_bwd: SiLU with a pre-activation residual needs the residual's forward value");
   int rows = cvx_stream_rows_per_block(M, C, 32);
   const dim3 grid(blocks_for(M, rows)), block(256);
-  if (ak.act == 0)
+  if (ak.act == 0 && ak.res_pre)
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<3>, grid, block, 0, st, xhat, M, C, hw, k, gout, ak.fout, part, rows);
+  else if (ak.act == 0)
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<0>, grid, block, 0, st, xhat, M, C, hw, k, gout, ak.fout, part, rows);
   else if (ak.act == 1)
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, block, 0, st, xhat, M, C, hw, k, gout, ak.fout, part, rows);
@@ -483,13 +490,16 @@ int cvx_bn_bwd_apply(const half_t* xhat, long long M, int C, int hw, const BnCoe
   CVX_TRY(check_c(C, M));
   CVX_TRY(check_act(ak.act, ak.res_pre, gres.p != nullptr));
   CVX_CHECK(ak.act != 1 || ak.fout.p, "bn_bwd: ReLU needs the forward output view");
+  CVX_CHECK(!(ak.act == 0 && ak.res_pre) || ak.fout.p, "bn_bwd: SiLU with a pre-activation residual needs the residual's forward value");
   int rows = cvx_stream_rows_per_block(M, C, 32);
   const dim3 grid(blocks_for(M, rows)), block(256);
   const size_t lds = fold_ws_bytes(C);
 #define CVX_LAUNCH_BWD(A, R)                                                                                                              \
   hipLaunchKernelGGL((bn_bwd_apply_kernel<A, R>), grid, block, lds, st, xhat, M, C, hw, k, part, inv_scale, dgamma, dbeta, gout, ak.fout, dy, gres, \
                      res_accumulate, rows)
-  if (ak.act == 0)
+  if (ak.act == 0 && ak.res_pre)
+    CVX_LAUNCH_BWD(3, true);
+  else if (ak.act == 0)
     CVX_LAUNCH_BWD(0, false);
   else if (ak.act == 1 && ak.res_pre)
     CVX_LAUNCH_BWD(1, true);

@@ -244,13 +244,13 @@ int build_static(cvx_engine* e) {
     CVX_CHECK(o.in.buf >= 0 && o.in.buf < (int)e->bufs.size() && o.out.buf >= 0 && o.out.buf < (int)e->bufs.size(), "op view buffer index");
     CVX_CHECK(o.type >= CVX_OP_CONV && o.type <= CVX_OP_DROPOUT, "unknown op type");
     // ops / epilogues without a backward pass: the DLA ops, L2Normalize, the conv + bias (+ ReLU) blocks with an fp16 output
-    if (o.type == CVX_OP_MAXPOOL2 || o.type == CVX_OP_DWCONVT || o.type == CVX_OP_COPY || o.type == CVX_OP_L2NORM ||
+    if (o.type == CVX_OP_DWCONVT || o.type == CVX_OP_COPY || o.type == CVX_OP_L2NORM ||
         (o.type == CVX_OP_CONV && (o.act >= CVX_ACT_BIAS_RELU || (o.flags & CVX_OPF_CONV_BIAS))))
       e->inference_only = true;
     if (o.type == CVX_OP_CONV && o.res.buf >= 0 && o.act != CVX_ACT_BIAS) {
       const bool pre = (o.flags & CVX_OPF_RES_PRE_ACT) != 0;
-      // the training passes hold relu(z + res) and silu(z) + res (bn_act.hip); the other two exist in the eval epilogue only
-      if ((o.act == CVX_ACT_BN_SILU && pre) || (o.act == CVX_ACT_BN_RELU && !pre)) e->inference_only = true;
+      // the training passes hold relu(z + res), silu(z + res) and silu(z) + res (bn_act.hip); relu(z) + res exists in the eval epilogue only
+      if (o.act == CVX_ACT_BN_RELU && !pre) e->inference_only = true;
     }
     if (o.type == CVX_OP_DROPOUT) CVX_CHECK(o.k >= 0 && o.k < 65536, "dropout: k = drop probability in units of 2^-16");
     if (o.type != CVX_OP_CONV) {
@@ -1124,6 +1124,12 @@ int backward_op(cvx_engine* e, int i) {
       CVX_TRY(cvx_upsample2_bwd(make_view(e, o.out, true), make_view(e, o.in, true), B, o.ih, o.iw, o.in.c, e->pool[i].in_accum, st));
       return 0;
     }
+    if (o.type == CVX_OP_MAXPOOL2) {
+      ProfScope ps(e, PROF_MISC, 0, (4.0 * o.ih * o.iw + 2.0 * o.oh * o.ow) * B * o.in.c, st);
+      CVX_TRY(cvx_maxpool2_bwd(make_view(e, o.in, false), make_view(e, o.out, true), make_view(e, o.in, true), B, o.ih, o.iw, o.oh, o.ow, o.in.c,
+                               e->pool[i].in_accum, st));
+      return 0;
+    }
     if (o.type == CVX_OP_MAXPOOL3S2 || o.type == CVX_OP_MAXPOOL3S1) {
       ProfScope ps(e, PROF_MISC, 0, (2.0 * o.ih * o.iw + 3.0 * o.oh * o.ow) * B * o.in.c, st);
       CVX_TRY(cvx_maxpool3_bwd(make_view(e, o.out, true), make_view(e, o.in, true), B, o.ih, o.iw, o.in.c, o.type == CVX_OP_MAXPOOL3S2 ? 2 : 1,
@@ -1162,7 +1168,10 @@ int backward_op(cvx_engine* e, int i) {
       ViewDesc gout = make_view(e, o.out, true);
       ViewDesc gres = make_view(e, o.res, true);
       BnCoef k{c.invstd, e->params + o.gamma_off, e->params + o.beta_off};
-      const BnActKind ak{act_kind(o), (o.flags & CVX_OPF_RES_PRE_ACT) ? 1 : 0, make_view(e, o.out, false)};
+      // ReLU: the mask is the sign of the forward output; SiLU with a pre-activation residual: the residual's forward value
+      const bool pre = (o.flags & CVX_OPF_RES_PRE_ACT) != 0 && o.res.buf >= 0;
+      const BnActKind ak{act_kind(o), pre ? 1 : 0,
+                         act_kind(o) == 1 ? make_view(e, o.out, false) : (act_kind(o) == 0 && pre ? make_view(e, o.res, false) : ViewDesc{nullptr, 0, 0})};
       ProfScope ps(e, PROF_BN_BWD, 0, (c.stem ? 4.0 : (gres.p ? 14.0 : 10.0) + (ak.act == 1 ? 4.0 : 0.0)) * M * C, st);
       static const bool tune_skip_reduce = cvx_tune_int("CVX_TUNE_SKIP_BN_REDUCE", 0) != 0;  // tuning build: timing without the pass (wrong results)
       if (!tune_skip_reduce) CVX_TRY(cvx_bn_bwd_reduce(c.ybuf, M, C, hw, k, gout, ak, c.stat_bwd, st));

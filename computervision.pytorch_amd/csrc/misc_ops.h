@@ -15,6 +15,9 @@ int cvx_copy_slice(const ViewDesc& in, const ViewDesc& out, int B, int HW, int C
 int cvx_maxpool3(const ViewDesc& in, const ViewDesc& out, int B, int IH, int IW, int C, int stride, uint8_t* idx, hipStream_t st);
 int cvx_maxpool3_bwd(const ViewDesc& gout, const ViewDesc& gin, int B, int IH, int IW, int C, int stride, const uint8_t* idx, int accumulate,
                      hipStream_t st);
+// gradient of the 2x2 stride-2 max pool (floor or ceil mode); `in` = the forward input (the argmax is re-derived from it)
+int cvx_maxpool2_bwd(const ViewDesc& in, const ViewDesc& gout, const ViewDesc& gin, int B, int IH, int IW, int OH, int OW, int C, int accumulate,
+                     hipStream_t st);
 int cvx_zero_slice(const ViewDesc& v, int B, int HW, int C, hipStream_t st);  // zero fill of a channel slice
 int cvx_avgpool_global_bwd(const ViewDesc& gout, const ViewDesc& gin, int B, int HW, int C, int accumulate, hipStream_t st);
 int cvx_resize_bilinear_bwd(const ViewDesc& gout, const ViewDesc& gin, int B, int IH, int IW, int OH, int OW, int C, int accumulate,

@@ -45,6 +45,60 @@ __global__ void maxpool2_kernel(ViewDesc in, ViewDesc out, int B, int IH, int IW
   *reinterpret_cast<h8*>(out.p + voff(out, b, (long long)h * OW + w) + cg * 8) = o;
 }
 
+// gradient of the 2x2 stride-2 max pool: the windows do not overlap, so every input pixel re-derives its own window's first maximum
+// (row-major scan, torch's rule) from the four forward inputs -- no argmax tensor.  Pixels outside every window (floor mode on an odd
+// size) receive zero.
+__global__ void maxpool2_bwd_kernel(ViewDesc in, ViewDesc gout, ViewDesc gin, int B, int IH, int IW, int OH, int OW, int CG, int accumulate) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long n = (long long)B * IH * IW * CG;
+  if (i >= n) return;
+  int cg = (int)(i % CG);
+  long long t = i / CG;
+  int ww = (int)(t % IW);
+  t /= IW;
+  int hh = (int)(t % IH);
+  int b = (int)(t / IH);
+  const int h = hh >> 1, w = ww >> 1;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  if (h < OH && w < OW) {
+    float best[8];
+    int bi[8];
+    bool first = true;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int y = 2 * h + (q >> 1), x = 2 * w + (q & 1);
+      if (y >= IH || x >= IW) continue;
+      const h8 v = *reinterpret_cast<const h8*>(in.p + voff(in, b, (long long)y * IW + x) + cg * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float f = (float)v[k];
+        if (first || f > best[k]) {
+          best[k] = f;
+          bi[k] = q;
+        }
+      }
+      first = false;
+    }
+    const int me = ((hh & 1) << 1) | (ww & 1);
+    const h8 g = *reinterpret_cast<const h8*>(gout.p + voff(gout, b, (long long)h * OW + w) + cg * 8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (bi[k] == me) acc[k] = (float)g[k];
+  }
+  half_t* q = gin.p + voff(gin, b, (long long)hh * IW + ww) + cg * 8;
+  if (accumulate) {
+    const h8 old = *reinterpret_cast<const h8*>(q);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += (float)old[k];
+  }
+  h8 o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = (half_t)acc[k];
+  *reinterpret_cast<h8*>(q) = o;
+}
+
 // ---- max pool 3x3 stride 2 pad 1 (ResNet stem, core/models/resnet.py:163) ----
 // idx (training): one byte per output element, the window tap dy*3+dx of the first maximum in row-major scan order (torch's rule)
 __global__ void maxpool3_kernel(ViewDesc in, ViewDesc out, int B, int IH, int IW, int OH, int OW, int CG, int stride, uint8_t* idx) {
@@ -800,6 +854,11 @@ int cvx_image_to_nhwc8(const float* img, int B, int H, int W, half_t* out, hipSt
 int cvx_maxpool2(const ViewDesc& in, const ViewDesc& out, int B, int IH, int IW, int OH, int OW, int C, hipStream_t st) {
   CVX_CHECK((OH == IH / 2 || OH == (IH + 1) / 2) && (OW == IW / 2 || OW == (IW + 1) / 2), "maxpool2: output size must be floor or ceil of half the input");
   return launch1d(maxpool2_kernel, (long long)B * OH * OW * (C / 8), st, in, out, B, IH, IW, OH, OW, C / 8);
+}
+int cvx_maxpool2_bwd(const ViewDesc& in, const ViewDesc& gout, const ViewDesc& gin, int B, int IH, int IW, int OH, int OW, int C, int accumulate,
+                     hipStream_t st) {
+  CVX_CHECK(C % 8 == 0 && (OH == IH / 2 || OH == (IH + 1) / 2) && (OW == IW / 2 || OW == (IW + 1) / 2), "maxpool2_bwd: C % 8 / output size");
+  return launch1d(maxpool2_bwd_kernel, (long long)B * IH * IW * (C / 8), st, in, gout, gin, B, IH, IW, OH, OW, C / 8, accumulate);
 }
 int cvx_l2norm(const ViewDesc& in, const ViewDesc& out, const float* weight, int B, int HW, int C, hipStream_t st) {
   CVX_CHECK(C % 8 == 0 && weight, "l2norm: C % 8 / weight");

@@ -58,6 +58,7 @@ extern "C" int cvx_bn_act_bwd_nhwc(const void* xhat_f16, const void* gout_f16, c
                                    float* dgamma, float* dbeta, void* dy_f16, void* gres_f16, int32_t res_accumulate, void* hip_stream) {
   CVX_CHECK(xhat_f16 && gout_f16 && gamma && beta && invstd && dgamma && dbeta && dy_f16 && batch > 0 && hw > 0, "bad arguments");
   CVX_CHECK(act != 1 || out_f16, "ReLU: the forward output is needed (its sign is the mask)");
+  CVX_CHECK(!(act == 0 && res_pre) || out_f16, "SiLU with a pre-activation residual: the residual's forward value is needed (pass it as out_f16)");
   const BnActKind ak{act, res_pre, out_f16 ? dense(out_f16, hw, c) : ViewDesc{nullptr, 0, 0}};
   hipStream_t st = (hipStream_t)hip_stream;
   const long long M = (long long)batch * hw;
@@ -147,6 +148,15 @@ extern "C" int cvx_maxpool3_bwd_nhwc(const void* gout_f16, const uint8_t* argmax
   CVX_CHECK(gout_f16 && argmax && gin_f16 && batch > 0 && c % 8 == 0, "bad arguments (channels in multiples of 8)");
   const int oh = (h - 1) / stride + 1, ow = (w - 1) / stride + 1;
   CVX_TRY(cvx_maxpool3_bwd(dense(gout_f16, oh * ow, c), dense(gin_f16, h * w, c), batch, h, w, c, stride, argmax, accumulate, (hipStream_t)hip_stream));
+  CVX_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
+  return 0;
+}
+extern "C" int cvx_maxpool2_bwd_nhwc(const void* x_f16, const void* gout_f16, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t ceil_mode,
+                                     void* gin_f16, int32_t accumulate, void* hip_stream) {
+  CVX_CHECK(x_f16 && gout_f16 && gin_f16 && batch > 0 && c % 8 == 0, "bad arguments (channels in multiples of 8)");
+  const int oh = ceil_mode ? (h + 1) / 2 : h / 2, ow = ceil_mode ? (w + 1) / 2 : w / 2;
+  CVX_TRY(cvx_maxpool2_bwd(dense(x_f16, h * w, c), dense(gout_f16, oh * ow, c), dense(gin_f16, h * w, c), batch, h, w, oh, ow, c, accumulate,
+                           (hipStream_t)hip_stream));
   CVX_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
   return 0;
 }

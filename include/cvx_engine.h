@@ -318,8 +318,9 @@ int cvx_bn_silu_bwd_nhwc(const void* xhat_f16, const void* gout_f16, int32_t bat
 /* The same two passes for the other Conv + BatchNorm blocks of the reference (C up to 2048).  act: 0 SiLU, 1 ReLU, 2 none.
  * res_pre = 1: the residual joins the PRE-activation, out = act(gamma*xhat + beta + res) (Bottleneck.forward, resnet.py:139-141:
  * out += identity; out = relu(out)) and gres receives the pre-activation gradient dz; res_pre = 0: out = act(.) + res, gres
- * receives gout.  ReLU's backward mask is the sign of the forward output `out_f16` (required for act = 1, else may be NULL);
- * ReLU with a post-activation residual and SiLU with a pre-activation one are refused.
+ * receives gout.  ReLU's backward mask is the sign of the forward output `out_f16` (required for act = 1); SiLU with a pre-activation
+ * residual (YOLOv7 RepConv: silu(bn(conv3x3) + bn(conv1x1)), yolov7_model.py:250-262) needs the residual's forward VALUE there instead;
+ * otherwise out_f16 may be NULL.  ReLU with a post-activation residual is refused.
  * Replaces: nn.BatchNorm2d + nn.ReLU in training mode (resnet.py:121-143, deeplabv3plus.py:19-27,63-68) and their autograd. */
 int cvx_bn_act_train_nhwc(const float* y_f32, int32_t batch, int32_t hw, int32_t c, const float* gamma, const float* beta, float eps,
                           float momentum, float* running_mean, float* running_var, const void* res_f16, int32_t act, int32_t res_pre,
@@ -386,6 +387,10 @@ int cvx_maxpool3_train_nhwc(const void* x_f16, int32_t batch, int32_t h, int32_t
 int cvx_maxpool3_bwd_nhwc(const void* gout_f16, const uint8_t* argmax, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t stride,
                           void* gin_f16, int32_t accumulate, void* hip_stream);
 int cvx_avgpool_global_bwd_nhwc(const void* gout_f16, int32_t batch, int32_t hw, int32_t c, void* gin_f16, int32_t accumulate, void* hip_stream);
+/* Gradient of the 2x2 stride-2 max pool of cvx_maxpool_nhwc (floor or ceil mode): x is the forward input, the first maximum of each
+ * window in row-major scan order takes the gradient (torch's rule).  Replaces: nn.MaxPool2d(2, 2) autograd (yolov7_model.py:74-86). */
+int cvx_maxpool2_bwd_nhwc(const void* x_f16, const void* gout_f16, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t ceil_mode,
+                          void* gin_f16, int32_t accumulate, void* hip_stream);
 int cvx_resize_bilinear_bwd_nhwc(const void* gout_f16, int32_t batch, int32_t ih, int32_t iw, int32_t c, int32_t oh, int32_t ow, void* gin_f16,
                                  int32_t accumulate, void* hip_stream);
 int cvx_dropout_nhwc(const void* x_f16, int32_t batch, int32_t hw, int32_t c, float p, uint64_t seed, void* out_f16, int32_t accumulate,

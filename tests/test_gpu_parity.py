@@ -181,7 +181,7 @@ def test_bn_silu_train_and_backward_unit(dev, B, H, W, C, res):
 
 
 @pytest.mark.parametrize("B,H,W,C,act,res_pre", [(2, 20, 20, 64, 1, 0), (2, 9, 11, 256, 1, 1), (1, 16, 16, 2048, 1, 1), (3, 7, 5, 1024, 2, 0),
-                                                   (2, 8, 8, 512, 2, 1), (16, 1, 1, 256, 1, 0)])
+                                                   (2, 8, 8, 512, 2, 1), (16, 1, 1, 256, 1, 0), (2, 10, 10, 256, 0, 1), (1, 20, 20, 512, 0, 1)])
 def test_bn_act_train_and_backward_unit(dev, B, H, W, C, act, res_pre):
     """The generalised BatchNorm passes (bn_act.hip): ReLU / no activation, the residual inside the activation (Bottleneck.forward,
     resnet.py:139-141), up to 2048 channels (layer4) and down to a 1 x 1 map (ASPPPooling, deeplabv3plus.py:29-33), against torch
@@ -198,7 +198,7 @@ def test_bn_act_train_and_backward_unit(dev, B, H, W, C, act, res_pre):
     z = F.batch_norm(yr, rm0.clone(), rv0.clone(), gr, br, True, 0.1, 1e-5)
     if res_pre:
         z = z + rr
-    out = F.relu(z) if act == 1 else z
+    out = F.relu(z) if act == 1 else (F.silu(z) if act == 0 else z)      # act 0 + res_pre: YOLOv7's RepConv, silu(bn(a) + bn(b))
     out.backward(gout16.float())
     st = L.stream_ptr(dev)
     yd = _nhwc(y).to(dev)
@@ -219,7 +219,8 @@ def test_bn_act_train_and_backward_unit(dev, B, H, W, C, act, res_pre):
     dgam, dbet = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
     dy = torch.empty_like(outd)
     gres = torch.full((B, H, W, C), 0.5, dtype=torch.float16, device=dev) if res_pre else None
-    L.check(lib.cvx_bn_act_bwd_nhwc(L.ptr(xh), L.ptr(goutd), L.ptr(outd), B, H * W, C, L.ptr(gd), L.ptr(bd), L.ptr(invstd), act, res_pre, 1.0,
+    fwd_operand = resd if (act == 0 and res_pre) else outd                # ReLU: its own output (mask); SiLU + pre-residual: the residual
+    L.check(lib.cvx_bn_act_bwd_nhwc(L.ptr(xh), L.ptr(goutd), L.ptr(fwd_operand), B, H * W, C, L.ptr(gd), L.ptr(bd), L.ptr(invstd), act, res_pre, 1.0,
                                     L.ptr(dgam), L.ptr(dbet), L.ptr(dy), L.ptr(gres), 1, st), "bn bwd")
     assert rel(dy.float().permute(0, 3, 1, 2), yr.grad) < 2e-3
     assert rel(dgam, gr.grad) < 1e-3 and rel(dbet, br.grad) < 1e-3
@@ -350,6 +351,16 @@ def test_training_pool_resize_dropout_units(dev, B, H, W, C):
             L.check(lib.cvx_maxpool3_bwd_nhwc(L.ptr(_nhwc(go16).to(dev)), L.ptr(am), B, H, W, C, stride, L.ptr(gin), acc, st), "maxpool3 bwd")
             want = xr.grad + (base16.float() if acc else 0)
             assert (gin.float().permute(0, 3, 1, 2).cpu() - want).abs().max() <= 2e-3 * max(1.0, float(want.abs().max()))
+    for ceil in ((0, 1) if H >= 2 and W >= 2 else (1,)):              # 2x2 / stride 2 (YOLOv7 Transition_Block, SSD's ceil-mode pool)
+        xr = x16.float().requires_grad_(True)
+        ref = F.max_pool2d(xr, 2, 2, ceil_mode=bool(ceil))
+        go16 = torch.randn(*ref.shape, generator=g).half()
+        ref.backward(go16.float())
+        for acc in (0, 1):
+            gin = _nhwc(base16).to(dev).clone()
+            L.check(lib.cvx_maxpool2_bwd_nhwc(L.ptr(xd), L.ptr(_nhwc(go16).to(dev)), B, H, W, C, ceil, L.ptr(gin), acc, st), "maxpool2 bwd")
+            want = xr.grad + (base16.float() if acc else 0)
+            assert (gin.float().permute(0, 3, 1, 2).cpu() - want).abs().max() <= 2e-3 * max(1.0, float(want.abs().max())), (ceil, acc)
     xf16 = torch.randn(B, C, H, W, generator=g).half()
     # global average pool
     xr = xf16.float().requires_grad_(True)

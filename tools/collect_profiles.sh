@@ -12,17 +12,21 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $RO
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $ROOT/bench.py --no-cpu-baseline --steps 3 --warmup 2 --profile-steps 1 > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $ROOT/bench.py --no-cpu-baseline --steps 3 --warmup 2 --profile-steps 1 > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cn -- python $ROOT/bench.py --workload centernet --steps 5 --warmup 2 > $OUT/${R}_bench_centernet_under_rocprof.json 2> $OUT/stats_cn.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_dl -- python $ROOT/bench.py --workload deeplab_train --steps 5 --warmup 2 > $OUT/${R}_bench_deeplab_train_under_rocprof.json 2> $OUT/stats_dl.err
 cd $ROOT
 cp $(ls $OUT/stats/*/*_kernel_stats.csv | head -1) $OUT/${R}_bench_kernel_stats.csv
 cp $(ls $OUT/stats_cn/*/*_kernel_stats.csv | head -1) $OUT/${R}_bench_centernet_kernel_stats.csv
+cp $(ls $OUT/stats_dl/*/*_kernel_stats.csv | head -1) $OUT/${R}_bench_deeplab_train_kernel_stats.csv
 python tools/pmc_traffic.py $(ls $OUT/pmc_fetch/*/*_counter_collection.csv | head -1) $(ls $OUT/pmc_write/*/*_counter_collection.csv | head -1) $OUT/${R}_conv_traffic.json
 cp $OUT/${R}_conv_traffic.json profiles/${R}_conv_traffic.json   # bench.py quotes it when its lib_sha256 is the running library's
 python bench.py --steps 30 --warmup 5 > $OUT/${R}_bench.json 2> $OUT/bench.err
 python bench.py --workload centernet --steps 10 --warmup 2 > $OUT/${R}_bench_centernet.json 2>> $OUT/bench.err
 python bench.py --model s --steps 20 --warmup 3 --no-cpu-baseline > $OUT/${R}_bench_yolov8s.json 2>> $OUT/bench.err
 python bench.py --workload deeplab --steps 10 --warmup 2 > $OUT/${R}_bench_deeplab.json 2>> $OUT/bench.err
+python bench.py --workload deeplab_train --steps 20 --warmup 3 > $OUT/${R}_bench_deeplab_train.json 2>> $OUT/bench.err
 python bench.py --workload yolov7 --steps 10 --warmup 2 > $OUT/${R}_bench_yolov7.json 2>> $OUT/bench.err
 python bench.py --workload ssd --steps 10 --warmup 2 > $OUT/${R}_bench_ssd.json 2>> $OUT/bench.err
 python tools/op_profile.py 5 > $OUT/${R}_op_profile.txt 2>> $OUT/bench.err
-rm -rf $OUT/stats $OUT/stats_cn $OUT/pmc_fetch $OUT/pmc_write
+python tools/op_profile.py 3 deeplab > $OUT/${R}_op_profile_deeplab_train.txt 2>> $OUT/bench.err
+rm -rf $OUT/stats $OUT/stats_cn $OUT/stats_dl $OUT/pmc_fetch $OUT/pmc_write
 ls -la $OUT
