@@ -144,7 +144,7 @@ def build_yolov7_graph(lay: Yolo7Layout, H: int, W: int) -> Graph:
         s = lay.convs[ckey]
         k, st = s["k"], s["stride"]
         ho, wo = (hin + 2 * (k // 2) - k) // st + 1, (win + 2 * (k // 2) - k) // st + 1
-        op = dict(type=L.OP_CONV, name=ckey, out=vout, ih=hin, iw=win, oh=ho, ow=wo, k=k, stride=st, pad=k // 2, dil=1, act=act, needs_dgrad=0,
+        op = dict(type=L.OP_CONV, name=ckey, out=vout, ih=hin, iw=win, oh=ho, ow=wo, k=k, stride=st, pad=k // 2, dil=1, act=act, needs_dgrad=0 if ckey == "backbone.stem.0.conv" else 1,
                   w_cin=s["cin"], w_off=s["w_off"], gamma_off=s.get("gamma_off", 0), beta_off=s.get("beta_off", 0), bias_off=s.get("bias_off", 0),
                   rmean_off=s.get("rmean_off", 0), rvar_off=s.get("rvar_off", 0), flags=L.OPF_RES_PRE_ACT if res is not None else 0)
         op["in"] = vin
@@ -270,14 +270,21 @@ class _Holder(nn.Module):
 
 
 class Yolo7L(nn.Module):
-    """``Yolo7(cfg)`` of the reference (phi 'l', yolov7_model.py:355-525) on the engine: ``model.eval(); model(x)`` returns
-    (out0, out1, out2), each (B, 3 * (5 + nc), H_l, W_l) fp32, coarsest level first."""
+    """``Yolo7(cfg)`` of the reference (phi 'l', yolov7_model.py:355-525) on the engine: ``model(x)`` returns (out0, out1, out2),
+    each (B, 3 * (5 + nc), H_l, W_l) fp32, coarsest level first.  In training mode (grad enabled) the outputs are connected to the
+    engine's backward pass: any torch loss on them (the reference's Yolo7Loss is plain torch code on these tensors,
+    core/loss/yolo7_loss.py) back-propagates into batch-statistics BatchNorm, the RepConv sum inside the SiLU, 2x2 / 5x5 max pools,
+    upsampling and every convolution's data / weight gradient; parameter gradients land in ``p.grad`` (views of one flat arena)."""
 
-    def __init__(self, num_classes: int = 20):
+    def __init__(self, num_classes: int = 20, loss_scale: float = 1024.0):
         super().__init__()
         self.layout = lay = Yolo7Layout(num_classes)
         self.num_classes = num_classes
-        self._flat = {"param": torch.zeros(lay.n_params), "stat": torch.zeros(lay.n_stats), "nbt": torch.zeros(len(lay.nbt_keys), dtype=torch.long)}
+        self.loss_scale = float(loss_scale)
+        self._flat = {"param": torch.zeros(lay.n_params), "stat": torch.zeros(lay.n_stats), "nbt": torch.zeros(len(lay.nbt_keys), dtype=torch.long),
+                      "grad": None}
+        self._anchor = torch.zeros(1, requires_grad=True)
+        self._grads_attached = False
         self._engines: Dict = {}
         self._build_tree()
         self._attach_views()
@@ -303,11 +310,15 @@ class Yolo7L(nn.Module):
                 continue
             view = torch.as_strided(self._flat[sl.arena], sl.shape, sl.strides, sl.offset)
             if sl.trainable:
-                mod._parameters[parts[-1]] = nn.Parameter(view, requires_grad=False)
+                old = mod._parameters.get(parts[-1])
+                mod._parameters[parts[-1]] = nn.Parameter(view, requires_grad=True if old is None else old.requires_grad)
             else:
                 mod._buffers[parts[-1]] = view
 
     def _apply(self, fn, recurse=True):
+        self._flat["grad"] = None
+        self._grads_attached = False
+        self._anchor = fn(self._anchor.detach()).requires_grad_(True)
         for k in ("param", "stat", "nbt"):
             t_ = fn(self._flat[k])
             if k != "nbt" and t_.dtype != torch.float32:
@@ -351,6 +362,21 @@ class Yolo7L(nn.Module):
             self._flat["nbt"].zero_()
 
     # ---- engine plumbing ---------------------------------------------------------------------------------
+    @property
+    def flat_params(self) -> torch.Tensor:
+        return self._flat["param"]
+
+    @property
+    def flat_stats(self) -> torch.Tensor:
+        return self._flat["stat"]
+
+    @property
+    def flat_grads(self) -> torch.Tensor:
+        if self._flat["grad"] is None or self._flat["grad"].device != self._flat["param"].device:
+            self._flat["grad"] = torch.zeros_like(self._flat["param"])
+            self._grads_attached = False
+        return self._flat["grad"]
+
     def engine_for(self, h: int, w: int) -> Engine:
         dev = self._flat["param"].device
         key = (h, w, dev)
@@ -361,29 +387,86 @@ class Yolo7L(nn.Module):
             eng = Engine(build_yolov7_graph(self.layout, h, w), dev)
             eng.set_bn(BN_EPS, BN_MOMENTUM)
             self._engines[key] = eng
-        eng.bind(self._flat["param"], None, self._flat["stat"])
+        eng.bind(self._flat["param"], self.flat_grads if self.training else self._flat["grad"], self._flat["stat"])
         return eng
 
-    def forward_rows(self, x: torch.Tensor) -> torch.Tensor:
+    def _run_forward(self, x: torch.Tensor, training: bool) -> torch.Tensor:
         """(B,3,H,W) -> the engine's fp32 head rows (B, sum_l H_l*W_l, no_pad): what ``cvx_yolo7_decode`` reads."""
-        if self.training:
-            raise L.CvxError("YOLOv7 on the MI355X engine is inference-only this round: call model.eval() first")
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError("expected images of shape (B, 3, H, W)")
         eng = self.engine_for(int(x.shape[2]), int(x.shape[3]))
         self._last_engine = eng
-        return eng.forward(x, False)
+        rows = eng.forward(x, training)
+        if training:
+            self._flat["nbt"] += 1
+        return rows
 
-    def forward(self, x: torch.Tensor):
-        rows = self.forward_rows(x)
-        self.last_rows = rows
-        B = int(x.shape[0])
+    def forward_rows(self, x: torch.Tensor) -> torch.Tensor:
+        return self._run_forward(x, self.training)
+
+    def _rows_to_levels(self, rows: torch.Tensor):
+        B = int(rows.shape[0])
         lay, lib = self.layout, L.load()
         outs, a_off = [], 0
         A = self._last_engine.graph.anchors
         for (hh, ww) in self._last_engine.graph.level_hw:
-            o = torch.empty(B, lay.no_pad, hh, ww, dtype=torch.float32, device=x.device)
-            L.check(lib.cvx_pred_level_to_nchw(L.ptr(rows), B, A, lay.no_pad, a_off, hh, ww, L.ptr(o), L.stream_ptr(x.device)), "cvx_pred_level_to_nchw")
-            outs.append(o[:, :lay.no])
+            o = torch.empty(B, lay.no_pad, hh, ww, dtype=torch.float32, device=rows.device)
+            L.check(lib.cvx_pred_level_to_nchw(L.ptr(rows), B, A, lay.no_pad, a_off, hh, ww, L.ptr(o), L.stream_ptr(rows.device)), "cvx_pred_level_to_nchw")
+            outs.append(o)
             a_off += hh * ww
-        return tuple(outs)
+        return outs
+
+    def attach_grads(self):
+        """Make ``p.grad`` of every parameter a view of the flat gradient arena (torch optimisers / GradScaler)."""
+        g = self.flat_grads
+        modules = dict(self.named_modules())
+        for key, slot in self.layout.slots.items():
+            if not slot.trainable:
+                continue
+            mod_name, attr = key.rsplit(".", 1)
+            modules[mod_name]._parameters[attr].grad = torch.as_strided(g, slot.shape, slot.strides, slot.offset)
+        self._grads_attached = True
+
+    def _backward_levels(self, grads):
+        """Gradients w.r.t. the three (B, no_pad, h, w) level tensors -> loss_scale * dLoss/drows in fp16 -> engine backward."""
+        eng, lay, lib = self._last_engine, self.layout, L.load()
+        ref = next(g for g in grads if g is not None)
+        B, A = int(ref.shape[0]), eng.graph.anchors
+        dpred = torch.zeros(B, A, lay.no_pad, dtype=torch.float16, device=ref.device)
+        a_off = 0
+        for g, (hh, ww) in zip(grads, eng.graph.level_hw):
+            if g is not None:
+                L.check(lib.cvx_nchw_grad_to_dpred(L.ptr(g.contiguous().float()), B, A, lay.no_pad, a_off, hh, ww, self.loss_scale, L.ptr(dpred),
+                                                   L.stream_ptr(ref.device)), "cvx_nchw_grad_to_dpred")
+            a_off += hh * ww
+        first = next(p for p in self.parameters() if p.requires_grad)
+        if first.grad is None:               # optimizer.zero_grad(set_to_none=True) happened (or first step)
+            self.flat_grads.zero_()
+            self._grads_attached = False
+        self.last_dpred = dpred
+        eng.backward(dpred, self.loss_scale)
+        if not self._grads_attached or first.grad is None:
+            self.attach_grads()
+
+    def forward(self, x: torch.Tensor):
+        if self.training and torch.is_grad_enabled():
+            outs = _Y7Fn.apply(x, self._anchor, self)
+        else:
+            self.last_rows = self._run_forward(x, self.training)
+            outs = self._rows_to_levels(self.last_rows)
+        return tuple(o[:, :self.layout.no] for o in outs)
+
+
+class _Y7Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, images, anchor, model):
+        ctx.model = model
+        ctx.set_materialize_grads(False)
+        model.last_rows = model._run_forward(images, training=True)
+        return tuple(model._rows_to_levels(model.last_rows))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        if any(g is not None for g in grads):
+            ctx.model._backward_levels(grads)
+        return None, None, None

@@ -42,7 +42,9 @@ class YOLOv7:
         return model, "YOLOv7"
 
     def build_loss(self):
-        raise L.CvxError("YOLOv7 training (Yolo7Loss, core/loss/yolo7_loss.py) is not built on the MI355X engine yet: inference only")
+        raise L.CvxError("Yolo7Loss (core/loss/yolo7_loss.py, SimOTA assignment) has no HIP kernel yet.  The network itself trains on the engine: "
+                         "model.train(); outs = model(x) are ordinary tensors connected to the engine's backward pass, so the reference's own "
+                         "Yolo7Loss module (plain torch code on these outputs) can be applied to them unchanged")
 
     # ---- decode ---------------------------------------------------------------------------------------
     def _levels(self, model):

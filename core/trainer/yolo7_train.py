@@ -1,5 +1,6 @@
 """``Yolo7Trainer`` -- registered as ``trainer_yolo7`` like the reference's (core/trainer/yolo7_train.py), so that
-``export_from_registry("yolo7")`` resolves.  The MI355X engine runs YOLOv7 for inference only this round; training raises."""
+``export_from_registry("yolo7")`` resolves.  The network's forward + backward run on the MI355X engine (``Yolo7L`` in training mode);
+the loss (Yolo7Loss, SimOTA) and therefore this trainer's loop are not built: ``train()`` raises."""
 from computervision.pytorch_amd import _lib as L
 from registry import trainer_registry
 
@@ -10,4 +11,4 @@ class Yolo7Trainer:
         self.cfg, self.device = cfg, device
 
     def train(self):
-        raise L.CvxError("YOLOv7 training is not built on the MI355X engine yet (inference + decode only); see DESIGN.md")
+        raise L.CvxError("the YOLOv7 training LOOP is not built (Yolo7Loss has no HIP kernel); the network's forward + backward are: see DESIGN.md 7c")

@@ -148,6 +148,56 @@ def deeplab_train_section(builder, report):
                                    note="bn3.weight = 0.1; dropout p = 0 (second pass: p = 0.1 with the reference's captured mask)")
 
 
+def yolov7_train_section(builder, report):
+    """11b. YOLOv7-l network forward + backward in training mode: the REAL reference model (model.train()), a fixed linear functional
+    of its three outputs (yolov7_ref.projection_loss; the reference's Yolo7Loss is torch code on these tensors and stays what it is),
+    loss.backward() -> every parameter gradient and the updated running statistics.  Pins the oracle's train-mode restatement."""
+    from oracle import yolov7_ref as Y7
+    ycfg, yalgo_cls, _ = builder.export_from_registry("yolo7")
+    ycfg.train.pretrained = False
+    torch.manual_seed(0)
+    ymodel, _ = yalgo_cls(ycfg, torch.device("cpu")).build_model()
+    nc = ycfg.dataset.num_classes
+    sd0 = {k: v.clone() for k, v in ymodel.state_dict().items()}
+    my0 = Y7.init_state_dict(nc, seed=0)
+    assert all(torch.equal(sd0[k], my0[k]) for k in sd0)
+    B, H, W = 2, 160, 224
+    g = torch.Generator().manual_seed(31)
+    x = torch.rand(B, 3, H, W, generator=g)
+    ymodel.train()
+    outs = ymodel(x.clone())
+    weights = Y7.projection_weights([o.shape for o in outs], seed=9)
+    loss = Y7.projection_loss(outs, weights)
+    loss.backward()
+    ref_grads = {k: p.grad.clone() for k, p in ymodel.named_parameters()}
+    ref_sd = {k: v.clone() for k, v in ymodel.state_dict().items()}
+    work = {k: v.clone() for k, v in sd0.items()}
+    my_loss, my_grads, my_outs = Y7.loss_and_grads(work, x.clone(), weights)
+    assert abs(float(my_loss) - float(loss)) <= 1e-6 * max(abs(float(loss)), 1e-3), (float(my_loss), float(loss))
+    for a_, b_ in zip(my_outs, outs):
+        assert torch.allclose(a_, b_.detach(), rtol=1e-4, atol=1e-5)
+    worst = 0.0
+    for k, gr in ref_grads.items():
+        e = float((my_grads[k] - gr).norm() / gr.norm().clamp_min(1e-30))
+        worst = max(worst, e)
+        assert e < 1e-4, (k, e)
+    for k in ref_sd:
+        if k.endswith(("running_mean", "running_var")):
+            assert torch.allclose(work[k], ref_sd[k], rtol=1e-5, atol=1e-6), k
+    keys = list(ref_grads.keys())
+    full = ["yolo_head_P3.weight", "yolo_head_P5.bias", "rep_conv_1.rbr_dense.1.weight", "rep_conv_1.rbr_1x1.0.weight", "sppcspc.cv1.bn.weight",
+            "down_sample1.cv1.conv.weight", "backbone.dark2.0.conv.weight", "backbone.stem.0.conv.weight", "backbone.stem.0.bn.bias"]
+    full = [k for k in full if k in ref_grads]
+    stat_keys = ["backbone.stem.0.bn.running_mean", "backbone.stem.0.bn.running_var", "rep_conv_2.rbr_1x1.1.running_var", "sppcspc.cv7.bn.running_mean"]
+    stat_keys = [k for k in stat_keys if k in ref_sd]
+    np.savez_compressed(os.path.join(GOLD, "yolov7_train_160x224.npz"), x=x.numpy(), proj_seed=np.array(9), loss=np.array(float(loss)),
+                        out_sub=np.concatenate([o.detach().flatten()[::7].numpy() for o in outs]), grad_keys=np.array(keys),
+                        grad_norm=np.array([float(ref_grads[k].double().norm()) for k in keys]),
+                        grad_sum=np.array([float(ref_grads[k].double().sum()) for k in keys]), stat_keys=np.array(stat_keys),
+                        **{"g:" + k: ref_grads[k].numpy() for k in full}, **{"s:" + k: ref_sd[k].numpy().copy() for k in stat_keys})
+    report["yolov7_train"] = dict(loss=float(loss), worst_grad_rel_oracle_vs_reference=worst, tensors=len(keys), full=full, stats=stat_keys)
+
+
 def main():
     sys.path.insert(0, ROOT)
     from oracle import yolov8_ref as O
@@ -554,6 +604,8 @@ def main():
     report["yolov7"] = dict(init="bit-exact, %d tensors" % len(ref_sd), params=int(sum(p_.numel() for p_ in ymodel.parameters())),
                             detections=n_det, out_absmax=[float(o_.abs().max()) for o_ in ref7])
 
+    yolov7_train_section(builder, report)
+
     # ---- 12. SSD300 VGG16-BN: init, priors, eval forward on a calibrated network, decode ----------------------
     from oracle import ssd_ref as SS
     scfg, salgo_cls, _ = builder.export_from_registry("ssd")
@@ -643,7 +695,7 @@ def only(section):
     builder = _import_reference()
     torch.set_num_threads(8)
     report = {}
-    {"deeplab_train": deeplab_train_section}[section](builder, report)
+    {"deeplab_train": deeplab_train_section, "yolov7_train": yolov7_train_section}[section](builder, report)
     path = os.path.join(GOLD, "PIN_REPORT.json")
     full = json.load(open(path)) if os.path.exists(path) else {}
     full.update(report)

@@ -1,4 +1,5 @@
-"""CPU oracle for YOLOv7-l inference (network + anchor decode + per-class NMS) -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+"""CPU oracle for YOLOv7-l: network forward (eval / train mode) and backward, anchor decode, per-class NMS -- TEST INFRASTRUCTURE,
+NOT PRODUCT CODE.
 
 SURVEY.md section 8 row a16 / (f)3.  A torch-CPU fp32 restatement, functional over a flat ``state_dict`` with the
 reference's keys, of
@@ -14,8 +15,13 @@ reference's keys, of
   absent here (parity unpinned upstream, as for YOLOv8): restated as the standard greedy algorithm, ties broken by the
   lower index (oracle/nms_ref.py).
 
+Training (``forward(training=True)``, ``projection_loss``, ``loss_and_grads``): batch-statistics BatchNorm with the running
+statistics updated in place; the backward pass is torch autograd over this restatement, driven by a fixed linear functional of
+the three outputs (the reference's Yolo7Loss, core/loss/yolo7_loss.py, is torch code on those tensors and is not restated).
+
 Parity pin: ``oracle/make_golden.py`` section 11 imports the real reference and asserts the seed-0 ``state_dict`` bit for
-bit, the forward to fp32 round-off and the decoded tensor (before NMS) exactly.
+bit, the forward to fp32 round-off and the decoded tensor (before NMS) exactly; section 11b asserts the train-mode outputs and
+every parameter gradient of ``projection_loss`` against the real model's autograd.
 """
 from __future__ import annotations
 
@@ -124,7 +130,11 @@ FP16_STORAGE = [False]
 
 
 def _q(t):
-    return t.half().float() if FP16_STORAGE[0] else t
+    if not FP16_STORAGE[0]:
+        return t
+    if t.requires_grad:                       # straight-through: the value is rounded, the gradient passes unrounded
+        return t + (t.detach().half().float() - t.detach())
+    return t.half().float()
 
 
 def _bn(sd, key, y, training):
@@ -236,3 +246,28 @@ def nms(decoded, nc: int, conf_threshold: float, nms_threshold: float):
             keep_idx.append(idx[sel][k])
         res.append((torch.cat(rows).numpy(), torch.cat(keep_idx).numpy()))
     return res
+
+
+def projection_weights(shapes, seed: int = 9):
+    """Fixed N(0,1) tensors of the three output shapes: the linear functional the backward parity runs on."""
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(*sh, generator=g) for sh in shapes]
+
+
+def projection_loss(outs, weights):
+    """sum_l mean(out_l * w_l): every output element receives the gradient w_l / numel_l."""
+    return sum((o * w).mean() for o, w in zip(outs, weights))
+
+
+def loss_and_grads(sd, x, weights=None, seed: int = 9):
+    """Train-mode forward + backward of ``projection_loss``: (loss, {key: grad}, outs); running statistics in ``sd`` are updated."""
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()
+              if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var"))}
+    work = dict(sd)
+    work.update(params)
+    outs = forward(work, x, training=True)
+    if weights is None:
+        weights = projection_weights([o.shape for o in outs], seed)
+    loss = projection_loss(outs, weights)
+    loss.backward()
+    return loss.detach(), {k: p.grad for k, p in params.items()}, [o.detach() for o in outs]

@@ -1458,9 +1458,7 @@ def test_yolov7_full_size_through_the_plugin_api(dev):
     assert float(dec[..., :2].min()) > -0.1 and float(dec[..., :2].max()) < 1.1 and float(dec[..., 4:].min()) >= 0 and float(dec[..., 4:].max()) <= 1
     res = algo.predict_tensor(model, x, 480, 640, conf_threshold=0.9)
     assert len(res) == 2
-    model.train()
-    with pytest.raises(LL.CvxError):
-        model(x)
+    # the network trains (test_yolov7_training_*); the SimOTA loss and the trainer around it are not built on the engine
     with pytest.raises(LL.CvxError):
         algo.build_loss()
     with pytest.raises(LL.CvxError):
@@ -1655,28 +1653,18 @@ def test_deeplab_training_step_matches_the_reference_fixture(dev, gold):
     assert int(sdm["backbone.bn1.num_batches_tracked"]) == 1
 
 
-def test_deeplab_per_layer_backward_on_the_engines_own_operands(dev, gold):
-    """Every op of the DeepLabv3+ backward pass against fp64 on the ENGINE'S OWN operands (cvx_engine_debug_copy): for each
-    Conv + BatchNorm block its xhat, its fp16 output (ReLU mask), the gradient g arriving at its output and the gradient dy it hands
-    on -> dgamma / dbeta (2e-6), dy (one fp16 rounding), the weight gradient conv_wgrad(x, dy) incl. the 7x7 stem on the NHWC image
-    copy, the dilated 3x3 and the 1x1 stride-2 downsample (5e-4: fp32 MFMA accumulation of fp16 products); for each activation
-    buffer the gradient it ends up with = the sum over ALL its consumers (data gradients of convolutions, residual branches
-    taking dz, max pool / average pool / resize / dropout backward), each recomputed in fp64 from that consumer's own operands
-    (2e-3: one fp16 rounding per accumulation).  Together with the unit tests this pins the backward pass op by op, which
-    the end-to-end comparison (mask flips) cannot."""
-    from computervision.pytorch_amd.deeplab import SegLoss
-    g = gold("deeplab_train_97x129.npz")
-    m = _deeplab_train_model(dev, g, dropout_p=0.1)
-    m.seed = 5
-    x, t = torch.from_numpy(g["x"]), torch.from_numpy(g["target"].astype(np.int64))
-    B = x.shape[0]
-    crit = SegLoss("focal")
-    loss = crit(m(x.to(dev)), t.to(dev))
-    loss.backward()
-    torch.cuda.synchronize()
+def _check_backward_per_layer(m, B, dpred, min_layers, min_buffers):
+    """Every op of the last backward pass of model `m` against fp64 on the ENGINE'S OWN operands (cvx_engine_debug_copy): for each
+    Conv + BatchNorm block its xhat, its forward output / residual, the gradient g arriving at its output and the gradient dy it
+    hands on -> dgamma / dbeta (2e-6), dy (one fp16 rounding), the weight gradient conv_wgrad(x, dy) (5e-4: fp32 MFMA accumulation of
+    fp16 products); for each activation buffer the gradient it ends up with = the sum over ALL its consumers (data gradients,
+    residual branches taking dz, pool / resize / upsample / dropout backward), each recomputed in fp64 from that consumer's own
+    operands (2e-3: one fp16 rounding per accumulation)."""
     eng, lay, scale = m._last_engine, m.layout, m.loss_scale
     gr = eng.graph
     P, G = m.flat_params.double().cpu(), m.flat_grads.double().cpu()
+    no_pad = gr.bufs[gr.pred_buf][2]
+    dpred = dpred.double().cpu().reshape(B, gr.anchors, no_pad)
 
     def act(view, grad=False):                              # (B, h, w, c) fp64 slice of an engine buffer
         b, off, c = view[0], view[1], view[2]
@@ -1685,45 +1673,63 @@ def test_deeplab_per_layer_backward_on_the_engines_own_operands(dev, gold):
 
     nchw = lambda a: a.permute(0, 3, 1, 2).contiguous()     # noqa: E731
     nhwc = lambda a: a.permute(0, 2, 3, 1).contiguous()     # noqa: E731
-    expect, unknown = {}, {}                                # buffer slice -> summed fp64 input-gradient contributions
+    expect, covered, unknown = {}, {}, {}                   # buffer -> summed fp64 input-gradient contributions, per channel
 
     def add(view, contrib):
-        key = (view[0], view[1], view[2])
-        expect[key] = contrib if key not in expect else expect[key] + contrib
+        b, off, c = view[0], view[1], view[2]
+        if b not in expect:
+            h, w, cc, _ = gr.bufs[b]
+            expect[b] = torch.zeros(B, h, w, cc, dtype=torch.float64)
+            covered[b] = torch.zeros(cc, dtype=torch.bool)
+        expect[b][..., off:off + c] += contrib               # consumers may read overlapping slices of a concat buffer (ELAN)
+        covered[b][off:off + c] = True
 
-    lh, lw = gr.level_hw[0]
+    def spec(name):
+        cs = lay.convs[name]
+        return cs if isinstance(cs, dict) else dict(cout_eng=cs.cout_eng, cin=cs.cin, k=cs.k, w_off=cs.w_off, gamma_off=cs.gamma_off,
+                                                    beta_off=cs.beta_off, bias_off=cs.bias_off)
+
     n_w = n_bn = 0
     for i, o in enumerate(gr.ops):
         typ = o["type"]
         if typ == L.OP_CONV:
-            cs = lay.convs[o["name"]]
-            C, cin, k = cs["cout_eng"], cs["cin"], cs["k"]
+            cs = spec(o["name"])
+            C, cin, k = cs.get("cout_eng", o["out"][2]), cs["cin"], cs["k"]
+            C = o["out"][2]
             xin = act(o["in"])[..., :cin]
             wq = P[cs["w_off"]:cs["w_off"] + C * k * k * cin].reshape(C, k, k, cin).permute(0, 3, 1, 2).float().half().double()
             if o["act"] == L.ACT_BIAS:
-                dy = m.last_dpred.double().cpu().reshape(B, lh, lw, C)      # the loss kernel's output: loss_scale * dLoss/drows
+                a0 = o["out"][3]
+                dy = dpred[:, a0:a0 + o["oh"] * o["ow"], o["out"][1]:o["out"][1] + C].reshape(B, o["oh"], o["ow"], C)
                 want_b = dy.reshape(-1, C).sum(0) / scale
-                assert rel(G[cs["bias_off"]:cs["bias_off"] + C][:lay.nc], want_b[:lay.nc]) < 1e-5, o["name"]
+                got_b = G[cs["bias_off"]:cs["bias_off"] + C]
+                assert rel(got_b, want_b) < 1e-5 or float(want_b.norm()) == 0.0, o["name"]
             else:
                 xh = eng.read_layer(i, B, "xhat").double().cpu().reshape(-1, C)
                 dy = eng.read_layer(i, B, "dy").double().cpu().reshape(B, o["oh"], o["ow"], C)
                 gout = act(o["out"], grad=True).reshape(-1, C)
-                fo = act(o["out"]).reshape(-1, C)
-                dz = gout * (fo > 0) if o["act"] == L.ACT_BN_RELU else gout
-                ga = P[cs["gamma_off"]:cs["gamma_off"] + C]
+                ga, be = P[cs["gamma_off"]:cs["gamma_off"] + C], P[cs["beta_off"]:cs["beta_off"] + C]
+                pre_res = "res" in o and (o.get("flags", 0) & L.OPF_RES_PRE_ACT)
+                if o["act"] == L.ACT_BN_RELU:
+                    dz = gout * (act(o["out"]).reshape(-1, C) > 0)
+                elif o["act"] == L.ACT_BN_SILU:
+                    z = xh * ga + be + (act(o["res"]).reshape(-1, C) if pre_res else 0)
+                    sg = torch.sigmoid(z)
+                    dz = gout * (sg * (1 + z * (1 - sg)))
+                else:
+                    dz = gout
                 want_g, want_b = (dz * xh).sum(0) / scale, dz.sum(0) / scale
                 got_g, got_b = G[cs["gamma_off"]:cs["gamma_off"] + C], G[cs["beta_off"]:cs["beta_off"] + C]
-                assert rel(got_g, want_g) < 2e-6 and rel(got_b, want_b) < 2e-6, (o["name"], rel(got_g, want_g), rel(got_b, want_b))
-                core = dz - dz.mean(0) - xh * (dz * xh).mean(0)
-                gi = (dy.reshape(-1, C) * core).sum(0) / (core * core).sum(0).clamp_min(1e-300)
-                rms = float(dy.pow(2).mean().sqrt())
-                e_dy = rel(dy.reshape(-1, C), core * gi)
-                assert e_dy < 1e-3 + 6e-8 / max(rms, 1e-30), (o["name"], e_dy, rms)
-                assert float((gi * ga).min()) >= 0.0, o["name"]          # gi = gamma * invstd: the sign of gamma
-                if "res" in o:                                            # Bottleneck: the identity branch receives dz (pre-activation residual)
-                    add(o["res"], dz.reshape(B, o["oh"], o["ow"], C))
-                n_bn += 1
-            # weight gradient on the layer's own operands
+                if float(want_g.norm()) > 0:
+                    assert rel(got_g, want_g) < 2e-6 and rel(got_b, want_b) < 2e-6, (o["name"], rel(got_g, want_g), rel(got_b, want_b))
+                    core = dz - dz.mean(0) - xh * (dz * xh).mean(0)
+                    gi = (dy.reshape(-1, C) * core).sum(0) / (core * core).sum(0).clamp_min(1e-300)
+                    rms = float(dy.pow(2).mean().sqrt())
+                    e_dy = rel(dy.reshape(-1, C), core * gi)
+                    assert e_dy < 1e-3 + 6e-8 / max(rms, 1e-30), (o["name"], e_dy, rms)
+                    n_bn += 1
+                if "res" in o:                 # the residual branch receives dz (residual inside the activation) or the incoming gradient
+                    add(o["res"], (dz if pre_res else gout).reshape(B, o["oh"], o["ow"], C))
             xr = nchw(xin).requires_grad_(o.get("needs_dgrad", 1) == 1)
             wr = wq.clone().requires_grad_(True)
             y = F.conv2d(xr, wr, None, o["stride"], o["pad"], o["dil"])
@@ -1734,12 +1740,21 @@ def test_deeplab_per_layer_backward_on_the_engines_own_operands(dev, gold):
                 assert rel(got_w, want_w) < 5e-4, (o["name"], rel(got_w, want_w))
                 n_w += 1
             if xr.requires_grad:
-                add(o["in"], nhwc(xr.grad))
+                g_in = nhwc(xr.grad)
+                if g_in.shape[-1] < o["in"][2]:                  # (views padded beyond the stored input channels)
+                    g_in = F.pad(g_in, (0, o["in"][2] - g_in.shape[-1]))
+                add(o["in"], g_in)
             continue
         xin = nchw(act(o["in"])).requires_grad_(True)
         gout = nchw(act(o["out"], grad=True))
         if typ == L.OP_MAXPOOL3S2:
             y = F.max_pool2d(xin, 3, 2, 1)
+        elif typ == L.OP_MAXPOOL2:
+            y = F.max_pool2d(xin, 2, 2)
+        elif typ == L.OP_MAXPOOL5:
+            y = F.max_pool2d(xin, 5, 1, 2)
+        elif typ == L.OP_UPSAMPLE2:
+            y = F.interpolate(xin, scale_factor=2, mode="nearest")
         elif typ == L.OP_AVGPOOL:
             y = F.adaptive_avg_pool2d(xin, 1)
         elif typ == L.OP_RESIZE:
@@ -1752,24 +1767,43 @@ def test_deeplab_per_layer_backward_on_the_engines_own_operands(dev, gold):
             assert 0.08 < frac < 0.12, frac                                                  # p = 0.1 of the non-zero elements dropped
             assert rel(out, xin.detach() * keep / 0.9) < 1e-3                                # inverted scaling, one fp16 rounding
             y = xin * keep / 0.9
-            unknown[(o["in"][0], o["in"][1], o["in"][2])] = nhwc(~nz)                         # the mask is not observable where the input is 0
+            unknown[o["in"][0]] = (o["in"][1], o["in"][2], nhwc(~nz))                         # the mask is not observable where the input is 0
         else:
-            raise AssertionError(f"op type {typ} in the DeepLab graph")
+            raise AssertionError(f"op type {typ} without a backward check")
         y.backward(gout)
         add(o["in"], nhwc(xin.grad))
-    assert n_w >= 100 and n_bn >= 100, (n_w, n_bn)
+    assert n_w >= min_layers and n_bn >= min_layers, (n_w, n_bn)
     checked = 0
-    for (b, off, c), want in expect.items():
+    for b, want in expect.items():
         if b == gr.image_buf:
             continue
-        got = act((b, off, c), grad=True)
-        if (b, off, c) in unknown:
-            want = torch.where(unknown[(b, off, c)], got, want)
+        got = act((b, 0, gr.bufs[b][2]), grad=True)
+        if b in unknown:
+            off, c, mask = unknown[b]
+            want[..., off:off + c] = torch.where(mask, got[..., off:off + c], want[..., off:off + c])
+        got, want = got[..., covered[b]], want[..., covered[b]]
         rms = float(want.pow(2).mean().sqrt())
         e = rel(got, want)
-        assert e < 2e-3 + 6e-8 / max(rms, 1e-30), (b, off, c, e, rms)
+        assert e < 2e-3 + 6e-8 / max(rms, 1e-30), (b, e, rms)
         checked += 1
-    assert checked >= 100
+    assert checked >= min_buffers, checked
+    return n_w, n_bn, checked
+
+
+def test_deeplab_per_layer_backward_on_the_engines_own_operands(dev, gold):
+    """_check_backward_per_layer on one DeepLabv3+ training step with dropout active: all 113 convolutions incl. the 7x7 stem on the
+    NHWC image copy, the dilated 3x3 and the 1x1 stride-2 downsample; max pool / average pool / resize / dropout backward; the
+    Bottleneck identity branches taking dz.  Together with the unit tests this pins the backward pass op by op, which the
+    end-to-end comparison (ReLU mask flips) cannot."""
+    from computervision.pytorch_amd.deeplab import SegLoss
+    g = gold("deeplab_train_97x129.npz")
+    m = _deeplab_train_model(dev, g, dropout_p=0.1)
+    m.seed = 5
+    x, t = torch.from_numpy(g["x"]), torch.from_numpy(g["target"].astype(np.int64))
+    loss = SegLoss("focal")(m(x.to(dev)), t.to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+    _check_backward_per_layer(m, x.shape[0], m.last_dpred, 100, 100)
 
 
 def test_deeplab_step_with_gradient_exchange_and_loss_scaling(dev, gold):
@@ -1848,3 +1882,94 @@ def test_letterbox_kernel_is_bit_exact(dev, h, w, H, W):
     plain = torch.empty(3, H, W, device=dev)
     letterbox_u8(torch.from_numpy(img).to(dev), plain, letterbox=False)
     assert torch.equal(plain.cpu(), torch.from_numpy(LB.to_tensor(LB.resize_nearest(img, H, W))))
+
+
+
+# ---- YOLOv7-l network forward + backward in training mode --------------------------------------------------
+def _yolov7_train_step(dev, g):
+    from computervision.pytorch_amd.yolov7 import Yolo7L
+    from oracle import yolov7_ref as Y7
+    torch.manual_seed(0)
+    m = Yolo7L(20)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.to(dev).train()
+    x = torch.from_numpy(g["x"])
+    outs = m(x.to(dev))
+    weights = Y7.projection_weights([o.shape for o in outs], int(g["proj_seed"]))
+    loss = Y7.projection_loss(outs, [w.to(dev) for w in weights])
+    loss.backward()
+    torch.cuda.synchronize()
+    return m, sd0, x, outs, weights
+
+
+def test_yolov7_training_forward_backward_matches_the_reference_fixture(dev, gold):
+    """model.train(); outs = model(x); loss(outs).backward() on the engine against the REAL reference's autograd (make_golden.py section
+    11b: a fixed linear functional of the three outputs): train-mode outputs, running statistics, all 282 parameter gradients.  A
+    random-init YOLOv7 (N(0, 0.02) weights, 105 layers) amplifies fp16 rounding: the reference's own arithmetic with fp16-rounded
+    operands (the oracle's emulation, run here) is off by 3-8 % on the outputs and ~26 % on the deepest gradients at this size.  That
+    is the yardstick; the engine must stay within 1.25x of it overall and 1.6x per tensor.  The exactness of the backward pass
+    itself: test_yolov7_per_layer_backward_on_the_engines_own_operands."""
+    from oracle import yolov7_ref as Y7
+    g = gold("yolov7_train_160x224.npz")
+    m, sd0, x, outs, weights = _yolov7_train_step(dev, g)
+    _, ref_grads, ref_outs = Y7.loss_and_grads({k: v.clone() for k, v in sd0.items()}, x, weights)
+    Y7.FP16_STORAGE[0] = True
+    try:
+        _, emu_grads, emu_outs = Y7.loss_and_grads({k: v.clone() for k, v in sd0.items()}, x, weights)
+    finally:
+        Y7.FP16_STORAGE[0] = False
+    assert rel(torch.cat([o.flatten()[::7] for o in ref_outs]), torch.from_numpy(g["out_sub"])) < 1e-4
+    for o, r, e in zip(outs, ref_outs, emu_outs):
+        assert tuple(o.shape) == tuple(r.shape)
+        assert rel(o.detach().cpu(), r) < max(1.25 * rel(e, r), 1e-2), (rel(o.detach().cpu(), r), rel(e, r))
+    eg = {k: p.grad.cpu() for k, p in m.named_parameters()}
+    assert list(eg.keys()) == [str(k) for k in g["grad_keys"]]
+
+    def total(a, b):
+        return (sum(float((a[k].double() - b[k].double()).pow(2).sum()) for k in b) / sum(float(b[k].double().pow(2).sum()) for k in b)) ** 0.5
+
+    e_tot, y_tot = total(eg, ref_grads), total(emu_grads, ref_grads)
+    print(f"yolov7 train: gradients engine vs reference {e_tot:.3e}, yardstick {y_tot:.3e}")
+    assert e_tot < 1.25 * y_tot, (e_tot, y_tot)
+    for k in eg:
+        e, y = rel(eg[k], ref_grads[k]), rel(emu_grads[k], ref_grads[k])
+        assert e < max(1.6 * y, 2e-2), (k, e, y)
+    sdm = m.state_dict()
+    for k in [str(k) for k in g["stat_keys"]]:
+        assert rel(sdm[k].cpu(), torch.from_numpy(g["s:" + k])) < 5e-2, k
+    assert int(sdm["backbone.stem.0.bn.num_batches_tracked"]) == 1
+
+
+def test_yolov7_per_layer_backward_on_the_engines_own_operands(dev, gold):
+    """_check_backward_per_layer on the YOLOv7 step: all 95 convolutions (92 Conv + BN + SiLU blocks incl. the RepConv pair (3x3 + BN into a buffer, 1x1 + BN
+    with that buffer inside the SiLU: the residual branch takes dz), the three biased heads on their slices of the prediction rows,
+    2x2 and 5x5 max pools, nearest upsampling, the concat buffers' accumulated gradients."""
+    g = gold("yolov7_train_160x224.npz")
+    m, _, x, _, _ = _yolov7_train_step(dev, g)
+    n_w, n_bn, checked = _check_backward_per_layer(m, x.shape[0], m.last_dpred, 90, 50)
+    assert n_w >= 95 and n_bn >= 92
+
+
+def test_yolov7_training_through_the_plugin_api(dev):
+    """export_from_registry("yolo7") at 640 x 640, batch 4: three optimisation steps with a torch-side loss on the model's outputs and
+    torch.optim.Adam over the parameters (their .grad are views of the engine's gradient arena): finite, the loss falls."""
+    import builder
+    cfg, algo_cls, _ = builder.export_from_registry("yolo7")
+    cfg.train.pretrained = False
+    torch.manual_seed(0)
+    model, _ = algo_cls(cfg, dev).build_model()
+    model = model.to(dev).train()
+    x = synth.images(4, 640, 640, seed=2).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad(set_to_none=False)
+        outs = model(x)
+        assert [tuple(o.shape) for o in outs] == [(4, 75, 20, 20), (4, 75, 40, 40), (4, 75, 80, 80)]
+        loss = sum(o.pow(2).mean() for o in outs)
+        loss.backward()
+        for p in model.parameters():
+            p.grad.div_(model.loss_scale)                    # the arena holds loss_scale x gradient (GradScaler.unscale_)
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(v) for v in losses) and losses[-1] < losses[0], losses

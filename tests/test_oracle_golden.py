@@ -286,6 +286,31 @@ def test_deeplab_oracle_training_step(gold):
     assert abs(float(D.focal_loss(lg, tt)) - want) < 1e-7
 
 
+def test_yolov7_oracle_training_forward_backward(gold):
+    """oracle/yolov7_ref.loss_and_grads against the REAL reference model's train-mode forward + autograd (make_golden.py section 11b):
+    outputs, the projection loss, norm and sum of all 282 parameter gradients, nine gradient tensors in full, running statistics."""
+    from oracle import yolov7_ref as Y
+    g = gold("yolov7_train_160x224.npz")
+    sd = Y.init_state_dict(20, seed=0)
+    x = torch.from_numpy(g["x"])
+    loss, grads, outs = Y.loss_and_grads(sd, x, seed=int(g["proj_seed"]))
+    assert [tuple(o.shape) for o in outs] == [(2, 75, 5, 7), (2, 75, 10, 14), (2, 75, 20, 28)]
+    sub = torch.cat([o.flatten()[::7] for o in outs])
+    assert float((sub - torch.from_numpy(g["out_sub"])).norm() / sub.norm()) < 1e-4
+    assert abs(float(loss) - float(g["loss"])) < 1e-3 * abs(float(g["loss"])) + 1e-7
+    keys = [str(k) for k in g["grad_keys"]]
+    assert list(grads.keys()) == keys and len(keys) == 282
+    norms = np.array([float(grads[k].double().norm()) for k in keys])
+    np.testing.assert_allclose(norms, g["grad_norm"], rtol=5e-3)            # (fp32 convolutions on another CPU: other summation order)
+    for name in g.files:
+        if name.startswith("g:"):
+            ref = torch.from_numpy(g[name])
+            assert float((grads[name[2:]] - ref).norm() / ref.norm()) < 5e-3, name
+        if name.startswith("s:"):
+            ref = torch.from_numpy(g[name])
+            assert float((sd[name[2:]] - ref).norm() / ref.norm()) < 1e-4, name
+
+
 def _yolov7_fixture_state(g):
     from oracle import yolov7_ref as Y
     sd = Y.init_state_dict(20, seed=0)
