@@ -84,4 +84,5 @@ struct ColsumBlock {
 };
 int cvx_colsum_multi(const half_t* base, const ColsumDesc* descs, int ndesc, int max_c, const ColsumBlock* blocks, int nblocks, float inv_scale,
                      float* grads, hipStream_t st);
+int cvx_colsum_finalize(const long long* part, int C, float inv_scale, float* dbias, hipStream_t st);  // dbias += inv_scale * folded column sums
 int cvx_colsum(long long M, int C, int hw, const ViewDesc& g, long long* part, float inv_scale, float* dbias, hipStream_t st);

@@ -522,6 +522,12 @@ int cvx_colsum_multi(const half_t* base, const ColsumDesc* descs, int ndesc, int
   CVX_HIP(hipGetLastError());
   return 0;
 }
+int cvx_colsum_finalize(const long long* part, int C, float inv_scale, float* dbias, hipStream_t st) {
+  CVX_TRY(check_c(C));
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(1), dim3(256), fold_ws_bytes(C), st, part, C, inv_scale, dbias);
+  CVX_HIP(hipGetLastError());
+  return 0;
+}
 int cvx_colsum(long long M, int C, int hw, const ViewDesc& g, long long* part, float inv_scale, float* dbias, hipStream_t st) {
   CVX_TRY(check_c(C, M));
   int rows = cvx_stream_rows_per_block(M, C, 32);

@@ -136,6 +136,7 @@ struct cvx_engine {
   hipEvent_t ev_seg[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // segmented backward: (main, side) pairs
   int ev_seg_next = 0;
   unsigned long long seed = 0, train_pass = 0;  // dropout: cvx_engine_set_seed, training forwards so far
+  bool has_bias_act = false;  // a conv + bias (+ ReLU) epilogue without BatchNorm exists (its scale / shift table entry is needed in training too)
   bool fwd_train_done = false;
   bool bwd_slabs_clean = false;  // the backward statistic slabs were zeroed by the training forward and not used since
   int last_batch = 0;
@@ -243,16 +244,16 @@ int build_static(cvx_engine* e) {
     const cvx_op_desc& o = e->ops[i];
     CVX_CHECK(o.in.buf >= 0 && o.in.buf < (int)e->bufs.size() && o.out.buf >= 0 && o.out.buf < (int)e->bufs.size(), "op view buffer index");
     CVX_CHECK(o.type >= CVX_OP_CONV && o.type <= CVX_OP_DROPOUT, "unknown op type");
-    // ops / epilogues without a backward pass: the DLA ops, L2Normalize, the conv + bias (+ ReLU) blocks with an fp16 output
-    if (o.type == CVX_OP_DWCONVT || o.type == CVX_OP_COPY || o.type == CVX_OP_L2NORM ||
-        (o.type == CVX_OP_CONV && (o.act >= CVX_ACT_BIAS_RELU || (o.flags & CVX_OPF_CONV_BIAS))))
-      e->inference_only = true;
+    // ops / epilogues without a backward pass: L2Normalize, BatchNorm behind a biased convolution (VGG-BN)
+    if (o.type == CVX_OP_L2NORM || (o.type == CVX_OP_CONV && (o.flags & CVX_OPF_CONV_BIAS))) e->inference_only = true;
+    if (o.type == CVX_OP_CONV && (o.act == CVX_ACT_BIAS_RELU || o.act == CVX_ACT_BIAS_LINEAR) && o.res.buf >= 0) e->inference_only = true;
     if (o.type == CVX_OP_CONV && o.res.buf >= 0 && o.act != CVX_ACT_BIAS) {
       const bool pre = (o.flags & CVX_OPF_RES_PRE_ACT) != 0;
       // the training passes hold relu(z + res), silu(z + res) and silu(z) + res (bn_act.hip); relu(z) + res exists in the eval epilogue only
       if (o.act == CVX_ACT_BN_RELU && !pre) e->inference_only = true;
     }
     if (o.type == CVX_OP_DROPOUT) CVX_CHECK(o.k >= 0 && o.k < 65536, "dropout: k = drop probability in units of 2^-16");
+    if (o.type == CVX_OP_CONV && (o.act == CVX_ACT_BIAS_RELU || o.act == CVX_ACT_BIAS_LINEAR)) e->has_bias_act = true;
     if (o.type != CVX_OP_CONV) {
       CVX_CHECK(o.in.c % 8 == 0 && o.in.coff % 8 == 0 && o.out.coff % 8 == 0 && o.in.c == o.out.c, "pool / resample / copy views: equal, 8-aligned channel slices");
       continue;
@@ -446,6 +447,10 @@ int plan_batch(cvx_engine* e, int B, bool training) {
                                  (o.flags & CVX_OPF_CONV_BIAS) ? (long long)o.bias_off : -1LL});
     else if (o.act == CVX_ACT_BIAS_RELU || o.act == CVX_ACT_BIAS_LINEAR)
       folds.push_back(BnFoldDesc{0, o.bias_off, 0, 0, c.scale, c.shift, C, 1, -1LL});
+    if (training && (o.act == CVX_ACT_BIAS_RELU || o.act == CVX_ACT_BIAS_LINEAR)) {  // no BatchNorm: only the masked gradient is kept
+      CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, M * C * 2));
+      c.dybuf = (half_t*)p;
+    }
     if (training && (o.act == CVX_ACT_BN_SILU || o.act == CVX_ACT_BN_RELU || o.act == CVX_ACT_BN_LINEAR)) {
       CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, M * C * 2));
       c.ybuf = (half_t*)p;
@@ -829,7 +834,8 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
   if (e->image_nhwc) CVX_TRY(cvx_image_to_nhwc8(images, B, ib.d.h, ib.d.w, ib.act, st));
   const Buf& pb = e->bufs[e->pred_buf];
   const long long A = (long long)pb.d.h * pb.d.w;
-  if (!training) CVX_TRY(cvx_bn_fold_all(e->d_fold, e->n_fold, e->params, e->stats, e->bn_eps, st));  // eval: running stats -> scale/shift (the stem's too)
+  // eval: running stats -> scale/shift (the stem's too); training graphs with bias-only epilogues (conv + bias + ReLU) need their table as well
+  if (!training || e->has_bias_act) CVX_TRY(cvx_bn_fold_all(e->d_fold, e->n_fold, e->params, e->stats, e->bn_eps, st));
   bool prep_pending = prep_beside_stem;
   if (prep_beside_stem) CVX_HIP(hipEventRecord(e->ev_pack, e->lane));
 
@@ -951,7 +957,7 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
     }
     ViewDesc outv = make_view(e, o.out, false);
     ViewDesc resv = make_view(e, o.res, false);
-    if (training) {
+    if (training && o.act != CVX_ACT_BIAS_RELU && o.act != CVX_ACT_BIAS_LINEAR) {
       cp.epi = CVX_EPI_RAW_STATS;
       cp.out32 = ytmp;  // raw fp32 output: lives until the normalisation pass right below, then the next layer (of this stream) reuses it
       cp.out_ld = C;
@@ -1124,6 +1130,20 @@ int backward_op(cvx_engine* e, int i) {
       CVX_TRY(cvx_upsample2_bwd(make_view(e, o.out, true), make_view(e, o.in, true), B, o.ih, o.iw, o.in.c, e->pool[i].in_accum, st));
       return 0;
     }
+    if (o.type == CVX_OP_COPY) {
+      ProfScope ps(e, PROF_MISC, 0, (e->pool[i].in_accum ? 6.0 : 4.0) * B * o.ih * o.iw * o.in.c, st);
+      if (e->pool[i].in_accum)
+        CVX_TRY(cvx_add_slice(make_view(e, o.out, true), make_view(e, o.in, true), B, o.ih * o.iw, o.in.c, st));
+      else
+        CVX_TRY(cvx_copy_slice(make_view(e, o.out, true), make_view(e, o.in, true), B, o.ih * o.iw, o.in.c, st));
+      return 0;
+    }
+    if (o.type == CVX_OP_DWCONVT) {
+      ProfScope ps(e, PROF_MISC, 0, 4.0 * B * (o.ih * o.iw + o.oh * o.ow) * o.in.c, st);
+      CVX_TRY(cvx_dwconvt_bwd(make_view(e, o.in, false), make_view(e, o.out, true), make_view(e, o.in, true), e->params + o.w_off,
+                              e->grads + o.w_off, w.inv_scale, B, o.ih, o.iw, o.in.c, o.stride, e->pool[i].in_accum, st));
+      return 0;
+    }
     if (o.type == CVX_OP_MAXPOOL2) {
       ProfScope ps(e, PROF_MISC, 0, (4.0 * o.ih * o.iw + 2.0 * o.oh * o.ow) * B * o.in.c, st);
       CVX_TRY(cvx_maxpool2_bwd(make_view(e, o.in, false), make_view(e, o.out, true), make_view(e, o.in, true), B, o.ih, o.iw, o.oh, o.ow, o.in.c,
@@ -1164,6 +1184,13 @@ int backward_op(cvx_engine* e, int i) {
       dyv.ld = pb.d.c;
       dyv.bstride = A * pb.d.c;
       // (the bias gradient = column sums of dy went out with all the others in backward_begin: cvx_colsum_multi)
+    } else if (o.act == CVX_ACT_BIAS_RELU || o.act == CVX_ACT_BIAS_LINEAR) {
+      ProfScope ps(e, PROF_BN_BWD, 0, 6.0 * M * C, st);
+      CVX_TRY(cvx_bias_act_bwd(make_view(e, o.out, true), make_view(e, o.out, false), o.act == CVX_ACT_BIAS_RELU ? 1 : 0, M, C, hw, c.dybuf, c.stat_bwd,
+                               w.inv_scale, e->grads + o.bias_off, st));
+      dyv.p = c.dybuf;
+      dyv.ld = C;
+      dyv.bstride = (long long)hw * C;
     } else {
       ViewDesc gout = make_view(e, o.out, true);
       ViewDesc gres = make_view(e, o.res, true);

@@ -18,6 +18,13 @@ int cvx_maxpool3_bwd(const ViewDesc& gout, const ViewDesc& gin, int B, int IH, i
 // gradient of the 2x2 stride-2 max pool (floor or ceil mode); `in` = the forward input (the argmax is re-derived from it)
 int cvx_maxpool2_bwd(const ViewDesc& in, const ViewDesc& gout, const ViewDesc& gin, int B, int IH, int IW, int OH, int OW, int C, int accumulate,
                      hipStream_t st);
+int cvx_add_slice(const ViewDesc& in, const ViewDesc& out, int B, int HW, int C, hipStream_t st);  // out += in
+// depthwise transposed conv (kernel 2f, stride f, padding f/2): data gradient into gin, weight gradient ACCUMULATED (x inv_scale) into dw fp32 [C][2f][2f]
+int cvx_dwconvt_bwd(const ViewDesc& in, const ViewDesc& gout, const ViewDesc& gin, const float* w, float* dw, float inv_scale, int B, int IH, int IW,
+                    int C, int f, int accumulate, hipStream_t st);
+// conv + bias (+ ReLU) without BatchNorm: dy = gout (* [fout > 0]) dense fp16 [M][C]; dbias += inv_scale * column sums (part: zeroed replica slabs)
+int cvx_bias_act_bwd(const ViewDesc& gout, const ViewDesc& fout, int relu, long long M, int C, int hw, half_t* dy, long long* part, float inv_scale,
+                     float* dbias, hipStream_t st);
 int cvx_zero_slice(const ViewDesc& v, int B, int HW, int C, hipStream_t st);  // zero fill of a channel slice
 int cvx_avgpool_global_bwd(const ViewDesc& gout, const ViewDesc& gin, int B, int HW, int C, int accumulate, hipStream_t st);
 int cvx_resize_bilinear_bwd(const ViewDesc& gout, const ViewDesc& gin, int B, int IH, int IW, int OH, int OW, int C, int accumulate,

@@ -1,6 +1,7 @@
 // HBM-bound helper kernels (gfx950): layout change, SPPF max-pool, nearest upsample, weight shadow
 // packing, gradient-slab reduction, fused Adam.  16-byte accesses wherever the layout allows.
 #include "misc_ops.h"
+#include "bn_common.h"
 
 namespace {
 
@@ -511,6 +512,112 @@ __global__ void dwconvt_kernel(ViewDesc in, ViewDesc out, const float* w, int B,
 }
 
 // ---- channel-slice copy (a tensor that must also live in a second concat buffer) ----
+// gradients of the depthwise transposed convolution (IDAUp.up_i): out[oy][ox] takes in[iy][ix] * w[ky][kx] with oy = iy*f - P + ky.
+// Data gradient: a gather over the K x K taps of every input pixel.
+__global__ void dwconvt_dgrad_kernel(ViewDesc gout, ViewDesc gin, const float* w, int B, int IH, int IW, int CG, int f, int accumulate) {
+  const int OH = IH * f, OW = IW * f, K = 2 * f, P = f / 2;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long n = (long long)B * IH * IW * CG;
+  if (i >= n) return;
+  int cg = (int)(i % CG);
+  long long t = i / CG;
+  int ix = (int)(t % IW);
+  t /= IW;
+  int iy = (int)(t % IH);
+  int b = (int)(t / IH);
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  for (int ky = 0; ky < K; ++ky) {
+    const int oy = iy * f - P + ky;
+    if (oy < 0 || oy >= OH) continue;
+    for (int kx = 0; kx < K; ++kx) {
+      const int ox = ix * f - P + kx;
+      if (ox < 0 || ox >= OW) continue;
+      const h8 g = *reinterpret_cast<const h8*>(gout.p + voff(gout, b, (long long)oy * OW + ox) + cg * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] = fmaf((float)g[k], w[((long long)(cg * 8 + k) * K + ky) * K + kx], acc[k]);
+    }
+  }
+  half_t* q = gin.p + voff(gin, b, (long long)iy * IW + ix) + cg * 8;
+  if (accumulate) {
+    const h8 old = *reinterpret_cast<const h8*>(q);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += (float)old[k];
+  }
+  h8 o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = (half_t)acc[k];
+  *reinterpret_cast<h8*>(q) = o;
+}
+// Weight gradient: dw[c][ky][kx] += inv_scale * sum over (b, iy, ix) of in * gout at the tap's offset; one workgroup per (channel group,
+// tap), fixed-order tree over the pixels (deterministic), fp32 straight into the gradient arena (the master weights are fp32 [C][K][K]).
+__global__ __launch_bounds__(256) void dwconvt_wgrad_kernel(ViewDesc in, ViewDesc gout, float* dw, int B, int IH, int IW, int CG, int f,
+                                                            float inv_scale) {
+  __shared__ float red[256 * 8];
+  const int OH = IH * f, OW = IW * f, K = 2 * f, P = f / 2;
+  const int cg = blockIdx.x % CG, tap = blockIdx.x / CG;
+  const int ky = tap / K, kx = tap - ky * K;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  const long long npix = (long long)B * IH * IW;
+  for (long long p = threadIdx.x; p < npix; p += 256) {
+    const int ix = (int)(p % IW);
+    long long t = p / IW;
+    const int iy = (int)(t % IH);
+    const int b = (int)(t / IH);
+    const int oy = iy * f - P + ky, ox = ix * f - P + kx;
+    if (oy < 0 || oy >= OH || ox < 0 || ox >= OW) continue;
+    const h8 v = *reinterpret_cast<const h8*>(in.p + voff(in, b, (long long)iy * IW + ix) + cg * 8);
+    const h8 g = *reinterpret_cast<const h8*>(gout.p + voff(gout, b, (long long)oy * OW + ox) + cg * 8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = fmaf((float)v[k], (float)g[k], acc[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = acc[k];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] += red[(threadIdx.x + s) * 8 + k];
+    __syncthreads();
+  }
+  if (threadIdx.x < 8) dw[((long long)(cg * 8 + threadIdx.x) * K + ky) * K + kx] += red[threadIdx.x] * inv_scale;
+}
+
+// gradient of conv + bias (+ ReLU) blocks without BatchNorm (CenterNet heads, SSD extras): dy = g * [out > 0] (relu) or g, dense fp16,
+// and the bias gradient's column sums into the replica slabs (finalised by colsum_finalize)
+__global__ __launch_bounds__(256) void bias_act_bwd_kernel(ViewDesc gout, ViewDesc fout, int relu, long long M, int C, int hw, half_t* dy,
+                                                           long long* part, int rows_per_block) {
+  __shared__ float sacc[256 * 8];
+  const int CG = C >> 3;
+  const int RP = 256 / CG;
+  const int cg = threadIdx.x % CG, r = threadIdx.x / CG;
+  const bool active = r < RP;
+  float acc[1][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[0][i] = 0.f;
+  if (active) {
+    const long long m0 = (long long)blockIdx.x * rows_per_block;
+    const long long m1 = min(M, m0 + rows_per_block);
+    for (long long m = m0 + r; m < m1; m += RP) {
+      const unsigned mu = (unsigned)m, b = mu / (unsigned)hw, pix = mu - b * (unsigned)hw;
+      h8 g = *reinterpret_cast<const h8*>(gout.p + voff(gout, (int)b, pix) + cg * 8);
+      if (relu) {
+        const h8 fo = *reinterpret_cast<const h8*>(fout.p + voff(fout, (int)b, pix) + cg * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (!((float)fo[i] > 0.f)) g[i] = (half_t)0.f;
+      }
+      *reinterpret_cast<h8*>(dy + m * C + cg * 8) = g;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[0][i] += (float)g[i];
+    }
+  }
+  cvx_bn::block_channel_sums<1>(acc, C, CG, cg, active, sacc, part, blockIdx.x);
+}
+
 __global__ void copy_slice_kernel(ViewDesc in, ViewDesc out, int B, int HW, int CG) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long n = (long long)B * HW * CG;
@@ -520,6 +627,21 @@ __global__ void copy_slice_kernel(ViewDesc in, ViewDesc out, int B, int HW, int 
   int pix = (int)(t % HW);
   int b = (int)(t / HW);
   *reinterpret_cast<h8*>(out.p + voff(out, b, pix) + cg * 8) = *reinterpret_cast<const h8*>(in.p + voff(in, b, pix) + cg * 8);
+}
+__global__ void add_slice_kernel(ViewDesc in, ViewDesc out, int B, int HW, int CG) {  // out += in (gradient of a slice copy onto a written slice)
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long n = (long long)B * HW * CG;
+  if (i >= n) return;
+  int cg = (int)(i % CG);
+  long long t = i / CG;
+  int pix = (int)(t % HW);
+  int b = (int)(t / HW);
+  half_t* q = out.p + voff(out, b, pix) + cg * 8;
+  const h8 a = *reinterpret_cast<const h8*>(in.p + voff(in, b, pix) + cg * 8), o = *reinterpret_cast<const h8*>(q);
+  h8 r;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r[k] = (half_t)((float)a[k] + (float)o[k]);
+  *reinterpret_cast<h8*>(q) = r;
 }
 
 // ---- max pool 5x5 s1 p2 ------------------------------------------------------------------------
@@ -924,6 +1046,25 @@ int cvx_dwconvt(const ViewDesc& in, const ViewDesc& out, const float* w, int B, 
 }
 int cvx_copy_slice(const ViewDesc& in, const ViewDesc& out, int B, int HW, int C, hipStream_t st) {
   return launch1d(copy_slice_kernel, (long long)B * HW * (C / 8), st, in, out, B, HW, C / 8);
+}
+int cvx_add_slice(const ViewDesc& in, const ViewDesc& out, int B, int HW, int C, hipStream_t st) {
+  return launch1d(add_slice_kernel, (long long)B * HW * (C / 8), st, in, out, B, HW, C / 8);
+}
+int cvx_dwconvt_bwd(const ViewDesc& in, const ViewDesc& gout, const ViewDesc& gin, const float* w, float* dw, float inv_scale, int B, int IH, int IW,
+                    int C, int f, int accumulate, hipStream_t st) {
+  CVX_CHECK(f >= 2 && f % 2 == 0 && C % 8 == 0, "dwconvt_bwd: even stride, C % 8");
+  CVX_TRY(launch1d(dwconvt_dgrad_kernel, (long long)B * IH * IW * (C / 8), st, gout, gin, w, B, IH, IW, C / 8, f, accumulate));
+  hipLaunchKernelGGL(dwconvt_wgrad_kernel, dim3((C / 8) * 4 * f * f), dim3(256), 0, st, in, gout, dw, B, IH, IW, C / 8, f, inv_scale);
+  CVX_HIP(hipGetLastError());
+  return 0;
+}
+int cvx_bias_act_bwd(const ViewDesc& gout, const ViewDesc& fout, int relu, long long M, int C, int hw, half_t* dy, long long* part, float inv_scale,
+                     float* dbias, hipStream_t st) {
+  CVX_CHECK(C % 8 == 0 && C >= 8 && C <= CVX_BN_MAX_C && M < (1LL << 32) && (!relu || fout.p), "bias_act_bwd: C % 8, C <= 2048; ReLU needs the output");
+  const int rows = cvx_stream_rows_per_block(M, C, 32);
+  hipLaunchKernelGGL(bias_act_bwd_kernel, dim3((unsigned)((M + rows - 1) / rows)), dim3(256), 0, st, gout, fout, relu, M, C, hw, dy, part, rows);
+  CVX_HIP(hipGetLastError());
+  return cvx_colsum_finalize(part, C, inv_scale, dbias, st);
 }
 int cvx_maxpool5_fwd(const ViewDesc& in, const ViewDesc& out, int B, int H, int W, int C, uint8_t* idx, hipStream_t st) {
   CVX_CHECK(C % 8 == 0, "maxpool5: C % 8");

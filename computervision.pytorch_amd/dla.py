@@ -187,7 +187,7 @@ def build_dla_graph(lay: DlaLayout, H: int, W: int) -> Graph:
         k = s["k"]
         ho, wo = (hin + 2 * (k // 2) - k) // stride + 1, (win + 2 * (k // 2) - k) // stride + 1
         op = dict(type=L.OP_CONV, name=name or ckey, out=vout, ih=hin, iw=win, oh=ho, ow=wo, k=k, stride=stride, pad=k // 2, dil=1, act=act,
-                  needs_dgrad=0, w_cin=s["cin"], w_off=s["w_off"], gamma_off=s.get("gamma_off", 0), beta_off=s.get("beta_off", 0),
+                  needs_dgrad=0 if vin[0] == img else 1, w_cin=s["cin"], w_off=s["w_off"], gamma_off=s.get("gamma_off", 0), beta_off=s.get("beta_off", 0),
                   bias_off=s.get("bias_off", 0), rmean_off=s.get("rmean_off", 0), rvar_off=s.get("rvar_off", 0),
                   flags=L.OPF_RES_PRE_ACT if res_pre else 0)
         op["in"] = vin
@@ -309,14 +309,21 @@ class _Holder(nn.Module):
 
 
 class CenterNetDLA34(nn.Module):
-    """``CenterNet(cfg)`` of the reference (centernet_model.py:365-379) on the engine: ``model.eval(); model(x)`` returns the
-    (B, H/4, W/4, nc + 4) NHWC tensor [heatmap | wh | reg]."""
+    """``CenterNet(cfg)`` of the reference (centernet_model.py:365-379) on the engine: ``model(x)`` returns the (B, H/4, W/4, nc + 4)
+    NHWC tensor [heatmap | wh | reg].  In training mode (grad enabled) the tensor is connected to the engine's backward pass
+    (batch-statistics BatchNorm + ReLU, the BasicBlock residual inside the ReLU, 2x2 max pools, the depthwise transposed
+    convolutions' data and weight gradients, the concat copies, the biased head convolutions): any torch loss on it -- the
+    reference's CombinedLoss is torch code on exactly this tensor -- trains the network."""
 
-    def __init__(self, num_classes: int = 80):
+    def __init__(self, num_classes: int = 80, loss_scale: float = 1024.0):
         super().__init__()
         self.layout = lay = DlaLayout(num_classes)
         self.num_classes = num_classes
-        self._flat = {"param": torch.zeros(lay.n_params), "stat": torch.zeros(lay.n_stats), "nbt": torch.zeros(len(lay.nbt_keys), dtype=torch.long)}
+        self.loss_scale = float(loss_scale)
+        self._flat = {"param": torch.zeros(lay.n_params), "stat": torch.zeros(lay.n_stats), "nbt": torch.zeros(len(lay.nbt_keys), dtype=torch.long),
+                      "grad": None}
+        self._anchor = torch.zeros(1, requires_grad=True)
+        self._grads_attached = False
         self._engines: Dict = {}
         self._build_tree()
         self._attach_views()
@@ -344,11 +351,15 @@ class CenterNetDLA34(nn.Module):
                 continue
             view = torch.as_strided(self._flat[sl.arena], sl.shape, sl.strides, sl.offset)
             if sl.trainable:
-                mod._parameters[parts[-1]] = nn.Parameter(view, requires_grad=False)
+                old = mod._parameters.get(parts[-1])
+                mod._parameters[parts[-1]] = nn.Parameter(view, requires_grad=True if old is None else old.requires_grad)
             else:
                 mod._buffers[parts[-1]] = view
 
     def _apply(self, fn, recurse=True):
+        self._flat["grad"] = None
+        self._grads_attached = False
+        self._anchor = fn(self._anchor.detach()).requires_grad_(True)
         for k in ("param", "stat", "nbt"):
             t = fn(self._flat[k])
             if k != "nbt" and t.dtype != torch.float32:
@@ -394,23 +405,78 @@ class CenterNetDLA34(nn.Module):
             eng = Engine(build_dla_graph(self.layout, h, w), dev)
             eng.set_bn(BN_EPS, BN_MOMENTUM)
             self._engines[key] = eng
-        eng.bind(self._flat["param"], None, self._flat["stat"])
+        eng.bind(self._flat["param"], self.flat_grads if self.training else self._flat["grad"], self._flat["stat"])
         return eng
 
-    def forward_raw(self, x: torch.Tensor) -> torch.Tensor:
-        """(B,3,H,W) -> the engine's fp32 head tensor (B, H/4 * W/4, nc_pad + 16): what ``centernet_decode`` reads."""
-        if self.training:
-            raise L.CvxError("CenterNet on the MI355X engine is inference-only this round: call model.eval() first")
+    @property
+    def flat_params(self) -> torch.Tensor:
+        return self._flat["param"]
+
+    @property
+    def flat_stats(self) -> torch.Tensor:
+        return self._flat["stat"]
+
+    @property
+    def flat_grads(self) -> torch.Tensor:
+        if self._flat["grad"] is None or self._flat["grad"].device != self._flat["param"].device:
+            self._flat["grad"] = torch.zeros_like(self._flat["param"])
+            self._grads_attached = False
+        return self._flat["grad"]
+
+    def attach_grads(self):
+        """Make ``p.grad`` of every parameter a view of the flat gradient arena (torch optimisers / GradScaler)."""
+        g = self.flat_grads
+        modules = dict(self.named_modules())
+        for key, slot in self.layout.slots.items():
+            if not slot.trainable:
+                continue
+            mod_name, attr = key.rsplit(".", 1)
+            modules[mod_name]._parameters[attr].grad = torch.as_strided(g, slot.shape, slot.strides, slot.offset)
+        self._grads_attached = True
+
+    def _run_forward(self, x: torch.Tensor, training: bool) -> torch.Tensor:
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError("expected images of shape (B, 3, H, W)")
         eng = self.engine_for(int(x.shape[2]), int(x.shape[3]))
         self._last_engine = eng
-        return eng.forward(x, False)
+        raw = eng.forward(x, training)
+        if training:
+            self._flat["nbt"] += 1
+        return raw
+
+    def forward_raw(self, x: torch.Tensor) -> torch.Tensor:
+        """(B,3,H,W) -> the engine's fp32 head tensor (B, H/4 * W/4, nc_pad + 16): what ``centernet_decode`` reads."""
+        return self._run_forward(x, self.training)
+
+    def _backward_rows(self, g: torch.Tensor):
+        """Gradient w.r.t. the fp32 head rows -> loss_scale * g in fp16 -> engine backward (parameter gradients accumulate)."""
+        first = next(p for p in self.parameters() if p.requires_grad)
+        if first.grad is None:               # optimizer.zero_grad(set_to_none=True) happened (or first step)
+            self.flat_grads.zero_()
+            self._grads_attached = False
+        self.last_dpred = (g * self.loss_scale).to(torch.float16).contiguous()
+        self._last_engine.backward(self.last_dpred, self.loss_scale)
+        if not self._grads_attached or first.grad is None:
+            self.attach_grads()
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        raw = self.forward_raw(x)
+        raw = _RowsFn.apply(x, self._anchor, self) if (self.training and torch.is_grad_enabled()) else self.forward_raw(x)
         self.last_raw = raw
         B, _, H, W = x.shape
         lay = self.layout
         out = torch.cat((raw[..., :lay.nc], raw[..., lay.nc_pad:lay.nc_pad + 2], raw[..., lay.nc_pad + 8:lay.nc_pad + 10]), -1)
         return out.reshape(B, H // 4, W // 4, lay.nc + 4)
+
+
+class _RowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, images, anchor, model):
+        ctx.model = model
+        ctx.set_materialize_grads(False)
+        return model._run_forward(images, training=True)
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is not None:
+            ctx.model._backward_rows(g)
+        return None, None, None

@@ -32,7 +32,9 @@ class CenterNetA:
         return CenterNetDLA34(self.num_classes), "CenterNet"
 
     def build_loss(self):
-        raise L.CvxError("CenterNet training (CombinedLoss, core/loss/centernet_loss.py) is not built on the MI355X engine yet: inference only")
+        raise L.CvxError("CombinedLoss (core/loss/centernet_loss.py) and the heat-map target drawing have no HIP kernels yet.  The network itself trains "
+                         "on the engine: model.train(); out = model(x) is an ordinary tensor connected to the engine's backward pass, so the "
+                         "reference's own CombinedLoss module (plain torch code on this output) can be applied to it unchanged")
 
     # ---- decode ---------------------------------------------------------------------------------------
     def decode_raw(self, raw: torch.Tensor, fh: int, fw: int, conf_threshold=None):

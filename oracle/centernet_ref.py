@@ -1,4 +1,5 @@
-"""CPU oracle for CenterNet (DLA-34) inference + heat-map decode -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+"""CPU oracle for CenterNet (DLA-34): network forward (eval / train mode) and backward, heat-map decode -- TEST INFRASTRUCTURE,
+NOT PRODUCT CODE.
 
 SURVEY.md section 8 row a18 / (f)1, BASELINE.json configs[3].  A torch-CPU fp32 restatement, functional over a flat
 ``state_dict`` with the reference's keys (``backbone.base...``, ``backbone.dla_up...``, ``backbone.<head>...``), of
@@ -9,6 +10,11 @@ SURVEY.md section 8 row a18 / (f)1, BASELINE.json configs[3].  A torch-CPU fp32 
   NHWC tensor as if it were NCHW -- the window spans (x, class) for a fixed row y, reproduced as is --, global top-K,
   gather, clamp, score mask, class-agnostic DIoU-NMS (core/utils/nms.py:9-31, core/utils/iou.py:8-64), letterbox
   inverse (core/utils/image_process.py:100-129).
+
+Training (``forward(training=True)``, ``projection_loss``, ``loss_and_grads``): batch-statistics BatchNorm (running statistics
+updated in place); the backward pass is torch autograd over this restatement, driven by a fixed linear functional of the output
+tensor (the reference's CombinedLoss, core/loss/centernet_loss.py, is torch code on that tensor and is not restated); pinned
+against the real model's autograd in ``make_golden.py`` (section 9b).
 
 Parity pin: ``oracle/make_golden.py`` imports the real reference in the build container and asserts that this file
 reproduces its seed-0 initialisation bit for bit, its forward to fp32 round-off and its decode exactly, then writes
@@ -152,7 +158,11 @@ FP16_STORAGE = [False]
 
 
 def _q(t):
-    return t.half().float() if FP16_STORAGE[0] else t
+    if not FP16_STORAGE[0]:
+        return t
+    if t.requires_grad:                       # straight-through: the value is rounded, the gradient passes unrounded
+        return t + (t.detach().half().float() - t.detach())
+    return t.half().float()
 
 
 def _conv(x, w, b=None, stride=1, pad=0):
@@ -324,3 +334,26 @@ def decode(pred: torch.Tensor, nc: int, input_hw, image_hw, k: int = 100, conf: 
     out[..., 3] -= top
     out *= scale
     return out, sc, cl, pos
+
+
+def projection_weights(shape, seed: int = 9):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def projection_loss(out, weights):
+    """mean(out * w): a fixed linear functional of the (B, H/4, W/4, nc + 4) output the backward parity runs on."""
+    return (out * weights).mean()
+
+
+def loss_and_grads(sd, x, nc: int = 80, weights=None, seed: int = 9):
+    """Train-mode forward + backward of ``projection_loss``: (loss, {key: grad}, out); running statistics in ``sd`` are updated."""
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()
+              if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var"))}
+    work = dict(sd)
+    work.update(params)
+    out = forward(work, x, nc, training=True)
+    if weights is None:
+        weights = projection_weights(out.shape, seed)
+    loss = projection_loss(out, weights)
+    loss.backward()
+    return loss.detach(), {k: p.grad for k, p in params.items() if p.grad is not None}, out.detach()

@@ -204,4 +204,4 @@ def loss_and_grads(sd, x, target, nc: int = 21, loss_type: str = "focal", keep_m
     out, rows = forward(work, x, nc, return_rows=True, train=True, keep_mask=keep_mask, dropout_p=dropout_p)
     loss = focal_loss(out, target) if loss_type == "focal" else F.cross_entropy(out, target, reduction="mean")
     loss.backward()
-    return loss.detach(), {k: p.grad for k, p in params.items()}, rows.detach()
+    return loss.detach(), {k: p.grad for k, p in params.items() if p.grad is not None}, rows.detach()

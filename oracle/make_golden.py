@@ -198,6 +198,51 @@ def yolov7_train_section(builder, report):
     report["yolov7_train"] = dict(loss=float(loss), worst_grad_rel_oracle_vs_reference=worst, tensors=len(keys), full=full, stats=stat_keys)
 
 
+def centernet_train_section(builder, report):
+    """9b. CenterNet DLA-34 network forward + backward in training mode: the REAL reference model (model.train()), a fixed linear
+    functional of its output tensor (centernet_ref.projection_loss), loss.backward() -> every parameter gradient (incl. the depthwise
+    transposed convolutions' weights) and the updated running statistics.  Pins the oracle's train-mode restatement."""
+    from oracle import centernet_ref as C
+    ccfg, calgo_cls, _ = builder.export_from_registry("centernet")
+    torch.manual_seed(0)
+    cmodel, _ = calgo_cls(ccfg, torch.device("cpu")).build_model()
+    nc = ccfg.dataset.num_classes
+    sd0 = {k: v.clone() for k, v in cmodel.state_dict().items()}
+    B, H, W = 2, 128, 160
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(41))
+    cmodel.train()
+    out = cmodel(x.clone())
+    weights = C.projection_weights(out.shape, seed=9)
+    loss = C.projection_loss(out, weights)
+    loss.backward()
+    ref_grads = {k: p.grad.clone() for k, p in cmodel.named_parameters() if p.grad is not None}
+    ref_sd = {k: v.clone() for k, v in cmodel.state_dict().items()}
+    work = {k: v.clone() for k, v in sd0.items()}
+    my_loss, my_grads, my_out = C.loss_and_grads(work, x.clone(), nc, weights)
+    assert abs(float(my_loss) - float(loss)) <= 1e-5 * max(abs(float(loss)), 1e-3), (float(my_loss), float(loss))
+    assert torch.allclose(my_out, out.detach(), rtol=1e-4, atol=1e-5)
+    worst = 0.0
+    for k, gr in ref_grads.items():
+        e = float((my_grads[k] - gr).norm() / gr.norm().clamp_min(1e-30))
+        worst = max(worst, e)
+        assert e < 1e-4, (k, e)
+    for k in ref_sd:
+        if k.endswith(("running_mean", "running_var")):
+            assert torch.allclose(work[k], ref_sd[k], rtol=1e-5, atol=1e-6), k
+    keys = list(ref_grads.keys())
+    full = [k for k in keys if (".up_" in k and k.endswith("weight"))][:3] + [k for k in ("backbone.heatmap_head.2.weight", "backbone.wh_head.0.bias",
+            "backbone.reg_head.2.bias", "backbone.base.base_layer.0.weight", "backbone.base.base_layer.1.bias", "backbone.base.level_2.tree1.bn2.weight",
+            "backbone.base.level_5.root.conv.weight") if k in ref_grads and ref_grads[k].numel() < 300000]
+    stat_keys = [k for k in ("backbone.base.base_layer.1.running_mean", "backbone.base.base_layer.1.running_var", "backbone.base.level_5.root.bn.running_var")
+                 if k in ref_sd]
+    np.savez_compressed(os.path.join(GOLD, "centernet_train_128x160.npz"), x=x.numpy(), proj_seed=np.array(9), loss=np.array(float(loss)), nc=np.array(nc),
+                        out_sub=out.detach().flatten()[::7].numpy().copy(), grad_keys=np.array(keys),
+                        grad_norm=np.array([float(ref_grads[k].double().norm()) for k in keys]),
+                        grad_sum=np.array([float(ref_grads[k].double().sum()) for k in keys]), stat_keys=np.array(stat_keys),
+                        **{"g:" + k: ref_grads[k].numpy() for k in full}, **{"s:" + k: ref_sd[k].numpy().copy() for k in stat_keys})
+    report["centernet_train"] = dict(loss=float(loss), worst_grad_rel_oracle_vs_reference=worst, tensors=len(keys), full=full, stats=stat_keys)
+
+
 def main():
     sys.path.insert(0, ROOT)
     from oracle import yolov8_ref as O
@@ -479,6 +524,8 @@ def main():
     report["centernet"] = dict(init="bit-exact, %d tensors" % len(ref_sd), params=int(sum(p_.numel() for p_ in cmodel.parameters())),
                                decode={t: int(dec[t + "_boxes"].shape[0]) for t in ("net", "synth")})
 
+    centernet_train_section(builder, report)
+
     # ---- 10. DeepLabv3+ ResNet-101: init, eval forward on a calibrated network ---------------------------------
     from oracle import deeplab_ref as D
     dcfg, dalgo_cls, _ = builder.export_from_registry("deeplabv3plus")
@@ -695,7 +742,7 @@ def only(section):
     builder = _import_reference()
     torch.set_num_threads(8)
     report = {}
-    {"deeplab_train": deeplab_train_section, "yolov7_train": yolov7_train_section}[section](builder, report)
+    {"deeplab_train": deeplab_train_section, "yolov7_train": yolov7_train_section, "centernet_train": centernet_train_section}[section](builder, report)
     path = os.path.join(GOLD, "PIN_REPORT.json")
     full = json.load(open(path)) if os.path.exists(path) else {}
     full.update(report)

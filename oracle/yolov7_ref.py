@@ -270,4 +270,4 @@ def loss_and_grads(sd, x, weights=None, seed: int = 9):
         weights = projection_weights([o.shape for o in outs], seed)
     loss = projection_loss(outs, weights)
     loss.backward()
-    return loss.detach(), {k: p.grad for k, p in params.items()}, [o.detach() for o in outs]
+    return loss.detach(), {k: p.grad for k, p in params.items() if p.grad is not None}, [o.detach() for o in outs]

@@ -311,6 +311,31 @@ def test_yolov7_oracle_training_forward_backward(gold):
             assert float((sd[name[2:]] - ref).norm() / ref.norm()) < 1e-4, name
 
 
+def test_centernet_oracle_training_forward_backward(gold):
+    """oracle/centernet_ref.loss_and_grads against the REAL reference model's train-mode forward + autograd (make_golden.py section 9b):
+    the output tensor, norm of all 165 parameter gradients (parameters the forward never uses have none), six gradient tensors in full
+    incl. depthwise transposed-convolution weights, running statistics."""
+    from oracle import centernet_ref as C
+    g = gold("centernet_train_128x160.npz")
+    nc = int(g["nc"])
+    sd = C.init_state_dict(nc, seed=0)
+    x = torch.from_numpy(g["x"])
+    loss, grads, out = C.loss_and_grads(sd, x, nc, seed=int(g["proj_seed"]))
+    assert tuple(out.shape) == (2, 32, 40, nc + 4)
+    assert float((out.flatten()[::7] - torch.from_numpy(g["out_sub"])).norm() / out.flatten()[::7].norm()) < 1e-4
+    keys = [str(k) for k in g["grad_keys"]]
+    assert list(grads.keys()) == keys and len(keys) == 165
+    norms = np.array([float(grads[k].double().norm()) for k in keys])
+    np.testing.assert_allclose(norms, g["grad_norm"], rtol=5e-3, atol=1e-9)
+    for name in g.files:
+        if name.startswith("g:"):
+            ref = torch.from_numpy(g[name])
+            assert float((grads[name[2:]] - ref).norm() / ref.norm()) < 5e-3, name
+        if name.startswith("s:"):
+            ref = torch.from_numpy(g[name])
+            assert float((sd[name[2:]] - ref).norm() / ref.norm()) < 1e-4, name
+
+
 def _yolov7_fixture_state(g):
     from oracle import yolov7_ref as Y
     sd = Y.init_state_dict(20, seed=0)
