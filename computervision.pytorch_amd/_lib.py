@@ -105,6 +105,8 @@ PROTOTYPES = {
     "cvx_resize_bilinear_nchw_grad_to_rows": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _P, _I32, _P]),
     "cvx_maxpool3_train_nhwc": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
     "cvx_maxpool3_bwd_nhwc": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P]),
+    "cvx_l2norm_bwd_nhwc": (_I32, [_P, _P, _P, _I32, _I32, _I32, _F, _P, _P, _I32, _P]),
+    "cvx_nchw_cols_grad_to_pred": (_I32, [_P, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _F, _P, _I32, _I32, _P]),
     "cvx_maxpool2_bwd_nhwc": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P]),
     "cvx_avgpool_global_bwd_nhwc": (_I32, [_P, _I32, _I32, _I32, _P, _I32, _P]),
     "cvx_resize_bilinear_bwd_nhwc": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P]),

@@ -32,6 +32,8 @@ struct BnTrainArgs {
   float* rmean;   // running statistics, updated with `momentum` (unbiased variance)
   float* rvar;
   float eps, momentum;
+  const float* cbias = nullptr;  // the convolution's own bias in front of the BatchNorm (VGG-BN, CVX_OPF_CONV_BIAS): the statistics are
+                                 // taken on the bias-free output (the normalised value is the same); only the running mean needs it
 };
 
 int cvx_stream_rows_per_block(long long M, int C, int kb_per_block);

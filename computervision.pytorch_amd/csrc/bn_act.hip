@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(const float* y, long 
       a.mean[c] = mo.mean;
       a.invstd[c] = mo.invstd;
       const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
-      a.rmean[c] = (float)((1.0 - a.momentum) * (double)a.rmean[c] + a.momentum * mu);
+      a.rmean[c] = (float)((1.0 - a.momentum) * (double)a.rmean[c] + a.momentum * (mu + (a.cbias ? (double)a.cbias[c] : 0.0)));
       a.rvar[c] = (float)((1.0 - a.momentum) * (double)a.rvar[c] + a.momentum * unbiased);
     }
   }

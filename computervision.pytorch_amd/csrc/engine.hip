@@ -244,8 +244,6 @@ int build_static(cvx_engine* e) {
     const cvx_op_desc& o = e->ops[i];
     CVX_CHECK(o.in.buf >= 0 && o.in.buf < (int)e->bufs.size() && o.out.buf >= 0 && o.out.buf < (int)e->bufs.size(), "op view buffer index");
     CVX_CHECK(o.type >= CVX_OP_CONV && o.type <= CVX_OP_DROPOUT, "unknown op type");
-    // ops / epilogues without a backward pass: L2Normalize, BatchNorm behind a biased convolution (VGG-BN)
-    if (o.type == CVX_OP_L2NORM || (o.type == CVX_OP_CONV && (o.flags & CVX_OPF_CONV_BIAS))) e->inference_only = true;
     if (o.type == CVX_OP_CONV && (o.act == CVX_ACT_BIAS_RELU || o.act == CVX_ACT_BIAS_LINEAR) && o.res.buf >= 0) e->inference_only = true;
     if (o.type == CVX_OP_CONV && o.res.buf >= 0 && o.act != CVX_ACT_BIAS) {
       const bool pre = (o.flags & CVX_OPF_RES_PRE_ACT) != 0;
@@ -426,6 +424,13 @@ int plan_batch(cvx_engine* e, int B, bool training) {
   e->slab_tail_op = -1;
   for (size_t i = 0; i < e->ops.size(); ++i) {
     const cvx_op_desc& o = e->ops[i];
+    if (o.type == CVX_OP_L2NORM) {
+      if (training) {  // per-workgroup partial sums of the weight gradient
+        CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, (long long)cvx_l2norm_bwd_blocks((long long)B * o.ih * o.iw) * o.in.c * 4));
+        e->pool[i].idx = (uint8_t*)p;
+      }
+      continue;
+    }
     if (o.type == CVX_OP_MAXPOOL5 || o.type == CVX_OP_MAXPOOL3S2 || o.type == CVX_OP_MAXPOOL3S1) {
       if (training) {  // argmax byte per output element: the operand of the backward gather
         CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, (long long)B * o.oh * o.ow * o.out.c));
@@ -972,6 +977,7 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
       ProfScope ps(e, PROF_BN_FWD, 0, (resv.p ? 10.0 : 8.0) * M * C, st);
       BnTrainArgs ta{c.stat_fwd,           e->params + o.gamma_off, e->params + o.beta_off, c.mean, c.invstd, e->stats + o.rmean_off,
                      e->stats + o.rvar_off, e->bn_eps,       e->bn_momentum};
+      if (o.flags & CVX_OPF_CONV_BIAS) ta.cbias = e->params + o.bias_off;  // (its gradient is exactly zero: BatchNorm removes the mean)
       CVX_TRY(cvx_bn_act_apply(ytmp, M, C, o.oh * o.ow, ta, outv, resv, act_kind(o), (o.flags & CVX_OPF_RES_PRE_ACT) ? 1 : 0, c.ybuf, st));
     } else {
       // scale / shift were folded for every layer at once before the op loop (cvx_bn_fold_all)
@@ -1128,6 +1134,12 @@ int backward_op(cvx_engine* e, int i) {
     if (o.type == CVX_OP_UPSAMPLE2) {
       ProfScope ps(e, PROF_MISC, 0, 12.0 * B * o.ih * o.iw * o.in.c, st);
       CVX_TRY(cvx_upsample2_bwd(make_view(e, o.out, true), make_view(e, o.in, true), B, o.ih, o.iw, o.in.c, e->pool[i].in_accum, st));
+      return 0;
+    }
+    if (o.type == CVX_OP_L2NORM) {
+      ProfScope ps(e, PROF_MISC, 0, 6.0 * B * o.ih * o.iw * o.in.c, st);
+      CVX_TRY(cvx_l2norm_bwd(make_view(e, o.in, false), make_view(e, o.out, true), make_view(e, o.in, true), e->params + o.gamma_off,
+                             e->grads + o.gamma_off, w.inv_scale, B, o.ih * o.iw, o.in.c, e->pool[i].in_accum, (float*)e->pool[i].idx, st));
       return 0;
     }
     if (o.type == CVX_OP_COPY) {

@@ -18,6 +18,12 @@ int cvx_maxpool3_bwd(const ViewDesc& gout, const ViewDesc& gin, int B, int IH, i
 // gradient of the 2x2 stride-2 max pool (floor or ceil mode); `in` = the forward input (the argmax is re-derived from it)
 int cvx_maxpool2_bwd(const ViewDesc& in, const ViewDesc& gout, const ViewDesc& gin, int B, int IH, int IW, int OH, int OW, int C, int accumulate,
                      hipStream_t st);
+// L2Normalize backward: gin (+)= dx, dweight += inv_scale * dw; partial: cvx_l2norm_bwd_blocks(B*HW) * C floats of scratch
+int cvx_l2norm_bwd_blocks(long long npix);
+int cvx_l2norm_bwd(const ViewDesc& in, const ViewDesc& gout, const ViewDesc& gin, const float* weight, float* dweight, float inv_scale, int B, int HW,
+                   int C, int accumulate, float* partial, hipStream_t st);
+int cvx_nchw_cols_grad_to_pred_launch(const float* g, long long g_bstride, long long g_off, int C, int B, int A, int a_off, int HW, float scale,
+                                      half_t* dpred, int ld, int col0, hipStream_t st);
 int cvx_add_slice(const ViewDesc& in, const ViewDesc& out, int B, int HW, int C, hipStream_t st);  // out += in
 // depthwise transposed conv (kernel 2f, stride f, padding f/2): data gradient into gin, weight gradient ACCUMULATED (x inv_scale) into dw fp32 [C][2f][2f]
 int cvx_dwconvt_bwd(const ViewDesc& in, const ViewDesc& gout, const ViewDesc& gin, const float* w, float* dw, float inv_scale, int B, int IH, int IW,

@@ -1,5 +1,6 @@
 // HBM-bound helper kernels (gfx950): layout change, SPPF max-pool, nearest upsample, weight shadow
 // packing, gradient-slab reduction, fused Adam.  16-byte accesses wherever the layout allows.
+#include <algorithm>
 #include "misc_ops.h"
 #include "bn_common.h"
 
@@ -290,6 +291,70 @@ __global__ __launch_bounds__(256) void l2norm_kernel(ViewDesc in, ViewDesc out, 
     for (int k = 0; k < 8; ++k) o[k] = (half_t)(weight[c + k] * ((float)v[k] * inv));
     *reinterpret_cast<h8*>(dst + c) = o;
   }
+}
+
+// gradient of L2Normalize, y = w * x / (n + eps), n = ||x||_2 over the channels of a pixel:
+//   dx = w * g / (n + eps) - x * (sum_c w g x) / (n (n + eps)^2),   dw_c = sum over pixels of g_c x_c / (n + eps).
+// One wave per pixel (C <= 512: one 8-channel group per lane); every workgroup parks its four waves' dw partial sums, a second
+// launch adds the workgroups' partials in fixed order (deterministic).
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(ViewDesc in, ViewDesc gout, ViewDesc gin, const float* weight, long long npix, int hw, int C,
+                                                         int pix_per_wave, int accumulate, float* partial) {
+  __shared__ float sdw[4 * 512];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c0 = lane * 8;
+  const bool on = c0 < C;
+  float wv[8], dw[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    wv[k] = on ? weight[c0 + k] : 0.f;
+    dw[k] = 0.f;
+  }
+  const long long p0 = ((long long)blockIdx.x * 4 + wave) * pix_per_wave;
+  for (long long pix = p0; pix < min(npix, p0 + pix_per_wave); ++pix) {
+    const int b = (int)(pix / hw);
+    const long long p = pix - (long long)b * hw;
+    h8 xv = {}, gv = {};
+    if (on) {
+      xv = *reinterpret_cast<const h8*>(in.p + voff(in, b, p) + c0);
+      gv = *reinterpret_cast<const h8*>(gout.p + voff(gout, b, p) + c0);
+    }
+    float ss = 0.f, dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      ss += (float)xv[k] * (float)xv[k];
+      dot += wv[k] * (float)gv[k] * (float)xv[k];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      ss += __shfl_xor(ss, o);
+      dot += __shfl_xor(dot, o);
+    }
+    const float n = sqrtf(ss), inv = 1.f / (n + 1e-10f);
+    const float coef = n > 0.f ? dot * inv * inv / n : 0.f;
+    if (on) {
+      half_t* q = gin.p + voff(gin, b, p) + c0;
+      h8 o;
+      h8 old = {};
+      if (accumulate) old = *reinterpret_cast<const h8*>(q);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        o[k] = (half_t)(wv[k] * (float)gv[k] * inv - (float)xv[k] * coef + (accumulate ? (float)old[k] : 0.f));
+        dw[k] += (float)gv[k] * (float)xv[k] * inv;
+      }
+      *reinterpret_cast<h8*>(q) = o;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sdw[wave * 512 + c0 + k] = dw[k];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256)
+    partial[(long long)blockIdx.x * C + c] = (sdw[c] + sdw[512 + c]) + (sdw[1024 + c] + sdw[1536 + c]);
+}
+__global__ void l2norm_dw_kernel(const float* partial, int nblocks, int C, float inv_scale, float* dw) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float acc = 0.f;
+  for (int b = 0; b < nblocks; ++b) acc += partial[(long long)b * C + c];
+  dw[c] += acc * inv_scale;
 }
 
 // ---- global average pool (ASPPPooling's AdaptiveAvgPool2d(1), core/models/deeplabv3plus.py:30): one workgroup per
@@ -989,6 +1054,18 @@ int cvx_l2norm(const ViewDesc& in, const ViewDesc& out, const float* weight, int
   CVX_HIP(hipGetLastError());
   return 0;
 }
+int cvx_l2norm_bwd_blocks(long long npix) { return (int)std::min<long long>(1024, (npix + 3) / 4); }
+int cvx_l2norm_bwd(const ViewDesc& in, const ViewDesc& gout, const ViewDesc& gin, const float* weight, float* dweight, float inv_scale, int B, int HW,
+                   int C, int accumulate, float* partial, hipStream_t st) {
+  CVX_CHECK(C % 8 == 0 && C <= 512 && weight && dweight && partial, "l2norm_bwd: C % 8, C <= 512, weight / scratch");
+  const long long npix = (long long)B * HW;
+  const int nblocks = cvx_l2norm_bwd_blocks(npix);
+  const int per_wave = (int)((npix + (long long)nblocks * 4 - 1) / ((long long)nblocks * 4));
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(nblocks), dim3(256), 0, st, in, gout, gin, weight, npix, HW, C, per_wave, accumulate, partial);
+  hipLaunchKernelGGL(l2norm_dw_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial, nblocks, C, inv_scale, dweight);
+  CVX_HIP(hipGetLastError());
+  return 0;
+}
 int cvx_maxpool3(const ViewDesc& in, const ViewDesc& out, int B, int IH, int IW, int C, int stride, uint8_t* idx, hipStream_t st) {
   CVX_CHECK(C % 8 == 0 && (stride == 1 || stride == 2), "maxpool3: C % 8, stride 1 or 2");
   const int OH = (IH - 1) / stride + 1, OW = (IW - 1) / stride + 1;  // floor((I + 2 - 3) / stride) + 1
@@ -1091,6 +1168,21 @@ __global__ void pred_cols_to_nchw_kernel(const float* rows, int ld, int col0, in
   const int c = (int)(t % C);
   const int b = (int)(t / C);
   out[(long long)b * out_bstride + out_off + (long long)c * HW + pix] = rows[((long long)b * A + a_off + pix) * ld + col0 + c];
+}
+// adjoint of pred_cols_to_nchw: a gradient in the flattened NCHW order of one level -> scale * gradient on the rows' columns (fp16)
+__global__ void nchw_cols_grad_to_pred_kernel(const float* g, long long g_bstride, long long g_off, int C, int B, int A, int a_off, int HW, float scale,
+                                              half_t* dpred, int ld, int col0) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * C * HW) return;
+  const int c = (int)(i % C);
+  long long t = i / C;
+  const int pix = (int)(t % HW);
+  const int b = (int)(t / HW);
+  dpred[((long long)b * A + a_off + pix) * ld + col0 + c] = (half_t)(g[(long long)b * g_bstride + g_off + (long long)c * HW + pix] * scale);
+}
+int cvx_nchw_cols_grad_to_pred_launch(const float* g, long long g_bstride, long long g_off, int C, int B, int A, int a_off, int HW, float scale,
+                                      half_t* dpred, int ld, int col0, hipStream_t st) {
+  return launch1d(nchw_cols_grad_to_pred_kernel, (long long)B * C * HW, st, g, g_bstride, g_off, C, B, A, a_off, HW, scale, dpred, ld, col0);
 }
 int cvx_pred_cols_to_nchw_launch(const float* rows, int ld, int col0, int C, int B, int A, int a_off, int HW, float* out, long long out_bstride,
                                  long long out_off, hipStream_t st) {

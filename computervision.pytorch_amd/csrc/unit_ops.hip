@@ -98,6 +98,22 @@ extern "C" int cvx_pred_cols_to_nchw(const float* rows, int32_t ld, int32_t col0
   CVX_CHECK(rows && out && batch > 0 && c > 0 && col0 >= 0 && col0 + c <= ld && a_off >= 0 && a_off + hw <= anchors, "bad arguments");
   return cvx_pred_cols_to_nchw_launch(rows, ld, col0, c, batch, anchors, a_off, hw, out, out_bstride, out_off, (hipStream_t)hip_stream);
 }
+extern "C" int cvx_nchw_cols_grad_to_pred(const float* grad, int64_t grad_bstride, int64_t grad_off, int32_t c, int32_t batch, int32_t anchors,
+                                          int32_t a_off, int32_t hw, float scale, void* dpred_f16, int32_t ld, int32_t col0, void* hip_stream) {
+  CVX_CHECK(grad && dpred_f16 && batch > 0 && c > 0 && col0 >= 0 && col0 + c <= ld && a_off >= 0 && a_off + hw <= anchors, "bad arguments");
+  return cvx_nchw_cols_grad_to_pred_launch(grad, grad_bstride, grad_off, c, batch, anchors, a_off, hw, scale, (half_t*)dpred_f16, ld, col0,
+                                           (hipStream_t)hip_stream);
+}
+extern "C" int cvx_l2norm_bwd_nhwc(const void* x_f16, const void* gout_f16, const float* weight, int32_t batch, int32_t hw, int32_t c, float inv_scale,
+                                   void* gin_f16, float* dweight, int32_t accumulate, void* hip_stream) {
+  CVX_CHECK(x_f16 && gout_f16 && weight && gin_f16 && dweight && batch > 0, "bad arguments");
+  Scratch part;
+  CVX_TRY(part.alloc((size_t)cvx_l2norm_bwd_blocks((long long)batch * hw) * c * 4));
+  CVX_TRY(cvx_l2norm_bwd(dense(x_f16, hw, c), dense(gout_f16, hw, c), dense(gin_f16, hw, c), weight, dweight, inv_scale, batch, hw, c, accumulate,
+                         (float*)part.p, (hipStream_t)hip_stream));
+  CVX_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
+  return 0;
+}
 // ---- the inference-only pooling / resampling / normalisation ops of the DLA, ResNet / DeepLab and VGG / SSD graphs, one by one ----
 extern "C" int cvx_maxpool_nhwc(const void* x_f16, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t kernel, int32_t stride,
                                 int32_t ceil_mode, void* out_f16, void* hip_stream) {

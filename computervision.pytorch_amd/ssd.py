@@ -132,7 +132,7 @@ def build_ssd_graph(lay: SsdLayout, H: int, W: int) -> Graph:
         s = lay.convs[key]
         ho, wo = conv_out(hin, s["k"], s["stride"], s["pad"], s["dil"]), conv_out(win, s["k"], s["stride"], s["pad"], s["dil"])
         op = dict(type=L.OP_CONV, name=key, out=vout, ih=hin, iw=win, oh=ho, ow=wo, k=s["k"], stride=s["stride"], pad=s["pad"], dil=s["dil"], act=act,
-                  needs_dgrad=0, w_cin=s["cin"], w_off=s["w_off"], gamma_off=s.get("gamma_off", 0), beta_off=s.get("beta_off", 0),
+                  needs_dgrad=0 if vin[0] == img else 1, w_cin=s["cin"], w_off=s["w_off"], gamma_off=s.get("gamma_off", 0), beta_off=s.get("beta_off", 0),
                   bias_off=s["bias_off"], rmean_off=s.get("rmean_off", 0), rvar_off=s.get("rvar_off", 0), flags=flags)
         op["in"] = vin
         g.ops.append(op)
@@ -197,14 +197,20 @@ class _Holder(nn.Module):
 
 
 class SSD300VGG(nn.Module):
-    """``SSD(cfg)`` of the reference (ssd_model.py:131-191) on the engine: ``model.eval(); model(x)`` returns
-    (loc (B, 8732, 4), conf (B, 8732, nc + 1)) fp32."""
+    """``SSD(cfg)`` of the reference (ssd_model.py:131-191) on the engine: ``model(x)`` returns (loc (B, 8732, 4), conf (B, 8732, nc + 1))
+    fp32.  In training mode (grad enabled) the two tensors are connected to the engine's backward pass (VGG16-BN with batch
+    statistics behind biased convolutions, ceil-mode and 3x3 stride-1 max pools, L2Normalize and its weight, the bias-only extra
+    layers and heads): any torch loss on them -- the reference's MultiBoxLossV2 is torch code on exactly these tensors -- trains it."""
 
-    def __init__(self, num_classes: int = 20):
+    def __init__(self, num_classes: int = 20, loss_scale: float = 1024.0):
         super().__init__()
         self.layout = lay = SsdLayout(num_classes)
         self.num_classes = num_classes
-        self._flat = {"param": torch.zeros(lay.n_params), "stat": torch.zeros(lay.n_stats), "nbt": torch.zeros(len(lay.nbt_keys), dtype=torch.long)}
+        self.loss_scale = float(loss_scale)
+        self._flat = {"param": torch.zeros(lay.n_params), "stat": torch.zeros(lay.n_stats), "nbt": torch.zeros(len(lay.nbt_keys), dtype=torch.long),
+                      "grad": None}
+        self._anchor = torch.zeros(1, requires_grad=True)
+        self._grads_attached = False
         self._engines: Dict = {}
         self._build_tree()
         self._attach_views()
@@ -230,11 +236,15 @@ class SSD300VGG(nn.Module):
                 continue
             view = torch.as_strided(self._flat[sl.arena], sl.shape, sl.strides, sl.offset)
             if sl.trainable:
-                mod._parameters[parts[-1]] = nn.Parameter(view, requires_grad=False)
+                old = mod._parameters.get(parts[-1])
+                mod._parameters[parts[-1]] = nn.Parameter(view, requires_grad=True if old is None else old.requires_grad)
             else:
                 mod._buffers[parts[-1]] = view
 
     def _apply(self, fn, recurse=True):
+        self._flat["grad"] = None
+        self._grads_attached = False
+        self._anchor = fn(self._anchor.detach()).requires_grad_(True)
         for k in ("param", "stat", "nbt"):
             t_ = fn(self._flat[k])
             if k != "nbt" and t_.dtype != torch.float32:
@@ -278,34 +288,120 @@ class SSD300VGG(nn.Module):
             eng = Engine(build_ssd_graph(self.layout, h, w), dev)
             eng.set_bn(BN_EPS, BN_MOMENTUM)
             self._engines[key] = eng
-        eng.bind(self._flat["param"], None, self._flat["stat"])
+        eng.bind(self._flat["param"], self.flat_grads if self.training else self._flat["grad"], self._flat["stat"])
         return eng
 
-    def forward_rows(self, x: torch.Tensor) -> torch.Tensor:
-        if self.training:
-            raise L.CvxError("SSD on the MI355X engine is inference-only this round: call model.eval() first")
+    @property
+    def flat_params(self) -> torch.Tensor:
+        return self._flat["param"]
+
+    @property
+    def flat_stats(self) -> torch.Tensor:
+        return self._flat["stat"]
+
+    @property
+    def flat_grads(self) -> torch.Tensor:
+        if self._flat["grad"] is None or self._flat["grad"].device != self._flat["param"].device:
+            self._flat["grad"] = torch.zeros_like(self._flat["param"])
+            self._grads_attached = False
+        return self._flat["grad"]
+
+    def attach_grads(self):
+        """Make ``p.grad`` of every parameter a view of the flat gradient arena (torch optimisers / GradScaler)."""
+        g = self.flat_grads
+        modules = dict(self.named_modules())
+        for key, slot in self.layout.slots.items():
+            if not slot.trainable:
+                continue
+            mod_name, attr = key.rsplit(".", 1)
+            modules[mod_name]._parameters[attr].grad = torch.as_strided(g, slot.shape, slot.strides, slot.offset)
+        self._grads_attached = True
+
+    def _run_forward(self, x: torch.Tensor, training: bool) -> torch.Tensor:
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError("expected images of shape (B, 3, 300, 300)")
         eng = self.engine_for(int(x.shape[2]), int(x.shape[3]))
         self._last_engine = eng
-        return eng.forward(x, False)
+        rows = eng.forward(x, training)
+        if training:
+            self._flat["nbt"] += 1
+        return rows
 
-    def forward(self, x: torch.Tensor):
-        rows = self.forward_rows(x)
-        self.last_rows = rows
-        B = int(x.shape[0])
-        lay, lib, g = self.layout, L.load(), self._last_engine.graph
-        nc1 = self.num_classes + 1
-        tot = sum(hh * ww * n for (hh, ww), n in zip(g.level_hw, BOXES_PER_PIXEL))
-        loc = torch.empty(B, tot * 4, dtype=torch.float32, device=x.device)
-        conf = torch.empty(B, tot * nc1, dtype=torch.float32, device=x.device)
-        a_off = lo = co = 0
-        st = L.stream_ptr(x.device)
-        for (hh, ww), n in zip(g.level_hw, BOXES_PER_PIXEL):     # NCHW-order flattening per level, levels concatenated (ssd_model.py:177-183)
-            L.check(lib.cvx_pred_cols_to_nchw(L.ptr(rows), lay.pred_ld, 0, n * 4, B, g.anchors, a_off, hh * ww, L.ptr(loc), tot * 4, lo, st), "loc")
-            L.check(lib.cvx_pred_cols_to_nchw(L.ptr(rows), lay.pred_ld, LOC_COLS, n * nc1, B, g.anchors, a_off, hh * ww, L.ptr(conf), tot * nc1, co, st),
-                    "conf")
+    def forward_rows(self, x: torch.Tensor) -> torch.Tensor:
+        return self._run_forward(x, self.training)
+
+    def _levels(self):
+        """(a_off, hw, boxes per pixel, offset in the flattened loc tensor, offset in the flattened conf tensor) per source level."""
+        g, nc1 = self._last_engine.graph, self.num_classes + 1
+        out, a_off, lo, co = [], 0, 0, 0
+        for (hh, ww), n in zip(g.level_hw, BOXES_PER_PIXEL):
+            out.append((a_off, hh * ww, n, lo, co))
             a_off += hh * ww
             lo += hh * ww * n * 4
             co += hh * ww * n * nc1
-        return loc.view(B, tot, 4), conf.view(B, tot, nc1)
+        return out, lo // 4
+
+    def _rows_to_outputs(self, rows: torch.Tensor):
+        B = int(rows.shape[0])
+        lay, lib, g = self.layout, L.load(), self._last_engine.graph
+        nc1 = self.num_classes + 1
+        levels, tot = self._levels()
+        loc = torch.empty(B, tot * 4, dtype=torch.float32, device=rows.device)
+        conf = torch.empty(B, tot * nc1, dtype=torch.float32, device=rows.device)
+        st = L.stream_ptr(rows.device)
+        for a_off, hw, n, lo, co in levels:                      # NCHW-order flattening per level, levels concatenated (ssd_model.py:177-183)
+            L.check(lib.cvx_pred_cols_to_nchw(L.ptr(rows), lay.pred_ld, 0, n * 4, B, g.anchors, a_off, hw, L.ptr(loc), tot * 4, lo, st), "loc")
+            L.check(lib.cvx_pred_cols_to_nchw(L.ptr(rows), lay.pred_ld, LOC_COLS, n * nc1, B, g.anchors, a_off, hw, L.ptr(conf), tot * nc1, co, st),
+                    "conf")
+        return loc, conf
+
+    def _backward_outputs(self, g_loc, g_conf):
+        """Gradients w.r.t. the flattened (B, tot*4) / (B, tot*(nc+1)) outputs -> loss_scale * dLoss/drows in fp16 -> engine backward."""
+        eng, lay, lib = self._last_engine, self.layout, L.load()
+        nc1 = self.num_classes + 1
+        levels, tot = self._levels()
+        ref = g_loc if g_loc is not None else g_conf
+        B = int(ref.shape[0])
+        dpred = torch.zeros(B, eng.graph.anchors, lay.pred_ld, dtype=torch.float16, device=ref.device)
+        st = L.stream_ptr(ref.device)
+        gl = None if g_loc is None else g_loc.contiguous().float()
+        gc = None if g_conf is None else g_conf.contiguous().float()
+        for a_off, hw, n, lo, co in levels:
+            if gl is not None:
+                L.check(lib.cvx_nchw_cols_grad_to_pred(L.ptr(gl), tot * 4, lo, n * 4, B, eng.graph.anchors, a_off, hw, self.loss_scale, L.ptr(dpred),
+                                                       lay.pred_ld, 0, st), "loc grad")
+            if gc is not None:
+                L.check(lib.cvx_nchw_cols_grad_to_pred(L.ptr(gc), tot * nc1, co, n * nc1, B, eng.graph.anchors, a_off, hw, self.loss_scale,
+                                                       L.ptr(dpred), lay.pred_ld, LOC_COLS, st), "conf grad")
+        first = next(p for p in self.parameters() if p.requires_grad)
+        if first.grad is None:               # optimizer.zero_grad(set_to_none=True) happened (or first step)
+            self.flat_grads.zero_()
+            self._grads_attached = False
+        self.last_dpred = dpred
+        eng.backward(dpred, self.loss_scale)
+        if not self._grads_attached or first.grad is None:
+            self.attach_grads()
+
+    def forward(self, x: torch.Tensor):
+        if self.training and torch.is_grad_enabled():
+            loc, conf = _SsdFn.apply(x, self._anchor, self)
+        else:
+            self.last_rows = self._run_forward(x, self.training)
+            loc, conf = self._rows_to_outputs(self.last_rows)
+        B, nc1 = int(x.shape[0]), self.num_classes + 1
+        return loc.view(B, -1, 4), conf.view(B, -1, nc1)
+
+
+class _SsdFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, images, anchor, model):
+        ctx.model = model
+        ctx.set_materialize_grads(False)
+        model.last_rows = model._run_forward(images, training=True)
+        return model._rows_to_outputs(model.last_rows)
+
+    @staticmethod
+    def backward(ctx, g_loc, g_conf):
+        if g_loc is not None or g_conf is not None:
+            ctx.model._backward_outputs(g_loc, g_conf)
+        return None, None, None

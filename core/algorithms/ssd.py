@@ -68,7 +68,9 @@ class Ssd:
         return SSD300VGG(self.num_classes), f"SSD{self.input_image_size[0]}_vgg"
 
     def build_loss(self):
-        raise L.CvxError("SSD training (MultiBoxLossV2, core/loss/multi_box_loss.py) is not built on the MI355X engine yet: inference only")
+        raise L.CvxError("MultiBoxLossV2 (core/loss/multi_box_loss.py) and the CPU target encoding have no HIP kernels yet.  The network itself trains on the "
+                         "engine: model.train(); loc, conf = model(x) are ordinary tensors connected to the engine's backward pass, so the "
+                         "reference's own MultiBoxLossV2 module (plain torch code on these outputs) can be applied to them unchanged")
 
     # ---- decode ---------------------------------------------------------------------------------------
     def decode_device(self, preds, conf_threshold=None):

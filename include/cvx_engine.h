@@ -387,6 +387,14 @@ int cvx_maxpool3_train_nhwc(const void* x_f16, int32_t batch, int32_t h, int32_t
 int cvx_maxpool3_bwd_nhwc(const void* gout_f16, const uint8_t* argmax, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t stride,
                           void* gin_f16, int32_t accumulate, void* hip_stream);
 int cvx_avgpool_global_bwd_nhwc(const void* gout_f16, int32_t batch, int32_t hw, int32_t c, void* gin_f16, int32_t accumulate, void* hip_stream);
+/* Gradient of cvx_l2norm_nhwc (L2Normalize, ssd_model.py:113-128): gin (+)= w*g/(n+eps) - x*(sum_c w g x)/(n (n+eps)^2), and
+ * dweight[c] += inv_scale * sum over pixels of g*x/(n+eps) (fixed summation order).  c <= 512. */
+int cvx_l2norm_bwd_nhwc(const void* x_f16, const void* gout_f16, const float* weight, int32_t batch, int32_t hw, int32_t c, float inv_scale,
+                        void* gin_f16, float* dweight, int32_t accumulate, void* hip_stream);
+/* Adjoint of cvx_pred_cols_to_nchw: a gradient laid out like its output (element (b, ch, pix) at grad[b*grad_bstride + grad_off + ch*hw + pix]:
+ * SSD's NCHW-order flattening, ssd_model.py:177-183) -> scale * gradient in fp16 on columns [col0, col0 + c) of rows a_off .. a_off + hw. */
+int cvx_nchw_cols_grad_to_pred(const float* grad, int64_t grad_bstride, int64_t grad_off, int32_t c, int32_t batch, int32_t anchors, int32_t a_off,
+                               int32_t hw, float scale, void* dpred_f16, int32_t ld, int32_t col0, void* hip_stream);
 /* Gradient of the 2x2 stride-2 max pool of cvx_maxpool_nhwc (floor or ceil mode): x is the forward input, the first maximum of each
  * window in row-major scan order takes the gradient (torch's rule).  Replaces: nn.MaxPool2d(2, 2) autograd (yolov7_model.py:74-86). */
 int cvx_maxpool2_bwd_nhwc(const void* x_f16, const void* gout_f16, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t ceil_mode,

@@ -243,6 +243,51 @@ def centernet_train_section(builder, report):
     report["centernet_train"] = dict(loss=float(loss), worst_grad_rel_oracle_vs_reference=worst, tensors=len(keys), full=full, stats=stat_keys)
 
 
+def ssd_train_section(builder, report):
+    """12b. SSD300 VGG16-BN network forward + backward in training mode: the REAL reference model (model.train()), a fixed linear
+    functional of (loc, conf) (ssd_ref.projection_loss), loss.backward() -> every parameter gradient (biases behind a BatchNorm: zero up
+    to round-off; L2Normalize's weight) and the updated running statistics.  Pins the oracle's train-mode restatement."""
+    from oracle import ssd_ref as S
+    scfg, salgo_cls, _ = builder.export_from_registry("ssd")
+    torch.manual_seed(0)
+    smodel, _ = salgo_cls(scfg, torch.device("cpu")).build_model()
+    nc = scfg.dataset.num_classes
+    sd0 = {k: v.clone() for k, v in smodel.state_dict().items()}
+    x = (torch.rand(2, 3, 300, 300, generator=torch.Generator().manual_seed(61)) * 255).round() / 255      # stored as bytes in the fixture
+    smodel.train()
+    outs = smodel(x.clone())
+    weights = S.projection_weights([o.shape for o in outs], seed=9)
+    loss = S.projection_loss(outs, weights)
+    loss.backward()
+    ref_grads = {k: p.grad.clone() for k, p in smodel.named_parameters() if p.grad is not None}
+    ref_sd = {k: v.clone() for k, v in smodel.state_dict().items()}
+    work = {k: v.clone() for k, v in sd0.items()}
+    my_loss, my_grads, my_outs = S.loss_and_grads(work, x.clone(), nc, weights)
+    assert abs(float(my_loss) - float(loss)) <= 1e-5 * max(abs(float(loss)), 1e-3), (float(my_loss), float(loss))
+    for a_, b_ in zip(my_outs, outs):
+        assert torch.allclose(a_, b_.detach(), rtol=1e-4, atol=1e-5)
+    gmax = max(float(v.norm()) for v in ref_grads.values())
+    worst = 0.0
+    for k, gr in ref_grads.items():
+        if float(gr.norm()) < 1e-6 * gmax:                        # conv biases in front of a BatchNorm: zero in exact arithmetic
+            continue
+        e = float((my_grads[k] - gr).norm() / gr.norm())
+        worst = max(worst, e)
+        assert e < 1e-3, (k, e)
+    for k in ref_sd:
+        if k.endswith(("running_mean", "running_var")):
+            assert torch.allclose(work[k], ref_sd[k], rtol=1e-5, atol=1e-6), k
+    keys = list(ref_grads.keys())
+    full = [k for k in ("l2_norm.weight", "locs.0.bias", "confs.5.bias", "locs.5.weight", "extras.conv8.weight", "extras.conv1.bias", "backbone.layers.0.weight",
+                        "backbone.layers.1.weight", "backbone.layers.1.bias", "backbone.layers.31.weight") if k in ref_grads]
+    stat_keys = [k for k in ("backbone.layers.1.running_mean", "backbone.layers.1.running_var", "backbone.layers.31.running_mean") if k in ref_sd]
+    np.savez_compressed(os.path.join(GOLD, "ssd_train_300.npz"), x=(x.numpy() * 255).round().astype(np.uint8), proj_seed=np.array(9),
+                        loss=np.array(float(loss)), nc=np.array(nc), out_sub=np.concatenate([o.detach().flatten()[::7].numpy() for o in outs]),
+                        grad_keys=np.array(keys), grad_norm=np.array([float(ref_grads[k].double().norm()) for k in keys]), stat_keys=np.array(stat_keys),
+                        **{"g:" + k: ref_grads[k].numpy() for k in full}, **{"s:" + k: ref_sd[k].numpy().copy() for k in stat_keys})
+    report["ssd_train"] = dict(loss=float(loss), worst_grad_rel_oracle_vs_reference=worst, tensors=len(keys), full=full, stats=stat_keys)
+
+
 def main():
     sys.path.insert(0, ROOT)
     from oracle import yolov8_ref as O
@@ -729,6 +774,7 @@ def main():
                         keep0=res[0][1], keep1=res[1][1], rows0=res[0][0], rows1=res[1][0])
     report["nms"] = "kept %d / %d" % (len(res[0][1]), len(res[1][1]))
 
+    ssd_train_section(builder, report)
     with open(os.path.join(GOLD, "PIN_REPORT.json"), "w") as f:
         json.dump(report, f, indent=1)
     print(json.dumps(report, indent=1))
@@ -742,7 +788,7 @@ def only(section):
     builder = _import_reference()
     torch.set_num_threads(8)
     report = {}
-    {"deeplab_train": deeplab_train_section, "yolov7_train": yolov7_train_section, "centernet_train": centernet_train_section}[section](builder, report)
+    {"deeplab_train": deeplab_train_section, "yolov7_train": yolov7_train_section, "centernet_train": centernet_train_section, "ssd_train": ssd_train_section}[section](builder, report)
     path = os.path.join(GOLD, "PIN_REPORT.json")
     full = json.load(open(path)) if os.path.exists(path) else {}
     full.update(report)

@@ -1,4 +1,5 @@
-"""CPU oracle for SSD300-VGG16(BN) inference (network + prior boxes + decode + per-class NMS) -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+"""CPU oracle for SSD300-VGG16(BN): network forward (eval / train mode) and backward, prior boxes, decode, per-class NMS -- TEST
+INFRASTRUCTURE, NOT PRODUCT CODE.
 
 SURVEY.md section 8 row a17 / (f)4.  A torch-CPU fp32 restatement, functional over a flat ``state_dict`` with the
 reference's keys, of
@@ -12,8 +13,13 @@ reference's keys, of
   the letterbox inverse: softmax, per class c = 1..num_classes (column 0 is the background), score > threshold, greedy NMS.  ``torchvision.ops.nms`` is third party and
   absent: restated as the standard greedy algorithm (oracle/nms_ref.py) -- parity unpinned upstream, as for the YOLO tails.
 
+Training (``forward(training=True)``, ``projection_loss``, ``loss_and_grads``): batch-statistics BatchNorm (running statistics
+updated in place); the backward pass is torch autograd over this restatement, driven by a fixed linear functional of (loc, conf)
+(the reference's MultiBoxLossV2, core/loss/multi_box_loss.py, is torch code on those tensors and is not restated).
+
 Parity pin: ``oracle/make_golden.py`` section 12 imports the real reference and asserts init bit for bit, forward to fp32
-round-off, priors and decoded boxes exactly.
+round-off, priors and decoded boxes exactly; section 12b asserts the train-mode outputs and every parameter gradient of
+``projection_loss`` against the real model's autograd.
 """
 from __future__ import annotations
 
@@ -92,7 +98,11 @@ FP16_STORAGE = [False]
 
 
 def _q(t):
-    return t.half().float() if FP16_STORAGE[0] else t
+    if not FP16_STORAGE[0]:
+        return t
+    if t.requires_grad:                       # straight-through: the value is rounded, the gradient passes unrounded
+        return t + (t.detach().half().float() - t.detach())
+    return t.half().float()
 
 
 def forward(sd, x, nc: int = 20, training: bool = False, return_maps: bool = False):
@@ -199,3 +209,27 @@ def decode(loc, conf, anchors, nc: int, conf_threshold: float, nms_threshold: fl
     classes ascending, scores descending inside a class."""
     prob = torch.softmax(conf, -1)
     return [nms_per_class(parse_loc(loc[i], anchors), prob[i], nc, conf_threshold, nms_threshold) for i in range(loc.shape[0])]
+
+
+def projection_weights(shapes, seed: int = 9):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(*sh, generator=g) for sh in shapes]
+
+
+def projection_loss(outs, weights):
+    """mean(loc * w0) + mean(conf * w1): a fixed linear functional of the two outputs the backward parity runs on."""
+    return sum((o * w).mean() for o, w in zip(outs, weights))
+
+
+def loss_and_grads(sd, x, nc: int = 20, weights=None, seed: int = 9):
+    """Train-mode forward + backward of ``projection_loss``: (loss, {key: grad}, (loc, conf)); running statistics in ``sd`` are updated."""
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()
+              if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var"))}
+    work = dict(sd)
+    work.update(params)
+    outs = forward(work, x, nc, training=True)
+    if weights is None:
+        weights = projection_weights([o.shape for o in outs], seed)
+    loss = projection_loss(outs, weights)
+    loss.backward()
+    return loss.detach(), {k: p.grad for k, p in params.items() if p.grad is not None}, [o.detach() for o in outs]

@@ -1755,7 +1755,18 @@ def _check_backward_per_layer(m, B, dpred, min_layers, min_buffers):
         if typ == L.OP_MAXPOOL3S2:
             y = F.max_pool2d(xin, 3, 2, 1)
         elif typ == L.OP_MAXPOOL2:
-            y = F.max_pool2d(xin, 2, 2)
+            y = F.max_pool2d(xin, 2, 2, ceil_mode=(o["oh"] * 2 != o["ih"]))
+        elif typ == L.OP_MAXPOOL3S1:
+            y = F.max_pool2d(xin, 3, 1, 1)
+        elif typ == L.OP_L2NORM:                             # x / (||x|| + 1e-10) * weight (ssd_model.py:113-128)
+            Cn = o["in"][2]
+            wn = P[o["gamma_off"]:o["gamma_off"] + Cn].clone().requires_grad_(True)
+            y = wn.view(1, -1, 1, 1) * (xin / (xin.pow(2).sum(1, keepdim=True).sqrt() + 1e-10))
+            y.backward(gout)
+            got_wn = G[o["gamma_off"]:o["gamma_off"] + Cn]
+            assert rel(got_wn, wn.grad / scale) < 1e-5, (o["name"], rel(got_wn, wn.grad / scale))
+            add(o["in"], nhwc(xin.grad))
+            continue
         elif typ == L.OP_MAXPOOL5:
             y = F.max_pool2d(xin, 5, 1, 2)
         elif typ == L.OP_UPSAMPLE2:
@@ -2076,3 +2087,69 @@ def test_centernet_training_through_the_plugin_api(dev):
         opt.step()
         losses.append(float(loss.detach()))
     assert all(np.isfinite(v) for v in losses) and losses[-1] < losses[0], losses
+
+
+# ---- SSD300 VGG16-BN network forward + backward in training mode -------------------------------------------
+def _ssd_train_step(dev, g):
+    from computervision.pytorch_amd.ssd import SSD300VGG
+    from oracle import ssd_ref as S
+    nc = int(g["nc"])
+    torch.manual_seed(0)
+    m = SSD300VGG(nc)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.to(dev).train()
+    x = torch.from_numpy(g["x"].astype(np.float32) / 255.0)
+    outs = m(x.to(dev))
+    weights = S.projection_weights([o.shape for o in outs], int(g["proj_seed"]))
+    loss = S.projection_loss(outs, [w.to(dev) for w in weights])
+    loss.backward()
+    torch.cuda.synchronize()
+    return m, sd0, x, outs, weights, nc
+
+
+def test_ssd_training_forward_backward_matches_the_reference_fixture(dev, gold):
+    """model.train(); loc, conf = model(x); loss(loc, conf).backward() on the engine against the REAL reference's autograd
+    (make_golden.py section 12b): train-mode outputs (NCHW-order flattening included), running statistics (the convolution's bias enters
+    the running mean), all 97 parameter gradients incl. L2Normalize's weight; conv biases in front of a BatchNorm have zero gradient
+    (exactly here, round-off in torch).  Yardstick: the oracle's fp16-operand emulation, run here."""
+    from oracle import ssd_ref as S
+    g = gold("ssd_train_300.npz")
+    m, sd0, x, outs, weights, nc = _ssd_train_step(dev, g)
+    _, ref_grads, ref_outs = S.loss_and_grads({k: v.clone() for k, v in sd0.items()}, x, nc, weights)
+    S.FP16_STORAGE[0] = True
+    try:
+        _, emu_grads, emu_outs = S.loss_and_grads({k: v.clone() for k, v in sd0.items()}, x, nc, weights)
+    finally:
+        S.FP16_STORAGE[0] = False
+    assert rel(torch.cat([o.flatten()[::7] for o in ref_outs]), torch.from_numpy(g["out_sub"])) < 1e-4
+    for o, r, e in zip(outs, ref_outs, emu_outs):
+        assert tuple(o.shape) == tuple(r.shape)
+        assert rel(o.detach().cpu(), r) < max(1.25 * rel(e, r), 1e-2), (rel(o.detach().cpu(), r), rel(e, r))
+    eg = {k: p.grad.cpu() for k, p in m.named_parameters() if k in ref_grads}
+    gmax = max(float(v.norm()) for v in ref_grads.values())
+    live = [k for k in ref_grads if float(ref_grads[k].norm()) >= 1e-6 * gmax]
+    dead = [k for k in ref_grads if k not in live]
+    assert len(dead) == 13 and all(float(eg[k].abs().max()) == 0.0 for k in dead)       # the 13 VGG convolution biases behind a BatchNorm
+
+    def total(a, b):
+        return (sum(float((a[k].double() - b[k].double()).pow(2).sum()) for k in live) / sum(float(b[k].double().pow(2).sum()) for k in live)) ** 0.5
+
+    e_tot, y_tot = total(eg, ref_grads), total(emu_grads, ref_grads)
+    print(f"ssd train: gradients engine vs reference {e_tot:.3e}, yardstick {y_tot:.3e}")
+    assert e_tot < max(1.25 * y_tot, 1e-2), (e_tot, y_tot)
+    for k in live:
+        e, y = rel(eg[k], ref_grads[k]), rel(emu_grads[k], ref_grads[k])
+        assert e < max(1.6 * y, 2e-2), (k, e, y)
+    sdm = m.state_dict()
+    for k in [str(k) for k in g["stat_keys"]]:
+        assert rel(sdm[k].cpu(), torch.from_numpy(g["s:" + k])) < 2e-2, k
+
+
+def test_ssd_per_layer_backward_on_the_engines_own_operands(dev, gold):
+    """_check_backward_per_layer on the SSD step: the 13 Conv(bias) + BN + ReLU blocks of VGG16, conv6 / conv7 (bias + ReLU), the eight
+    activation-free extra layers, the twelve 3x3 heads on their column ranges of the prediction rows, 2x2 (one ceil-mode) and 3x3
+    stride-1 max pools, L2Normalize (data gradient and its weight gradient)."""
+    g = gold("ssd_train_300.npz")
+    m, _, x, _, _, _ = _ssd_train_step(dev, g)
+    n_w, n_bn, checked = _check_backward_per_layer(m, x.shape[0], m.last_dpred, 13, 25)
+    assert n_w >= 35

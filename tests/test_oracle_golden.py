@@ -336,6 +336,34 @@ def test_centernet_oracle_training_forward_backward(gold):
             assert float((sd[name[2:]] - ref).norm() / ref.norm()) < 1e-4, name
 
 
+def test_ssd_oracle_training_forward_backward(gold):
+    """oracle/ssd_ref.loss_and_grads against the REAL reference model's train-mode forward + autograd (make_golden.py section 12b):
+    (loc, conf), norms of all 97 parameter gradients, ten gradient tensors in full (L2Normalize's weight among them), running statistics
+    (a BatchNorm behind a biased convolution tracks mean(conv) + bias)."""
+    from oracle import ssd_ref as S
+    g = gold("ssd_train_300.npz")
+    nc = int(g["nc"])
+    sd = S.init_state_dict(nc, seed=0)
+    x = torch.from_numpy(g["x"].astype(np.float32) / 255.0)
+    loss, grads, outs = S.loss_and_grads(sd, x, nc, seed=int(g["proj_seed"]))
+    assert [tuple(o.shape) for o in outs] == [(2, 8732, 4), (2, 8732, nc + 1)]
+    sub = torch.cat([o.flatten()[::7] for o in outs])
+    assert float((sub - torch.from_numpy(g["out_sub"])).norm() / sub.norm()) < 1e-4
+    keys = [str(k) for k in g["grad_keys"]]
+    assert list(grads.keys()) == keys and len(keys) == 97
+    norms = np.array([float(grads[k].double().norm()) for k in keys])
+    live = g["grad_norm"] >= 1e-6 * g["grad_norm"].max()
+    assert int((~live).sum()) == 13                                           # conv biases in front of a BatchNorm: zero up to round-off
+    np.testing.assert_allclose(norms[live], g["grad_norm"][live], rtol=5e-3)
+    for name in g.files:
+        if name.startswith("g:") and float(np.linalg.norm(g[name])) >= 1e-6 * g["grad_norm"].max():
+            ref = torch.from_numpy(g[name])
+            assert float((grads[name[2:]] - ref).norm() / ref.norm()) < 5e-3, name
+        if name.startswith("s:"):
+            ref = torch.from_numpy(g[name])
+            assert float((sd[name[2:]] - ref).norm() / ref.norm()) < 1e-4, name
+
+
 def _yolov7_fixture_state(g):
     from oracle import yolov7_ref as Y
     sd = Y.init_state_dict(20, seed=0)
