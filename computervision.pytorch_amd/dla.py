@@ -21,7 +21,7 @@ from __future__ import annotations
 
 import math
 from collections import OrderedDict
-from typing import Dict, List, Optional
+from typing import Dict, List, Optional, Sequence
 
 import torch
 import torch.nn as nn
@@ -461,11 +461,13 @@ class CenterNetDLA34(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         raw = _RowsFn.apply(x, self._anchor, self) if (self.training and torch.is_grad_enabled()) else self.forward_raw(x)
-        self.last_raw = raw
+        self.last_raw = raw.detach()
         B, _, H, W = x.shape
         lay = self.layout
         out = torch.cat((raw[..., :lay.nc], raw[..., lay.nc_pad:lay.nc_pad + 2], raw[..., lay.nc_pad + 8:lay.nc_pad + 10]), -1)
-        return out.reshape(B, H // 4, W // 4, lay.nc + 4)
+        out = out.reshape(B, H // 4, W // 4, lay.nc + 4)
+        out.model = self                       # the fused CenterNetLoss starts from the head rows (last_raw)
+        return out
 
 
 class _RowsFn(torch.autograd.Function):
@@ -480,3 +482,126 @@ class _RowsFn(torch.autograd.Function):
         if g is not None:
             ctx.model._backward_rows(g)
         return None, None, None
+
+
+class _CnLossFn(torch.autograd.Function):
+    """loss = CombinedLoss(rows, targets) with the gradient taken by the fused kernel; ``.backward()`` runs the engine's backward."""
+
+    @staticmethod
+    def forward(ctx, out, owner, model, targets):
+        items, dpred = owner.op(model.last_raw.detach(), targets, model._last_engine.graph.level_hw[0], model.loss_scale)
+        ctx.model, ctx.dpred = model, dpred
+        model.last_dpred = dpred
+        owner.last_items = items
+        return items[0].reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        m = ctx.model
+        first = next(p for p in m.parameters() if p.requires_grad)
+        if first.grad is None:
+            m.flat_grads.zero_()
+            m._grads_attached = False
+        m._last_engine.backward(ctx.dpred, m.loss_scale / float(gout))
+        if not m._grads_attached or first.grad is None:
+            m.attach_grads()
+        return None, None, None, None
+
+
+class CenterNetLoss:
+    """``CombinedLoss(num_classes, hm_weight, wh_weight, off_weight)`` of the reference (core/loss/centernet_loss.py:46-67) on the engine:
+    ``loss = criterion(preds, targets)`` with ``preds = model(images)`` and ``targets = [heatmap_true (B,h,w,nc), reg_true (B,K,2),
+    wh_true (B,K,2), reg_mask (B,K), indices (B,K)]`` as ``centernet_collate`` builds them.  Value and gradient come from
+    ``cvx_centernet_loss`` on the head rows behind ``preds``; ``loss.backward()`` then runs the engine's backward pass.  The
+    reference applies its "reg" term to the output's columns nc, nc+1 and its "wh" term to the last two -- kept as is."""
+
+    def __init__(self, num_classes: int, hm_weight: float = 1.0, wh_weight: float = 0.1, off_weight: float = 1.0, check_targets: bool = True):
+        self.num_classes = int(num_classes)
+        self.hm_weight, self.wh_weight, self.off_weight = float(hm_weight), float(wh_weight), float(off_weight)
+        self.check_targets = check_targets
+        self._ws = self._bad = None
+        self.last_items = None
+
+    def bad_targets(self) -> bool:
+        return self._bad is not None and int(self._bad.item()) != 0
+
+    def op(self, rows: torch.Tensor, targets: Sequence[torch.Tensor], hw, loss_scale: float, dpred: Optional[torch.Tensor] = None,
+           check: Optional[bool] = None):
+        """rows (B, h*w, ld) fp32 -> (loss items (4,): total, heat-map, L1 "reg", L1 "wh"; dpred (B, h*w, ld) fp16)."""
+        if rows.device.type != "cuda":
+            raise L.CvxError("CenterNetLoss runs on an MI355X only (there is no CPU path)")
+        lib = L.load()
+        B, A, ld = rows.shape
+        nc = self.num_classes
+        nc_pad = (nc + 7) & ~7
+        heat, reg_t, wh_t, mask, idx = (t.to(rows.device) for t in targets)
+        if tuple(heat.shape) != (B, hw[0], hw[1], nc):
+            raise ValueError(f"heatmap_true must have shape {(B, hw[0], hw[1], nc)}")
+        K = int(mask.shape[1])
+        heat, reg_t, wh_t, mask = (t.float().contiguous() for t in (heat, reg_t, wh_t, mask))
+        idx = idx.long().contiguous()
+        need = int(lib.cvx_centernet_loss_workspace_bytes(B, A))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != rows.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=rows.device)
+            self._bad = torch.zeros(1, dtype=torch.int32, device=rows.device)
+        if dpred is None:
+            dpred = torch.empty(B, A, ld, dtype=torch.float16, device=rows.device)
+        items = torch.empty(4, device=rows.device)
+        # model output = [heatmap | wh head | reg head]; the loss's "reg" = output[..., nc:nc+2] (rows' columns nc_pad..), "wh" = the last two
+        L.check(lib.cvx_centernet_loss(L.ptr(rows), ld, B, A, nc, nc_pad, nc_pad + 8, L.ptr(heat), L.ptr(reg_t), L.ptr(wh_t), L.ptr(mask), L.ptr(idx), K,
+                                       self.hm_weight, self.off_weight, self.wh_weight, float(loss_scale), L.ptr(items), L.ptr(dpred),
+                                       L.ptr(self._bad), L.ptr(self._ws), L.stream_ptr(rows.device)), "cvx_centernet_loss")
+        if (self.check_targets if check is None else check) and self.bad_targets():
+            raise L.CvxError("CenterNetLoss: a masked object's index lies outside the feature map")
+        return items, dpred
+
+    def __call__(self, preds: torch.Tensor, targets):
+        model = getattr(preds, "model", None)
+        if model is None:
+            raise L.CvxError("CenterNetLoss needs the output of CenterNetDLA34.forward (it carries the head rows the loss starts from)")
+        if model.training and torch.is_grad_enabled():
+            return _CnLossFn.apply(preds, self, model, targets)
+        return self.op(model.last_raw, targets, model._last_engine.graph.level_hw[0], model.loss_scale)[0][0].reshape(())
+
+
+class CenterNetTrainStep:
+    """One optimisation step of the reference's ``CenterNetTrainer.train_loop`` (core/trainer/centernet_train.py:104-121) as C-ABI calls:
+    engine forward (training), ``cvx_centernet_loss``, engine backward, [gradient sum over the ranks], fused Adam with GradScaler's
+    inf/nan check.  Returns the loss items (4,)."""
+
+    def __init__(self, model: "CenterNetDLA34", criterion: CenterNetLoss, optimizer, scaler=None, process_group=None, n_buckets: int = 4):
+        self.model, self.criterion, self.optimizer, self.scaler = model, criterion, optimizer, scaler
+        self.pg, self.n_buckets = process_group, n_buckets
+        self.world, self.distributed = 1, False
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+            self.distributed = True
+        self._dpred = self._side = None
+
+    def __call__(self, images: torch.Tensor, targets) -> torch.Tensor:
+        from .engine import check_finite
+        from .train import allreduce_mean_flat
+        m, crit = self.model, self.criterion
+        if not m.training:
+            raise L.CvxError("CenterNetTrainStep: call model.train() first")
+        dev = m.flat_params.device
+        self.optimizer.sync_lr()
+        rows = m._run_forward(images, True)
+        m.last_raw = rows
+        eng = m._last_engine
+        if self._dpred is None or self._dpred.shape != rows.shape:
+            self._dpred = torch.empty(rows.shape, device=dev, dtype=torch.float16)
+        scale = self.scaler.begin_step() if self.scaler is not None else m.loss_scale
+        items, dpred = crit.op(rows, targets, eng.graph.level_hw[0], scale, self._dpred, check=False)
+        eng.backward(dpred, scale)
+        if self.distributed and dev.type == "cuda":
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev, priority=-1)
+            allreduce_mean_flat(m.flat_grads, self.world, self.pg, self.n_buckets, self._side, average=False)
+        if self.scaler is not None:
+            check_finite(m.flat_grads, self.scaler.found_inf)
+            self.optimizer.found_inf = self.scaler.found_inf
+        self.optimizer.step(zero_grad=True, grad_scale=1.0 / self.world)
+        if self.scaler is not None:
+            self.scaler.end_step()
+        return items

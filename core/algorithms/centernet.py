@@ -2,14 +2,15 @@
 (core/algorithms/centernet.py:25-338) for the INFERENCE path: ``__init__(cfg, device)``, ``build_model() -> (nn.Module, name)``,
 ``decode_boxes(pred, h, w, conf_threshold=None) -> (boxes, scores, classes)``, ``predict``.  The DLA-34 network and the
 heat-map decode run on the MI355X engine (``computervision.pytorch_amd.dla``, ``cvx_centernet_decode``); the loss and
-target generation of the training path are not built this round (``build_loss`` raises).
+``build_loss`` returns the engine's fused CombinedLoss; the heat-map target drawing (``generate_targets``, CPU work inside the
+reference's collate) is not built.
 """
 import numpy as np
 import torch
 
 from computervision.pytorch_amd import _lib as L
 from computervision.pytorch_amd import engine as _engine
-from computervision.pytorch_amd.dla import CenterNetDLA34
+from computervision.pytorch_amd.dla import CenterNetDLA34, CenterNetLoss
 from configs import CenternetConfig
 from registry import model_registry
 
@@ -32,9 +33,10 @@ class CenterNetA:
         return CenterNetDLA34(self.num_classes), "CenterNet"
 
     def build_loss(self):
-        raise L.CvxError("CombinedLoss (core/loss/centernet_loss.py) and the heat-map target drawing have no HIP kernels yet.  The network itself trains "
-                         "on the engine: model.train(); out = model(x) is an ordinary tensor connected to the engine's backward pass, so the "
-                         "reference's own CombinedLoss module (plain torch code on this output) can be applied to it unchanged")
+        """Reference :63-64: CombinedLoss(num_classes, hm_weight, wh_weight, off_weight) -- here the engine's fused CenterNetLoss
+        (``cvx_centernet_loss``: value and gradient on the head rows)."""
+        lc = self.cfg.loss
+        return CenterNetLoss(self.num_classes, lc.hm_weight, lc.wh_weight, lc.off_weight)
 
     # ---- decode ---------------------------------------------------------------------------------------
     def decode_raw(self, raw: torch.Tensor, fh: int, fw: int, conf_threshold=None):

@@ -366,6 +366,19 @@ int64_t cvx_seg_loss_workspace_bytes(int32_t batch, int32_t nc, int32_t oh, int3
 int cvx_seg_loss(const float* rows_f32, int32_t ld, int32_t batch, int32_t nc, int32_t ih, int32_t iw, int32_t oh, int32_t ow,
                  const int64_t* target, int32_t mode, float alpha, float gamma, int64_t ignore_index, float loss_scale, float* loss_out,
                  void* dpred_f16, int32_t* bad_target, void* workspace, void* hip_stream);
+/* CenterNet's CombinedLoss with its gradient.  rows: the engine's fp32 head rows (batch, anchors = h*w, ld): heat-map logits in columns
+ * [0, nc), the loss's "reg" pair at columns col_a, col_a+1 (= the model output's columns nc, nc+1) and its "wh" pair at col_b, col_b+1 (= the
+ * output's last two) -- the reference's loss names are swapped against the heads that produce them, reproduced as is.  Targets as
+ * centernet_collate builds them: heat_true (batch, h, w, nc) fp32, true_a / true_b (batch, K, 2), mask (batch, K) fp32, indices (batch, K)
+ * int64 = y*w + x.  loss_items: 4 floats (device): total, heat-map focal, L1(a), L1(b) (unweighted).  dpred: (batch, anchors, ld) fp16 =
+ * loss_scale * dLoss/drows.  bad_index: set non-zero when a masked object's index lies outside [0, anchors).  Asynchronous on hip_stream.
+ * Replaces: CombinedLoss.__call__ + loss.backward() down to the head outputs, core/loss/centernet_loss.py:5-67,
+ * core/trainer/centernet_train.py:104-118. */
+int64_t cvx_centernet_loss_workspace_bytes(int32_t batch, int32_t anchors);
+int cvx_centernet_loss(const float* rows_f32, int32_t ld, int32_t batch, int32_t anchors, int32_t nc, int32_t col_a, int32_t col_b,
+                       const float* heat_true, const float* true_a, const float* true_b, const float* mask, const int64_t* indices,
+                       int32_t max_objects, float hm_weight, float a_weight, float b_weight, float loss_scale, float* loss_items, void* dpred_f16,
+                       int32_t* bad_index, void* workspace, void* hip_stream);
 /* Adjoint of cvx_resize_bilinear_rows_to_nchw: a gradient w.r.t. the full-resolution logits (batch, nc, oh, ow) fp32 -> scale * the
  * gradient w.r.t. the rows (batch, ih*iw, ld) fp16 (a deterministic gather).  For callers that compute their own loss on the
  * model's NCHW output.  Asynchronous on hip_stream. */

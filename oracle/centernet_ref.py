@@ -357,3 +357,51 @@ def loss_and_grads(sd, x, nc: int = 80, weights=None, seed: int = 9):
     loss = projection_loss(out, weights)
     loss.backward()
     return loss.detach(), {k: p.grad for k, p in params.items() if p.grad is not None}, out.detach()
+
+
+def combined_loss(pred, targets, nc: int, hm_weight: float = 1.0, wh_weight: float = 0.1, off_weight: float = 1.0):
+    """CombinedLoss.__call__ (core/loss/centernet_loss.py:46-67) with FocalLoss (:5-26) and RegL1Loss (:29-43): pred (B, h, w, nc + 4),
+    targets = [heatmap_true (B,h,w,nc), reg_true (B,K,2), wh_true (B,K,2), reg_mask (B,K), indices (B,K)].  The "reg" term reads
+    pred[..., nc:nc+2], the "wh" term pred[..., -2:] (the model emits [heatmap | wh head | reg head]: the names are swapped in the
+    reference, kept).  Returns (total, heat-map, L1 reg, L1 wh)."""
+    heat_t, reg_t, wh_t, mask, idx = targets
+    heat = torch.clamp(torch.sigmoid(pred[..., :nc]), min=1e-4, max=1.0 - 1e-4)
+    pos, neg = torch.eq(heat_t, 1).float(), torch.lt(heat_t, 1).float()
+    num_pos = pos.sum()
+    pos_loss = (torch.log(heat) * torch.pow(1 - heat, 2) * pos).sum()
+    neg_loss = (torch.log(1 - heat) * torch.pow(heat, 2) * torch.pow(1 - heat_t, 4) * neg).sum()
+    hm = -neg_loss if float(num_pos) == 0 else -(pos_loss + neg_loss) / num_pos
+
+    def l1(feat, true):
+        f = feat.reshape(feat.shape[0], -1, feat.shape[3])
+        g = torch.gather(f, 1, idx.unsqueeze(2).long().expand(idx.shape[0], idx.shape[1], f.shape[2]))
+        m = mask.unsqueeze(2).expand_as(g).float()
+        return F.l1_loss(g * m, true * m, reduction="sum") / (m.sum() + 1e-4)
+
+    off, wh = l1(pred[..., nc:nc + 2], reg_t), l1(pred[..., -2:], wh_t)
+    return hm_weight * hm + off_weight * off + wh_weight * wh, hm, off, wh
+
+
+def synth_targets(B: int, h: int, w: int, nc: int, K: int = 30, seed: int = 3):
+    """Seeded targets in the format of CenterNet.generate_targets (core/algorithms/centernet.py:66-120): Gaussian bumps with an exact 1
+    at each centre (the later object wins the maximum), sub-pixel offsets, sizes, mask and flat indices.  NOT a restatement of the
+    reference's radius rule -- synthetic inputs for the loss kernel only."""
+    g = torch.Generator().manual_seed(seed)
+    heat = torch.zeros(B, h, w, nc)
+    reg, wh, mask, idx = torch.zeros(B, K, 2), torch.zeros(B, K, 2), torch.zeros(B, K), torch.zeros(B, K, dtype=torch.long)
+    ys, xs = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing="ij")
+    for b in range(B):
+        n = int(torch.randint(1, max(2, min(K, 8)), (1,), generator=g))
+        for k in range(n):
+            cx, cy = float(torch.rand(1, generator=g)) * (w - 1), float(torch.rand(1, generator=g)) * (h - 1)
+            bw, bh = 2 + float(torch.rand(1, generator=g)) * w / 3, 2 + float(torch.rand(1, generator=g)) * h / 3
+            c = int(torch.randint(0, nc, (1,), generator=g))
+            ix, iy = int(cx), int(cy)
+            sigma = max(1.0, min(bw, bh) / 6)
+            bump = torch.exp(-((xs - ix) ** 2 + (ys - iy) ** 2) / (2 * sigma * sigma))
+            heat[b, :, :, c] = torch.maximum(heat[b, :, :, c], bump)
+            reg[b, k] = torch.tensor([cx - ix, cy - iy])
+            wh[b, k] = torch.tensor([bw, bh])
+            mask[b, k] = 1.0
+            idx[b, k] = iy * w + ix
+    return [heat, reg, wh, mask, idx]

@@ -288,6 +288,39 @@ def ssd_train_section(builder, report):
     report["ssd_train"] = dict(loss=float(loss), worst_grad_rel_oracle_vs_reference=worst, tensors=len(keys), full=full, stats=stat_keys)
 
 
+def centernet_loss_section(builder, report):
+    """9c. CombinedLoss (core/loss/centernet_loss.py): the REAL reference loss object on random head outputs and seeded targets (two
+    cases: objects present incl. two sharing a centre; no object at all) -> loss and its gradient w.r.t. the predictions by torch
+    autograd.  Pins oracle/centernet_ref.combined_loss."""
+    from oracle import centernet_ref as C
+    ccfg, calgo_cls, _ = builder.export_from_registry("centernet")
+    calgo = calgo_cls(ccfg, torch.device("cpu"))
+    crit = calgo.build_loss()
+    assert type(crit).__name__ == "CombinedLoss"
+    nc = ccfg.dataset.num_classes
+    out = {}
+    for tag, B, h, w, K, seed, empty in (("a", 2, 24, 32, 30, 3, False), ("b", 1, 8, 8, 4, 5, True)):
+        g = torch.Generator().manual_seed(100 + seed)
+        pred = (torch.randn(B, h, w, nc + 4, generator=g) * 2).requires_grad_(True)
+        targets = C.synth_targets(B, h, w, nc, K, seed)
+        if empty:
+            targets = [torch.zeros_like(targets[0]), targets[1], targets[2], torch.zeros_like(targets[3]), targets[4]]
+        else:
+            targets[4][0, 1] = targets[4][0, 0]                  # two objects on one centre
+            targets[3][0, 1] = 1.0
+        loss = crit(pred, targets)
+        loss.backward()
+        p2 = pred.detach().clone().requires_grad_(True)
+        mine = C.combined_loss(p2, targets, nc, ccfg.loss.hm_weight, ccfg.loss.wh_weight, ccfg.loss.off_weight)
+        mine[0].backward()
+        assert abs(float(mine[0]) - float(loss)) <= 1e-6 * abs(float(loss)) and torch.allclose(p2.grad, pred.grad, rtol=1e-5, atol=1e-9)
+        out.update({f"{tag}_pred": pred.detach().numpy(), f"{tag}_heat": targets[0].numpy(), f"{tag}_reg": targets[1].numpy(), f"{tag}_wh": targets[2].numpy(),
+                    f"{tag}_mask": targets[3].numpy(), f"{tag}_idx": targets[4].numpy(), f"{tag}_loss": np.array(float(loss)),
+                    f"{tag}_grad": pred.grad.numpy()})
+    np.savez_compressed(os.path.join(GOLD, "centernet_loss.npz"), nc=np.array(nc), weights=np.array([ccfg.loss.hm_weight, ccfg.loss.wh_weight, ccfg.loss.off_weight]), **out)
+    report["centernet_loss"] = dict(loss_a=float(out["a_loss"]), loss_b=float(out["b_loss"]), nc=int(nc))
+
+
 def main():
     sys.path.insert(0, ROOT)
     from oracle import yolov8_ref as O
@@ -570,6 +603,7 @@ def main():
                                decode={t: int(dec[t + "_boxes"].shape[0]) for t in ("net", "synth")})
 
     centernet_train_section(builder, report)
+    centernet_loss_section(builder, report)
 
     # ---- 10. DeepLabv3+ ResNet-101: init, eval forward on a calibrated network ---------------------------------
     from oracle import deeplab_ref as D
@@ -788,7 +822,7 @@ def only(section):
     builder = _import_reference()
     torch.set_num_threads(8)
     report = {}
-    {"deeplab_train": deeplab_train_section, "yolov7_train": yolov7_train_section, "centernet_train": centernet_train_section, "ssd_train": ssd_train_section}[section](builder, report)
+    {"deeplab_train": deeplab_train_section, "yolov7_train": yolov7_train_section, "centernet_train": centernet_train_section, "ssd_train": ssd_train_section, "centernet_loss": centernet_loss_section}[section](builder, report)
     path = os.path.join(GOLD, "PIN_REPORT.json")
     full = json.load(open(path)) if os.path.exists(path) else {}
     full.update(report)

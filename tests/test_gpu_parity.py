@@ -2153,3 +2153,74 @@ def test_ssd_per_layer_backward_on_the_engines_own_operands(dev, gold):
     m, _, x, _, _, _ = _ssd_train_step(dev, g)
     n_w, n_bn, checked = _check_backward_per_layer(m, x.shape[0], m.last_dpred, 13, 25)
     assert n_w >= 35
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_centernet_loss_kernel_matches_the_reference_fixture(dev, gold, tag):
+    """cvx_centernet_loss against the REAL reference's CombinedLoss + torch autograd (make_golden.py section 9c): random head outputs,
+    (a) objects present, two of them on one centre; (b) no object at all (num_pos == 0 branch, empty masks).  Loss value 1e-5, the
+    gradient on the head rows to one fp16 rounding, the row padding zero."""
+    from computervision.pytorch_amd.dla import CenterNetLoss
+    g = gold("centernet_loss.npz")
+    nc = int(g["nc"])
+    hm_w, wh_w, off_w = (float(v) for v in g["weights"])
+    pred = torch.from_numpy(g[tag + "_pred"])
+    B, h, w, _ = pred.shape
+    nc_pad = (nc + 7) & ~7
+    ld = nc_pad + 16
+    rows = torch.zeros(B, h * w, ld)
+    flat = pred.reshape(B, h * w, nc + 4)
+    rows[..., :nc], rows[..., nc_pad:nc_pad + 2], rows[..., nc_pad + 8:nc_pad + 10] = flat[..., :nc], flat[..., nc:nc + 2], flat[..., nc + 2:]
+    targets = [torch.from_numpy(g[tag + "_" + k]) for k in ("heat", "reg", "wh", "mask", "idx")]
+    crit = CenterNetLoss(nc, hm_w, wh_w, off_w)
+    scale = 64.0
+    items, dpred = crit.op(rows.to(dev), targets, (h, w), scale)
+    assert abs(float(items[0]) - float(g[tag + "_loss"])) < 1e-5 * abs(float(g[tag + "_loss"])), (float(items[0]), float(g[tag + "_loss"]))
+    got = dpred.float().cpu() / scale
+    want = torch.from_numpy(g[tag + "_grad"]).reshape(B, h * w, nc + 4)
+    back = torch.cat((got[..., :nc], got[..., nc_pad:nc_pad + 2], got[..., nc_pad + 8:nc_pad + 10]), -1)
+    assert rel(back, want) < 1e-3, rel(back, want)
+    pad = torch.ones(ld, dtype=torch.bool)
+    pad[:nc] = pad[nc_pad:nc_pad + 2] = pad[nc_pad + 8:nc_pad + 10] = False
+    assert float(got[..., pad].abs().max()) == 0.0
+    bad = [t.clone() for t in targets]
+    bad[4][0, 0], bad[3][0, 0] = h * w + 5, 1.0
+    with pytest.raises(L.CvxError):
+        crit.op(rows.to(dev), bad, (h, w), scale)
+
+
+def test_centernet_trainer_fused_step(dev):
+    """export_from_registry("centernet") -> CenterNetTrainer at the config's 384 x 384, batch 4: six fused steps of the reference's
+    train_loop (centernet_train.py:104-121) on a repeated batch: losses finite and falling, parameters and BatchNorm statistics move,
+    no overflow skip; the fused path and loss.backward() on the model's output give the same gradients; evaluate_loop's metric."""
+    import builder
+    from core.trainer.centernet_train import SyntheticCenterNetLoader
+    cfg, algo_cls, trainer_cls = builder.export_from_registry("centernet")
+    cfg.train.batch_size = 4
+    torch.manual_seed(0)
+    loader = SyntheticCenterNetLoader(4, (384, 384), cfg.dataset.num_classes, length=2, seed=3)
+    tr = trainer_cls(cfg, dev, dataloader=loader)
+    assert type(tr.criterion).__name__ == "CenterNetLoss"
+    batch = next(iter(loader))
+    # (a) autograd path == fused path: loss.backward() on model(x) fills the same gradient arena
+    tr.model.train()
+    x, targets = batch[0].to(dev), [t.to(dev) for t in batch[1]]
+    loss = tr.criterion(tr.model(x), targets)
+    loss.backward()
+    g_auto = tr.model.flat_grads.clone()
+    tr.model.flat_grads.zero_()
+    tr.model.flat_stats.copy_(torch.zeros_like(tr.model.flat_stats))
+    with torch.no_grad():
+        for k, v in tr.model.state_dict().items():
+            if k.endswith("running_var"):
+                v.fill_(1.0)
+    p0 = tr.model.flat_params.clone()
+    losses = [float(tr.train_loop(batch, None)[0]) for _ in range(6)]
+    torch.cuda.synchronize()
+    assert abs(losses[0] - float(loss.detach())) < 2e-3 * abs(losses[0])          # (BatchNorm saw the same batch: same forward)
+    assert all(np.isfinite(v) for v in losses) and losses[-1] < losses[0], losses
+    assert float(g_auto.abs().max()) > 0 and not torch.equal(tr.model.flat_params, p0)
+    tr._step.scaler.poll()
+    assert tr._step.scaler.skipped == 0 and tr.optimizer.device_step() == 6 and not tr.criterion.bad_targets()
+    ev = tr.evaluate_loop()
+    assert np.isfinite(ev["val_loss"])

@@ -364,6 +364,25 @@ def test_ssd_oracle_training_forward_backward(gold):
             assert float((sd[name[2:]] - ref).norm() / ref.norm()) < 1e-4, name
 
 
+def test_centernet_oracle_combined_loss(gold):
+    """oracle/centernet_ref.combined_loss against the REAL reference's CombinedLoss and its torch-autograd gradient (make_golden.py
+    section 9c): objects present (two on one centre) and no object at all."""
+    from oracle import centernet_ref as C
+    g = gold("centernet_loss.npz")
+    nc = int(g["nc"])
+    hm_w, wh_w, off_w = (float(v) for v in g["weights"])
+    for tag in ("a", "b"):
+        pred = torch.from_numpy(g[tag + "_pred"]).requires_grad_(True)
+        targets = [torch.from_numpy(g[tag + "_" + k]) for k in ("heat", "reg", "wh", "mask", "idx")]
+        total, hm, off, wh = C.combined_loss(pred, targets, nc, hm_w, wh_w, off_w)
+        total.backward()
+        assert abs(float(total) - float(g[tag + "_loss"])) < 1e-5 * abs(float(g[tag + "_loss"]))
+        np.testing.assert_allclose(pred.grad.numpy(), g[tag + "_grad"], rtol=1e-4, atol=1e-7)
+    assert float(targets[3].sum()) == 0 and float((targets[0] == 1).sum()) == 0      # case b: the num_pos == 0 branch
+    t = C.synth_targets(2, 12, 16, nc, K=6, seed=1)
+    assert tuple(t[0].shape) == (2, 12, 16, nc) and float(t[0].max()) == 1.0 and int((t[0] == 1).sum()) >= 2 and int(t[4].max()) < 12 * 16
+
+
 def _yolov7_fixture_state(g):
     from oracle import yolov7_ref as Y
     sd = Y.init_state_dict(20, seed=0)
