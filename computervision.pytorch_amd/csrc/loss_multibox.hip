@@ -1,0 +1,257 @@
+// SSD's MultiBoxLossV2 on gfx950: softmax cross-entropy with batch-wide hard-negative mining + smooth-L1 on the positives, forward value
+// AND the gradient w.r.t. (loc, conf) in one pass chain (no autograd tape, no sort).
+//
+// Reference semantics (core/loss/multi_box_loss.py:77-192):
+//   y_pred = cat(loc, softmax(conf));  conf_loss = -sum_c y_true_c * log(clamp(p_c, 1e-7));  loc_loss = sum smooth_l1(true - pred)
+//   pos = y_true[..., -1];  num_pos per image;  num_neg = min(ratio * num_pos, A - num_pos);  k = sum(num_neg) (100 if no image has any)
+//   max_confs = sum_{c >= 1} p_c * (1 - pos), flattened over the WHOLE batch;  indices = topk(max_confs, k);  neg = conf_loss[indices]
+//   conf = (sum pos conf + sum neg) / sum(num_pos or 1);  loc = sum pos loc / sum(num_pos or 1);  total = (1 - alpha) conf + alpha loc, alpha 0.5
+//
+// The top-k is a SELECTION, not a sort: an 8-bit radix select over the order-preserving bit patterns of the non-negative keys finds the
+// k-th largest key T in four histogram passes; everything above T is taken, ties at T are taken in flat-index order (torch.topk leaves the
+// choice among equal keys unspecified).
+//
+//   K1 mb_anchor     per anchor: softmax, conf / loc loss, key; per-image positives, positive sums
+//   K2 mb_plan       one thread: k and the normaliser from the per-image counts
+//   K3 mb_hist / mb_pick (x4)  radix select of the k-th largest key
+//   K4 mb_ties       one workgroup: which of the keys equal to T are taken (index order)
+//   K5 mb_grad       per anchor: negative sum, gradients w.r.t. loc and conf (times grad_scale), loss items by the last block
+#include <algorithm>
+#include "cvx_common.h"
+#include "../../include/cvx_engine.h"
+
+namespace {
+
+struct MbState {
+  double pos_conf, pos_loc, neg_conf;
+  double norm;               // sum over images of (num_pos or 1)
+  unsigned long long k;      // negatives to take, batch-wide
+  unsigned prefix, remaining;  // radix select state: key bits fixed so far, rank still to resolve inside the prefix bucket
+  unsigned thr, take_ties;   // final threshold key and how many keys equal to it are taken
+  unsigned hist[256];
+  unsigned done_blocks;
+};
+
+__device__ __forceinline__ double wsum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void mb_anchor_kernel(const float* loc, const float* conf, const float* y_true, int B, int A, int nc1, unsigned* key,
+                                                        float* closs, int* num_pos, MbState* stt) {
+  __shared__ double sm[2][4];
+  const long long N = (long long)B * A;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int ld = 4 + nc1 + 1;
+  double pc = 0, pl = 0;
+  if (i < N) {
+    const float* yt = y_true + i * ld;
+    const float* z = conf + i * nc1;
+    float zmax = -INFINITY;
+    for (int c = 0; c < nc1; ++c) zmax = fmaxf(zmax, z[c]);
+    float se = 0.f;
+    for (int c = 0; c < nc1; ++c) se += expf(z[c] - zmax);
+    float cl = 0.f, fg = 0.f;
+    for (int c = 0; c < nc1; ++c) {
+      const float p = expf(z[c] - zmax) / se;
+      cl -= yt[4 + c] * logf(fmaxf(p, 1e-7f));
+      if (c >= 1) fg += p;
+    }
+    const float pos = yt[ld - 1];
+    float ll = 0.f;
+    for (int j = 0; j < 4; ++j) {
+      const float d = yt[j] - loc[i * 4 + j], a = fabsf(d);
+      ll += a < 1.f ? 0.5f * d * d : a - 0.5f;
+    }
+    closs[i] = cl;
+    key[i] = __float_as_uint(fg * (1.f - pos));   // >= 0: the bit pattern orders like the value
+    pc = (double)(cl * pos);
+    pl = (double)(ll * pos);
+    if (pos != 0.f) atomicAdd(&num_pos[i / A], 1);
+  }
+  pc = wsum(pc);
+  pl = wsum(pl);
+  if ((threadIdx.x & 63) == 0) {
+    sm[0][threadIdx.x >> 6] = pc;
+    sm[1][threadIdx.x >> 6] = pl;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&stt->pos_conf, (sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3]));
+    atomicAdd(&stt->pos_loc, (sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3]));
+  }
+}
+
+__global__ void mb_plan_kernel(const int* num_pos, int B, int A, float ratio, MbState* stt) {
+  double k = 0, norm = 0;
+  int any = 0;
+  for (int b = 0; b < B; ++b) {
+    const double np = (double)num_pos[b];
+    const double nn = fmin((double)ratio * np, (double)A - np);
+    if (nn > 0) any = 1;
+    k += nn;
+    norm += np != 0.0 ? np : 1.0;
+  }
+  if (!any) k = 100.0;                                   // negatives_for_hard
+  const double cap = (double)B * A;
+  stt->k = (unsigned long long)(k < cap ? k : cap);      // int(num_neg_batch)
+  stt->norm = norm;
+  stt->prefix = 0;
+  stt->remaining = (unsigned)stt->k;
+}
+
+__global__ __launch_bounds__(256) void mb_hist_kernel(const unsigned* key, long long N, int shift, MbState* stt) {
+  __shared__ unsigned h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const unsigned prefix = stt->prefix;
+  const unsigned hi_mask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
+    const unsigned kx = key[i];
+    if ((kx & hi_mask) == (prefix & hi_mask)) atomicAdd(&h[(kx >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&stt->hist[threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ void mb_pick_kernel(int shift, MbState* stt) {  // one thread: the bucket (from the top) that holds the rank still looked for
+  unsigned rem = stt->remaining;
+  int b = 255;
+  if (rem == 0) {  // k == 0: nothing is taken; a threshold above every key
+    stt->prefix = 0xFFFFFFFFu;
+  } else {
+    for (; b > 0; --b) {
+      if (stt->hist[b] >= rem) break;
+      rem -= stt->hist[b];
+    }
+    stt->prefix |= (unsigned)b << shift;
+    stt->remaining = rem;
+  }
+  for (int q = 0; q < 256; ++q) stt->hist[q] = 0;
+  if (shift == 0) {
+    stt->thr = stt->prefix;
+    stt->take_ties = stt->remaining;  // of the keys equal to thr, this many (lowest indices first) complete the k
+  }
+}
+
+__global__ __launch_bounds__(1024) void mb_ties_kernel(const unsigned* key, long long N, const MbState* stt, unsigned char* tie_sel) {
+  __shared__ unsigned s_cnt[16];
+  __shared__ unsigned s_base;
+  const unsigned thr = stt->thr, take = stt->take_ties;
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  for (long long i0 = 0; i0 < N; i0 += 1024) {
+    const long long i = i0 + threadIdx.x;
+    const bool tie = i < N && key[i] == thr;
+    const unsigned long long bal = __ballot(tie);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) s_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    unsigned before = s_base;
+    for (int q = 0; q < wave; ++q) before += s_cnt[q];
+    before += __popcll(bal & ((1ull << lane) - 1ull));
+    if (i < N) tie_sel[i] = tie && before < take ? 1 : 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned t = 0;
+      for (int q = 0; q < 16; ++q) t += s_cnt[q];
+      s_base += t;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void mb_grad_kernel(const float* loc, const float* conf, const float* y_true, int B, int A, int nc1, const unsigned* key,
+                                                      const float* closs, const unsigned char* tie_sel, MbState* stt, float alpha, float grad_scale,
+                                                      float* dloc, float* dconf, float* loss_items, unsigned nblocks) {
+  __shared__ double sm[4];
+  const long long N = (long long)B * A;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int ld = 4 + nc1 + 1;
+  const float inv = (float)((double)grad_scale / stt->norm);
+  const unsigned thr = stt->thr;
+  double neg = 0;
+  if (i < N) {
+    const float* yt = y_true + i * ld;
+    const float pos = yt[ld - 1];
+    const bool taken = stt->k > 0 && (key[i] > thr || tie_sel[i]);
+    if (taken) neg = (double)closs[i];
+    const float wc = (pos + (taken ? 1.f : 0.f)) * (1.f - alpha) * inv;   // weight of this anchor's cross-entropy term
+    const float* z = conf + i * nc1;
+    float zmax = -INFINITY;
+    for (int c = 0; c < nc1; ++c) zmax = fmaxf(zmax, z[c]);
+    float se = 0.f;
+    for (int c = 0; c < nc1; ++c) se += expf(z[c] - zmax);
+    // d/dz_j of -sum_c y_c log(clamp(p_c)) = sum_c y_c [p_c >= 1e-7] (p_j - delta_jc)
+    float ysum = 0.f;
+    for (int c = 0; c < nc1; ++c) {
+      const float p = expf(z[c] - zmax) / se;
+      if (p >= 1e-7f) ysum += yt[4 + c];
+    }
+    for (int j = 0; j < nc1; ++j) {
+      const float p = expf(z[j] - zmax) / se;
+      const float yj = p >= 1e-7f ? yt[4 + j] : 0.f;
+      dconf[i * nc1 + j] = wc != 0.f ? wc * (p * ysum - yj) : 0.f;
+    }
+    const float wl = pos * alpha * inv;
+    for (int j = 0; j < 4; ++j) {
+      const float d = loc[i * 4 + j] - yt[j];              // d smooth_l1(true - pred) / d pred
+      dloc[i * 4 + j] = wl != 0.f ? wl * (fabsf(d) < 1.f ? d : (d > 0.f ? 1.f : -1.f)) : 0.f;
+    }
+  }
+  neg = wsum(neg);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = neg;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&stt->neg_conf, (sm[0] + sm[1]) + (sm[2] + sm[3]));
+    __threadfence();
+    if (atomicAdd(&stt->done_blocks, 1u) == nblocks - 1) {  // the last workgroup to finish writes the loss items
+      __threadfence();
+      const double c = (stt->pos_conf + atomicAdd(&stt->neg_conf, 0.0)) / stt->norm, l = stt->pos_loc / stt->norm;
+      loss_items[0] = (float)(c * (1.0 - (double)alpha) + l * (double)alpha);
+      loss_items[1] = (float)l;
+      loss_items[2] = (float)c;
+    }
+  }
+}
+
+size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" int64_t cvx_multibox_loss_workspace_bytes(int32_t batch, int32_t anchors) {
+  const size_t N = (size_t)batch * anchors;
+  return (int64_t)(al256(sizeof(MbState)) + al256((size_t)batch * 4) + al256(N * 4) * 2 + al256(N));
+}
+
+extern "C" int cvx_multibox_loss(const float* loc, const float* conf, const float* y_true, int32_t batch, int32_t anchors, int32_t nc1, float neg_pos_ratio,
+                                 float alpha, float grad_scale, float* loss_items, float* dloc, float* dconf, void* workspace, void* hip_stream) {
+  CVX_CHECK(loc && conf && y_true && loss_items && dloc && dconf && workspace, "null arguments");
+  CVX_CHECK(batch > 0 && anchors > 0 && nc1 >= 2 && (long long)batch * anchors < (1LL << 31), "bad sizes");
+  hipStream_t st = (hipStream_t)hip_stream;
+  const long long N = (long long)batch * anchors;
+  char* w = (char*)workspace;
+  MbState* stt = (MbState*)w;
+  w += al256(sizeof(MbState));
+  int* num_pos = (int*)w;
+  w += al256((size_t)batch * 4);
+  unsigned* key = (unsigned*)w;
+  w += al256((size_t)N * 4);
+  float* closs = (float*)w;
+  w += al256((size_t)N * 4);
+  unsigned char* tie_sel = (unsigned char*)w;
+  CVX_HIP(hipMemsetAsync(workspace, 0, al256(sizeof(MbState)) + al256((size_t)batch * 4), st));
+  const unsigned nb = (unsigned)cvx_cdiv(N, 256);
+  hipLaunchKernelGGL(mb_anchor_kernel, dim3(nb), dim3(256), 0, st, loc, conf, y_true, batch, anchors, nc1, key, closs, num_pos, stt);
+  hipLaunchKernelGGL(mb_plan_kernel, dim3(1), dim3(1), 0, st, num_pos, batch, anchors, neg_pos_ratio, stt);
+  const int hb = (int)std::min<long long>(512, nb);
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    hipLaunchKernelGGL(mb_hist_kernel, dim3(hb), dim3(256), 0, st, key, N, shift, stt);
+    hipLaunchKernelGGL(mb_pick_kernel, dim3(1), dim3(1), 0, st, shift, stt);
+  }
+  hipLaunchKernelGGL(mb_ties_kernel, dim3(1), dim3(1024), 0, st, key, N, stt, tie_sel);
+  hipLaunchKernelGGL(mb_grad_kernel, dim3(nb), dim3(256), 0, st, loc, conf, y_true, batch, anchors, nc1, key, closs, tie_sel, stt, alpha, grad_scale, dloc,
+                     dconf, loss_items, nb);
+  CVX_HIP(hipGetLastError());
+  return 0;
+}

@@ -17,7 +17,7 @@ from __future__ import annotations
 
 import math
 from collections import OrderedDict
-from typing import Dict, List
+from typing import Dict, Optional, List
 
 import torch
 import torch.nn as nn
@@ -355,9 +355,10 @@ class SSD300VGG(nn.Module):
                     "conf")
         return loc, conf
 
-    def _backward_outputs(self, g_loc, g_conf):
+    def _backward_outputs(self, g_loc, g_conf, scale: Optional[float] = None):
         """Gradients w.r.t. the flattened (B, tot*4) / (B, tot*(nc+1)) outputs -> loss_scale * dLoss/drows in fp16 -> engine backward."""
         eng, lay, lib = self._last_engine, self.layout, L.load()
+        scale = self.loss_scale if scale is None else float(scale)
         nc1 = self.num_classes + 1
         levels, tot = self._levels()
         ref = g_loc if g_loc is not None else g_conf
@@ -368,17 +369,17 @@ class SSD300VGG(nn.Module):
         gc = None if g_conf is None else g_conf.contiguous().float()
         for a_off, hw, n, lo, co in levels:
             if gl is not None:
-                L.check(lib.cvx_nchw_cols_grad_to_pred(L.ptr(gl), tot * 4, lo, n * 4, B, eng.graph.anchors, a_off, hw, self.loss_scale, L.ptr(dpred),
+                L.check(lib.cvx_nchw_cols_grad_to_pred(L.ptr(gl), tot * 4, lo, n * 4, B, eng.graph.anchors, a_off, hw, scale, L.ptr(dpred),
                                                        lay.pred_ld, 0, st), "loc grad")
             if gc is not None:
-                L.check(lib.cvx_nchw_cols_grad_to_pred(L.ptr(gc), tot * nc1, co, n * nc1, B, eng.graph.anchors, a_off, hw, self.loss_scale,
+                L.check(lib.cvx_nchw_cols_grad_to_pred(L.ptr(gc), tot * nc1, co, n * nc1, B, eng.graph.anchors, a_off, hw, scale,
                                                        L.ptr(dpred), lay.pred_ld, LOC_COLS, st), "conf grad")
         first = next(p for p in self.parameters() if p.requires_grad)
         if first.grad is None:               # optimizer.zero_grad(set_to_none=True) happened (or first step)
             self.flat_grads.zero_()
             self._grads_attached = False
         self.last_dpred = dpred
-        eng.backward(dpred, self.loss_scale)
+        eng.backward(dpred, scale)
         if not self._grads_attached or first.grad is None:
             self.attach_grads()
 
@@ -405,3 +406,96 @@ class _SsdFn(torch.autograd.Function):
         if g_loc is not None or g_conf is not None:
             ctx.model._backward_outputs(g_loc, g_conf)
         return None, None, None
+
+
+class _MbLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, loc, conf, owner, y_true):
+        items, dloc, dconf = owner.op(loc.detach(), conf.detach(), y_true)
+        ctx.save_for_backward(dloc, dconf)
+        owner.last_items = items
+        return items[0].reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        dloc, dconf = ctx.saved_tensors
+        return dloc * gout, dconf * gout, None, None
+
+
+class MultiBoxLoss:
+    """``MultiBoxLossV2(neg_pos_ratio, num_classes)`` of the reference (core/loss/multi_box_loss.py:77-192) on the engine:
+    ``total, loc_loss, conf_loss = criterion(y_true, y_pred)`` with ``y_pred = model(images) = (loc, conf)`` and ``y_true`` (B, 8732,
+    4 + (nc + 1) + 1) as ``ssd_collate`` encodes it.  Values and the gradient w.r.t. (loc, conf) come from ``cvx_multibox_loss``
+    (radix-select hard-negative mining, no sort); ``total.backward()`` hands them to the engine's backward pass."""
+
+    def __init__(self, neg_pos_ratio: float, num_classes: int, alpha: float = 0.5):
+        self.neg_pos_ratio, self.nc1, self.alpha = float(neg_pos_ratio), int(num_classes) + 1, float(alpha)
+        self._ws = None
+        self.last_items = None
+
+    def op(self, loc: torch.Tensor, conf: torch.Tensor, y_true: torch.Tensor, grad_scale: float = 1.0):
+        """-> (items (3,): total, loc, conf; dloc, dconf = grad_scale * gradients, fp32)"""
+        if loc.device.type != "cuda":
+            raise L.CvxError("MultiBoxLoss runs on an MI355X only (there is no CPU path)")
+        lib = L.load()
+        B, A = int(loc.shape[0]), int(loc.shape[1])
+        if tuple(conf.shape) != (B, A, self.nc1) or tuple(y_true.shape) != (B, A, 4 + self.nc1 + 1):
+            raise ValueError(f"expected conf {(B, A, self.nc1)} and y_true {(B, A, 4 + self.nc1 + 1)}")
+        loc, conf = loc.contiguous().float(), conf.contiguous().float()
+        y_true = y_true.to(loc.device).contiguous().float()
+        need = int(lib.cvx_multibox_loss_workspace_bytes(B, A))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != loc.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=loc.device)
+        items, dloc, dconf = torch.empty(3, device=loc.device), torch.empty_like(loc), torch.empty_like(conf)
+        L.check(lib.cvx_multibox_loss(L.ptr(loc), L.ptr(conf), L.ptr(y_true), B, A, self.nc1, self.neg_pos_ratio, self.alpha, float(grad_scale),
+                                      L.ptr(items), L.ptr(dloc), L.ptr(dconf), L.ptr(self._ws), L.stream_ptr(loc.device)), "cvx_multibox_loss")
+        return items, dloc, dconf
+
+    def __call__(self, y_true, y_pred):
+        loc, conf = y_pred
+        if torch.is_grad_enabled() and (loc.requires_grad or conf.requires_grad):
+            total = _MbLossFn.apply(loc, conf, self, y_true)
+            return total, self.last_items[1], self.last_items[2]
+        items = self.op(loc, conf, y_true)[0]
+        return items[0], items[1], items[2]
+
+
+class SsdTrainStep:
+    """One optimisation step of the reference's ``SsdTrainer.train_loop`` (core/trainer/ssd_train.py: zero_grad -> forward ->
+    MultiBoxLossV2 -> backward -> Adam under AMP) as C-ABI calls: engine forward (training), the NCHW-order flattening, ``cvx_multibox_loss``,
+    its adjoint onto the prediction rows, engine backward, [gradient sum over the ranks], fused Adam with GradScaler's inf/nan check."""
+
+    def __init__(self, model: SSD300VGG, criterion: MultiBoxLoss, optimizer, scaler=None, process_group=None, n_buckets: int = 4):
+        self.model, self.criterion, self.optimizer, self.scaler = model, criterion, optimizer, scaler
+        self.pg, self.n_buckets = process_group, n_buckets
+        self.world, self.distributed = 1, False
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+            self.distributed = True
+        self._side = None
+
+    def __call__(self, images: torch.Tensor, y_true: torch.Tensor) -> torch.Tensor:
+        from .engine import check_finite
+        from .train import allreduce_mean_flat
+        m, crit = self.model, self.criterion
+        if not m.training:
+            raise L.CvxError("SsdTrainStep: call model.train() first")
+        dev = m.flat_params.device
+        self.optimizer.sync_lr()
+        B, nc1 = int(images.shape[0]), m.num_classes + 1
+        m.last_rows = m._run_forward(images, True)
+        loc, conf = m._rows_to_outputs(m.last_rows)
+        scale = self.scaler.begin_step() if self.scaler is not None else m.loss_scale
+        items, dloc, dconf = crit.op(loc.view(B, -1, 4), conf.view(B, -1, nc1), y_true)
+        m._backward_outputs(dloc.view(B, -1), dconf.view(B, -1), scale)
+        if self.distributed and dev.type == "cuda":
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev, priority=-1)
+            allreduce_mean_flat(m.flat_grads, self.world, self.pg, self.n_buckets, self._side, average=False)
+        if self.scaler is not None:
+            check_finite(m.flat_grads, self.scaler.found_inf)
+            self.optimizer.found_inf = self.scaler.found_inf
+        self.optimizer.step(zero_grad=True, grad_scale=1.0 / self.world)
+        if self.scaler is not None:
+            self.scaler.end_step()
+        return items

@@ -8,7 +8,7 @@ import torch
 
 from computervision.pytorch_amd import _lib as L
 from computervision.pytorch_amd import engine as _engine
-from computervision.pytorch_amd.ssd import SSD300VGG
+from computervision.pytorch_amd.ssd import MultiBoxLoss, SSD300VGG
 from configs import SsdConfig
 from registry import model_registry
 
@@ -68,11 +68,10 @@ class Ssd:
         return SSD300VGG(self.num_classes), f"SSD{self.input_image_size[0]}_vgg"
 
     def build_loss(self):
-        raise L.CvxError("MultiBoxLossV2 (core/loss/multi_box_loss.py) and the CPU target encoding have no HIP kernels yet.  The network itself trains on the "
-                         "engine: model.train(); loc, conf = model(x) are ordinary tensors connected to the engine's backward pass, so the "
-                         "reference's own MultiBoxLossV2 module (plain torch code on these outputs) can be applied to them unchanged")
+        """Reference :62-66: MultiBoxLossV2(neg_pos_ratio=cfg.loss.neg_pos, num_classes) -- here the engine's fused MultiBoxLoss
+        (``cvx_multibox_loss``: values and gradient w.r.t. (loc, conf), radix-select hard-negative mining)."""
+        return MultiBoxLoss(self.cfg.loss.neg_pos, self.num_classes)
 
-    # ---- decode ---------------------------------------------------------------------------------------
     def decode_device(self, preds, conf_threshold=None):
         """(loc, conf) on the device -> per image ((n, 6) tensor [x1, y1, x2, y2, label, conf], (n, 2) kept (prior, class column)):
         classes ascending, scores descending inside a class, like the reference's loop (reference :246-274)."""

@@ -379,6 +379,17 @@ int cvx_centernet_loss(const float* rows_f32, int32_t ld, int32_t batch, int32_t
                        const float* heat_true, const float* true_a, const float* true_b, const float* mask, const int64_t* indices,
                        int32_t max_objects, float hm_weight, float a_weight, float b_weight, float loss_scale, float* loss_items, void* dpred_f16,
                        int32_t* bad_index, void* workspace, void* hip_stream);
+/* SSD's MultiBoxLossV2 with its gradient.  loc (batch, anchors, 4) and conf (batch, anchors, nc1 = num_classes + 1) fp32 as the model
+ * returns them; y_true (batch, anchors, 4 + nc1 + 1) fp32 as ssd_collate encodes it: box targets, one-hot class incl. background, positive
+ * flag.  Softmax cross-entropy (probabilities clamped at 1e-7) on the positives and on the k hardest negatives of the WHOLE batch
+ * (k = sum over images of min(ratio * num_pos, anchors - num_pos), 100 when no image has a positive; hardness = sum of the non-background
+ * probabilities), smooth-L1 on the positives, total = (1 - alpha) * conf + alpha * loc with both sums divided by sum(num_pos or 1).  The
+ * top-k is a radix SELECT (no sort); keys equal to the k-th are taken in flat-index order (torch.topk leaves that choice open).
+ * loss_items: 3 floats (device): total, loc, conf.  dloc / dconf: grad_scale * dLoss/d(loc, conf), fp32, same shapes.  Asynchronous.
+ * Replaces: MultiBoxLossV2.__call__ + loss.backward() down to the model outputs, core/loss/multi_box_loss.py:77-192. */
+int64_t cvx_multibox_loss_workspace_bytes(int32_t batch, int32_t anchors);
+int cvx_multibox_loss(const float* loc, const float* conf, const float* y_true, int32_t batch, int32_t anchors, int32_t nc1, float neg_pos_ratio,
+                      float alpha, float grad_scale, float* loss_items, float* dloc, float* dconf, void* workspace, void* hip_stream);
 /* Adjoint of cvx_resize_bilinear_rows_to_nchw: a gradient w.r.t. the full-resolution logits (batch, nc, oh, ow) fp32 -> scale * the
  * gradient w.r.t. the rows (batch, ih*iw, ld) fp16 (a deterministic gather).  For callers that compute their own loss on the
  * model's NCHW output.  Asynchronous on hip_stream. */

@@ -321,6 +321,36 @@ def centernet_loss_section(builder, report):
     report["centernet_loss"] = dict(loss_a=float(out["a_loss"]), loss_b=float(out["b_loss"]), nc=int(nc))
 
 
+def ssd_loss_section(builder, report):
+    """12c. MultiBoxLossV2 (core/loss/multi_box_loss.py): the REAL reference loss object on random (loc, conf) and seeded encoded targets
+    (case a: positives in every image; case b: no positive anywhere -> the 100-negatives branch) -> the three loss values and the
+    gradient w.r.t. (loc, conf) by torch autograd.  Pins oracle/ssd_ref.multibox_loss."""
+    from oracle import ssd_ref as S
+    scfg, salgo_cls, _ = builder.export_from_registry("ssd")
+    crit = salgo_cls(scfg, torch.device("cpu")).build_loss()
+    assert type(crit).__name__ == "MultiBoxLossV2"
+    nc = scfg.dataset.num_classes
+    out = {}
+    for tag, B, A, seed, empty in (("a", 3, 1200, 5, False), ("b", 2, 400, 6, True)):
+        g = torch.Generator().manual_seed(200 + seed)
+        loc = torch.randn(B, A, 4, generator=g).requires_grad_(True)
+        conf = (torch.randn(B, A, nc + 1, generator=g) * 2).requires_grad_(True)
+        y = S.synth_y_true(B, A, nc, 12, seed)
+        if empty:
+            y[:, :, :4], y[:, :, 4], y[:, :, 5:-1], y[:, :, -1] = 0.0, 1.0, 0.0, 0.0
+        total, l_loss, c_loss = crit(y_true=y, y_pred=(loc, conf))
+        total.backward()
+        l2, c2 = loc.detach().clone().requires_grad_(True), conf.detach().clone().requires_grad_(True)
+        mine = S.multibox_loss(y, l2, c2, scfg.loss.neg_pos, 0.5)
+        mine[0].backward()
+        assert abs(float(mine[0]) - float(total)) <= 1e-6 * abs(float(total)), (float(mine[0]), float(total))
+        assert torch.allclose(l2.grad, loc.grad, rtol=1e-5, atol=1e-9) and torch.allclose(c2.grad, conf.grad, rtol=1e-5, atol=1e-9)
+        out.update({f"{tag}_loc": loc.detach().numpy(), f"{tag}_conf": conf.detach().numpy(), f"{tag}_y": y.numpy(),
+                    f"{tag}_items": np.array([float(total), float(l_loss), float(c_loss)]), f"{tag}_dloc": loc.grad.numpy(), f"{tag}_dconf": conf.grad.numpy()})
+    np.savez_compressed(os.path.join(GOLD, "ssd_loss.npz"), nc=np.array(nc), neg_pos=np.array(float(scfg.loss.neg_pos)), **out)
+    report["ssd_loss"] = dict(items_a=[float(v) for v in out["a_items"]], items_b=[float(v) for v in out["b_items"]], nc=int(nc))
+
+
 def main():
     sys.path.insert(0, ROOT)
     from oracle import yolov8_ref as O
@@ -809,6 +839,7 @@ def main():
     report["nms"] = "kept %d / %d" % (len(res[0][1]), len(res[1][1]))
 
     ssd_train_section(builder, report)
+    ssd_loss_section(builder, report)
     with open(os.path.join(GOLD, "PIN_REPORT.json"), "w") as f:
         json.dump(report, f, indent=1)
     print(json.dumps(report, indent=1))
@@ -822,7 +853,7 @@ def only(section):
     builder = _import_reference()
     torch.set_num_threads(8)
     report = {}
-    {"deeplab_train": deeplab_train_section, "yolov7_train": yolov7_train_section, "centernet_train": centernet_train_section, "ssd_train": ssd_train_section, "centernet_loss": centernet_loss_section}[section](builder, report)
+    {"deeplab_train": deeplab_train_section, "yolov7_train": yolov7_train_section, "centernet_train": centernet_train_section, "ssd_train": ssd_train_section, "centernet_loss": centernet_loss_section, "ssd_loss": ssd_loss_section}[section](builder, report)
     path = os.path.join(GOLD, "PIN_REPORT.json")
     full = json.load(open(path)) if os.path.exists(path) else {}
     full.update(report)

@@ -233,3 +233,42 @@ def loss_and_grads(sd, x, nc: int = 20, weights=None, seed: int = 9):
     loss = projection_loss(outs, weights)
     loss.backward()
     return loss.detach(), {k: p.grad for k, p in params.items() if p.grad is not None}, [o.detach() for o in outs]
+
+
+def multibox_loss(y_true, loc, conf, neg_pos_ratio: float = 3.0, alpha: float = 0.5):
+    """MultiBoxLossV2.__call__ (core/loss/multi_box_loss.py:117-192): y_true (B, A, 4 + nc1 + 1), loc (B, A, 4), conf (B, A, nc1) logits ->
+    (total, loc_loss, conf_loss).  Hard negatives: the k anchors of the WHOLE batch with the largest non-background probability mass
+    among the non-positives, k = sum_b min(ratio * num_pos_b, A - num_pos_b) (100 when that is 0 for every image)."""
+    A = y_true.shape[1]
+    nc1 = conf.shape[-1]
+    p = torch.softmax(conf, -1)
+    conf_loss = -(y_true[:, :, 4:-1] * torch.log(torch.clamp(p, min=1e-7))).sum(-1)
+    d = y_true[:, :, :4] - loc
+    loc_loss = torch.where(d.abs() < 1.0, 0.5 * d * d, d.abs() - 0.5).sum(-1)
+    pos = y_true[:, :, -1]
+    num_pos = pos.sum(-1)
+    num_neg = torch.minimum(neg_pos_ratio * num_pos, A - num_pos)
+    k = int(num_neg.sum()) if int((num_neg > 0).sum()) > 0 else 100
+    hard = (p[:, :, 1:nc1].sum(2) * (1 - pos)).reshape(-1)
+    _, idx = torch.topk(hard, k=k)
+    neg = conf_loss.reshape(-1)[idx]
+    norm = torch.where(num_pos != 0, num_pos, torch.ones_like(num_pos)).sum()
+    c = ((conf_loss * pos).sum() + neg.sum()) / norm
+    l = (loc_loss * pos).sum() / norm
+    return c * (1 - alpha) + l * alpha, l, c
+
+
+def synth_y_true(B: int, A: int, nc: int, n_pos: int = 12, seed: int = 5):
+    """Seeded encoded targets in the format of Ssd.generate_targets (core/algorithms/ssd.py:327-480): box regression targets, one-hot
+    class incl. the background column, positive flag -- synthetic inputs for the loss kernel (not the reference's prior matching)."""
+    g = torch.Generator().manual_seed(seed)
+    y = torch.zeros(B, A, 4 + nc + 1 + 1)
+    y[:, :, 4] = 1.0                                              # background
+    for b in range(B):
+        k = int(torch.randint(0 if b else 1, n_pos + 1, (1,), generator=g))
+        idx = torch.randperm(A, generator=g)[:k]
+        y[b, idx, :4] = torch.randn(k, 4, generator=g) * 1.5
+        y[b, idx, 4] = 0.0
+        y[b, idx, 5 + torch.randint(0, nc, (k,), generator=g)] = 1.0
+        y[b, idx, -1] = 1.0
+    return y

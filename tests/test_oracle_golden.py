@@ -383,6 +383,25 @@ def test_centernet_oracle_combined_loss(gold):
     assert tuple(t[0].shape) == (2, 12, 16, nc) and float(t[0].max()) == 1.0 and int((t[0] == 1).sum()) >= 2 and int(t[4].max()) < 12 * 16
 
 
+def test_ssd_oracle_multibox_loss(gold):
+    """oracle/ssd_ref.multibox_loss against the REAL reference's MultiBoxLossV2 and its torch-autograd gradients (make_golden.py section
+    12c): positives present (batch-wide top-k of 3 x positives) and no positive anywhere (100 negatives)."""
+    from oracle import ssd_ref as S
+    g = gold("ssd_loss.npz")
+    for tag in ("a", "b"):
+        loc = torch.from_numpy(g[tag + "_loc"]).requires_grad_(True)
+        conf = torch.from_numpy(g[tag + "_conf"]).requires_grad_(True)
+        y = torch.from_numpy(g[tag + "_y"])
+        total, l_loss, c_loss = S.multibox_loss(y, loc, conf, float(g["neg_pos"]))
+        total.backward()
+        np.testing.assert_allclose([float(total), float(l_loss), float(c_loss)], g[tag + "_items"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(loc.grad.numpy(), g[tag + "_dloc"], rtol=1e-4, atol=1e-8)
+        np.testing.assert_allclose(conf.grad.numpy(), g[tag + "_dconf"], rtol=1e-4, atol=1e-8)
+    assert float(y[..., -1].sum()) == 0 and float(g["b_items"][1]) == 0.0               # case b: no positives, loc loss 0
+    yt = S.synth_y_true(2, 50, 20, 5, seed=1)
+    assert tuple(yt.shape) == (2, 50, 26) and torch.all(yt[..., 4:-1].sum(-1) == 1) and float(yt[0, :, -1].sum()) >= 1
+
+
 def _yolov7_fixture_state(g):
     from oracle import yolov7_ref as Y
     sd = Y.init_state_dict(20, seed=0)
