@@ -38,7 +38,7 @@ typedef struct {
 } cvx_view;
 
 enum { CVX_OP_CONV = 1, CVX_OP_MAXPOOL5 = 2, CVX_OP_UPSAMPLE2 = 3,
-       /* inference-only ops (DLA-34 / CenterNet, core/models/centernet_model.py): */
+       /* DLA-34 / CenterNet ops (core/models/centernet_model.py), forward and backward: */
        CVX_OP_MAXPOOL2 = 4, /* 2x2 stride-2 max pool (Tree.downsample, :128-129) */
        CVX_OP_DWCONVT = 5,  /* depthwise ConvTranspose2d, kernel 2*stride, padding stride/2 (IDAUp.up_i, :256); w_off -> fp32 [C][2f][2f] */
        CVX_OP_COPY = 6,     /* channel-slice copy (a tensor that lives in two concat buffers) */
@@ -46,7 +46,7 @@ enum { CVX_OP_CONV = 1, CVX_OP_MAXPOOL5 = 2, CVX_OP_UPSAMPLE2 = 3,
        CVX_OP_MAXPOOL3S2 = 7, /* 3x3 stride-2 pad-1 max pool (resnet.py:163) */
        CVX_OP_AVGPOOL = 8,    /* global average pool -> (B, 1, 1, C) (ASPPPooling, deeplabv3plus.py:30) */
        CVX_OP_RESIZE = 9,     /* bilinear resize (ih, iw) -> (oh, ow), align_corners = False (deeplabv3plus.py:38,117-122) */
-       /* inference-only ops (SSD / VGG, core/models/ssd_model.py): */
+       /* SSD / VGG ops (core/models/ssd_model.py), forward and backward: */
        CVX_OP_MAXPOOL3S1 = 10, /* 3x3 stride-1 pad-1 max pool (VGG pool5, :30) */
        CVX_OP_L2NORM = 11,     /* x / (||x||_2 over channels + 1e-10) * weight[c] (L2Normalize, :113-128); gamma_off -> weight (C floats) */
        CVX_OP_DROPOUT = 12 };  /* nn.Dropout (deeplabv3plus.py:67): k = drop probability in units of 2^-16; identity in eval mode.
@@ -56,7 +56,7 @@ enum { CVX_OP_CONV = 1, CVX_OP_MAXPOOL5 = 2, CVX_OP_UPSAMPLE2 = 3,
 enum { CVX_ACT_BN_SILU = 1, CVX_ACT_BIAS = 2,
        CVX_ACT_BN_RELU = 3,   /* Conv + BN + ReLU (trainable: batch statistics, backward) */
        CVX_ACT_BN_LINEAR = 4, /* Conv + BN (Tree.project, ResNet downsample; trainable) */
-       /* inference-only epilogues: */
+       /* epilogues without BatchNorm (trainable: dy = g * [out > 0] / g, bias gradient = column sums): */
        CVX_ACT_BIAS_RELU = 5,   /* Conv + bias + ReLU, fp16 output (head 3x3, :314-318) */
        CVX_ACT_BIAS_LINEAR = 6 }; /* Conv + bias, fp16 output, no activation (SSD ExtraLayer, ssd_model.py:90-110) */
 #define CVX_OPF_RES_PRE_ACT 1 /* cvx_op_desc.flags: the residual is added before the activation (BasicBlock, :20-27) */
@@ -81,9 +81,9 @@ typedef struct {
 
 typedef struct cvx_engine cvx_engine;
 
-/* A graph that contains an inference-only op or epilogue (CVX_OP_MAXPOOL2, _DWCONVT, _COPY, _L2NORM; CVX_ACT_BIAS_RELU, _BIAS_LINEAR,
- * CVX_OPF_CONV_BIAS; SiLU with a pre-activation residual, ReLU with a post-activation one), or none of whose convolutions asks for
- * a data gradient, can only run cvx_engine_forward(training = 0).  The op that reads `image_buf` may be the YOLO stem (below) or any
+/* Every op kind and epilogue has a backward pass except: ReLU with a POST-activation residual, and CVX_ACT_BIAS_RELU / _BIAS_LINEAR with a
+ * residual.  A graph that contains one of those, or none of whose convolutions asks for a data gradient, can only run
+ * cvx_engine_forward(training = 0).  The op that reads `image_buf` may be the YOLO stem (below) or any
  * convolution with 3 stored input channels and needs_dgrad = 0 (the image is converted to NHWC fp16, 8 channels; its weight gradient
  * reads that copy).
  *
