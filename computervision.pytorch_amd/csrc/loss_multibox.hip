@@ -255,3 +255,121 @@ extern "C" int cvx_multibox_loss(const float* loc, const float* conf, const floa
   CVX_HIP(hipGetLastError());
   return 0;
 }
+
+// ---- SSD target encoding (Ssd.generate_targets + _encode_box, core/algorithms/ssd.py:327-480): the CPU work of ssd_collate -------------
+// Per ground-truth box: IoU with every prior (float64 on float32-valued operands, as the reference's numpy code ends up doing); priors above the overlap
+// threshold are "assigned" -- or the single best prior when none is.  Per prior: among the ground truths it is assigned to, the one with the
+// largest IoU (first on ties, numpy argmax) -- positive iff that IoU > 0; its box encoded against the prior in float64, the row cast to
+// float32.
+namespace {
+
+__device__ __forceinline__ double prior_iou(const float* a, double bx0, double by0, double bx1, double by1) {
+  const double w = fmax(fmin((double)a[2], bx1) - fmax((double)a[0], bx0), 0.0), h = fmax(fmin((double)a[3], by1) - fmax((double)a[1], by0), 0.0);
+  const double inter = w * h;
+  const double area_true = (bx1 - bx0) * (by1 - by0), area_gt = (double)((a[2] - a[0]) * (a[3] - a[1]));  // float32 product of the float32 anchors (:423)
+  return inter / (area_true + area_gt - inter);
+}
+// (cx, cy, w, h) -> corners in float32 (xywh_to_xyxy on the float32 label), then float64: the reference carries the corners in a float64
+// array next to the one-hot labels (ssd.py:343), so IoU and encoding run in float64 on float32-valued operands
+__device__ __forceinline__ void label_box(const float* l, double* x0, double* y0, double* x1, double* y1) {
+  *x0 = (double)(l[1] - l[3] / 2);
+  *y0 = (double)(l[2] - l[4] / 2);
+  *x1 = (double)(l[1] + l[3] / 2);
+  *y1 = (double)(l[2] + l[4] / 2);
+}
+
+// one workgroup per (image, ground truth): is any prior above the threshold?  else the first prior of maximal IoU is forced
+__global__ __launch_bounds__(256) void ssd_force_kernel(const float* labels, const int* counts, int nmax, const float* priors, int A, float thr, int* force) {
+  __shared__ double s_v[256];
+  __shared__ int s_i[256], s_any;
+  const int b = blockIdx.x / nmax, n = blockIdx.x - b * nmax;
+  if (threadIdx.x == 0) s_any = 0;
+  __syncthreads();
+  if (n >= counts[b]) {
+    if (threadIdx.x == 0) force[blockIdx.x] = -1;
+    return;
+  }
+  double x0, y0, x1, y1;
+  label_box(labels + ((long long)b * nmax + n) * 5, &x0, &y0, &x1, &y1);
+  double best = -INFINITY;
+  int bi = 0x7fffffff, any = 0;
+  for (int a = threadIdx.x; a < A; a += 256) {
+    const double iou = prior_iou(priors + (long long)a * 4, x0, y0, x1, y1);
+    if (iou > (double)thr) any = 1;
+    if (iou > best) {          // strict: the first index of the maximum inside this thread's stride
+      best = iou;
+      bi = a;
+    }
+  }
+  if (any) s_any = 1;
+  s_v[threadIdx.x] = best;
+  s_i[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      const double v = s_v[threadIdx.x + s];
+      const int i = s_i[threadIdx.x + s];
+      if (v > s_v[threadIdx.x] || (v == s_v[threadIdx.x] && i < s_i[threadIdx.x])) {
+        s_v[threadIdx.x] = v;
+        s_i[threadIdx.x] = i;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) force[blockIdx.x] = s_any ? -1 : s_i[0];
+}
+
+__global__ __launch_bounds__(256) void ssd_encode_kernel(const float* labels, const int* counts, int nmax, const float* priors, int A, int nc1, float thr,
+                                                         float var_xy, float var_wh, const int* force, int B, float* y_true) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)B * A) return;
+  const int b = (int)(i / A), a = (int)(i - (long long)b * A);
+  const float* pr = priors + (long long)a * 4;
+  double best = 0.0;
+  int bn = -1;
+  const int cnt = counts[b];
+  for (int n = 0; n < cnt; ++n) {
+    double x0, y0, x1, y1;
+    label_box(labels + ((long long)b * nmax + n) * 5, &x0, &y0, &x1, &y1);
+    const double iou = prior_iou(pr, x0, y0, x1, y1);
+    const double stored = (iou > (double)thr || force[b * nmax + n] == a) ? iou : 0.0;
+    if (bn < 0 ? stored > 0.0 : stored > best) {   // numpy argmax over the ground truths: the first maximum; positive only when > 0
+      best = stored;
+      bn = n;
+    }
+  }
+  const int ld = 4 + nc1 + 1;
+  float* row = y_true + i * ld;
+  for (int c = 0; c < ld; ++c) row[c] = 0.f;
+  if (bn < 0) {
+    row[4] = 1.f;  // background
+    return;
+  }
+  const float* l = labels + ((long long)b * nmax + bn) * 5;
+  double x0, y0, x1, y1;
+  label_box(l, &x0, &y0, &x1, &y1);
+  const double bcx = 0.5 * (x0 + x1), bcy = 0.5 * (y0 + y1), bw = x1 - x0, bh = y1 - y0;
+  // the prior's centre and size are float32 operations on the float32 anchors (assigned_anchors, :455-458), promoted afterwards
+  const double acx = (double)((pr[0] + pr[2]) * 0.5f), acy = (double)((pr[1] + pr[3]) * 0.5f), aw = (double)(pr[2] - pr[0]), ah = (double)(pr[3] - pr[1]);
+  row[0] = (float)((bcx - acx) / aw / (double)var_xy);
+  row[1] = (float)((bcy - acy) / ah / (double)var_xy);
+  row[2] = (float)(log(bw / aw) / (double)var_wh);
+  row[3] = (float)(log(bh / ah) / (double)var_wh);
+  const int cls = (int)l[0] + 1;  // label[:, 1] += 1: column 0 of the one-hot is the background
+  if (cls >= 0 && cls < nc1) row[4 + cls] = 1.f;
+  row[ld - 1] = 1.f;
+}
+
+}  // namespace
+
+extern "C" int cvx_ssd_encode_targets(const float* labels, const int32_t* counts, int32_t batch, int32_t max_boxes, const float* priors, int32_t anchors,
+                                      int32_t nc1, float overlap_threshold, float variance_xy, float variance_wh, float* y_true, int32_t* workspace,
+                                      void* hip_stream) {
+  CVX_CHECK(labels && counts && priors && y_true && workspace && batch > 0 && max_boxes > 0 && anchors > 0 && nc1 >= 2, "bad arguments");
+  hipStream_t st = (hipStream_t)hip_stream;
+  hipLaunchKernelGGL(ssd_force_kernel, dim3(batch * max_boxes), dim3(256), 0, st, labels, counts, max_boxes, priors, anchors, overlap_threshold, workspace);
+  hipLaunchKernelGGL(ssd_encode_kernel, dim3((unsigned)cvx_cdiv((long long)batch * anchors, 256)), dim3(256), 0, st, labels, counts, max_boxes, priors,
+                     anchors, nc1, overlap_threshold, variance_xy, variance_wh, workspace, batch, y_true);
+  CVX_HIP(hipGetLastError());
+  return 0;
+}

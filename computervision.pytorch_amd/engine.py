@@ -342,3 +342,24 @@ def letterbox_u8(image_u8: torch.Tensor, out_chw: torch.Tensor, letterbox: bool 
                                          L.ptr(out_chw), int(out_chw.shape[1]), int(out_chw.shape[2]), L.stream_ptr(image_u8.device)),
             "cvx_letterbox_u8_to_nchw")
     return out_chw
+
+
+def ssd_encode_targets(labels: torch.Tensor, counts: torch.Tensor, priors: torch.Tensor, num_classes: int, overlap_threshold: float = 0.5,
+                       variances=(0.1, 0.2)) -> torch.Tensor:
+    """labels (B, Nmax, 5) fp32 [class id, cx, cy, w, h], counts (B) int32, priors (A, 4) fp32 -> y_true (B, A, 4 + (nc + 1) + 1) fp32: the
+    reference's Ssd.generate_targets for a whole batch in two launches (core/algorithms/ssd.py:327-480)."""
+    _need_gpu(labels, "labels")
+    lib = L.load()
+    B, nmax = int(labels.shape[0]), int(labels.shape[1])
+    A, nc1 = int(priors.shape[0]), int(num_classes) + 1
+    labels, priors = labels.contiguous().float(), priors.to(labels.device).contiguous().float()
+    counts = counts.to(labels.device).to(torch.int32).contiguous()
+    y = torch.empty(B, A, 4 + nc1 + 1, device=labels.device)
+    if nmax == 0:
+        y.zero_()
+        y[:, :, 4] = 1.0
+        return y
+    ws = torch.empty(B * nmax, dtype=torch.int32, device=labels.device)
+    L.check(lib.cvx_ssd_encode_targets(L.ptr(labels), L.ptr(counts), B, nmax, L.ptr(priors), A, nc1, float(overlap_threshold), float(variances[0]),
+                                       float(variances[1]), L.ptr(y), L.ptr(ws), L.stream_ptr(labels.device)), "cvx_ssd_encode_targets")
+    return y

@@ -72,6 +72,28 @@ class Ssd:
         (``cvx_multibox_loss``: values and gradient w.r.t. (loc, conf), radix-select hard-negative mining)."""
         return MultiBoxLoss(self.cfg.loss.neg_pos, self.num_classes)
 
+    def generate_targets(self, label):
+        """Reference :327-388 for one image: label (N, 6) [_, class id, cx, cy, w, h] (numpy or tensor) -> (8732, 4 + (nc + 1) + 1) tensor on
+        the device, by the batch kernel below."""
+        lab = torch.as_tensor(np.asarray(label, dtype=np.float32) if not torch.is_tensor(label) else label).float()
+        return self.encode_targets([lab])[0]
+
+    def encode_targets(self, labels):
+        """What ssd_collate does image by image on the CPU (core/data/collate.py:32-49), for the batch in two launches: a list of (N_i, 6)
+        label arrays -> y_true (B, 8732, 4 + (nc + 1) + 1) on the device (``cvx_ssd_encode_targets``)."""
+        dev = torch.device(self.device)
+        nmax = max([int(l.shape[0]) for l in labels] + [1])
+        packed = torch.zeros(len(labels), nmax, 5)
+        for i, l in enumerate(labels):
+            l = torch.as_tensor(l).float()
+            if l.shape[0]:
+                packed[i, :l.shape[0]] = l[:, 1:6]
+        counts = torch.tensor([int(l.shape[0]) for l in labels], dtype=torch.int32)
+        if self._priors_dev is None or self._priors_dev.device != dev:
+            self._priors_dev = torch.from_numpy(self.anchors).to(dev)
+        return _engine.ssd_encode_targets(packed.to(dev), counts.to(dev), self._priors_dev, self.num_classes, self.overlap_threshold,
+                                          self.variance[::2].tolist())
+
     def decode_device(self, preds, conf_threshold=None):
         """(loc, conf) on the device -> per image ((n, 6) tensor [x1, y1, x2, y2, label, conf], (n, 2) kept (prior, class column)):
         classes ascending, scores descending inside a class, like the reference's loop (reference :246-274)."""

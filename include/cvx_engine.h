@@ -390,6 +390,13 @@ int cvx_centernet_loss(const float* rows_f32, int32_t ld, int32_t batch, int32_t
 int64_t cvx_multibox_loss_workspace_bytes(int32_t batch, int32_t anchors);
 int cvx_multibox_loss(const float* loc, const float* conf, const float* y_true, int32_t batch, int32_t anchors, int32_t nc1, float neg_pos_ratio,
                       float alpha, float grad_scale, float* loss_items, float* dloc, float* dconf, void* workspace, void* hip_stream);
+/* SSD target encoding on the device: what ssd_collate does per image on the CPU.  labels: (batch, max_boxes, 5) fp32 rows
+ * [class id (0-based), cx, cy, w, h] (normalised), counts (batch) valid rows per image; priors (anchors, 4) fp32 corner boxes
+ * (Ssd._get_ssd_anchors).  y_true: (batch, anchors, 4 + nc1 + 1) fp32: encoded box | one-hot class incl. the background column 0 | positive
+ * flag -- the input of cvx_multibox_loss.  workspace: batch * max_boxes int32.  Asynchronous on hip_stream.
+ * Replaces: Ssd.generate_targets + _encode_box, core/algorithms/ssd.py:327-480 (called from core/data/collate.py:32-49). */
+int cvx_ssd_encode_targets(const float* labels, const int32_t* counts, int32_t batch, int32_t max_boxes, const float* priors, int32_t anchors, int32_t nc1,
+                           float overlap_threshold, float variance_xy, float variance_wh, float* y_true, int32_t* workspace, void* hip_stream);
 /* Adjoint of cvx_resize_bilinear_rows_to_nchw: a gradient w.r.t. the full-resolution logits (batch, nc, oh, ow) fp32 -> scale * the
  * gradient w.r.t. the rows (batch, ih*iw, ld) fp16 (a deterministic gather).  For callers that compute their own loss on the
  * model's NCHW output.  Asynchronous on hip_stream. */

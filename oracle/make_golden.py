@@ -351,6 +351,42 @@ def ssd_loss_section(builder, report):
     report["ssd_loss"] = dict(items_a=[float(v) for v in out["a_items"]], items_b=[float(v) for v in out["b_items"]], nc=int(nc))
 
 
+def ssd_targets_section(builder, report):
+    """12d. Ssd.generate_targets (core/algorithms/ssd.py:327-480): the REAL reference method on seeded label sets -- ordinary boxes, a box no
+    prior overlaps above the threshold (forced best prior), two boxes competing for the same priors, no box at all.  Pins
+    oracle/ssd_ref.generate_targets (exact) and is the fixture of the device kernel."""
+    from oracle import ssd_ref as S
+    scfg, salgo_cls, _ = builder.export_from_registry("ssd")
+    algo = salgo_cls(scfg, torch.device("cpu"))
+    nc = scfg.dataset.num_classes
+    g = torch.Generator().manual_seed(77)
+    cases = []
+    for n in (5, 1, 12, 0):
+        lab = np.zeros((n, 6), dtype=np.float32)
+        if n:
+            lab[:, 1] = torch.randint(0, nc, (n,), generator=g).numpy()
+            lab[:, 2:4] = (torch.rand(n, 2, generator=g) * 0.8 + 0.1).numpy()
+            lab[:, 4:6] = (torch.rand(n, 2, generator=g) * 0.5 + 0.02).numpy()
+        cases.append(lab)
+    cases[1][0, 4:6] = (0.004, 0.9)                              # a sliver: nothing above the threshold -> the best prior is forced
+    cases[2][1] = cases[2][0]                                    # two identical boxes of different class: the first wins the ties
+    cases[2][1, 1] = (cases[2][0, 1] + 1) % nc
+    outs = []
+    for lab in cases:
+        ref = algo.generate_targets(lab.copy()).numpy()
+        mine = S.generate_targets(lab.copy(), algo.anchors, nc, scfg.loss.overlap_threshold, algo.variance)
+        assert ref.dtype == np.float32 and np.array_equal(ref, mine), float(np.abs(ref - mine).max())
+        outs.append(ref)
+    nmax = max(len(c) for c in cases)
+    labels = np.zeros((len(cases), nmax, 5), dtype=np.float32)
+    for i, c in enumerate(cases):
+        labels[i, :len(c)] = c[:, 1:]
+    np.savez_compressed(os.path.join(GOLD, "ssd_targets.npz"), labels=labels, counts=np.array([len(c) for c in cases], dtype=np.int32),
+                        y_true=np.stack(outs), anchors=algo.anchors.astype(np.float32), nc=np.array(nc), thr=np.array(scfg.loss.overlap_threshold),
+                        variance=np.asarray(algo.variance, dtype=np.float32))
+    report["ssd_targets"] = dict(positives=[int(o[:, -1].sum()) for o in outs])
+
+
 def main():
     sys.path.insert(0, ROOT)
     from oracle import yolov8_ref as O
@@ -840,6 +876,7 @@ def main():
 
     ssd_train_section(builder, report)
     ssd_loss_section(builder, report)
+    ssd_targets_section(builder, report)
     with open(os.path.join(GOLD, "PIN_REPORT.json"), "w") as f:
         json.dump(report, f, indent=1)
     print(json.dumps(report, indent=1))
@@ -853,7 +890,7 @@ def only(section):
     builder = _import_reference()
     torch.set_num_threads(8)
     report = {}
-    {"deeplab_train": deeplab_train_section, "yolov7_train": yolov7_train_section, "centernet_train": centernet_train_section, "ssd_train": ssd_train_section, "centernet_loss": centernet_loss_section, "ssd_loss": ssd_loss_section}[section](builder, report)
+    {"deeplab_train": deeplab_train_section, "yolov7_train": yolov7_train_section, "centernet_train": centernet_train_section, "ssd_train": ssd_train_section, "centernet_loss": centernet_loss_section, "ssd_loss": ssd_loss_section, "ssd_targets": ssd_targets_section}[section](builder, report)
     path = os.path.join(GOLD, "PIN_REPORT.json")
     full = json.load(open(path)) if os.path.exists(path) else {}
     full.update(report)

@@ -272,3 +272,49 @@ def synth_y_true(B: int, A: int, nc: int, n_pos: int = 12, seed: int = 5):
         y[b, idx, 5 + torch.randint(0, nc, (k,), generator=g)] = 1.0
         y[b, idx, -1] = 1.0
     return y
+
+
+def generate_targets(label, anchors, nc: int, overlap_threshold: float = 0.5, variance=(0.1, 0.1, 0.2, 0.2)):
+    """Ssd.generate_targets + _encode_box (core/algorithms/ssd.py:327-480), numpy, the reference's dtypes: label (N, 6) float32
+    [_, class id, cx, cy, w, h] -> corners in float32; then float64 arithmetic against the float32 anchors (the corners ride in a float64
+    array with the one-hot labels, :343); result (A, 4 + (nc + 1) + 1) float32."""
+    label = np.array(label, dtype=np.float32, copy=True)
+    anchors = np.asarray(anchors, dtype=np.float32)
+    variance = np.asarray(variance, dtype=np.float32)
+    A = anchors.shape[0]
+    label[:, 1] += 1
+    cls = label[:, 1].astype(np.int32)
+    c = label[:, 2:]
+    coord = np.concatenate((c[:, 0:1] - c[:, 2:3] / 2, c[:, 1:2] - c[:, 3:4] / 2, c[:, 0:1] + c[:, 2:3] / 2, c[:, 1:2] + c[:, 3:4] / 2), -1)
+    assignment = np.zeros((A, 4 + 1 + nc + 1), dtype=np.float32)
+    assignment[:, 4] = 1.0
+    if len(coord) == 0:
+        return assignment
+    enc = []
+    for box in coord.astype(np.float64):                          # the reference concatenates the float32 corners with a float64 one-hot: float64 from here
+        wh = np.maximum(np.minimum(anchors[:, 2:4], box[2:]) - np.maximum(anchors[:, :2], box[:2]), 0)
+        inter = wh[:, 0] * wh[:, 1]
+        iou = inter / ((box[2] - box[0]) * (box[3] - box[1]) + (anchors[:, 2] - anchors[:, 0]) * (anchors[:, 3] - anchors[:, 1]) - inter)
+        e = np.zeros((A, 5))
+        mask = iou > overlap_threshold
+        if not mask.any():
+            mask[iou.argmax()] = True
+        e[:, -1][mask] = iou[mask]
+        aa = anchors[mask]
+        a_center, a_wh = (aa[:, 0:2] + aa[:, 2:4]) * 0.5, aa[:, 2:4] - aa[:, 0:2]
+        e[:, :2][mask] = 0.5 * (box[:2] + box[2:]) - a_center
+        e[:, :2][mask] /= a_wh
+        e[:, :2][mask] /= variance[:2]
+        e[:, 2:4][mask] = np.log((box[2:] - box[:2]) / a_wh)
+        e[:, 2:4][mask] /= variance[2:4]
+        enc.append(e)
+    enc = np.stack(enc)
+    best = enc[:, :, -1].max(0)
+    idx = enc[:, :, -1].argmax(0)
+    m = best > 0
+    idx = idx[m]
+    assignment[:, :4][m] = enc[:, m, :][idx, np.arange(len(idx)), :4]
+    assignment[:, 4][m] = 0
+    assignment[:, 5:-1][m] = np.eye(nc + 1)[cls][idx, 1:]
+    assignment[:, -1][m] = 1
+    return assignment

@@ -2279,3 +2279,24 @@ def test_ssd_trainer_fused_step(dev):
     assert tr._step.scaler.skipped == 0 and tr.optimizer.device_step() == 6
     ev = tr.evaluate_loop()
     assert np.isfinite(ev["val_loss"])
+
+
+def test_ssd_target_encoding_matches_the_reference_fixture(dev, gold):
+    """cvx_ssd_encode_targets against the REAL reference's Ssd.generate_targets (make_golden.py section 12d) on four label sets in one
+    batch: ordinary boxes, a sliver no prior overlaps above the threshold (its best prior is forced), two identical boxes of different
+    class (the first wins), an image without boxes.  Positive flags, classes and which ground truth a prior takes: exact; the encoded
+    boxes to 2 ulp of float32 (the device's float64 log / divide against numpy's)."""
+    import builder
+    g = gold("ssd_targets.npz")
+    cfg, algo_cls, _ = builder.export_from_registry("ssd")
+    algo = algo_cls(cfg, dev)
+    assert np.array_equal(algo.anchors, g["anchors"]) and int(g["nc"]) == cfg.dataset.num_classes
+    labels = [np.concatenate((np.zeros((int(n), 1), np.float32), g["labels"][i, :int(n)]), 1) for i, n in enumerate(g["counts"])]
+    y = algo.encode_targets(labels).cpu().numpy()
+    ref = g["y_true"]
+    assert y.shape == ref.shape == (4, 8732, 26)
+    assert np.array_equal(y[..., 4:], ref[..., 4:])                            # one-hot classes, background column, positive flag
+    assert [int(v) for v in ref[..., -1].sum(1)] == [56, 1, 104, 0]
+    np.testing.assert_allclose(y[..., :4], ref[..., :4], rtol=3e-7, atol=1e-7)
+    one = algo.generate_targets(labels[1]).cpu().numpy()
+    assert np.array_equal(one[:, 4:], ref[1][:, 4:])

@@ -402,6 +402,18 @@ def test_ssd_oracle_multibox_loss(gold):
     assert tuple(yt.shape) == (2, 50, 26) and torch.all(yt[..., 4:-1].sum(-1) == 1) and float(yt[0, :, -1].sum()) >= 1
 
 
+def test_ssd_oracle_target_encoding(gold):
+    """oracle/ssd_ref.generate_targets against the REAL reference's Ssd.generate_targets (make_golden.py section 12d): exact on all four
+    label sets (the reference's float32 -> float64 -> float32 arithmetic is reproduced), incl. the forced-best-prior and the no-box cases."""
+    from oracle import ssd_ref as S
+    g = gold("ssd_targets.npz")
+    for i, n in enumerate(g["counts"]):
+        lab = np.concatenate((np.zeros((int(n), 1), np.float32), g["labels"][i, :int(n)]), 1)
+        mine = S.generate_targets(lab, g["anchors"], int(g["nc"]), float(g["thr"]), g["variance"])
+        assert mine.dtype == np.float32 and np.array_equal(mine, g["y_true"][i]), i
+    assert np.array_equal(S.priors().numpy() if hasattr(S.priors(), "numpy") else np.asarray(S.priors()), g["anchors"])
+
+
 def _yolov7_fixture_state(g):
     from oracle import yolov7_ref as Y
     sd = Y.init_state_dict(20, seed=0)
