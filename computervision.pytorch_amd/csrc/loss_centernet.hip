@@ -165,3 +165,80 @@ extern "C" int cvx_centernet_loss(const float* rows_f32, int32_t ld, int32_t bat
   CVX_HIP(hipGetLastError());
   return 0;
 }
+
+// ---- CenterNet target drawing (CenterNet.generate_targets, core/algorithms/centernet.py:66-112; gaussian_radius / gaussian2D /
+// draw_umich_gaussian, core/utils/gaussian.py:5-57): the CPU work of centernet_collate -------------------------------------------
+// Per object: corners from (cx, cy, w, h) in float32, scaled to the feature map; integer height / width (truncation); the CornerNet radius
+// (three quadratics, float64); the integer centre; a (2r+1)^2 Gaussian with sigma = (2r+1)/6 in float64, values below eps * max dropped,
+// merged into the class plane with a maximum -- which commutes, so all objects of the batch are drawn concurrently with an atomic
+// maximum on the bit patterns of the non-negative floats.  reg = fractional part of the centre, wh = the integer size, ind = y * W + x.
+namespace {
+
+__global__ __launch_bounds__(256) void cn_draw_kernel(const float* labels, const int* counts, int kmax, int H, int W, int nc, float* heat, float* reg,
+                                                      float* wh, float* mask, float* ind) {
+#pragma clang fp contract(off)  // numpy rounds every product and sum: no fused multiply-adds in the coordinate arithmetic
+  __shared__ int s_par[5];  // x, y, radius, class, valid
+  const int b = blockIdx.x / kmax, j = blockIdx.x - b * kmax;
+  const long long o = (long long)b * kmax + j;
+  if (threadIdx.x == 0) {
+    s_par[4] = 0;
+    if (j < counts[b]) {
+      const float* l = labels + o * 5;  // class id, cx, cy, w, h (normalised)
+      const float xmin = (l[1] - l[3] / 2) * (float)W, ymin = (l[2] - l[4] / 2) * (float)H;
+      const float xmax = (l[1] + l[3] / 2) * (float)W, ymax = (l[2] + l[4] / 2) * (float)H;
+      const int h = (int)(ymax - ymin), w = (int)(xmax - xmin);
+      const double ov = 0.7, hh = (double)h, ww = (double)w;
+      const double b1 = hh + ww, c1 = ww * hh * (1 - ov) / (1 + ov);
+      const double r1 = (b1 + sqrt(b1 * b1 - 4 * 1 * c1)) / 2;
+      const double b2 = 2 * (hh + ww), c2 = (1 - ov) * ww * hh;
+      const double r2 = (b2 + sqrt(b2 * b2 - 4 * 4 * c2)) / 2;
+      const double a3 = 4 * ov, b3 = -2 * ov * (hh + ww), c3 = (ov - 1) * ww * hh;
+      const double r3 = (b3 + sqrt(b3 * b3 - 4 * a3 * c3)) / 2;
+      const double rr = fmin(r1, fmin(r2, r3));
+      int radius = (int)rr;
+      if (radius < 0) radius = 0;
+      const float cx = (xmin + xmax) / 2, cy = (ymin + ymax) / 2;
+      const int ix = (int)cx, iy = (int)cy;
+      s_par[0] = ix;
+      s_par[1] = iy;
+      s_par[2] = radius;
+      s_par[3] = (int)l[0];
+      s_par[4] = 1;
+      reg[o * 2] = cx - (float)ix;
+      reg[o * 2 + 1] = cy - (float)iy;
+      wh[o * 2] = (float)w;
+      wh[o * 2 + 1] = (float)h;
+      mask[o] = 1.f;
+      ind[o] = (float)(iy * W + ix);
+    } else {
+      reg[o * 2] = reg[o * 2 + 1] = wh[o * 2] = wh[o * 2 + 1] = mask[o] = ind[o] = 0.f;
+    }
+  }
+  __syncthreads();
+  if (!s_par[4]) return;
+  const int x = s_par[0], y = s_par[1], r = s_par[2], cls = s_par[3];
+  if (x < 0 || y < 0 || cls < 0 || cls >= nc) return;
+  const int left = min(x, r), right = min(W - x, r + 1), top = min(y, r), bottom = min(H - y, r + 1);
+  const int nw = left + right, nh = top + bottom;
+  if (nw <= 0 || nh <= 0) return;
+  const double sigma = (double)(2 * r + 1) / 6.0;
+  for (int t = threadIdx.x; t < nw * nh; t += 256) {
+    const int dy = t / nw - top, dx = t - (t / nw) * nw - left;
+    double g = exp(-(double)(dx * dx + dy * dy) / (2 * sigma * sigma));
+    if (g < 2.220446049250313e-16) g = 0.0;  // h[h < eps * h.max()] = 0, h.max() = 1 at the centre
+    const float gf = (float)g;
+    atomicMax(reinterpret_cast<unsigned*>(heat + (((long long)b * H + (y + dy)) * W + (x + dx)) * nc + cls), __float_as_uint(gf));
+  }
+}
+
+}  // namespace
+
+extern "C" int cvx_centernet_draw_targets(const float* labels, const int32_t* counts, int32_t batch, int32_t max_boxes, int32_t fh, int32_t fw, int32_t nc,
+                                          float* heatmap, float* reg, float* wh, float* reg_mask, float* indices, void* hip_stream) {
+  CVX_CHECK(labels && counts && heatmap && reg && wh && reg_mask && indices && batch > 0 && max_boxes > 0 && fh > 0 && fw > 0 && nc > 0, "bad arguments");
+  hipStream_t st = (hipStream_t)hip_stream;
+  CVX_HIP(hipMemsetAsync(heatmap, 0, (size_t)batch * fh * fw * nc * 4, st));
+  hipLaunchKernelGGL(cn_draw_kernel, dim3(batch * max_boxes), dim3(256), 0, st, labels, counts, max_boxes, fh, fw, nc, heatmap, reg, wh, reg_mask, indices);
+  CVX_HIP(hipGetLastError());
+  return 0;
+}

@@ -264,6 +264,7 @@ extern "C" int cvx_multibox_loss(const float* loc, const float* conf, const floa
 namespace {
 
 __device__ __forceinline__ double prior_iou(const float* a, double bx0, double by0, double bx1, double by1) {
+#pragma clang fp contract(off)  // numpy rounds every product and sum: no fused multiply-adds
   const double w = fmax(fmin((double)a[2], bx1) - fmax((double)a[0], bx0), 0.0), h = fmax(fmin((double)a[3], by1) - fmax((double)a[1], by0), 0.0);
   const double inter = w * h;
   const double area_true = (bx1 - bx0) * (by1 - by0), area_gt = (double)((a[2] - a[0]) * (a[3] - a[1]));  // float32 product of the float32 anchors (:423)
@@ -272,6 +273,7 @@ __device__ __forceinline__ double prior_iou(const float* a, double bx0, double b
 // (cx, cy, w, h) -> corners in float32 (xywh_to_xyxy on the float32 label), then float64: the reference carries the corners in a float64
 // array next to the one-hot labels (ssd.py:343), so IoU and encoding run in float64 on float32-valued operands
 __device__ __forceinline__ void label_box(const float* l, double* x0, double* y0, double* x1, double* y1) {
+#pragma clang fp contract(off)
   *x0 = (double)(l[1] - l[3] / 2);
   *y0 = (double)(l[2] - l[4] / 2);
   *x1 = (double)(l[1] + l[3] / 2);
@@ -321,6 +323,7 @@ __global__ __launch_bounds__(256) void ssd_force_kernel(const float* labels, con
 
 __global__ __launch_bounds__(256) void ssd_encode_kernel(const float* labels, const int* counts, int nmax, const float* priors, int A, int nc1, float thr,
                                                          float var_xy, float var_wh, const int* force, int B, float* y_true) {
+#pragma clang fp contract(off)
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long long)B * A) return;
   const int b = (int)(i / A), a = (int)(i - (long long)b * A);

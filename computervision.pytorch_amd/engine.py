@@ -363,3 +363,21 @@ def ssd_encode_targets(labels: torch.Tensor, counts: torch.Tensor, priors: torch
     L.check(lib.cvx_ssd_encode_targets(L.ptr(labels), L.ptr(counts), B, nmax, L.ptr(priors), A, nc1, float(overlap_threshold), float(variances[0]),
                                        float(variances[1]), L.ptr(y), L.ptr(ws), L.stream_ptr(labels.device)), "cvx_ssd_encode_targets")
     return y
+
+
+def centernet_draw_targets(labels: torch.Tensor, counts: torch.Tensor, feature_hw, num_classes: int):
+    """labels (B, K, 5) fp32 [class id, cx, cy, w, h], counts (B) -> [heatmap (B,h,w,nc), reg (B,K,2), wh (B,K,2), reg_mask (B,K),
+    indices (B,K)]: the reference's CenterNet.generate_targets for a whole batch in one launch (core/algorithms/centernet.py:66-112)."""
+    _need_gpu(labels, "labels")
+    lib = L.load()
+    B, K = int(labels.shape[0]), int(labels.shape[1])
+    h, w = feature_hw
+    dev = labels.device
+    labels = labels.contiguous().float()
+    counts = counts.to(dev).to(torch.int32).contiguous()
+    heat = torch.empty(B, h, w, int(num_classes), device=dev)
+    reg, wh = torch.empty(B, K, 2, device=dev), torch.empty(B, K, 2, device=dev)
+    mask, ind = torch.empty(B, K, device=dev), torch.empty(B, K, device=dev)
+    L.check(lib.cvx_centernet_draw_targets(L.ptr(labels), L.ptr(counts), B, K, h, w, int(num_classes), L.ptr(heat), L.ptr(reg), L.ptr(wh), L.ptr(mask),
+                                           L.ptr(ind), L.stream_ptr(dev)), "cvx_centernet_draw_targets")
+    return [heat, reg, wh, mask, ind]

@@ -38,6 +38,27 @@ class CenterNetA:
         lc = self.cfg.loss
         return CenterNetLoss(self.num_classes, lc.hm_weight, lc.wh_weight, lc.off_weight)
 
+    def draw_targets(self, labels):
+        """What centernet_collate does image by image on the CPU (core/data/collate.py:52-68), for the batch in one launch: a list of
+        (N_i, 6) label arrays [_, class id, cx, cy, w, h] -> [heatmap (B,h,w,nc), reg (B,K,2), wh (B,K,2), reg_mask (B,K), indices (B,K)] on
+        the device (``cvx_centernet_draw_targets``), K = cfg.train.max_num_boxes (longer lists are truncated, as in the reference)."""
+        dev = torch.device(self.device)
+        K = int(getattr(self.cfg.train, "max_num_boxes", 30))
+        packed = torch.zeros(len(labels), K, 5)
+        counts = []
+        for i, l in enumerate(labels):
+            l = torch.as_tensor(np.asarray(l, dtype=np.float32) if not torch.is_tensor(l) else l).float()[:K]
+            if l.shape[0]:
+                packed[i, :l.shape[0]] = l[:, 1:6]
+            counts.append(int(l.shape[0]))
+        ratio = int(self.cfg.arch.downsampling_ratio)
+        fh, fw = self.cfg.arch.input_size[1] // ratio, self.cfg.arch.input_size[2] // ratio
+        return _engine.centernet_draw_targets(packed.to(dev), torch.tensor(counts, dtype=torch.int32, device=dev), (fh, fw), self.num_classes)
+
+    def generate_targets(self, label):
+        """Reference :66-112 for one image -> (heatmap (h,w,nc), reg (K,2), wh (K,2), reg_mask (K,), indices (K,)) on the device."""
+        return tuple(t[0] for t in self.draw_targets([label]))
+
     # ---- decode ---------------------------------------------------------------------------------------
     def decode_raw(self, raw: torch.Tensor, fh: int, fw: int, conf_threshold=None):
         """The engine's head tensor (B, fh*fw, ld) -> device dict of cvx_centernet_decode (normalised boxes, before the

@@ -390,6 +390,13 @@ int cvx_centernet_loss(const float* rows_f32, int32_t ld, int32_t batch, int32_t
 int64_t cvx_multibox_loss_workspace_bytes(int32_t batch, int32_t anchors);
 int cvx_multibox_loss(const float* loc, const float* conf, const float* y_true, int32_t batch, int32_t anchors, int32_t nc1, float neg_pos_ratio,
                       float alpha, float grad_scale, float* loss_items, float* dloc, float* dconf, void* workspace, void* hip_stream);
+/* CenterNet target drawing on the device: what centernet_collate does per image on the CPU.  labels: (batch, max_boxes, 5) fp32 rows
+ * [class id, cx, cy, w, h] (normalised), counts (batch) valid rows (<= max_boxes = cfg.train.max_num_boxes).  Outputs in the reference's
+ * formats: heatmap (batch, fh, fw, nc) -- per object a (2r+1)^2 Gaussian, r the CornerNet radius of its integer size, merged by maximum;
+ * reg (batch, max_boxes, 2) = fractional part of the centre; wh = integer (w, h); reg_mask; indices = y*fw + x as float32.  Asynchronous.
+ * Replaces: CenterNet.generate_targets, core/algorithms/centernet.py:66-112 + core/utils/gaussian.py:5-57 (called from collate.py:52-68). */
+int cvx_centernet_draw_targets(const float* labels, const int32_t* counts, int32_t batch, int32_t max_boxes, int32_t fh, int32_t fw, int32_t nc,
+                               float* heatmap, float* reg, float* wh, float* reg_mask, float* indices, void* hip_stream);
 /* SSD target encoding on the device: what ssd_collate does per image on the CPU.  labels: (batch, max_boxes, 5) fp32 rows
  * [class id (0-based), cx, cy, w, h] (normalised), counts (batch) valid rows per image; priors (anchors, 4) fp32 corner boxes
  * (Ssd._get_ssd_anchors).  y_true: (batch, anchors, 4 + nc1 + 1) fp32: encoded box | one-hot class incl. the background column 0 | positive

@@ -24,6 +24,8 @@ it as (score descending, flat index ascending) -- the fixtures contain no ties a
 from __future__ import annotations
 
 import math
+
+import numpy as np
 from collections import OrderedDict
 
 import torch
@@ -405,3 +407,56 @@ def synth_targets(B: int, h: int, w: int, nc: int, K: int = 30, seed: int = 3):
             mask[b, k] = 1.0
             idx[b, k] = iy * w + ix
     return [heat, reg, wh, mask, idx]
+
+
+def gaussian_radius(det_size, min_overlap=0.7):
+    """core/utils/gaussian.py:5-25 (the CornerNet radius), float64."""
+    height, width = det_size
+    b1, c1 = (height + width), width * height * (1 - min_overlap) / (1 + min_overlap)
+    r1 = (b1 + np.sqrt(b1 ** 2 - 4 * 1 * c1)) / 2
+    b2, c2 = 2 * (height + width), (1 - min_overlap) * width * height
+    r2 = (b2 + np.sqrt(b2 ** 2 - 4 * 4 * c2)) / 2
+    a3, b3, c3 = 4 * min_overlap, -2 * min_overlap * (height + width), (min_overlap - 1) * width * height
+    r3 = (b3 + np.sqrt(b3 ** 2 - 4 * a3 * c3)) / 2
+    return min(r1, r2, r3)
+
+
+def generate_targets(label, feature_hw, nc: int, max_num_boxes: int = 30):
+    """CenterNet.generate_targets (core/algorithms/centernet.py:66-112) with gaussian2D / draw_umich_gaussian (gaussian.py:28-57), numpy,
+    the reference's dtypes: label (N, 6) float32 [_, class id, cx, cy, w, h] -> (heatmap (h, w, nc), reg (K, 2), wh (K, 2), reg_mask (K,),
+    ind (K,)) float32."""
+    H, W = feature_hw
+    label = np.array(label, dtype=np.float32, copy=True)
+    c = label[:, 2:]
+    rows = np.concatenate((c[:, 0:1] - c[:, 2:3] / 2, c[:, 1:2] - c[:, 3:4] / 2, c[:, 0:1] + c[:, 2:3] / 2, c[:, 1:2] + c[:, 3:4] / 2, label[:, 1:2]), -1)
+    rows = rows[:max_num_boxes]
+    hm = np.zeros((H, W, nc), dtype=np.float32)
+    reg, wh = np.zeros((max_num_boxes, 2), dtype=np.float32), np.zeros((max_num_boxes, 2), dtype=np.float32)
+    mask, ind = np.zeros((max_num_boxes,), dtype=np.float32), np.zeros((max_num_boxes,), dtype=np.float32)
+    for j, item in enumerate(rows):
+        item[:4:2] = item[:4:2] * W
+        item[1:4:2] = item[1:4:2] * H
+        xmin, ymin, xmax, ymax, cid = item
+        cid = cid.astype(np.int32)
+        h, w = int(ymax - ymin), int(xmax - xmin)
+        radius = max(0, int(gaussian_radius((h, w))))
+        ctr = np.array([(xmin + xmax) / 2, (ymin + ymax) / 2], dtype=np.float32)
+        ci = ctr.astype(np.int32)
+        d = 2 * radius + 1
+        m = (d - 1.0) / 2.0
+        yy, xx = np.ogrid[-m:m + 1, -m:m + 1]
+        gk = np.exp(-(xx * xx + yy * yy) / (2 * (d / 6) * (d / 6)))
+        gk[gk < np.finfo(gk.dtype).eps * gk.max()] = 0
+        x, y = int(ci[0]), int(ci[1])
+        left, right, top, bottom = min(x, radius), min(W - x, radius + 1), min(y, radius), min(H - y, radius + 1)
+        mh = hm[:, :, cid][y - top:y + bottom, x - left:x + right]
+        mg = gk[radius - top:radius + bottom, radius - left:radius + right]
+        if min(mg.shape) > 0 and min(mh.shape) > 0:
+            plane = hm[:, :, cid].copy()
+            np.maximum(plane[y - top:y + bottom, x - left:x + right], mg, out=plane[y - top:y + bottom, x - left:x + right])
+            hm[:, :, cid] = plane
+        reg[j] = ctr - ci
+        wh[j] = np.array([w, h], dtype=np.float32)
+        mask[j] = 1
+        ind[j] = ci[1] * W + ci[0]
+    return hm, reg, wh, mask, ind

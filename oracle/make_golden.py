@@ -387,6 +387,44 @@ def ssd_targets_section(builder, report):
     report["ssd_targets"] = dict(positives=[int(o[:, -1].sum()) for o in outs])
 
 
+def centernet_targets_section(builder, report):
+    """9d. CenterNet.generate_targets (core/algorithms/centernet.py:66-112): the REAL reference method on seeded label sets -- ordinary
+    boxes, overlapping boxes of one class (maximum merge), a box at the map's border (clipped Gaussian), a tiny box (radius 0), no box.
+    Pins oracle/centernet_ref.generate_targets (exact) and is the fixture of the device kernel."""
+    from oracle import centernet_ref as C
+    ccfg, calgo_cls, _ = builder.export_from_registry("centernet")
+    algo = calgo_cls(ccfg, torch.device("cpu"))
+    nc, K = ccfg.dataset.num_classes, ccfg.train.max_num_boxes
+    fh, fw = algo.feature_size
+    g = torch.Generator().manual_seed(91)
+    cases = []
+    for n in (6, 3, 2, 0):
+        lab = np.zeros((n, 6), dtype=np.float32)
+        if n:
+            lab[:, 1] = torch.randint(0, nc, (n,), generator=g).numpy()
+            lab[:, 2:4] = (torch.rand(n, 2, generator=g) * 0.8 + 0.1).numpy()
+            lab[:, 4:6] = (torch.rand(n, 2, generator=g) * 0.4 + 0.03).numpy()
+        cases.append(lab)
+    cases[1][1, 1] = cases[1][0, 1]                               # same class, overlapping
+    cases[1][1, 2:4] = cases[1][0, 2:4] + 0.03
+    cases[2][0, 2:6] = (0.99, 0.02, 0.3, 0.25)                    # at the corner: the Gaussian is clipped
+    cases[2][1, 4:6] = (0.004, 0.006)                             # sub-pixel box: h = w = 0, radius 0
+    outs = []
+    for lab in cases:
+        ref = [t.numpy() for t in algo.generate_targets(lab.copy())]
+        mine = C.generate_targets(lab.copy(), (fh, fw), nc, K)
+        for a_, b_ in zip(ref, mine):
+            assert a_.dtype == np.float32 and np.array_equal(a_, b_), float(np.abs(a_ - b_).max())
+        outs.append(ref)
+    labels = np.zeros((len(cases), K, 5), dtype=np.float32)
+    for i, c in enumerate(cases):
+        labels[i, :len(c)] = c[:, 1:]
+    np.savez_compressed(os.path.join(GOLD, "centernet_targets.npz"), labels=labels, counts=np.array([len(c) for c in cases], dtype=np.int32), nc=np.array(nc),
+                        fh=np.array(fh), fw=np.array(fw), heat=np.stack([o[0] for o in outs]), reg=np.stack([o[1] for o in outs]),
+                        wh=np.stack([o[2] for o in outs]), mask=np.stack([o[3] for o in outs]), ind=np.stack([o[4] for o in outs]))
+    report["centernet_targets"] = dict(feature=[int(fh), int(fw)], objects=[int(o[3].sum()) for o in outs])
+
+
 def main():
     sys.path.insert(0, ROOT)
     from oracle import yolov8_ref as O
@@ -670,6 +708,7 @@ def main():
 
     centernet_train_section(builder, report)
     centernet_loss_section(builder, report)
+    centernet_targets_section(builder, report)
 
     # ---- 10. DeepLabv3+ ResNet-101: init, eval forward on a calibrated network ---------------------------------
     from oracle import deeplab_ref as D
@@ -890,7 +929,7 @@ def only(section):
     builder = _import_reference()
     torch.set_num_threads(8)
     report = {}
-    {"deeplab_train": deeplab_train_section, "yolov7_train": yolov7_train_section, "centernet_train": centernet_train_section, "ssd_train": ssd_train_section, "centernet_loss": centernet_loss_section, "ssd_loss": ssd_loss_section, "ssd_targets": ssd_targets_section}[section](builder, report)
+    {"deeplab_train": deeplab_train_section, "yolov7_train": yolov7_train_section, "centernet_train": centernet_train_section, "ssd_train": ssd_train_section, "centernet_loss": centernet_loss_section, "ssd_loss": ssd_loss_section, "ssd_targets": ssd_targets_section, "centernet_targets": centernet_targets_section}[section](builder, report)
     path = os.path.join(GOLD, "PIN_REPORT.json")
     full = json.load(open(path)) if os.path.exists(path) else {}
     full.update(report)

@@ -2300,3 +2300,27 @@ def test_ssd_target_encoding_matches_the_reference_fixture(dev, gold):
     np.testing.assert_allclose(y[..., :4], ref[..., :4], rtol=3e-7, atol=1e-7)
     one = algo.generate_targets(labels[1]).cpu().numpy()
     assert np.array_equal(one[:, 4:], ref[1][:, 4:])
+
+
+def test_centernet_target_drawing_matches_the_reference_fixture(dev, gold):
+    """cvx_centernet_draw_targets against the REAL reference's CenterNet.generate_targets (make_golden.py section 9d) on four label sets in
+    one batch: ordinary boxes, two overlapping boxes of one class (maximum merge), a box at the corner (clipped Gaussian) with a sub-pixel
+    box (radius 0), no box.  reg / wh / mask / indices exact; the heat map to 1 ulp of float32 (float64 exp on the device vs numpy)."""
+    import builder
+    g = gold("centernet_targets.npz")
+    cfg, algo_cls, _ = builder.export_from_registry("centernet")
+    algo = algo_cls(cfg, dev)
+    assert int(g["nc"]) == cfg.dataset.num_classes and int(g["fh"]) == cfg.arch.input_size[1] // cfg.arch.downsampling_ratio
+    labels = [np.concatenate((np.zeros((int(n), 1), np.float32), g["labels"][i, :int(n)]), 1) for i, n in enumerate(g["counts"])]
+    heat, reg, wh, mask, ind = (t.cpu().numpy() for t in algo.draw_targets(labels))
+    assert np.array_equal(reg, g["reg"]) and np.array_equal(wh, g["wh"]) and np.array_equal(mask, g["mask"]) and np.array_equal(ind, g["ind"])
+    assert np.array_equal(heat == 1.0, g["heat"] == 1.0) and np.array_equal(heat == 0.0, g["heat"] == 0.0)      # centres and support
+    np.testing.assert_allclose(heat, g["heat"], rtol=2e-7, atol=0)
+    assert int((g["heat"] == 1.0).sum()) >= 10
+    # the drawn targets feed the loss kernel directly
+    from computervision.pytorch_amd.dla import CenterNetLoss
+    crit = CenterNetLoss(cfg.dataset.num_classes)
+    B, h, w, nc = heat.shape
+    rows = torch.randn(B, h * w, ((nc + 7) & ~7) + 16, device=dev)
+    items, _ = crit.op(rows, algo.draw_targets(labels), (h, w), 1.0)
+    assert bool(torch.isfinite(items).all())

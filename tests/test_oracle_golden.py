@@ -414,6 +414,21 @@ def test_ssd_oracle_target_encoding(gold):
     assert np.array_equal(S.priors().numpy() if hasattr(S.priors(), "numpy") else np.asarray(S.priors()), g["anchors"])
 
 
+def test_centernet_oracle_target_drawing(gold):
+    """oracle/centernet_ref.generate_targets against the REAL reference's CenterNet.generate_targets (make_golden.py section 9d): exact on
+    all four label sets (radius rule, float64 Gaussian with its eps cut, maximum merge, clipping at the border, truncation casts)."""
+    from oracle import centernet_ref as C
+    g = gold("centernet_targets.npz")
+    K = g["reg"].shape[1]
+    for i, n in enumerate(g["counts"]):
+        lab = np.concatenate((np.zeros((int(n), 1), np.float32), g["labels"][i, :int(n)]), 1)
+        hm, reg, wh, mask, ind = C.generate_targets(lab, (int(g["fh"]), int(g["fw"])), int(g["nc"]), K)
+        assert np.array_equal(hm, g["heat"][i]) and np.array_equal(reg, g["reg"][i]) and np.array_equal(wh, g["wh"][i])
+        assert np.array_equal(mask, g["mask"][i]) and np.array_equal(ind, g["ind"][i])
+    assert abs(C.gaussian_radius((10, 20)) - min((30 + np.sqrt(900 - 4 * 200 * 0.3 / 1.7)) / 2, (60 + np.sqrt(3600 - 16 * 0.3 * 200)) / 2,
+                                                  (-42 + np.sqrt(42 ** 2 + 4 * 2.8 * 0.3 * 200)) / 2)) < 1e-12
+
+
 def _yolov7_fixture_state(g):
     from oracle import yolov7_ref as Y
     sd = Y.init_state_dict(20, seed=0)
