@@ -102,6 +102,8 @@ PROTOTYPES = {
     "cvx_engine_set_seed": (_I32, [_P, _U64]),
     "cvx_centernet_loss_workspace_bytes": (_I64, [_I32, _I32]),
     "cvx_centernet_loss": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I32, _F, _F, _F, _F, _P, _P, _P, _P, _P]),
+    "cvx_yolo7_loss_workspace_bytes": (_I64, [_I32, _I32, _I32, _I32]),
+    "cvx_yolo7_loss": (_I32, [_P, _I32, _I32, _I32, _P, _P, _P, _P, _I32, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P]),
     "cvx_centernet_draw_targets": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P]),
     "cvx_ssd_encode_targets": (_I32, [_P, _P, _I32, _I32, _P, _I32, _I32, _F, _F, _F, _P, _P, _P]),
     "cvx_multibox_loss_workspace_bytes": (_I64, [_I32, _I32]),

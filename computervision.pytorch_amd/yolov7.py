@@ -21,7 +21,7 @@ from __future__ import annotations
 
 import math
 from collections import OrderedDict
-from typing import Dict, List
+from typing import Dict, Optional, List
 
 import torch
 import torch.nn as nn
@@ -454,7 +454,9 @@ class Yolo7L(nn.Module):
         else:
             self.last_rows = self._run_forward(x, self.training)
             outs = self._rows_to_levels(self.last_rows)
-        return tuple(o[:, :self.layout.no] for o in outs)
+        res = tuple(o[:, :self.layout.no] for o in outs)
+        res[0].model = self                    # the fused Yolo7Loss starts from the head rows (last_rows)
+        return res
 
 
 class _Y7Fn(torch.autograd.Function):
@@ -470,3 +472,132 @@ class _Y7Fn(torch.autograd.Function):
         if any(g is not None for g in grads):
             ctx.model._backward_levels(grads)
         return None, None, None
+
+
+ANCHORS_PX = (12, 16, 19, 36, 40, 28, 36, 75, 76, 55, 72, 146, 142, 110, 192, 243, 459, 401)    # configs/yolo7_cfg.py
+ANCHORS_MASK = ((6, 7, 8), (3, 4, 5), (0, 1, 2))
+LOSS_STRIDES = (32.0, 16.0, 8.0)
+
+
+class _Y7LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out0, owner, model, targets, img_size):
+        items, dpred = owner.op(model.last_rows.detach(), model._last_engine.graph.level_hw, targets, img_size, model.loss_scale)
+        ctx.model, ctx.dpred = model, dpred
+        model.last_dpred = dpred
+        owner.last_items = items
+        return items[0].reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        m = ctx.model
+        first = next(p for p in m.parameters() if p.requires_grad)
+        if first.grad is None:
+            m.flat_grads.zero_()
+            m._grads_attached = False
+        m._last_engine.backward(ctx.dpred, m.loss_scale / float(gout))
+        if not m._grads_attached or first.grad is None:
+            m.attach_grads()
+        return None, None, None, None, None
+
+
+class Yolo7Loss:
+    """``Yolo7Loss(anchors, num_classes, input_shape, anchors_mask, label_smoothing)`` of the reference (core/loss/yolo7_loss.py:14-444) on
+    the engine: ``loss, box, obj, cls = criterion(predictions, targets, imgs)`` with ``predictions = model(imgs)`` and ``targets`` (N, 6)
+    [image, class, cx, cy, w, h] as ``yolo7_collate`` builds them.  Candidate generation, the SimOTA assignment and the three loss terms
+    with their gradient run in ``cvx_yolo7_loss`` on the head rows behind ``predictions``; ``loss.backward()`` runs the engine's backward."""
+
+    def __init__(self, anchors=None, num_classes: int = 20, input_shape=(640, 640), anchors_mask=ANCHORS_MASK, label_smoothing: float = 0.0):
+        import numpy as np
+        a = np.asarray(ANCHORS_PX if anchors is None else anchors, dtype=np.float32).reshape(-1, 2)
+        self.anchors_px = torch.from_numpy(np.concatenate([a[list(m)] for m in anchors_mask]).astype(np.float32).copy())   # level-major
+        self.nc = int(num_classes)
+        self.box_ratio = 0.05
+        self.obj_ratio = 1.0 * (input_shape[0] * input_shape[1]) / (640 ** 2)
+        self.cls_ratio = 0.5 * (num_classes / 80)
+        self.label_smoothing = float(label_smoothing)
+        self._ws = self._bad = None
+        self.last_items = None
+
+    def overflowed(self) -> int:
+        """bit 0: an image had more than 64 ground truths, bit 1: more than 2880 candidates (the surplus was dropped); synchronises."""
+        return 0 if self._bad is None else int(self._bad.item())
+
+    def op(self, rows: torch.Tensor, level_hw, targets: torch.Tensor, img_size: float, loss_scale: float, dpred: Optional[torch.Tensor] = None):
+        """rows (B, A, ld) fp32 -> (items (4,): total, box, obj, cls (ratios applied); dpred (B, A, ld) fp16)"""
+        if rows.device.type != "cuda":
+            raise L.CvxError("Yolo7Loss runs on an MI355X only (there is no CPU path)")
+        lib = L.load()
+        B, A, ld = rows.shape
+        dev = rows.device
+        targets = targets.to(dev).float().contiguous()
+        N = int(targets.shape[0])
+        need = int(lib.cvx_yolo7_loss_workspace_bytes(B, A, ld, N))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            self._bad = torch.zeros(1, dtype=torch.int32, device=dev)
+        if dpred is None:
+            dpred = torch.empty(B, A, ld, dtype=torch.float16, device=dev)
+        items = torch.empty(4, device=dev)
+        import ctypes as C
+        hw = (C.c_int32 * 6)(*[int(v) for pair in level_hw for v in pair])
+        anc = (C.c_float * 18)(*[float(v) for v in self.anchors_px.flatten().tolist()])
+        strides = (C.c_float * 3)(*LOSS_STRIDES)
+        L.check(lib.cvx_yolo7_loss(L.ptr(rows), ld, B, self.nc, hw, anc, strides, L.ptr(targets) if N else None, N, float(img_size), self.box_ratio,
+                                   self.obj_ratio, self.cls_ratio, self.label_smoothing, float(loss_scale), L.ptr(items), L.ptr(dpred),
+                                   L.ptr(self._bad), L.ptr(self._ws), L.stream_ptr(dev)), "cvx_yolo7_loss")
+        return items, dpred
+
+    def __call__(self, predictions, targets, imgs):
+        model = getattr(predictions[0], "model", None)
+        if model is None:
+            raise L.CvxError("Yolo7Loss needs the output of Yolo7L.forward (it carries the head rows the loss starts from)")
+        img_size = float(imgs.shape[2])                           # imgs[b].shape[1]
+        if model.training and torch.is_grad_enabled():
+            total = _Y7LossFn.apply(predictions[0], self, model, targets, img_size)
+            it = self.last_items
+            return total, it[1], it[2], it[3]
+        it = self.op(model.last_rows, model._last_engine.graph.level_hw, targets, img_size, model.loss_scale)[0]
+        return it[0], it[1], it[2], it[3]
+
+
+class Yolo7TrainStep:
+    """One optimisation step of the reference's ``Yolo7Trainer.train_loop`` (core/trainer/yolo7_train.py:79-97) as C-ABI calls: engine
+    forward (training), ``cvx_yolo7_loss``, engine backward, [gradient sum over the ranks], fused Adam with GradScaler's inf/nan check."""
+
+    def __init__(self, model: Yolo7L, criterion: Yolo7Loss, optimizer, scaler=None, process_group=None, n_buckets: int = 4):
+        self.model, self.criterion, self.optimizer, self.scaler = model, criterion, optimizer, scaler
+        self.pg, self.n_buckets = process_group, n_buckets
+        self.world, self.distributed = 1, False
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+            self.distributed = True
+        self._dpred = self._side = None
+
+    def __call__(self, images: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+        from .engine import check_finite
+        from .train import allreduce_mean_flat
+        m, crit = self.model, self.criterion
+        if not m.training:
+            raise L.CvxError("Yolo7TrainStep: call model.train() first")
+        dev = m.flat_params.device
+        self.optimizer.sync_lr()
+        rows = m._run_forward(images, True)
+        m.last_rows = rows
+        eng = m._last_engine
+        if self._dpred is None or self._dpred.shape != rows.shape:
+            self._dpred = torch.empty(rows.shape, device=dev, dtype=torch.float16)
+        scale = self.scaler.begin_step() if self.scaler is not None else m.loss_scale
+        items, dpred = crit.op(rows, eng.graph.level_hw, targets, float(images.shape[2]), scale, self._dpred)
+        eng.backward(dpred, scale)
+        if self.distributed and dev.type == "cuda":
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev, priority=-1)
+            allreduce_mean_flat(m.flat_grads, self.world, self.pg, self.n_buckets, self._side, average=False)
+        if self.scaler is not None:
+            check_finite(m.flat_grads, self.scaler.found_inf)
+            self.optimizer.found_inf = self.scaler.found_inf
+        self.optimizer.step(zero_grad=True, grad_scale=1.0 / self.world)
+        if self.scaler is not None:
+            self.scaler.end_step()
+        return items

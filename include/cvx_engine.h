@@ -390,6 +390,19 @@ int cvx_centernet_loss(const float* rows_f32, int32_t ld, int32_t batch, int32_t
 int64_t cvx_multibox_loss_workspace_bytes(int32_t batch, int32_t anchors);
 int cvx_multibox_loss(const float* loc, const float* conf, const float* y_true, int32_t batch, int32_t anchors, int32_t nc1, float neg_pos_ratio,
                       float alpha, float grad_scale, float* loss_items, float* dloc, float* dconf, void* workspace, void* hip_stream);
+/* YOLOv7's loss (Yolo7Loss) with its gradient.  rows: the engine's fp32 head rows (batch, anchors, ld): level l (coarsest first, level_hw =
+ * {h0, w0, h1, w1, h2, w2}) occupies rows a_off_l .. + h_l*w_l in (gj, gi) order, anchor a of a cell in columns a*(5+nc) .. : x, y, w, h,
+ * objectness, classes.  anchors_px: 9 (w, h) pairs in pixels, level-major (the reference's anchors[anchors_mask[l]]); strides {32, 16, 8};
+ * targets: (n_targets, 6) fp32 [image, class, cx, cy, w, h] normalised; img_size = imgs[b].shape[1] (the reference scales all four
+ * coordinates by it).  Candidate generation (find_3_positive), SimOTA assignment per image (build_targets: dynamic k = int(sum of the
+ * top-20 IoUs) >= 1, the k cheapest candidates, conflicts to the cheapest ground truth) and the CIoU / objectness / class terms all run on
+ * the device.  loss_items: 4 floats: total, box * box_ratio, obj * obj_ratio, cls * cls_ratio.  dpred: (batch, anchors, ld) fp16 =
+ * loss_scale * dLoss/drows.  bad: bit 0 = more than 64 ground truths in an image, bit 1 = more than 2880 candidates (both truncated).
+ * Replaces: Yolo7Loss.__call__ + loss.backward() down to the head outputs, core/loss/yolo7_loss.py:14-444. */
+int64_t cvx_yolo7_loss_workspace_bytes(int32_t batch, int32_t anchors, int32_t ld, int32_t n_targets);
+int cvx_yolo7_loss(const float* rows_f32, int32_t ld, int32_t batch, int32_t nc, const int32_t* level_hw, const float* anchors_px, const float* strides,
+                   const float* targets, int32_t n_targets, float img_size, float box_ratio, float obj_ratio, float cls_ratio, float label_smoothing,
+                   float loss_scale, float* loss_items, void* dpred_f16, int32_t* bad, void* workspace, void* hip_stream);
 /* CenterNet target drawing on the device: what centernet_collate does per image on the CPU.  labels: (batch, max_boxes, 5) fp32 rows
  * [class id, cx, cy, w, h] (normalised), counts (batch) valid rows (<= max_boxes = cfg.train.max_num_boxes).  Outputs in the reference's
  * formats: heatmap (batch, fh, fw, nc) -- per object a (2r+1)^2 Gaussian, r the CornerNet radius of its integer size, merged by maximum;

@@ -425,6 +425,47 @@ def centernet_targets_section(builder, report):
     report["centernet_targets"] = dict(feature=[int(fh), int(fw)], objects=[int(o[3].sum()) for o in outs])
 
 
+def yolov7_loss_section(builder, report):
+    """11c. Yolo7Loss (core/loss/yolo7_loss.py): the REAL reference loss object on random head outputs (scaled so that assignments are
+    non-trivial) and seeded targets -- an image with several objects (some sharing cells), an image with one object, an image without --
+    -> the four loss values and the gradient w.r.t. the three outputs by torch autograd.  Pins oracle/yolov7_ref.yolo7_loss."""
+    from oracle import yolov7_ref as Y7
+    ycfg, yalgo_cls, _ = builder.export_from_registry("yolo7")
+    ycfg.train.pretrained = False
+    algo = yalgo_cls(ycfg, torch.device("cpu"))
+    crit = algo.build_loss()
+    assert type(crit).__name__ == "Yolo7Loss"
+    nc = ycfg.dataset.num_classes
+    H = W = 256
+    B = 3
+    g = torch.Generator().manual_seed(17)
+    outs = [(torch.randn(B, 3 * (5 + nc), H // s, W // s, generator=g) * 1.5).requires_grad_(True) for s in (32, 16, 8)]
+    rows = []
+    for b, n in ((0, 6), (1, 1)):
+        for _ in range(n):
+            wh = torch.rand(2, generator=g) * 0.5 + 0.05
+            rows.append([b, int(torch.randint(0, nc, (1,), generator=g)), float(torch.rand(1, generator=g) * 0.8 + 0.1),
+                         float(torch.rand(1, generator=g) * 0.8 + 0.1), float(wh[0]), float(wh[1])])
+    rows[1][2:] = rows[0][2:]                                    # two objects on top of each other (different class): shared candidate cells
+    targets = torch.tensor(rows, dtype=torch.float32)
+    imgs = torch.zeros(B, 3, H, W)
+    crit.input_shape = (H, W)
+    crit.obj_ratio = 1 * (H * W) / (640 ** 2)
+    loss, box_l, obj_l, cls_l = crit(outs, targets.clone(), imgs)
+    loss.backward()
+    mine_in = [o.detach().clone().requires_grad_(True) for o in outs]
+    mine = Y7.yolo7_loss(mine_in, targets.clone(), float(H), nc, (H, W))
+    mine[0].backward()
+    for a_, b_ in zip(mine, (loss, box_l, obj_l, cls_l)):
+        assert abs(float(a_) - float(b_)) <= 1e-5 * max(abs(float(b_)), 1e-6), (float(a_), float(b_))
+    for a_, b_ in zip(mine_in, outs):
+        assert torch.allclose(a_.grad, b_.grad, rtol=1e-4, atol=1e-8), float((a_.grad - b_.grad).abs().max())
+    np.savez_compressed(os.path.join(GOLD, "yolov7_loss.npz"), nc=np.array(nc), hw=np.array([H, W]), targets=targets.numpy(),
+                        items=np.array([float(loss), float(box_l), float(obj_l), float(cls_l)]),
+                        **{f"out{i}": o.detach().numpy() for i, o in enumerate(outs)}, **{f"grad{i}": o.grad.numpy() for i, o in enumerate(outs)})
+    report["yolov7_loss"] = dict(items=[float(loss), float(box_l), float(obj_l), float(cls_l)], targets=len(rows))
+
+
 def main():
     sys.path.insert(0, ROOT)
     from oracle import yolov8_ref as O
@@ -836,6 +877,7 @@ def main():
                             detections=n_det, out_absmax=[float(o_.abs().max()) for o_ in ref7])
 
     yolov7_train_section(builder, report)
+    yolov7_loss_section(builder, report)
 
     # ---- 12. SSD300 VGG16-BN: init, priors, eval forward on a calibrated network, decode ----------------------
     from oracle import ssd_ref as SS
@@ -929,7 +971,7 @@ def only(section):
     builder = _import_reference()
     torch.set_num_threads(8)
     report = {}
-    {"deeplab_train": deeplab_train_section, "yolov7_train": yolov7_train_section, "centernet_train": centernet_train_section, "ssd_train": ssd_train_section, "centernet_loss": centernet_loss_section, "ssd_loss": ssd_loss_section, "ssd_targets": ssd_targets_section, "centernet_targets": centernet_targets_section}[section](builder, report)
+    {"deeplab_train": deeplab_train_section, "yolov7_train": yolov7_train_section, "centernet_train": centernet_train_section, "ssd_train": ssd_train_section, "centernet_loss": centernet_loss_section, "ssd_loss": ssd_loss_section, "ssd_targets": ssd_targets_section, "centernet_targets": centernet_targets_section, "yolov7_loss": yolov7_loss_section}[section](builder, report)
     path = os.path.join(GOLD, "PIN_REPORT.json")
     full = json.load(open(path)) if os.path.exists(path) else {}
     full.update(report)

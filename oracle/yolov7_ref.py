@@ -25,6 +25,7 @@ every parameter gradient of ``projection_loss`` against the real model's autogra
 """
 from __future__ import annotations
 
+import math
 from collections import OrderedDict
 
 import numpy as np
@@ -271,3 +272,164 @@ def loss_and_grads(sd, x, weights=None, seed: int = 9):
     loss = projection_loss(outs, weights)
     loss.backward()
     return loss.detach(), {k: p.grad for k, p in params.items() if p.grad is not None}, [o.detach() for o in outs]
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------------
+# Yolo7Loss (core/loss/yolo7_loss.py:14-444): candidate generation ("find_3_positive"), SimOTA assignment per image ("build_targets"),
+# CIoU / objectness / class terms.  Restated with explicit loops over candidates; pinned against the real class in make_golden.py (11c).
+STRIDES_LOSS = (32, 16, 8)
+BALANCE = (0.4, 1.0, 4.0)
+OFFSETS = ((0.0, 0.0), (0.5, 0.0), (0.0, 0.5), (-0.5, 0.0), (0.0, -0.5))
+
+
+def _level_anchors(level: int):
+    """anchors of a level in grid units, float32 (find_3_positive: torch.from_numpy(anchors[mask] / stride).type_as(pred))."""
+    a = np.asarray(ANCHORS, dtype=np.float64).reshape(-1, 2)[list(ANCHORS_MASK[level])] / STRIDES_LOSS[level]
+    return torch.from_numpy(a).float()
+
+
+def loss_candidates(targets, level_hw, threshold: float = 4.0):
+    """find_3_positive (:340-398): per level the ordered candidate list [(image, anchor, gj, gi, target row)] -- for each of the five cell
+    offsets in turn, every (anchor, target) pair whose size ratio to the anchor is below `threshold` and whose centre lies in the half of
+    its cell that faces the neighbour (and more than one cell away from the border on that side)."""
+    out = []
+    N = targets.shape[0]
+    for lv, (h, w) in enumerate(level_hw):
+        anc = _level_anchors(lv)
+        gain = torch.tensor([w, h, w, h], dtype=torch.float32)
+        t = targets[:, 2:6].float() * gain                                    # gx, gy, gw, gh in grid units
+        keep = []
+        for a in range(3):
+            r = t[:, 2:4] / anc[a]
+            ok = torch.max(r, 1.0 / r).max(1)[0] < threshold
+            keep += [(a, n) for n in range(N) if bool(ok[n])]
+        cands = []
+        for oi, (ox, oy) in enumerate(OFFSETS):
+            for a, n in keep:
+                gx, gy = t[n, 0], t[n, 1]
+                ix, iy = gain[0] - gx, gain[1] - gy
+                cond = (True, bool((gx % 1.0 < 0.5) & (gx > 1.0)), bool((gy % 1.0 < 0.5) & (gy > 1.0)), bool((ix % 1.0 < 0.5) & (ix > 1.0)),
+                        bool((iy % 1.0 < 0.5) & (iy > 1.0)))[oi]
+                if not cond:
+                    continue
+                gi = min(max(int((gx - ox).to(torch.int64)), 0), w - 1)
+                gj = min(max(int((gy - oy).to(torch.int64)), 0), h - 1)
+                cands.append((int(targets[n, 0]), a, gj, gi, n))
+        out.append(cands)
+    return out
+
+
+def simota_assign(preds, targets, cands, img_size: float, nc: int):
+    """build_targets (:129-338): per image, among its candidates of all levels, the SimOTA assignment.  Returns per level the ordered list of
+    matched (image, anchor, gj, gi, target row)."""
+    matched = [[] for _ in preds]
+    B = preds[0].shape[0]
+    for b in range(B):
+        rows = [n for n in range(targets.shape[0]) if int(targets[n, 0]) == b]
+        if not rows:
+            continue
+        tgt = targets[rows]
+        txywh = tgt[:, 2:6] * img_size                                        # imgs[b].shape[1] for all four coordinates
+        txyxy = torch.cat((txywh[:, :2] - txywh[:, 2:] / 2, txywh[:, :2] + txywh[:, 2:] / 2), 1)
+        entries, boxes, p_obj, p_cls = [], [], [], []
+        for lv, p in enumerate(preds):
+            anc = _level_anchors(lv)
+            for (cb, a, gj, gi, n) in cands[lv]:
+                if cb != b:
+                    continue
+                v = p[b, a, gj, gi]
+                grid = torch.tensor([gi, gj], dtype=v.dtype)
+                pxy = (v[:2].sigmoid() * 2.0 - 0.5 + grid) * STRIDES_LOSS[lv]
+                pwh = (v[2:4].sigmoid() * 2) ** 2 * anc[a] * STRIDES_LOSS[lv]
+                boxes.append(torch.cat((pxy - pwh / 2, pxy + pwh / 2)))
+                p_obj.append(v[4:5])
+                p_cls.append(v[5:])
+                entries.append((lv, cb, a, gj, gi))
+        if not entries:
+            continue
+        boxes, p_obj, p_cls = torch.stack(boxes), torch.stack(p_obj), torch.stack(p_cls)
+        G, C = txyxy.shape[0], boxes.shape[0]
+        lt, rb = torch.max(txyxy[:, None, :2], boxes[None, :, :2]), torch.min(txyxy[:, None, 2:], boxes[None, :, 2:])
+        inter = (rb - lt).clamp(min=0).prod(2)
+        area_t = ((txyxy[:, 2] - txyxy[:, 0]) * (txyxy[:, 3] - txyxy[:, 1]))[:, None]
+        area_p = ((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]))[None]
+        iou = inter / (area_t + area_p - inter)
+        topv, _ = torch.topk(iou, min(20, C), dim=1)
+        dyn_k = torch.clamp(topv.sum(1).int(), min=1)
+        onehot = F.one_hot(tgt[:, 1].long(), nc).float()[:, None, :].expand(G, C, nc)
+        y = (p_cls.float().sigmoid()[None] * p_obj.sigmoid()[None]).expand(G, C, nc).sqrt()
+        cls_cost = F.binary_cross_entropy_with_logits(torch.log(y / (1 - y)), onehot, reduction="none").sum(-1)
+        cost = cls_cost + 3.0 * (-torch.log(iou + 1e-8))
+        match = torch.zeros_like(cost)
+        for g in range(G):
+            _, pos = torch.topk(cost[g], k=int(dyn_k[g]), largest=False)
+            match[g][pos] = 1.0
+        multi = match.sum(0) > 1
+        if int(multi.sum()) > 0:
+            amin = torch.min(cost[:, multi], dim=0)[1]
+            match[:, multi] *= 0.0
+            match[amin, multi] = 1.0
+        fg = match.sum(0) > 0
+        gt_of = match[:, fg].argmax(0)
+        k = 0
+        for c in range(C):
+            if bool(fg[c]):
+                lv, cb, a, gj, gi = entries[c]
+                matched[lv].append((cb, a, gj, gi, rows[int(gt_of[k])]))
+                k += 1
+    return matched
+
+
+def _ciou_xywh(box, tbox, eps: float = 1e-7):
+    """yolo7_bbox_iou(box.T, tbox, x1y1x2y2=False, CIoU=True) (core/utils/iou.py:184-218); rows of (cx, cy, w, h)."""
+    b1x1, b1x2, b1y1, b1y2 = box[:, 0] - box[:, 2] / 2, box[:, 0] + box[:, 2] / 2, box[:, 1] - box[:, 3] / 2, box[:, 1] + box[:, 3] / 2
+    b2x1, b2x2, b2y1, b2y2 = tbox[:, 0] - tbox[:, 2] / 2, tbox[:, 0] + tbox[:, 2] / 2, tbox[:, 1] - tbox[:, 3] / 2, tbox[:, 1] + tbox[:, 3] / 2
+    inter = (torch.min(b1x2, b2x2) - torch.max(b1x1, b2x1)).clamp(0) * (torch.min(b1y2, b2y2) - torch.max(b1y1, b2y1)).clamp(0)
+    w1, h1, w2, h2 = b1x2 - b1x1, b1y2 - b1y1 + eps, b2x2 - b2x1, b2y2 - b2y1 + eps
+    union = w1 * h1 + w2 * h2 - inter + eps
+    iou = inter / union
+    cw, ch = torch.max(b1x2, b2x2) - torch.min(b1x1, b2x1), torch.max(b1y2, b2y2) - torch.min(b1y1, b2y1)
+    c2 = cw ** 2 + ch ** 2 + eps
+    rho2 = ((b2x1 + b2x2 - b1x1 - b1x2) ** 2 + (b2y1 + b2y2 - b1y1 - b1y2) ** 2) / 4
+    v = (4 / math.pi ** 2) * torch.pow(torch.atan(w2 / h2) - torch.atan(w1 / h1), 2)
+    with torch.no_grad():
+        alpha = v / (v - iou + (1 + eps))
+    return iou - (rho2 / c2 + v * alpha)
+
+
+def yolo7_loss(outs, targets, img_size: float, nc: int, input_hw=(640, 640), label_smoothing: float = 0.0):
+    """Yolo7Loss.__call__ (:38-127): outs = the three (B, 3*(5+nc), h, w) maps, coarsest first; targets (N, 6) [image, class, cx, cy, w, h]
+    normalised; img_size = imgs[b].shape[1].  Returns (total, box, obj, cls) with the reference's ratios applied."""
+    preds = [o.reshape(o.shape[0], 3, -1, o.shape[2], o.shape[3]).permute(0, 1, 3, 4, 2) for o in outs]
+    level_hw = [(p.shape[2], p.shape[3]) for p in preds]
+    with torch.no_grad():
+        cands = loss_candidates(targets, level_hw)
+        matched = simota_assign([p.detach() for p in preds], targets, cands, img_size, nc)
+    cp, cn = 1.0 - 0.5 * label_smoothing, 0.5 * label_smoothing
+    box_loss, obj_loss, cls_loss = torch.zeros(1), torch.zeros(1), torch.zeros(1)
+    for lv, p in enumerate(preds):
+        h, w = level_hw[lv]
+        tobj = torch.zeros_like(p[..., 0])
+        m = matched[lv]
+        if m:
+            b, a, gj, gi = (torch.tensor([e[k] for e in m]) for k in range(4))
+            tt = targets[[e[4] for e in m]]
+            pp = p[b, a, gj, gi]
+            anc = _level_anchors(lv)[a]
+            xy = pp[:, :2].sigmoid() * 2.0 - 0.5
+            wh = (pp[:, 2:4].sigmoid() * 2) ** 2 * anc
+            tbox = tt[:, 2:6] * torch.tensor([w, h, w, h], dtype=pp.dtype)
+            tbox = torch.cat((tbox[:, :2] - torch.stack([gi, gj], 1).to(pp.dtype), tbox[:, 2:]), 1)
+            iou = _ciou_xywh(torch.cat((xy, wh), 1), tbox)
+            box_loss = box_loss + (1.0 - iou).mean()
+            vals = iou.detach().clamp(0).to(tobj.dtype)
+            for k in range(len(m)):                                           # duplicates: the last entry of the list wins (index_put on the CPU)
+                tobj[b[k], a[k], gj[k], gi[k]] = vals[k]
+            t = torch.full_like(pp[:, 5:], cn)
+            t[range(len(m)), tt[:, 1].long()] = cp
+            cls_loss = cls_loss + F.binary_cross_entropy_with_logits(pp[:, 5:], t)
+        obj_loss = obj_loss + F.binary_cross_entropy_with_logits(p[..., 4], tobj) * BALANCE[lv]
+    box_loss = box_loss * 0.05
+    obj_loss = obj_loss * (1.0 * (input_hw[0] * input_hw[1]) / (640 ** 2))
+    cls_loss = cls_loss * (0.5 * (nc / 80))
+    return box_loss + obj_loss + cls_loss, box_loss, obj_loss, cls_loss

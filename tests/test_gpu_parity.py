@@ -2324,3 +2324,39 @@ def test_centernet_target_drawing_matches_the_reference_fixture(dev, gold):
     rows = torch.randn(B, h * w, ((nc + 7) & ~7) + 16, device=dev)
     items, _ = crit.op(rows, algo.draw_targets(labels), (h, w), 1.0)
     assert bool(torch.isfinite(items).all())
+
+
+def test_yolov7_loss_kernel_matches_the_reference_fixture(dev, gold):
+    """cvx_yolo7_loss against the REAL reference's Yolo7Loss + torch autograd (make_golden.py section 11c): random head outputs at 256 x 256,
+    an image with six objects (two on top of each other: shared candidate cells), an image with one, an image with none.  Candidate
+    generation, SimOTA assignment and the three terms on the device: the four loss values 2e-5, the gradient w.r.t. the head outputs
+    1e-3 (fp16 rounding of the scaled gradient; box / class gradients are accumulated with float atomics)."""
+    from computervision.pytorch_amd.yolov7 import Yolo7Loss
+    g = gold("yolov7_loss.npz")
+    nc, (H, W) = int(g["nc"]), (int(v) for v in g["hw"])
+    outs = [torch.from_numpy(g[f"out{i}"]) for i in range(3)]
+    grads = [torch.from_numpy(g[f"grad{i}"]) for i in range(3)]
+    B = outs[0].shape[0]
+    level_hw = [tuple(o.shape[2:]) for o in outs]
+    A, ld = sum(h * w for h, w in level_hw), 80
+    rows = torch.zeros(B, A, ld)
+    a_off = 0
+    for o, (h, w) in zip(outs, level_hw):
+        rows[:, a_off:a_off + h * w, :o.shape[1]] = o.permute(0, 2, 3, 1).reshape(B, h * w, -1)
+        a_off += h * w
+    crit = Yolo7Loss(None, nc, (H, W))
+    scale = 256.0
+    items, dpred = crit.op(rows.to(dev), level_hw, torch.from_numpy(g["targets"]), float(H), scale)
+    assert crit.overflowed() == 0
+    np.testing.assert_allclose(items.cpu().numpy(), g["items"], rtol=2e-5, atol=1e-7)
+    got = dpred.float().cpu() / scale
+    a_off = 0
+    for gr, (h, w) in zip(grads, level_hw):
+        want = gr.permute(0, 2, 3, 1).reshape(B, h * w, -1)
+        have = got[:, a_off:a_off + h * w, :want.shape[2]]
+        assert rel(have, want) < 1e-3, rel(have, want)
+        a_off += h * w
+    assert float(got[..., 75:].abs().max()) == 0.0
+    # no targets at all: only the objectness term
+    items0, _ = crit.op(rows.to(dev), level_hw, torch.zeros(0, 6), float(H), scale)
+    assert float(items0[1]) == 0.0 and float(items0[3]) == 0.0 and float(items0[2]) > 0.0
