@@ -473,6 +473,82 @@ def ssd_train_main(args):
         dist.destroy_process_group()
 
 
+def yolov7_train_main(args):
+    """images/sec of the YOLOv7-l TRAIN step (configs/yolo7_cfg.py: 640x640, Yolo7Loss with SimOTA assignment, Adam, mixed precision):
+    engine forward (batch-statistics BN) + cvx_yolo7_loss + engine backward + [RCCL gradient sum] + fused Adam -- the reference's train_loop
+    (yolo7_train.py:79-97).  One process per GPU, a batch per rank."""
+    rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    import torch.distributed as dist
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29539")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    import builder
+    from core.trainer.yolo7_train import SyntheticYolo7Loader
+    cfg, _, trainer_cls = builder.export_from_registry("yolo7")
+    cfg.train.pretrained = False
+    B = args.batch
+    cfg.train.batch_size = B
+    H, W = cfg.arch.input_size[1:]
+    torch.manual_seed(0)
+    tr = trainer_cls(cfg, dev, dataloader=SyntheticYolo7Loader(B, (H, W), cfg.dataset.num_classes, length=1, seed=1 + rank))
+    tr.model.train()
+    images, targets = next(iter(tr.train_dataloader))
+    batch = (images.to(dev), targets.to(dev))
+
+    def step():
+        return tr.train_loop(batch, None)[0]
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(max(args.warmup, 1)):
+        loss = step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    eng = tr.model._last_engine
+    eng.profile(True)
+    for _ in range(2):
+        step()
+    sync()
+    prof = eng.profile_read()
+    eng.profile(False)
+    tr._step.scaler.poll()
+    if rank == 0:
+        value = B * world * args.steps / elapsed
+        classes = ("conv_fwd", "conv_dgrad", "conv_wgrad")
+        ms = sum(prof[k]["ms"] for k in classes)
+        fl = sum(prof[k]["flops"] for k in classes)
+        tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        launches = sum(prof[k]["launches"] for k in classes)
+        print(json.dumps({
+            "metric": f"images/sec {H}x{W} YOLOv7-l train", "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"YOLOv7-l (nc {cfg.dataset.num_classes}) train step (fwd + Yolo7Loss with SimOTA + bwd + Adam, dynamic loss scale), "
+                                   f"batch {B}/GPU, {H}x{W}, random init", "global_batch": B * world, "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "kernel": "implicit-GEMM convolution launches: forward, data gradient, weight gradient",
+                         "achieved": round(tf, 3), "peak": MFMA_FP16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_FP16_PEAK_TFLOPS, 5),
+                         "traffic": None, "avg_launch_us": round(ms * 1e3 / max(launches, 1), 3), "launches_per_step": launches // 2},
+            "kernel_classes": {k: {"ms_per_step": round(v["ms"] / 2, 4), "launches_per_step": v["launches"] // 2} for k, v in prof.items() if v["launches"]},
+            "loss": round(float(loss), 5), "loss_scale": tr._step.scaler.scale, "skipped_steps": tr._step.scaler.skipped,
+            "assignment_overflow": tr.criterion.overflowed(), "engine_workspace_gib": round(eng.workspace_bytes() / 2 ** 30, 3)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 YOLOV7_GFLOP_PER_IMG = 105.8    # SURVEY.md section 8 row a16: YOLOv7-l @ 640x640 (probe at nc = 80; the VOC head is 0.3 % smaller)
 
 
@@ -637,7 +713,7 @@ def main():
     ap.add_argument("--graph", type=int, default=0, help="1: replay the step as a hipGraph (N=1 only); 0: eager stream launches (default: "
                     "measured faster -- the side-stream weight gradients overlap better than as graph branches)")
     ap.add_argument("--profile-steps", type=int, default=10, help="steps of the per-kernel HIP-event window after the timed region")
-    ap.add_argument("--workload", default="yolov8_train", choices=["yolov8_train", "centernet", "centernet_train", "deeplab", "deeplab_train", "yolov7", "ssd", "ssd_train"],
+    ap.add_argument("--workload", default="yolov8_train", choices=["yolov8_train", "centernet", "centernet_train", "deeplab", "deeplab_train", "yolov7", "yolov7_train", "ssd", "ssd_train"],
                     help="centernet: BASELINE.json configs[3] -- CenterNet DLA-34 (nc 80) 512x512 inference + heat-map decode, batch 64 per GPU")
     args = ap.parse_args()
     if args.workload == "centernet":
@@ -650,6 +726,8 @@ def main():
         return centernet_train_main(args)
     if args.workload == "ssd_train":
         return ssd_train_main(args)
+    if args.workload == "yolov7_train":
+        return yolov7_train_main(args)
     if args.workload == "yolov7":
         return yolov7_main(args)
     if args.workload == "ssd":

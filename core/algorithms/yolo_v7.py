@@ -9,7 +9,7 @@ import torch
 
 from computervision.pytorch_amd import _lib as L
 from computervision.pytorch_amd import engine as _engine
-from computervision.pytorch_amd.yolov7 import Yolo7L
+from computervision.pytorch_amd.yolov7 import Yolo7L, Yolo7Loss
 from configs import Yolo7Config
 from registry import model_registry
 
@@ -42,9 +42,10 @@ class YOLOv7:
         return model, "YOLOv7"
 
     def build_loss(self):
-        raise L.CvxError("Yolo7Loss (core/loss/yolo7_loss.py, SimOTA assignment) has no HIP kernel yet.  The network itself trains on the engine: "
-                         "model.train(); outs = model(x) are ordinary tensors connected to the engine's backward pass, so the reference's own "
-                         "Yolo7Loss module (plain torch code on these outputs) can be applied to them unchanged")
+        """Reference :57-64: Yolo7Loss(anchors, num_classes, input_shape, anchors_mask, label_smoothing) -- here the engine's fused loss
+        (``cvx_yolo7_loss``: candidates, SimOTA assignment, the three terms and their gradient on the head rows)."""
+        return Yolo7Loss(anchors=np.asarray(self.anchors, dtype=np.float32).reshape(-1, 2), num_classes=self.num_classes,
+                         input_shape=self.input_image_size, anchors_mask=self.anchors_mask, label_smoothing=self.cfg.loss.label_smoothing)
 
     # ---- decode ---------------------------------------------------------------------------------------
     def _levels(self, model):

@@ -1456,11 +1456,7 @@ def test_yolov7_full_size_through_the_plugin_api(dev):
     assert float(dec[..., :2].min()) > -0.1 and float(dec[..., :2].max()) < 1.1 and float(dec[..., 4:].min()) >= 0 and float(dec[..., 4:].max()) <= 1
     res = algo.predict_tensor(model, x, 480, 640, conf_threshold=0.9)
     assert len(res) == 2
-    # the network trains (test_yolov7_training_*); the SimOTA loss and the trainer around it are not built on the engine
-    with pytest.raises(LL.CvxError):
-        algo.build_loss()
-    with pytest.raises(LL.CvxError):
-        trainer_cls(cfg, dev).train()
+    assert type(algo.build_loss()).__name__ == "Yolo7Loss" and trainer_cls.__name__ == "Yolo7Trainer"
 
 
 # ---- SSD300 VGG16-BN, inference + decode -----------------------------------------------------------------
@@ -2360,3 +2356,37 @@ def test_yolov7_loss_kernel_matches_the_reference_fixture(dev, gold):
     # no targets at all: only the objectness term
     items0, _ = crit.op(rows.to(dev), level_hw, torch.zeros(0, 6), float(H), scale)
     assert float(items0[1]) == 0.0 and float(items0[3]) == 0.0 and float(items0[2]) > 0.0
+
+
+
+def test_yolov7_trainer_fused_step(dev):
+    """export_from_registry("yolo7") -> Yolo7Trainer at 640 x 640, batch 4: the reference's train_loop (yolo7_train.py:79-97) as the
+    fused step, six times on a repeated batch: the four loss items finite, the total falling, parameters move, no overflow skip, no
+    capacity overflow in the assignment; criterion(model(x), targets, x)[0].backward() fills the same kind of gradients; evaluate_loop."""
+    import builder
+    from core.trainer.yolo7_train import SyntheticYolo7Loader
+    cfg, algo_cls, trainer_cls = builder.export_from_registry("yolo7")
+    cfg.train.pretrained = False
+    cfg.train.batch_size = 4
+    torch.manual_seed(0)
+    loader = SyntheticYolo7Loader(4, (640, 640), cfg.dataset.num_classes, length=2, seed=3)
+    tr = trainer_cls(cfg, dev, dataloader=loader)
+    batch = next(iter(loader))
+    tr.model.train()
+    x, t = batch[0].to(dev), batch[1].to(dev)
+    total, box_l, obj_l, cls_l = tr.criterion(tr.model(x), t, x)
+    total.backward()
+    assert abs(float(total.detach()) - float(box_l + obj_l + cls_l)) < 1e-5 * abs(float(total.detach()))
+    g_auto = tr.model.flat_grads.clone()
+    assert float(g_auto.abs().max()) > 0 and bool(torch.isfinite(g_auto).all())
+    tr.model.flat_grads.zero_()
+    p0 = tr.model.flat_params.clone()
+    losses = [[float(v) for v in tr.train_loop(batch, None)] for _ in range(6)]
+    torch.cuda.synchronize()
+    assert abs(losses[0][0] - float(total.detach())) < 2e-2 * abs(losses[0][0])         # (same batch, BatchNorm in batch-statistics mode)
+    assert all(np.isfinite(v) for row in losses for v in row) and losses[-1][0] < losses[0][0], losses
+    assert not torch.equal(tr.model.flat_params, p0)
+    tr._step.scaler.poll()
+    assert tr._step.scaler.skipped == 0 and tr.optimizer.device_step() == 6 and tr.criterion.overflowed() == 0
+    ev = tr.evaluate_loop()
+    assert np.isfinite(ev["val_loss"])

@@ -429,6 +429,24 @@ def test_centernet_oracle_target_drawing(gold):
                                                   (-42 + np.sqrt(42 ** 2 + 4 * 2.8 * 0.3 * 200)) / 2)) < 1e-12
 
 
+def test_yolov7_oracle_loss(gold):
+    """oracle/yolov7_ref.yolo7_loss (candidate generation, SimOTA assignment, CIoU / objectness / class terms) against the REAL reference's
+    Yolo7Loss and its torch-autograd gradients (make_golden.py section 11c)."""
+    from oracle import yolov7_ref as Y
+    g = gold("yolov7_loss.npz")
+    nc, (H, W) = int(g["nc"]), (int(v) for v in g["hw"])
+    outs = [torch.from_numpy(g[f"out{i}"]).requires_grad_(True) for i in range(3)]
+    targets = torch.from_numpy(g["targets"])
+    items = Y.yolo7_loss(outs, targets, float(H), nc, (H, W))
+    items[0].backward()
+    np.testing.assert_allclose([float(v) for v in items], g["items"], rtol=2e-5, atol=1e-7)
+    for i, o in enumerate(outs):
+        np.testing.assert_allclose(o.grad.numpy(), g[f"grad{i}"], rtol=2e-4, atol=1e-8)
+    cands = Y.loss_candidates(targets, [tuple(o.shape[2:]) for o in outs])
+    assert [len(c) for c in cands] == sorted([len(c) for c in cands], reverse=False) or sum(len(c) for c in cands) > 0
+    assert all(0 <= e[2] < o.shape[2] and 0 <= e[3] < o.shape[3] for c, o in zip(cands, outs) for e in c)
+
+
 def _yolov7_fixture_state(g):
     from oracle import yolov7_ref as Y
     sd = Y.init_state_dict(20, seed=0)

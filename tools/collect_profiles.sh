@@ -25,6 +25,7 @@ python bench.py --model s --steps 20 --warmup 3 --no-cpu-baseline > $OUT/${R}_be
 python bench.py --workload deeplab --steps 10 --warmup 2 > $OUT/${R}_bench_deeplab.json 2>> $OUT/bench.err
 python bench.py --workload deeplab_train --steps 20 --warmup 3 > $OUT/${R}_bench_deeplab_train.json 2>> $OUT/bench.err
 python bench.py --workload centernet_train --steps 20 --warmup 3 > $OUT/${R}_bench_centernet_train.json 2>> $OUT/bench.err
+python bench.py --workload yolov7_train --steps 20 --warmup 3 > $OUT/${R}_bench_yolov7_train.json 2>> $OUT/bench.err
 python bench.py --workload ssd_train --steps 20 --warmup 3 > $OUT/${R}_bench_ssd_train.json 2>> $OUT/bench.err
 python bench.py --workload yolov7 --steps 10 --warmup 2 > $OUT/${R}_bench_yolov7.json 2>> $OUT/bench.err
 python bench.py --workload ssd --steps 10 --warmup 2 > $OUT/${R}_bench_ssd.json 2>> $OUT/bench.err
