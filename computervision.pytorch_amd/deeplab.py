@@ -560,7 +560,6 @@ class SegTrainStep:
 
     def __call__(self, images: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
         from .engine import check_finite
-        from .train import allreduce_mean_flat
         m, crit = self.model, self.criterion
         if not m.training:
             raise L.CvxError("SegTrainStep: call model.train() first")
@@ -576,11 +575,13 @@ class SegTrainStep:
         rows = m._run_forward(images, True, self._pred)
         crit.nc = m.num_classes
         loss, dpred = crit.op(rows, targets, (lh, lw), scale, self._dpred, check=False)   # no host sync in the step: crit.bad_targets() polls
-        eng.backward(dpred, scale)
-        if self.distributed and dev.type == "cuda":
+        if self.distributed and dev.type == "cuda":               # gradient exchange overlapped with the backward pass, bucket by bucket
             if self._side is None:
-                self._side = torch.cuda.Stream(device=dev, priority=-1)
-            allreduce_mean_flat(m.flat_grads, self.world, self.pg, self.n_buckets, self._side, average=False)
+                from .train import OverlappedExchange
+                self._side = OverlappedExchange(self.pg, self.n_buckets)
+            self._side.backward(eng, m.flat_grads, dpred, scale)
+        else:
+            eng.backward(dpred, scale)
         if self.scaler is not None:
             check_finite(m.flat_grads, self.scaler.found_inf)
             self.optimizer.found_inf = self.scaler.found_inf

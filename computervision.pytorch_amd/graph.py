@@ -394,3 +394,74 @@ def grad_buckets(g: Graph, lay: ParamLayout, n_buckets: int, tail_modules: int =
     for a, b in zip(out, out[1:]):
         assert b[0] == a[1] - 1 and b[3] == a[2], (a, b)  # ops and parameters both tile without gaps
     return out
+
+
+def op_param_interval(o):
+    """[start, end) of the flat parameter arena an op's trainable tensors occupy (weights, BatchNorm affine, bias), or None."""
+    t = o["type"]
+    iv = []
+    if t == L.OP_CONV:
+        cout = o["out"][2]
+        iv.append((o["w_off"], o["w_off"] + cout * o["k"] * o["k"] * o["w_cin"]))
+        act = o.get("act", 0)
+        if act in (L.ACT_BN_SILU, L.ACT_BN_RELU, L.ACT_BN_LINEAR):
+            iv += [(o["gamma_off"], o["gamma_off"] + cout), (o["beta_off"], o["beta_off"] + cout)]
+        if act in (L.ACT_BIAS, L.ACT_BIAS_RELU, L.ACT_BIAS_LINEAR) or (o.get("flags", 0) & L.OPF_CONV_BIAS):
+            iv.append((o["bias_off"], o["bias_off"] + cout))
+    elif t == L.OP_DWCONVT:
+        f = o["stride"]
+        iv.append((o["w_off"], o["w_off"] + o["in"][2] * 4 * f * f))
+    elif t == L.OP_L2NORM:
+        iv.append((o["gamma_off"], o["gamma_off"] + o["in"][2]))
+    if not iv:
+        return None
+    return min(a for a, _ in iv), max(b for _, b in iv)
+
+
+def generic_grad_buckets(g: Graph, n_buckets: int):
+    """``grad_buckets`` for any graph, from the ops' own parameter offsets: op ranges, in backward order, whose parameters form disjoint,
+    ordered slices of the flat arena -- ``[(op_hi, op_lo, p_start, p_end), ...]``, the units of the overlapped gradient exchange.  A cut
+    between op k and k + 1 is allowed where every parameter of ops <= k lies below every parameter of ops > k (layouts follow the
+    reference's state_dict order, which is not always op order: a Bottleneck's downsample runs before conv3 but is stored after it);
+    the atomic units between allowed cuts are grouped from the head backwards into ``n_buckets`` of similar parameter count.
+    Parameters no op touches (the reference's unused modules) have zero gradients on every rank and need no exchange."""
+    nops = len(g.ops)
+    iv = [op_param_interval(o) for o in g.ops]
+    INF = 1 << 62
+    pre_end, suf_start = [0] * nops, [INF] * (nops + 1)
+    run = 0
+    for k in range(nops):
+        if iv[k] is not None:
+            run = max(run, iv[k][1])
+        pre_end[k] = run
+    for k in range(nops - 1, -1, -1):
+        suf_start[k] = min(suf_start[k + 1], iv[k][0] if iv[k] is not None else INF)
+    units, lo = [], 0                                    # atomic units [op_lo, op_hi, p_start, p_end] in op order
+    for k in range(nops):
+        if k == nops - 1 or pre_end[k] <= suf_start[k + 1]:
+            ivs = [iv[q] for q in range(lo, k + 1) if iv[q] is not None]
+            if ivs:
+                units.append([lo, k, min(a for a, _ in ivs), max(b for _, b in ivs)])
+            elif units:
+                units[-1][1] = k                         # parameter-free ops ride with their predecessor
+            else:
+                units.append([lo, k, 0, 0])
+            lo = k + 1
+    units[0][0] = 0
+    total = sum(u[3] - u[2] for u in units)
+    n = max(1, min(int(n_buckets), len(units)))
+    groups, cur, acc = [], [], 0
+    for idx in range(len(units) - 1, -1, -1):            # backward order: the head first
+        cur.append(units[idx])
+        acc += units[idx][3] - units[idx][2]
+        left = n - len(groups) - 1
+        if left > 0 and (acc >= total / n or idx == left):
+            groups.append(cur)
+            cur, acc = [], 0
+    if cur:
+        groups.append(cur)
+    out = [(max(u[1] for u in b), min(u[0] for u in b), min(u[2] for u in b), max(u[3] for u in b)) for b in groups]
+    assert out[0][0] == nops - 1 and out[-1][1] == 0
+    for a, b in zip(out, out[1:]):
+        assert b[0] == a[1] - 1 and b[3] <= a[2], (a, b)  # ops tile without gaps; parameter slices are disjoint and ordered
+    return out

@@ -355,7 +355,7 @@ class SSD300VGG(nn.Module):
                     "conf")
         return loc, conf
 
-    def _backward_outputs(self, g_loc, g_conf, scale: Optional[float] = None):
+    def _backward_outputs(self, g_loc, g_conf, scale: Optional[float] = None, run_backward=None):
         """Gradients w.r.t. the flattened (B, tot*4) / (B, tot*(nc+1)) outputs -> loss_scale * dLoss/drows in fp16 -> engine backward."""
         eng, lay, lib = self._last_engine, self.layout, L.load()
         scale = self.loss_scale if scale is None else float(scale)
@@ -379,7 +379,10 @@ class SSD300VGG(nn.Module):
             self.flat_grads.zero_()
             self._grads_attached = False
         self.last_dpred = dpred
-        eng.backward(dpred, scale)
+        if run_backward is not None:                              # (the data-parallel step runs it bucket by bucket)
+            run_backward(eng, dpred, scale)
+        else:
+            eng.backward(dpred, scale)
         if not self._grads_attached or first.grad is None:
             self.attach_grads()
 
@@ -476,7 +479,6 @@ class SsdTrainStep:
 
     def __call__(self, images: torch.Tensor, y_true: torch.Tensor) -> torch.Tensor:
         from .engine import check_finite
-        from .train import allreduce_mean_flat
         m, crit = self.model, self.criterion
         if not m.training:
             raise L.CvxError("SsdTrainStep: call model.train() first")
@@ -487,11 +489,14 @@ class SsdTrainStep:
         loc, conf = m._rows_to_outputs(m.last_rows)
         scale = self.scaler.begin_step() if self.scaler is not None else m.loss_scale
         items, dloc, dconf = crit.op(loc.view(B, -1, 4), conf.view(B, -1, nc1), y_true)
-        m._backward_outputs(dloc.view(B, -1), dconf.view(B, -1), scale)
-        if self.distributed and dev.type == "cuda":
+        if self.distributed and dev.type == "cuda":               # gradient exchange overlapped with the backward pass, bucket by bucket
             if self._side is None:
-                self._side = torch.cuda.Stream(device=dev, priority=-1)
-            allreduce_mean_flat(m.flat_grads, self.world, self.pg, self.n_buckets, self._side, average=False)
+                from .train import OverlappedExchange
+                self._side = OverlappedExchange(self.pg, self.n_buckets)
+            m._backward_outputs(dloc.view(B, -1), dconf.view(B, -1), scale,
+                                run_backward=lambda eng, dpred, sc: self._side.backward(eng, m.flat_grads, dpred, sc))
+        else:
+            m._backward_outputs(dloc.view(B, -1), dconf.view(B, -1), scale)
         if self.scaler is not None:
             check_finite(m.flat_grads, self.scaler.found_inf)
             self.optimizer.found_inf = self.scaler.found_inf

@@ -337,6 +337,27 @@ def backward_with_overlapped_exchange(eng, buckets, g: torch.Tensor, dpred, loss
     eng.backward_end()
 
 
+class OverlappedExchange:
+    """The data-parallel backward of the engine-backed train steps other than YOLOv8's: buckets from the graph's own parameter offsets
+    (``graph.generic_grad_buckets``), each bucket's slice of the flat gradient arena SUM-all-reduced (RCCL) on a high-priority side stream
+    as soon as its op range has run, while the main stream runs the next range; the caller folds 1/world into the optimiser step."""
+
+    def __init__(self, process_group=None, n_buckets: int = 4):
+        self.pg, self.n_buckets = process_group, n_buckets
+        self._side = None
+        self._buckets, self._key = None, None
+
+    def backward(self, eng, flat_grads: torch.Tensor, dpred: torch.Tensor, loss_scale: float):
+        from .graph import generic_grad_buckets
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=flat_grads.device, priority=-1)
+        if self._key != id(eng):
+            self._buckets, self._key = generic_grad_buckets(eng.graph, self.n_buckets), id(eng)
+        cur = torch.cuda.current_stream(flat_grads.device)
+        backward_with_overlapped_exchange(eng, self._buckets, flat_grads, dpred, loss_scale, self.pg, self._side)
+        cur.wait_stream(self._side)
+
+
 def broadcast_bn_statistics(model: Yolo8, group=None, src: int = 0):
     """BatchNorm running statistics are per rank (the reference has no SyncBN) and drift apart; before a checkpoint is
     written every rank takes rank ``src``'s, so that a resumed job starts from ONE consistent model."""

@@ -576,7 +576,6 @@ class Yolo7TrainStep:
 
     def __call__(self, images: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
         from .engine import check_finite
-        from .train import allreduce_mean_flat
         m, crit = self.model, self.criterion
         if not m.training:
             raise L.CvxError("Yolo7TrainStep: call model.train() first")
@@ -589,11 +588,13 @@ class Yolo7TrainStep:
             self._dpred = torch.empty(rows.shape, device=dev, dtype=torch.float16)
         scale = self.scaler.begin_step() if self.scaler is not None else m.loss_scale
         items, dpred = crit.op(rows, eng.graph.level_hw, targets, float(images.shape[2]), scale, self._dpred)
-        eng.backward(dpred, scale)
-        if self.distributed and dev.type == "cuda":
+        if self.distributed and dev.type == "cuda":               # gradient exchange overlapped with the backward pass, bucket by bucket
             if self._side is None:
-                self._side = torch.cuda.Stream(device=dev, priority=-1)
-            allreduce_mean_flat(m.flat_grads, self.world, self.pg, self.n_buckets, self._side, average=False)
+                from .train import OverlappedExchange
+                self._side = OverlappedExchange(self.pg, self.n_buckets)
+            self._side.backward(eng, m.flat_grads, dpred, scale)
+        else:
+            eng.backward(dpred, scale)
         if self.scaler is not None:
             check_finite(m.flat_grads, self.scaler.found_inf)
             self.optimizer.found_inf = self.scaler.found_inf

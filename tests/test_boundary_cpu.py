@@ -250,3 +250,33 @@ def test_letterbox_geometry_and_oracle():
     assert t.dtype == np.float32 and t.shape == (3, 6, 6) and t[0, 0, 0] == np.float32(128) / np.float32(255)
     with pytest.raises(CvxError):
         letterbox_u8(torch.zeros(4, 4, 3, dtype=torch.uint8), torch.zeros(3, 8, 8))
+
+
+def test_generic_grad_buckets_on_every_graph():
+    """graph.generic_grad_buckets (the op ranges of the overlapped gradient exchange of the DeepLab / CenterNet / SSD / YOLOv7 steps): on
+    each model's graph the ranges tile the op list from the last op down to 0, their parameter slices are disjoint and ordered, every
+    op's parameters lie inside the slice of its own range, and for YOLOv8 they cover the arena exactly like its hand-made buckets."""
+    from computervision.pytorch_amd import deeplab, dla, graph, ssd, yolov7
+    from computervision.pytorch_amd.model import Yolo8
+    graphs = {
+        "deeplab": deeplab.build_deeplab_graph(deeplab.DeepLabLayout(21), 513, 513),
+        "dla": dla.build_dla_graph(dla.DlaLayout(20), 384, 384),
+        "yolov7": yolov7.build_yolov7_graph(yolov7.Yolo7Layout(20), 640, 640),
+        "ssd": ssd.build_ssd_graph(ssd.SsdLayout(20), 300, 300),
+    }
+    m8 = Yolo8("n", 80)
+    graphs["yolov8"] = graph.build_yolov8_graph(m8.layout, 640, 640)
+    for name, g in graphs.items():
+        for nb in (1, 4, 7):
+            b = graph.generic_grad_buckets(g, nb)
+            assert 1 <= len(b) <= nb and b[0][0] == len(g.ops) - 1 and b[-1][1] == 0, name
+            for (hi, lo, p0, p1), nxt in zip(b, list(b[1:]) + [None]):
+                assert hi >= lo and p1 >= p0
+                if nxt is not None:
+                    assert nxt[0] == lo - 1 and nxt[3] <= p0, (name, nb)
+                for o in g.ops[lo:hi + 1]:
+                    iv = graph.op_param_interval(o)
+                    assert iv is None or (p0 <= iv[0] and iv[1] <= p1), (name, o["name"])
+    own = graph.grad_buckets(graphs["yolov8"], m8.layout, 5)
+    gen = graph.generic_grad_buckets(graphs["yolov8"], 5)
+    assert gen[-1][2] == 0 and abs(gen[0][3] - own[0][3]) <= 4                # same arena extent (up to the 16-byte alignment of the last slot)

@@ -2390,3 +2390,48 @@ def test_yolov7_trainer_fused_step(dev):
     assert tr._step.scaler.skipped == 0 and tr.optimizer.device_step() == 6 and tr.criterion.overflowed() == 0
     ev = tr.evaluate_loop()
     assert np.isfinite(ev["val_loss"])
+
+
+def test_overlapped_exchange_of_the_other_train_steps_is_bit_identical(dev):
+    """CenterNet / SSD / YOLOv7 fused steps with an RCCL group of size 1: the backward pass cut into op ranges by
+    graph.generic_grad_buckets (from the ops' own parameter offsets), each range's slice of the gradient arena folded and all-reduced on
+    a side stream while the next range runs -- the same losses and parameters as the plain step, bit for bit."""
+    import torch.distributed as dist
+    from computervision.pytorch_amd.dla import CenterNetDLA34, CenterNetLoss, CenterNetTrainStep
+    from computervision.pytorch_amd.ssd import MultiBoxLoss, SSD300VGG, SsdTrainStep
+    from computervision.pytorch_amd.train import FlatAdam
+    from computervision.pytorch_amd.yolov7 import Yolo7L, Yolo7Loss, Yolo7TrainStep
+    from core.trainer.centernet_train import SyntheticCenterNetLoader
+    from core.trainer.ssd_train import SyntheticSsdLoader
+    from core.trainer.yolo7_train import SyntheticYolo7Loader
+    created = False
+    if not dist.is_initialized():
+        try:
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29615", rank=0, world_size=1, device_id=dev)
+            created = True
+        except Exception as exc:
+            pytest.skip(f"RCCL process group unavailable: {exc}")
+    cases = {
+        "centernet": (lambda: CenterNetDLA34(20), lambda m: CenterNetLoss(20), CenterNetTrainStep, SyntheticCenterNetLoader(2, (128, 160), 20, length=1, seed=2)),
+        "ssd": (lambda: SSD300VGG(20), lambda m: MultiBoxLoss(3, 20), SsdTrainStep, SyntheticSsdLoader(2, (300, 300), 20, length=1, seed=2)),
+        "yolov7": (lambda: Yolo7L(20), lambda m: Yolo7Loss(None, 20, (160, 224)), Yolo7TrainStep, SyntheticYolo7Loader(2, (160, 224), 20, length=1, seed=2)),
+    }
+    try:
+        for name, (make, crit, step_cls, loader) in cases.items():
+            images, targets = next(iter(loader))
+            images = images.to(dev)
+            targets = [t.to(dev) for t in targets] if isinstance(targets, list) else targets.to(dev)
+            runs = []
+            for distributed in (False, True):
+                torch.manual_seed(0)
+                m = make().to(dev).train()
+                step = step_cls(m, crit(m), FlatAdam(m, lr=1e-3), n_buckets=4)
+                step.distributed = distributed
+                losses = [step(images, targets).clone() for _ in range(3)]
+                torch.cuda.synchronize()
+                runs.append((torch.stack(losses).cpu(), m.flat_params.clone().cpu()))
+            assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]), name
+            assert bool(torch.isfinite(runs[0][0]).all()), name
+    finally:
+        if created:
+            dist.destroy_process_group()
