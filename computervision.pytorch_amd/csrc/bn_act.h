@@ -61,8 +61,7 @@ int cvx_bn_act_apply(const float* y, long long M, int C, int hw, const BnTrainAr
                      int res_pre, half_t* xhat, hipStream_t st);
 struct BnActKind {
   int act, res_pre;
-  ViewDesc fout;  // ReLU: the layer's forward output (its sign is the backward mask); SiLU + res_pre: the residual's forward value;
-                  // plain SiLU / none: must be {nullptr}
+  ViewDesc fout;  // SiLU + res_pre: the residual's forward value; else unused (ReLU's mask rides in the lowest bit of xhat)
 };
 // part (zero on entry) receives per-channel (sum y, sum y^2) of an fp32 [M][C] tensor -- the conv epilogues' job in the engine
 int cvx_bn_stats_f32(const float* y, long long M, int C, long long* part, hipStream_t st);

@@ -120,7 +120,6 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(const float* y, long 
       else
         f[i] = act_fwd<ACT>(x * ga[i] + be[i]);
     }
-    *reinterpret_cast<h8*>(xhat + m * C + cg * 8) = xh;
     if (!RES_PRE && res.p) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) f[i] += (float)rr[i];
@@ -128,6 +127,14 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(const float* y, long 
     h8 o;
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = (half_t)f[i];
+    if constexpr (ACT == 1) {
+      // ReLU: the backward mask [out > 0] rides in the lowest mantissa bit of the kept xhat (one ulp of a value the backward only
+      // uses in sums): the backward passes then need neither the output nor the pre-activation
+      unsigned short* xb = reinterpret_cast<unsigned short*>(&xh);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xb[i] = (unsigned short)((xb[i] & 0xFFFEu) | ((float)o[i] > 0.f ? 1u : 0u));
+    }
+    *reinterpret_cast<h8*>(xhat + m * C + cg * 8) = xh;
     *reinterpret_cast<h8*>(out.p + view_off(out, m, hw) + cg * 8) = o;
   };
   // UNR rows per trip with every load issued before the first use: the passes are latency-bound otherwise
@@ -155,9 +162,10 @@ struct Coef8 {
   float a[8], b[8];
 };
 
-// dz = g * act'(pre).  SiLU: pre = gamma * xhat + beta is recomputed from the kept xhat.  ReLU: the mask is the sign of the
-// layer's own fp16 forward OUTPUT (`fout`): recomputing the pre-activation from the rounded xhat would flip the mask of
-// ~2e-4 of the elements (|pre| below the fp16 rounding of xhat), a 1 % gradient error per layer.  fout = relu(pre (+res)).
+// dz = g * act'(pre).  SiLU: pre = gamma * xhat + beta is recomputed from the kept xhat.  ReLU: the mask is [out > 0] of the layer's
+// own fp16 forward output, kept in the lowest mantissa bit of xhat by the forward pass: recomputing the pre-activation from the
+// rounded xhat would flip the mask of ~2e-4 of the elements (|pre| below the fp16 rounding of xhat), a 1 % gradient error per layer,
+// and reading the output tensor again would cost 2 of the pass's ~8 bytes per element.
 // SiLU with a pre-activation residual (YOLOv7's RepConv, yolov7_model.py: silu(bn(conv3x3) + bn(conv1x1))): `fo` carries the residual
 // VALUE (the other branch's output) instead, and pre = gamma * xhat + beta + residual.
 template <int ACT>
@@ -192,7 +200,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const half_t* xhat, 
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         float xh = (float)v[i];
-        float dz = act_dz<ACT>((float)g[i], xh, s.a[i], s.b[i], (float)fo[i]);
+        const float fb = ACT == 1 ? (float)(reinterpret_cast<const unsigned short*>(&v)[i] & 1u) : (float)fo[i];  // ReLU: the mask bit of xhat
+        float dz = act_dz<ACT>((float)g[i], xh, s.a[i], s.b[i], fb);
         acc[0][i] += dz;
         acc[1][i] += dz * xh;
       }
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const half_t* xhat, 
       for (int q = 0; q < UNR; ++q) {
         v[q] = *reinterpret_cast<const h8*>(xhat + (m + q * RP) * C + cg * 8);
         g[q] = *reinterpret_cast<const h8*>(gout.p + view_off(gout, m + q * RP, hw) + cg * 8);
-        if constexpr (ACT == 1 || ACT == 3) fo[q] = *reinterpret_cast<const h8*>(fout.p + view_off(fout, m + q * RP, hw) + cg * 8);
+        if constexpr (ACT == 3) fo[q] = *reinterpret_cast<const h8*>(fout.p + view_off(fout, m + q * RP, hw) + cg * 8);
       }
 #pragma unroll
       for (int q = 0; q < UNR; ++q) one(v[q], g[q], fo[q]);
@@ -213,7 +222,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const half_t* xhat, 
       h8 v = *reinterpret_cast<const h8*>(xhat + m * C + cg * 8);
       h8 g = *reinterpret_cast<const h8*>(gout.p + view_off(gout, m, hw) + cg * 8);
       h8 fo = {};
-      if constexpr (ACT == 1 || ACT == 3) fo = *reinterpret_cast<const h8*>(fout.p + view_off(fout, m, hw) + cg * 8);
+      if constexpr (ACT == 3) fo = *reinterpret_cast<const h8*>(fout.p + view_off(fout, m, hw) + cg * 8);
       one(v, g, fo);
     }
   }
@@ -257,7 +266,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const half_t* xhat, l
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       float xh = (float)v[i];
-      float dz = act_dz<ACT>((float)g[i], xh, s.a[i], s.b[i], (float)fo[i]);
+      const float fb = ACT == 1 ? (float)(reinterpret_cast<const unsigned short*>(&v)[i] & 1u) : (float)fo[i];  // ReLU: the mask bit of xhat
+      float dz = act_dz<ACT>((float)g[i], xh, s.a[i], s.b[i], fb);
       o[i] = (half_t)(gi[i] * (dz - k1[i] - xh * k2[i]));
       if constexpr (RES_PRE) g[i] = (half_t)dz;
     }
@@ -279,7 +289,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const half_t* xhat, l
       v[q] = *reinterpret_cast<const h8*>(xhat + (m + q * RP) * C + cg * 8);
       g[q] = *reinterpret_cast<const h8*>(gout.p + view_off(gout, m + q * RP, hw) + cg * 8);
       if (rd_old) old[q] = *reinterpret_cast<const h8*>(gres.p + view_off(gres, m + q * RP, hw) + cg * 8);
-      if constexpr (ACT == 1 || ACT == 3) fo[q] = *reinterpret_cast<const h8*>(fout.p + view_off(fout, m + q * RP, hw) + cg * 8);
+      if constexpr (ACT == 3) fo[q] = *reinterpret_cast<const h8*>(fout.p + view_off(fout, m + q * RP, hw) + cg * 8);
     }
 #pragma unroll
     for (int q = 0; q < UNR; ++q) one(m + q * RP, v[q], g[q], old[q], fo[q]);
@@ -289,7 +299,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const half_t* xhat, l
     h8 g = *reinterpret_cast<const h8*>(gout.p + view_off(gout, m, hw) + cg * 8);
     h8 old = {}, fo = {};
     if (rd_old) old = *reinterpret_cast<const h8*>(gres.p + view_off(gres, m, hw) + cg * 8);
-    if constexpr (ACT == 1 || ACT == 3) fo = *reinterpret_cast<const h8*>(fout.p + view_off(fout, m, hw) + cg * 8);
+    if constexpr (ACT == 3) fo = *reinterpret_cast<const h8*>(fout.p + view_off(fout, m, hw) + cg * 8);
     one(m, v, g, old, fo);
   }
 }
@@ -470,7 +480,7 @@ int cvx_bn_stats_f32(const float* y, long long M, int C, long long* part, hipStr
 int cvx_bn_bwd_reduce(const half_t* xhat, long long M, int C, int hw, const BnCoef& k, const ViewDesc& gout, const BnActKind& ak, long long* part,
                       hipStream_t st) {
   CVX_TRY(check_c(C, M));
-  CVX_CHECK(ak.act >= 0 && ak.act <= 2 && (ak.act != 1 || ak.fout.p), "bn_bwd: ReLU needs the forward output view");
+  CVX_CHECK(ak.act >= 0 && ak.act <= 2, "bn_bwd: activation kind");
   CVX_CHECK(!(ak.act == 0 && ak.res_pre) || ak.fout.p, "bn_bwd: SiLU with a pre-activation residual needs the residual's forward value");
   int rows = cvx_stream_rows_per_block(M, C, 32);
   const dim3 grid(blocks_for(M, rows)), block(256);
@@ -489,7 +499,6 @@ int cvx_bn_bwd_apply(const half_t* xhat, long long M, int C, int hw, const BnCoe
                      float* dbeta, const ViewDesc& gout, const BnActKind& ak, half_t* dy, const ViewDesc& gres, int res_accumulate, hipStream_t st) {
   CVX_TRY(check_c(C, M));
   CVX_TRY(check_act(ak.act, ak.res_pre, gres.p != nullptr));
-  CVX_CHECK(ak.act != 1 || ak.fout.p, "bn_bwd: ReLU needs the forward output view");
   CVX_CHECK(!(ak.act == 0 && ak.res_pre) || ak.fout.p, "bn_bwd: SiLU with a pre-activation residual needs the residual's forward value");
   int rows = cvx_stream_rows_per_block(M, C, 32);
   const dim3 grid(blocks_for(M, rows)), block(256);

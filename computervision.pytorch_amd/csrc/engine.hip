@@ -1207,11 +1207,10 @@ int backward_op(cvx_engine* e, int i) {
       ViewDesc gout = make_view(e, o.out, true);
       ViewDesc gres = make_view(e, o.res, true);
       BnCoef k{c.invstd, e->params + o.gamma_off, e->params + o.beta_off};
-      // ReLU: the mask is the sign of the forward output; SiLU with a pre-activation residual: the residual's forward value
+      // SiLU with a pre-activation residual needs the residual's forward value (ReLU's mask rides in xhat's lowest bit)
       const bool pre = (o.flags & CVX_OPF_RES_PRE_ACT) != 0 && o.res.buf >= 0;
-      const BnActKind ak{act_kind(o), pre ? 1 : 0,
-                         act_kind(o) == 1 ? make_view(e, o.out, false) : (act_kind(o) == 0 && pre ? make_view(e, o.res, false) : ViewDesc{nullptr, 0, 0})};
-      ProfScope ps(e, PROF_BN_BWD, 0, (c.stem ? 4.0 : (gres.p ? 14.0 : 10.0) + (ak.act == 1 ? 4.0 : 0.0)) * M * C, st);
+      const BnActKind ak{act_kind(o), pre ? 1 : 0, act_kind(o) == 0 && pre ? make_view(e, o.res, false) : ViewDesc{nullptr, 0, 0}};
+      ProfScope ps(e, PROF_BN_BWD, 0, (c.stem ? 4.0 : (gres.p ? 14.0 : 10.0)) * M * C, st);
       static const bool tune_skip_reduce = cvx_tune_int("CVX_TUNE_SKIP_BN_REDUCE", 0) != 0;  // tuning build: timing without the pass (wrong results)
       if (!tune_skip_reduce) CVX_TRY(cvx_bn_bwd_reduce(c.ybuf, M, C, hw, k, gout, ak, c.stat_bwd, st));
       // the stem's "apply" half is fused into its weight gradient (cvx_stem_backward, queued below): dy is never materialised

@@ -57,7 +57,6 @@ extern "C" int cvx_bn_act_bwd_nhwc(const void* xhat_f16, const void* gout_f16, c
                                    const float* gamma, const float* beta, const float* invstd, int32_t act, int32_t res_pre, float inv_scale,
                                    float* dgamma, float* dbeta, void* dy_f16, void* gres_f16, int32_t res_accumulate, void* hip_stream) {
   CVX_CHECK(xhat_f16 && gout_f16 && gamma && beta && invstd && dgamma && dbeta && dy_f16 && batch > 0 && hw > 0, "bad arguments");
-  CVX_CHECK(act != 1 || out_f16, "ReLU: the forward output is needed (its sign is the mask)");
   CVX_CHECK(!(act == 0 && res_pre) || out_f16, "SiLU with a pre-activation residual: the residual's forward value is needed (pass it as out_f16)");
   const BnActKind ak{act, res_pre, out_f16 ? dense(out_f16, hw, c) : ViewDesc{nullptr, 0, 0}};
   hipStream_t st = (hipStream_t)hip_stream;

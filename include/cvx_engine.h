@@ -318,9 +318,10 @@ int cvx_bn_silu_bwd_nhwc(const void* xhat_f16, const void* gout_f16, int32_t bat
 /* The same two passes for the other Conv + BatchNorm blocks of the reference (C up to 2048).  act: 0 SiLU, 1 ReLU, 2 none.
  * res_pre = 1: the residual joins the PRE-activation, out = act(gamma*xhat + beta + res) (Bottleneck.forward, resnet.py:139-141:
  * out += identity; out = relu(out)) and gres receives the pre-activation gradient dz; res_pre = 0: out = act(.) + res, gres
- * receives gout.  ReLU's backward mask is the sign of the forward output `out_f16` (required for act = 1); SiLU with a pre-activation
- * residual (YOLOv7 RepConv: silu(bn(conv3x3) + bn(conv1x1)), yolov7_model.py:250-262) needs the residual's forward VALUE there instead;
- * otherwise out_f16 may be NULL.  ReLU with a post-activation residual is refused.
+ * receives gout.  ReLU's backward mask [out > 0] is kept by the forward pass in the lowest mantissa bit of xhat (so xhat of a ReLU layer is
+ * accurate to one fp16 ulp instead of half); SiLU with a pre-activation residual (YOLOv7 RepConv: silu(bn(conv3x3) + bn(conv1x1)),
+ * yolov7_model.py:250-262) needs the residual's forward VALUE in `out_f16`; otherwise out_f16 may be NULL.  ReLU with a post-activation
+ * residual is refused.
  * Replaces: nn.BatchNorm2d + nn.ReLU in training mode (resnet.py:121-143, deeplabv3plus.py:19-27,63-68) and their autograd. */
 int cvx_bn_act_train_nhwc(const float* y_f32, int32_t batch, int32_t hw, int32_t c, const float* gamma, const float* beta, float eps,
                           float momentum, float* running_mean, float* running_var, const void* res_f16, int32_t act, int32_t res_pre,
