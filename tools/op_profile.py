@@ -2,7 +2,7 @@
 cvx_engine_profile_dump records with the op list and prints, per (class, op), the mean time, algorithmic TF/s and GB/s, and the
 time the tighter of the two rooflines would allow.
 
-    python tools/op_profile.py [steps] [yolov8|deeplab] > gpurun_out/op_profile.txt
+    python tools/op_profile.py [steps] [yolov8|deeplab|yolo7|ssd|centernet] > gpurun_out/op_profile.txt
 """
 import collections
 import csv
@@ -22,6 +22,8 @@ def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     if len(sys.argv) > 2 and sys.argv[2] == "deeplab":
         return report(*deeplab_step(), steps)
+    if len(sys.argv) > 2 and sys.argv[2] in ("yolo7", "ssd", "centernet"):
+        return report(*trainer_step(sys.argv[2]), steps)
     from computervision.pytorch_amd.model import Yolo8
     from computervision.pytorch_amd.train import FlatAdam, FusedTrainStep, V8DetectionLoss
     from configs import Yolo8DetConfig
@@ -50,6 +52,24 @@ def deeplab_step():
     tr.model.train()
     images, targets = next(iter(tr.train_dataloader))
     batch = (images.to(dev), targets.to(dev))
+    for _ in range(3):
+        tr.train_loop(batch, None)
+    torch.cuda.synchronize()
+    return tr.model._last_engine, lambda: tr.train_loop(batch, None)
+
+
+def trainer_step(name):
+    """the fused train step of a registered trainer on one synthetic batch of its default configuration"""
+    import builder
+    dev = torch.device("cuda", 0)
+    cfg, _, trainer_cls = builder.export_from_registry(name)
+    cfg.train.pretrained = False
+    if name in ("yolo7", "ssd"):
+        cfg.train.batch_size = 32
+    torch.manual_seed(0)
+    tr = trainer_cls(cfg, dev)
+    tr.model.train()
+    batch = next(iter(tr.train_dataloader))
     for _ in range(3):
         tr.train_loop(batch, None)
     torch.cuda.synchronize()
