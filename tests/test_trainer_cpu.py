@@ -78,3 +78,34 @@ def test_checkpoint_round_trip_in_the_reference_format(tmp_path):
     CheckPoint.load_pure(bare, "cpu", m3)
     CheckPoint.load_pure(path, "cpu", m3)                       # either format
     assert torch.equal(m3.bias, model.bias)
+
+
+def test_checkpoint_interchange_of_the_engine_models(tmp_path):
+    """`.pth` interchange (core/utils/ckpt.py:38-75): every engine-backed model's state_dict has the reference's keys
+    (pinned in the per-model tests), so a checkpoint written by CheckPoint.save loads into a fresh model bit for bit -- through the
+    views of the flat arenas, including BatchNorm statistics and num_batches_tracked -- in both of the reference's file formats, and
+    FlatAdam's state travels with it."""
+    from computervision.pytorch_amd.deeplab import DeepLabV3PlusR101
+    from computervision.pytorch_amd.dla import CenterNetDLA34
+    from computervision.pytorch_amd.ssd import SSD300VGG
+    from computervision.pytorch_amd.train import FlatAdam
+    from computervision.pytorch_amd.yolov7 import Yolo7L
+    for i, make in enumerate((lambda: DeepLabV3PlusR101(21), lambda: CenterNetDLA34(20), lambda: SSD300VGG(20), lambda: Yolo7L(20))):
+        torch.manual_seed(i)
+        m = make()
+        with torch.no_grad():
+            m.flat_stats.add_(torch.rand_like(m.flat_stats))            # statistics that differ from a fresh model's
+            m._flat["nbt"] += 7
+        opt = FlatAdam(m, lr=3e-4)
+        path, bare = str(tmp_path / f"m{i}.pth"), str(tmp_path / f"m{i}_bare.pth")
+        CheckPoint.save(m, path, optimizer=opt)
+        CheckPoint.save(m, bare)
+        torch.manual_seed(100 + i)
+        m2 = make()
+        assert not torch.equal(m2.flat_params, m.flat_params)
+        CheckPoint.load(path, "cpu", m2, optimizer=FlatAdam(m2, lr=1e-3))
+        assert torch.equal(m2.flat_params, m.flat_params) and torch.equal(m2.flat_stats, m.flat_stats) and torch.equal(m2._flat["nbt"], m._flat["nbt"])
+        m3 = make()
+        CheckPoint.load_pure(bare, "cpu", m3)
+        sd, sd3 = m.state_dict(), m3.state_dict()
+        assert list(sd) == list(sd3) and all(torch.equal(sd[k], sd3[k]) for k in sd)
