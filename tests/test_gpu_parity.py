@@ -2435,3 +2435,47 @@ def test_overlapped_exchange_of_the_other_train_steps_is_bit_identical(dev):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_loss_kernels_edge_cases(dev):
+    """Degenerate inputs of the added loss kernels behave like the reference's torch code: (a) segmentation loss with every pixel
+    ignored -- focal: loss 0 and zero gradient (the mean still divides by all pixels), cross-entropy: nan loss (0 / 0, as
+    nn.CrossEntropyLoss) and zero gradient; (b) YOLOv7 loss with more ground truths in one image than the assignment kernel holds (64):
+    flagged through overflowed(), never silent, result finite; (c) MultiBoxLoss where every anchor of an image is positive (no negatives
+    to mine there) against the oracle."""
+    from computervision.pytorch_amd.deeplab import SegLoss
+    from computervision.pytorch_amd.ssd import MultiBoxLoss
+    from computervision.pytorch_amd.yolov7 import Yolo7Loss
+    from oracle import ssd_ref as S
+    g = torch.Generator().manual_seed(3)
+    rows = torch.randn(1, 9 * 9, 24, generator=g).to(dev)
+    t = torch.full((1, 33, 33), -100, dtype=torch.long, device=dev)
+    for kind in ("focal", "ce"):
+        crit = SegLoss(kind)
+        crit.nc = 21
+        loss, dpred = crit.op(rows, t, (9, 9), 1024.0)
+        assert float(dpred.float().abs().max()) == 0.0
+        ref = F.cross_entropy(torch.zeros(1, 21, 33, 33), t.cpu(), reduction="mean") if kind == "ce" else torch.zeros(())
+        assert (np.isnan(float(loss)) and bool(torch.isnan(ref))) if kind == "ce" else float(loss) == 0.0
+    # (b)
+    level_hw = [(4, 4), (8, 8), (16, 16)]
+    A = sum(h * w for h, w in level_hw)
+    rows7 = torch.randn(2, A, 80, generator=g).to(dev)
+    tg = torch.zeros(70, 6)
+    tg[:, 1] = torch.randint(0, 20, (70,), generator=g).float()
+    tg[:, 2:4] = torch.rand(70, 2, generator=g) * 0.8 + 0.1
+    tg[:, 4:6] = torch.rand(70, 2, generator=g) * 0.3 + 0.05
+    crit7 = Yolo7Loss(None, 20, (128, 128))
+    items, dp = crit7.op(rows7, level_hw, tg, 128.0, 64.0)
+    assert crit7.overflowed() & 1 and bool(torch.isfinite(items).all()) and bool(torch.isfinite(dp.float()).all())
+    items_ok, _ = crit7.op(rows7, level_hw, tg[:20], 128.0, 64.0)
+    assert crit7.overflowed() == 0 and bool(torch.isfinite(items_ok).all())
+    # (c)
+    B, Aa, nc = 2, 300, 20
+    y = S.synth_y_true(B, Aa, nc, 10, seed=4)
+    y[0, :, 4], y[0, :, 5], y[0, :, -1] = 0.0, 1.0, 1.0            # every anchor of image 0 is a positive of class 1
+    y[0, :, 6:-1] = 0.0
+    loc, conf = torch.randn(B, Aa, 4, generator=g), torch.randn(B, Aa, nc + 1, generator=g) * 2
+    want = S.multibox_loss(y, loc.clone().requires_grad_(True), conf.clone().requires_grad_(True), 3.0)
+    items, _, _ = MultiBoxLoss(3.0, nc).op(loc.to(dev), conf.to(dev), y.to(dev))
+    np.testing.assert_allclose(items.cpu().numpy(), [float(v) for v in want], rtol=2e-5)
