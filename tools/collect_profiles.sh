@@ -13,7 +13,11 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $ROOT/bench.py --no-cpu-baseline --steps 3 --warmup 2 --profile-steps 1 > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cn -- python $ROOT/bench.py --workload centernet --steps 5 --warmup 2 > $OUT/${R}_bench_centernet_under_rocprof.json 2> $OUT/stats_cn.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_dl -- python $ROOT/bench.py --workload deeplab_train --steps 5 --warmup 2 > $OUT/${R}_bench_deeplab_train_under_rocprof.json 2> $OUT/stats_dl.err
+for wl in centernet_train ssd_train yolov7_train; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$wl -- python $ROOT/bench.py --workload $wl --steps 5 --warmup 2 > $OUT/${R}_bench_${wl}_under_rocprof.json 2> $OUT/stats_$wl.err
+done
 cd $ROOT
+for wl in centernet_train ssd_train yolov7_train; do cp $(ls $OUT/stats_$wl/*/*_kernel_stats.csv | head -1) $OUT/${R}_bench_${wl}_kernel_stats.csv; done
 cp $(ls $OUT/stats/*/*_kernel_stats.csv | head -1) $OUT/${R}_bench_kernel_stats.csv
 cp $(ls $OUT/stats_cn/*/*_kernel_stats.csv | head -1) $OUT/${R}_bench_centernet_kernel_stats.csv
 cp $(ls $OUT/stats_dl/*/*_kernel_stats.csv | head -1) $OUT/${R}_bench_deeplab_train_kernel_stats.csv
@@ -31,5 +35,5 @@ python bench.py --workload yolov7 --steps 10 --warmup 2 > $OUT/${R}_bench_yolov7
 python bench.py --workload ssd --steps 10 --warmup 2 > $OUT/${R}_bench_ssd.json 2>> $OUT/bench.err
 python tools/op_profile.py 5 > $OUT/${R}_op_profile.txt 2>> $OUT/bench.err
 python tools/op_profile.py 3 deeplab > $OUT/${R}_op_profile_deeplab_train.txt 2>> $OUT/bench.err
-rm -rf $OUT/stats $OUT/stats_cn $OUT/stats_dl $OUT/pmc_fetch $OUT/pmc_write
+rm -rf $OUT/stats $OUT/stats_cn $OUT/stats_dl $OUT/stats_centernet_train $OUT/stats_ssd_train $OUT/stats_yolov7_train $OUT/pmc_fetch $OUT/pmc_write
 ls -la $OUT
