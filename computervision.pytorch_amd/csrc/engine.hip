@@ -431,6 +431,13 @@ int plan_batch(cvx_engine* e, int B, bool training) {
       }
       continue;
     }
+    if (o.type == CVX_OP_DWCONVT) {
+      if (training) {  // per-workgroup partial sums of the weight gradient
+        CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, cvx_dwconvt_bwd_scratch_floats((long long)B * o.ih * o.iw, o.in.c, o.stride) * 4));
+        e->pool[i].idx = (uint8_t*)p;
+      }
+      continue;
+    }
     if (o.type == CVX_OP_MAXPOOL5 || o.type == CVX_OP_MAXPOOL3S2 || o.type == CVX_OP_MAXPOOL3S1) {
       if (training) {  // argmax byte per output element: the operand of the backward gather
         CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, (long long)B * o.oh * o.ow * o.out.c));
@@ -1153,7 +1160,7 @@ int backward_op(cvx_engine* e, int i) {
     if (o.type == CVX_OP_DWCONVT) {
       ProfScope ps(e, PROF_MISC, 0, 4.0 * B * (o.ih * o.iw + o.oh * o.ow) * o.in.c, st);
       CVX_TRY(cvx_dwconvt_bwd(make_view(e, o.in, false), make_view(e, o.out, true), make_view(e, o.in, true), e->params + o.w_off,
-                              e->grads + o.w_off, w.inv_scale, B, o.ih, o.iw, o.in.c, o.stride, e->pool[i].in_accum, st));
+                              e->grads + o.w_off, w.inv_scale, B, o.ih, o.iw, o.in.c, o.stride, e->pool[i].in_accum, (float*)e->pool[i].idx, st));
       return 0;
     }
     if (o.type == CVX_OP_MAXPOOL2) {

@@ -25,9 +25,11 @@ int cvx_l2norm_bwd(const ViewDesc& in, const ViewDesc& gout, const ViewDesc& gin
 int cvx_nchw_cols_grad_to_pred_launch(const float* g, long long g_bstride, long long g_off, int C, int B, int A, int a_off, int HW, float scale,
                                       half_t* dpred, int ld, int col0, hipStream_t st);
 int cvx_add_slice(const ViewDesc& in, const ViewDesc& out, int B, int HW, int C, hipStream_t st);  // out += in
-// depthwise transposed conv (kernel 2f, stride f, padding f/2): data gradient into gin, weight gradient ACCUMULATED (x inv_scale) into dw fp32 [C][2f][2f]
+// depthwise transposed conv (kernel 2f, stride f, padding f/2): data gradient into gin, weight gradient ACCUMULATED (x inv_scale) into dw fp32 [C][2f][2f];
+// part: cvx_dwconvt_bwd_scratch_floats(B*IH*IW, C, f) floats of scratch (per-workgroup partial sums, summed in index order)
+long long cvx_dwconvt_bwd_scratch_floats(long long npix, int C, int f);
 int cvx_dwconvt_bwd(const ViewDesc& in, const ViewDesc& gout, const ViewDesc& gin, const float* w, float* dw, float inv_scale, int B, int IH, int IW,
-                    int C, int f, int accumulate, hipStream_t st);
+                    int C, int f, int accumulate, float* part, hipStream_t st);
 // conv + bias (+ ReLU) without BatchNorm: dy = gout (* [fout > 0]) dense fp16 [M][C]; dbias += inv_scale * column sums (part: zeroed replica slabs)
 int cvx_bias_act_bwd(const ViewDesc& gout, const ViewDesc& fout, int relu, long long M, int C, int hw, half_t* dy, long long* part, float inv_scale,
                      float* dbias, hipStream_t st);

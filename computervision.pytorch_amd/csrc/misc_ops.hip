@@ -615,40 +615,92 @@ __global__ void dwconvt_dgrad_kernel(ViewDesc gout, ViewDesc gin, const float* w
   for (int k = 0; k < 8; ++k) o[k] = (half_t)acc[k];
   *reinterpret_cast<h8*>(q) = o;
 }
-// Weight gradient: dw[c][ky][kx] += inv_scale * sum over (b, iy, ix) of in * gout at the tap's offset; one workgroup per (channel group,
-// tap), fixed-order tree over the pixels (deterministic), fp32 straight into the gradient arena (the master weights are fp32 [C][K][K]).
-__global__ __launch_bounds__(256) void dwconvt_wgrad_kernel(ViewDesc in, ViewDesc gout, float* dw, int B, int IH, int IW, int CG, int f,
-                                                            float inv_scale) {
-  __shared__ float red[256 * 8];
-  const int OH = IH * f, OW = IW * f, K = 2 * f, P = f / 2;
-  const int cg = blockIdx.x % CG, tap = blockIdx.x / CG;
-  const int ky = tap / K, kx = tap - ky * K;
-  float acc[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+// Weight gradient: dw[c][ky][kx] += inv_scale * sum over (b, iy, ix) of in * gout at the tap's offset.  Two launches, deterministic:
+// (1) a workgroup takes a run of input pixels, thread = (pixel lane, channel group) so that a pixel's channel row is one coalesced read,
+// 16 taps per blockIdx.y in registers, lanes folded through LDS in a fixed order -> part[block][tap][C]; (2) the blocks are summed in
+// index order.  With all taps in one group (f = 2, every up-layer of DLA-34 but one) the same pass also produces the data gradient
+// (DGRAD): both walk gout at the same K x K offsets of an input pixel, so gout is read once instead of twice.
+template <bool DGRAD>
+__global__ __launch_bounds__(256) void dwconvt_wgrad_part_kernel(ViewDesc in, ViewDesc gout, ViewDesc gin, const float* __restrict__ w, float* part,
+                                                                 int B, int IH, int IW, int CG, int f, int rows, int accumulate) {
+  __shared__ float sacc[4 * 256 * 8];
+  const int OH = IH * f, OW = IW * f, K = 2 * f, P = f / 2, KK = K * K, C = CG * 8;
+  const int RP = 256 / CG;
+  const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
+  const int tap0 = blockIdx.y * 16;
   const long long npix = (long long)B * IH * IW;
-  for (long long p = threadIdx.x; p < npix; p += 256) {
-    const int ix = (int)(p % IW);
-    long long t = p / IW;
-    const int iy = (int)(t % IH);
-    const int b = (int)(t / IH);
-    const int oy = iy * f - P + ky, ox = ix * f - P + kx;
-    if (oy < 0 || oy >= OH || ox < 0 || ox >= OW) continue;
-    const h8 v = *reinterpret_cast<const h8*>(in.p + voff(in, b, (long long)iy * IW + ix) + cg * 8);
-    const h8 g = *reinterpret_cast<const h8*>(gout.p + voff(gout, b, (long long)oy * OW + ox) + cg * 8);
+  const long long p0 = (long long)blockIdx.x * rows, p1 = p0 + rows < npix ? p0 + rows : npix;
+  float acc[16][8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = fmaf((float)v[k], (float)g[k], acc[k]);
-  }
+  for (int t = 0; t < 16; ++t)
 #pragma unroll
-  for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = acc[k];
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (threadIdx.x < s)
+    for (int k = 0; k < 8; ++k) acc[t][k] = 0.f;
+  if (pl < RP)
+    for (long long p = p0 + pl; p < p1; p += RP) {
+      const int ix = (int)(p % IW);
+      const long long q = p / IW;
+      const int iy = (int)(q % IH);
+      const int b = (int)(q / IH);
+      const h8 v = *reinterpret_cast<const h8*>(in.p + voff(in, b, (long long)iy * IW + ix) + cg * 8);
+      float d[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] += red[(threadIdx.x + s) * 8 + k];
+      for (int k = 0; k < 8; ++k) d[k] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int tap = tap0 + t;
+        const int ky = tap / K, kx = tap - ky * K;
+        const int oy = iy * f - P + ky, ox = ix * f - P + kx;
+        if (oy < 0 || oy >= OH || ox < 0 || ox >= OW) continue;
+        const h8 g = *reinterpret_cast<const h8*>(gout.p + voff(gout, b, (long long)oy * OW + ox) + cg * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[t][k] = fmaf((float)v[k], (float)g[k], acc[t][k]);
+        if (DGRAD) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) d[k] = fmaf((float)g[k], w[(long long)(cg * 8 + k) * KK + tap], d[k]);
+        }
+      }
+      if (DGRAD) {
+        half_t* gq = gin.p + voff(gin, b, (long long)iy * IW + ix) + cg * 8;
+        if (accumulate) {
+          const h8 old = *reinterpret_cast<const h8*>(gq);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) d[k] += (float)old[k];
+        }
+        h8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (half_t)d[k];
+        *reinterpret_cast<h8*>(gq) = o;
+      }
+    }
+  for (int r = 0; r < 4; ++r) {  // four taps per round through 32 KB of LDS
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sacc[(j * 256 + threadIdx.x) * 8 + k] = acc[r * 4 + j][k];
+    __syncthreads();
+    for (int o = threadIdx.x; o < 4 * C; o += 256) {
+      const int j = o / C, ch = o - j * C;
+      float sum = 0.f;
+      for (int l = 0; l < RP; ++l) sum += sacc[(j * 256 + l * CG + (ch >> 3)) * 8 + (ch & 7)];
+      part[((long long)blockIdx.x * KK + tap0 + r * 4 + j) * C + ch] = sum;
+    }
     __syncthreads();
   }
-  if (threadIdx.x < 8) dw[((long long)(cg * 8 + threadIdx.x) * K + ky) * K + kx] += red[threadIdx.x] * inv_scale;
+}
+__global__ void dwconvt_wgrad_fin_kernel(const float* __restrict__ part, int nblk, int KK, int C, float inv_scale, float* dw) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;  // (tap, channel), channel fastest: coalesced over the partial rows
+  if (o >= KK * C) return;
+  const int tap = o / C, ch = o - tap * C;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int blk = 0;
+  for (; blk + 4 <= nblk; blk += 4) {
+    s0 += part[(long long)(blk + 0) * KK * C + o];
+    s1 += part[(long long)(blk + 1) * KK * C + o];
+    s2 += part[(long long)(blk + 2) * KK * C + o];
+    s3 += part[(long long)(blk + 3) * KK * C + o];
+  }
+  for (; blk < nblk; ++blk) s0 += part[(long long)blk * KK * C + o];
+  dw[(long long)ch * KK + tap] += ((s0 + s1) + (s2 + s3)) * inv_scale;
 }
 
 // gradient of conv + bias (+ ReLU) blocks without BatchNorm (CenterNet heads, SSD extras): dy = g * [out > 0] (relu) or g, dense fp16,
@@ -1127,11 +1179,29 @@ int cvx_copy_slice(const ViewDesc& in, const ViewDesc& out, int B, int HW, int C
 int cvx_add_slice(const ViewDesc& in, const ViewDesc& out, int B, int HW, int C, hipStream_t st) {
   return launch1d(add_slice_kernel, (long long)B * HW * (C / 8), st, in, out, B, HW, C / 8);
 }
+// partial-sum geometry of the weight gradient: rows of input pixels per workgroup (a multiple of the pixel lanes), at most 256 workgroups
+static int dwconvt_rows(long long npix, int C) {
+  const int RP = 256 / (C / 8);
+  long long rows = (npix + 255) / 256;
+  rows = std::max<long long>(rows, 4LL * RP);
+  return (int)((rows + RP - 1) / RP * RP);
+}
+long long cvx_dwconvt_bwd_scratch_floats(long long npix, int C, int f) {
+  const int rows = dwconvt_rows(npix, C);
+  return (npix + rows - 1) / rows * 4LL * f * f * C;
+}
 int cvx_dwconvt_bwd(const ViewDesc& in, const ViewDesc& gout, const ViewDesc& gin, const float* w, float* dw, float inv_scale, int B, int IH, int IW,
-                    int C, int f, int accumulate, hipStream_t st) {
-  CVX_CHECK(f >= 2 && f % 2 == 0 && C % 8 == 0, "dwconvt_bwd: even stride, C % 8");
-  CVX_TRY(launch1d(dwconvt_dgrad_kernel, (long long)B * IH * IW * (C / 8), st, gout, gin, w, B, IH, IW, C / 8, f, accumulate));
-  hipLaunchKernelGGL(dwconvt_wgrad_kernel, dim3((C / 8) * 4 * f * f), dim3(256), 0, st, in, gout, dw, B, IH, IW, C / 8, f, inv_scale);
+                    int C, int f, int accumulate, float* part, hipStream_t st) {
+  CVX_CHECK(f >= 2 && f % 2 == 0 && C % 8 == 0 && C <= 2048 && part, "dwconvt_bwd: even stride, C % 8, C <= 2048, scratch");
+  const long long npix = (long long)B * IH * IW;
+  const int rows = dwconvt_rows(npix, C), nblk = (int)((npix + rows - 1) / rows), KK = 4 * f * f;
+  if (KK == 16) {
+    hipLaunchKernelGGL(dwconvt_wgrad_part_kernel<true>, dim3(nblk, 1), dim3(256), 0, st, in, gout, gin, w, part, B, IH, IW, C / 8, f, rows, accumulate);
+  } else {
+    CVX_TRY(launch1d(dwconvt_dgrad_kernel, npix * (C / 8), st, gout, gin, w, B, IH, IW, C / 8, f, accumulate));
+    hipLaunchKernelGGL(dwconvt_wgrad_part_kernel<false>, dim3(nblk, KK / 16), dim3(256), 0, st, in, gout, gin, w, part, B, IH, IW, C / 8, f, rows, 0);
+  }
+  hipLaunchKernelGGL(dwconvt_wgrad_fin_kernel, dim3((KK * C + 255) / 256), dim3(256), 0, st, part, nblk, KK, C, inv_scale, dw);
   CVX_HIP(hipGetLastError());
   return 0;
 }

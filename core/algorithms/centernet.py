@@ -1,9 +1,9 @@
 """CenterNet algorithm wrapper -- the duck-typed interface of the reference's ``CenterNetA``
 (core/algorithms/centernet.py:25-338) for the INFERENCE path: ``__init__(cfg, device)``, ``build_model() -> (nn.Module, name)``,
 ``decode_boxes(pred, h, w, conf_threshold=None) -> (boxes, scores, classes)``, ``predict``.  The DLA-34 network and the
-heat-map decode run on the MI355X engine (``computervision.pytorch_amd.dla``, ``cvx_centernet_decode``); the loss and
-``build_loss`` returns the engine's fused CombinedLoss; the heat-map target drawing (``generate_targets``, CPU work inside the
-reference's collate) is not built.
+heat-map decode run on the MI355X engine (``computervision.pytorch_amd.dla``, ``cvx_centernet_decode``); ``build_loss`` returns the
+engine's fused CombinedLoss; the heat-map target drawing (``generate_targets``, CPU work inside the reference's collate) is one
+launch for the whole batch (``draw_targets`` -> ``cvx_centernet_draw_targets``).
 """
 import numpy as np
 import torch
@@ -117,14 +117,8 @@ class CenterNetA:
             raise ImportError("predict() needs opencv-python for image I/O; use predict_tensor() with a prepared tensor") from e
         bgr = cv2.imread(image_path, cv2.IMREAD_COLOR | cv2.IMREAD_IGNORE_ORIENTATION)
         img = cv2.cvtColor(bgr, cv2.COLOR_BGR2RGB)
-        h, w, _ = img.shape
-        H, W = self.input_size
-        scale = min(H / h, W / w)
-        nh, nw = int(h * scale), int(w * scale)
-        img = cv2.resize(img, (nw, nh), interpolation=cv2.INTER_NEAREST)
-        top, left = (H - nh) // 2, (W - nw) // 2
-        img = cv2.copyMakeBorder(img, top, H - nh - top, left, W - nw - left, cv2.BORDER_CONSTANT, value=(128, 128, 128))
-        x = torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1).float().div(255.0).unsqueeze(0)
+        from core.utils.image_process import read_image_and_convert_to_tensor
+        x, h, w = read_image_and_convert_to_tensor(img, self.input_size, letterbox=self.letterbox_image, device=self.device)
         boxes, scores, classes = self.predict_tensor(model, x, h, w)
         for b, s_, c in zip(boxes, scores, classes):
             x1, y1, x2, y2 = (int(round(float(v))) for v in b)

@@ -157,16 +157,8 @@ class Ssd:
         """Reference :69-100: read + letterbox to 300 x 300, forward, decode, draw.  Image I/O needs OpenCV (lazy import)."""
         import cv2
         img = cv2.cvtColor(cv2.imread(image_path), cv2.COLOR_BGR2RGB)
-        h, w = img.shape[:2]
-        H, W = self.input_image_size
-        if self.letterbox_image:
-            s = min(H / h, W / w)
-            nh, nw = int(h * s), int(w * s)
-            canvas = np.full((H, W, 3), 128, dtype=np.uint8)
-            canvas[(H - nh) // 2:(H - nh) // 2 + nh, (W - nw) // 2:(W - nw) // 2 + nw] = cv2.resize(img, (nw, nh))
-        else:
-            canvas = cv2.resize(img, (W, H))
-        x = torch.from_numpy(canvas.astype(np.float32) / 255.0).permute(2, 0, 1).unsqueeze(0).to(self.device)
+        from core.utils.image_process import read_image_and_convert_to_tensor
+        x, h, w = read_image_and_convert_to_tensor(img, self.input_image_size, letterbox=self.letterbox_image, device=self.device)
         results = self.predict_tensor(model, x, h, w)
         out = cv2.cvtColor(img, cv2.COLOR_RGB2BGR)
         for x1, y1, x2, y2, cls, sc in (results[0] if len(results[0]) else []):

@@ -1898,6 +1898,9 @@ def test_letterbox_kernel_is_bit_exact(dev, h, w, H, W):
     assert torch.equal(x[0].cpu(), want)
     xs, _, _ = letter_box(img[:, :, ::-1], (H, W), device=dev, swap_rb=True)
     assert torch.equal(xs[0].cpu(), want)
+    from core.utils.image_process import read_image_and_convert_to_tensor
+    xr, rh, rw = read_image_and_convert_to_tensor(img, (H, W), letterbox=True, device=dev)     # what every predict() feeds its model
+    assert (rh, rw) == (h, w) and torch.equal(xr[0].cpu(), want)
     other = rng.integers(0, 256, (w + 1, h + 2, 3), dtype=np.uint8)
     batch = images_to_batch([img, other, img], (H, W), dev)
     assert torch.equal(batch[0].cpu(), want) and torch.equal(batch[2].cpu(), want)
