@@ -147,21 +147,28 @@ __global__ __launch_bounds__(256) void resize_grad_rows_kernel(const float* g, i
   bilinear_dst_range(x, sw, OW, &ox0, &ox1);
   const float* gp = g + ((long long)b * nc + c) * OH * OW;
   float accv = 0.f;
-  for (int oy = oy0; oy <= oy1; ++oy) {
-    int y0, y1;
-    float ly;
-    bilinear_src(oy, sh, ih, &y0, &y1, &ly);
-    const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
-    if (wy == 0.f) continue;
-    float row = 0.f;
-    for (int ox = ox0; ox <= ox1; ++ox) {
+  for (int oxc = ox0; oxc <= ox1; oxc += 16) {  // the column weights of up to 16 label columns once, then every label row against them
+    float wx[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
       int x0, x1;
       float lx;
-      bilinear_src(ox, sw, iw, &x0, &x1, &lx);
-      const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
-      if (wx != 0.f) row = fmaf(wx, gp[(long long)oy * OW + ox], row);
+      bilinear_src(oxc + j, sw, iw, &x0, &x1, &lx);
+      wx[j] = oxc + j <= ox1 ? (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f) : 0.f;
     }
-    accv = fmaf(wy, row, accv);
+    for (int oy = oy0; oy <= oy1; ++oy) {
+      int y0, y1;
+      float ly;
+      bilinear_src(oy, sh, ih, &y0, &y1, &ly);
+      const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
+      if (wy == 0.f) continue;
+      const float* gr = gp + (long long)oy * OW + oxc;
+      float row = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (wx[j] != 0.f) row = fmaf(wx[j], gr[j], row);
+      accv = fmaf(wy, row, accv);
+    }
   }
   const double denom = norm_mode == 0 ? norm_const : (acc[1] > 0.0 ? acc[1] : 1.0);
   *dst = (half_t)(accv * (float)((double)grad_scale / denom));

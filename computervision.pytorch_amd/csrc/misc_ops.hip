@@ -47,26 +47,27 @@ __global__ void maxpool2_kernel(ViewDesc in, ViewDesc out, int B, int IH, int IW
   *reinterpret_cast<h8*>(out.p + voff(out, b, (long long)h * OW + w) + cg * 8) = o;
 }
 
-// gradient of the 2x2 stride-2 max pool: the windows do not overlap, so every input pixel re-derives its own window's first maximum
-// (row-major scan, torch's rule) from the four forward inputs -- no argmax tensor.  Pixels outside every window (floor mode on an odd
-// size) receive zero.
+// gradient of the 2x2 stride-2 max pool: the windows do not overlap, so one thread owns a window -- it reads the four forward inputs once,
+// re-derives the first maximum (row-major scan, torch's rule; no argmax tensor) and writes all four input gradients.  Pixels outside
+// every window (floor mode on an odd size) belong to the threads of an extra window row / column and receive zero.
 __global__ void maxpool2_bwd_kernel(ViewDesc in, ViewDesc gout, ViewDesc gin, int B, int IH, int IW, int OH, int OW, int CG, int accumulate) {
+  const int WH = (IH + 1) >> 1, WW = (IW + 1) >> 1;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  long long n = (long long)B * IH * IW * CG;
+  long long n = (long long)B * WH * WW * CG;
   if (i >= n) return;
   int cg = (int)(i % CG);
   long long t = i / CG;
-  int ww = (int)(t % IW);
-  t /= IW;
-  int hh = (int)(t % IH);
-  int b = (int)(t / IH);
-  const int h = hh >> 1, w = ww >> 1;
-  float acc[8];
+  int w = (int)(t % WW);
+  t /= WW;
+  int h = (int)(t % WH);
+  int b = (int)(t / WH);
+  const bool window = h < OH && w < OW;
+  int bi[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-  if (h < OH && w < OW) {
+  for (int k = 0; k < 8; ++k) bi[k] = -1;
+  h8 g;
+  if (window) {
     float best[8];
-    int bi[8];
     bool first = true;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -83,22 +84,26 @@ __global__ void maxpool2_bwd_kernel(ViewDesc in, ViewDesc gout, ViewDesc gin, in
       }
       first = false;
     }
-    const int me = ((hh & 1) << 1) | (ww & 1);
-    const h8 g = *reinterpret_cast<const h8*>(gout.p + voff(gout, b, (long long)h * OW + w) + cg * 8);
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (bi[k] == me) acc[k] = (float)g[k];
+    g = *reinterpret_cast<const h8*>(gout.p + voff(gout, b, (long long)h * OW + w) + cg * 8);
   }
-  half_t* q = gin.p + voff(gin, b, (long long)hh * IW + ww) + cg * 8;
-  if (accumulate) {
-    const h8 old = *reinterpret_cast<const h8*>(q);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] += (float)old[k];
+  for (int q = 0; q < 4; ++q) {
+    const int y = 2 * h + (q >> 1), x = 2 * w + (q & 1);
+    if (y >= IH || x >= IW) continue;
+    half_t* dst = gin.p + voff(gin, b, (long long)y * IW + x) + cg * 8;
+    h8 o;
+    if (accumulate) {
+      if (!window) continue;
+      o = *reinterpret_cast<const h8*>(dst);
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (bi[k] == q) o[k] = (half_t)((float)o[k] + (float)g[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = (bi[k] == q) ? g[k] : (half_t)0.f;
+    }
+    *reinterpret_cast<h8*>(dst) = o;
   }
-  h8 o;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) o[k] = (half_t)acc[k];
-  *reinterpret_cast<h8*>(q) = o;
 }
 
 // ---- max pool 3x3 stride 2 pad 1 (ResNet stem, core/models/resnet.py:163) ----
@@ -349,12 +354,29 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(ViewDesc in, ViewDesc g
   for (int c = threadIdx.x; c < C; c += 256)
     partial[(long long)blockIdx.x * C + c] = (sdw[c] + sdw[512 + c]) + (sdw[1024 + c] + sdw[1536 + c]);
 }
-__global__ void l2norm_dw_kernel(const float* partial, int nblocks, int C, float inv_scale, float* dw) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float acc = 0.f;
-  for (int b = 0; b < nblocks; ++b) acc += partial[(long long)b * C + c];
-  dw[c] += acc * inv_scale;
+// 16 channels x 16 lanes per workgroup: lane j adds the workgroups j, j + 16, ... (four independent chains), the lanes are folded in order
+__global__ __launch_bounds__(256) void l2norm_dw_kernel(const float* __restrict__ partial, int nblocks, int C, float inv_scale, float* dw) {
+  __shared__ float red[256];
+  const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < C) {
+    int b = lane;
+    for (; b + 48 < nblocks; b += 64) {
+      a0 += partial[(long long)b * C + c];
+      a1 += partial[(long long)(b + 16) * C + c];
+      a2 += partial[(long long)(b + 32) * C + c];
+      a3 += partial[(long long)(b + 48) * C + c];
+    }
+    for (; b < nblocks; b += 16) a0 += partial[(long long)b * C + c];
+  }
+  red[lane * 16 + cl] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (threadIdx.x < 16 && c < C) {
+    float acc = 0.f;
+    for (int j = 0; j < 16; ++j) acc += red[j * 16 + cl];
+    dw[c] += acc * inv_scale;
+  }
 }
 
 // ---- global average pool (ASPPPooling's AdaptiveAvgPool2d(1), core/models/deeplabv3plus.py:30): one workgroup per
@@ -540,8 +562,16 @@ __global__ void resize_bilinear_f32_nchw_kernel(const float* in, int ld, int B, 
 
 // ---- depthwise ConvTranspose2d, kernel 2f, stride f, padding f/2 (IDAUp.up_i, centernet_model.py:256): every output pixel
 // receives exactly 2 x 2 taps.  w: fp32 [C][2f][2f] (the master tensor), out = sum_{ky,kx} in[(oy + p - ky) / f][..] * w[c][ky][kx] ----
-__global__ void dwconvt_kernel(ViewDesc in, ViewDesc out, const float* w, int B, int IH, int IW, int CG, int f) {
-  const int OH = IH * f, OW = IW * f, K = 2 * f, P = f / 2;
+// The taps live in LDS as [tap][C] (a thread's 8 channels contiguous) when they fit 32 KB; the master layout [C][K][K] would cost 8 scattered
+// 4-byte loads per tap.
+__global__ __launch_bounds__(256) void dwconvt_kernel(ViewDesc in, ViewDesc out, const float* __restrict__ w, int B, int IH, int IW, int CG, int f) {
+  __shared__ float sw[8192];
+  const int OH = IH * f, OW = IW * f, K = 2 * f, P = f / 2, KK = K * K, C = CG * 8;
+  const bool staged = C * KK <= 8192;
+  if (staged) {
+    for (int j = threadIdx.x; j < C * KK; j += 256) sw[(j % KK) * C + j / KK] = w[j];
+    __syncthreads();
+  }
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long n = (long long)B * OH * OW * CG;
   if (i >= n) return;
@@ -566,8 +596,14 @@ __global__ void dwconvt_kernel(ViewDesc in, ViewDesc out, const float* w, int B,
       const int ix = (ox + P - kx) / f;
       if (kx >= K || ix < 0 || ix >= IW) continue;
       const h8 v = *reinterpret_cast<const h8*>(in.p + voff(in, b, (long long)iy * IW + ix) + cg * 8);
+      if (staged) {
+        const float* wl = sw + (ky * K + kx) * C + cg * 8;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) acc[k] = fmaf((float)v[k], w[((long long)(cg * 8 + k) * K + ky) * K + kx], acc[k]);
+        for (int k = 0; k < 8; ++k) acc[k] = fmaf((float)v[k], wl[k], acc[k]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = fmaf((float)v[k], w[((long long)(cg * 8 + k) * K + ky) * K + kx], acc[k]);
+      }
     }
   }
   h8 o;
@@ -635,6 +671,10 @@ __global__ __launch_bounds__(256) void dwconvt_wgrad_part_kernel(ViewDesc in, Vi
   for (int t = 0; t < 16; ++t)
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[t][k] = 0.f;
+  if (DGRAD) {  // the 16 taps as [tap][C] in the LDS the fold uses afterwards (C <= 512, checked by the launcher)
+    for (int j = threadIdx.x; j < C * 16; j += 256) sacc[(j & 15) * C + (j >> 4)] = w[j];
+    __syncthreads();
+  }
   if (pl < RP)
     for (long long p = p0 + pl; p < p1; p += RP) {
       const int ix = (int)(p % IW);
@@ -655,8 +695,9 @@ __global__ __launch_bounds__(256) void dwconvt_wgrad_part_kernel(ViewDesc in, Vi
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[t][k] = fmaf((float)v[k], (float)g[k], acc[t][k]);
         if (DGRAD) {
+          const float* wl = sacc + tap * C + cg * 8;
 #pragma unroll
-          for (int k = 0; k < 8; ++k) d[k] = fmaf((float)g[k], w[(long long)(cg * 8 + k) * KK + tap], d[k]);
+          for (int k = 0; k < 8; ++k) d[k] = fmaf((float)g[k], wl[k], d[k]);
         }
       }
       if (DGRAD) {
@@ -672,6 +713,7 @@ __global__ __launch_bounds__(256) void dwconvt_wgrad_part_kernel(ViewDesc in, Vi
         *reinterpret_cast<h8*>(gq) = o;
       }
     }
+  if (DGRAD) __syncthreads();
   for (int r = 0; r < 4; ++r) {  // four taps per round through 32 KB of LDS
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -1097,7 +1139,7 @@ int cvx_maxpool2(const ViewDesc& in, const ViewDesc& out, int B, int IH, int IW,
 int cvx_maxpool2_bwd(const ViewDesc& in, const ViewDesc& gout, const ViewDesc& gin, int B, int IH, int IW, int OH, int OW, int C, int accumulate,
                      hipStream_t st) {
   CVX_CHECK(C % 8 == 0 && (OH == IH / 2 || OH == (IH + 1) / 2) && (OW == IW / 2 || OW == (IW + 1) / 2), "maxpool2_bwd: C % 8 / output size");
-  return launch1d(maxpool2_bwd_kernel, (long long)B * IH * IW * (C / 8), st, in, gout, gin, B, IH, IW, OH, OW, C / 8, accumulate);
+  return launch1d(maxpool2_bwd_kernel, (long long)B * ((IH + 1) / 2) * ((IW + 1) / 2) * (C / 8), st, in, gout, gin, B, IH, IW, OH, OW, C / 8, accumulate);
 }
 int cvx_l2norm(const ViewDesc& in, const ViewDesc& out, const float* weight, int B, int HW, int C, hipStream_t st) {
   CVX_CHECK(C % 8 == 0 && weight, "l2norm: C % 8 / weight");
@@ -1114,7 +1156,7 @@ int cvx_l2norm_bwd(const ViewDesc& in, const ViewDesc& gout, const ViewDesc& gin
   const int nblocks = cvx_l2norm_bwd_blocks(npix);
   const int per_wave = (int)((npix + (long long)nblocks * 4 - 1) / ((long long)nblocks * 4));
   hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(nblocks), dim3(256), 0, st, in, gout, gin, weight, npix, HW, C, per_wave, accumulate, partial);
-  hipLaunchKernelGGL(l2norm_dw_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial, nblocks, C, inv_scale, dweight);
+  hipLaunchKernelGGL(l2norm_dw_kernel, dim3((C + 15) / 16), dim3(256), 0, st, partial, nblocks, C, inv_scale, dweight);
   CVX_HIP(hipGetLastError());
   return 0;
 }
@@ -1195,7 +1237,7 @@ int cvx_dwconvt_bwd(const ViewDesc& in, const ViewDesc& gout, const ViewDesc& gi
   CVX_CHECK(f >= 2 && f % 2 == 0 && C % 8 == 0 && C <= 2048 && part, "dwconvt_bwd: even stride, C % 8, C <= 2048, scratch");
   const long long npix = (long long)B * IH * IW;
   const int rows = dwconvt_rows(npix, C), nblk = (int)((npix + rows - 1) / rows), KK = 4 * f * f;
-  if (KK == 16) {
+  if (KK == 16 && C <= 512) {
     hipLaunchKernelGGL(dwconvt_wgrad_part_kernel<true>, dim3(nblk, 1), dim3(256), 0, st, in, gout, gin, w, part, B, IH, IW, C / 8, f, rows, accumulate);
   } else {
     CVX_TRY(launch1d(dwconvt_dgrad_kernel, npix * (C / 8), st, gout, gin, w, B, IH, IW, C / 8, f, accumulate));
