@@ -509,8 +509,13 @@ int plan_batch(cvx_engine* e, int B, bool training) {
           int gx, gy;
           cvx_conv_wgrad_halo_grid(C, c.cin_g, &gx, &gy);
           const long long ptiles = cvx_conv_wgrad_halo_tiles(B, o.oh, o.ow);
-          static const long long wh_blocks = cvx_tune_int("CVX_WH_BLOCKS", 128);  // measured: 128 beats 64/256/512 (slab volume vs. parallelism)
+          // split count by the layer's work: 128 workgroups for the small layers (YOLOv8-n: 128 beats 64/256/512 -- slab volume vs.
+          // parallelism), 512 from 8 GFLOP up (SSD300's 150^2 / 300^2 layers: -9 % on the whole step; tools/sweeps/sweep_wh.sh, sweep_wh2.sh)
+          static const long long wh_small = cvx_tune_int("CVX_WH_BLOCKS", 128), wh_big = cvx_tune_int("CVX_WH_BLOCKS_BIG", 512);
+          static const long long wh_big_gf = cvx_tune_int("CVX_WH_BIG_GF", 8);
           static const long long wh_slab_mb = cvx_tune_int("CVX_WH_SLAB_MB", 16);
+          const double gflop = 2.0 * (double)M * C * c.cin_g * c.ntaps * 1e-9;
+          const long long wh_blocks = gflop >= (double)wh_big_gf ? wh_big : wh_small;
           ns = std::max<long long>(1, wh_blocks / ((long long)gx * gy));
           ns = std::min(ns, ptiles);
           ns = std::min(ns, std::max<long long>(1, (wh_slab_mb << 20) / (slab_elems * 4)));
