@@ -35,5 +35,8 @@ python bench.py --workload yolov7 --steps 10 --warmup 2 > $OUT/${R}_bench_yolov7
 python bench.py --workload ssd --steps 10 --warmup 2 > $OUT/${R}_bench_ssd.json 2>> $OUT/bench.err
 python tools/op_profile.py 5 > $OUT/${R}_op_profile.txt 2>> $OUT/bench.err
 python tools/op_profile.py 3 deeplab > $OUT/${R}_op_profile_deeplab_train.txt 2>> $OUT/bench.err
+python tools/op_profile.py 3 ssd > $OUT/${R}_op_profile_ssd_train.txt 2>> $OUT/bench.err
+python tools/op_profile.py 3 yolo7 > $OUT/${R}_op_profile_yolov7_train.txt 2>> $OUT/bench.err
+python tools/op_profile.py 3 centernet > $OUT/${R}_op_profile_centernet_train.txt 2>> $OUT/bench.err
 rm -rf $OUT/stats $OUT/stats_cn $OUT/stats_dl $OUT/stats_centernet_train $OUT/stats_ssd_train $OUT/stats_yolov7_train $OUT/pmc_fetch $OUT/pmc_write
 ls -la $OUT
