@@ -115,6 +115,8 @@ PROTOTYPES = {
     "cvx_maxpool3_bwd_nhwc": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P]),
     "cvx_l2norm_bwd_nhwc": (_I32, [_P, _P, _P, _I32, _I32, _I32, _F, _P, _P, _I32, _P]),
     "cvx_nchw_cols_grad_to_pred": (_I32, [_P, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _F, _P, _I32, _I32, _P]),
+    "cvx_dwconvt_nhwc": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
+    "cvx_dwconvt_bwd_nhwc": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _P, _F, _P]),
     "cvx_maxpool2_bwd_nhwc": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P]),
     "cvx_avgpool_global_bwd_nhwc": (_I32, [_P, _I32, _I32, _I32, _P, _I32, _P]),
     "cvx_resize_bilinear_bwd_nhwc": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P]),

@@ -175,6 +175,25 @@ extern "C" int cvx_maxpool2_bwd_nhwc(const void* x_f16, const void* gout_f16, in
   CVX_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
   return 0;
 }
+extern "C" int cvx_dwconvt_nhwc(const void* x_f16, int32_t batch, int32_t ih, int32_t iw, int32_t c, int32_t f, const float* weight, void* out_f16,
+                                void* hip_stream) {
+  CVX_CHECK(x_f16 && weight && out_f16 && batch > 0 && c % 8 == 0 && f >= 2 && f % 2 == 0, "bad arguments (channels in multiples of 8, even stride)");
+  CVX_TRY(cvx_dwconvt(dense(x_f16, ih * iw, c), dense(out_f16, ih * f * iw * f, c), weight, batch, ih, iw, c, f, (hipStream_t)hip_stream));
+  CVX_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
+  return 0;
+}
+extern "C" int cvx_dwconvt_bwd_nhwc(const void* x_f16, const void* gout_f16, int32_t batch, int32_t ih, int32_t iw, int32_t c, int32_t f,
+                                    const float* weight, void* gin_f16, int32_t accumulate, float* dweight, float inv_scale, void* hip_stream) {
+  CVX_CHECK(x_f16 && gout_f16 && weight && gin_f16 && dweight && batch > 0 && c % 8 == 0 && f >= 2 && f % 2 == 0,
+            "bad arguments (channels in multiples of 8, even stride)");
+  float* part = nullptr;
+  CVX_HIP(hipMalloc((void**)&part, (size_t)cvx_dwconvt_bwd_scratch_floats((long long)batch * ih * iw, c, f) * 4));
+  int rc = cvx_dwconvt_bwd(dense(x_f16, ih * iw, c), dense(gout_f16, ih * f * iw * f, c), dense(gin_f16, ih * iw, c), weight, dweight, inv_scale, batch,
+                           ih, iw, c, f, accumulate, part, (hipStream_t)hip_stream);
+  (void)hipStreamSynchronize((hipStream_t)hip_stream);
+  (void)hipFree(part);
+  return rc;
+}
 extern "C" int cvx_avgpool_global_bwd_nhwc(const void* gout_f16, int32_t batch, int32_t hw, int32_t c, void* gin_f16, int32_t accumulate,
                                            void* hip_stream) {
   CVX_CHECK(gout_f16 && gin_f16 && batch > 0 && c % 8 == 0, "bad arguments (channels in multiples of 8)");

@@ -451,6 +451,13 @@ int cvx_nchw_cols_grad_to_pred(const float* grad, int64_t grad_bstride, int64_t 
  * window in row-major scan order takes the gradient (torch's rule).  Replaces: nn.MaxPool2d(2, 2) autograd (yolov7_model.py:74-86). */
 int cvx_maxpool2_bwd_nhwc(const void* x_f16, const void* gout_f16, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t ceil_mode,
                           void* gin_f16, int32_t accumulate, void* hip_stream);
+/* Depthwise ConvTranspose2d of CenterNet's IDAUp.up_i (kernel 2f, stride f, padding f/2, groups = c, no bias; centernet_model.py:256) on a dense
+ * NHWC fp16 tensor, and its gradients: gin (+)= data gradient, dweight[c][2f][2f] += inv_scale * weight gradient (fp32, deterministic).
+ * weight: fp32 [c][2f][2f] (the master tensor).  Replaces: nn.ConvTranspose2d forward + autograd. */
+int cvx_dwconvt_nhwc(const void* x_f16, int32_t batch, int32_t ih, int32_t iw, int32_t c, int32_t f, const float* weight, void* out_f16,
+                     void* hip_stream);
+int cvx_dwconvt_bwd_nhwc(const void* x_f16, const void* gout_f16, int32_t batch, int32_t ih, int32_t iw, int32_t c, int32_t f, const float* weight,
+                         void* gin_f16, int32_t accumulate, float* dweight, float inv_scale, void* hip_stream);
 int cvx_resize_bilinear_bwd_nhwc(const void* gout_f16, int32_t batch, int32_t ih, int32_t iw, int32_t c, int32_t oh, int32_t ow, void* gin_f16,
                                  int32_t accumulate, void* hip_stream);
 int cvx_dropout_nhwc(const void* x_f16, int32_t batch, int32_t hw, int32_t c, float p, uint64_t seed, void* out_f16, int32_t accumulate,

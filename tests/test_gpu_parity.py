@@ -71,6 +71,41 @@ CONV_CASES = [(2, 16, 16, 16, 16, 3, 1), (2, 20, 20, 8, 16, 3, 2), (1, 24, 24, 3
               (1, 80, 80, 128, 32, 3, 1), (4, 20, 20, 128, 128, 3, 1), (1, 160, 160, 32, 32, 1, 1), (2, 20, 20, 512, 256, 1, 1)]
 
 
+@pytest.mark.parametrize("B,H,W,C,f", [(2, 12, 10, 64, 2), (1, 7, 9, 24, 2), (2, 6, 5, 64, 4), (1, 5, 4, 16, 8), (1, 3, 3, 520, 2), (3, 24, 24, 256, 2)])
+def test_depthwise_transposed_conv_fwd_bwd(dev, B, H, W, C, f):
+    """cvx_dwconvt_nhwc / cvx_dwconvt_bwd_nhwc (IDAUp.up_i: ConvTranspose2d(c, c, 2f, stride=f, padding=f//2, groups=c, bias=False),
+    centernet_model.py:256) against torch fp32 on fp16-valued operands: forward one fp16 rounding, data gradient likewise (plain and
+    accumulate), weight gradient 1e-5 (accumulated into a non-zero arena with inv_scale).  f = 2 takes the one-pass backward (weight +
+    data gradient together), f = 4 / 8 and C > 512 the tap-group kernel with the separate data gradient; C = 24 has 3 channel groups
+    (256 threads do not divide evenly)."""
+    lib = L.load()
+    st = L.stream_ptr(dev)
+    g = torch.Generator().manual_seed(B * 100 + H * 10 + C + f)
+    x16 = torch.randn(B, C, H, W, generator=g).half()
+    wt = torch.randn(C, 1, 2 * f, 2 * f, generator=g) * 0.3
+    xr, wr = x16.float().requires_grad_(True), wt.clone().requires_grad_(True)
+    ref = F.conv_transpose2d(xr, wr, None, stride=f, padding=f // 2, groups=C)
+    assert tuple(ref.shape) == (B, C, H * f, W * f)
+    go16 = torch.randn(B, C, H * f, W * f, generator=g).half()
+    ref.backward(go16.float())
+    xd, wd = _nhwc(x16).to(dev), wt.reshape(C, 2 * f, 2 * f).contiguous().to(dev)
+    out = torch.empty(B, H * f, W * f, C, dtype=torch.float16, device=dev)
+    L.check(lib.cvx_dwconvt_nhwc(L.ptr(xd), B, H, W, C, f, L.ptr(wd), L.ptr(out), st), "dwconvt")
+    assert (out.float().permute(0, 3, 1, 2).cpu() - ref.detach()).abs().max() <= 1e-3 * max(1.0, float(ref.abs().max()))
+    base16 = torch.randn(B, C, H, W, generator=g).half()
+    dw0 = torch.randn(C, 2 * f, 2 * f, generator=g)
+    inv_scale = 0.25
+    for acc in (0, 1):
+        gin = _nhwc(base16).to(dev).clone()
+        dw = dw0.to(dev).clone()
+        L.check(lib.cvx_dwconvt_bwd_nhwc(L.ptr(xd), L.ptr(_nhwc(go16).to(dev)), B, H, W, C, f, L.ptr(wd), L.ptr(gin), acc, L.ptr(dw), inv_scale, st),
+                "dwconvt bwd")
+        want = xr.grad + (base16.float() if acc else 0)
+        assert (gin.float().permute(0, 3, 1, 2).cpu() - want).abs().max() <= 2e-3 * max(1.0, float(want.abs().max())), acc
+        want_dw = dw0 + inv_scale * wr.grad.reshape(C, 2 * f, 2 * f)
+        assert rel(dw.cpu(), want_dw) < 1e-5, (acc, rel(dw.cpu(), want_dw))
+
+
 @pytest.mark.parametrize("B,H,W,Ci,Co,k,s", CONV_CASES)
 def test_conv_fwd_dgrad_wgrad(dev, B, H, W, Ci, Co, k, s):
     lib = L.load()
