@@ -1568,7 +1568,8 @@ def test_ssd_forward_and_decode_match_the_reference_fixture(dev, gold):
 
 
 # ---- DeepLabv3+ training (BASELINE configs[5]) ---------------------------------------------------------------
-@pytest.mark.parametrize("B,ih,iw,H,W,nc,mode", [(2, 25, 33, 97, 129, 21, 0), (1, 9, 9, 33, 33, 21, 1), (3, 17, 12, 65, 45, 5, 0), (2, 33, 33, 33, 33, 19, 1)])
+@pytest.mark.parametrize("B,ih,iw,H,W,nc,mode", [(2, 25, 33, 97, 129, 21, 0), (1, 9, 9, 33, 33, 21, 1), (3, 17, 12, 65, 45, 5, 0), (2, 33, 33, 33, 33, 19, 1),
+                                                 (1, 5, 6, 40, 48, 21, 0)])
 def test_seg_loss_kernel_against_torch(dev, B, ih, iw, H, W, nc, mode):
     """cvx_seg_loss (loss_seg.hip) against torch autograd in fp32: F.interpolate(bilinear, align_corners=False) of the logits rows
     (deeplabv3plus.py:147), then FocalLoss (focal_loss.py:14-22) or nn.CrossEntropyLoss(mean) (segmentation_2d.py:61), with ignored
@@ -1599,6 +1600,11 @@ def test_seg_loss_kernel_against_torch(dev, B, ih, iw, H, W, nc, mode):
     got = dpred.float().cpu() / scale
     assert rel(got[..., :nc], want) < 1e-3, rel(got[..., :nc], want)               # one fp16 rounding of the scaled gradient
     assert float(got[..., nc:].abs().max()) == 0.0 if ld > nc else True
+    # rows whose stride is not a multiple of 8 floats take the scalar-load path of the pixel kernel: same numbers
+    rows_odd = torch.zeros(B, ih * iw, nc + 1)
+    rows_odd[..., :nc] = rows[..., :nc]
+    loss_o, dpred_o = crit.op(rows_odd.to(dev), t.to(dev), (ih, iw), scale)
+    assert abs(float(loss_o) - float(loss)) <= 1e-6 * abs(float(loss)) and rel(dpred_o[..., :nc].float(), dpred[..., :nc].float()) < 1e-3
     # labels outside [0, nc) that are not the ignore index: flagged (torch asserts on the device), the pixel is skipped
     tb = t.clone()
     tb[0, 0, 0] = nc + 3
