@@ -155,7 +155,8 @@ extern "C" int cvx_centernet_loss(const float* rows_f32, int32_t ld, int32_t bat
   const long long npix = (long long)batch * anchors;
   CVX_HIP(hipMemsetAsync(workspace, 0, 256 + (size_t)npix * 16, st));
   CVX_HIP(hipMemsetAsync(bad_index, 0, 4, st));
-  const int blocks = (int)std::min<long long>(2048, cvx_cdiv(npix * nc, 256));
+  // one workgroup per CU: every workgroup ends in three double atomics on the same three addresses, and those serialise (2048 of them: 80 us)
+  const int blocks = (int)std::min<long long>(256, cvx_cdiv(npix * nc, 256));
   hipLaunchKernelGGL(cn_reduce_kernel, dim3(blocks), dim3(256), 0, st, rows_f32, ld, npix, nc, heat_true, acc);
   hipLaunchKernelGGL(cn_l1_kernel, dim3(batch), dim3(64), 0, st, rows_f32, ld, anchors, col_a, col_b, true_a, true_b, mask, (const long long*)indices,
                      max_objects, plane, acc, bad_index);

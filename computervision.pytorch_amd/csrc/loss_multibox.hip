@@ -23,13 +23,12 @@
 namespace {
 
 struct MbState {
-  double pos_conf, pos_loc, neg_conf;
+  double pos_conf, pos_loc;
   double norm;               // sum over images of (num_pos or 1)
   unsigned long long k;      // negatives to take, batch-wide
   unsigned prefix, remaining;  // radix select state: key bits fixed so far, rank still to resolve inside the prefix bucket
   unsigned thr, take_ties;   // final threshold key and how many keys equal to it are taken
   unsigned hist[256];
-  unsigned done_blocks;
 };
 
 __device__ __forceinline__ double wsum(double v) {
@@ -37,16 +36,34 @@ __device__ __forceinline__ double wsum(double v) {
   return v;
 }
 
+// A workgroup's 256 anchors own one contiguous run of conf (256 x nc1 floats) and of y_true (256 x ld): with STAGED they are copied to
+// LDS with coalesced loads and every thread walks its own row there (odd row strides: no bank conflicts); straight from memory a
+// thread's row sits 4 * nc1 bytes from its neighbour's, every load instruction touches 64 cache lines and the address path is the
+// bound (0.39 ms for 32 x 8732 anchors).  The staged form needs 256 * (nc1 + ld) * 4 bytes <= 64 KB (SSD's 21 classes: 48 KB).
+template <bool STAGED>
+__device__ __forceinline__ void mb_stage_rows(const float* conf, const float* y_true, long long i0, long long N, int nc1, int ld, float* sconf, float* sy) {
+  if (!STAGED) return;
+  const int nvalid = (int)(N - i0 < 256 ? N - i0 : 256);
+  const float* c0 = conf + i0 * nc1;
+  const float* y0 = y_true + i0 * ld;
+  for (int j = threadIdx.x; j < nvalid * nc1; j += 256) sconf[j] = c0[j];
+  for (int j = threadIdx.x; j < nvalid * ld; j += 256) sy[j] = y0[j];
+  __syncthreads();
+}
+
+template <bool STAGED>
 __global__ __launch_bounds__(256) void mb_anchor_kernel(const float* loc, const float* conf, const float* y_true, int B, int A, int nc1, unsigned* key,
-                                                        float* closs, int* num_pos, MbState* stt) {
+                                                        float* closs, int* num_pos, double* part /* per block: sum cl*pos, sum ll*pos */) {
+  extern __shared__ __attribute__((aligned(16))) float srows[];
   __shared__ double sm[2][4];
   const long long N = (long long)B * A;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   const int ld = 4 + nc1 + 1;
+  mb_stage_rows<STAGED>(conf, y_true, (long long)blockIdx.x * 256, N, nc1, ld, srows, srows + 256 * nc1);
   double pc = 0, pl = 0;
   if (i < N) {
-    const float* yt = y_true + i * ld;
-    const float* z = conf + i * nc1;
+    const float* yt = STAGED ? srows + 256 * nc1 + threadIdx.x * ld : y_true + i * ld;
+    const float* z = STAGED ? srows + threadIdx.x * nc1 : conf + i * nc1;
     float zmax = -INFINITY;
     for (int c = 0; c < nc1; ++c) zmax = fmaxf(zmax, z[c]);
     float se = 0.f;
@@ -76,13 +93,33 @@ __global__ __launch_bounds__(256) void mb_anchor_kernel(const float* loc, const 
     sm[1][threadIdx.x >> 6] = pl;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    atomicAdd(&stt->pos_conf, (sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3]));
-    atomicAdd(&stt->pos_loc, (sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3]));
+  if (threadIdx.x == 0) {  // summed in block order by mb_plan_kernel: deterministic, and no same-address atomics (1000+ of them serialise)
+    part[2 * (long long)blockIdx.x] = (sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3]);
+    part[2 * (long long)blockIdx.x + 1] = (sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3]);
   }
 }
 
-__global__ void mb_plan_kernel(const int* num_pos, int B, int A, float ratio, MbState* stt) {
+// fixed-order sum of n doubles at stride `stride` by one 256-thread workgroup (every thread returns the total)
+__device__ double block_sum_256(const double* v, int n, int stride, double* sh) {
+  double a = 0;
+  for (int i = threadIdx.x; i < n; i += 256) a += v[(long long)i * stride];
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  const double t = sh[0];
+  __syncthreads();
+  return t;
+}
+
+__global__ __launch_bounds__(256) void mb_plan_kernel(const int* num_pos, int B, int A, float ratio, const double* part, int nblocks, MbState* stt) {
+  __shared__ double sh[256];
+  const double pc = block_sum_256(part, nblocks, 2, sh), pl = block_sum_256(part + 1, nblocks, 2, sh);
+  if (threadIdx.x != 0) return;
+  stt->pos_conf = pc;
+  stt->pos_loc = pl;
   double k = 0, norm = 0;
   int any = 0;
   for (int b = 0; b < B; ++b) {
@@ -134,50 +171,74 @@ __global__ void mb_pick_kernel(int shift, MbState* stt) {  // one thread: the bu
   }
 }
 
-__global__ __launch_bounds__(1024) void mb_ties_kernel(const unsigned* key, long long N, const MbState* stt, unsigned char* tie_sel) {
-  __shared__ unsigned s_cnt[16];
-  __shared__ unsigned s_base;
-  const unsigned thr = stt->thr, take = stt->take_ties;
-  if (threadIdx.x == 0) s_base = 0;
+// Keys equal to the threshold are taken in flat-index order until k is complete.  Rank of a tie = ties in the workgroups before it
+// (count per 256-key block, then one exclusive scan) + ties before it inside its block (ballots, in mb_grad_kernel).
+__global__ __launch_bounds__(256) void mb_tie_count_kernel(const unsigned* key, long long N, const MbState* stt, unsigned* cnt) {
+  __shared__ unsigned sc[4];
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long bal = __ballot(i < N && key[i] == stt->thr);
+  if ((threadIdx.x & 63) == 0) sc[threadIdx.x >> 6] = (unsigned)__popcll(bal);
   __syncthreads();
-  for (long long i0 = 0; i0 < N; i0 += 1024) {
-    const long long i = i0 + threadIdx.x;
-    const bool tie = i < N && key[i] == thr;
-    const unsigned long long bal = __ballot(tie);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) s_cnt[wave] = __popcll(bal);
+  if (threadIdx.x == 0) cnt[blockIdx.x] = (sc[0] + sc[1]) + (sc[2] + sc[3]);
+}
+__global__ __launch_bounds__(1024) void mb_tie_scan_kernel(const unsigned* cnt, int n, unsigned* base) {  // exclusive scan, one workgroup
+  __shared__ unsigned sw[16];
+  __shared__ unsigned carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    const int i = i0 + threadIdx.x;
+    const unsigned v = i < n ? cnt[i] : 0u;
+    unsigned inc = v;
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned t = __shfl_up(inc, o);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) sw[wave] = inc;
     __syncthreads();
-    unsigned before = s_base;
-    for (int q = 0; q < wave; ++q) before += s_cnt[q];
-    before += __popcll(bal & ((1ull << lane) - 1ull));
-    if (i < N) tie_sel[i] = tie && before < take ? 1 : 0;
+    unsigned before = carry;
+    for (int q = 0; q < wave; ++q) before += sw[q];
+    if (i < n) base[i] = before + inc - v;
     __syncthreads();
     if (threadIdx.x == 0) {
       unsigned t = 0;
-      for (int q = 0; q < 16; ++q) t += s_cnt[q];
-      s_base += t;
+      for (int q = 0; q < 16; ++q) t += sw[q];
+      carry += t;
     }
     __syncthreads();
   }
 }
 
+template <bool STAGED>
 __global__ __launch_bounds__(256) void mb_grad_kernel(const float* loc, const float* conf, const float* y_true, int B, int A, int nc1, const unsigned* key,
-                                                      const float* closs, const unsigned char* tie_sel, MbState* stt, float alpha, float grad_scale,
-                                                      float* dloc, float* dconf, float* loss_items, unsigned nblocks) {
+                                                      const float* closs, const unsigned* tie_base, const MbState* stt, float alpha, float grad_scale,
+                                                      float* dloc, float* dconf, double* part_neg) {
+  extern __shared__ __attribute__((aligned(16))) float srows[];
   __shared__ double sm[4];
+  __shared__ unsigned sties[4];
   const long long N = (long long)B * A;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   const int ld = 4 + nc1 + 1;
+  mb_stage_rows<STAGED>(conf, y_true, (long long)blockIdx.x * 256, N, nc1, ld, srows, srows + 256 * nc1);
   const float inv = (float)((double)grad_scale / stt->norm);
   const unsigned thr = stt->thr;
   double neg = 0;
+  const unsigned kx = i < N ? key[i] : 0u;
+  const bool tie = i < N && kx == thr;
+  const unsigned long long bal = __ballot(tie);
+  if ((threadIdx.x & 63) == 0) sties[threadIdx.x >> 6] = (unsigned)__popcll(bal);
+  __syncthreads();
+  unsigned rank = tie_base[blockIdx.x] + (unsigned)__popcll(bal & ((1ull << (threadIdx.x & 63)) - 1ull));
+  for (int q = 0; q < (int)(threadIdx.x >> 6); ++q) rank += sties[q];
   if (i < N) {
-    const float* yt = y_true + i * ld;
+    const float* yt = STAGED ? srows + 256 * nc1 + threadIdx.x * ld : y_true + i * ld;
     const float pos = yt[ld - 1];
-    const bool taken = stt->k > 0 && (key[i] > thr || tie_sel[i]);
+    const bool taken = stt->k > 0 && (kx > thr || (tie && rank < stt->take_ties));
     if (taken) neg = (double)closs[i];
     const float wc = (pos + (taken ? 1.f : 0.f)) * (1.f - alpha) * inv;   // weight of this anchor's cross-entropy term
-    const float* z = conf + i * nc1;
+    const float* z = STAGED ? srows + threadIdx.x * nc1 : conf + i * nc1;
+    float* dz = STAGED ? srows + threadIdx.x * nc1 : dconf + i * nc1;  // staged: in place over the thread's own logits (z[j] is read before dz[j] is written)
     float zmax = -INFINITY;
     for (int c = 0; c < nc1; ++c) zmax = fmaxf(zmax, z[c]);
     float se = 0.f;
@@ -191,7 +252,7 @@ __global__ __launch_bounds__(256) void mb_grad_kernel(const float* loc, const fl
     for (int j = 0; j < nc1; ++j) {
       const float p = expf(z[j] - zmax) / se;
       const float yj = p >= 1e-7f ? yt[4 + j] : 0.f;
-      dconf[i * nc1 + j] = wc != 0.f ? wc * (p * ysum - yj) : 0.f;
+      dz[j] = wc != 0.f ? wc * (p * ysum - yj) : 0.f;
     }
     const float wl = pos * alpha * inv;
     for (int j = 0; j < 4; ++j) {
@@ -202,17 +263,22 @@ __global__ __launch_bounds__(256) void mb_grad_kernel(const float* loc, const fl
   neg = wsum(neg);
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = neg;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    atomicAdd(&stt->neg_conf, (sm[0] + sm[1]) + (sm[2] + sm[3]));
-    __threadfence();
-    if (atomicAdd(&stt->done_blocks, 1u) == nblocks - 1) {  // the last workgroup to finish writes the loss items
-      __threadfence();
-      const double c = (stt->pos_conf + atomicAdd(&stt->neg_conf, 0.0)) / stt->norm, l = stt->pos_loc / stt->norm;
-      loss_items[0] = (float)(c * (1.0 - (double)alpha) + l * (double)alpha);
-      loss_items[1] = (float)l;
-      loss_items[2] = (float)c;
-    }
+  if (STAGED) {  // the workgroup's gradient rows leave as one contiguous run
+    const long long i0 = (long long)blockIdx.x * 256;
+    const int nvalid = (int)(N - i0 < 256 ? N - i0 : 256);
+    float* d0 = dconf + i0 * nc1;
+    for (int j = threadIdx.x; j < nvalid * nc1; j += 256) d0[j] = srows[j];
   }
+  if (threadIdx.x == 0) part_neg[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);  // summed in block order by mb_final_kernel
+}
+__global__ __launch_bounds__(256) void mb_final_kernel(const double* part_neg, int nblocks, const MbState* stt, float alpha, float* loss_items) {
+  __shared__ double sh[256];
+  const double neg = block_sum_256(part_neg, nblocks, 1, sh);
+  if (threadIdx.x != 0) return;
+  const double c = (stt->pos_conf + neg) / stt->norm, l = stt->pos_loc / stt->norm;
+  loss_items[0] = (float)(c * (1.0 - (double)alpha) + l * (double)alpha);
+  loss_items[1] = (float)l;
+  loss_items[2] = (float)c;
 }
 
 size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -221,7 +287,8 @@ size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 extern "C" int64_t cvx_multibox_loss_workspace_bytes(int32_t batch, int32_t anchors) {
   const size_t N = (size_t)batch * anchors;
-  return (int64_t)(al256(sizeof(MbState)) + al256((size_t)batch * 4) + al256(N * 4) * 2 + al256(N));
+  const size_t nb = (N + 255) / 256;  // state, positives per image, keys, per-anchor loss, per-block (pos_conf, pos_loc, neg) sums, tie counts + bases
+  return (int64_t)(al256(sizeof(MbState)) + al256((size_t)batch * 4) + al256(N * 4) * 2 + al256(nb * 24) + al256(nb * 4) * 2);
 }
 
 extern "C" int cvx_multibox_loss(const float* loc, const float* conf, const float* y_true, int32_t batch, int32_t anchors, int32_t nc1, float neg_pos_ratio,
@@ -239,19 +306,35 @@ extern "C" int cvx_multibox_loss(const float* loc, const float* conf, const floa
   w += al256((size_t)N * 4);
   float* closs = (float*)w;
   w += al256((size_t)N * 4);
-  unsigned char* tie_sel = (unsigned char*)w;
-  CVX_HIP(hipMemsetAsync(workspace, 0, al256(sizeof(MbState)) + al256((size_t)batch * 4), st));
   const unsigned nb = (unsigned)cvx_cdiv(N, 256);
-  hipLaunchKernelGGL(mb_anchor_kernel, dim3(nb), dim3(256), 0, st, loc, conf, y_true, batch, anchors, nc1, key, closs, num_pos, stt);
-  hipLaunchKernelGGL(mb_plan_kernel, dim3(1), dim3(1), 0, st, num_pos, batch, anchors, neg_pos_ratio, stt);
+  double* part = (double*)w;            // [nb][2] positives' sums, then [nb] negatives' sums
+  double* part_neg = part + 2 * (size_t)nb;
+  w += al256((size_t)nb * 24);
+  unsigned* tie_cnt = (unsigned*)w;
+  w += al256((size_t)nb * 4);
+  unsigned* tie_base = (unsigned*)w;
+  CVX_HIP(hipMemsetAsync(workspace, 0, al256(sizeof(MbState)) + al256((size_t)batch * 4), st));
+  const size_t stage_bytes = (size_t)256 * (nc1 + 4 + nc1 + 1) * 4;
+  const bool staged = stage_bytes <= 64 * 1024;
+  if (staged)
+    hipLaunchKernelGGL(mb_anchor_kernel<true>, dim3(nb), dim3(256), stage_bytes, st, loc, conf, y_true, batch, anchors, nc1, key, closs, num_pos, part);
+  else
+    hipLaunchKernelGGL(mb_anchor_kernel<false>, dim3(nb), dim3(256), 0, st, loc, conf, y_true, batch, anchors, nc1, key, closs, num_pos, part);
+  hipLaunchKernelGGL(mb_plan_kernel, dim3(1), dim3(256), 0, st, num_pos, batch, anchors, neg_pos_ratio, part, (int)nb, stt);
   const int hb = (int)std::min<long long>(512, nb);
   for (int shift = 24; shift >= 0; shift -= 8) {
     hipLaunchKernelGGL(mb_hist_kernel, dim3(hb), dim3(256), 0, st, key, N, shift, stt);
     hipLaunchKernelGGL(mb_pick_kernel, dim3(1), dim3(1), 0, st, shift, stt);
   }
-  hipLaunchKernelGGL(mb_ties_kernel, dim3(1), dim3(1024), 0, st, key, N, stt, tie_sel);
-  hipLaunchKernelGGL(mb_grad_kernel, dim3(nb), dim3(256), 0, st, loc, conf, y_true, batch, anchors, nc1, key, closs, tie_sel, stt, alpha, grad_scale, dloc,
-                     dconf, loss_items, nb);
+  hipLaunchKernelGGL(mb_tie_count_kernel, dim3(nb), dim3(256), 0, st, key, N, stt, tie_cnt);
+  hipLaunchKernelGGL(mb_tie_scan_kernel, dim3(1), dim3(1024), 0, st, tie_cnt, (int)nb, tie_base);
+  if (staged)
+    hipLaunchKernelGGL(mb_grad_kernel<true>, dim3(nb), dim3(256), stage_bytes, st, loc, conf, y_true, batch, anchors, nc1, key, closs, tie_base, stt, alpha,
+                       grad_scale, dloc, dconf, part_neg);
+  else
+    hipLaunchKernelGGL(mb_grad_kernel<false>, dim3(nb), dim3(256), 0, st, loc, conf, y_true, batch, anchors, nc1, key, closs, tie_base, stt, alpha,
+                       grad_scale, dloc, dconf, part_neg);
+  hipLaunchKernelGGL(mb_final_kernel, dim3(1), dim3(256), 0, st, part_neg, (int)nb, stt, alpha, loss_items);
   CVX_HIP(hipGetLastError());
   return 0;
 }

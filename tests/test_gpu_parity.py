@@ -2289,6 +2289,43 @@ def test_multibox_loss_kernel_matches_the_reference_fixture(dev, gold, tag):
     assert rel(c2.grad.cpu(), torch.from_numpy(g[tag + "_dconf"])) < 1e-5
 
 
+@pytest.mark.parametrize("B,A,nc", [(3, 1000, 20), (2, 777, 80), (1, 300, 4)])
+def test_multibox_loss_kernel_against_the_oracle(dev, B, A, nc):
+    """cvx_multibox_loss against oracle/ssd_ref.multibox_loss + torch autograd on seeded inputs: anchor counts that do not fill the last
+    256-anchor workgroup, 80 classes (rows too large for the LDS-staged kernels: the direct form runs), and a run of anchors with
+    identical logits spanning several workgroups whose hard-negative key ties at the selection threshold -- the kernel takes ties in
+    flat-index order, torch.topk may take others of the same value, so the loss values are compared there, and the gradient where
+    no tie exists."""
+    from computervision.pytorch_amd.ssd import MultiBoxLoss
+    from oracle import ssd_ref as SS
+    g = torch.Generator().manual_seed(B * 31 + A + nc)
+    y = SS.synth_y_true(B, A, nc, n_pos=10, seed=A)
+    loc = torch.randn(B, A, 4, generator=g)
+    conf = torch.randn(B, A, nc + 1, generator=g) * 2
+    crit = MultiBoxLoss(3.0, nc)
+    for ties in (False, True):
+        c = conf.clone()
+        if ties:                                   # anchors 100..699 of image 0: one logit row -> one key value, far more of them than k needs
+            c[0, 100:min(700, A)] = c[0, 100].clone()
+            c[0, 100:min(700, A), 1:] += 10.0      # ... and the largest foreground mass, so the threshold falls inside the run
+        l2, c2 = loc.clone().requires_grad_(True), c.clone().requires_grad_(True)
+        want = SS.multibox_loss(y, l2, c2, 3.0)
+        want[0].backward()
+        items, dloc, dconf = crit.op(loc.to(dev), c.to(dev), y.to(dev))
+        np.testing.assert_allclose(items.cpu().numpy(), np.array([float(v) for v in want]), rtol=2e-5, atol=1e-7)
+        assert rel(dloc.cpu(), l2.grad) < 1e-5
+        if not ties:
+            assert rel(dconf.cpu(), c2.grad) < 1e-5
+        else:                                      # same number of anchors taken, all of them from the front of the tied run
+            got_taken = (dconf.cpu()[0, 100:min(700, A)].abs().sum(-1) > 0)
+            ref_taken = (c2.grad[0, 100:min(700, A)].abs().sum(-1) > 0)
+            npos_in_run = int(y[0, 100:min(700, A), -1].sum())
+            assert int(got_taken.sum()) == int(ref_taken.sum())
+            if npos_in_run == 0:
+                n = int(got_taken.sum())
+                assert bool(got_taken[:n].all()) and not bool(got_taken[n:].any())
+
+
 def test_ssd_trainer_fused_step(dev):
     """export_from_registry("ssd") -> SsdTrainer at 300 x 300, batch 4: six fused steps of the reference's train_loop on a repeated
     batch: losses finite and falling, parameters move, no overflow skip; the fused path and (criterion(...)[0]).backward() on the model's
