@@ -85,6 +85,7 @@ PROTOTYPES = {
     "cvx_decode": (_I32, [_P, _I32, _I32, _I32, C.POINTER(_I32), C.POINTER(_F), _I32, _P, _P]),
     "cvx_yolo7_decode": (_I32, [_P, _I32, _I32, _I32, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
     "cvx_ssd_decode": (_I32, [_P, _P, _P, _I32, _I32, _I32, _F, _F, _P, _P, _P]),
+    "cvx_ssd_decode_max": (_I32, [_P, _P, _P, _I32, _I32, _I32, _F, _F, _P, _P, _P, _P]),
     "cvx_pred_cols_to_nchw": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I64, _I64, _P]),
     "cvx_nms_workspace_bytes": (_I64, [_I32, _I32]),
     "cvx_nms": (_I32, [_P, _I32, _I32, _I32, _F, _F, _I32, _P, _P, _P, _P, _I64, _P]),

@@ -387,11 +387,12 @@ __global__ __launch_bounds__(256) void y7_obj_kernel(const float* rows, Y7Geom G
   const int lv = blockIdx.y;
   const Y7Level L = G.lv[lv];
   const long long ncell = (long long)G.B * 3 * L.h * L.w;
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   double lo = 0;
-  if (i < ncell) {
-    long long base = 0;
-    for (int q = 0; q < lv; ++q) base += (long long)G.B * 3 * G.lv[q].h * G.lv[q].w;
+  long long base = 0;
+  for (int q = 0; q < lv; ++q) base += (long long)G.B * 3 * G.lv[q].h * G.lv[q].w;
+  // grid-stride over the level's cells: the launch is capped at 128 workgroups per level, because every workgroup ends in a double atomic on
+  // the level's one sum and those serialise (a workgroup per 256 cells: 7200 atomics, 90 us)
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < ncell; i += (long long)gridDim.x * 256) {
     const unsigned long long key = tobj[base + i];
     const float tv = key ? __uint_as_float((unsigned)(key & 0xFFFFFFFFull)) : 0.f;
     const int gi = (int)(i % L.w);
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(256) void y7_obj_kernel(const float* rows, Y7Geom G
     t /= L.h;
     const int a = (int)(t % 3), b = (int)(t / 3);
     const float* v = cell(rows, G, lv, b, a, gj, gi);
-    lo = (double)bce_logits(v[4], tv);
+    lo += (double)bce_logits(v[4], tv);
     gbuf[(v - rows) + 4] = obj_w * L.balance / (float)ncell * (sigm(v[4]) - tv);
   }
   for (int o = 32; o > 0; o >>= 1) lo += __shfl_xor(lo, o);
@@ -515,7 +516,7 @@ extern "C" int cvx_yolo7_loss(const float* rows_f32, int32_t ld, int32_t batch, 
   }
   long long maxcell = 0;
   for (int lv = 0; lv < 3; ++lv) maxcell = std::max(maxcell, (long long)batch * 3 * G.lv[lv].h * G.lv[lv].w);
-  hipLaunchKernelGGL(y7_obj_kernel, dim3((unsigned)cvx_cdiv(maxcell, 256), 3), dim3(256), 0, st, rows_f32, G, (const unsigned long long*)(w + l.tobj),
+  hipLaunchKernelGGL(y7_obj_kernel, dim3((unsigned)std::min<long long>(128, cvx_cdiv(maxcell, 256)), 3), dim3(256), 0, st, rows_f32, G, (const unsigned long long*)(w + l.tobj),
                      obj_ratio, (float*)(w + l.gbuf), state);
   const long long n = (long long)batch * A * ld;
   hipLaunchKernelGGL(y7_final_kernel, dim3((unsigned)cvx_cdiv(n, 256)), dim3(256), 0, st, (const float*)(w + l.gbuf), n, loss_scale, (half_t*)dpred_f16, G,

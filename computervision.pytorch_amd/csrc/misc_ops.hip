@@ -538,26 +538,45 @@ __global__ __launch_bounds__(256) void resize_from_1x1_bwd_kernel(ViewDesc gout,
   }
 }
 // fp32 rows (B, IH*IW, ld) -> NCHW fp32 (B, C, OH, OW): the segmentation logits back at input resolution (deeplabv3plus.py:147)
-__global__ void resize_bilinear_f32_nchw_kernel(const float* in, int ld, int B, int C, int IH, int IW, int OH, int OW, float sh, float sw,
-                                                float* out) {
+// One thread per output pixel walks the classes: the source indices and weights are computed once, the four source rows are read with
+// 16-byte loads (their C floats are contiguous), every class plane is written with consecutive lanes on consecutive x.
+__global__ __launch_bounds__(256) void resize_bilinear_f32_nchw_kernel(const float* in, int ld, int B, int C, int IH, int IW, int OH, int OW, float sh,
+                                                                       float sw, float* out) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  long long n = (long long)B * C * OH * OW;
+  long long n = (long long)B * OH * OW;
   if (i >= n) return;
   int w = (int)(i % OW);
   long long t = i / OW;
   int h = (int)(t % OH);
-  t /= OH;
-  int c = (int)(t % C);
-  int b = (int)(t / C);
+  int b = (int)(t / OH);
   int y0, y1, x0, x1;
   float ly, lx;
   bilinear_src(h, sh, IH, &y0, &y1, &ly);
   bilinear_src(w, sw, IW, &x0, &x1, &lx);
-  const float* base = in + (long long)b * IH * IW * ld + c;
-  const float v00 = base[((long long)y0 * IW + x0) * ld], v01 = base[((long long)y0 * IW + x1) * ld];
-  const float v10 = base[((long long)y1 * IW + x0) * ld], v11 = base[((long long)y1 * IW + x1) * ld];
-  const float top = v00 * (1.f - lx) + v01 * lx, bot = v10 * (1.f - lx) + v11 * lx;
-  out[i] = top * (1.f - ly) + bot * ly;
+  const float* base = in + (long long)b * IH * IW * ld;
+  const float* r00 = base + ((long long)y0 * IW + x0) * ld;
+  const float* r01 = base + ((long long)y0 * IW + x1) * ld;
+  const float* r10 = base + ((long long)y1 * IW + x0) * ld;
+  const float* r11 = base + ((long long)y1 * IW + x1) * ld;
+  const long long plane = (long long)OH * OW;
+  float* o = out + (long long)b * C * plane + (long long)h * OW + w;
+  int c = 0;
+  if ((ld & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
+    for (; c + 4 <= C; c += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(r00 + c), bq = *reinterpret_cast<const float4*>(r01 + c);
+      const float4 cq = *reinterpret_cast<const float4*>(r10 + c), d = *reinterpret_cast<const float4*>(r11 + c);
+      const float va[4] = {a.x, a.y, a.z, a.w}, vb[4] = {bq.x, bq.y, bq.z, bq.w}, vc[4] = {cq.x, cq.y, cq.z, cq.w}, vd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float top = va[k] * (1.f - lx) + vb[k] * lx, bot = vc[k] * (1.f - lx) + vd[k] * lx;
+        o[(long long)(c + k) * plane] = top * (1.f - ly) + bot * ly;
+      }
+    }
+  }
+  for (; c < C; ++c) {
+    const float top = r00[c] * (1.f - lx) + r01[c] * lx, bot = r10[c] * (1.f - lx) + r11[c] * lx;
+    o[(long long)c * plane] = top * (1.f - ly) + bot * ly;
+  }
 }
 
 // ---- depthwise ConvTranspose2d, kernel 2f, stride f, padding f/2 (IDAUp.up_i, centernet_model.py:256): every output pixel
@@ -1208,7 +1227,7 @@ int cvx_resize_bilinear(const ViewDesc& in, const ViewDesc& out, int B, int IH, 
 }
 int cvx_resize_bilinear_f32_nchw(const float* in, int ld, int B, int C, int IH, int IW, int OH, int OW, float* out, hipStream_t st) {
   CVX_CHECK(in && out && C > 0 && C <= ld && IH > 0 && IW > 0 && OH > 0 && OW > 0, "resize_bilinear_f32_nchw: bad arguments");
-  return launch1d(resize_bilinear_f32_nchw_kernel, (long long)B * C * OH * OW, st, in, ld, B, C, IH, IW, OH, OW, (float)IH / (float)OH,
+  return launch1d(resize_bilinear_f32_nchw_kernel, (long long)B * OH * OW, st, in, ld, B, C, IH, IW, OH, OW, (float)IH / (float)OH,
                   (float)IW / (float)OW, out);
 }
 int cvx_dwconvt(const ViewDesc& in, const ViewDesc& out, const float* w, int B, int IH, int IW, int C, int f, hipStream_t st) {

@@ -349,43 +349,76 @@ struct Y7Levels {
   int w[4], h[4];
   float aw[4][3], ah[4][3];  // anchors scaled to the level's grid (anchor / stride)
 };
-__global__ void yolo7_decode_kernel(const float* pred, int ld, int B, int nc, Y7Levels L, float* dec, float* y) {
-  const int attrs = 5 + nc;
-  const long long R = L.row0[L.n];  // rows per image
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)B * 3 * R) return;
-  const int b = (int)(i / (3 * R));
-  long long r = i - (long long)b * 3 * R;  // reference anchor index inside the image
+// A workgroup takes 32 consecutive anchors of the reference's order.  Every anchor's 5 + nc attributes are one contiguous run both in the
+// head rows and in `dec`, so a wave moves one anchor at a time (lane = attribute: coalesced in and out) through an LDS tile; `y` is
+// attribute-major (contiguous along the anchors), so it is written from the tile with the anchor as the fast index.  One thread per anchor
+// walking its own row touched 64 cache lines per load / store instruction.
+struct Y7Where {
+  int b, l, a, gx, gy;
+  long long r;
+  const float* p;
+};
+__device__ __forceinline__ Y7Where y7_locate(long long i, const float* pred, int ld, int attrs, const Y7Levels& L) {
+  Y7Where w;
+  const long long R = L.row0[L.n];
+  w.b = (int)(i / (3 * R));
+  w.r = i - (long long)w.b * 3 * R;  // reference anchor index inside the image
   int l = 0;
-  while (l + 1 < L.n && r >= 3LL * L.row0[l + 1]) ++l;
+  while (l + 1 < L.n && w.r >= 3LL * L.row0[l + 1]) ++l;
   const int hw = L.row0[l + 1] - L.row0[l];
-  const long long rl = r - 3LL * L.row0[l];
-  const int a = (int)(rl / hw), pix = (int)(rl - (long long)a * hw);
-  const int gy = pix / L.w[l], gx = pix - gy * L.w[l];
-  const float* p = pred + ((long long)b * R + L.row0[l] + pix) * ld + a * attrs;
-  float* d = dec + i * attrs;
+  const long long rl = w.r - 3LL * L.row0[l];
+  w.l = l;
+  w.a = (int)(rl / hw);
+  const int pix = (int)(rl - (long long)w.a * hw);
+  w.gy = pix / L.w[l];
+  w.gx = pix - w.gy * L.w[l];
+  w.p = pred + ((long long)w.b * R + L.row0[l] + pix) * ld + w.a * attrs;
+  return w;
+}
+__global__ __launch_bounds__(256) void yolo7_decode_kernel(const float* pred, int ld, int B, int nc, Y7Levels L, float* dec, float* y) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [32][TS]
+  const int attrs = 5 + nc, TS = attrs | 1;
+  const long long R = L.row0[L.n], total = (long long)B * 3 * R;
+  const long long i0 = (long long)blockIdx.x * 32;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   auto sg = [](float v) { return 1.f / (1.f + expf(-v)); };
-  const float sx = sg(p[0]), sy = sg(p[1]), sw = sg(p[2]), sh = sg(p[3]), obj = sg(p[4]);
-  const float cx = (sx * 2.f - 0.5f + (float)gx) / (float)L.w[l], cy = (sy * 2.f - 0.5f + (float)gy) / (float)L.h[l];
-  const float tw = sw * 2.f, th = sh * 2.f;
-  const float bw = tw * tw * L.aw[l][a] / (float)L.w[l], bh = th * th * L.ah[l][a] / (float)L.h[l];
-  d[0] = cx;
-  d[1] = cy;
-  d[2] = bw;
-  d[3] = bh;
-  d[4] = obj;
-  const long long A3 = 3 * R;
-  float* yb = y ? y + (long long)b * (4 + nc) * A3 + r : nullptr;
-  if (yb) {
-    yb[0] = cx;
-    yb[A3] = cy;
-    yb[2 * A3] = bw;
-    yb[3 * A3] = bh;
+  for (int q = 0; q < 8; ++q) {
+    const int al = wave * 8 + q;
+    if (i0 + al >= total) break;
+    const Y7Where w = y7_locate(i0 + al, pred, ld, attrs, L);
+    for (int k = lane; k < attrs; k += 64) tile[al * TS + k] = sg(w.p[k]);
   }
-  for (int k = 0; k < nc; ++k) {
-    const float c = sg(p[5 + k]);
-    d[5 + k] = c;
-    if (yb) yb[(long long)(4 + k) * A3] = obj * c;
+  __syncthreads();
+  if (threadIdx.x < 32 && i0 + threadIdx.x < total) {
+    const Y7Where w = y7_locate(i0 + threadIdx.x, pred, ld, attrs, L);
+    float* t = tile + threadIdx.x * TS;
+    const float sx = t[0], sy = t[1], sw = t[2], sh = t[3];
+    const int l = w.l;
+    const float cx = (sx * 2.f - 0.5f + (float)w.gx) / (float)L.w[l], cy = (sy * 2.f - 0.5f + (float)w.gy) / (float)L.h[l];
+    const float tw = sw * 2.f, th = sh * 2.f;
+    t[0] = cx;
+    t[1] = cy;
+    t[2] = tw * tw * L.aw[l][w.a] / (float)L.w[l];
+    t[3] = th * th * L.ah[l][w.a] / (float)L.h[l];
+  }
+  __syncthreads();
+  for (int q = 0; q < 8; ++q) {
+    const int al = wave * 8 + q;
+    if (i0 + al >= total) break;
+    float* d = dec + (i0 + al) * attrs;
+    for (int k = lane; k < attrs; k += 64) d[k] = tile[al * TS + k];
+  }
+  if (y) {
+    const int al = threadIdx.x & 31, kk = threadIdx.x >> 5;
+    const long long i = i0 + al;
+    if (i < total) {
+      const long long A3 = 3 * R;
+      const int b = (int)(i / A3);
+      float* yb = y + (long long)b * (4 + nc) * A3 + (i - (long long)b * A3);
+      const float* t = tile + al * TS;
+      const float obj = t[4];
+      for (int k = kk; k < 4 + nc; k += 8) yb[(long long)k * A3] = k < 4 ? t[k] : obj * t[k + 1];
+    }
   }
 }
 }  // namespace
@@ -411,7 +444,9 @@ extern "C" int cvx_yolo7_decode(const float* pred, int32_t pred_ld, int32_t B, i
   }
   L.row0[n_levels] = off;
   const long long n = (long long)B * 3 * off;
-  hipLaunchKernelGGL(yolo7_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, pred, pred_ld, B, nc, L, dec, y);
+  CVX_CHECK(nc <= 400 && (n + 31) / 32 < (1LL << 31), "too many classes / anchors");
+  hipLaunchKernelGGL(yolo7_decode_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), (size_t)32 * ((5 + nc) | 1) * 4, (hipStream_t)hip_stream, pred, pred_ld,
+                     B, nc, L, dec, y);
   CVX_HIP(hipGetLastError());
   return 0;
 }
@@ -419,39 +454,82 @@ extern "C" int cvx_yolo7_decode(const float* pred, int32_t pred_ld, int32_t B, i
 // ---- SSD decode (core/algorithms/ssd.py:236-325): softmax over the class scores, prior-box regression decode with
 // variances (0.1, 0.2), corners clipped to [0, 1].  One thread per prior. ----
 namespace {
-__global__ void ssd_decode_kernel(const float* loc, const float* conf, const float* priors, int B, int A, int nc1, float v0, float v1,
-                                  float* boxes, float* prob) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)B * A) return;
-  const int a = (int)(i % A);
-  const float* l = loc + i * 4;
-  const float4 pr = *reinterpret_cast<const float4*>(priors + (long long)a * 4);
-  const float aw = pr.z - pr.x, ah = pr.w - pr.y;
-  const float acx = 0.5f * (pr.z + pr.x), acy = 0.5f * (pr.w + pr.y);
-  const float cx = l[0] * aw * v0 + acx, cy = l[1] * ah * v0 + acy;
-  const float w = expf(l[2] * v1) * aw, h = expf(l[3] * v1) * ah;
-  float4 o = make_float4(cx - 0.5f * w, cy - 0.5f * h, cx + 0.5f * w, cy + 0.5f * h);
-  o.x = fminf(fmaxf(o.x, 0.f), 1.f);
-  o.y = fminf(fmaxf(o.y, 0.f), 1.f);
-  o.z = fminf(fmaxf(o.z, 0.f), 1.f);
-  o.w = fminf(fmaxf(o.w, 0.f), 1.f);
-  *reinterpret_cast<float4*>(boxes + i * 4) = o;
-  const float* c = conf + i * nc1;
-  float m = c[0];
-  for (int k = 1; k < nc1; ++k) m = fmaxf(m, c[k]);
-  float sum = 0.f;
-  for (int k = 0; k < nc1; ++k) sum += expf(c[k] - m);
-  float* p = prob + i * nc1;
-  for (int k = 0; k < nc1; ++k) p[k] = expf(c[k] - m) / sum;
+// STAGED: the workgroup's 256 score rows (one contiguous run of 256 * nc1 floats) pass through LDS -- coalesced in, softmax in place on the
+// thread's own row (odd stride: conflict-free), coalesced out; straight from memory a thread's row lies 4 * nc1 bytes from its neighbour's
+// and every load / store instruction touches 64 cache lines.
+template <bool STAGED>
+__global__ __launch_bounds__(256) void ssd_decode_kernel(const float* loc, const float* conf, const float* priors, int B, int A, int nc1, float v0,
+                                                         float v1, float* boxes, float* prob, unsigned* class_max) {
+  extern __shared__ __attribute__((aligned(16))) float srow[];
+  const long long N = (long long)B * A;
+  const long long i0 = (long long)blockIdx.x * 256;
+  const long long i = i0 + threadIdx.x;
+  const int nvalid = (int)(N - i0 < 256 ? N - i0 : 256);
+  if (STAGED) {
+    const float* c0 = conf + i0 * nc1;
+    for (int j = threadIdx.x; j < nvalid * nc1; j += 256) srow[j] = c0[j];
+    __syncthreads();
+  }
+  if (i < N) {
+    const int a = (int)(i % A);
+    const float* l = loc + i * 4;
+    const float4 pr = *reinterpret_cast<const float4*>(priors + (long long)a * 4);
+    const float aw = pr.z - pr.x, ah = pr.w - pr.y;
+    const float acx = 0.5f * (pr.z + pr.x), acy = 0.5f * (pr.w + pr.y);
+    const float cx = l[0] * aw * v0 + acx, cy = l[1] * ah * v0 + acy;
+    const float w = expf(l[2] * v1) * aw, h = expf(l[3] * v1) * ah;
+    float4 o = make_float4(cx - 0.5f * w, cy - 0.5f * h, cx + 0.5f * w, cy + 0.5f * h);
+    o.x = fminf(fmaxf(o.x, 0.f), 1.f);
+    o.y = fminf(fmaxf(o.y, 0.f), 1.f);
+    o.z = fminf(fmaxf(o.z, 0.f), 1.f);
+    o.w = fminf(fmaxf(o.w, 0.f), 1.f);
+    *reinterpret_cast<float4*>(boxes + i * 4) = o;
+    const float* c = STAGED ? srow + threadIdx.x * nc1 : conf + i * nc1;
+    float m = c[0];
+    for (int k = 1; k < nc1; ++k) m = fmaxf(m, c[k]);
+    float sum = 0.f;
+    for (int k = 0; k < nc1; ++k) sum += expf(c[k] - m);
+    float* p = STAGED ? srow + threadIdx.x * nc1 : prob + i * nc1;
+    for (int k = 0; k < nc1; ++k) p[k] = expf(c[k] - m) / sum;
+  }
+  if (STAGED) {
+    __syncthreads();
+    float* p0 = prob + i0 * nc1;
+    for (int j = threadIdx.x; j < nvalid * nc1; j += 256) p0[j] = srow[j];
+    if (class_max)  // largest probability per class over the batch (probabilities are >= 0: their bit patterns order like the values)
+      for (int k = threadIdx.x; k < nc1; k += 256) {
+        float m = 0.f;
+        for (int r = 0; r < nvalid; ++r) m = fmaxf(m, srow[r * nc1 + k]);
+        if (__float_as_uint(m) > class_max[k]) atomicMax(&class_max[k], __float_as_uint(m));
+      }
+  } else if (class_max) {
+    const float* p = prob + i * nc1;
+    for (int k = 0; k < nc1; ++k) {
+      float m = i < N ? p[k] : 0.f;
+      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      if ((threadIdx.x & 63) == 0 && __float_as_uint(m) > class_max[k]) atomicMax(&class_max[k], __float_as_uint(m));
+    }
+  }
 }
 }  // namespace
 
-extern "C" int cvx_ssd_decode(const float* loc, const float* conf, const float* priors, int32_t B, int32_t A, int32_t num_classes_plus_bg,
-                              float variance_xy, float variance_wh, float* boxes, float* prob, void* hip_stream) {
+extern "C" int cvx_ssd_decode_max(const float* loc, const float* conf, const float* priors, int32_t B, int32_t A, int32_t num_classes_plus_bg,
+                                  float variance_xy, float variance_wh, float* boxes, float* prob, float* class_max, void* hip_stream) {
   CVX_CHECK(loc && conf && priors && boxes && prob && B > 0 && A > 0 && num_classes_plus_bg > 1, "bad arguments");
   const long long n = (long long)B * A;
-  hipLaunchKernelGGL(ssd_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, loc, conf, priors, B, A,
-                     num_classes_plus_bg, variance_xy, variance_wh, boxes, prob);
+  hipStream_t st = (hipStream_t)hip_stream;
+  if (class_max) CVX_HIP(hipMemsetAsync(class_max, 0, (size_t)num_classes_plus_bg * 4, st));
+  const size_t stage = (size_t)256 * num_classes_plus_bg * 4;
+  if (stage <= 64 * 1024)
+    hipLaunchKernelGGL(ssd_decode_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), stage, st, loc, conf, priors, B, A, num_classes_plus_bg,
+                       variance_xy, variance_wh, boxes, prob, (unsigned*)class_max);
+  else
+    hipLaunchKernelGGL(ssd_decode_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, loc, conf, priors, B, A, num_classes_plus_bg,
+                       variance_xy, variance_wh, boxes, prob, (unsigned*)class_max);
   CVX_HIP(hipGetLastError());
   return 0;
+}
+extern "C" int cvx_ssd_decode(const float* loc, const float* conf, const float* priors, int32_t B, int32_t A, int32_t num_classes_plus_bg,
+                              float variance_xy, float variance_wh, float* boxes, float* prob, void* hip_stream) {
+  return cvx_ssd_decode_max(loc, conf, priors, B, A, num_classes_plus_bg, variance_xy, variance_wh, boxes, prob, nullptr, hip_stream);
 }

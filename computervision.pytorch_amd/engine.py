@@ -281,17 +281,19 @@ def yolo7_decode(rows: torch.Tensor, nc: int, level_hw, anchors_wh, input_hw, wa
     return dec, y
 
 
-def ssd_decode(loc: torch.Tensor, conf: torch.Tensor, priors: torch.Tensor, variances=(0.1, 0.2)):
+def ssd_decode(loc: torch.Tensor, conf: torch.Tensor, priors: torch.Tensor, variances=(0.1, 0.2), with_class_max: bool = False):
     """loc (B, A, 4), conf (B, A, nc+1) fp32 (the SSD model's outputs), priors (A, 4) -> (boxes (B, A, 4) clipped corners,
-    prob (B, A, nc+1) softmax), on device (cvx_ssd_decode, include/cvx_engine.h)."""
+    prob (B, A, nc+1) softmax), on device (cvx_ssd_decode, include/cvx_engine.h); with_class_max: also the largest probability per
+    score column over the batch ((nc+1,) tensor, cvx_ssd_decode_max)."""
     lib = L.load()
     _need_gpu(loc, "loc")
     loc, conf, priors = loc.contiguous().float(), conf.contiguous().float(), priors.contiguous().float()
     B, A, _ = loc.shape
     boxes, prob = torch.empty_like(loc), torch.empty_like(conf)
-    L.check(lib.cvx_ssd_decode(L.ptr(loc), L.ptr(conf), L.ptr(priors), B, A, conf.shape[2], float(variances[0]), float(variances[1]), L.ptr(boxes),
-                               L.ptr(prob), L.stream_ptr(loc.device)), "cvx_ssd_decode")
-    return boxes, prob
+    cmax = torch.empty(conf.shape[2], device=loc.device) if with_class_max else None
+    L.check(lib.cvx_ssd_decode_max(L.ptr(loc), L.ptr(conf), L.ptr(priors), B, A, conf.shape[2], float(variances[0]), float(variances[1]), L.ptr(boxes),
+                                   L.ptr(prob), L.ptr(cmax) if with_class_max else None, L.stream_ptr(loc.device)), "cvx_ssd_decode_max")
+    return (boxes, prob, cmax) if with_class_max else (boxes, prob)
 
 
 _cn_ws = {}

@@ -102,12 +102,13 @@ class Ssd:
         dev = loc.device
         if self._priors_dev is None or self._priors_dev.device != dev:
             self._priors_dev = torch.from_numpy(self.anchors).to(dev)
-        boxes, prob = _engine.ssd_decode(loc, conf, self._priors_dev, self.variance[::2].tolist())
+        boxes, prob, cmax = _engine.ssd_decode(loc, conf, self._priors_dev, self.variance[::2].tolist(), with_class_max=True)
         B, A, _ = boxes.shape
         bt = boxes.transpose(1, 2).contiguous()                                  # (B, 4, A): corner boxes, channel-major for cvx_nms
         per_img = [([], []) for _ in range(B)]
+        active = (cmax > conf_thr).cpu().tolist()       # the decode kernel's per-class maxima: one host read decides every class
         for c in range(1, self.num_classes + 1):
-            if not bool((prob[:, :, c] > conf_thr).any()):
+            if not active[c]:
                 continue
             y = torch.cat((bt, prob[:, :, c].unsqueeze(1)), 1)
             rows, index, counts = _engine.nms(y, float(conf_thr), self.nms_threshold, max_det=MAX_DET, variant="vanilla", boxes_xyxy=True)

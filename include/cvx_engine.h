@@ -242,6 +242,10 @@ int cvx_decode_strided(const float* pred, int32_t pred_ld, int32_t batch, int32_
  * Replaces: torch.softmax + Ssd._parse_mbox_loc, core/algorithms/ssd.py:246-247,285-325. */
 int cvx_ssd_decode(const float* loc, const float* conf, const float* priors, int32_t batch, int32_t anchors, int32_t num_classes_plus_bg,
                    float variance_xy, float variance_wh, float* boxes, float* prob, void* hip_stream);
+/* cvx_ssd_decode that also returns, per score column, the largest probability of the whole batch (class_max: num_classes_plus_bg floats, may be
+ * NULL): the caller's per-class loop (ssd.py:246-274) skips the classes nothing passes the threshold in after ONE host read. */
+int cvx_ssd_decode_max(const float* loc, const float* conf, const float* priors, int32_t B, int32_t A, int32_t num_classes_plus_bg,
+                       float variance_xy, float variance_wh, float* boxes, float* prob, float* class_max, void* hip_stream);
 /* Column range [col0, col0 + c) of fp32 rows (batch, anchors, ld), pixels a_off .. a_off + h*w, as an NCHW block written at
  * out[b * out_bstride + out_off + ch * h*w + pix]: SSD flattens its head maps in NCHW order and concatenates the levels
  * (core/models/ssd_model.py:177-183).  Asynchronous on hip_stream. */

@@ -1552,6 +1552,19 @@ def test_ssd_forward_and_decode_match_the_reference_fixture(dev, gold):
     boxes, prob = E.ssd_decode(sloc, sconf, torch.from_numpy(algo.anchors).to(dev))
     np.testing.assert_allclose(boxes.cpu().numpy(), torch.stack([SS.parse_loc(sloc[b].cpu(), algo.anchors) for b in range(2)]).numpy(), rtol=2e-6, atol=1e-7)
     np.testing.assert_allclose(prob.cpu().numpy(), torch.softmax(sconf.cpu(), -1).numpy(), rtol=2e-6, atol=1e-9)
+    # 81 score columns: rows too long for the LDS-staged form (the direct kernel runs); an anchor count that leaves the last workgroup ragged
+    gq = torch.Generator().manual_seed(5)
+    wide_conf, some_loc = torch.randn(1, 1000, 81, generator=gq) * 3, torch.randn(1, 1000, 4, generator=gq)
+    anc = torch.from_numpy(algo.anchors)[:1000].contiguous()
+    b2, p2 = E.ssd_decode(some_loc.to(dev), wide_conf.to(dev), anc.to(dev))
+    np.testing.assert_allclose(p2.cpu().numpy(), torch.softmax(wide_conf, -1).numpy(), rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(b2.cpu().numpy(), SS.parse_loc(some_loc[0], anc.numpy()).unsqueeze(0).numpy(), rtol=2e-6, atol=1e-7)
+    b3, p3, m3 = E.ssd_decode(some_loc[:, :777].contiguous().to(dev), wide_conf[:, :777, :21].contiguous().to(dev), anc[:777].contiguous().to(dev),
+                              with_class_max=True)
+    np.testing.assert_allclose(p3.cpu().numpy(), torch.softmax(wide_conf[:, :777, :21], -1).numpy(), rtol=2e-6, atol=1e-9)
+    assert torch.equal(m3, p3.reshape(-1, 21).amax(0))                       # per-class maxima of the batch: exact (a max of the kernel's own values)
+    _, p4, m4 = E.ssd_decode(some_loc.to(dev), wide_conf.to(dev), anc.to(dev), with_class_max=True)
+    assert torch.equal(m4, p4.reshape(-1, 81).amax(0))
     got = algo.decode_device((sloc, sconf))
     for b in range(2):
         rows, pairs = got[b]
@@ -1618,6 +1631,21 @@ def test_seg_loss_kernel_against_torch(dev, B, ih, iw, H, W, nc, mode):
     d2 = torch.empty(B, ih * iw, ld, dtype=torch.float16, device=dev)
     L.check(lib.cvx_resize_bilinear_nchw_grad_to_rows(L.ptr(gl.to(dev)), B, nc, ih, iw, H, W, 0.125, L.ptr(d2), ld, L.stream_ptr(dev)), "adjoint")
     assert rel(d2.float().cpu()[..., :nc] * 8, rr2.permute(0, 2, 3, 1).reshape(B, ih * iw, nc)) < 1e-3
+
+
+@pytest.mark.parametrize("B,ih,iw,H,W,nc,ld", [(2, 9, 12, 33, 45, 21, 24), (1, 5, 5, 17, 17, 5, 5), (2, 7, 6, 7, 6, 8, 8), (1, 33, 33, 129, 129, 3, 8)])
+def test_logit_rows_to_nchw_resize(dev, B, ih, iw, H, W, nc, ld):
+    """cvx_resize_bilinear_rows_to_nchw (the final F.interpolate(bilinear, align_corners=False) of the segmentation logits,
+    deeplabv3plus.py:147) against torch in fp32: 16-byte row loads with a scalar tail (21 of 24 columns), rows whose stride rules the
+    vector loads out (ld = 5), identity size."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(ih * 7 + nc)
+    rows = torch.randn(B, ih * iw, ld, generator=g)
+    want = F.interpolate(rows[..., :nc].reshape(B, ih, iw, nc).permute(0, 3, 1, 2), size=(H, W), mode="bilinear", align_corners=False)
+    out = torch.empty(B, nc, H, W, device=dev)
+    rd = rows.to(dev)
+    L.check(lib.cvx_resize_bilinear_rows_to_nchw(L.ptr(rd), ld, B, nc, ih, iw, H, W, L.ptr(out), L.stream_ptr(dev)), "rows_to_nchw")
+    assert float((out.cpu() - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max()))
 
 
 def _deeplab_train_model(dev, g, dropout_p=0.0):
