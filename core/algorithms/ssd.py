@@ -112,8 +112,9 @@ class Ssd:
                 continue
             y = torch.cat((bt, prob[:, :, c].unsqueeze(1)), 1)
             rows, index, counts = _engine.nms(y, float(conf_thr), self.nms_threshold, max_det=MAX_DET, variant="vanilla", boxes_xyxy=True)
+            counts_h = counts.cpu().tolist()                      # one host read per class, not one per image
             for b in range(B):
-                n = int(counts[b])
+                n = int(counts_h[b])
                 if n < 0 or n >= MAX_DET:
                     raise L.CvxError(f"more than {MAX_DET} detections of one class in one image: raise decode.confidence_threshold")
                 if n == 0:

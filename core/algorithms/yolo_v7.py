@@ -66,8 +66,9 @@ class YOLOv7:
         thr = float(np.nextafter(np.float32(conf), np.float32(-1.0)))
         rows, index, counts = _engine.nms(y, thr, self.nms_threshold, max_det=MAX_DET, variant="vanilla")
         out = []
+        counts_h = counts.cpu().tolist()                           # one host read for the batch, not one per image
         for b in range(y.shape[0]):
-            n = int(counts[b])
+            n = int(counts_h[b])
             if n < 0:
                 raise L.CvxError("cvx_nms: more than 16384 candidates above the confidence threshold in one image")
             if n >= MAX_DET:
