@@ -33,20 +33,27 @@ __global__ __launch_bounds__(256) void peak_scores_kernel(const float* pred, int
   const long long n = (long long)B * H * W * C;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const int c = (int)(i % C);
-  const long long pix = i / C;  // b*H*W + y*W + x
-  const int x = (int)(pix % W);
-  const float* row = pred + pix * ld;
-  const float v = row[c];
-  float m = v;
-#pragma unroll
-  for (int dx = -1; dx <= 1; ++dx) {
-    if ((unsigned)(x + dx) >= (unsigned)W) continue;
-    const float* r = row + (long long)dx * ld;
-#pragma unroll
-    for (int dc = -1; dc <= 1; ++dc)
-      if ((unsigned)(c + dc) < (unsigned)C) m = fmaxf(m, r[c + dc]);
+  int c, x;
+  long long pix;  // b*H*W + y*W + x
+  if (n <= 0x7fffffffLL) {  // 32-bit index arithmetic: three 64-bit divisions by run-time values cost more than the rest of the thread
+    const unsigned iu = (unsigned)i, pu = iu / (unsigned)C;
+    c = (int)(iu - pu * (unsigned)C);
+    x = (int)(pu % (unsigned)W);
+    pix = pu;
+  } else {
+    c = (int)(i % C);
+    pix = i / C;
+    x = (int)(pix % W);
   }
+  const float* row = pred + pix * ld;
+  // the 3 x 3 window over (x, class) with its offsets clamped into the map: a clamped offset lands on an element the window holds anyway,
+  // so the maximum is unchanged, and the nine loads are unconditional -- issued together instead of one memory round trip per branch
+  const int dxm = x > 0 ? -1 : 0, dxp = x < W - 1 ? 1 : 0, cm = c > 0 ? c - 1 : c, cp = c < C - 1 ? c + 1 : c;
+  const float* rm = row + (long long)dxm * ld;
+  const float* rp = row + (long long)dxp * ld;
+  const float v = row[c];
+  const float a0 = rm[cm], a1 = rm[c], a2 = rm[cp], b0 = row[cm], b2 = row[cp], c0 = rp[cm], c1 = rp[c], c2 = rp[cp];
+  const float m = fmaxf(fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, b0)), fmaxf(fmaxf(b2, c0), fmaxf(c1, c2))), v);
   const float s = sigmoid_ref(v);
   scores[i] = (m == v || sigmoid_ref(m) == s) ? s : 0.f;
 }
@@ -88,12 +95,31 @@ struct SelShared {
   unsigned prefix, remaining, ncand;
 };
 
+// Histogram increment for a whole wave (every lane calls it; `valid` says whether the lane has a key).  Heat maps are concentrated --
+// an untrained head puts every score near 0.5, a trained one most of them near 0 -- so plain LDS atomics pile 64 lanes on one bin and
+// serialise; two rounds of "all lanes that share the first lane's bin add once", then the stragglers one by one.
+__device__ __forceinline__ void wave_hist_add(unsigned* hist, unsigned bin, bool valid) {
+  unsigned long long todo = __ballot(valid);
+  const int lane = threadIdx.x & 63;
+  for (int round = 0; round < 2 && todo; ++round) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const unsigned b0 = __shfl(bin, leader);
+    const bool mine = valid && bin == b0;
+    const unsigned long long same = __ballot(mine);
+    if (lane == leader) atomicAdd(&hist[b0], (unsigned)__popcll(same));
+    todo &= ~same;
+    if (mine) valid = false;
+  }
+  if (valid) atomicAdd(&hist[bin], 1u);
+}
+
 __device__ int topk_sorted(const unsigned* key, long long n, unsigned idx0, int K, SelShared& sh) {
   const int tid = threadIdx.x;
   if (tid == 0) {
     sh.prefix = 0;
     sh.remaining = (unsigned)K;
   }
+  const bool vec4 = (reinterpret_cast<uintptr_t>(key) & 15) == 0;
   const int shifts[3] = {21, 10, 0};
   const int widths[3] = {11, 11, 10};
   unsigned known_mask = 0;
@@ -103,20 +129,50 @@ __device__ int topk_sorted(const unsigned* key, long long n, unsigned idx0, int 
     const unsigned prefix = sh.prefix;
     const int sft = shifts[pass];
     const unsigned mask = (1u << widths[pass]) - 1;
-    for (long long i = tid; i < n; i += SEL_THREADS) {
-      const unsigned k = key[i];
-      if ((k & known_mask) == prefix) atomicAdd(&sh.hist[(k >> sft) & mask], 1u);
+    // zeros (suppressed non-peaks: 8 of 9 elements) never qualify and the walk below never reads the bin they would fall into.
+    // Four keys per lane and trip (one 16-byte load when the slice allows it): a single 4-byte load per trip leaves the pass waiting
+    // for memory 80 times over.  Uniform trip count: the wave-level histogram add needs every lane.
+    for (long long i0 = 0; i0 < n; i0 += 4 * SEL_THREADS) {
+      const long long i = i0 + 4 * tid;
+      unsigned k4[4] = {0u, 0u, 0u, 0u};
+      if (vec4 && i + 4 <= n) {
+        const uint4 q = *reinterpret_cast<const uint4*>(key + i);
+        k4[0] = q.x, k4[1] = q.y, k4[2] = q.z, k4[3] = q.w;
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (i + u < n) k4[u] = key[i + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) wave_hist_add(sh.hist, (k4[u] >> sft) & mask, k4[u] != 0u && (k4[u] & known_mask) == prefix);
     }
     __syncthreads();
-    if (tid == 0) {  // walk the bins from the top: the bin that holds the remaining-th largest
-      unsigned rem = sh.remaining;
-      int bin = (int)mask;
-      for (; bin > 0; --bin) {
-        if (sh.hist[bin] >= rem) break;
-        rem -= sh.hist[bin];
+    {  // the bin that holds the remaining-th largest key, counting from the top bin down: suffix sums of the 2048 bins by all 1024
+       // threads (two bins each; Hillis-Steele over the reversed thread order in the candidate array's LDS, free at this point) -- one
+       // thread walking the bins costs ~100 us per pass when the scores sit in the lower half of the value range
+      static_assert(SEL_THREADS * 2 == 2048, "two histogram bins per thread");
+      unsigned* scr = reinterpret_cast<unsigned*>(sh.cand);
+      const unsigned c0 = sh.hist[2 * tid], c1 = sh.hist[2 * tid + 1], pair = c0 + c1;
+      const int r = SEL_THREADS - 1 - tid;
+      scr[r] = pair;
+      __syncthreads();
+      for (int o = 1; o < SEL_THREADS; o <<= 1) {
+        const unsigned v = r >= o ? scr[r - o] : 0u;
+        __syncthreads();
+        scr[r] += v;
+        __syncthreads();
       }
-      sh.remaining = rem;
-      sh.prefix = prefix | ((unsigned)bin << sft);
+      const unsigned above = scr[r] - pair;         // keys in the bins above this thread's two
+      const unsigned rem = sh.remaining;
+      __syncthreads();
+      const unsigned s1 = above + c1, s0 = s1 + c0;  // keys in bins >= 2 tid + 1, >= 2 tid
+      if (above < rem && s1 >= rem) {
+        sh.remaining = rem - above;
+        sh.prefix = prefix | ((unsigned)(2 * tid + 1) << sft);
+      } else if (s1 < rem && (s0 >= rem || tid == 0)) {  // bin 0 also when fewer than `remaining` keys exist at all (the walk's fall-through)
+        sh.remaining = rem - s1;
+        sh.prefix = prefix | ((unsigned)(2 * tid) << sft);
+      }
     }
     __syncthreads();
     known_mask |= mask << sft;
@@ -124,11 +180,24 @@ __device__ int topk_sorted(const unsigned* key, long long n, unsigned idx0, int 
   const unsigned T = sh.prefix;  // K-th largest value (0 when fewer than K elements are non-zero)
   if (tid == 0) sh.ncand = 0;
   __syncthreads();
-  for (long long i = tid; i < n; i += SEL_THREADS) {
-    const unsigned k = key[i];
-    if (k >= T && k != 0) {  // zero = suppressed / never a detection (conf > 0): a top-K that reaches into the zeros is cut short
-      const unsigned slot = atomicAdd(&sh.ncand, 1u);
-      if (slot < CAND_CAP) sh.cand[slot] = ((unsigned long long)(0xFFFFFFFFu - k) << 32) | (idx0 + (unsigned)i);
+  for (long long i0 = 0; i0 < n; i0 += 4 * SEL_THREADS) {
+    const long long i = i0 + 4 * tid;
+    unsigned k4[4] = {0u, 0u, 0u, 0u};
+    if (vec4 && i + 4 <= n) {
+      const uint4 q = *reinterpret_cast<const uint4*>(key + i);
+      k4[0] = q.x, k4[1] = q.y, k4[2] = q.z, k4[3] = q.w;
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i + u < n) k4[u] = key[i + u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned k = k4[u];
+      if (k >= T && k != 0) {  // zero = suppressed / never a detection (conf > 0): a top-K that reaches into the zeros is cut short
+        const unsigned slot = atomicAdd(&sh.ncand, 1u);
+        if (slot < CAND_CAP) sh.cand[slot] = ((unsigned long long)(0xFFFFFFFFu - k) << 32) | (idx0 + (unsigned)(i + u));
+      }
     }
   }
   __syncthreads();

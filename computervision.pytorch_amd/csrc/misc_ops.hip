@@ -33,14 +33,18 @@ __global__ void maxpool2_kernel(ViewDesc in, ViewDesc out, int B, int IH, int IW
   float best[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) best[k] = -INFINITY;
+  // ceil_mode: the last window of an odd size is clipped -- its missing taps are clamped onto the window's own last row / column (the
+  // maximum does not change), so the four loads are unconditional and issued together
+  h8 v4[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int hh = 2 * h + (q >> 1), ww = 2 * w + (q & 1);
-    if (hh >= IH || ww >= IW) continue;  // ceil_mode: the last window of an odd size is clipped
-    const h8 v = *reinterpret_cast<const h8*>(in.p + voff(in, b, (long long)hh * IW + ww) + cg * 8);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) best[k] = fmaxf(best[k], (float)v[k]);
+    const int hh = min(2 * h + (q >> 1), IH - 1), ww = min(2 * w + (q & 1), IW - 1);
+    v4[q] = *reinterpret_cast<const h8*>(in.p + voff(in, b, (long long)hh * IW + ww) + cg * 8);
   }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) best[k] = fmaxf(best[k], (float)v4[q][k]);
   h8 o;
 #pragma unroll
   for (int k = 0; k < 8; ++k) o[k] = (half_t)best[k];
@@ -604,27 +608,42 @@ __global__ __launch_bounds__(256) void dwconvt_kernel(ViewDesc in, ViewDesc out,
 #pragma unroll
   for (int k = 0; k < 8; ++k) acc[k] = 0.f;
   const int ky0 = (oy + P) % f, kx0 = (ox + P) % f;
+  // the 2 x 2 taps with out-of-range ones clamped onto a valid pixel / tap and given the factor 0: the four pixel loads are unconditional
+  // (issued together; a branch per tap waits for memory once per tap), an absent tap adds exactly +0
+  int kys[2], kxs[2], iys[2], ixs[2];
+  float my[2], mx[2];
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
-    const int ky = ky0 + a * f;
-    const int iy = (oy + P - ky) / f;  // exact
-    if (ky >= K || iy < 0 || iy >= IH) continue;
+    const int ky = ky0 + a * f, iy = (oy + P - ky) / f;  // exact
+    const bool ok = ky < K && iy >= 0 && iy < IH;
+    kys[a] = ok ? ky : ky0;
+    iys[a] = ok ? iy : (iy < 0 ? 0 : IH - 1);
+    my[a] = ok ? 1.f : 0.f;
+    const int kx = kx0 + a * f, ix = (ox + P - kx) / f;
+    const bool okx = kx < K && ix >= 0 && ix < IW;
+    kxs[a] = okx ? kx : kx0;
+    ixs[a] = okx ? ix : (ix < 0 ? 0 : IW - 1);
+    mx[a] = okx ? 1.f : 0.f;
+  }
+  h8 v[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) v[a][c] = *reinterpret_cast<const h8*>(in.p + voff(in, b, (long long)iys[a] * IW + ixs[c]) + cg * 8);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      const int kx = kx0 + c * f;
-      const int ix = (ox + P - kx) / f;
-      if (kx >= K || ix < 0 || ix >= IW) continue;
-      const h8 v = *reinterpret_cast<const h8*>(in.p + voff(in, b, (long long)iy * IW + ix) + cg * 8);
+      const float m = my[a] * mx[c];
       if (staged) {
-        const float* wl = sw + (ky * K + kx) * C + cg * 8;
+        const float* wl = sw + (kys[a] * K + kxs[c]) * C + cg * 8;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] = fmaf((float)v[k], wl[k], acc[k]);
+        for (int k = 0; k < 8; ++k) acc[k] = fmaf((float)v[a][c][k], wl[k] * m, acc[k]);
       } else {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] = fmaf((float)v[k], w[((long long)(cg * 8 + k) * K + ky) * K + kx], acc[k]);
+        for (int k = 0; k < 8; ++k) acc[k] = fmaf((float)v[a][c][k], w[((long long)(cg * 8 + k) * K + kys[a]) * K + kxs[c]] * m, acc[k]);
       }
     }
-  }
   h8 o;
 #pragma unroll
   for (int k = 0; k < 8; ++k) o[k] = (half_t)acc[k];
