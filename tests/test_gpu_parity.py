@@ -1246,6 +1246,18 @@ def test_centernet_full_size_properties(dev):
     d = algo.decode_raw(sparse, 128, 128)
     assert int(d["counts"][0]) == 7 and sorted(d["topk_index"][0, :7].tolist()) == sorted((y * 128 + x_) * 80 + c for y, x_, c in peaks)
     assert d["topk_index"][0, 7:].tolist() == [-1] * 93
+    # logits spread over several octaves of score (0.007 ... 0.995: every digit of the radix select sees many occupied bins, the lanes of
+    # a wave land in different bins; the top stays below the saturated range where fp32 sigmoids tie) against torch: sigmoid, the
+    # reference's 3 x 3 pool over (x, class), top-100 of the surviving peaks in descending order
+    gq = torch.Generator().manual_seed(11)
+    wide = torch.zeros(2, 128 * 128, 96)
+    wide[..., :80] = torch.randn(2, 128 * 128, 80, generator=gq)
+    dw = algo.decode_raw(wide.to(dev), 128, 128)
+    heat = torch.sigmoid(wide[..., :80]).reshape(2, 128, 128, 80)
+    peak = heat * (F.max_pool2d(heat, 3, 1, 1) == heat)                      # (B, H, W, C) pooled as if it were NCHW: over (x, class)
+    want = torch.topk(peak.reshape(2, -1), 100)
+    assert int((want.values[:, 1:] == want.values[:, :-1]).sum()) == 0       # no ties in this draw: the order is unique
+    assert torch.equal(dw["topk_index"].cpu().long(), want.indices)
 
 
 # ---- DeepLabv3+ ResNet-101, inference --------------------------------------------------------------------
