@@ -16,7 +16,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_dl -- python 
 for wl in centernet_train ssd_train yolov7_train; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$wl -- python $ROOT/bench.py --workload $wl --steps 5 --warmup 2 > $OUT/${R}_bench_${wl}_under_rocprof.json 2> $OUT/stats_$wl.err
 done
+for wl in ssd yolov7 deeplab; do   # inference tails (decode / NMS / resize kernels beside the convolutions)
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_inf_$wl -- python $ROOT/bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/stats_inf_$wl.err
+done
 cd $ROOT
+for wl in ssd yolov7 deeplab; do cp $(ls $OUT/stats_inf_$wl/*/*_kernel_stats.csv | head -1) $OUT/${R}_bench_${wl}_kernel_stats.csv; done
 for wl in centernet_train ssd_train yolov7_train; do cp $(ls $OUT/stats_$wl/*/*_kernel_stats.csv | head -1) $OUT/${R}_bench_${wl}_kernel_stats.csv; done
 cp $(ls $OUT/stats/*/*_kernel_stats.csv | head -1) $OUT/${R}_bench_kernel_stats.csv
 cp $(ls $OUT/stats_cn/*/*_kernel_stats.csv | head -1) $OUT/${R}_bench_centernet_kernel_stats.csv
@@ -38,5 +42,5 @@ python tools/op_profile.py 3 deeplab > $OUT/${R}_op_profile_deeplab_train.txt 2>
 python tools/op_profile.py 3 ssd > $OUT/${R}_op_profile_ssd_train.txt 2>> $OUT/bench.err
 python tools/op_profile.py 3 yolo7 > $OUT/${R}_op_profile_yolov7_train.txt 2>> $OUT/bench.err
 python tools/op_profile.py 3 centernet > $OUT/${R}_op_profile_centernet_train.txt 2>> $OUT/bench.err
-rm -rf $OUT/stats $OUT/stats_cn $OUT/stats_dl $OUT/stats_centernet_train $OUT/stats_ssd_train $OUT/stats_yolov7_train $OUT/pmc_fetch $OUT/pmc_write
+rm -rf $OUT/stats_inf_ssd $OUT/stats_inf_yolov7 $OUT/stats_inf_deeplab $OUT/stats $OUT/stats_cn $OUT/stats_dl $OUT/stats_centernet_train $OUT/stats_ssd_train $OUT/stats_yolov7_train $OUT/pmc_fetch $OUT/pmc_write
 ls -la $OUT
