@@ -136,6 +136,10 @@ PROTOTYPES = {
     "cvx_stem_train_nchw": (_I32, [_P, _I32, _I32, _I32, _P, _I32, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
     "cvx_stem_eval_nchw": (_I32, [_P, _I32, _I32, _I32, _P, _I32, _P, _P, _P, _P]),
     "cvx_stem_wgrad_nchw": (_I32, [_P, _I32, _I32, _I32, _P, _I32, _P, _P]),
+    "cvx_chain_pair_unit": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _I32, _I32, _I32, C.POINTER(_F), _P]),
+    "cvx_chain_conv_unit": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _I32, _P, _P, _I32, _P, _I32, _I32, _I32, C.POINTER(_F), _P]),
+    "cvx_chain_detect_unit": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32,
+                                     _I32, _I32, C.POINTER(_F), _P]),
     "cvx_stem_backward_nchw": (_I32, [_P, _I32, _I32, _I32, _P, _P, _I32, _P, _P, _P, _F, _P, _P, _P, _P]),
 }
 

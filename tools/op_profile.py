@@ -2,7 +2,7 @@
 cvx_engine_profile_dump records with the op list and prints, per (class, op), the mean time, algorithmic TF/s and GB/s, and the
 time the tighter of the two rooflines would allow.
 
-    python tools/op_profile.py [steps] [yolov8|deeplab|yolo7|ssd|centernet] > gpurun_out/op_profile.txt
+    python tools/op_profile.py [steps] [yolov8|yolov8_eval|deeplab|yolo7|ssd|centernet] > gpurun_out/op_profile.txt
 """
 import collections
 import csv
@@ -24,6 +24,8 @@ def main():
         return report(*deeplab_step(), steps)
     if len(sys.argv) > 2 and sys.argv[2] in ("yolo7", "ssd", "centernet"):
         return report(*trainer_step(sys.argv[2]), steps)
+    if len(sys.argv) > 2 and sys.argv[2] == "yolov8_eval":
+        return report(*yolov8_eval(), steps)
     from computervision.pytorch_amd.model import Yolo8
     from computervision.pytorch_amd.train import FlatAdam, FusedTrainStep, V8DetectionLoss
     from configs import Yolo8DetConfig
@@ -40,6 +42,25 @@ def main():
         step(x, batch)
     torch.cuda.synchronize()
     report(model._last_engine, lambda: step(x, batch), steps)
+
+
+def yolov8_eval():
+    """eval-mode forward of YOLOv8-n, batch 32, 640x640 (the forward north_star quotes its MFMA fraction on)"""
+    from computervision.pytorch_amd.model import Yolo8
+    from computervision.pytorch_amd import synth
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    model = Yolo8("n", 80).to(dev).eval()
+    x = synth.images(32, 640, 640, seed=1).to(dev)
+    with torch.no_grad():
+        for _ in range(3):
+            model._run_forward(x, False)
+    torch.cuda.synchronize()
+
+    def run():
+        with torch.no_grad():
+            model._run_forward(x, False)
+    return model._last_engine, run
 
 
 def deeplab_step():
