@@ -49,13 +49,14 @@ struct ChainPass {
   int RW, npix;              // output region: width, pixel count (flat enumeration q = qy * RW + qx)
   int drain;                 // 1: full vmcnt(0) before the first chunk (global stores or late loads precede)
   // epilogue
-  int par_off;               // float offset of [scale rows | shift rows] (fp16 out) or [bias rows] (fp32 out) in the LDS parameter table
+  int par_off, par_off2;     // float offsets of the pass's scale rows and shift rows (fp16 out) or bias rows (fp32 out, par_off) in the LDS parameter table
   int act;                   // 0 SiLU, 1 ReLU, 2 none
   int out_kind;              // 0: fp16 LDS plane, 1: fp32 global rows (+ bias)
   int out_base, out_ps, out_W, oy, ox, out_c0;  // destination plane, pixel (oy + qy, ox + qx), first channel (halves)
   int has_res, res_base, res_ps, res_W, ry, rx, res_c0;
   int img_scale, img_y0, img_x0, IH, IW;  // image coordinates of region pixel (0, 0) and the image size there: out-of-image pixels are stored as zero
-  float* out32;              // out_kind 1: element (b, iy * IW + ix, out_c0 + n)
+  float* out32;              // out_kind 1: element (b, iy * IW + ix, out_c0 + n) of out32 (or, when NULL, of the launch's base pointer) + out32_off
+  long long out32_off;
   long long out_bstride;
   int out_ld;
 };
@@ -83,10 +84,18 @@ struct ChainDesc {
 };
 
 // ---- host side: a planned chain (descriptor in device memory + launch geometry) ----
+// weight pre-pack job: [rows][K] fp16 (row pitch src_ld) -> ring chunk images (conv_chain.hip: chain_pack_kernel)
+struct ChainPackJob {
+  const half_t* src;
+  half_t* dst;
+  int src_ld, rows, K, RR, units;  // units: 16-byte units of the destination
+};
+#define CHAIN_MAX_JOBS CHAIN_MAX_PASSES
 struct ChainPlan {
   ChainDesc* d_desc = nullptr;
   void* d_jobs = nullptr;  // device array of the weight pre-pack jobs (one per pass)
   int njobs = 0, max_job_units = 0;
+  ChainPackJob jobs[CHAIN_MAX_JOBS];  // host copy (the engine packs the weights of all its chains in one launch)
   int cfg = -1;        // index into the compiled (MT, NT, KSUB) table
   int lds_bytes = 0;
   int blocks = 0;
@@ -103,11 +112,14 @@ struct ChainStageSpec {
   int wt_ld, cout;
   const float *scale, *shift;  // folded BN (fp16 out) ...
   const float* bias;           // ... or bias (fp32 out)
+  int live_params;             // 1: the kernel reads scale / shift / bias from these arrays at every launch (shift == scale + cout required);
+                               // 0: they are copied into the plan when it is built
   int act;
   int out_plane, out_c0;     // out_plane < 0: fp32 global rows
   int res_plane, res_c0;     // res_plane < 0: none
   int ry0, rx0, RH, RW;      // output region in OUT-plane pixel coordinates (fp32 out: in tile coordinates, scale 1)
-  float* out32;
+  float* out32;              // NULL: the base pointer comes with the launch (cvx_chain_launch's out32_base)
+  long long out32_off;       // elements added to the base
   long long out_bstride;
   int out_ld, out32_c0;
 };
@@ -150,7 +162,9 @@ int cvx_chain_plan(const ChainSpec& spec, ChainPlan* out, void** d_alloc, bool d
 inline int cvx_chain_pixel_units(int C) { return (C / 8) | 1; }
 // Re-packs the chain's weights from the fp16 shadows into the ring image order (call after the shadows changed, before the launch).
 int cvx_chain_pack(const ChainPlan& plan, hipStream_t stream);
-int cvx_chain_launch(const ChainPlan& plan, hipStream_t stream);
+// the same for a device array of jobs gathered from several plans
+int cvx_chain_pack_jobs(const ChainPackJob* d_jobs, int njobs, int max_job_units, hipStream_t stream);
+int cvx_chain_launch(const ChainPlan& plan, hipStream_t stream, float* out32_base = nullptr);
 
 // ---- specs of the fusion groups (conv_chain.hip) ----
 struct ChainConvArgs {
@@ -159,7 +173,11 @@ struct ChainConvArgs {
   const float *scale, *shift;  // folded BN (fp16 out)
   const float* bias;           // fp32 out
   int act;                     // 0 SiLU, 1 ReLU, 2 none
+  int live;                    // ChainStageSpec::live_params
 };
+// estimated device time (us) of a planned chain on one MI355X: rounds of workgroups x (MFMA time of the per-wave register tiles at the
+// measured ~45 % issue efficiency + fixed prologue / epilogue / store time) -- ranks tile shapes, nothing else
+double cvx_chain_cost_us(const ChainSpec& spec, const ChainPlan& plan);
 int cvx_chain_spec_pair(ChainSpec* sp, const half_t* x, long long x_bs, int x_ld, int B, int H, int W, int C, const ChainConvArgs& c1,
                         const ChainConvArgs& c2, bool shortcut, half_t* out, long long out_bs, int out_ld, int TH, int TW, const half_t* zeros);
 int cvx_chain_spec_single(ChainSpec* sp, const half_t* x, long long x_bs, int x_ld, int B, int IH, int IW, int Cin, int k, int stride, int up,

@@ -59,7 +59,7 @@ __device__ __forceinline__ unsigned fast_div(unsigned u, unsigned m) { return __
 // fields of a pass the epilogue needs, copied into registers once per pass (a reference into the descriptor would be re-read
 // from memory at every use: the compiler must assume the LDS-DMA intrinsic may have written it)
 struct EpiArgs {
-  int rows, par_off, act, out_kind, has_res;
+  int rows, par_off, par_off2, act, out_kind, has_res;
   float* out32;  // already advanced by the image
 };
 
@@ -240,7 +240,7 @@ __device__ __forceinline__ void run_pass_t(const ChainDesc& d, RingCursor& rc, c
       if (j * 32 + g * 8 >= E.rows) continue;
       const int n0 = j * 32 + g * 8 + lh * 4;
       const f4 sc = *reinterpret_cast<const f4*>(par + E.par_off + n0);
-      const f4 sh = *reinterpret_cast<const f4*>(par + E.par_off + E.rows + n0);
+      const f4 sh = *reinterpret_cast<const f4*>(par + E.par_off2 + n0);
       f4 v[MTU];
 #pragma unroll
       for (int i = 0; i < MTU; ++i)
@@ -278,7 +278,7 @@ __device__ __forceinline__ void run_pass_t(const ChainDesc& d, RingCursor& rc, c
 // K-step s + 1 are requested before the MFMAs of s.  (A 256-register budget also keeps the accumulators in VGPRs: with 512 the compiler
 // parked them in AGPRs and copied all of them to VGPRs and back around every barrier of the K loop, 96 + 96 moves per chunk.)
 template <int MT, int NT, int KSUB>
-__global__ __launch_bounds__(64 * NW) void conv_chain_kernel(const ChainDesc* __restrict__ dp) {
+__global__ __launch_bounds__(64 * NW) void conv_chain_kernel(const ChainDesc* __restrict__ dp, float* out32_base) {
   using G = ChainGeom<MT, NT, KSUB>;
   constexpr int NWAIT = (SLOTS - 2) * G::PB;
   static_assert(NWAIT <= 63, "vmcnt field");
@@ -348,8 +348,8 @@ __global__ __launch_bounds__(64 * NW) void conv_chain_kernel(const ChainDesc* __
                                   : 16 * (P.out_base + ((P.oy + qy) * P.out_W + P.ox + qx) * P.out_ps) + 2 * P.out_c0;
         pixr[i] = 16 * (P.res_base + ((P.ry + qy) * P.res_W + P.rx + qx) * P.res_ps) + 2 * P.res_c0;
       }
-      E.rows = P.rows, E.par_off = P.par_off, E.act = P.act, E.out_kind = P.out_kind, E.has_res = P.has_res;
-      E.out32 = P.out32 + (P.out_kind == 1 ? (long long)b * P.out_bstride : 0);
+      E.rows = P.rows, E.par_off = P.par_off, E.par_off2 = P.par_off2, E.act = P.act, E.out_kind = P.out_kind, E.has_res = P.has_res;
+      E.out32 = (P.out32 ? P.out32 : out32_base) + (P.out_kind == 1 ? P.out32_off + (long long)b * P.out_bstride : 0);
     }
     const int subtiles = (p_npix + 31) >> 5;
     const int mt_pass = min(MT, (subtiles + NW - 1) / NW);  // sub-tiles per wave this pass (workgroup-uniform)
@@ -431,11 +431,6 @@ __global__ __launch_bounds__(64 * NW) void conv_chain_kernel(const ChainDesc* __
 }
 
 // Weight pre-pack: [rows][K] fp16 (row pitch src_ld) -> chunk images [chunk][K-step][k-half][RR rows][8] (zero rows / zero K tail).
-struct ChainPackJob {
-  const half_t* src;
-  half_t* dst;
-  int src_ld, rows, K, RR, units;  // units: 16-byte units of the destination = nchunks * KSUB * 2 * RR
-};
 __global__ void chain_pack_kernel(const ChainPackJob* __restrict__ jobs) {
   const ChainPackJob J = jobs[blockIdx.y];
   for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < J.units; u += gridDim.x * blockDim.x) {
@@ -463,12 +458,12 @@ constexpr CfgInfo kCfg[] = {
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
 template <int I>
-int launch_cfg_i(const ChainPlan& plan, hipStream_t stream) {
+int launch_cfg_i(const ChainPlan& plan, hipStream_t stream, float* out32_base) {
   constexpr CfgInfo c = kCfg[I];
   auto kern = conv_chain_kernel<c.MT, c.NT, c.KSUB>;
   static unsigned long long optin_mask = 0;
   CVX_TRY(cvx_lds_optin((const void*)kern, 160 * 1024, &optin_mask));
-  hipLaunchKernelGGL(kern, dim3(plan.blocks), dim3(64 * NW), plan.lds_bytes, stream, (const ChainDesc*)plan.d_desc);
+  hipLaunchKernelGGL(kern, dim3(plan.blocks), dim3(64 * NW), plan.lds_bytes, stream, (const ChainDesc*)plan.d_desc, out32_base);
   return 0;
 }
 
@@ -481,26 +476,51 @@ inline int odd_stride(int P) { return cvx_chain_pixel_units(P * 8); }
 
 }  // namespace
 
-int cvx_chain_launch(const ChainPlan& plan, hipStream_t stream) {
+int cvx_chain_launch(const ChainPlan& plan, hipStream_t stream, float* out32_base) {
   CVX_CHECK(plan.d_desc && plan.cfg >= 0 && plan.cfg < kNumCfg, "chain: plan not built");
   switch (plan.cfg) {
-    case 0: CVX_TRY(launch_cfg_i<0>(plan, stream)); break;
-    case 1: CVX_TRY(launch_cfg_i<1>(plan, stream)); break;
-    case 2: CVX_TRY(launch_cfg_i<2>(plan, stream)); break;
-    case 3: CVX_TRY(launch_cfg_i<3>(plan, stream)); break;
-    case 4: CVX_TRY(launch_cfg_i<4>(plan, stream)); break;
-    default: CVX_TRY(launch_cfg_i<5>(plan, stream)); break;
+    case 0: CVX_TRY(launch_cfg_i<0>(plan, stream, out32_base)); break;
+    case 1: CVX_TRY(launch_cfg_i<1>(plan, stream, out32_base)); break;
+    case 2: CVX_TRY(launch_cfg_i<2>(plan, stream, out32_base)); break;
+    case 3: CVX_TRY(launch_cfg_i<3>(plan, stream, out32_base)); break;
+    case 4: CVX_TRY(launch_cfg_i<4>(plan, stream, out32_base)); break;
+    default: CVX_TRY(launch_cfg_i<5>(plan, stream, out32_base)); break;
   }
   CVX_HIP(hipGetLastError());
   return 0;
 }
 
-int cvx_chain_pack(const ChainPlan& plan, hipStream_t stream) {
-  CVX_CHECK(plan.d_jobs && plan.njobs > 0, "chain: plan not built");
-  const int gx = std::min(64, (plan.max_job_units + 255) / 256);
-  hipLaunchKernelGGL(chain_pack_kernel, dim3(gx, plan.njobs), dim3(256), 0, stream, (const ChainPackJob*)plan.d_jobs);
+int cvx_chain_pack_jobs(const ChainPackJob* d_jobs, int njobs, int max_job_units, hipStream_t stream) {
+  CVX_CHECK(d_jobs && njobs > 0, "chain: no pack jobs");
+  const int gx = std::min(64, (max_job_units + 255) / 256);
+  hipLaunchKernelGGL(chain_pack_kernel, dim3(gx, njobs), dim3(256), 0, stream, d_jobs);
   CVX_HIP(hipGetLastError());
   return 0;
+}
+int cvx_chain_pack(const ChainPlan& plan, hipStream_t stream) {
+  CVX_CHECK(plan.d_jobs && plan.njobs > 0, "chain: plan not built");
+  return cvx_chain_pack_jobs((const ChainPackJob*)plan.d_jobs, plan.njobs, plan.max_job_units, stream);
+}
+
+double cvx_chain_cost_us(const ChainSpec& sp, const ChainPlan& plan) {
+  const CfgInfo& c = kCfg[plan.cfg];
+  const int RR = 32 * c.NT;
+  double clk = 0;
+  for (int s = 0; s < sp.nstages; ++s) {
+    const ChainStageSpec& st = sp.stages[s];
+    const int subt = (st.RH * st.RW + 31) / 32;
+    const int mt = std::min(c.MT, (subt + NW - 1) / NW);
+    const int K = st.k * st.k * (1 + st.nextra) * st.cin;
+    const int ksteps = ((K + KS * c.KSUB - 1) / (KS * c.KSUB)) * c.KSUB;
+    for (int r0 = 0; r0 < st.cout; r0 += RR) {
+      const int nt = (std::min(RR, st.cout - r0) + 31) / 32;
+      clk += (double)ksteps * 2 * mt * nt * 32 / 0.45;  // two waves per SIMD, 32 cycles per MFMA
+      clk += 2500.0 * mt * nt;                           // epilogue
+    }
+  }
+  const double per_wg = clk / 2300.0 + 6.0;  // us at ~2.3 GHz + prologue (plane load) and store
+  const int rounds = (plan.blocks + 255) / 256;
+  return per_wg * rounds + 2.0;
 }
 
 // Turns a ChainSpec into the device descriptor: lays the planes out in LDS (odd pixel strides, aliases), splits every stage
@@ -509,7 +529,7 @@ int cvx_chain_pack(const ChainPlan& plan, hipStream_t stream) {
 // (then the least wasted weight rows) that covers the largest region and fits the LDS.
 int cvx_chain_plan(const ChainSpec& sp, ChainPlan* out, void** d_alloc, bool dry_run) {
   CVX_CHECK(sp.nplanes > 0 && sp.nplanes <= 8 && sp.nstages > 0 && sp.nloads > 0, "chain: empty spec");
-  CVX_CHECK(sp.nstages <= CHAIN_MAX_PASSES && sp.nloads < CHAIN_MAX_LOADS && sp.nstores <= CHAIN_MAX_STORES, "chain: spec too long");
+  CVX_CHECK(sp.nstages <= CHAIN_MAX_PASSES && sp.nloads + sp.nstages <= CHAIN_MAX_LOADS && sp.nstores <= CHAIN_MAX_STORES, "chain: spec too long");
   // ---- planes ----
   int base[8], ps[8], units = 0;
   struct Rect {
@@ -534,9 +554,13 @@ int cvx_chain_plan(const ChainSpec& sp, ChainPlan* out, void** d_alloc, bool dry
     valid[i] = Rect{0, 0, 0, 0};
   }
   for (int l = 0; l < sp.nloads; ++l) valid[sp.loads[l].plane] = Rect{0, 0, sp.planes[sp.loads[l].plane].PH, sp.planes[sp.loads[l].plane].PW};
-  int par_floats = 0;
-  for (int s = 0; s < sp.nstages; ++s) par_floats += (sp.stages[s].out_plane >= 0 ? 2 : 1) * ((sp.stages[s].cout + 3) & ~3);
-  par_floats = (par_floats + 255) & ~255;  // whole DMA pieces (64 units of 4 floats)
+  // parameter table: one segment per stage, [scale cout | shift cout] or [bias cout], each a whole number of DMA pieces (256 floats)
+  int seg_off[CHAIN_MAX_PASSES], seg_floats[CHAIN_MAX_PASSES], par_floats = 0;
+  for (int s = 0; s < sp.nstages; ++s) {
+    seg_off[s] = par_floats;
+    seg_floats[s] = (sp.stages[s].out_plane >= 0 ? 2 : 1) * sp.stages[s].cout;
+    par_floats += (seg_floats[s] + 255) & ~255;
+  }
   const int par_base = units;
   units += par_floats / 4;
 
@@ -589,7 +613,6 @@ int cvx_chain_plan(const ChainSpec& sp, ChainPlan* out, void** d_alloc, bool dry
   };
   std::vector<ParCopy> par_copies;
   std::vector<ChainPackJob> jobs;
-  int par_used = 0;
 
   // ---- passes ----
   int np = 0;
@@ -655,7 +678,8 @@ int cvx_chain_plan(const ChainSpec& sp, ChainPlan* out, void** d_alloc, bool dry
       P.img_x0 = xo0 + st.rx0;
       P.IH = sp.OH * so;
       P.IW = sp.OW * so;
-      P.par_off = par_used;
+      P.par_off = seg_off[s] + r0;
+      P.par_off2 = seg_off[s] + st.cout + r0;
       if (st.out_plane >= 0) {
         CVX_CHECK(st.scale && st.shift, "chain: fp16 output needs the folded scale / shift");
         P.out_kind = 0;
@@ -665,9 +689,6 @@ int cvx_chain_plan(const ChainSpec& sp, ChainPlan* out, void** d_alloc, bool dry
         P.oy = st.ry0;
         P.ox = st.rx0;
         P.out_c0 = st.out_c0 + r0;
-        par_copies.push_back({st.scale + r0, par_used, P.rows});
-        par_copies.push_back({st.shift + r0, par_used + P.rows, P.rows});
-        par_used += 2 * P.rows;
         if (st.res_plane >= 0) {
           const ChainPlaneSpec& pr = sp.planes[st.res_plane];
           CVX_CHECK(pr.scale == so, "chain: residual plane resolution");
@@ -683,14 +704,14 @@ int cvx_chain_plan(const ChainSpec& sp, ChainPlan* out, void** d_alloc, bool dry
           CVX_CHECK(st.res_c0 % 4 == 0 && st.res_c0 + st.cout <= pr.C, "chain: residual channels");
         }
       } else {
-        CVX_CHECK(st.out32 && st.bias && ((uintptr_t)st.out32 % 16) == 0 && st.out_ld % 4 == 0 && st.out32_c0 % 4 == 0, "chain: fp32 output needs an aligned destination and a bias");
+        CVX_CHECK(st.bias && ((uintptr_t)st.out32 % 16) == 0 && st.out32_off % 4 == 0 && st.out_ld % 4 == 0 && st.out32_c0 % 4 == 0,
+                  "chain: fp32 output needs an aligned destination and a bias");
         P.out_kind = 1;
         P.out32 = st.out32;
+        P.out32_off = st.out32_off;
         P.out_bstride = st.out_bstride;
         P.out_ld = st.out_ld;
         P.out_c0 = st.out32_c0 + r0;
-        par_copies.push_back({st.bias + r0, par_used, P.rows});
-        par_used += P.rows;
       }
       // the pass after one with global stores must drain: stores and loads share vmcnt and do not retire in order between the kinds
       if (np > 0 && d.pass[np - 1].out_kind == 1) P.drain = 1;
@@ -701,7 +722,18 @@ int cvx_chain_plan(const ChainSpec& sp, ChainPlan* out, void** d_alloc, bool dry
   }
   first_pass_of_stage[sp.nstages] = np;
   d.npass = np;
-  CVX_CHECK(par_used <= par_floats, "chain: parameter table overflow (planner bug)");
+  for (int s = 0; s < sp.nstages; ++s) {
+    const ChainStageSpec& st = sp.stages[s];
+    if (st.live_params) {
+      CVX_CHECK(st.out_plane < 0 || st.shift == st.scale + st.cout, "chain: live parameters need shift == scale + cout");
+      CVX_CHECK(((uintptr_t)(st.out_plane >= 0 ? st.scale : st.bias) % 16) == 0, "chain: live parameter arrays must be 16-byte aligned");
+    } else if (st.out_plane >= 0) {
+      par_copies.push_back({st.scale, seg_off[s], st.cout});
+      par_copies.push_back({st.shift, seg_off[s] + st.cout, st.cout});
+    } else {
+      par_copies.push_back({st.bias, seg_off[s], st.cout});
+    }
+  }
 
   // ---- loads ----
   int nl = 0;
@@ -736,13 +768,17 @@ int cvx_chain_plan(const ChainSpec& sp, ChainPlan* out, void** d_alloc, bool dry
     }
     bytes += 2.0 * sp.B * (ls.IH >> ls.up) * (ls.IW >> ls.up) * ls.c;
   }
-  {
+  const int first_par_load = nl;
+  CVX_CHECK(nl + sp.nstages <= CHAIN_MAX_LOADS, "chain: too many loads");
+  for (int s = 0; s < sp.nstages; ++s) {  // one raw load per stage segment (source: the live arrays, or the plan's copy -- set below)
     ChainLoad& L = d.load[nl++];
     L.kind = 1;
-    L.base = par_base;
-    L.nunits = par_floats / 4;
+    L.base = par_base + seg_off[s] / 4;
+    L.nunits = (seg_floats[s] + 3) / 4;
     L.per_wave = ((L.nunits + 63) / 64 + NW - 1) / NW;
     L.at_pass = 0;
+    const ChainStageSpec& st = sp.stages[s];
+    L.src = st.live_params ? (const void*)(st.out_plane >= 0 ? st.scale : st.bias) : nullptr;
   }
   d.nload = nl;
   // ---- stores ----
@@ -797,7 +833,10 @@ int cvx_chain_plan(const ChainSpec& sp, ChainPlan* out, void** d_alloc, bool dry
     maxu = std::max(maxu, jobs[i].units);
   }
   CVX_HIP(hipMemcpy(dev + jobs_off, jobs.data(), jobs.size() * sizeof(ChainPackJob), hipMemcpyHostToDevice));
-  d.load[nl - 1].src = dev;
+  for (int s = 0; s < sp.nstages; ++s)
+    if (!d.load[first_par_load + s].src) d.load[first_par_load + s].src = dev + (size_t)seg_off[s] * 4;
+  CVX_CHECK((int)jobs.size() <= CHAIN_MAX_JOBS, "chain: too many pack jobs");
+  for (size_t i = 0; i < jobs.size(); ++i) out->jobs[i] = jobs[i];
   CVX_HIP(hipMemcpy(dev + desc_off, &d, sizeof(d), hipMemcpyHostToDevice));
   out->d_jobs = dev + jobs_off;
   out->njobs = (int)jobs.size();
@@ -830,6 +869,7 @@ ChainStageSpec stage_fp16(int in_plane, int in_c0, int cin, int k, int stride, c
   st.shift = c.shift;
   st.bias = c.bias;
   st.act = c.act;
+  st.live_params = c.live;
   st.out_plane = out_plane;
   st.out_c0 = out_c0;
   st.res_plane = res_plane;
@@ -926,12 +966,14 @@ int cvx_chain_spec_detect(ChainSpec* sp, const half_t* x, long long x_bs, int x_
   sp->stages[1] = stage_fp16(1, 0, cb, 3, 1, b1, 2, 0, 0, 0, TH, TW);
   sp->stages[2] = stage_fp16(1, cb, cc, 3, 1, b2, 3, 0, 0, 0, TH, TW);
   ChainStageSpec s3 = stage_fp16(2, 0, cb, 1, 1, o1, -1, 0, 0, 0, TH, TW);
-  s3.out32 = pred + (long long)a_off * pred_ld;
+  s3.out32 = pred;  // NULL: supplied with every launch
+  s3.out32_off = (long long)a_off * pred_ld;
   s3.out_bstride = pred_bs;
   s3.out_ld = pred_ld;
   s3.out32_c0 = 0;
   ChainStageSpec s4 = stage_fp16(3, 0, cc, 1, 1, o2, -1, 0, 0, 0, TH, TW);
   s4.out32 = s3.out32;
+  s4.out32_off = s3.out32_off;
   s4.out_bstride = pred_bs;
   s4.out_ld = pred_ld;
   s4.out32_c0 = 64;
@@ -991,7 +1033,7 @@ extern "C" int cvx_chain_pair_unit(const void* x, int32_t batch, int32_t h, int3
   const half_t* zeros;
   CVX_TRY(g_unit_zeros.get(&zeros));
   ChainSpec sp;
-  ChainConvArgs c1{(const half_t*)w1, 9 * c, c, sc1, sh1, nullptr, 0}, c2{(const half_t*)w2, 9 * c, c, sc2, sh2, nullptr, 0};
+  ChainConvArgs c1{(const half_t*)w1, 9 * c, c, sc1, sh1, nullptr, 0, 0}, c2{(const half_t*)w2, 9 * c, c, sc2, sh2, nullptr, 0, 0};
   CVX_TRY(cvx_chain_spec_pair(&sp, (const half_t*)x, (long long)h * w * c, c, batch, h, w, c, c1, c2, shortcut != 0, (half_t*)out, (long long)h * w * c, c, th,
                               tw, zeros));
   return run_spec_once(sp, (hipStream_t)hip_stream, reps, elapsed_us);
@@ -1004,7 +1046,7 @@ extern "C" int cvx_chain_conv_unit(const void* x, int32_t batch, int32_t ih, int
   const half_t* zeros;
   CVX_TRY(g_unit_zeros.get(&zeros));
   ChainSpec sp;
-  ChainConvArgs c{(const half_t*)wt, k * k * cin, cout, scale, shift, nullptr, act};
+  ChainConvArgs c{(const half_t*)wt, k * k * cin, cout, scale, shift, nullptr, act, 0};
   const int sih = upsample ? ih / 2 : ih, siw = upsample ? iw / 2 : iw;
   const int oh = ih / stride, ow = iw / stride;
   CVX_TRY(cvx_chain_spec_single(&sp, (const half_t*)x, (long long)sih * siw * cin, cin, batch, ih, iw, cin, k, stride, upsample ? 1 : 0, c, (half_t*)out,
@@ -1021,9 +1063,9 @@ extern "C" int cvx_chain_detect_unit(const void* x, int32_t batch, int32_t h, in
   CVX_TRY(g_unit_zeros.get(&zeros));
   ChainSpec sp;
   const int no = 64 + ncp;
-  ChainConvArgs a{(const half_t*)wa, 9 * cin, cb + cc, sca, sha, nullptr, 0};
-  ChainConvArgs b1{(const half_t*)wb1, 9 * cb, cb, scb, shb, nullptr, 0}, b2{(const half_t*)wb2, 9 * cc, cc, scb + cb, shb + cb, nullptr, 0};
-  ChainConvArgs o1{(const half_t*)wo1, cb, 64, nullptr, nullptr, bias, 2}, o2{(const half_t*)wo2, cc, ncp, nullptr, nullptr, bias + 64, 2};
+  ChainConvArgs a{(const half_t*)wa, 9 * cin, cb + cc, sca, sha, nullptr, 0, 0};
+  ChainConvArgs b1{(const half_t*)wb1, 9 * cb, cb, scb, shb, nullptr, 0, 0}, b2{(const half_t*)wb2, 9 * cc, cc, scb + cb, shb + cb, nullptr, 0, 0};
+  ChainConvArgs o1{(const half_t*)wo1, cb, 64, nullptr, nullptr, bias, 2, 0}, o2{(const half_t*)wo2, cc, ncp, nullptr, nullptr, bias + 64, 2, 0};
   CVX_TRY(cvx_chain_spec_detect(&sp, (const half_t*)x, (long long)h * w * cin, cin, batch, h, w, cin, cb, cc, ncp, a, b1, b2, o1, o2, pred,
                                 (long long)anchors * no, no, a_off, th, tw, zeros));
   return run_spec_once(sp, (hipStream_t)hip_stream, reps, elapsed_us);

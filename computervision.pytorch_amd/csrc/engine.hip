@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/cvx_engine.h"
+#include "conv_chain.h"
 #include "bn_act.h"
 #include "conv_igemm.h"
 #include "misc_ops.h"
@@ -151,6 +152,17 @@ struct cvx_engine {
     int op;
   };
   int cur_op = -1;  // op index the launch loops are at (profile records carry it)
+  // eval-mode fusion groups (conv_chain.hip): a Bottleneck's two 3x3 convs, or a whole Detect level, as one tile-resident launch
+  struct FusedGroup {
+    int first = 0, last = 0;  // op range the launch replaces
+    ChainPlan plan;
+    void* mem = nullptr;
+  };
+  std::vector<FusedGroup> fused;
+  std::vector<int> fused_at;              // op index -> group that STARTS there, -1 otherwise
+  ChainPackJob* d_chain_jobs = nullptr;   // weight pre-pack jobs of all groups (one launch per forward)
+  int n_chain_jobs = 0, chain_max_units = 0;
+  bool chain_fusion = true;
   struct cvx_bw_state* bw = nullptr;  // backward-pass state (whole-pass and segmented entry points)
   std::vector<ProfRec> prof_recs;
 };
@@ -392,12 +404,177 @@ int build_static(cvx_engine* e) {
   return 0;
 }
 
+// ---- eval-mode fusion groups: recognised in the op list, planned as tile-resident chains (conv_chain.hip) ----
+bool same_view(const cvx_view& a, const cvx_view& b) { return a.buf == b.buf && a.coff == b.coff && a.c == b.c && a.pix_off == b.pix_off; }
+bool is_bn_silu_3x3(const cvx_op_desc& o) {
+  return o.type == CVX_OP_CONV && o.k == 3 && o.stride == 1 && o.pad == 1 && o.dil == 1 && o.act == CVX_ACT_BN_SILU && !(o.flags & CVX_OPF_CONV_BIAS);
+}
+// true when no op other than `reader` reads (in / res) buffer `buf`
+bool sole_reader(const cvx_engine* e, int buf, int reader) {
+  for (size_t i = 0; i < e->ops.size(); ++i) {
+    if ((int)i == reader) continue;
+    if (e->ops[i].in.buf == buf || e->ops[i].res.buf == buf) return false;
+  }
+  return true;
+}
+ChainConvArgs chain_args_bn(const cvx_engine* e, int i) {
+  const cvx_op_desc& o = e->ops[i];
+  const ConvRt& c = e->conv[i];
+  return ChainConvArgs{e->shadow + c.sh_fwd, c.ntaps * c.cin_g, o.out.c, c.scale, c.shift, nullptr, 0, 1};
+}
+ChainConvArgs chain_args_bias(const cvx_engine* e, int i) {
+  const cvx_op_desc& o = e->ops[i];
+  const ConvRt& c = e->conv[i];
+  return ChainConvArgs{e->shadow + c.sh_fwd, c.ntaps * c.cin_g, o.out.c, nullptr, nullptr, e->params + o.bias_off, 2, 1};
+}
+// best tile (estimated time) among the divisor pairs of (H, W) for which `make_spec` yields a feasible plan; false if none
+template <typename MakeSpec>
+bool choose_tile(int H, int W, int max_th, int max_tw, MakeSpec make_spec, int* th_out, int* tw_out, double* cost_out, int pref_th = 0, int pref_tw = 0) {
+  double best = -1;
+  if (pref_th > 0 && pref_tw > 0 && H % pref_th == 0 && W % pref_tw == 0) {  // the tile measured best on this shape class (tools/chain_probe.py sweep)
+    ChainSpec sp;
+    ChainPlan plan;
+    void* unused = nullptr;
+    if (make_spec(&sp, pref_th, pref_tw) == 0 && cvx_chain_plan(sp, &plan, &unused, true) == 0) {
+      *th_out = pref_th;
+      *tw_out = pref_tw;
+      *cost_out = cvx_chain_cost_us(sp, plan);
+      return true;
+    }
+    cvx_set_error("");
+  }
+  for (int th = 1; th <= std::min(H, max_th); ++th) {
+    if (H % th) continue;
+    for (int tw = 1; tw <= std::min(W, max_tw); ++tw) {
+      if (W % tw || th * tw < 32) continue;
+      ChainSpec sp;
+      if (make_spec(&sp, th, tw) != 0) continue;
+      ChainPlan plan;
+      void* unused = nullptr;
+      if (cvx_chain_plan(sp, &plan, &unused, true) != 0) continue;
+      const double c = cvx_chain_cost_us(sp, plan);
+      if (best < 0 || c < best) {
+        best = c;
+        *th_out = th;
+        *tw_out = tw;
+      }
+    }
+  }
+  cvx_set_error("");
+  if (best < 0) return false;
+  *cost_out = best;
+  return true;
+}
+
+void free_fused(cvx_engine* e) {
+  for (auto& g : e->fused)
+    if (g.mem) (void)hipFree(g.mem);
+  e->fused.clear();
+  e->fused_at.assign(e->ops.size(), -1);
+  if (e->d_chain_jobs) (void)hipFree(e->d_chain_jobs);
+  e->d_chain_jobs = nullptr;
+  e->n_chain_jobs = e->chain_max_units = 0;
+}
+
+// Bottleneck pairs (core/models/yolov8/modules.py:124-135) with 64+ channels and the Detect levels of at most 40x40 cells
+// (modules.py:428-433) run as ONE launch each in eval mode; everything else keeps its per-layer kernels (measured: tools/chain_probe.py
+// -- at 32 channels and below, and at 80x80, the per-layer kernels are as fast or faster).
+int plan_fused_groups(cvx_engine* e, int B) {
+  free_fused(e);
+  static const bool off = cvx_tune_set("CVX_NO_CHAIN");
+  if (off || !e->chain_fusion || !e->zero_page) return 0;
+  const Buf& pb = e->bufs[e->pred_buf];
+  const long long A = (long long)pb.d.h * pb.d.w;
+  std::vector<ChainPackJob> all_jobs;
+  const int nops = (int)e->ops.size();
+  for (int i = 0; i < nops; ++i) {
+    const cvx_op_desc& o = e->ops[i];
+    cvx_engine::FusedGroup g;
+    ChainSpec sp;
+    bool ok = false;
+    // ---- Detect level: 3x3 (box | class) -> 3x3, 3x3 -> 1x1 + bias, 1x1 + bias ----
+    if (i + 4 < nops && is_bn_silu_3x3(o) && is_bn_silu_3x3(e->ops[i + 1]) && is_bn_silu_3x3(e->ops[i + 2]) && e->ops[i + 3].type == CVX_OP_CONV &&
+        e->ops[i + 3].act == CVX_ACT_BIAS && e->ops[i + 3].k == 1 && e->ops[i + 4].type == CVX_OP_CONV && e->ops[i + 4].act == CVX_ACT_BIAS &&
+        e->ops[i + 4].k == 1 && o.res.buf < 0) {
+      const cvx_op_desc &b1 = e->ops[i + 1], &b2 = e->ops[i + 2], &o1 = e->ops[i + 3], &o2 = e->ops[i + 4];
+      const int cb = b1.out.c, cc = b2.out.c;
+      const bool shape = o.out.c == cb + cc && b1.in.buf == o.out.buf && b1.in.coff == o.out.coff && b1.in.c == cb && b2.in.buf == o.out.buf &&
+                         b2.in.coff == o.out.coff + cb && b2.in.c == cc && same_view(o1.in, b1.out) && same_view(o2.in, b2.out) && o1.out.c == 64 &&
+                         o1.out.buf == e->pred_buf && o2.out.buf == e->pred_buf && o1.out.coff == 0 && o2.out.coff == 64 &&
+                         o1.out.pix_off == o2.out.pix_off && b1.res.buf < 0 && b2.res.buf < 0 && o.ih * o.iw <= 1600 && cb % 16 == 0 && cc % 16 == 0 &&
+                         e->conv[i].cin_g % 16 == 0 && sole_reader(e, b1.out.buf, i + 3) && sole_reader(e, b2.out.buf, i + 4);
+      bool readers = shape;
+      for (int q = 0; readers && q < nops; ++q)
+        if (q != i + 1 && q != i + 2 && (e->ops[q].in.buf == o.out.buf || e->ops[q].res.buf == o.out.buf)) readers = false;
+      if (readers) {
+        const ViewDesc xin = make_view(e, o.in, false);
+        auto mk = [&](ChainSpec* s, int th, int tw) {
+          return cvx_chain_spec_detect(s, xin.p, xin.bstride, xin.ld, B, o.ih, o.iw, e->conv[i].cin_g, cb, cc, o2.out.c, chain_args_bn(e, i),
+                                       chain_args_bn(e, i + 1), chain_args_bn(e, i + 2), chain_args_bias(e, i + 3), chain_args_bias(e, i + 4), nullptr,
+                                       A * pb.d.c, pb.d.c, o1.out.pix_off, th, tw, e->zero_page);
+        };
+        int th, tw;
+        double cost;
+        // (the destination is the caller's `pred`, known at forward time: the plan holds offsets, the base comes with the launch)
+        // measured: 40x40 -> 8 x 10 tiles, 20x20 -> 5 x 10
+        const bool big = o.ih * o.iw > 400;
+        if (choose_tile(o.ih, o.iw, 10, 20, mk, &th, &tw, &cost, big ? o.ih / 5 : o.ih / 4, big ? o.iw / 4 : o.iw / 2)) {
+          mk(&sp, th, tw);
+          g.first = i;
+          g.last = i + 4;
+          ok = true;
+        }
+      }
+    }
+    // ---- Bottleneck pair: 3x3 -> 3x3 (+ shortcut) ----
+    if (!ok && i + 1 < nops && is_bn_silu_3x3(o) && is_bn_silu_3x3(e->ops[i + 1]) && o.res.buf < 0) {
+      const cvx_op_desc& o2 = e->ops[i + 1];
+      const int C = o.out.c;
+      const bool shortcut = o2.res.buf >= 0;
+      if (same_view(o2.in, o.out) && e->conv[i].cin_g == C && o2.out.c == C && C >= 64 && C % 16 == 0 && (!shortcut || same_view(o2.res, o.in)) &&
+          o.out.buf != o.in.buf && sole_reader(e, o.out.buf, i + 1) && e->bufs[o.out.buf].d.c == C) {
+        const ViewDesc xin = make_view(e, o.in, false), yout = make_view(e, o2.out, false);
+        auto mk = [&](ChainSpec* s, int th, int tw) {
+          return cvx_chain_spec_pair(s, xin.p, xin.bstride, xin.ld, B, o.ih, o.iw, C, chain_args_bn(e, i), chain_args_bn(e, i + 1), shortcut, yout.p,
+                                     yout.bstride, yout.ld, th, tw, e->zero_page);
+        };
+        int th, tw;
+        double cost;
+        if (choose_tile(o.ih, o.iw, 16, 40, mk, &th, &tw, &cost, o.ih / 4, o.iw / 2)) {  // measured: 40x40 -> 10 x 20, 20x20 -> 5 x 10
+          mk(&sp, th, tw);
+          g.first = i;
+          g.last = i + 1;
+          ok = true;
+        }
+      }
+    }
+    if (!ok) continue;
+    if (cvx_chain_plan(sp, &g.plan, &g.mem) != 0) {
+      if (g.mem) (void)hipFree(g.mem);
+      cvx_set_error("");
+      continue;
+    }
+    for (int q = 0; q < g.plan.njobs; ++q) all_jobs.push_back(g.plan.jobs[q]);
+    e->chain_max_units = std::max(e->chain_max_units, g.plan.max_job_units);
+    e->fused_at[i] = (int)e->fused.size();
+    e->fused.push_back(g);
+    i = g.last;
+  }
+  if (!all_jobs.empty()) {
+    CVX_HIP(hipMalloc((void**)&e->d_chain_jobs, all_jobs.size() * sizeof(ChainPackJob)));
+    CVX_HIP(hipMemcpy(e->d_chain_jobs, all_jobs.data(), all_jobs.size() * sizeof(ChainPackJob), hipMemcpyHostToDevice));
+    e->n_chain_jobs = (int)all_jobs.size();
+  }
+  return 0;
+}
+
 int plan_batch(cvx_engine* e, int B, bool training) {
   if (e->planned_batch == B && (e->planned_train || !training)) return 0;
   CVX_HIP(hipStreamSynchronize(e->stream));
   if (e->side) CVX_HIP(hipStreamSynchronize(e->side));
   if (e->lane) CVX_HIP(hipStreamSynchronize(e->lane));
   free_pool(e->batch_allocs);
+  free_fused(e);
   e->batch_bytes = 0;
   e->planned_batch = 0;
   e->plan_generation++;  // every per-batch buffer moves: a hipGraph captured against the old plan must be dropped
@@ -604,6 +781,8 @@ int plan_batch(cvx_engine* e, int B, bool training) {
   }
   e->planned_batch = B;
   e->planned_train = training;
+  // the fused groups hold pointers into this plan's buffers; a training plan serves eval forwards too
+  CVX_TRY(plan_fused_groups(e, B));
   return 0;
 }
 
@@ -748,6 +927,7 @@ extern "C" int cvx_engine_destroy(cvx_engine* e) {
   for (hipEvent_t ev : e->ev_seg)
     if (ev) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
+  free_fused(e);
   free_pool(e->batch_allocs);
   free_pool(e->static_allocs);
   cvx_engine_free_bw(e);
@@ -784,6 +964,22 @@ extern "C" int cvx_engine_set_bn(cvx_engine* e, float eps, float momentum) {
   e->bn_momentum = momentum;
   return 0;
 }
+
+extern "C" int cvx_engine_set_fusion(cvx_engine* e, int32_t enable) {
+  CVX_CHECK(e, "null engine");
+  if (e->chain_fusion != (enable != 0)) {
+    e->chain_fusion = enable != 0;
+    if (e->planned_batch > 0) {  // re-derive the groups of the current plan (the per-batch buffers stay)
+      CVX_HIP(hipStreamSynchronize(e->stream));
+      if (e->lane) CVX_HIP(hipStreamSynchronize(e->lane));
+      CVX_TRY(plan_fused_groups(e, e->planned_batch));
+      e->plan_generation++;  // captured hipGraphs hold the old launch sequence
+    }
+  }
+  return 0;
+}
+
+extern "C" int32_t cvx_engine_fused_groups(const cvx_engine* e) { return e ? (int32_t)e->fused.size() : -1; }
 
 extern "C" int cvx_engine_set_seed(cvx_engine* e, uint64_t seed) {
   CVX_CHECK(e, "null engine");
@@ -845,6 +1041,7 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
   {
     ProfScope ps(e, PROF_MISC, 0, 6.0 * e->n_params, prep);
     CVX_TRY(cvx_pack_weights(e->params, e->shadow, e->d_pack, e->d_pack_blocks, e->n_pack_blocks, prep));
+    if (!training && e->n_chain_jobs > 0) CVX_TRY(cvx_chain_pack_jobs(e->d_chain_jobs, e->n_chain_jobs, e->chain_max_units, prep));
   }
   e->last_images = training ? images : nullptr;
   if (training) e->train_pass++;  // dropout masks: one per (seed, training forward, op)
@@ -878,6 +1075,13 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
       st = e->lane;
     }
     float* const ytmp = st == main_st ? e->ytmp : e->ytmp_lane;
+    if (!training && !e->fused_at.empty() && e->fused_at[i] >= 0) {  // a fused group starts here: one tile-resident launch for ops i .. last
+      const cvx_engine::FusedGroup& g = e->fused[e->fused_at[i]];
+      ProfScope ps(e, PROF_CONV_FWD, g.plan.flops, g.plan.bytes, st);
+      CVX_TRY(cvx_chain_launch(g.plan, st, pred));
+      i = (size_t)g.last;
+      continue;
+    }
     if (o.type == CVX_OP_MAXPOOL5) {
       ProfScope ps(e, PROF_MISC, 0, 4.0 * B * o.ih * o.iw * o.in.c, st);
       CVX_TRY(cvx_maxpool5_fwd(make_view(e, o.in, false), make_view(e, o.out, false), B, o.ih, o.iw, o.in.c,

@@ -48,6 +48,13 @@ class Engine:
     def set_bn(self, eps: float, momentum: float):
         L.check(self.lib.cvx_engine_set_bn(self.handle, eps, momentum), "cvx_engine_set_bn")
 
+    def set_fusion(self, enable: bool):
+        """eval-mode cross-layer fusion (Bottleneck pairs, Detect levels as one launch each); default on"""
+        L.check(self.lib.cvx_engine_set_fusion(self.handle, int(bool(enable))), "cvx_engine_set_fusion")
+
+    def fused_groups(self) -> int:
+        return int(self.lib.cvx_engine_fused_groups(self.handle))
+
     def set_seed(self, seed: int):
         """Seed of the graph's dropout masks (nn.Dropout layers of the reference model; torch.manual_seed there)."""
         if seed != getattr(self, "_seed", None):

@@ -2600,3 +2600,102 @@ def test_loss_kernels_edge_cases(dev):
     want = S.multibox_loss(y, loc.clone().requires_grad_(True), conf.clone().requires_grad_(True), 3.0)
     items, _, _ = MultiBoxLoss(3.0, nc).op(loc.to(dev), conf.to(dev), y.to(dev))
     np.testing.assert_allclose(items.cpu().numpy(), [float(v) for v in want], rtol=2e-5)
+
+
+# ---- tile-resident chains (csrc/conv_chain.hip): eval-mode cross-layer fusion ------------------------------------------------
+def _chain_conv_ref(x_nhwc, w_okkc, k, stride=1):
+    return F.conv2d(x_nhwc.float().permute(0, 3, 1, 2), w_okkc.float().permute(0, 3, 1, 2), stride=stride, padding=k // 2).permute(0, 2, 3, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,C,th,tw,shortcut", [(2, 40, 40, 64, 10, 20, True), (1, 24, 40, 32, 8, 8, False), (3, 20, 20, 128, 5, 10, True),
+                                                    (2, 30, 50, 64, 12, 16, True), (2, 16, 48, 16, 8, 16, True)])
+def test_chain_bottleneck_pair_unit(dev, B, H, W, C, th, tw, shortcut):
+    """Bottleneck (modules.py:124-135, eval) as ONE launch vs torch fp32 on the same fp16 operands (the intermediate rounded to fp16 like the
+    per-layer path); ragged tilings (tiles overhanging the image, 24 = 3 x 8) included."""
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, H, W, C, generator=g).half()
+    w1, w2 = [(torch.randn(C, 3, 3, C, generator=g) * (9 * C) ** -0.5).half() for _ in range(2)]
+    sc1, sc2 = torch.rand(C, generator=g) + 0.5, torch.rand(C, generator=g) + 0.5
+    sh1, sh2 = torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    mid = F.silu(_chain_conv_ref(x, w1, 3) * sc1 + sh1).half()
+    ref = F.silu(_chain_conv_ref(mid, w2, 3) * sc2 + sh2) + (x.float() if shortcut else 0)
+    d = [t.to(dev) for t in (x, w1, sc1, sh1, w2, sc2, sh2)]
+    out = torch.zeros(B, H, W, C, dtype=torch.float16, device=dev)
+    L.check(L.load().cvx_chain_pair_unit(L.ptr(d[0]), B, H, W, C, L.ptr(d[1]), L.ptr(d[2]), L.ptr(d[3]), L.ptr(d[4]), L.ptr(d[5]), L.ptr(d[6]),
+                                         int(shortcut), L.ptr(out), th, tw, 1, None, L.stream_ptr(dev)), "chain pair")
+    torch.cuda.synchronize()
+    assert float((out.float().cpu() - ref).abs().max() / ref.abs().max()) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,Ci,Co,k,s,up,th,tw", [(2, 40, 40, 64, 64, 3, 1, 0, 10, 20), (2, 40, 40, 64, 128, 3, 2, 0, 10, 10),
+                                                      (2, 20, 20, 64, 32, 1, 1, 0, 10, 20), (2, 40, 40, 48, 64, 1, 1, 1, 10, 20),
+                                                      (1, 36, 28, 32, 80, 3, 1, 0, 12, 14)])
+def test_chain_single_conv_unit(dev, B, H, W, Ci, Co, k, s, up, th, tw):
+    """one conv + folded BN + SiLU as a one-stage chain: 1x1 / 3x3, stride 1 / 2, and the nearest-2x upsample folded into the load
+    (yolo_v8.py:39-41) -- x is then the HALF-resolution tensor"""
+    g = torch.Generator().manual_seed(1)
+    xs = torch.randn(B, H // 2 if up else H, W // 2 if up else W, Ci, generator=g).half()
+    x = xs.repeat_interleave(2, 1).repeat_interleave(2, 2) if up else xs
+    w = (torch.randn(Co, k, k, Ci, generator=g) * (k * k * Ci) ** -0.5).half()
+    sc, sh = torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g) * 0.1
+    ref = F.silu(_chain_conv_ref(x, w, k, s) * sc + sh)
+    d = [t.to(dev) for t in (xs, w, sc, sh)]
+    out = torch.zeros(B, H // s, W // s, Co, dtype=torch.float16, device=dev)
+    L.check(L.load().cvx_chain_conv_unit(L.ptr(d[0]), B, H, W, Ci, L.ptr(d[1]), Co, k, s, up, L.ptr(d[2]), L.ptr(d[3]), 0, L.ptr(out), th, tw, 1, None,
+                                         L.stream_ptr(dev)), "chain conv")
+    torch.cuda.synchronize()
+    assert float((out.float().cpu() - ref).abs().max() / ref.abs().max()) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,Cin,th,tw", [(2, 16, 24, 64, 8, 16), (2, 40, 40, 128, 8, 10), (2, 20, 20, 256, 5, 10)])
+def test_chain_detect_level_unit(dev, B, H, W, Cin, th, tw):
+    """one Detect level (modules.py:428-433, train-mode rows) as ONE launch: rows outside the level stay untouched"""
+    cb, cc, ncp = 64, 80, 80
+    g = torch.Generator().manual_seed(2)
+    mk = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).half()  # noqa: E731
+    x = mk(B, H, W, Cin)
+    wa = mk(cb + cc, 3, 3, Cin, scale=(9 * Cin) ** -0.5)
+    wb1, wb2 = mk(cb, 3, 3, cb, scale=(9 * cb) ** -0.5), mk(cc, 3, 3, cc, scale=(9 * cc) ** -0.5)
+    wo1, wo2 = mk(64, 1, 1, cb, scale=cb ** -0.5), mk(ncp, 1, 1, cc, scale=cc ** -0.5)
+    sca, scb = torch.rand(cb + cc, generator=g) + 0.5, torch.rand(cb + cc, generator=g) + 0.5
+    sha, shb = torch.randn(cb + cc, generator=g) * 0.1, torch.randn(cb + cc, generator=g) * 0.1
+    bias = torch.randn(64 + ncp, generator=g)
+    a = F.silu(_chain_conv_ref(x, wa, 3) * sca + sha).half()
+    hb = F.silu(_chain_conv_ref(a[..., :cb], wb1, 3) * scb[:cb] + shb[:cb]).half()
+    hc = F.silu(_chain_conv_ref(a[..., cb:], wb2, 3) * scb[cb:] + shb[cb:]).half()
+    ref = torch.cat([_chain_conv_ref(hb, wo1, 1) + bias[:64], _chain_conv_ref(hc, wo2, 1) + bias[64:]], -1).reshape(B, H * W, 64 + ncp)
+    d = [t.to(dev) for t in (x, wa, sca, sha, wb1, wb2, scb, shb, wo1, wo2, bias)]
+    A = H * W + 64
+    pred = torch.full((B, A, 64 + ncp), 7.0, device=dev)
+    L.check(L.load().cvx_chain_detect_unit(L.ptr(d[0]), B, H, W, Cin, cb, cc, ncp, L.ptr(d[1]), L.ptr(d[2]), L.ptr(d[3]), L.ptr(d[4]), L.ptr(d[5]), L.ptr(d[6]),
+                                           L.ptr(d[7]), L.ptr(d[8]), L.ptr(d[9]), L.ptr(d[10]), L.ptr(pred), A, 32, th, tw, 1, None, L.stream_ptr(dev)), "chain detect")
+    torch.cuda.synchronize()
+    assert float((pred[:, 32:32 + H * W].cpu() - ref).abs().max() / ref.abs().max()) < 1e-3
+    assert bool((pred[:, :32] == 7.0).all()) and bool((pred[:, 32 + H * W:] == 7.0).all())
+
+
+@pytest.mark.gpu
+def test_eval_forward_with_fused_groups_matches_the_per_layer_path(dev, gold):
+    """the engine's eval forward with the fusion groups (Bottleneck pairs, Detect levels) against the same forward layer by layer, and
+    both against the reference fixture: 128x128 (the 4x4 level stays unfused: no feasible tile) and 320x320 (all group kinds)"""
+    g = gold("yolov8n_fwd_128.npz")
+    m = new_model(dev).eval()
+    for x in (torch.from_numpy(g["x"]), synth.images(2, 320, 320, seed=3)):
+        with torch.no_grad():
+            y1, _ = m(x.to(dev))
+            eng = m._last_engine
+            n = eng.fused_groups()
+            eng.set_fusion(False)
+            assert eng.fused_groups() == 0
+            y0, _ = m(x.to(dev))
+            eng.set_fusion(True)
+            y2, _ = m(x.to(dev))
+        assert n >= 6, n
+        assert torch.equal(y1, y2)
+        # same operands, same fp16 rounding points, another summation order inside a K loop: fp32 round-off through the decode
+        np.testing.assert_allclose(y1.cpu().numpy(), y0.cpu().numpy(), rtol=2e-3, atol=2e-3)
+        if x.shape[-1] == 128:
+            np.testing.assert_allclose(y1.cpu().numpy(), g["eval_y"], rtol=5e-3, atol=5e-3)
