@@ -33,7 +33,8 @@ sys.path.insert(0, ROOT)
 MFMA_FP16_PEAK_TFLOPS = 2516.6                  # MI355X dense fp16
 HBM_PEAK_GBS = 8000.0
 GFLOP = {"n": (8.742912, 26.140262), "s": (28.601549, 85.627699)}   # (forward, train step) per image, SURVEY section 8(d)
-TRAFFIC_FILES = ("r02_conv_traffic.json",)      # newest first; PMC passes of a build, keyed by that build's library hash
+TRAFFIC_FILES = ("r03_conv_traffic.json", "r02_conv_traffic.json")      # newest first; PMC passes of a build, keyed by that build's library hash
+MFMA_FILES = ("r03_mfma_busy.json",)                                     # SQ_VALU_MFMA_BUSY_CYCLES pass (tools/pmc_mfma.py), same keying
 
 
 def lib_sha256():
@@ -54,6 +55,20 @@ def measured_traffic(model, batch):
             return round(t["hbm_bytes_per_launch"]), f"profiles/{name} (library {sha[:12]})"
         return None, f"profiles/{name} was measured on library {str(t.get('lib_sha256'))[:12]}, running {sha[:12]}: refused"
     return None, "no PMC passes committed for this round yet"
+
+
+def measured_mfma_busy():
+    """MFMA-busy fraction of the conv kernels from the committed PMC pass (tools/pmc_mfma.py) -- only if taken on THIS build."""
+    sha = lib_sha256()
+    for name in MFMA_FILES:
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        t = json.load(open(path))
+        if t.get("lib_sha256") == sha:
+            return t.get("conv_mfma_busy_frac"), f"profiles/{name} (library {sha[:12]})"
+        return None, f"profiles/{name} was measured on library {str(t.get('lib_sha256'))[:12]}, running {sha[:12]}: refused"
+    return None, "no MFMA-busy PMC pass committed for this round yet"
 
 
 def usable_cores() -> int:
@@ -702,6 +717,81 @@ def ssd_main(args):
         dist.destroy_process_group()
 
 
+def yolov8_eval_main(args):
+    """images/sec of the YOLOv8-n EVAL forward (the pass north_star quotes the MFMA fraction of): engine forward with folded BatchNorm, the
+    eval-mode fusion groups and the DFL decode to (B, 84, 8400) on synthetic 640x640 batches of 32; one process per GPU, images sharded
+    with no exchange.  `--fusion 0` runs the same forward layer by layer (A/B of the cross-layer fusion on one box)."""
+    rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    import torch.distributed as dist
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29537")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from computervision.pytorch_amd.model import Yolo8
+    from computervision.pytorch_amd import synth
+    torch.manual_seed(0)
+    model = Yolo8(args.model, 80).to(dev).eval()
+    B = args.batch
+    x = synth.images(B, 640, 640, seed=1 + rank).to(dev)
+
+    def step():
+        with torch.no_grad():
+            return model(x)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    step()
+    eng = model._last_engine
+    eng.set_fusion(bool(args.fusion))
+    for _ in range(max(args.warmup, 1)):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    eng.profile(True)
+    for _ in range(3):
+        step()
+    sync()
+    prof = eng.profile_read()
+    eng.profile(False)
+    if rank == 0:
+        fwd_gf = GFLOP.get(args.model, (float("nan"), float("nan")))[0]
+        value = B * world * args.steps / elapsed
+        conv = prof["conv_fwd"]
+        tf = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+        launches = sum(v["launches"] for v in prof.values()) // 3
+        print(json.dumps({
+            "metric": f"images/sec 640x640 YOLOv8-{args.model} eval forward + decode", "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"YOLOv8-{args.model} eval forward (folded BN + SiLU epilogues, fusion groups {'on' if args.fusion else 'off'}) + DFL decode, "
+                                   f"batch {B}/GPU, 640x640, nc=80, random init", "global_batch": B * world, "parallelism": f"dp{world}",
+                       "fused_groups": eng.fused_groups()},
+            "roofline": {"bound": "mfma", "kernel": "convolution launches of the eval forward (conv_chain / conv_halo / conv_pw / conv_igemm_dma + the fp32 stem), "
+                                                    "HIP events on the engine's streams, serialised window after the timed steps",
+                         "achieved": round(tf, 3), "peak": MFMA_FP16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_FP16_PEAK_TFLOPS, 5),
+                         "traffic": None, "avg_launch_us": round(conv["ms"] * 1e3 / max(conv["launches"], 1), 3),
+                         "launches_per_step": conv["launches"] // 3},
+            "whole_step": {"tflops": round(value / world * fwd_gf / 1e3, 3), "frac_of_mfma_peak": round(value / world * fwd_gf / 1e3 / MFMA_FP16_PEAK_TFLOPS, 5),
+                           "gflop_per_image": fwd_gf, "engine_launches_per_forward": launches},
+            "kernel_classes": {k: {"ms_per_step": round(v["ms"] / 3, 4), "launches_per_step": v["launches"] // 3} for k, v in prof.items() if v["launches"]},
+            "engine_workspace_gib": round(eng.workspace_bytes() / 2 ** 30, 3)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -713,9 +803,12 @@ def main():
     ap.add_argument("--graph", type=int, default=0, help="1: replay the step as a hipGraph (N=1 only); 0: eager stream launches (default: "
                     "measured faster -- the side-stream weight gradients overlap better than as graph branches)")
     ap.add_argument("--profile-steps", type=int, default=10, help="steps of the per-kernel HIP-event window after the timed region")
-    ap.add_argument("--workload", default="yolov8_train", choices=["yolov8_train", "centernet", "centernet_train", "deeplab", "deeplab_train", "yolov7", "yolov7_train", "ssd", "ssd_train"],
+    ap.add_argument("--workload", default="yolov8_train", choices=["yolov8_train", "yolov8_eval", "centernet", "centernet_train", "deeplab", "deeplab_train", "yolov7", "yolov7_train", "ssd", "ssd_train"],
                     help="centernet: BASELINE.json configs[3] -- CenterNet DLA-34 (nc 80) 512x512 inference + heat-map decode, batch 64 per GPU")
+    ap.add_argument("--fusion", type=int, default=1, help="yolov8_eval: 0 runs the eval forward layer by layer (no cross-layer fusion groups)")
     args = ap.parse_args()
+    if args.workload == "yolov8_eval":
+        return yolov8_eval_main(args)
     if args.workload == "centernet":
         return centernet_main(args)
     if args.workload == "deeplab":
@@ -824,6 +917,7 @@ def main():
         conv_by = sum(v["bytes"] for v in conv.values())
         conv_gbs = conv_by / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0
         traffic, traffic_note = measured_traffic(args.model, B)
+        mfma_busy, mfma_note = measured_mfma_busy()
         classes = {}
         for k, v in prof.items():
             if v["launches"] == 0:
@@ -844,6 +938,7 @@ def main():
                                    "conv_igemm_dma_kernel (+ the fp32 stem passes)",
                          "achieved": round(achieved, 3), "peak": MFMA_FP16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_FP16_PEAK_TFLOPS, 5), "traffic": traffic, "traffic_source": traffic_note,
+                         "mfma_busy_frac": mfma_busy, "mfma_busy_source": mfma_note,
                          "algorithmic_flops_per_launch": round(conv_fl / max(conv_launches, 1)),
                          "algorithmic_bytes_per_launch": round(conv_by / max(conv_launches, 1)),
                          "avg_launch_us": round(conv_ms * 1e3 / max(conv_launches, 1), 3), "launches_per_step": conv_launches // prof_steps,
