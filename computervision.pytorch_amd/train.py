@@ -129,24 +129,74 @@ class FlatAdam(torch.optim.Optimizer):
         """Steps actually applied: read from the device state (overflow-skipped steps and graph replays are counted there)."""
         return self._step if self._state is None else int(self._state[1].item())
 
+    # ---- checkpoint interchange: torch.optim.Adam's state_dict layout (what the reference saves and loads, core/utils/ckpt.py:41-66) ----
+    def _all_params(self):
+        return list(self.model.parameters())   # the reference hands model.parameters() to Adam: frozen tensors (DFL) keep their index, without state
+
+    def _moment_views(self, p):
+        """the slices of the flat moment arenas that belong to parameter `p` (a strided view of the flat parameter arena)"""
+        flat = self.model.flat_params
+        if p.untyped_storage().data_ptr() != flat.untyped_storage().data_ptr():
+            return None
+        off = p.storage_offset() - flat.storage_offset()
+        return (torch.as_strided(self._m, p.shape, p.stride(), off), torch.as_strided(self._v, p.shape, p.stride(), off))
+
     def state_dict(self):
-        return {"step": self.device_step(), "exp_avg": self._m, "exp_avg_sq": self._v, "param_groups": [
-            {k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+        """torch.optim.Adam's layout: per-parameter ``state[i] = {step, exp_avg, exp_avg_sq}`` in ``model.parameters()`` order, with the
+        reference's logical shapes (copies of the flat arenas' slices), so ``torch.optim.Adam(model.parameters()).load_state_dict`` of the
+        reference accepts it -- and load_state_dict below accepts the reference's."""
+        self._ensure_state()
+        step = float(self.device_step())
+        state = {}
+        params = self._all_params()
+        for i, p in enumerate(params):
+            mv = self._moment_views(p) if p.requires_grad else None
+            if mv is not None and step > 0:
+                state[i] = {"step": torch.tensor(step), "exp_avg": mv[0].detach().clone().contiguous(), "exp_avg_sq": mv[1].detach().clone().contiguous()}
+        g = self.param_groups[0]
+        group = {"lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"], "weight_decay": 0, "amsgrad": False, "maximize": False, "foreach": None,
+                 "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": False,
+                 "params": list(range(len(params)))}
+        for k, v in g.items():                       # scheduler bookkeeping (initial_lr ...) rides along like in torch
+            if k not in group and k != "params":
+                group[k] = v
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
+        """Accepts torch.optim.Adam's layout (a reference checkpoint, or state_dict() above) and the round-1/2 flat format
+        ``{step, exp_avg, exp_avg_sq, param_groups}``."""
         for g, s in zip(self.param_groups, sd.get("param_groups", [])):
-            g.update(s)
-        self._step = int(sd["step"])
+            g.update({k: v for k, v in s.items() if k != "params"})
         self._ensure_state()
+        if "state" in sd:
+            params = self._all_params()
+            self._m.zero_()
+            self._v.zero_()
+            step = 0
+            for i, st in sd["state"].items():
+                i = int(i)
+                if i >= len(params):
+                    raise L.CvxError(f"optimizer checkpoint has state for parameter {i}, the model has {len(params)} parameters")
+                mv = self._moment_views(params[i])
+                if mv is None:
+                    continue
+                if tuple(st["exp_avg"].shape) != tuple(params[i].shape):
+                    raise L.CvxError(f"optimizer checkpoint: parameter {i} has shape {tuple(st['exp_avg'].shape)}, the model's is {tuple(params[i].shape)}")
+                mv[0].copy_(st["exp_avg"])
+                mv[1].copy_(st["exp_avg_sq"])
+                step = max(step, int(float(st["step"])))
+            self._step = step
+        else:
+            self._step = int(sd["step"])
+            if sd.get("exp_avg") is not None:
+                self._m.copy_(sd["exp_avg"])
+                self._v.copy_(sd["exp_avg_sq"])
+            else:
+                self._m.zero_()
+                self._v.zero_()
         # rebuild the device state unconditionally: [lr, step, -, -] (the derived factors are recomputed by the next step)
         self._state.copy_(torch.tensor([self.param_groups[0]["lr"], float(self._step), 0.0, 0.0]))
         self._lr_on_device = self.param_groups[0]["lr"]
-        if sd.get("exp_avg") is not None:
-            self._m.copy_(sd["exp_avg"])
-            self._v.copy_(sd["exp_avg_sq"])
-        else:
-            self._m.zero_()
-            self._v.zero_()
 
 
 class DynamicLossScale:

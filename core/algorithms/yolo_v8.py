@@ -6,6 +6,8 @@ Model, loss and the decode + NMS tail run on the MI355X engine (``computervision
 import numpy as np
 import torch
 
+from computervision.pytorch_amd._lib import CvxError
+
 from computervision.pytorch_amd import engine as _engine
 from computervision.pytorch_amd.model import Yolo8
 from computervision.pytorch_amd.train import V8DetectionLoss
@@ -48,6 +50,9 @@ class YOLOv8:
         conf = self.conf_threshold if conf_threshold is None else conf_threshold
         rows, _, counts = _engine.nms(y, conf, self.iou_threshold, self.max_det)
         counts = counts.cpu().tolist()
+        if min(counts, default=0) < 0:   # cvx_nms_variant signals "more candidates than the in-LDS sort holds" with -1: never slice rows[:-1]
+            raise CvxError(f"non_max_suppression: image {counts.index(min(counts))} has more than 16384 candidates above conf {conf} "
+                           "(the in-LDS sort capacity of cvx_nms); raise the confidence threshold")
         return [rows[i, :k] for i, k in enumerate(counts)]
 
     def decode_box(self, preds, image_h, image_w, conf_threshold=None):

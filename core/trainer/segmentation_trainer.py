@@ -106,6 +106,12 @@ class DeeplabV3PlusTrainer(BaseTrainer):
                                                  last_step=self.last_iter if self.last_iter > 0 else -1)
 
     def set_criterion(self):
+        # dropout masks (aspp.project.3, deeplabv3plus.py:67) are a counter-based hash of (seed, training pass, op, element) on the engine:
+        # derive the seed from torch's global seed, the rank (the reference's ranks draw independent masks) and the iteration a resumed run
+        # starts at (a resumed job must not replay the mask sequence from pass 0)
+        import torch.distributed as dist
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        self.model.seed = (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + rank * 0xBF58476D1CE4E5B9 + int(self.last_iter) * 0x94D049BB133111EB) & (2 ** 64 - 1)
         self.criterion = self.model_algorithm.build_loss()
         scaler = DynamicLossScale(self.device, init_scale=self.model.loss_scale) if self.mixed_precision else None   # GradScaler()
         self._step = SegTrainStep(self.model, self.criterion, self.optimizer, scaler=scaler)

@@ -1,6 +1,9 @@
 """Checkpoint files in the reference's format (core/utils/ckpt.py:7-75): ``torch.save`` of either a bare ``state_dict`` or
-``{"model", "optimizer", "scheduler", "warm_up"}``; the model's ``state_dict`` has the reference's keys and shapes, so
-files are interchangeable in both directions (a reference ``.pth`` loads into the engine-backed model and vice versa).
+``{"model", "optimizer", "scheduler", "warm_up"}``; the model's ``state_dict`` has the reference's keys and shapes and the
+optimizer entry is ``torch.optim.Adam``'s own layout (per-parameter ``state[i] = {step, exp_avg, exp_avg_sq}`` in
+``model.parameters()`` order -- ``FlatAdam.state_dict`` slices its flat moment arenas accordingly), so full checkpoints are
+interchangeable in both directions: a reference ``.pth`` resumes here, and a file written here loads into the reference's
+``torch.optim.Adam`` (tests/test_trainer_cpu.py).
 
 One deliberate difference: the reference loads the ``warm_up`` entry into the *scheduler* (ckpt.py:65-66, a bug that
 overwrites the scheduler state just restored); here it goes to the warm-up object it was saved from.
@@ -9,6 +12,16 @@ import os
 
 import numpy as np
 import torch
+
+
+def _to_cpu(obj):
+    if torch.is_tensor(obj):
+        return obj.detach().cpu()
+    if isinstance(obj, dict):
+        return {k: _to_cpu(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_to_cpu(v) for v in obj)
+    return obj
 
 
 class CheckPoint:
@@ -44,8 +57,7 @@ class CheckPoint:
             return
         obj = {"model": sd}
         if optimizer is not None:
-            osd = optimizer.state_dict()
-            obj["optimizer"] = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in osd.items()}
+            obj["optimizer"] = _to_cpu(optimizer.state_dict())
         if scheduler is not None:
             obj["scheduler"] = scheduler.state_dict()
         if warm_up is not None:

@@ -13,6 +13,8 @@ Tolerances (stated once, used below):
   fp16-storage emulation of the oracle itself deviates by ~4e-2); fully end to end (own loss, discrete assignment): <= 1.2e-1;
   per-layer activation gradients vs the fp16-storage emulation: see test_per_layer_backward_parity.
 """
+import contextlib
+
 import numpy as np
 import pytest
 import torch
@@ -509,7 +511,9 @@ def test_forward_matches_golden_and_oracle(dev, gold):
     with torch.no_grad():
         y, feats = m(x.to(dev))
     assert tuple(y.shape) == (2, 84, 336) and len(feats) == 3
-    np.testing.assert_allclose(y.cpu().numpy(), g["eval_y"], rtol=5e-3, atol=5e-3)
+    # decoded output: boxes in pixels (|v| <= 128 here) and class probabilities; the logits behind them carry <= 1e-3 (LEVEL_TOL), the DFL
+    # softmax expectation and the sigmoid do not amplify it: 2e-3 (relative for the box coordinates, absolute for the probabilities)
+    np.testing.assert_allclose(y.cpu().numpy(), g["eval_y"], rtol=2e-3, atol=2e-3)
 
 
 def test_forward_640_subsample(dev, gold):
@@ -661,15 +665,25 @@ def test_assigner_fixture_through_the_loss(dev, gold):
 
 
 def test_pack_targets_kernel(dev):
-    """cvx_pack_targets == the host ordering (stable sort by image) of the yolo8_collate dict."""
+    """cvx_pack_targets against the ORACLE's Loss.preprocess (core/algorithms/yolo_v8.py:51-65, oracle build_targets): image j's rows of the
+    packed (N, 6) list, in order, are row j of the reference's (B, Gmax, 5) tensor (class, then the boxes the oracle converts to pixel
+    corners); the host path of flatten_targets must give the same rows."""
     from computervision.pytorch_amd.train import flatten_targets
     gen = torch.Generator().manual_seed(3)
-    n = 777
-    batch = {"batch_idx": torch.randint(0, 9, (n,), generator=gen).float(), "cls": torch.randint(0, 80, (n, 1), generator=gen).float(),
+    n, B, H, W = 777, 9, 96.0, 160.0
+    batch = {"batch_idx": torch.randint(0, B, (n,), generator=gen).float(), "cls": torch.randint(0, 80, (n, 1), generator=gen).float(),
              "bboxes": torch.rand(n, 4, generator=gen)}
-    host = flatten_targets(batch, "cpu")
-    devd = flatten_targets({k: v.to(dev) for k, v in batch.items()}, dev)
-    assert torch.equal(devd.cpu(), host)
+    ref = O.build_targets(batch, B, H, W)                               # (B, Gmax, 5): cls, x1, y1, x2, y2 in pixels
+    for rows in (flatten_targets({k: v.to(dev) for k, v in batch.items()}, dev).cpu(), flatten_targets(batch, "cpu")):
+        assert rows.shape == (n, 6) and bool((rows[1:, 0] >= rows[:-1, 0]).all())
+        for j in range(B):
+            mine = rows[rows[:, 0] == j]
+            k = mine.shape[0]
+            assert k == int((batch["batch_idx"] == j).sum())
+            assert torch.equal(mine[:, 1], ref[j, :k, 0]) and bool((ref[j, k:] == 0).all())
+            cxcywh = mine[:, 2:6] * torch.tensor([W, H, W, H])
+            xyxy = torch.cat((cxcywh[:, :2] - cxcywh[:, 2:] / 2, cxcywh[:, :2] + cxcywh[:, 2:] / 2), 1)
+            assert torch.equal(xyxy, ref[j, :k, 1:])
     assert flatten_targets({"batch_idx": torch.zeros(0), "cls": torch.zeros(0, 1), "bboxes": torch.zeros(0, 4)}, dev).shape == (0, 6)
 
 
@@ -747,6 +761,36 @@ def test_fused_steps_track_the_reference_loss_curve(dev, gold):
     for s in range(2):
         items = step(x, batch)
         assert abs(float(items.sum() * 4) / float(g["loss"][s]) - 1) < 1e-2, s
+
+
+def test_fifty_fused_steps_follow_the_oracle_loss_trajectory(dev):
+    """50 steps of engine (fp16 operands, fused step) vs oracle (fp32 CPU restatement of the reference's train_loop, yolo8_train.py:93-111)
+    from the same seed-0 initialisation on one repeated 128x128 batch.  Adam at lr 1e-3 on a 2-image batch is chaotic step by step (the
+    oracle's OWN curve jumps by 10-25 % between consecutive steps; its fp16-storage emulation leaves its fp32 run by up to 47 % on single
+    steps and 24 % on 10-step window means, measured), so the yardstick is computed here: the oracle is run a second time with the engine's
+    rounding points emulated, and the engine's 10-step window means must stay as close to the fp32 curve as 1.5 x that emulation does (+ 5 %).
+    Hard bounds on top: the first two steps (before anything can diverge) within 2 %, both curves fall by > 6 x, last windows within 20 %."""
+    from computervision.pytorch_amd.train import FlatAdam, FusedTrainStep, V8DetectionLoss
+    from configs import Yolo8DetConfig
+    x, batch = synth.images(2, 128, 128, seed=1), synth.targets(2, seed=2)
+    m = new_model(dev).train()
+    step = FusedTrainStep(m, V8DetectionLoss(Yolo8DetConfig(), m), FlatAdam(m, lr=1e-3))
+    xd = x.to(dev)
+    mine = np.array([float(step(xd, batch).sum()) * 2 for _ in range(50)])   # items are per-image means; the reference's loss is items.sum() * batch
+
+    def oracle_curve(emulate):
+        sd, state = O.init_state_dict("n", 80, seed=0), {}
+        with (fp16_storage() if emulate else contextlib.nullcontext()):
+            return np.array([float(O.train_step(sd, x, batch, state)[0]) for _ in range(50)])
+    ref, emu = oracle_curve(False), oracle_curve(True)
+    win = lambda c: c.reshape(5, 10).mean(1)  # noqa: E731
+    d_eng, d_emu = np.abs(win(mine) / win(ref) - 1), np.abs(win(emu) / win(ref) - 1)
+    print("10-step window means: engine", np.round(win(mine), 3), "oracle fp32", np.round(win(ref), 3), "oracle fp16-emulation", np.round(win(emu), 3),
+          "| engine vs fp32", np.round(d_eng, 3), "emulation vs fp32", np.round(d_emu, 3))
+    assert np.isfinite(mine).all() and win(mine)[-1] < win(mine)[0] / 6 and win(ref)[-1] < win(ref)[0] / 6
+    assert np.abs(mine[:2] / ref[:2] - 1).max() < 2e-2
+    assert d_eng.max() < 1.5 * d_emu.max() + 0.05, (d_eng, d_emu)
+    assert d_eng[-1] < 0.2
 
 
 def test_autograd_compat_path_matches_fused_path(dev):
@@ -2699,3 +2743,50 @@ def test_eval_forward_with_fused_groups_matches_the_per_layer_path(dev, gold):
         np.testing.assert_allclose(y1.cpu().numpy(), y0.cpu().numpy(), rtol=2e-3, atol=2e-3)
         if x.shape[-1] == 128:
             np.testing.assert_allclose(y1.cpu().numpy(), g["eval_y"], rtol=5e-3, atol=5e-3)
+
+
+# ---- BASELINE configs 4 and 5 at their stated batch ------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_centernet_config4_at_batch_64(dev):
+    """BASELINE.json configs[3]: CenterNet 512x512 inference, batch 64, forward + heat-map decode through the plugin API: finite outputs,
+    count bounds, and per-image independence at the full batch (image 37 of the batch == the same image alone, bit for bit)."""
+    import builder
+    m = _centernet(dev)
+    x = synth.images(64, 512, 512, seed=5).to(dev)
+    with torch.no_grad():
+        raw = m.forward_raw(x)
+        one = m.forward_raw(x[37:38])
+    assert raw.shape[0] == 64 and bool(torch.isfinite(raw).all()) and torch.equal(raw[37:38], one)
+    cfg, algo_cls, _ = builder.export_from_registry("centernet")
+    cfg.dataset.num_classes = 80
+    cfg.arch.input_size = (3, 512, 512)
+    algo = algo_cls(cfg, dev)
+    d_all, d_one = algo.decode_raw(raw, 128, 128), algo.decode_raw(one, 128, 128)
+    counts = d_all["counts"].cpu()
+    assert counts.shape[0] == 64 and bool((counts >= 0).all()) and bool((counts <= 100).all())
+    n = int(d_one["counts"][0])
+    assert n == int(counts[37]) and torch.equal(d_all["topk_index"][37], d_one["topk_index"][0]) and torch.equal(d_all["keep"][37, :n], d_one["keep"][0, :n])
+    for k in ("boxes", "scores"):
+        assert bool(torch.isfinite(d_all[k]).all())
+
+
+@pytest.mark.gpu
+def test_deeplab_config5_at_batch_16(dev):
+    """BASELINE.json configs[4]: DeepLabv3+ 513x513 train step, batch 16: fused steps of the registered trainer on one repeated batch --
+    finite losses that fall, no overflow skip of the dynamic loss scale, every BatchNorm updated."""
+    import builder
+    from core.trainer.segmentation_trainer import SyntheticSegmentationLoader
+    cfg, _, trainer_cls = builder.export_from_registry("deeplabv3plus")
+    assert cfg.train.batch_size == 16
+    torch.manual_seed(0)
+    loader = SyntheticSegmentationLoader(16, (513, 513), 21, length=1, seed=4)
+    tr = trainer_cls(cfg, dev, dataloader=loader)
+    batch = next(iter(loader))
+    tr.model.train()
+    rv0 = tr.model.flat_stats.clone()
+    losses = [float(tr.train_loop(batch, None)[0]) for _ in range(3)]
+    torch.cuda.synchronize()
+    assert all(np.isfinite(v) for v in losses) and losses[-1] < losses[0], losses
+    tr._step.scaler.poll()
+    assert tr._step.scaler.skipped == 0 and tr.optimizer.device_step() == 3
+    assert not torch.equal(tr.model.flat_stats, rv0) and bool(torch.isfinite(tr.model.flat_params).all())

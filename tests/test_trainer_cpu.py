@@ -109,3 +109,44 @@ def test_checkpoint_interchange_of_the_engine_models(tmp_path):
         CheckPoint.load_pure(bare, "cpu", m3)
         sd, sd3 = m.state_dict(), m3.state_dict()
         assert list(sd) == list(sd3) and all(torch.equal(sd[k], sd3[k]) for k in sd)
+
+
+def test_optimizer_state_interchanges_with_torch_adam(tmp_path):
+    """The "optimizer" entry of a full checkpoint is torch.optim.Adam's own layout (the reference saves optimizer.state_dict() of a
+    torch.optim.Adam over model.parameters(), core/utils/ckpt.py:41-48, core/trainer/lr_scheduler.py:37-43): a REAL torch.optim.Adam
+    checkpoint resumes in FlatAdam, and FlatAdam's checkpoint loads into a real torch.optim.Adam -- moments equal per parameter."""
+    from computervision.pytorch_amd.model import Yolo8
+    from computervision.pytorch_amd.train import FlatAdam
+    torch.manual_seed(0)
+    m = Yolo8("n", 80)
+    params = list(m.parameters())
+    # a reference-style optimizer over tensors of the reference's shapes: three Adam steps on random gradients
+    ref_params = [torch.nn.Parameter(p.detach().clone().contiguous(), requires_grad=p.requires_grad) for p in params]
+    ref_opt = torch.optim.Adam(ref_params, lr=2e-3)
+    g = torch.Generator().manual_seed(1)
+    for _ in range(3):
+        for p in ref_params:
+            p.grad = torch.randn(p.shape, generator=g) if p.requires_grad else None
+        ref_opt.step()
+    path = str(tmp_path / "ref_full.pth")
+    torch.save({"model": {k: v.detach().clone() for k, v in m.state_dict().items()}, "optimizer": ref_opt.state_dict()}, path)
+    opt = FlatAdam(m, lr=1e-3)
+    CheckPoint.load(path, "cpu", m, optimizer=opt)                       # used to die with KeyError: 'step'
+    assert opt.device_step() == 3 and opt.param_groups[0]["lr"] == 2e-3
+    for i, p in enumerate(params):
+        if i in ref_opt.state:
+            mv = opt._moment_views(p)
+            assert torch.equal(mv[0], ref_opt.state[ref_params[i]]["exp_avg"]) and torch.equal(mv[1], ref_opt.state[ref_params[i]]["exp_avg_sq"])
+    # the other direction: FlatAdam's file into a fresh torch.optim.Adam
+    mine = str(tmp_path / "mine_full.pth")
+    CheckPoint.save(m, mine, optimizer=opt)
+    sd = torch.load(mine, weights_only=False)["optimizer"]
+    assert set(sd) == {"state", "param_groups"} and sd["param_groups"][0]["params"] == list(range(len(params)))
+    fresh = torch.optim.Adam([torch.nn.Parameter(p.detach().clone().contiguous(), requires_grad=p.requires_grad) for p in params], lr=1e-3)
+    fresh.load_state_dict(sd)
+    for i, p in enumerate(fresh.param_groups[0]["params"]):
+        if i in ref_opt.state_dict()["state"]:
+            assert torch.equal(fresh.state[p]["exp_avg"], ref_opt.state[ref_params[i]]["exp_avg"]) and float(fresh.state[p]["step"]) == 3.0
+    # the round-1/2 flat format still loads
+    opt.load_state_dict({"step": 5, "exp_avg": None, "exp_avg_sq": None, "param_groups": [{"lr": 5e-4}]})
+    assert opt.device_step() == 5 and float(opt._m.abs().max()) == 0.0
