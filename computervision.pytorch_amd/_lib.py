@@ -138,6 +138,12 @@ PROTOTYPES = {
     "cvx_stem_train_nchw": (_I32, [_P, _I32, _I32, _I32, _P, _I32, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
     "cvx_stem_eval_nchw": (_I32, [_P, _I32, _I32, _I32, _P, _I32, _P, _P, _P, _P]),
     "cvx_stem_wgrad_nchw": (_I32, [_P, _I32, _I32, _I32, _P, _I32, _P, _P]),
+    "cvx_comm_unique_id": (_I32, [_P]),
+    "cvx_comm_create": (_I32, [C.POINTER(_P), _P, _I32, _I32, _I32]),
+    "cvx_comm_destroy": (_I32, [_P]),
+    "cvx_allreduce_f32": (_I32, [_P, _I64, _P, _P]),
+    "cvx_allreduce_grads": (_I32, [_P, _P, _P]),
+    "cvx_engine_backward_exchange": (_I32, [_P, _P, _F, _P, _P, _I32, _P]),
     "cvx_chain_pair_unit": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _I32, _I32, _I32, C.POINTER(_F), _P]),
     "cvx_chain_conv_unit": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _I32, _P, _P, _I32, _P, _I32, _I32, _I32, C.POINTER(_F), _P]),
     "cvx_chain_detect_unit": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32,

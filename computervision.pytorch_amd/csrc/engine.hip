@@ -1656,6 +1656,35 @@ extern "C" int cvx_engine_grads_ready(cvx_engine* e, int32_t op_hi, int32_t op_l
   return 0;
 }
 
+int cvx_comm_allreduce_slice(float* base, long long p0, long long p1, void* comm, hipStream_t stream);  // comm.hip
+
+extern "C" int cvx_allreduce_grads(cvx_engine* e, void* nccl_comm, void* hip_stream) {
+  CVX_CHECK(e && nccl_comm && e->grads && e->n_params > 0, "bad arguments (engine bound with a gradient arena, RCCL communicator)");
+  return cvx_comm_allreduce_slice(e->grads, 0, e->n_params, nccl_comm, (hipStream_t)hip_stream);
+}
+
+extern "C" int cvx_engine_backward_exchange(cvx_engine* e, const void* dpred_f16, float loss_scale, void* nccl_comm, const int64_t* buckets,
+                                            int32_t n_buckets, void* comm_stream) {
+  CVX_CHECK(e && dpred_f16 && nccl_comm && buckets && n_buckets > 0 && comm_stream, "bad arguments");
+  CVX_CHECK(e->grads, "cvx_engine_bind was called without a gradient arena");
+  hipStream_t cs = (hipStream_t)comm_stream;
+  CVX_TRY(cvx_engine_backward_begin(e, dpred_f16, loss_scale));
+  for (int b = 0; b < n_buckets; ++b) {
+    const int64_t* q = buckets + 4 * b;  // op_hi, op_lo, p_start, p_end
+    CVX_CHECK(q[2] >= 0 && q[3] <= e->n_params && q[2] <= q[3], "bucket slice outside the gradient arena");
+    CVX_TRY(cvx_engine_backward_range(e, (int32_t)q[0], (int32_t)q[1]));
+    CVX_TRY(cvx_engine_grads_ready(e, (int32_t)q[0], (int32_t)q[1], comm_stream));
+    CVX_TRY(cvx_comm_allreduce_slice(e->grads, q[2], q[3], nccl_comm, cs));
+  }
+  CVX_TRY(cvx_engine_backward_end(e));
+  // the engine's stream (the optimiser step comes next on it) waits for the last exchange
+  hipEvent_t* ev = &e->ev_seg[(e->ev_seg_next++ % 4) * 2];
+  if (!ev[0]) CVX_HIP(hipEventCreateWithFlags(&ev[0], cvx_event_flags()));
+  CVX_HIP(hipEventRecord(ev[0], cs));
+  CVX_HIP(hipStreamWaitEvent(e->stream, ev[0], 0));
+  return 0;
+}
+
 extern "C" int cvx_engine_backward_end(cvx_engine* e) {
   CVX_CHECK(e && e->bw && e->bw->active, "cvx_engine_backward_end without cvx_engine_backward_begin");
   cvx_bw_state& w = bw_of(e);

@@ -14,6 +14,8 @@ from typing import Dict, List, Optional
 
 import torch
 
+import ctypes as C
+
 from . import _lib as L
 from .engine import V8LossOp, adam_step, adam_step_dev, check_finite
 from .graph import STRIDES
@@ -254,6 +256,51 @@ class DynamicLossScale:
         self.scale, self._good = float(sd["scale"]), int(sd.get("good_steps", 0))
 
 
+class CvxComm:
+    """An RCCL communicator owned by the engine library (include/cvx_engine.h: cvx_comm_*): the gradient exchange then runs entirely
+    behind the C ABI (``cvx_engine_backward_exchange``: no Python between the op ranges of the backward pass).  The 128-byte unique id
+    is created on rank 0 and shipped through torch.distributed (any backend -- gloo is enough: it only carries these bytes)."""
+
+    def __init__(self, device: torch.device, process_group=None, rank: Optional[int] = None, world: Optional[int] = None, unique_id: Optional[bytes] = None):
+        import torch.distributed as dist
+        lib = L.load()
+        have_pg = dist.is_available() and dist.is_initialized()
+        self.rank = rank if rank is not None else (dist.get_rank(process_group) if have_pg else 0)
+        self.world = world if world is not None else (dist.get_world_size(process_group) if have_pg else 1)
+        if unique_id is None:
+            buf = C.create_string_buffer(128)
+            if self.rank == 0:
+                L.check(lib.cvx_comm_unique_id(buf), "cvx_comm_unique_id")
+            box = [bytes(buf.raw)]
+            if self.world > 1:
+                dist.broadcast_object_list(box, src=0, group=process_group)
+            unique_id = box[0]
+        self.handle = C.c_void_p()
+        dev_index = device.index if device.index is not None else torch.cuda.current_device()
+        L.check(lib.cvx_comm_create(C.byref(self.handle), C.c_char_p(unique_id), self.rank, self.world, dev_index), "cvx_comm_create")
+        self.stream = torch.cuda.Stream(device=device, priority=-1)   # high priority: a hardware queue of its own
+        self._lib = lib
+
+    def all_reduce_(self, t: torch.Tensor, stream: Optional[torch.cuda.Stream] = None):
+        st = stream or torch.cuda.current_stream(t.device)
+        L.check(self._lib.cvx_allreduce_f32(L.ptr(t), t.numel(), self.handle, C.c_void_p(st.cuda_stream)), "cvx_allreduce_f32")
+        return t
+
+    def backward_exchange(self, eng, buckets, dpred: torch.Tensor, loss_scale: float):
+        """the data-parallel backward pass in one C call (buckets: graph.grad_buckets rows)"""
+        flat = (C.c_int64 * (4 * len(buckets)))(*[int(v) for b in buckets for v in b])
+        eng._use_current_stream()
+        L.check(self._lib.cvx_engine_backward_exchange(eng.handle, L.ptr(dpred), float(loss_scale), self.handle, flat, len(buckets),
+                                                       C.c_void_p(self.stream.cuda_stream)), "cvx_engine_backward_exchange")
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self._lib.cvx_comm_destroy(self.handle)
+        except Exception:
+            pass
+
+
 class FusedTrainStep:
     """One optimisation step = forward, loss(+grad), backward, optional DP all-reduce, Adam.
 
@@ -263,8 +310,9 @@ class FusedTrainStep:
     """
 
     def __init__(self, model: Yolo8, criterion: V8DetectionLoss, optimizer: FlatAdam, process_group=None, n_buckets: int = 4,
-                 use_graph: bool = False, scaler: Optional[DynamicLossScale] = None):
+                 use_graph: bool = False, scaler: Optional[DynamicLossScale] = None, comm: Optional["CvxComm"] = None):
         self.model, self.criterion, self.optimizer = model, criterion, optimizer
+        self.comm = comm               # CvxComm: the exchange runs behind the C ABI (cvx_engine_backward_exchange) instead of torch.distributed
         self.scaler = scaler           # None: static loss scale (criterion.loss_scale); hipGraph replay needs the static one
         self.pg = process_group
         self.n_buckets = n_buckets
@@ -276,6 +324,8 @@ class FusedTrainStep:
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
             self.distributed = True     # a 1-rank group still exercises the RCCL exchange path (bench.py CVX_FORCE_DIST)
+        if comm is not None:
+            self.world, self.distributed = comm.world, True
         self._pred = None
         self._dpred = None
         self._side = None
@@ -357,6 +407,9 @@ class FusedTrainStep:
         if self._buckets_key != key:
             self._buckets = eng.grad_buckets(m.layout, self.n_buckets)
             self._buckets_key = key
+        if self.comm is not None:        # whole pass in one C call: ranges, slab folds and RCCL all-reduces enqueued without host code between them
+            self.comm.backward_exchange(eng, self._buckets, dpred, loss_scale)
+            return
         cur = torch.cuda.current_stream(g.device)
         backward_with_overlapped_exchange(eng, self._buckets, g, dpred, loss_scale, self.pg, self._side)
         cur.wait_stream(self._side)

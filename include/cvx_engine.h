@@ -496,6 +496,23 @@ int cvx_stem_backward_nchw(const float* images, int32_t batch, int32_t h, int32_
                            const float* gamma, const float* beta, const float* invstd, float inv_scale, float* dgamma, float* dbeta, float* dw,
                            void* hip_stream);
 
+/* ---- data-parallel gradient exchange over RCCL (csrc/comm.hip), SURVEY.md section 8(b) / 8(e) --------------------------------------
+ * One process per GPU.  Rank 0 calls cvx_comm_unique_id (128 bytes, ncclGetUniqueId), ships them to every rank by any means, all ranks
+ * call cvx_comm_create (ncclCommInitRank; RCCL is dlopen'ed on first use).  `comm` below is the ncclComm_t.
+ * cvx_allreduce_grads: SUM all-reduce of the engine's whole flat gradient arena on `hip_stream` (after cvx_engine_backward).
+ * cvx_engine_backward_exchange: the overlapped form, the whole data-parallel backward pass in one call -- `buckets` holds n_buckets rows
+ *   (op_hi, op_lo, p_start, p_end), op ranges in backward order with their slice of the gradient arena (graph.grad_buckets); each range
+ *   is queued on the engine's stream, `comm_stream` waits for it, folds its weight-gradient slabs and all-reduces its slice while the next
+ *   range runs; on return the engine's stream waits for the last exchange.  The mean's 1/world belongs to the optimiser step.
+ * The reference has no distributed path; north_star: RCCL all-reduce of gradients overlapped with the backward pass. */
+int cvx_comm_unique_id(void* out128);
+int cvx_comm_create(void** comm, const void* unique_id128, int32_t rank, int32_t world, int32_t device);
+int cvx_comm_destroy(void* comm);
+int cvx_allreduce_f32(float* data, int64_t count, void* comm, void* hip_stream);
+int cvx_allreduce_grads(cvx_engine* e, void* comm, void* hip_stream);
+int cvx_engine_backward_exchange(cvx_engine* e, const void* dpred_f16, float loss_scale, void* comm, const int64_t* buckets, int32_t n_buckets,
+                                 void* comm_stream);
+
 /* ---- tile-resident convolution chains (csrc/conv_chain.hip), single-op entry points ------------------------------------
  * Eval-mode fusion groups as ONE launch each: the intermediates stay in LDS, the weights of all stages stream through one
  * LDS-DMA ring.  x / out are NHWC fp16, weights [cout][kh][kw][cin] fp16, scale / shift the folded BatchNorm (fp32);

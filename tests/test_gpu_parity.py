@@ -14,6 +14,7 @@ Tolerances (stated once, used below):
   per-layer activation gradients vs the fp16-storage emulation: see test_per_layer_backward_parity.
 """
 import contextlib
+import os
 
 import numpy as np
 import pytest
@@ -21,6 +22,7 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from computervision.pytorch_amd import _lib as L  # noqa: E402
 from computervision.pytorch_amd import engine as E  # noqa: E402
@@ -763,31 +765,28 @@ def test_fused_steps_track_the_reference_loss_curve(dev, gold):
         assert abs(float(items.sum() * 4) / float(g["loss"][s]) - 1) < 1e-2, s
 
 
-def test_fifty_fused_steps_follow_the_oracle_loss_trajectory(dev):
+def test_fifty_fused_steps_follow_the_oracle_loss_trajectory(dev, gold):
     """50 steps of engine (fp16 operands, fused step) vs oracle (fp32 CPU restatement of the reference's train_loop, yolo8_train.py:93-111)
-    from the same seed-0 initialisation on one repeated 128x128 batch.  Adam at lr 1e-3 on a 2-image batch is chaotic step by step (the
-    oracle's OWN curve jumps by 10-25 % between consecutive steps; its fp16-storage emulation leaves its fp32 run by up to 47 % on single
-    steps and 24 % on 10-step window means, measured), so the yardstick is computed here: the oracle is run a second time with the engine's
-    rounding points emulated, and the engine's 10-step window means must stay as close to the fp32 curve as 1.5 x that emulation does (+ 5 %).
-    Hard bounds on top: the first two steps (before anything can diverge) within 2 %, both curves fall by > 6 x, last windows within 20 %."""
+    from the same seed-0 initialisation on one repeated 128x128 batch; the oracle's two curves (fp32, and with the engine's rounding
+    points emulated) come from tests/golden/yolov8n_traj_128.npz (oracle/make_traj_fixture.py).  Adam at lr 1e-3 on a 2-image batch is
+    chaotic step by step (the oracle's OWN curve jumps by 10-25 % between consecutive steps; its fp16 emulation leaves its fp32 run by up
+    to 47 % on single steps and 24 % on 10-step window means), so the yardstick is the emulation: the engine's 10-step window means must
+    stay as close to the fp32 curve as 1.5 x the emulation does (+ 5 %).  Hard bounds on top: the first two steps (before anything can
+    diverge) within 2 %, the curve falls by > 6 x, the last window within 20 %."""
     from computervision.pytorch_amd.train import FlatAdam, FusedTrainStep, V8DetectionLoss
     from configs import Yolo8DetConfig
+    g = gold("yolov8n_traj_128.npz")
+    ref, emu = g["fp32"], g["fp16_emulation"]
     x, batch = synth.images(2, 128, 128, seed=1), synth.targets(2, seed=2)
     m = new_model(dev).train()
     step = FusedTrainStep(m, V8DetectionLoss(Yolo8DetConfig(), m), FlatAdam(m, lr=1e-3))
     xd = x.to(dev)
     mine = np.array([float(step(xd, batch).sum()) * 2 for _ in range(50)])   # items are per-image means; the reference's loss is items.sum() * batch
-
-    def oracle_curve(emulate):
-        sd, state = O.init_state_dict("n", 80, seed=0), {}
-        with (fp16_storage() if emulate else contextlib.nullcontext()):
-            return np.array([float(O.train_step(sd, x, batch, state)[0]) for _ in range(50)])
-    ref, emu = oracle_curve(False), oracle_curve(True)
     win = lambda c: c.reshape(5, 10).mean(1)  # noqa: E731
     d_eng, d_emu = np.abs(win(mine) / win(ref) - 1), np.abs(win(emu) / win(ref) - 1)
     print("10-step window means: engine", np.round(win(mine), 3), "oracle fp32", np.round(win(ref), 3), "oracle fp16-emulation", np.round(win(emu), 3),
           "| engine vs fp32", np.round(d_eng, 3), "emulation vs fp32", np.round(d_emu, 3))
-    assert np.isfinite(mine).all() and win(mine)[-1] < win(mine)[0] / 6 and win(ref)[-1] < win(ref)[0] / 6
+    assert np.isfinite(mine).all() and win(mine)[-1] < win(mine)[0] / 6
     assert np.abs(mine[:2] / ref[:2] - 1).max() < 2e-2
     assert d_eng.max() < 1.5 * d_emu.max() + 0.05, (d_eng, d_emu)
     assert d_eng[-1] < 0.2
@@ -2790,3 +2789,70 @@ def test_deeplab_config5_at_batch_16(dev):
     tr._step.scaler.poll()
     assert tr._step.scaler.skipped == 0 and tr.optimizer.device_step() == 3
     assert not torch.equal(tr.model.flat_stats, rv0) and bool(torch.isfinite(tr.model.flat_params).all())
+
+
+# ---- gradient exchange behind the C ABI (csrc/comm.hip) ---------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_c_abi_exchange_with_one_rank_is_bit_identical_to_plain_backward(dev):
+    """cvx_engine_backward_exchange (ranges, slab folds and RCCL all-reduces enqueued from C, communicator created through
+    cvx_comm_unique_id / cvx_comm_create) with a communicator of ONE rank: the step must give exactly the plain step's losses and
+    parameters; cvx_allreduce_grads (whole arena) leaves a gradient arena unchanged at world 1."""
+    from computervision.pytorch_amd.train import CvxComm, FlatAdam, FusedTrainStep, V8DetectionLoss
+    from configs import Yolo8DetConfig
+    x, batch = synth.images(2, 128, 128, seed=1).to(dev), {k: v.to(dev) for k, v in synth.targets(2, seed=2).items()}
+    try:
+        comm = CvxComm(dev, rank=0, world=1)
+    except L.CvxError as exc:                                        # no RCCL library on this box
+        pytest.skip(f"RCCL unavailable: {exc}")
+    runs = []
+    for c in (None, comm):
+        m = new_model(dev).train()
+        step = FusedTrainStep(m, V8DetectionLoss(Yolo8DetConfig(), m), FlatAdam(m, lr=1e-3), n_buckets=4, comm=c)
+        losses = [step(x, batch).clone() for _ in range(3)]
+        torch.cuda.synchronize()
+        runs.append((torch.stack(losses).cpu(), m.flat_params.clone().cpu()))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    g = torch.randn(100003, device=dev)
+    g0 = g.clone()
+    comm.all_reduce_(g)
+    torch.cuda.synchronize()
+    assert torch.equal(g, g0)
+    m = new_model(dev).train()
+    crit = V8DetectionLoss(Yolo8DetConfig(), m)
+    pred = m._run_forward(x, training=True)
+    from computervision.pytorch_amd.train import flatten_targets
+    _, dpred = crit.op(pred, flatten_targets(batch, dev), m.level_shapes(128, 128), (8, 16, 32), crit.loss_scale)
+    eng = m.engine_for(128, 128)
+    eng.backward(dpred, crit.loss_scale)
+    torch.cuda.synchronize()
+    before = m.flat_grads.clone()
+    L.check(L.load().cvx_allreduce_grads(eng.handle, comm.handle, L.stream_ptr(dev)), "cvx_allreduce_grads")
+    torch.cuda.synchronize()
+    assert torch.equal(m.flat_grads, before)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (one process per GPU over RCCL)")
+@pytest.mark.parametrize("exchange", ["c", "torch"])
+def test_two_rank_rccl_step_against_the_dp_fixture(gold, tmp_path, exchange):
+    """Two FRESH child processes (tools/dp_rccl_child.py; never a re-exec of a process that touched the GPU), one per GPU, each with its
+    half of the fixture batch: the gradients after the overlapped RCCL exchange (C ABI path and torch.distributed path) are the mean of
+    the per-shard gradients -- equal on both ranks, and the reference's shard-by-shard mean (tests/golden/dp_sim_96.npz) within the
+    end-to-end bound of the single-GPU simulation test."""
+    import subprocess
+    import sys as _sys
+    port = 29650 + (0 if exchange == "c" else 1)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([_sys.executable, os.path.join(ROOT, "tools", "dp_rccl_child.py"), str(r), "2", str(port), str(tmp_path), exchange], env=env)
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(r0["grads"], r1["grads"])
+    f = gold("dp_sim_96.npz")
+    from computervision.pytorch_amd.graph import ParamLayout
+    mean = ParamLayout("n", 80).views(torch.from_numpy(r0["grads"]))
+    flat = torch.cat([mean[str(k)].flatten() for k in f["keys"]])
+    ref = torch.from_numpy(f["w2_sub"])
+    assert float((flat[::211] - ref).norm() / ref.norm()) < 1.6e-1
+    assert abs(float(flat.norm()) / float(f["w2_norm"]) - 1) < 5e-2
