@@ -105,25 +105,28 @@ class Ssd:
         boxes, prob, cmax = _engine.ssd_decode(loc, conf, self._priors_dev, self.variance[::2].tolist(), with_class_max=True)
         B, A, _ = boxes.shape
         bt = boxes.transpose(1, 2).contiguous()                                  # (B, 4, A): corner boxes, channel-major for cvx_nms
-        per_img = [([], []) for _ in range(B)]
         active = (cmax > conf_thr).cpu().tolist()       # the decode kernel's per-class maxima: one host read decides every class
-        for c in range(1, self.num_classes + 1):
-            if not active[c]:
-                continue
-            y = torch.cat((bt, prob[:, :, c].unsqueeze(1)), 1)
-            rows, index, counts = _engine.nms(y, float(conf_thr), self.nms_threshold, max_det=MAX_DET, variant="vanilla", boxes_xyxy=True)
-            counts_h = counts.cpu().tolist()                      # one host read per class, not one per image
-            for b in range(B):
-                n = int(counts_h[b])
-                if n < 0 or n >= MAX_DET:
-                    raise L.CvxError(f"more than {MAX_DET} detections of one class in one image: raise decode.confidence_threshold")
-                if n == 0:
-                    continue
-                idx = index[b, :n].long()
-                per_img[b][0].append(torch.cat((rows[b, :n, :4], torch.full((n, 1), float(c - 1), device=dev), rows[b, :n, 4:5]), 1))
-                per_img[b][1].append(torch.stack((idx, torch.full_like(idx, c)), 1))
-        return [(torch.cat(r), torch.cat(p)) if r else (torch.zeros(0, 6, device=dev), torch.zeros(0, 2, dtype=torch.long, device=dev))
-                for r, p in per_img]
+        classes = [c for c in range(1, self.num_classes + 1) if active[c]]
+        empty = (torch.zeros(0, 6, device=dev), torch.zeros(0, 2, dtype=torch.long, device=dev))
+        if not classes:
+            return [empty for _ in range(B)]
+        # one NMS launch per class that has a score above the threshold, all queued back to back; ONE host read (the counts of every
+        # class and image) afterwards, and one masked gather per image instead of a cat per (class, image)
+        outs = [_engine.nms(torch.cat((bt, prob[:, :, c].unsqueeze(1)), 1), float(conf_thr), self.nms_threshold, max_det=MAX_DET, variant="vanilla",
+                            boxes_xyxy=True) for c in classes]
+        rows = torch.stack([o[0] for o in outs])                                 # (C', B, MAX_DET, 6)
+        index = torch.stack([o[1] for o in outs]).long()                         # (C', B, MAX_DET)
+        counts = torch.stack([o[2] for o in outs])                               # (C', B)
+        counts_h = counts.cpu()
+        if bool((counts_h < 0).any()) or bool((counts_h >= MAX_DET).any()):
+            raise L.CvxError(f"more than {MAX_DET} detections of one class in one image: raise decode.confidence_threshold")
+        cls_col = torch.tensor(classes, device=dev).view(-1, 1, 1).expand(-1, B, rows.shape[2])      # class column per slot
+        valid = torch.arange(rows.shape[2], device=dev).view(1, 1, -1) < counts.unsqueeze(2)         # (C', B, MAX_DET)
+        det = torch.cat((rows[..., :4], (cls_col - 1).unsqueeze(3).to(rows.dtype), rows[..., 4:5]), 3)
+        pairs = torch.stack((index, cls_col), 3)
+        per_image = counts_h.sum(0).tolist()
+        # boolean-mask indexing walks (class, rank) in order: classes ascending, scores descending inside a class, like the reference's loop
+        return [(det[:, b][valid[:, b]], pairs[:, b][valid[:, b]]) if per_image[b] > 0 else empty for b in range(B)]
 
     def decode_boxes(self, preds, h, w, conf_threshold=None):
         results = []

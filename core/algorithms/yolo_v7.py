@@ -65,25 +65,23 @@ class YOLOv7:
         # cvx_nms keeps scores > threshold (ultralytics_ops.py:190), the reference here keeps >= : the next float below
         thr = float(np.nextafter(np.float32(conf), np.float32(-1.0)))
         rows, index, counts = _engine.nms(y, thr, self.nms_threshold, max_det=MAX_DET, variant="vanilla")
-        out = []
-        counts_h = counts.cpu().tolist()                           # one host read for the batch, not one per image
-        for b in range(y.shape[0]):
-            n = int(counts_h[b])
+        counts_h = counts.cpu().tolist()                           # the ONE host read of the tail
+        for b, n in enumerate(counts_h):
             if n < 0:
-                raise L.CvxError("cvx_nms: more than 16384 candidates above the confidence threshold in one image")
+                raise L.CvxError(f"cvx_nms: more than 16384 candidates above the confidence threshold in image {b}")
             if n >= MAX_DET:
-                raise L.CvxError(f"more than {MAX_DET} detections in one image: raise decode.conf_threshold")
-            if n == 0:
-                out.append((None, None))
-                continue
-            idx = index[b, :n].long()
-            r = rows[b, :n]
-            order = torch.argsort(r[:, 5], stable=True)          # class ascending; cvx_nms rows come in descending score
-            idx, r = idx[order], r[order]
-            d = dec[b, idx]
-            cconf = d[:, 5:5 + self.num_classes].gather(1, r[:, 5:6].long())
-            out.append((torch.cat((r[:, :4], d[:, 4:5], cconf, r[:, 5:6]), 1), idx))
-        return out
+                raise L.CvxError(f"more than {MAX_DET} detections in image {b}: raise decode.conf_threshold")
+        # re-order every image's kept rows at once (no per-image kernels): class ascending, cvx_nms's descending score inside a class;
+        # rows past an image's count sort to the end
+        B, K = rows.shape[0], rows.shape[1]
+        valid = torch.arange(K, device=rows.device).unsqueeze(0) < counts.unsqueeze(1)
+        order = torch.argsort(torch.where(valid, rows[:, :, 5], torch.full_like(rows[:, :, 5], float("inf"))), dim=1, stable=True)
+        r = rows.gather(1, order.unsqueeze(2).expand(-1, -1, rows.shape[2]))
+        idx = index.long().gather(1, order).clamp_(min=0)
+        d = dec.gather(1, idx.unsqueeze(2).expand(-1, -1, dec.shape[2]))
+        cconf = d[:, :, 5:5 + self.num_classes].gather(2, r[:, :, 5:6].long().clamp_(0, self.num_classes - 1))
+        det = torch.cat((r[:, :, :4], d[:, :, 4:5], cconf, r[:, :, 5:6]), 2)
+        return [(det[b, :n], idx[b, :n]) if n > 0 else (None, None) for b, n in enumerate(counts_h)]
 
     def decode_box(self, preds, image_h, image_w, conf_threshold=None, model=None):
         """Reference signature (yolo_v7.py:234).  ``preds``: the model's output tuple; the decode reads the engine's rows of that
