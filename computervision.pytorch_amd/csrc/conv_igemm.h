@@ -96,6 +96,10 @@ int cvx_conv_igemm_dma_launch(const ConvParams& p, hipStream_t stream);
 // 3x3 stride-1 halo-tile kernel (conv_halo.hip)
 bool cvx_conv_halo_supported(const ConvParams& p);
 int cvx_conv_halo_launch(const ConvParams& p, hipStream_t stream);
+// GEMM-shaped kernel for the big-channel layers (conv_gemm.hip)
+bool cvx_conv_gemm_shape_ok(const ConvParams& p);   // what the kernel can run at all
+bool cvx_conv_gemm_supported(const ConvParams& p);  // ... and where the dispatcher prefers it
+int cvx_conv_gemm_launch(const ConvParams& p, hipStream_t stream);
 // pointwise (1x1 stride-1) persistent GEMM kernel (conv_pw.hip)
 bool cvx_conv_pw_supported(const ConvParams& p);
 int cvx_conv_pw_launch(const ConvParams& p, hipStream_t stream);

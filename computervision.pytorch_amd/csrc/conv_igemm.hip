@@ -1,6 +1,8 @@
 // Convolution dispatcher: validates a ConvParams block and routes it to one of the three implicit-GEMM kernels
 //   * conv_pw.hip         1x1 stride-1 forward / data gradient: persistent, barrier-free, weights resident in LDS;
 //   * conv_halo.hip       3x3 stride-1 forward / data gradient: persistent, halo patch + weights resident in LDS;
+//   * conv_gemm.hip       big-channel layers (taps * Cin >= 1024, Cin % 32 == 0): 256 x 256 ... 128 x 128 macro tiles, both operands
+//                         through an LDS-DMA ring, v_mfma_f32_32x32x16_f16;
 //   * conv_igemm_dma.hip  every other shape (stride 2, 256+ channels, dilation, merged stride-2 gradient phases):
 //                         LDS-DMA ring.
 // (The register-staged first-generation kernel that used to live here was retired once the DMA kernels covered every
@@ -23,5 +25,6 @@ int cvx_conv_igemm_launch(const ConvParams& p_in, hipStream_t stream, int* m_blo
   if (p.nphase > 1) return cvx_conv_igemm_dma_launch(p, stream);  // merged phases: the DMA-ring kernel only
   if (cvx_conv_pw_supported(p)) return cvx_conv_pw_launch(p, stream);
   if (cvx_conv_halo_supported(p)) return cvx_conv_halo_launch(p, stream);
+  if (cvx_conv_gemm_supported(p)) return cvx_conv_gemm_launch(p, stream);
   return cvx_conv_igemm_dma_launch(p, stream);
 }

@@ -1803,6 +1803,8 @@ extern "C" int cvx_conv2d_nhwc(const void* x_f16, int32_t batch, int32_t ih, int
                                const float* shift, void* out, void* hip_stream) {
   CVX_CHECK(x_f16 && w_f16 && out && k * k <= CVX_MAX_TAPS && stride >= 1 && dil >= 1, "bad arguments");
   hipStream_t st = (hipStream_t)hip_stream;
+  const bool force_gemm = (mode & 0x100) != 0;  // unit tests of the GEMM-shaped kernel on shapes the dispatcher gives to another one
+  mode &= 0xff;
   const int oh = (ih + 2 * pad - dil * (k - 1) - 1) / stride + 1, ow = (iw + 2 * pad - dil * (k - 1) - 1) / stride + 1;
   std::vector<ConvTap> taps;
   for (int r = 0; r < k; ++r)
@@ -1852,7 +1854,16 @@ extern "C" int cvx_conv2d_nhwc(const void* x_f16, int32_t batch, int32_t ih, int
     cp.stats = (long long*)shift;
     cp.stats_replicas = cvx_stat_replicas(cout);
   }
-  int rc = cvx_conv_igemm_launch(cp, st, nullptr);
+  int rc;
+  if (force_gemm) {
+    if (!cvx_conv_gemm_shape_ok(cp)) {
+      (void)hipFree(dt);
+      CVX_CHECK(false, "shape outside the GEMM-shaped kernel (cin % 32, cout % 4)");
+    }
+    rc = cvx_conv_gemm_launch(cp, st);
+  } else {
+    rc = cvx_conv_igemm_launch(cp, st, nullptr);
+  }
   (void)hipStreamSynchronize(st);
   (void)hipFree(dt);
   return rc;

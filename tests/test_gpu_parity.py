@@ -72,7 +72,12 @@ class fp16_storage:
 CONV_CASES = [(2, 16, 16, 16, 16, 3, 1), (2, 20, 20, 8, 16, 3, 2), (1, 24, 24, 32, 64, 3, 2), (2, 10, 10, 64, 144, 3, 1),
               (2, 12, 12, 48, 32, 1, 1), (1, 20, 20, 384, 256, 1, 1), (3, 7, 9, 80, 80, 3, 1), (1, 13, 13, 256, 512, 3, 2),
               (1, 5, 5, 16, 16, 3, 1), (2, 33, 17, 96, 64, 1, 1), (2, 40, 40, 144, 64, 3, 1), (1, 80, 80, 80, 80, 3, 1),
-              (1, 80, 80, 128, 32, 3, 1), (4, 20, 20, 128, 128, 3, 1), (1, 160, 160, 32, 32, 1, 1), (2, 20, 20, 512, 256, 1, 1)]
+              (1, 80, 80, 128, 32, 3, 1), (4, 20, 20, 128, 128, 3, 1), (1, 160, 160, 32, 32, 1, 1), (2, 20, 20, 512, 256, 1, 1),
+              # big-channel shapes (VGG 19x19 512->512, 38x38 256->512, ResNet-101 1x1 1024->256, a stride-2 3x3, ragged tiles)
+              (8, 19, 19, 512, 512, 3, 1), (2, 38, 38, 256, 512, 3, 1), (4, 33, 33, 1024, 256, 1, 1), (8, 40, 40, 128, 256, 3, 2),
+              (3, 27, 31, 160, 200, 3, 1)]
+GEMM_CASES = [(8, 19, 19, 512, 512, 3, 1, 1), (2, 38, 38, 256, 512, 3, 1, 1), (4, 33, 33, 1024, 256, 1, 1, 1), (8, 40, 40, 128, 256, 3, 2, 1),
+              (3, 27, 31, 160, 200, 3, 1, 1), (2, 33, 33, 256, 256, 3, 1, 2), (1, 9, 9, 32, 68, 3, 1, 1), (40, 38, 38, 512, 512, 3, 1, 1)]
 
 
 @pytest.mark.parametrize("B,H,W,C,f", [(2, 12, 10, 64, 2), (1, 7, 9, 24, 2), (2, 6, 5, 64, 4), (1, 5, 4, 16, 8), (1, 3, 3, 520, 2), (3, 24, 24, 256, 2)])
@@ -137,6 +142,40 @@ def test_conv_fwd_dgrad_wgrad(dev, B, H, W, Ci, Co, k, s):
     dw = torch.empty(Co, k, k, Ci, dtype=torch.float32, device=dev)
     L.check(lib.cvx_conv2d_wgrad_nhwc(L.ptr(xd), L.ptr(dyd), B, H, W, Ci, Co, k, s, k // 2, 1, L.ptr(dw), L.ptr(ws), need, st), "wgrad")
     assert rel(dw.permute(0, 3, 1, 2), wr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,k,s,dil", GEMM_CASES)
+def test_gemm_shaped_conv_kernel_all_epilogues(dev, B, H, W, Ci, Co, k, s, dil):
+    """conv_gemm.hip run directly (mode | 0x100) -- the dispatcher only prefers it on the largest layers: plain fp16 store, folded BN + SiLU,
+    bias -> fp32, and the training epilogue (raw fp32 + per-channel statistics), on VGG / ResNet-101 / atrous shapes, ragged pixel and
+    channel tiles (9x9 pixels, 68 / 200 channels), and the batch-40 38x38 512->512 layer that takes the 256 x 256 macro tile."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(B + H + Ci + Co + k)
+    x16 = torch.randn(B, Ci, H, W, generator=g).half()
+    w16 = (torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5).half()
+    pad = dil * (k // 2)
+    xd, wd = x16.permute(0, 2, 3, 1).contiguous().to(dev), w16.permute(0, 2, 3, 1).contiguous().to(dev)
+    conv = F.conv2d(x16.float().to(dev), w16.float().to(dev), None, s, pad, dil)
+    OH, OW = conv.shape[2:]
+    st = L.stream_ptr(dev)
+    sc, sh = (torch.rand(Co, generator=g) + 0.5).to(dev), torch.randn(Co, generator=g).to(dev)
+    out = torch.empty(B, OH, OW, Co, dtype=torch.float16, device=dev)
+    L.check(lib.cvx_conv2d_nhwc(L.ptr(xd), B, H, W, Ci, L.ptr(wd), Co, k, s, pad, dil, 0x100, None, None, L.ptr(out), st), "plain")
+    assert rel(out.float().permute(0, 3, 1, 2), conv) < 5e-4
+    L.check(lib.cvx_conv2d_nhwc(L.ptr(xd), B, H, W, Ci, L.ptr(wd), Co, k, s, pad, dil, 0x101, L.ptr(sc), L.ptr(sh), L.ptr(out), st), "affine")
+    assert rel(out.float().permute(0, 3, 1, 2), F.silu(conv * sc[None, :, None, None] + sh[None, :, None, None])) < 5e-4
+    out32 = torch.empty(B, OH, OW, Co, dtype=torch.float32, device=dev)
+    L.check(lib.cvx_conv2d_nhwc(L.ptr(xd), B, H, W, Ci, L.ptr(wd), Co, k, s, pad, dil, 0x102, L.ptr(sh), None, L.ptr(out32), st), "bias")
+    assert rel(out32.permute(0, 3, 1, 2), conv + sh[None, :, None, None]) < 1e-5
+    R = 16 if Co <= 32 else 8 if Co <= 64 else 4 if Co <= 128 else 2 if Co <= 256 else 1  # cvx_stat_replicas (csrc/bn_act.h:8)
+    slab = torch.zeros(R, Co, 2, 2, dtype=torch.int64, device=dev)  # [replica][channel][sum, sum of squares][coarse 2^-6, fine 2^-40]
+    L.check(lib.cvx_conv2d_nhwc(L.ptr(xd), B, H, W, Ci, L.ptr(wd), Co, k, s, pad, dil, 0x103, None, L.ptr(slab), L.ptr(out32), st), "stats")
+    assert rel(out32.permute(0, 3, 1, 2), conv) < 1e-5
+    tot = slab.sum(0).double()
+    sums = tot[..., 0] / 64.0 + tot[..., 1] / 2.0 ** 40
+    n = B * OH * OW
+    assert (sums[:, 0] / n - conv.double().mean((0, 2, 3))).abs().max() < 1e-5
+    assert rel(sums[:, 1] / n, (conv.double() ** 2).mean((0, 2, 3))) < 1e-5
 
 
 def test_conv_epilogues_affine_silu_and_bias(dev):
