@@ -1,18 +1,24 @@
-// GEMM-shaped implicit convolution for the big-channel layers (gfx950): K = taps * Cin >= 1024, Cin a multiple of 32 -- VGG's 256..1024-
+// GEMM-shaped implicit convolution for the big-channel layers (gfx950): K = taps * Cin large, Cin a multiple of 32 -- VGG's 256..1024-
 // channel 3x3 layers, ResNet-101's bottleneck 1x1 / 3x3 convs, the atrous ASPP branches, their data gradients.
 //
 //   * 512 threads = 8 waves as 4 (pixels) x 2 (channels); macro tile BM x BN = (4 * MT * 32) x (2 * NT * 32): 256 x 256, 256 x 128,
 //     128 x 256 or 128 x 128; every wave owns MT x NT tiles of v_mfma_f32_32x32x16_f16 (weights as the A operand: a lane ends up with
 //     4 consecutive channels of one pixel);
 //   * BOTH operands stream through one LDS-DMA ring of CHUNK = 32 K-values (2 MFMA K-steps), 4 slots, 2 chunks in flight beyond the
-//     one being computed (counted vmcnt + one raw s_barrier per chunk):
-//       - pixels: the implicit-GEMM gather -- chunk (tap, 32 channels) of pixel p is 64 contiguous bytes of the NHWC view, DMA'd to
-//         LDS unit p * 5 + (0..3): an ODD pixel stride (5 units of 16 B), so the 32 lanes of a fragment read fall on 32 different
-//         16-byte slots (no bank conflict, tools/lds_conflicts.py); the zero page feeds padding and pad units;
+//     one being computed, issued as `buffer_load_dwordx4 ... lds` (tools/micro/buffer_lds_probe.hip: out-of-range lanes deliver zeros,
+//     LDS destinations above 64 KiB work):
+//       - pixels: the implicit-GEMM gather -- chunk (tap, 32 channels) of pixel p is 64 contiguous bytes of the NHWC view.  A lane's
+//         byte offset (pixel, 8-channel group) is computed ONCE; per tap one compare + select turns it into ~0 where the tap falls
+//         outside the image, and the hardware range check writes the zeros; per chunk only the scalar offset moves.  No pad units:
+//         LDS unit (16 B) pixel * 4 + (group ^ ((pixel >> 2) & 3)) -- the swizzle is applied on the global side (which group a lane
+//         fetches), so the 32 lanes of a fragment read fall on 32 different 16-byte slots (tools/lds_conflicts.py);
 //       - weights: pre-packed once per launch into the ring image order ([chunk][K-step][k-half][BN rows][8]: gemm_pack_kernel), so a
 //         chunk is one contiguous block and every DMA piece reads 1 KiB of consecutive bytes;
-//   * fragments of the second K-step of a chunk are requested before the MFMAs of the first (inline-asm ds_read: the compiler's own
-//     waitcnt insertion would put lgkmcnt(0) in front of every MFMA block), two waves per SIMD cover the rest;
+//     every wave issues the same MT + NT / 2 DMA instructions per chunk: counted vmcnt needs no dummy transfers;
+//   * software pipeline over K-steps: the fragments of K-step 1 are requested before the MFMAs of K-step 0, the workgroup barrier
+//     that publishes chunk c + 1 sits BETWEEN the two MFMA blocks of chunk c, and the fragments of (c + 1, K-step 0) are requested
+//     before the MFMAs of (c, K-step 1) -- every ds_read has a full MFMA block (8 x 32 cycles at 2 x 4 tiles) to land.  Inline-asm
+//     ds_read / s_waitcnt: the compiler's own waitcnt insertion would put lgkmcnt(0) in front of every MFMA block;
 //   * blockIdx -> (pixel tile, channel tile) keeps the channel tiles of one pixel tile on one XCD (they share the gathered pixels in
 //     that XCD's L2).
 // Roofline: MFMA (these shapes sit above the 315 FLOP/B ridge).  Algorithmic bytes per launch: engine.hip conv_bytes.
@@ -30,40 +36,36 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 constexpr int GSLOTS = 4;
 constexpr int GW = 8;        // waves
 constexpr int CHUNK = 32;    // K-values per ring chunk
-constexpr int APS = 5;       // LDS units (16 B) per pixel and chunk: 4 data + 1 pad (odd stride)
 
 template <int MT, int NT>
 struct GemmGeom {
+  static_assert(NT % 2 == 0, "channel pieces divide evenly over the 8 waves");
   static constexpr int BM = 4 * MT * 32, BN = 2 * NT * 32;
-  static constexpr int A_UNITS = BM * APS, B_UNITS = BN * 4;
-  static constexpr int A_PIECES = (A_UNITS + 63) / 64, B_PIECES = B_UNITS / 64;
-  static constexpr int A_PER_WAVE = (A_PIECES + GW - 1) / GW, B_PER_WAVE = (B_PIECES + GW - 1) / GW;
-  static constexpr int PER_WAVE = A_PER_WAVE + B_PER_WAVE;  // DMA instructions per wave per chunk
-  static constexpr int SLOT_UNITS = A_PIECES * 64 + B_UNITS;
-  static constexpr int LDS_BYTES = GSLOTS * SLOT_UNITS * 16 + 1024 + 4 * BN * 2 * 4;  // ring | dump | statistics scratch
+  static constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;  // one chunk (32 K-values) of each operand
+  static constexpr int SLOT_BYTES = A_BYTES + B_BYTES;
+  static constexpr int A_PW = MT, B_PW = NT / 2;  // 1-KiB DMA pieces per wave and chunk
+  static constexpr int PW = A_PW + B_PW;
+  static constexpr int RING_BYTES = GSLOTS * SLOT_BYTES + 4 * BN * 2 * 4 + CVX_MAX_TAPS * 8;  // ring | statistics scratch | tap offsets
+  static constexpr int STAGE_BYTES = GW * (MT * 32 * (NT * 64 + 16) + MT * 32 * 8);         // epilogue staging (GemmStage), reuses the ring
+  static constexpr int LDS_BYTES = RING_BYTES > STAGE_BYTES ? RING_BYTES : STAGE_BYTES;
 };
 
+template <int OFF>
 __device__ __forceinline__ h8 lds_frag(unsigned a) {
   h8 v;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
   return v;
 }
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p; }
 __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-// [rows][taps*Cin] fp16 (row pitch src_ld, tap block wtap[t] at wtap[t]*Cin) -> [n-block][chunk][K-step][k-half][BN rows][8]
-struct GemmPackArgs {
-  const half_t* src;
-  half_t* dst;
-  const ConvTap* taps;  // device table: chunk block `tap` reads weight tap taps[tap].wtap
-  int src_ld, rows, Cin, ntaps, BN, nblocks, chunks;
-  unsigned long long* dbg;  // cvx_debug_clock_buffer: range check of the source reads (slot 8..)
-};
-__global__ void gemm_pack_kernel(const GemmPackArgs a) {
+// [rows][taps*Cin] fp16 (row pitch src_ld, tap block wtap[t] at wtap[t]*Cin) -> [n-block][chunk][K-step][k-half][BN rows][8]; one thread per
+// 16-byte unit of the image
+constexpr int PACK_UNITS_PER_BLOCK = 256 * 8;
+__device__ __forceinline__ void gemm_pack_units(const GemmPackJob& a, long long u0, long long u1) {
   const long long per_block = (long long)a.chunks * 4 * a.BN;  // units per n-block
-  const long long total = per_block * a.nblocks;
-  const int cpt = a.Cin / CHUNK;  // chunks per tap
-  for (long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += (long long)gridDim.x * blockDim.x) {
+  const int cpt = a.Cin / CHUNK;                               // chunks per tap
+  for (long long u = u0 + threadIdx.x; u < u1; u += blockDim.x) {
     const int nb = (int)(u / per_block);
     const long long r0 = u - (long long)nb * per_block;
     const int chunk = (int)(r0 / (4 * a.BN));
@@ -72,124 +74,186 @@ __global__ void gemm_pack_kernel(const GemmPackArgs a) {
     const int n = nb * a.BN + row;
     const int tap = chunk / cpt, c0 = (chunk - tap * cpt) * CHUNK + kh * 8;
     h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (n < a.rows) {
-      const long long off = (long long)n * a.src_ld + a.taps[tap].wtap * a.Cin + c0;
-      if (a.dbg && (off < 0 || off + 8 > (long long)a.rows * a.src_ld || tap >= a.ntaps)) {
-        if (atomicAdd(a.dbg + 8, 1ull) == 0) {
-          a.dbg[9] = (unsigned long long)off;
-          a.dbg[10] = (unsigned long long)tap;
-          a.dbg[11] = (unsigned long long)a.taps[tap].wtap;
-          a.dbg[12] = (unsigned long long)u;
-        }
-      } else {
-        v = *reinterpret_cast<const h8*>(a.src + off);
-      }
-    }
+    if (n < a.rows) v = *reinterpret_cast<const h8*>(a.src + (long long)n * a.src_ld + a.taps[tap].wtap * a.Cin + c0);
     *reinterpret_cast<h8*>(a.dst + u * 8) = v;
   }
 }
-
-// tuning / debugging aid (cvx_debug_clock_buffer set): every DMA source address is range-checked against the operand it belongs to; a
-// violation is recorded in the buffer (slot 0: count, 1: kind, 2: offset, 3: chunk, 4: block) and the access goes to the zero page instead
-__device__ __forceinline__ const half_t* dbg_check(const ConvParams& p, const half_t* g, const half_t* base, long long elems, int kind, int chunk) {
-  if (!p.clk || g == p.zeros) return g;
-  const long long off = g - base;
-  if (off >= 0 && off + 8 <= elems) return g;
-  if (atomicAdd(p.clk, 1ull) == 0) {
-    p.clk[1] = (unsigned long long)kind;
-    p.clk[2] = (unsigned long long)off;
-    p.clk[3] = (unsigned long long)chunk;
-    p.clk[4] = (unsigned long long)blockIdx.x;
-    p.clk[5] = (unsigned long long)threadIdx.x;
+__global__ __launch_bounds__(256) void gemm_pack_kernel(const GemmPackJob a) {
+  const long long total = (long long)a.chunks * 4 * a.BN * a.nblocks;
+  const long long u0 = (long long)blockIdx.x * PACK_UNITS_PER_BLOCK;
+  gemm_pack_units(a, u0, u0 + PACK_UNITS_PER_BLOCK < total ? u0 + PACK_UNITS_PER_BLOCK : total);
+}
+// all layers of a forward in one launch: block b belongs to the job whose [blk0, blk0 + nblk) holds it (binary search, jobs sorted by blk0)
+__global__ __launch_bounds__(256) void gemm_pack_jobs_kernel(const GemmPackJob* jobs, int njobs) {
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].blk0 <= (int)blockIdx.x)
+      lo = mid;
+    else
+      hi = mid - 1;
   }
-  return p.zeros;
+  const GemmPackJob a = jobs[lo];
+  const long long total = (long long)a.chunks * 4 * a.BN * a.nblocks;
+  const long long u0 = (long long)((int)blockIdx.x - a.blk0) * PACK_UNITS_PER_BLOCK;
+  if (u0 < total) gemm_pack_units(a, u0, u0 + PACK_UNITS_PER_BLOCK < total ? u0 + PACK_UNITS_PER_BLOCK : total);
 }
 
-// epilogue body of one kind (EPI): lane holds pixel lr of sub-tile i, channels nbase + j*32 + 8 g + 4 lh + (0..3) in acc[i][j][4 g ..]
-template <int MT, int NT, int EPI>
-__device__ __forceinline__ void gemm_store(const ConvParams& p, const f16v (&acc)[MT][NT], const long long (&out_off)[MT], const long long (&res_off)[MT],
-                                           const bool (&pvalid)[MT], int nbase, int lh) {
-  const int act_kind = p.act_kind, res_pre = p.res_pre, accumulate = p.accumulate;
-  const half_t* res = p.res;
-  const bool guard = p.clk != nullptr;
-  const long long out_elems = (long long)p.B * p.out_bstride;
+// Epilogue of the fp32 head outputs (EPI = BIAS_F32): lane holds pixel lr of sub-tile i, channels nbase + j*32 + 8 g + 4 lh + (0..3) in
+// acc[i][j][4 g ..] -- 16-byte stores straight from the accumulators.
+template <int MT, int NT>
+__device__ __forceinline__ void gemm_store_f32(const ConvParams& p, const f16v (&acc)[MT][NT], const long long (&out_off)[MT], const bool (&pvalid)[MT],
+                                               int nbase, int lh) {
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int n0 = nbase + j * 32 + g * 8 + lh * 4;
       if (n0 < p.Cout) {
-        f4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (EPI == CVX_EPI_AFFINE_SILU) {
-          sc = *reinterpret_cast<const f4*>(p.scale + n0);
-          sh = *reinterpret_cast<const f4*>(p.shift + n0);
-        } else if constexpr (EPI == CVX_EPI_BIAS_F32) {
-          sh = *reinterpret_cast<const f4*>(p.bias + n0);
-        }
+        const f4 sh = *reinterpret_cast<const f4*>(p.bias + n0);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
           if (pvalid[i]) {
-            const long long off = out_off[i] + n0;
             f4 v;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][4 * g + r] * sc[r] + sh[r];
-            if constexpr (EPI == CVX_EPI_BIAS_F32) {
-              *reinterpret_cast<f4*>(p.out32 + off) = v;
-            } else {
-              if constexpr (EPI == CVX_EPI_AFFINE_SILU) {
-                f4 rv = {0.f, 0.f, 0.f, 0.f};
-                if (res) {
-                  const h4 rr = *reinterpret_cast<const h4*>(res + res_off[i] + n0);
-#pragma unroll
-                  for (int r = 0; r < 4; ++r) rv[r] = (float)rr[r];
-                }
-                if (res_pre) {
-#pragma unroll
-                  for (int r = 0; r < 4; ++r) v[r] += rv[r];
-                }
-                if (act_kind == 0) {
-#pragma unroll
-                  for (int r = 0; r < 4; ++r) v[r] = cvx_silu(v[r]);
-                } else if (act_kind == 1) {
-#pragma unroll
-                  for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                }
-                if (!res_pre) {
-#pragma unroll
-                  for (int r = 0; r < 4; ++r) v[r] += rv[r];
-                }
-              }
-              const bool bad = guard && (off < 0 || off + 4 > out_elems);
-              if (bad) {
-                if (atomicAdd(p.clk + 16, 1ull) == 0) {
-                  p.clk[17] = (unsigned long long)off;
-                  p.clk[18] = (unsigned long long)blockIdx.x;
-                }
-              } else {
-                half_t* dst = p.out16 + off;
-                if (accumulate) {
-                  const h4 old = *reinterpret_cast<const h4*>(dst);
-#pragma unroll
-                  for (int r = 0; r < 4; ++r) v[r] += (float)old[r];
-                }
-                *reinterpret_cast<h4*>(dst) = h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-              }
-            }
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][4 * g + r] + sh[r];
+            *reinterpret_cast<f4*>(p.out32 + out_off[i] + n0) = v;
           }
         }
       }
     }
 }
 
+// Epilogue of the fp16 outputs (EPI = AFFINE_SILU or PLAIN).  Straight from the accumulators a lane would store 8 bytes at a pixel pitch of
+// Cout * 2 bytes -- 64 different cache lines per instruction, 20 us per 256 x 256 tile (measured, 14 % of the kernel).  Instead every
+// wave transposes its MT*32 x NT*32 sub-tile through its own slice of the (now idle) ring: 8-byte LDS writes in the MFMA layout (row
+// pitch NT*64 + 16 bytes: conflict-free), 16-byte reads along the channel axis, and 16-byte global stores in which the lanes of a pixel
+// cover NT*64 contiguous bytes.  The slice is private to the wave: no barrier between the two halves.
 template <int MT, int NT>
-__global__ __launch_bounds__(64 * GW) void conv_gemm_kernel(const ConvParams p, const half_t* __restrict__ wpk, int m_tiles, int n_tiles, int nchunks) {
+struct GemmStage {
+  static constexpr int RS = NT * 64 + 16;                 // bytes per staged pixel row
+  static constexpr int OFFS = MT * 32 * RS;               // the pixels' output offsets (8 bytes each) follow the rows
+  static constexpr int WAVE_BYTES = OFFS + MT * 32 * 8;
+};
+template <int MT, int NT, int EPI>
+__device__ __forceinline__ void gemm_store_f16(const ConvParams& p, const f16v (&acc)[MT][NT], const long long (&out_off)[MT],
+                                               const long long (&res_off)[MT], const bool (&pvalid)[MT], int nbase, int lane, unsigned char* wreg) {
+  using S = GemmStage<MT, NT>;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int act_kind = p.act_kind, res_pre = p.res_pre, accumulate = p.accumulate;
+  const half_t* res = p.res;
+  if (lh == 0) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) *reinterpret_cast<long long*>(wreg + S::OFFS + (i * 32 + lr) * 8) = pvalid[i] ? out_off[i] : -1;
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int cl = j * 32 + g * 8 + lh * 4;  // channel inside the wave's sub-tile
+      const int n0 = nbase + cl;
+      f4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+      const bool inside = n0 < p.Cout;
+      if constexpr (EPI == CVX_EPI_AFFINE_SILU) {
+        if (inside) {
+          sc = *reinterpret_cast<const f4*>(p.scale + n0);
+          sh = *reinterpret_cast<const f4*>(p.shift + n0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        f4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][4 * g + r] * sc[r] + sh[r];
+        if constexpr (EPI == CVX_EPI_AFFINE_SILU) {
+          f4 rv = {0.f, 0.f, 0.f, 0.f};
+          if (res && inside && pvalid[i]) {
+            const h4 rr = *reinterpret_cast<const h4*>(res + res_off[i] + n0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rv[r] = (float)rr[r];
+          }
+          if (res_pre) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += rv[r];
+          }
+          if (act_kind == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = cvx_silu(v[r]);
+          } else if (act_kind == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+          }
+          if (!res_pre) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += rv[r];
+          }
+        }
+        if (accumulate && inside && pvalid[i]) {  // data gradients that add to what another consumer left there
+          const h4 old = *reinterpret_cast<const h4*>(p.out16 + out_off[i] + n0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)old[r];
+        }
+        *reinterpret_cast<h4*>(wreg + (i * 32 + lr) * S::RS + cl * 2) = h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+      }
+    }
+  // ---- rows back out: COLS lanes (16 bytes each) per pixel ----
+  constexpr int COLS = NT * 4, PPI = 64 / COLS;  // pixels per store instruction
+  const int c16 = lane % COLS, pr = lane / COLS;
+  const int n = nbase + c16 * 8;
+#pragma unroll
+  for (int it = 0; it < MT * 32 / PPI; ++it) {
+    const int r = it * PPI + pr;
+    const long long off = *reinterpret_cast<const long long*>(wreg + S::OFFS + r * 8);
+    const h8 v = *reinterpret_cast<const h8*>(wreg + r * S::RS + c16 * 16);
+    if (off >= 0) {
+      half_t* dst = p.out16 + off + n;
+      if (n + 8 <= p.Cout)
+        *reinterpret_cast<h8*>(dst) = v;
+      else if (n + 4 <= p.Cout)
+        *reinterpret_cast<h4*>(dst) = h4{v[0], v[1], v[2], v[3]};
+    }
+  }
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+// timing experiments of the tuning build (CVX_GEMM_DBG bits 32: no DMA inside the K loop, 64: no MFMA, 128: no barrier; results are WRONG)
+#ifdef CVX_TUNING
+#define CVX_GEMM_DBG_BIT(b) ((p.dbg & (b)) != 0)
+#else
+#define CVX_GEMM_DBG_BIT(b) false
+#endif
+
+// issue cursor of the ring: which (tap, channel block) the next chunk is, and the per-lane gather offsets under that tap
+template <int MT>
+struct GemmCursor {
+  int chunk, tap, cc;      // next chunk to issue; its tap and its 32-channel block inside the tap
+  unsigned vo[MT];         // per lane: byte offset of (pixel + tap, channel group), or ~0 where the tap leaves the image
+};
+
+// the tap table is staged in LDS at kernel start (sTap: dh, dw per tap): a global load inside the K loop would sit in the middle of the
+// counted vmcnt queue of the ring
+template <int MT>
+__device__ __forceinline__ void gemm_enter_tap(GemmCursor<MT>& k, const ConvParams& p, const int* sTap, const int (&a_ih)[MT], const int (&a_iw)[MT],
+                                               const unsigned (&a_off)[MT]) {
+  const int dh = __builtin_amdgcn_readfirstlane(sTap[2 * k.tap]), dw = __builtin_amdgcn_readfirstlane(sTap[2 * k.tap + 1]);
+  const int toff = ((dh * p.IW + dw) * p.in_ld) * 2;  // bytes; negative for the taps above / left of the pixel
+#pragma unroll
+  for (int q = 0; q < MT; ++q) {
+    const bool ok = (unsigned)(a_ih[q] + dh) < (unsigned)p.IH && (unsigned)(a_iw[q] + dw) < (unsigned)p.IW;
+    k.vo[q] = ok ? a_off[q] + (unsigned)toff : 0xffffffffu;  // inside the image the sum is a valid offset into the view
+  }
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(64 * GW) void conv_gemm_kernel(const ConvParams p, const half_t* __restrict__ wpk, int m_tiles, int n_tiles, int nchunks,
+                                                            unsigned a_records) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (and has no __amdgpu_buffer_rsrc_t)
   using G = GemmGeom<MT, NT>;
   constexpr int BM = G::BM, BN = G::BN;
-  constexpr int NWAIT = (GSLOTS - 2) * G::PER_WAVE;
-  static_assert(NWAIT <= 63, "vmcnt field");
+  static_assert(2 * G::PW <= 63, "vmcnt field");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* dump = smem + GSLOTS * G::SLOT_UNITS * 16;
-  float* sStat = reinterpret_cast<float*>(dump + 1024);
+  float* sStat = reinterpret_cast<float*>(smem + GSLOTS * G::SLOT_BYTES);
+  int* sTap = reinterpret_cast<int*>(smem + GSLOTS * G::SLOT_BYTES + 4 * BN * 2 * 4);
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -200,24 +264,28 @@ __global__ __launch_bounds__(64 * GW) void conv_gemm_kernel(const ConvParams p, 
   const int n_tile = seq % n_tiles;
   const int m_tile = (seq / n_tiles) * 8 + xcd;
   if (m_tile >= m_tiles) return;
-  if (p.dbg & 4) return;
+  clk_mark(p, 0);
+  if (tid < p.ntaps) {
+    const ConvTap td = p.taps[tid];
+    sTap[2 * tid] = td.dh;
+    sTap[2 * tid + 1] = td.dw;
+  }
+  __syncthreads();
   const long long M = (long long)p.B * p.OH2 * p.OW2;
   const long long m_base = (long long)m_tile * BM;
   const int cpt = p.Cin / CHUNK;  // chunks per tap
 
-  // ---- per-lane gather assignment: A piece q of this wave covers units piece * 64 + lane -> (pixel, 8-channel group) ----
-  const half_t* a_src[G::A_PER_WAVE];
-  int a_ih[G::A_PER_WAVE], a_iw[G::A_PER_WAVE], a_ch[G::A_PER_WAVE];
+  // ---- per-lane gather assignment: pixel piece q of this wave covers LDS units (q * 8 + wave) * 64 + lane = pixel * 4 + slot ----
+  int a_ih[MT], a_iw[MT];
+  unsigned a_off[MT];
 #pragma unroll
-  for (int q = 0; q < G::A_PER_WAVE; ++q) {
-    const int piece = q * GW + wave;
-    const int u = piece * 64 + lane;
-    const int pix = u / APS;
-    a_ch[q] = u - pix * APS;
-    a_src[q] = nullptr;
-    a_ih[q] = a_iw[q] = 0;
+  for (int q = 0; q < MT; ++q) {
+    const int pix = (q * GW + wave) * 16 + (lane >> 2);
+    const int grp = (lane & 3) ^ ((pix >> 2) & 3);  // the channel group this lane fetches: the read-side swizzle, applied at the source
     const long long m = m_base + pix;
-    if (piece < G::A_PIECES && pix < BM && a_ch[q] < 4 && m < M) {
+    a_ih[q] = a_iw[q] = -(1 << 24);  // rows past the last pixel: no tap is ever inside the image
+    a_off[q] = 0;
+    if (m < M) {
       const unsigned mu = (unsigned)m;
       const unsigned tq = mu / (unsigned)p.OW2;
       const int ow2 = (int)(mu - tq * (unsigned)p.OW2);
@@ -225,37 +293,36 @@ __global__ __launch_bounds__(64 * GW) void conv_gemm_kernel(const ConvParams p, 
       const int oh2 = (int)(tq - (unsigned)b * (unsigned)p.OH2);
       a_ih[q] = oh2 * p.IS;
       a_iw[q] = ow2 * p.IS;
-      a_src[q] = p.in + (long long)b * p.in_bstride + a_ch[q] * 8;
+      a_off[q] = (unsigned)(((long long)b * p.in_bstride + ((long long)a_ih[q] * p.IW + a_iw[q]) * p.in_ld + grp * 8) * 2);
     }
   }
-  const half_t* wblk = wpk + (long long)n_tile * nchunks * (4 * BN * 8);
+  const __amdgpu_buffer_rsrc_t rsrc_a =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.in), (short)0, (int)a_records, 0x00020000);
+  const half_t* wblk = wpk + (long long)n_tile * nchunks * (G::B_BYTES / 2);
+  const __amdgpu_buffer_rsrc_t rsrc_b =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(wblk), (short)0, (int)((long long)nchunks * G::B_BYTES), 0x00020000);
+  const unsigned vb = (unsigned)(lane * 16);
 
-  auto issue = [&](int chunk, int slot) __attribute__((always_inline)) {
-    unsigned char* sb = smem + slot * (G::SLOT_UNITS * 16);
-    if (chunk < nchunks) {
-      const int tap = chunk / cpt, c0 = (chunk - tap * cpt) * CHUNK;
-      const ConvTap td = p.taps[tap];
+  GemmCursor<MT> cur;
+  cur.chunk = 0;
+  cur.tap = 0;
+  cur.cc = 0;
+  gemm_enter_tap<MT>(cur, p, sTap, a_ih, a_iw, a_off);
+  auto issue = [&]() __attribute__((always_inline)) {
+    unsigned char* sb = smem + (cur.chunk & (GSLOTS - 1)) * G::SLOT_BYTES;
+    const unsigned sa = (unsigned)(cur.cc * (CHUNK * 2));
 #pragma unroll
-      for (int q = 0; q < G::A_PER_WAVE; ++q) {
-        const int piece = q * GW + wave;
-        const half_t* g = p.zeros;
-        const int ih = a_ih[q] + td.dh, iw = a_iw[q] + td.dw;
-        if (a_src[q] && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW) g = a_src[q] + ((long long)ih * p.IW + iw) * p.in_ld + c0;
-        g = dbg_check(p, g, p.in, (long long)p.B * p.in_bstride, 1, chunk);
-        unsigned char* dst = piece < G::A_PIECES ? sb + piece * 1024 : dump;
-        __builtin_amdgcn_global_load_lds((gbl_void_ptr)g, (lds_void_ptr)dst, 16, 0, 0);
-      }
-      const half_t* wsrc = wblk + (long long)chunk * (4 * BN * 8) + lane * 8;
+    for (int q = 0; q < G::A_PW; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sb + (q * GW + wave) * 1024), 16, cur.vo[q], sa, 0, 0);
+    const unsigned sw = (unsigned)cur.chunk * (unsigned)G::B_BYTES;
 #pragma unroll
-      for (int q = 0; q < G::B_PER_WAVE; ++q) {
-        const int piece = q * GW + wave;
-        const bool real = piece < G::B_PIECES;
-        const half_t* gw = dbg_check(p, real ? wsrc + piece * 512 : p.zeros, wpk, (long long)n_tiles * nchunks * (4 * BN * 8), 2, chunk);
-        __builtin_amdgcn_global_load_lds((gbl_void_ptr)gw, (lds_void_ptr)(real ? sb + G::A_PIECES * 1024 + piece * 1024 : dump), 16, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < G::PER_WAVE; ++q) __builtin_amdgcn_global_load_lds((gbl_void_ptr)p.zeros, (lds_void_ptr)dump, 16, 0, 0);
+    for (int q = 0; q < G::B_PW; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(sb + G::A_BYTES + (q * GW + wave) * 1024), 16, vb, sw + (q * GW + wave) * 1024, 0, 0);
+    ++cur.chunk;
+    if (++cur.cc == cpt && cur.chunk < nchunks) {
+      cur.cc = 0;
+      ++cur.tap;
+      gemm_enter_tap<MT>(cur, p, sTap, a_ih, a_iw, a_off);
     }
   };
 
@@ -267,46 +334,81 @@ __global__ __launch_bounds__(64 * GW) void conv_gemm_kernel(const ConvParams p, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  clk_mark(p, 1);
+  if (p.clk) wait_vmcnt<0>();  // the stamp is a store: keep it out of the counted queue
 #pragma unroll
-  for (int s = 0; s < GSLOTS - 1; ++s) issue(s, s);
-  if (p.dbg & 8) {
-    wait_vmcnt<0>();
-    return;
-  }
+  for (int s = 0; s < GSLOTS - 1; ++s)
+    if (s < nchunks) issue();
 
-  // fragment addresses inside a slot (bytes): pixel operand (sub-tile i, K-step ks) and weight operand (tile j, K-step ks)
-  const unsigned a_lane = lds_addr(smem) + (unsigned)(((wm * MT * 32 + lr) * APS + lh) * 16);
-  const unsigned b_lane = lds_addr(smem) + (unsigned)(G::A_PIECES * 1024 + ((lh * BN) + wn * NT * 32 + lr) * 16);
-  for (int c = 0; c < nchunks; ++c) {
-    wait_vmcnt<NWAIT>();
-    workgroup_barrier();  // chunk c landed for every wave; the slot of chunk c - 1 is free
-    issue(c + GSLOTS - 1, (c + GSLOTS - 1) % GSLOTS);
-    const unsigned so = (unsigned)((c % GSLOTS) * (G::SLOT_UNITS * 16));
-    h8 xa[2][MT], wb[2][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) xa[0][i] = lds_frag(a_lane + so + i * (32 * APS * 16));
-#pragma unroll
-    for (int j = 0; j < NT; ++j) wb[0][j] = lds_frag(b_lane + so + j * (32 * 16));
-#pragma unroll
-    for (int i = 0; i < MT; ++i) xa[1][i] = lds_frag(a_lane + so + i * (32 * APS * 16) + 2 * 16);
-#pragma unroll
-    for (int j = 0; j < NT; ++j) wb[1][j] = lds_frag(b_lane + so + 2 * BN * 16 + j * (32 * 16));
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT + NT) : "memory");  // the first K-step's fragments (LDS returns in order)
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int i = 0; i < MT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[0][j], xa[0][i], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    wait_lgkm();
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int i = 0; i < MT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[1][j], xa[1][i], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
+  // fragment addresses inside a slot (bytes).  Pixel operand: unit pixel * 4 + (group ^ swizzle), K-step 1 = group + 2 = address ^ 32;
+  // sub-tile i is 32 pixels = 2048 bytes further (the swizzle term (pixel >> 2) & 3 does not change).  Weight operand: [K-step][k-half][BN][8]
+  const unsigned a_rd0 = lds_addr(smem) + (unsigned)((wm * MT * 32 + lr) * 64 + ((lh ^ ((lr >> 2) & 3)) << 4));
+  const unsigned a_rd1 = a_rd0 ^ 32u;
+  const unsigned b_rd = lds_addr(smem) + (unsigned)(G::A_BYTES + (lh * BN + wn * NT * 32 + lr) * 16);
+  h8 xa0[MT], wb0[NT], xa1[MT], wb1[NT];
+#define CVX_GEMM_READ(XA, WB, AR, SO, KS)                                                     \
+  {                                                                                           \
+    const unsigned va_ = (AR) + (SO), vb_ = b_rd + (SO);                                      \
+    if constexpr (MT >= 1) XA[0] = lds_frag<0>(va_);                                          \
+    if constexpr (MT >= 2) XA[1] = lds_frag<2048>(va_);                                       \
+    if constexpr (NT >= 1) WB[0] = lds_frag<(KS) * 2 * BN * 16 + 0 * 512>(vb_);               \
+    if constexpr (NT >= 2) WB[1] = lds_frag<(KS) * 2 * BN * 16 + 1 * 512>(vb_);               \
+    if constexpr (NT >= 3) WB[2] = lds_frag<(KS) * 2 * BN * 16 + 2 * 512>(vb_);               \
+    if constexpr (NT >= 4) WB[3] = lds_frag<(KS) * 2 * BN * 16 + 3 * 512>(vb_);               \
   }
-  wait_vmcnt<0>();  // surplus prefetches (dump pieces) retire before the epilogue's own loads share the counter
+#define CVX_GEMM_MFMA(XA, WB)                                                                 \
+  {                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    if (!CVX_GEMM_DBG_BIT(64))                                                                \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) _Pragma("unroll") for (int i = 0; i < MT; ++i) acc[i][j] =                       \
+        __builtin_amdgcn_mfma_f32_32x32x16_f16(WB[j], XA[i], acc[i][j], 0, 0, 0);             \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+  }
+  static_assert(MT <= 2 && NT <= 4, "fragment macros");
+  // Loop invariant at the top of iteration c: the fragments of BOTH K-steps of chunk c are in registers (or on their way), chunk c + 1
+  // has landed for this wave.  The barrier then publishes chunk c + 1 and retires chunk c - 1, and the first thing behind it is an MFMA
+  // block whose operands are already there: MFMA issue blocks the wave and the pipe holds no queue, so cycles in which all eight waves
+  // sit between a barrier and their next MFMA are lost outright (measured: 1.43x the MFMA time with the barrier in mid-chunk).
+  if (nchunks >= 3)
+    wait_vmcnt<2 * G::PW>();
+  else if (nchunks == 2)
+    wait_vmcnt<G::PW>();
+  else
+    wait_vmcnt<0>();
+  workgroup_barrier();  // chunk 0 published
+  if (p.clk) {  // tuning runs only: the stamp's store would sit in the counted vmcnt queue, so the ring is drained once here
+    clk_mark(p, 2);
+    wait_vmcnt<0>();
+    workgroup_barrier();
+  }
+  CVX_GEMM_READ(xa0, wb0, a_rd0, 0u, 0);
+  CVX_GEMM_READ(xa1, wb1, a_rd1, 0u, 1);
+  if (nchunks >= 3)
+    wait_vmcnt<G::PW>();
+  else
+    wait_vmcnt<0>();
+  for (int c = 0; c + 1 < nchunks; ++c) {
+    if (!CVX_GEMM_DBG_BIT(128)) workgroup_barrier();  // chunk c + 1 published; every wave is done reading chunk c - 1: its slot takes chunk c + 3
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT + NT) : "memory");  // K-step 0 of chunk c (LDS returns in order)
+    CVX_GEMM_MFMA(xa0, wb0);
+    if (cur.chunk < nchunks && !CVX_GEMM_DBG_BIT(32)) issue();
+    const unsigned sn = (unsigned)(((c + 1) & (GSLOTS - 1)) * G::SLOT_BYTES);
+    CVX_GEMM_READ(xa0, wb0, a_rd0, sn, 0);
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT + NT) : "memory");  // K-step 1 of chunk c
+    CVX_GEMM_MFMA(xa1, wb1);
+    CVX_GEMM_READ(xa1, wb1, a_rd1, sn, 1);
+    if (c + 3 < nchunks)
+      wait_vmcnt<G::PW>();  // chunk c + 2 landed (chunk c + 3 may be in flight)
+    else
+      wait_vmcnt<0>();
+  }
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT + NT) : "memory");  // the last chunk
+  CVX_GEMM_MFMA(xa0, wb0);
+  wait_lgkm();
+  CVX_GEMM_MFMA(xa1, wb1);
+#undef CVX_GEMM_READ
+#undef CVX_GEMM_MFMA
+  clk_mark(p, 3);
   if (p.dbg & 16) return;
 
   // ---- epilogue: lane holds pixel lr of sub-tile i, channels n_tile*BN + (wn*NT + j)*32 + 8 g + 4 lh + (0..3) in acc[i][j][4 g ..] ----
@@ -373,11 +475,18 @@ __global__ __launch_bounds__(64 * GW) void conv_gemm_kernel(const ConvParams p, 
   }
   // one straight-line body per epilogue kind: with the kinds tested inside the (j, g, i) loops hipcc 7.2 structurised the control flow
   // into a path that left the channel offset of the PLAIN store undefined (a stale pointer was used: the faults of the first bring-up)
-  switch (p.epi) {
-    case CVX_EPI_AFFINE_SILU: gemm_store<MT, NT, CVX_EPI_AFFINE_SILU>(p, acc, out_off, res_off, pvalid, nbase, lh); break;
-    case CVX_EPI_BIAS_F32: gemm_store<MT, NT, CVX_EPI_BIAS_F32>(p, acc, out_off, res_off, pvalid, nbase, lh); break;
-    default: gemm_store<MT, NT, CVX_EPI_PLAIN>(p, acc, out_off, res_off, pvalid, nbase, lh); break;
+  if (p.epi == CVX_EPI_BIAS_F32) {
+    gemm_store_f32<MT, NT>(p, acc, out_off, pvalid, nbase, lh);
+  } else {
+    __syncthreads();  // every wave is done with the ring: its space stages the output tile
+    unsigned char* wreg = smem + wave * GemmStage<MT, NT>::WAVE_BYTES;
+    if (p.epi == CVX_EPI_AFFINE_SILU)
+      gemm_store_f16<MT, NT, CVX_EPI_AFFINE_SILU>(p, acc, out_off, res_off, pvalid, nbase, lane, wreg);
+    else
+      gemm_store_f16<MT, NT, CVX_EPI_PLAIN>(p, acc, out_off, res_off, pvalid, nbase, lane, wreg);
   }
+  clk_mark(p, 4);
+#endif
 }
 
 // packed weights of a (weight pointer, tap table) pair: re-packed at EVERY launch (the fp16 shadows change with every optimiser step),
@@ -394,37 +503,43 @@ int launch_gemm(const ConvParams& p, hipStream_t stream) {
   const long long M = (long long)p.B * p.OH2 * p.OW2;
   const int m_tiles = (int)((M + G::BM - 1) / G::BM), n_tiles = (p.Cout + G::BN - 1) / G::BN;
   const int nchunks = p.ntaps * (p.Cin / CHUNK);
-  // ---- weights -> ring image order ----
-  PackSlot& ps = g_pack[{p.wt, {p.taps, G::BN}}];
-  const size_t need = (size_t)n_tiles * nchunks * 4 * G::BN * 16;
-  if (ps.bytes < need) {
-    if (ps.buf) CVX_HIP(hipFree(ps.buf));
-    CVX_HIP(hipMalloc((void**)&ps.buf, need));
-    ps.bytes = need;
+  // ---- weights -> ring image order: done for all layers at once by the engine (wt_packed), or here for a stand-alone launch ----
+  static const int dbg = cvx_tune_int("CVX_GEMM_DBG", 0);  // tuning build: 1 no pack, 2 no main kernel, 16 main kernel stops after the K loop, 32.. see CVX_GEMM_DBG_BIT
+  const half_t* packed = p.wt_packed_bn == G::BN ? p.wt_packed : nullptr;
+  if (!packed) {
+    PackSlot& ps = g_pack[{p.wt, {p.taps, G::BN}}];
+    const size_t need = (size_t)n_tiles * nchunks * G::B_BYTES;
+    if (ps.bytes < need) {
+      if (ps.buf) CVX_HIP(hipFree(ps.buf));
+      CVX_HIP(hipMalloc((void**)&ps.buf, need));
+      ps.bytes = need;
+    }
+    GemmPackJob a;
+    memset(&a, 0, sizeof(a));
+    a.src = p.wt;
+    a.dst = ps.buf;
+    a.src_ld = p.wt_ld;
+    a.rows = p.Cout;
+    a.Cin = p.Cin;
+    a.ntaps = p.ntaps;
+    a.BN = G::BN;
+    a.nblocks = n_tiles;
+    a.chunks = nchunks;
+    a.taps = p.taps;
+    const long long units = (long long)n_tiles * nchunks * 4 * G::BN;
+    if (!(dbg & 1)) hipLaunchKernelGGL(gemm_pack_kernel, dim3((unsigned)((units + PACK_UNITS_PER_BLOCK - 1) / PACK_UNITS_PER_BLOCK)), dim3(256), 0, stream, a);
+    packed = ps.buf;
   }
-  GemmPackArgs a;
-  memset(&a, 0, sizeof(a));
-  a.src = p.wt;
-  a.dst = ps.buf;
-  a.src_ld = p.wt_ld;
-  a.rows = p.Cout;
-  a.Cin = p.Cin;
-  a.ntaps = p.ntaps;
-  a.BN = G::BN;
-  a.nblocks = n_tiles;
-  a.chunks = nchunks;
-  a.taps = p.taps;
-  a.dbg = p.clk;
-  const long long units = (long long)n_tiles * nchunks * 4 * G::BN;
-  static const int dbg = cvx_tune_int("CVX_GEMM_DBG", 0);  // tuning build: 1 no pack, 2 no main kernel, 4 / 8 / 16 main kernel stops after entry / prologue / K loop
-  if (!(dbg & 1)) hipLaunchKernelGGL(gemm_pack_kernel, dim3((unsigned)std::min<long long>(1024, (units + 255) / 256)), dim3(256), 0, stream, a);
   if (dbg & 2) return 0;
   ConvParams pd = p;
   pd.dbg = dbg;
+  pd.clk = g_cvx_clk;
   static unsigned long long optin_mask = 0;
   CVX_TRY(cvx_lds_optin((const void*)conv_gemm_kernel<MT, NT>, G::LDS_BYTES, &optin_mask));
   const int grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
-  hipLaunchKernelGGL((conv_gemm_kernel<MT, NT>), dim3(grid), dim3(64 * GW), G::LDS_BYTES, stream, pd, (const half_t*)ps.buf, m_tiles, n_tiles, nchunks);
+  const unsigned a_records = (unsigned)std::min<long long>((long long)p.B * p.in_bstride * 2, 0xffffffffLL);
+  hipLaunchKernelGGL((conv_gemm_kernel<MT, NT>), dim3(grid), dim3(64 * GW), G::LDS_BYTES, stream, pd, packed, m_tiles, n_tiles, nchunks,
+                     a_records);
   return 0;
 }
 
@@ -432,7 +547,9 @@ int launch_gemm(const ConvParams& p, hipStream_t stream) {
 
 bool cvx_conv_gemm_shape_ok(const ConvParams& p) {
   const long long M = (long long)p.B * p.OH2 * p.OW2;
-  return p.zeros && p.nphase <= 1 && p.Cin % CHUNK == 0 && p.ntaps <= CVX_MAX_TAPS && p.Cout % 4 == 0 && M < (1LL << 31);
+  // buffer_load offsets are 32-bit: the gathered view and one channel tile's packed weights stay below 4 GiB / 2 GiB
+  return p.nphase <= 1 && p.Cin % CHUNK == 0 && p.ntaps <= CVX_MAX_TAPS && p.Cout % 4 == 0 && M < (1LL << 31) &&
+         (long long)p.B * p.in_bstride * 2 < (1LL << 32) && (long long)p.ntaps * p.Cin * 256 * 2 < (1LL << 31);
 }
 
 bool cvx_conv_gemm_supported(const ConvParams& p) {
@@ -440,24 +557,77 @@ bool cvx_conv_gemm_supported(const ConvParams& p) {
   if (off || !cvx_conv_gemm_shape_ok(p)) return false;
   const long long M = (long long)p.B * p.OH2 * p.OW2;
   const long long K = (long long)p.ntaps * p.Cin;
-  // measured against the LDS-DMA ring kernel (tools/gemm_probe.py, profiles/r03_gemm_probe.txt): ahead where both dimensions of the
-  // weight matrix are large and the pixel count fills two rounds of 256 x 256 tiles; the tuning build lowers the gates for A/B runs
-  static const int kmin = cvx_tune_int("CVX_GEMM_KMIN", 4608);
-  static const int mmin = cvx_tune_int("CVX_GEMM_MMIN", 32768);
-  return K >= kmin && p.Cout >= 256 && M >= mmin;
+  // measured against the pointwise / halo / LDS-DMA ring kernels (tools/gemm_probe.py + tools/gemm_trace.py, profiles/r03_gemm_*): ahead
+  // on every shape from 128 channels up (1.5 - 2x at 256+); the tuning build moves the gates for A/B runs of whole models
+  static const int kmin = cvx_tune_int("CVX_GEMM_KMIN", 256);
+  static const int mmin = cvx_tune_int("CVX_GEMM_MMIN", 2048);
+  static const int cmin = cvx_tune_int("CVX_GEMM_CMIN", 128);
+  static const int gfmin = cvx_tune_int("CVX_GEMM_GFMIN", 6);  // GFLOP per launch: below, the 20..30-us layers of YOLOv8-n stay where they were (6.79 vs 6.96 ms/step)
+  return K >= kmin && p.Cout >= cmin && M >= mmin && 2.0 * (double)M * (double)K * p.Cout >= gfmin * 1e9;
+}
+
+// Macro tile by a cost model calibrated on the phase stamps of tools/gemm_debug.py (MI355X, clock as held under this load): time of one
+// workgroup = chunks * (us per 32-deep chunk with the CU saturated by this tile) + prologue / epilogue, times the number of rounds
+// the grid needs on 256 CUs.  The model reproduces the measured launches within 10 % (GEMM-shaped kernel).
+static int gemm_pick_tile(long long M, int Cout, int nchunks, double* est_us) {
+  struct Cfg {
+    int bm, bn, per_cu;
+    double chunk_us, fixed_us;
+  };
+  static const Cfg cfg[4] = {{256, 256, 1, 0.80, 12.0}, {256, 128, 1, 0.50, 7.0}, {128, 256, 1, 0.52, 7.6}, {128, 128, 2, 0.56, 6.0}};
+  int best = 3;
+  double best_t = 1e30;
+  for (int i = 0; i < 4; ++i) {
+    if (cfg[i].bn > 128 && Cout <= 128) continue;  // half of every channel tile would be padding
+    const long long wgs = ((M + cfg[i].bm - 1) / cfg[i].bm) * ((Cout + cfg[i].bn - 1) / cfg[i].bn);
+    const long long rounds = (wgs + 256 * cfg[i].per_cu - 1) / (256 * cfg[i].per_cu);
+    // a last round that fills under half of the slots of a two-per-CU tile runs its workgroups alone on their CUs: ~0.6 of the pair time
+    double t = (double)rounds * (nchunks * cfg[i].chunk_us + cfg[i].fixed_us);
+    if (cfg[i].per_cu == 2 && (wgs - (rounds - 1) * 512) <= 256) t -= 0.4 * (nchunks * cfg[i].chunk_us + cfg[i].fixed_us);
+    if (t < best_t) {
+      best_t = t;
+      best = i;
+    }
+  }
+  if (est_us) *est_us = best_t;
+  return best + 1;
+}
+
+static int gemm_tile_for(const ConvParams& p) {
+  static const int force = cvx_tune_int("CVX_GEMM_TILE", 0);  // 1: 256x256, 2: 256x128, 3: 128x256, 4: 128x128
+  if (force) return force;
+  return gemm_pick_tile((long long)p.B * p.OH2 * p.OW2, p.Cout, p.ntaps * (p.Cin / CHUNK), nullptr);
+}
+
+bool cvx_conv_gemm_plan(const ConvParams& p, GemmPackJob* job, size_t* bytes) {
+  if (p.nphase > 1 || !cvx_conv_gemm_supported(p)) return false;
+  const int pick = gemm_tile_for(p);
+  const int BN = (pick == 1 || pick == 3) ? 256 : 128;
+  memset(job, 0, sizeof(*job));
+  job->src = p.wt;
+  job->taps = p.taps;
+  job->src_ld = p.wt_ld;
+  job->rows = p.Cout;
+  job->Cin = p.Cin;
+  job->ntaps = p.ntaps;
+  job->BN = BN;
+  job->nblocks = (p.Cout + BN - 1) / BN;
+  job->chunks = p.ntaps * (p.Cin / CHUNK);
+  const long long units = (long long)job->nblocks * job->chunks * 4 * BN;
+  job->nblk = (int)((units + PACK_UNITS_PER_BLOCK - 1) / PACK_UNITS_PER_BLOCK);
+  *bytes = (size_t)units * 16;
+  return true;
+}
+
+int cvx_conv_gemm_pack_jobs(const GemmPackJob* d_jobs, int njobs, int nblocks, hipStream_t stream) {
+  if (njobs <= 0 || nblocks <= 0) return 0;
+  hipLaunchKernelGGL(gemm_pack_jobs_kernel, dim3(nblocks), dim3(256), 0, stream, d_jobs, njobs);
+  CVX_HIP(hipGetLastError());
+  return 0;
 }
 
 int cvx_conv_gemm_launch(const ConvParams& p, hipStream_t stream) {
-  const long long M = (long long)p.B * p.OH2 * p.OW2;
-  // macro tile: the largest whose grid still gives every CU a workgroup (256 of them)
-  static const int force = cvx_tune_int("CVX_GEMM_TILE", 0);  // 1: 256x256, 2: 256x128, 3: 128x256, 4: 128x128
-  auto wgs = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn); };
-  int pick = 4;
-  if (p.Cout >= 256 && wgs(256, 256) >= 256) pick = 1;
-  else if (wgs(256, 128) >= 256) pick = 2;
-  else if (p.Cout >= 256 && wgs(128, 256) >= 256) pick = 3;
-  if (force) pick = force;
-  switch (pick) {
+  switch (gemm_tile_for(p)) {
     case 1: CVX_TRY((launch_gemm<2, 4>(p, stream))); break;
     case 2: CVX_TRY((launch_gemm<2, 2>(p, stream))); break;
     case 3: CVX_TRY((launch_gemm<1, 4>(p, stream))); break;

@@ -68,6 +68,10 @@ struct ConvParams {
   } phase[4];
   int pointwise;       // 1 when the table is the single tap (0, 0, weight tap 0): a 1x1 convolution (conv_pw.hip)
   unsigned long long halo_pos, halo_wt;  // cvx_halo_pack_taps of the table (valid when halo_taps_ok): 4 bits per tap
+  // GEMM-shaped kernel: the weights already in its ring image order for channel tiles of wt_packed_bn rows (cvx_conv_gemm_pack_jobs, once
+  // per forward for all layers); null: the launch packs them itself
+  const half_t* wt_packed;
+  int wt_packed_bn;
 };
 
 // Packs a 9-entry tap table whose offsets all lie in the 3x3 neighbourhood into two 64-bit words, 4 bits per tap:
@@ -97,6 +101,17 @@ int cvx_conv_igemm_dma_launch(const ConvParams& p, hipStream_t stream);
 bool cvx_conv_halo_supported(const ConvParams& p);
 int cvx_conv_halo_launch(const ConvParams& p, hipStream_t stream);
 // GEMM-shaped kernel for the big-channel layers (conv_gemm.hip)
+// one layer's weights -> ring image order ([channel tile][chunk][K-step][k-half][BN rows][8]); blocks [blk0, blk0 + nblk) of the batched launch
+struct GemmPackJob {
+  const half_t* src;
+  half_t* dst;
+  const ConvTap* taps;  // device table: chunk block `tap` reads weight tap taps[tap].wtap
+  int src_ld, rows, Cin, ntaps, BN, nblocks, chunks;
+  int blk0, nblk;
+};
+// Fills `job` (all but dst, blk0) and the bytes of its image when the dispatcher will take this launch to the GEMM-shaped kernel
+bool cvx_conv_gemm_plan(const ConvParams& p, GemmPackJob* job, size_t* bytes);
+int cvx_conv_gemm_pack_jobs(const GemmPackJob* d_jobs, int njobs, int nblocks, hipStream_t stream);
 bool cvx_conv_gemm_shape_ok(const ConvParams& p);   // what the kernel can run at all
 bool cvx_conv_gemm_supported(const ConvParams& p);  // ... and where the dispatcher prefers it
 int cvx_conv_gemm_launch(const ConvParams& p, hipStream_t stream);

@@ -35,6 +35,8 @@ struct DgClass {
   int pointwise = 0;
   unsigned long long halo_pos = 0, halo_wt = 0;
   int ntaps = 0, oph = 0, opw = 0, OH2 = 0, OW2 = 0;
+  const half_t* gemm_pk = nullptr;  // data-gradient weights in the GEMM-shaped kernel's ring image order (per batch plan), channel tiles of gemm_bn rows
+  int gemm_bn = 0;
 };
 
 struct ConvRt {
@@ -62,6 +64,8 @@ struct ConvRt {
   hipEvent_t ev_dy = nullptr;
   long long slab_off = 0;
   int nsplit = 1;
+  const half_t* gemm_fwd = nullptr;  // forward weights in the GEMM-shaped kernel's ring image order (per batch plan)
+  int gemm_fwd_bn = 0;
 };
 
 struct PoolRt {
@@ -163,6 +167,10 @@ struct cvx_engine {
   ChainPackJob* d_chain_jobs = nullptr;   // weight pre-pack jobs of all groups (one launch per forward)
   int n_chain_jobs = 0, chain_max_units = 0;
   bool chain_fusion = true;
+  // GEMM-shaped conv kernel: every routed layer's weights are re-ordered by ONE launch per forward, next to cvx_pack_weights
+  half_t* gemm_arena = nullptr;
+  GemmPackJob* d_gemm_jobs = nullptr;
+  int n_gemm_jobs = 0, n_gemm_fwd_jobs = 0, gemm_blocks = 0, gemm_fwd_blocks = 0;
   struct cvx_bw_state* bw = nullptr;  // backward-pass state (whole-pass and segmented entry points)
   std::vector<ProfRec> prof_recs;
 };
@@ -568,6 +576,9 @@ int plan_fused_groups(cvx_engine* e, int B) {
   return 0;
 }
 
+int plan_gemm_packs(cvx_engine* e, int B, bool training);
+void free_gemm_packs(cvx_engine* e);
+
 int plan_batch(cvx_engine* e, int B, bool training) {
   if (e->planned_batch == B && (e->planned_train || !training)) return 0;
   CVX_HIP(hipStreamSynchronize(e->stream));
@@ -575,6 +586,7 @@ int plan_batch(cvx_engine* e, int B, bool training) {
   if (e->lane) CVX_HIP(hipStreamSynchronize(e->lane));
   free_pool(e->batch_allocs);
   free_fused(e);
+  free_gemm_packs(e);
   e->batch_bytes = 0;
   e->planned_batch = 0;
   e->plan_generation++;  // every per-batch buffer moves: a hipGraph captured against the old plan must be dropped
@@ -783,6 +795,7 @@ int plan_batch(cvx_engine* e, int B, bool training) {
   e->planned_train = training;
   // the fused groups hold pointers into this plan's buffers; a training plan serves eval forwards too
   CVX_TRY(plan_fused_groups(e, B));
+  CVX_TRY(plan_gemm_packs(e, B, training));
   return 0;
 }
 
@@ -813,6 +826,112 @@ void fill_conv_fwd(const cvx_engine* e, int i, int B, ConvParams* cp) {
   cp->pointwise = c.pointwise;
   cp->halo_pos = c.halo_pos;
   cp->halo_wt = c.halo_wt;
+  cp->wt_packed = c.gemm_fwd;
+  cp->wt_packed_bn = c.gemm_fwd_bn;
+}
+
+void free_gemm_packs(cvx_engine* e) {
+  if (e->gemm_arena) (void)hipFree(e->gemm_arena);
+  if (e->d_gemm_jobs) (void)hipFree(e->d_gemm_jobs);
+  e->gemm_arena = nullptr;
+  e->d_gemm_jobs = nullptr;
+  e->n_gemm_jobs = e->n_gemm_fwd_jobs = e->gemm_blocks = e->gemm_fwd_blocks = 0;
+  for (auto& c : e->conv) {
+    c.gemm_fwd = nullptr;
+    c.gemm_fwd_bn = 0;
+    for (auto& d : c.dg) {
+      d.gemm_pk = nullptr;
+      d.gemm_bn = 0;
+    }
+  }
+}
+
+// the launch geometry of one phase class of a data gradient, as far as the dispatcher's choice of kernel depends on it
+void fill_conv_dgrad_shape(const cvx_engine* e, int i, int q, int B, ConvParams* cp) {
+  const cvx_op_desc& o = e->ops[i];
+  const ConvRt& c = e->conv[i];
+  const DgClass& dc = c.dg[q];
+  const int C = o.out.c;
+  memset(cp, 0, sizeof(*cp));
+  cp->in_ld = C;
+  cp->in_bstride = (long long)o.oh * o.ow * C;  // dy of a BN layer is dense; a head's dpred slice is wider (the launch re-checks its own view)
+  cp->IH = o.oh;
+  cp->IW = o.ow;
+  cp->Cin = C;
+  cp->wt = e->shadow + c.sh_dg;
+  cp->wt_ld = c.ntaps * C;
+  cp->Cout = o.in.c;
+  cp->B = B;
+  cp->OH2 = dc.OH2;
+  cp->OW2 = dc.OW2;
+  cp->IS = 1;
+  cp->OS = o.stride;
+  cp->ntaps = dc.ntaps;
+  cp->taps = dc.taps;
+  cp->zeros = e->zero_page;
+}
+
+// Every conv launch the dispatcher will give to the GEMM-shaped kernel (conv_gemm.hip) gets its weights in ring image order from one
+// batched launch per forward instead of a 4..8-us launch of its own in front of every convolution.
+int plan_gemm_packs(cvx_engine* e, int B, bool training) {
+  free_gemm_packs(e);
+  struct Ref {
+    int op, q;  // q < 0: forward
+  };
+  std::vector<GemmPackJob> jobs;
+  std::vector<Ref> refs;
+  std::vector<size_t> offs;
+  size_t total = 0;
+  int blocks = 0;
+  auto add = [&](const ConvParams& cp, int op, int q) {
+    GemmPackJob j;
+    size_t bytes = 0;
+    if (!cvx_conv_gemm_plan(cp, &j, &bytes)) return;
+    j.blk0 = blocks;
+    blocks += j.nblk;
+    offs.push_back(total);
+    total += (bytes + 255) / 256 * 256;
+    jobs.push_back(j);
+    refs.push_back(Ref{op, q});
+  };
+  for (size_t i = 0; i < e->ops.size(); ++i) {
+    if (e->ops[i].type != CVX_OP_CONV || e->conv[i].stem) continue;
+    ConvParams cp;
+    fill_conv_fwd(e, (int)i, B, &cp);
+    add(cp, (int)i, -1);
+  }
+  const int n_fwd = (int)jobs.size(), fwd_blocks = blocks;
+  if (training) {
+    for (size_t i = 0; i < e->ops.size(); ++i) {
+      const cvx_op_desc& o = e->ops[i];
+      const ConvRt& c = e->conv[i];
+      if (o.type != CVX_OP_CONV || c.stem || !o.needs_dgrad || c.sh_dg < 0 || c.ndg != 1) continue;  // strided data gradients go out as merged phases
+      if (c.dg[0].OH2 <= 0 || c.dg[0].OW2 <= 0 || c.dg[0].ntaps <= 0) continue;
+      ConvParams cp;
+      fill_conv_dgrad_shape(e, (int)i, 0, B, &cp);
+      add(cp, (int)i, 0);
+    }
+  }
+  if (jobs.empty()) return 0;
+  CVX_HIP(hipMalloc((void**)&e->gemm_arena, total));
+  for (size_t k = 0; k < jobs.size(); ++k) {
+    jobs[k].dst = reinterpret_cast<half_t*>(reinterpret_cast<char*>(e->gemm_arena) + offs[k]);
+    ConvRt& c = e->conv[refs[k].op];
+    if (refs[k].q < 0) {
+      c.gemm_fwd = jobs[k].dst;
+      c.gemm_fwd_bn = jobs[k].BN;
+    } else {
+      c.dg[refs[k].q].gemm_pk = jobs[k].dst;
+      c.dg[refs[k].q].gemm_bn = jobs[k].BN;
+    }
+  }
+  CVX_HIP(hipMalloc((void**)&e->d_gemm_jobs, jobs.size() * sizeof(GemmPackJob)));
+  CVX_HIP(hipMemcpy(e->d_gemm_jobs, jobs.data(), jobs.size() * sizeof(GemmPackJob), hipMemcpyHostToDevice));
+  e->n_gemm_jobs = (int)jobs.size();
+  e->n_gemm_fwd_jobs = n_fwd;
+  e->gemm_blocks = blocks;
+  e->gemm_fwd_blocks = fwd_blocks;
+  return 0;
 }
 
 }  // namespace
@@ -928,6 +1047,10 @@ extern "C" int cvx_engine_destroy(cvx_engine* e) {
     if (ev) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   free_fused(e);
+  {
+    if (e->gemm_arena) (void)hipFree(e->gemm_arena);
+    if (e->d_gemm_jobs) (void)hipFree(e->d_gemm_jobs);
+  }
   free_pool(e->batch_allocs);
   free_pool(e->static_allocs);
   cvx_engine_free_bw(e);
@@ -1042,6 +1165,10 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
     ProfScope ps(e, PROF_MISC, 0, 6.0 * e->n_params, prep);
     CVX_TRY(cvx_pack_weights(e->params, e->shadow, e->d_pack, e->d_pack_blocks, e->n_pack_blocks, prep));
     if (!training && e->n_chain_jobs > 0) CVX_TRY(cvx_chain_pack_jobs(e->d_chain_jobs, e->n_chain_jobs, e->chain_max_units, prep));
+    if (training)
+      CVX_TRY(cvx_conv_gemm_pack_jobs(e->d_gemm_jobs, e->n_gemm_jobs, e->gemm_blocks, prep));
+    else
+      CVX_TRY(cvx_conv_gemm_pack_jobs(e->d_gemm_jobs, e->n_gemm_fwd_jobs, e->gemm_fwd_blocks, prep));
   }
   e->last_images = training ? images : nullptr;
   if (training) e->train_pass++;  // dropout masks: one per (seed, training forward, op)
@@ -1484,6 +1611,8 @@ int backward_op(cvx_engine* e, int i) {
         cp.halo_pos = dc.halo_pos;
         cp.halo_wt = dc.halo_wt;
         cp.accumulate = c.in_accum;
+        cp.wt_packed = dc.gemm_pk;
+        cp.wt_packed_bn = dc.gemm_bn;
         cp.out16 = gin.p;
         cp.out_ld = gin.ld;
         cp.out_bstride = gin.bstride;

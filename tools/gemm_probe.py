@@ -20,6 +20,9 @@ SHAPES = [  # (B, H, W, Cin, Cout, k, stride, what)
 ]
 
 
+MODE = 0x101 if os.environ.get("GEMM_PROBE_FORCE") else 1  # GEMM_PROBE_FORCE=1: the GEMM-shaped kernel on every shape
+
+
 def main():
     lib = L.load()
     dev = torch.device("cuda", 0)
@@ -32,7 +35,7 @@ def main():
         sc, sh = torch.ones(Co, device=dev), torch.zeros(Co, device=dev)
 
         def run():
-            L.check(lib.cvx_conv2d_nhwc(L.ptr(x), B, H, W, Ci, L.ptr(w), Co, k, s, k // 2, 1, 1, L.ptr(sc), L.ptr(sh), L.ptr(out), L.stream_ptr(dev)), "conv")
+            L.check(lib.cvx_conv2d_nhwc(L.ptr(x), B, H, W, Ci, L.ptr(w), Co, k, s, k // 2, 1, MODE, L.ptr(sc), L.ptr(sh), L.ptr(out), L.stream_ptr(dev)), "conv")
         for _ in range(3):
             run()
         torch.cuda.synchronize()
