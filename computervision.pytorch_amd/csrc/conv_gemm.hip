@@ -64,7 +64,7 @@ __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(0)
 constexpr int PACK_UNITS_PER_BLOCK = 256 * 8;
 __device__ __forceinline__ void gemm_pack_units(const GemmPackJob& a, long long u0, long long u1) {
   const long long per_block = (long long)a.chunks * 4 * a.BN;  // units per n-block
-  const int cpt = a.Cin / CHUNK;                               // chunks per tap
+  const int cpt = (a.Cin + CHUNK - 1) / CHUNK;                 // chunks per tap; the last one is zero-padded when Cin % 32 != 0
   for (long long u = u0 + threadIdx.x; u < u1; u += blockDim.x) {
     const int nb = (int)(u / per_block);
     const long long r0 = u - (long long)nb * per_block;
@@ -74,7 +74,7 @@ __device__ __forceinline__ void gemm_pack_units(const GemmPackJob& a, long long 
     const int n = nb * a.BN + row;
     const int tap = chunk / cpt, c0 = (chunk - tap * cpt) * CHUNK + kh * 8;
     h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (n < a.rows) v = *reinterpret_cast<const h8*>(a.src + (long long)n * a.src_ld + a.taps[tap].wtap * a.Cin + c0);
+    if (n < a.rows && c0 < a.Cin) v = *reinterpret_cast<const h8*>(a.src + (long long)n * a.src_ld + a.taps[tap].wtap * a.Cin + c0);
     *reinterpret_cast<h8*>(a.dst + u * 8) = v;
   }
 }
@@ -135,6 +135,60 @@ struct GemmStage {
   static constexpr int OFFS = MT * 32 * RS;               // the pixels' output offsets (8 bytes each) follow the rows
   static constexpr int WAVE_BYTES = OFFS + MT * 32 * 8;
 };
+// Sum over the 32 lanes of each half of the wave, valid in lanes 16..31 / 48..63: five DPP adds (quad swaps, half-row and row mirrors, the
+// row broadcast) instead of five ds_bpermute round trips -- 640 of those per wave made the statistics the longest part of the epilogue.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+  return v + __builtin_bit_cast(float, t);
+}
+__device__ __forceinline__ float half_wave_sum(float v) {
+  v = dpp_add<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]: every lane holds its quad's sum
+  v = dpp_add<0x141, 0xf>(v);  // row_half_mirror: the other quad of the half row
+  v = dpp_add<0x140, 0xf>(v);  // row_mirror: the other half of the 16-lane row
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3: lanes 16..31 / 48..63 now hold the sum of their 32 lanes
+  return v;
+}
+
+// The training epilogue's raw fp32 rows, staged like the fp16 outputs (a lane would otherwise store 16 bytes at a pixel pitch of Cout * 4
+// bytes): two passes of NT / 2 channel tiles each, so that a pass of the wave's sub-tile has the footprint of the fp16 staging.
+template <int MT, int NT>
+__device__ __forceinline__ void gemm_store_raw(const ConvParams& p, const f16v (&acc)[MT][NT], const long long (&out_off)[MT], const bool (&pvalid)[MT],
+                                               int nbase, int lane, unsigned char* wreg) {
+  using S = GemmStage<MT, NT>;
+  constexpr int JH = NT / 2;
+  static_assert(JH * 128 + 16 == S::RS, "an fp32 pass of NT / 2 tiles has the row pitch of the fp16 staging");
+  const int lr = lane & 31, lh = lane >> 5;
+  if (lh == 0) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) *reinterpret_cast<long long*>(wreg + S::OFFS + (i * 32 + lr) * 8) = pvalid[i] ? out_off[i] : -1;
+  }
+  constexpr int COLS = JH * 8, PPI = 64 / COLS;  // 16-byte columns of a staged row; pixels per store instruction
+  const int c16 = lane % COLS, pr = lane / COLS;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int jj = 0; jj < JH; ++jj)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int j = pass * JH + jj;
+          *reinterpret_cast<f4*>(wreg + (i * 32 + lr) * S::RS + (jj * 32 + g * 8 + lh * 4) * 4) =
+              f4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        }
+    const int n = nbase + pass * JH * 32 + c16 * 4;
+#pragma unroll
+    for (int it = 0; it < MT * 32 / PPI; ++it) {
+      const int r = it * PPI + pr;
+      const long long off = *reinterpret_cast<const long long*>(wreg + S::OFFS + r * 8);
+      const f4 v = *reinterpret_cast<const f4*>(wreg + r * S::RS + c16 * 16);
+      if (off >= 0 && n < p.Cout) *reinterpret_cast<f4*>(p.out32 + off + n) = v;
+    }
+  }
+}
+
 template <int MT, int NT, int EPI>
 __device__ __forceinline__ void gemm_store_f16(const ConvParams& p, const f16v (&acc)[MT][NT], const long long (&out_off)[MT],
                                                const long long (&res_off)[MT], const bool (&pvalid)[MT], int nbase, int lane, unsigned char* wreg) {
@@ -228,19 +282,21 @@ template <int MT>
 struct GemmCursor {
   int chunk, tap, cc;      // next chunk to issue; its tap and its 32-channel block inside the tap
   unsigned vo[MT];         // per lane: byte offset of (pixel + tap, channel group), or ~0 where the tap leaves the image
+  unsigned vo_tail[MT];    // the same for the tap's last chunk when it is ragged: ~0 for the channel groups past Cin
 };
 
 // the tap table is staged in LDS at kernel start (sTap: dh, dw per tap): a global load inside the K loop would sit in the middle of the
 // counted vmcnt queue of the ring
 template <int MT>
 __device__ __forceinline__ void gemm_enter_tap(GemmCursor<MT>& k, const ConvParams& p, const int* sTap, const int (&a_ih)[MT], const int (&a_iw)[MT],
-                                               const unsigned (&a_off)[MT]) {
+                                               const unsigned (&a_off)[MT], const bool (&a_tail_ok)[MT]) {
   const int dh = __builtin_amdgcn_readfirstlane(sTap[2 * k.tap]), dw = __builtin_amdgcn_readfirstlane(sTap[2 * k.tap + 1]);
   const int toff = ((dh * p.IW + dw) * p.in_ld) * 2;  // bytes; negative for the taps above / left of the pixel
 #pragma unroll
   for (int q = 0; q < MT; ++q) {
     const bool ok = (unsigned)(a_ih[q] + dh) < (unsigned)p.IH && (unsigned)(a_iw[q] + dw) < (unsigned)p.IW;
     k.vo[q] = ok ? a_off[q] + (unsigned)toff : 0xffffffffu;  // inside the image the sum is a valid offset into the view
+    k.vo_tail[q] = a_tail_ok[q] ? k.vo[q] : 0xffffffffu;
   }
 }
 
@@ -273,15 +329,18 @@ __global__ __launch_bounds__(64 * GW) void conv_gemm_kernel(const ConvParams p, 
   __syncthreads();
   const long long M = (long long)p.B * p.OH2 * p.OW2;
   const long long m_base = (long long)m_tile * BM;
-  const int cpt = p.Cin / CHUNK;  // chunks per tap
+  const int cpt = (p.Cin + CHUNK - 1) / CHUNK;  // chunks per tap
+  const int tail_groups = (p.Cin % CHUNK) / 8;  // 8-channel groups of a tap's last chunk when Cin % 32 != 0 (0: every chunk is full)
 
   // ---- per-lane gather assignment: pixel piece q of this wave covers LDS units (q * 8 + wave) * 64 + lane = pixel * 4 + slot ----
   int a_ih[MT], a_iw[MT];
   unsigned a_off[MT];
+  bool a_tail_ok[MT];
 #pragma unroll
   for (int q = 0; q < MT; ++q) {
     const int pix = (q * GW + wave) * 16 + (lane >> 2);
     const int grp = (lane & 3) ^ ((pix >> 2) & 3);  // the channel group this lane fetches: the read-side swizzle, applied at the source
+    a_tail_ok[q] = tail_groups == 0 || grp < tail_groups;
     const long long m = m_base + pix;
     a_ih[q] = a_iw[q] = -(1 << 24);  // rows past the last pixel: no tap is ever inside the image
     a_off[q] = 0;
@@ -307,13 +366,14 @@ __global__ __launch_bounds__(64 * GW) void conv_gemm_kernel(const ConvParams p, 
   cur.chunk = 0;
   cur.tap = 0;
   cur.cc = 0;
-  gemm_enter_tap<MT>(cur, p, sTap, a_ih, a_iw, a_off);
+  gemm_enter_tap<MT>(cur, p, sTap, a_ih, a_iw, a_off, a_tail_ok);
   auto issue = [&]() __attribute__((always_inline)) {
     unsigned char* sb = smem + (cur.chunk & (GSLOTS - 1)) * G::SLOT_BYTES;
     const unsigned sa = (unsigned)(cur.cc * (CHUNK * 2));
+    const bool tail = cur.cc == cpt - 1;  // (uniform) the ragged chunk, if any: vo_tail == vo when Cin % 32 == 0
 #pragma unroll
     for (int q = 0; q < G::A_PW; ++q)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sb + (q * GW + wave) * 1024), 16, cur.vo[q], sa, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sb + (q * GW + wave) * 1024), 16, tail ? cur.vo_tail[q] : cur.vo[q], sa, 0, 0);
     const unsigned sw = (unsigned)cur.chunk * (unsigned)G::B_BYTES;
 #pragma unroll
     for (int q = 0; q < G::B_PW; ++q)
@@ -322,7 +382,7 @@ __global__ __launch_bounds__(64 * GW) void conv_gemm_kernel(const ConvParams p, 
     if (++cur.cc == cpt && cur.chunk < nchunks) {
       cur.cc = 0;
       ++cur.tap;
-      gemm_enter_tap<MT>(cur, p, sTap, a_ih, a_iw, a_off);
+      gemm_enter_tap<MT>(cur, p, sTap, a_ih, a_iw, a_off, a_tail_ok);
     }
   };
 
@@ -441,7 +501,6 @@ __global__ __launch_bounds__(64 * GW) void conv_gemm_kernel(const ConvParams p, 
         for (int i = 0; i < MT; ++i) {
           if (!pvalid[i]) continue;
           f4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-          if (n0 < p.Cout) *reinterpret_cast<f4*>(p.out32 + out_off[i] + n0) = v;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             s1[r] += v[r];
@@ -450,13 +509,8 @@ __global__ __launch_bounds__(64 * GW) void conv_gemm_kernel(const ConvParams p, 
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float a = s1[r], b2 = s2[r];
-#pragma unroll
-          for (int o = 1; o < 32; o <<= 1) {
-            a += __shfl_xor(a, o);
-            b2 += __shfl_xor(b2, o);
-          }
-          if (lr == 0) {
+          const float a = half_wave_sum(s1[r]), b2 = half_wave_sum(s2[r]);
+          if (lr == 31) {
             sStat[(wm * BN + chl + r) * 2 + 0] = a;
             sStat[(wm * BN + chl + r) * 2 + 1] = b2;
           }
@@ -471,6 +525,9 @@ __global__ __launch_bounds__(64 * GW) void conv_gemm_kernel(const ConvParams p, 
         cvx_fix_atomic_add(p.stats, ((long long)(m_tile % p.stats_replicas) * p.Cout + n) * 2 + which, v);
       }
     }
+    __syncthreads();  // the statistics scratch has been read, every wave is done with the ring: its space stages the raw output
+    gemm_store_raw<MT, NT>(p, acc, out_off, pvalid, nbase, lane, smem + wave * GemmStage<MT, NT>::WAVE_BYTES);
+    clk_mark(p, 4);
     return;
   }
   // one straight-line body per epilogue kind: with the kinds tested inside the (j, g, i) loops hipcc 7.2 structurised the control flow
@@ -502,7 +559,7 @@ int launch_gemm(const ConvParams& p, hipStream_t stream) {
   using G = GemmGeom<MT, NT>;
   const long long M = (long long)p.B * p.OH2 * p.OW2;
   const int m_tiles = (int)((M + G::BM - 1) / G::BM), n_tiles = (p.Cout + G::BN - 1) / G::BN;
-  const int nchunks = p.ntaps * (p.Cin / CHUNK);
+  const int nchunks = p.ntaps * ((p.Cin + CHUNK - 1) / CHUNK);
   // ---- weights -> ring image order: done for all layers at once by the engine (wt_packed), or here for a stand-alone launch ----
   static const int dbg = cvx_tune_int("CVX_GEMM_DBG", 0);  // tuning build: 1 no pack, 2 no main kernel, 16 main kernel stops after the K loop, 32.. see CVX_GEMM_DBG_BIT
   const half_t* packed = p.wt_packed_bn == G::BN ? p.wt_packed : nullptr;
@@ -548,8 +605,8 @@ int launch_gemm(const ConvParams& p, hipStream_t stream) {
 bool cvx_conv_gemm_shape_ok(const ConvParams& p) {
   const long long M = (long long)p.B * p.OH2 * p.OW2;
   // buffer_load offsets are 32-bit: the gathered view and one channel tile's packed weights stay below 4 GiB / 2 GiB
-  return p.nphase <= 1 && p.Cin % CHUNK == 0 && p.ntaps <= CVX_MAX_TAPS && p.Cout % 4 == 0 && M < (1LL << 31) &&
-         (long long)p.B * p.in_bstride * 2 < (1LL << 32) && (long long)p.ntaps * p.Cin * 256 * 2 < (1LL << 31);
+  return p.nphase <= 1 && p.Cin % 8 == 0 && p.ntaps <= CVX_MAX_TAPS && p.Cout % 4 == 0 && M < (1LL << 31) &&
+         (long long)p.B * p.in_bstride * 2 < (1LL << 32) && (long long)p.ntaps * (p.Cin + CHUNK) * 256 * 2 < (1LL << 31);
 }
 
 bool cvx_conv_gemm_supported(const ConvParams& p) {
@@ -562,7 +619,7 @@ bool cvx_conv_gemm_supported(const ConvParams& p) {
   static const int kmin = cvx_tune_int("CVX_GEMM_KMIN", 256);
   static const int mmin = cvx_tune_int("CVX_GEMM_MMIN", 2048);
   static const int cmin = cvx_tune_int("CVX_GEMM_CMIN", 128);
-  static const int gfmin = cvx_tune_int("CVX_GEMM_GFMIN", 6);  // GFLOP per launch: below, the 20..30-us layers of YOLOv8-n stay where they were (6.79 vs 6.96 ms/step)
+  static const int gfmin = cvx_tune_int("CVX_GEMM_GFMIN", 2);  // GFLOP per launch: below, the 20-us layers of YOLOv8-n stay where they were (profiles/r03_gemm_model_ab.txt)
   return K >= kmin && p.Cout >= cmin && M >= mmin && 2.0 * (double)M * (double)K * p.Cout >= gfmin * 1e9;
 }
 
@@ -596,7 +653,7 @@ static int gemm_pick_tile(long long M, int Cout, int nchunks, double* est_us) {
 static int gemm_tile_for(const ConvParams& p) {
   static const int force = cvx_tune_int("CVX_GEMM_TILE", 0);  // 1: 256x256, 2: 256x128, 3: 128x256, 4: 128x128
   if (force) return force;
-  return gemm_pick_tile((long long)p.B * p.OH2 * p.OW2, p.Cout, p.ntaps * (p.Cin / CHUNK), nullptr);
+  return gemm_pick_tile((long long)p.B * p.OH2 * p.OW2, p.Cout, p.ntaps * ((p.Cin + CHUNK - 1) / CHUNK), nullptr);
 }
 
 bool cvx_conv_gemm_plan(const ConvParams& p, GemmPackJob* job, size_t* bytes) {
@@ -612,7 +669,7 @@ bool cvx_conv_gemm_plan(const ConvParams& p, GemmPackJob* job, size_t* bytes) {
   job->ntaps = p.ntaps;
   job->BN = BN;
   job->nblocks = (p.Cout + BN - 1) / BN;
-  job->chunks = p.ntaps * (p.Cin / CHUNK);
+  job->chunks = p.ntaps * ((p.Cin + CHUNK - 1) / CHUNK);
   const long long units = (long long)job->nblocks * job->chunks * 4 * BN;
   job->nblk = (int)((units + PACK_UNITS_PER_BLOCK - 1) / PACK_UNITS_PER_BLOCK);
   *bytes = (size_t)units * 16;

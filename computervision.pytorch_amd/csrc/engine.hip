@@ -1987,7 +1987,7 @@ extern "C" int cvx_conv2d_nhwc(const void* x_f16, int32_t batch, int32_t ih, int
   if (force_gemm) {
     if (!cvx_conv_gemm_shape_ok(cp)) {
       (void)hipFree(dt);
-      CVX_CHECK(false, "shape outside the GEMM-shaped kernel (cin % 32, cout % 4)");
+      CVX_CHECK(false, "shape outside the GEMM-shaped kernel (cin % 8, cout % 4)");
     }
     rc = cvx_conv_gemm_launch(cp, st);
   } else {

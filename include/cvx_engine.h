@@ -299,7 +299,7 @@ int cvx_centernet_decode(const float* pred, int32_t pred_ld, int32_t batch, int3
  * NHWC fp16 convolution, weights [cout][kh][kw][cin] fp16.  mode 0: out fp16 = conv; mode 1: out fp16 =
  * silu(conv*scale+shift); mode 2: out fp32 = conv + bias; mode 3 (the training epilogue): out fp32 = conv, and the
  * per-channel (sum, sum of squares) are added into `shift` viewed as zeroed fixed-point replica slabs.  mode | 0x100 runs the GEMM-shaped
- * kernel (conv_gemm.hip) whatever the dispatcher would pick (needs cin % 32 == 0, cout % 4 == 0).  Replaces: F.conv2d as used by
+ * kernel (conv_gemm.hip) whatever the dispatcher would pick (needs cin % 8 == 0, cout % 4 == 0).  Replaces: F.conv2d as used by
  * Conv.forward, core/models/yolov8/modules.py:29-30. */
 int cvx_conv2d_nhwc(const void* x_f16, int32_t batch, int32_t ih, int32_t iw, int32_t cin, const void* w_f16, int32_t cout, int32_t k,
                     int32_t stride, int32_t pad, int32_t dil, int32_t mode, const float* scale_or_bias, const float* shift, void* out,

@@ -77,7 +77,8 @@ CONV_CASES = [(2, 16, 16, 16, 16, 3, 1), (2, 20, 20, 8, 16, 3, 2), (1, 24, 24, 3
               (8, 19, 19, 512, 512, 3, 1), (2, 38, 38, 256, 512, 3, 1), (4, 33, 33, 1024, 256, 1, 1), (8, 40, 40, 128, 256, 3, 2),
               (3, 27, 31, 160, 200, 3, 1)]
 GEMM_CASES = [(8, 19, 19, 512, 512, 3, 1, 1), (2, 38, 38, 256, 512, 3, 1, 1), (4, 33, 33, 1024, 256, 1, 1, 1), (8, 40, 40, 128, 256, 3, 2, 1),
-              (3, 27, 31, 160, 200, 3, 1, 1), (2, 33, 33, 256, 256, 3, 1, 2), (1, 9, 9, 32, 68, 3, 1, 1), (40, 38, 38, 512, 512, 3, 1, 1)]
+              (3, 27, 31, 160, 200, 3, 1, 1), (2, 33, 33, 256, 256, 3, 1, 2), (1, 9, 9, 32, 68, 3, 1, 1), (40, 38, 38, 512, 512, 3, 1, 1),
+              (2, 33, 33, 304, 256, 3, 1, 1), (3, 20, 20, 80, 144, 3, 1, 1), (2, 24, 24, 8, 128, 1, 1, 1)]  # Cin % 32 != 0: ragged last chunk of every tap
 
 
 @pytest.mark.parametrize("B,H,W,C,f", [(2, 12, 10, 64, 2), (1, 7, 9, 24, 2), (2, 6, 5, 64, 4), (1, 5, 4, 16, 8), (1, 3, 3, 520, 2), (3, 24, 24, 256, 2)])
@@ -148,7 +149,8 @@ def test_conv_fwd_dgrad_wgrad(dev, B, H, W, Ci, Co, k, s):
 def test_gemm_shaped_conv_kernel_all_epilogues(dev, B, H, W, Ci, Co, k, s, dil):
     """conv_gemm.hip run directly (mode | 0x100) -- the dispatcher only prefers it on the largest layers: plain fp16 store, folded BN + SiLU,
     bias -> fp32, and the training epilogue (raw fp32 + per-channel statistics), on VGG / ResNet-101 / atrous shapes, ragged pixel and
-    channel tiles (9x9 pixels, 68 / 200 channels), and the batch-40 38x38 512->512 layer that takes the 256 x 256 macro tile."""
+    channel tiles (9x9 pixels, 68 / 200 channels), the batch-40 38x38 512->512 layer that takes the 256 x 256 macro tile, and input
+    channel counts that are not multiples of the 32-deep ring chunk (304: DeepLab's decoder concat; 80; 8)."""
     lib = L.load()
     g = torch.Generator().manual_seed(B + H + Ci + Co + k)
     x16 = torch.randn(B, Ci, H, W, generator=g).half()

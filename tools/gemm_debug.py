@@ -21,8 +21,15 @@ for (B, H, W, Ci, Co, k) in SHAPES:
     out = torch.zeros(B, H, W, Co, dtype=torch.float16, device=dev)
     sc, sh = torch.ones(Co, device=dev), torch.zeros(Co, device=dev)
 
-    def run(mode=0x101):
-        L.check(lib.cvx_conv2d_nhwc(L.ptr(x), B, H, W, Ci, L.ptr(w), Co, k, 1, k // 2, 1, mode, L.ptr(sc), L.ptr(sh), L.ptr(out), L.stream_ptr(dev)), "conv")
+    MODE = int(os.environ.get("GEMM_DEBUG_MODE", "1"))  # 1: folded BN + SiLU -> fp16; 3: the training epilogue (raw fp32 + statistics)
+    out32 = torch.zeros(B, H, W, Co, dtype=torch.float32, device=dev) if MODE == 3 else None
+    slab = torch.zeros(16 * Co * 4, dtype=torch.int64, device=dev)
+
+    def run():
+        if MODE == 3:
+            L.check(lib.cvx_conv2d_nhwc(L.ptr(x), B, H, W, Ci, L.ptr(w), Co, k, 1, k // 2, 1, 0x103, None, L.ptr(slab), L.ptr(out32), L.stream_ptr(dev)), "conv")
+        else:
+            L.check(lib.cvx_conv2d_nhwc(L.ptr(x), B, H, W, Ci, L.ptr(w), Co, k, 1, k // 2, 1, 0x101, L.ptr(sc), L.ptr(sh), L.ptr(out), L.stream_ptr(dev)), "conv")
     for _ in range(3):
         run()
     dbg = torch.zeros(8 * 4096, dtype=torch.int64, device=dev)
