@@ -4,7 +4,7 @@
 //   * 512 threads = 8 waves as 4 (pixels) x 2 (channels); macro tile BM x BN = (4 * MT * 32) x (2 * NT * 32): 256 x 256, 256 x 128,
 //     128 x 256 or 128 x 128; every wave owns MT x NT tiles of v_mfma_f32_32x32x16_f16 (weights as the A operand: a lane ends up with
 //     4 consecutive channels of one pixel);
-//   * BOTH operands stream through one LDS-DMA ring of CHUNK = 32 K-values (2 MFMA K-steps), 4 slots, 2 chunks in flight beyond the
+//   * BOTH operands stream through one LDS-DMA ring of 32 (or 64: small tiles) K-values per chunk = 2 (4) MFMA K-steps, 3-4 slots, the chunks beyond the
 //     one being computed, issued as `buffer_load_dwordx4 ... lds` (tools/micro/buffer_lds_probe.hip: out-of-range lanes deliver zeros,
 //     LDS destinations above 64 KiB work):
 //       - pixels: the implicit-GEMM gather -- chunk (tap, 32 channels) of pixel p is 64 contiguous bytes of the NHWC view.  A lane's
@@ -33,17 +33,20 @@ namespace {
 using namespace cvx_tile;
 
 typedef float f16v __attribute__((ext_vector_type(16)));
-constexpr int GSLOTS = 4;
 constexpr int GW = 8;        // waves
-constexpr int CHUNK = 32;    // K-values per ring chunk
 
-template <int MT, int NT>
+template <int MT, int NT, int NS, int KC>
 struct GemmGeom {
   static_assert(NT % 2 == 0, "channel pieces divide evenly over the 8 waves");
+  static_assert(NS >= 3 && NS <= 8, "ring slots");
+  static_assert(KC == 32 || KC == 64, "K-values per ring chunk");
+  static constexpr int GSLOTS = NS;
+  static constexpr int KSTEPS = KC / 16;  // MFMA K-steps per chunk
+  static constexpr int UPP = KC / 8;      // 16-byte units per pixel (and per weight row) and chunk
   static constexpr int BM = 4 * MT * 32, BN = 2 * NT * 32;
-  static constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;  // one chunk (32 K-values) of each operand
+  static constexpr int A_BYTES = BM * KC * 2, B_BYTES = BN * KC * 2;  // one chunk of each operand
   static constexpr int SLOT_BYTES = A_BYTES + B_BYTES;
-  static constexpr int A_PW = MT, B_PW = NT / 2;  // 1-KiB DMA pieces per wave and chunk
+  static constexpr int A_PW = MT * KC / 32, B_PW = NT / 2 * KC / 32;  // 1-KiB DMA pieces per wave and chunk
   static constexpr int PW = A_PW + B_PW;
   static constexpr int RING_BYTES = GSLOTS * SLOT_BYTES + 4 * BN * 2 * 4 + CVX_MAX_TAPS * 8;  // ring | statistics scratch | tap offsets
   static constexpr int STAGE_BYTES = GW * (MT * 32 * (NT * 64 + 16) + MT * 32 * 8);         // epilogue staging (GemmStage), reuses the ring
@@ -63,23 +66,24 @@ __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(0)
 // 16-byte unit of the image
 constexpr int PACK_UNITS_PER_BLOCK = 256 * 8;
 __device__ __forceinline__ void gemm_pack_units(const GemmPackJob& a, long long u0, long long u1) {
-  const long long per_block = (long long)a.chunks * 4 * a.BN;  // units per n-block
-  const int cpt = (a.Cin + CHUNK - 1) / CHUNK;                 // chunks per tap; the last one is zero-padded when Cin % 32 != 0
+  const long long per_block = (long long)a.chunks * (a.kc / 8) * a.BN;  // units per n-block
+  const int upp = a.kc / 8;                                    // 16-byte units per row and chunk
+  const int cpt = (a.Cin + a.kc - 1) / a.kc;                   // chunks per tap; the last one is zero-padded when Cin % kc != 0
   for (long long u = u0 + threadIdx.x; u < u1; u += blockDim.x) {
     const int nb = (int)(u / per_block);
     const long long r0 = u - (long long)nb * per_block;
-    const int chunk = (int)(r0 / (4 * a.BN));
-    const int r1 = (int)(r0 - (long long)chunk * 4 * a.BN);
+    const int chunk = (int)(r0 / (upp * a.BN));
+    const int r1 = (int)(r0 - (long long)chunk * upp * a.BN);
     const int kh = r1 / a.BN, row = r1 - kh * a.BN;  // kh = K-step * 2 + half
     const int n = nb * a.BN + row;
-    const int tap = chunk / cpt, c0 = (chunk - tap * cpt) * CHUNK + kh * 8;
+    const int tap = chunk / cpt, c0 = (chunk - tap * cpt) * a.kc + kh * 8;
     h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
     if (n < a.rows && c0 < a.Cin) v = *reinterpret_cast<const h8*>(a.src + (long long)n * a.src_ld + a.taps[tap].wtap * a.Cin + c0);
     *reinterpret_cast<h8*>(a.dst + u * 8) = v;
   }
 }
 __global__ __launch_bounds__(256) void gemm_pack_kernel(const GemmPackJob a) {
-  const long long total = (long long)a.chunks * 4 * a.BN * a.nblocks;
+  const long long total = (long long)a.chunks * (a.kc / 8) * a.BN * a.nblocks;
   const long long u0 = (long long)blockIdx.x * PACK_UNITS_PER_BLOCK;
   gemm_pack_units(a, u0, u0 + PACK_UNITS_PER_BLOCK < total ? u0 + PACK_UNITS_PER_BLOCK : total);
 }
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(256) void gemm_pack_jobs_kernel(const GemmPackJob* 
       hi = mid - 1;
   }
   const GemmPackJob a = jobs[lo];
-  const long long total = (long long)a.chunks * 4 * a.BN * a.nblocks;
+  const long long total = (long long)a.chunks * (a.kc / 8) * a.BN * a.nblocks;
   const long long u0 = (long long)((int)blockIdx.x - a.blk0) * PACK_UNITS_PER_BLOCK;
   if (u0 < total) gemm_pack_units(a, u0, u0 + PACK_UNITS_PER_BLOCK < total ? u0 + PACK_UNITS_PER_BLOCK : total);
 }
@@ -270,6 +274,19 @@ __device__ __forceinline__ void gemm_store_f16(const ConvParams& p, const f16v (
 }
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// waits until at most k chunks (of PW pieces each) are outstanding; k is wave-uniform, 0..5
+template <int PW>
+__device__ __forceinline__ void wait_chunks(int k) {
+  switch (k) {
+    case 0: wait_vmcnt<0>(); break;
+    case 1: wait_vmcnt<PW>(); break;
+    case 2: wait_vmcnt<2 * PW>(); break;
+    case 3: wait_vmcnt<3 * PW>(); break;
+    case 4: wait_vmcnt<4 * PW>(); break;
+    default: wait_vmcnt<5 * PW>(); break;
+  }
+}
 // timing experiments of the tuning build (CVX_GEMM_DBG bits 32: no DMA inside the K loop, 64: no MFMA, 128: no barrier; results are WRONG)
 #ifdef CVX_TUNING
 #define CVX_GEMM_DBG_BIT(b) ((p.dbg & (b)) != 0)
@@ -278,35 +295,36 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #endif
 
 // issue cursor of the ring: which (tap, channel block) the next chunk is, and the per-lane gather offsets under that tap
-template <int MT>
+template <int AP>
 struct GemmCursor {
   int chunk, tap, cc;      // next chunk to issue; its tap and its 32-channel block inside the tap
-  unsigned vo[MT];         // per lane: byte offset of (pixel + tap, channel group), or ~0 where the tap leaves the image
-  unsigned vo_tail[MT];    // the same for the tap's last chunk when it is ragged: ~0 for the channel groups past Cin
+  int slot;                // ring slot the next chunk goes to
+  unsigned vo[AP];         // per lane: byte offset of (pixel + tap, channel group), or ~0 where the tap leaves the image
+  unsigned vo_tail[AP];    // the same for the tap's last chunk when it is ragged: ~0 for the channel groups past Cin
 };
 
 // the tap table is staged in LDS at kernel start (sTap: dh, dw per tap): a global load inside the K loop would sit in the middle of the
 // counted vmcnt queue of the ring
-template <int MT>
-__device__ __forceinline__ void gemm_enter_tap(GemmCursor<MT>& k, const ConvParams& p, const int* sTap, const int (&a_ih)[MT], const int (&a_iw)[MT],
-                                               const unsigned (&a_off)[MT], const bool (&a_tail_ok)[MT]) {
+template <int AP>
+__device__ __forceinline__ void gemm_enter_tap(GemmCursor<AP>& k, const ConvParams& p, const int* sTap, const int (&a_ih)[AP], const int (&a_iw)[AP],
+                                               const unsigned (&a_off)[AP], const bool (&a_tail_ok)[AP]) {
   const int dh = __builtin_amdgcn_readfirstlane(sTap[2 * k.tap]), dw = __builtin_amdgcn_readfirstlane(sTap[2 * k.tap + 1]);
   const int toff = ((dh * p.IW + dw) * p.in_ld) * 2;  // bytes; negative for the taps above / left of the pixel
 #pragma unroll
-  for (int q = 0; q < MT; ++q) {
+  for (int q = 0; q < AP; ++q) {
     const bool ok = (unsigned)(a_ih[q] + dh) < (unsigned)p.IH && (unsigned)(a_iw[q] + dw) < (unsigned)p.IW;
     k.vo[q] = ok ? a_off[q] + (unsigned)toff : 0xffffffffu;  // inside the image the sum is a valid offset into the view
     k.vo_tail[q] = a_tail_ok[q] ? k.vo[q] : 0xffffffffu;
   }
 }
 
-template <int MT, int NT>
+template <int MT, int NT, int NS, int KC>
 __global__ __launch_bounds__(64 * GW) void conv_gemm_kernel(const ConvParams p, const half_t* __restrict__ wpk, int m_tiles, int n_tiles, int nchunks,
                                                             unsigned a_records) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (and has no __amdgpu_buffer_rsrc_t)
-  using G = GemmGeom<MT, NT>;
-  constexpr int BM = G::BM, BN = G::BN;
-  static_assert(2 * G::PW <= 63, "vmcnt field");
+  using G = GemmGeom<MT, NT, NS, KC>;
+  constexpr int BM = G::BM, BN = G::BN, GSLOTS = NS, UPP = G::UPP, KS = G::KSTEPS, AP = G::A_PW;
+  static_assert(5 * G::PW <= 63 && GSLOTS - 3 <= 5, "vmcnt field; wait_chunks cases");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* sStat = reinterpret_cast<float*>(smem + GSLOTS * G::SLOT_BYTES);
   int* sTap = reinterpret_cast<int*>(smem + GSLOTS * G::SLOT_BYTES + 4 * BN * 2 * 4);
@@ -329,17 +347,18 @@ __global__ __launch_bounds__(64 * GW) void conv_gemm_kernel(const ConvParams p, 
   __syncthreads();
   const long long M = (long long)p.B * p.OH2 * p.OW2;
   const long long m_base = (long long)m_tile * BM;
-  const int cpt = (p.Cin + CHUNK - 1) / CHUNK;  // chunks per tap
-  const int tail_groups = (p.Cin % CHUNK) / 8;  // 8-channel groups of a tap's last chunk when Cin % 32 != 0 (0: every chunk is full)
+  const int cpt = (p.Cin + KC - 1) / KC;  // chunks per tap
+  const int tail_groups = (p.Cin % KC) / 8;  // 8-channel groups of a tap's last chunk when Cin % KC != 0 (0: every chunk is full)
 
-  // ---- per-lane gather assignment: pixel piece q of this wave covers LDS units (q * 8 + wave) * 64 + lane = pixel * 4 + slot ----
-  int a_ih[MT], a_iw[MT];
-  unsigned a_off[MT];
-  bool a_tail_ok[MT];
+  // ---- per-lane gather assignment: pixel piece q of this wave covers LDS units (q * 8 + wave) * 64 + lane = pixel * UPP + slot ----
+  int a_ih[AP], a_iw[AP];
+  unsigned a_off[AP];
+  bool a_tail_ok[AP];
 #pragma unroll
-  for (int q = 0; q < MT; ++q) {
-    const int pix = (q * GW + wave) * 16 + (lane >> 2);
-    const int grp = (lane & 3) ^ ((pix >> 2) & 3);  // the channel group this lane fetches: the read-side swizzle, applied at the source
+  for (int q = 0; q < AP; ++q) {
+    const int pix = (q * GW + wave) * (64 / UPP) + lane / UPP;
+    // the channel group this lane fetches: the read-side swizzle (gemm_swizzle), applied at the source
+    const int grp = (lane % UPP) ^ (UPP == 4 ? (pix >> 2) & 3 : (pix >> 1) & 7);
     a_tail_ok[q] = tail_groups == 0 || grp < tail_groups;
     const long long m = m_base + pix;
     a_ih[q] = a_iw[q] = -(1 << 24);  // rows past the last pixel: no tap is ever inside the image
@@ -362,14 +381,16 @@ __global__ __launch_bounds__(64 * GW) void conv_gemm_kernel(const ConvParams p, 
       __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(wblk), (short)0, (int)((long long)nchunks * G::B_BYTES), 0x00020000);
   const unsigned vb = (unsigned)(lane * 16);
 
-  GemmCursor<MT> cur;
+  GemmCursor<AP> cur;
   cur.chunk = 0;
   cur.tap = 0;
   cur.cc = 0;
-  gemm_enter_tap<MT>(cur, p, sTap, a_ih, a_iw, a_off, a_tail_ok);
+  cur.slot = 0;
+  gemm_enter_tap<AP>(cur, p, sTap, a_ih, a_iw, a_off, a_tail_ok);
   auto issue = [&]() __attribute__((always_inline)) {
-    unsigned char* sb = smem + (cur.chunk & (GSLOTS - 1)) * G::SLOT_BYTES;
-    const unsigned sa = (unsigned)(cur.cc * (CHUNK * 2));
+    unsigned char* sb = smem + cur.slot * G::SLOT_BYTES;
+    cur.slot = cur.slot + 1 == GSLOTS ? 0 : cur.slot + 1;
+    const unsigned sa = (unsigned)(cur.cc * (KC * 2));
     const bool tail = cur.cc == cpt - 1;  // (uniform) the ragged chunk, if any: vo_tail == vo when Cin % 32 == 0
 #pragma unroll
     for (int q = 0; q < G::A_PW; ++q)
@@ -382,7 +403,7 @@ __global__ __launch_bounds__(64 * GW) void conv_gemm_kernel(const ConvParams p, 
     if (++cur.cc == cpt && cur.chunk < nchunks) {
       cur.cc = 0;
       ++cur.tap;
-      gemm_enter_tap<MT>(cur, p, sTap, a_ih, a_iw, a_off, a_tail_ok);
+      gemm_enter_tap<AP>(cur, p, sTap, a_ih, a_iw, a_off, a_tail_ok);
     }
   };
 
@@ -400,72 +421,96 @@ __global__ __launch_bounds__(64 * GW) void conv_gemm_kernel(const ConvParams p, 
   for (int s = 0; s < GSLOTS - 1; ++s)
     if (s < nchunks) issue();
 
-  // fragment addresses inside a slot (bytes).  Pixel operand: unit pixel * 4 + (group ^ swizzle), K-step 1 = group + 2 = address ^ 32;
-  // sub-tile i is 32 pixels = 2048 bytes further (the swizzle term (pixel >> 2) & 3 does not change).  Weight operand: [K-step][k-half][BN][8]
-  const unsigned a_rd0 = lds_addr(smem) + (unsigned)((wm * MT * 32 + lr) * 64 + ((lh ^ ((lr >> 2) & 3)) << 4));
-  const unsigned a_rd1 = a_rd0 ^ 32u;
+  // fragment addresses inside a slot (bytes).  Pixel operand: unit pixel * UPP + (group ^ swizzle); K-step ks reads groups 2 ks + lh, i.e.
+  // the address of K-step 0 XOR ks * 32; sub-tile i is 32 pixels further (the swizzle term does not change).  Swizzle: (pixel >> 2) & 3
+  // with 4 units per pixel, (pixel >> 1) & 7 with 8: the 16 lanes of every ds_read_b128 lane group fall on 16 different 16-byte slots
+  // (tools/lds_conflicts.py).  Weight operand: [K-step][k-half][BN][8].
+  const int a_sw = UPP == 4 ? (lr >> 2) & 3 : (lr >> 1) & 7;
+  const unsigned a_rd0 = lds_addr(smem) + (unsigned)((wm * MT * 32 + lr) * (UPP * 16) + ((lh ^ a_sw) << 4));
   const unsigned b_rd = lds_addr(smem) + (unsigned)(G::A_BYTES + (lh * BN + wn * NT * 32 + lr) * 16);
-  h8 xa0[MT], wb0[NT], xa1[MT], wb1[NT];
-#define CVX_GEMM_READ(XA, WB, AR, SO, KS)                                                     \
+  h8 xa[2][MT], wb[2][NT];
+#define CVX_GEMM_READ(SET, SO, KSTEP)                                                         \
   {                                                                                           \
-    const unsigned va_ = (AR) + (SO), vb_ = b_rd + (SO);                                      \
-    if constexpr (MT >= 1) XA[0] = lds_frag<0>(va_);                                          \
-    if constexpr (MT >= 2) XA[1] = lds_frag<2048>(va_);                                       \
-    if constexpr (NT >= 1) WB[0] = lds_frag<(KS) * 2 * BN * 16 + 0 * 512>(vb_);               \
-    if constexpr (NT >= 2) WB[1] = lds_frag<(KS) * 2 * BN * 16 + 1 * 512>(vb_);               \
-    if constexpr (NT >= 3) WB[2] = lds_frag<(KS) * 2 * BN * 16 + 2 * 512>(vb_);               \
-    if constexpr (NT >= 4) WB[3] = lds_frag<(KS) * 2 * BN * 16 + 3 * 512>(vb_);               \
+    const unsigned va_ = (a_rd0 ^ (unsigned)((KSTEP) * 32)) + (SO), vb_ = b_rd + (SO);        \
+    if constexpr (MT >= 1) xa[SET][0] = lds_frag<0>(va_);                                     \
+    if constexpr (MT >= 2) xa[SET][1] = lds_frag<32 * UPP * 16>(va_);                         \
+    if constexpr (NT >= 1) wb[SET][0] = lds_frag<(KSTEP) * 2 * BN * 16 + 0 * 512>(vb_);       \
+    if constexpr (NT >= 2) wb[SET][1] = lds_frag<(KSTEP) * 2 * BN * 16 + 1 * 512>(vb_);       \
+    if constexpr (NT >= 3) wb[SET][2] = lds_frag<(KSTEP) * 2 * BN * 16 + 2 * 512>(vb_);       \
+    if constexpr (NT >= 4) wb[SET][3] = lds_frag<(KSTEP) * 2 * BN * 16 + 3 * 512>(vb_);       \
   }
-#define CVX_GEMM_MFMA(XA, WB)                                                                 \
+#define CVX_GEMM_MFMA(SET)                                                                    \
   {                                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                        \
     if (!CVX_GEMM_DBG_BIT(64))                                                                \
     _Pragma("unroll") for (int j = 0; j < NT; ++j) _Pragma("unroll") for (int i = 0; i < MT; ++i) acc[i][j] =                       \
-        __builtin_amdgcn_mfma_f32_32x32x16_f16(WB[j], XA[i], acc[i][j], 0, 0, 0);             \
+        __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[SET][j], xa[SET][i], acc[i][j], 0, 0, 0);   \
     __builtin_amdgcn_sched_barrier(0);                                                        \
   }
   static_assert(MT <= 2 && NT <= 4, "fragment macros");
-  // Loop invariant at the top of iteration c: the fragments of BOTH K-steps of chunk c are in registers (or on their way), chunk c + 1
+  static_assert(KS == 2 || KS == 4, "the K-step schedule below");
+  // Loop invariant at the top of iteration c: the fragments of K-steps 0 and 1 of chunk c are in registers (or on their way), chunk c + 1
   // has landed for this wave.  The barrier then publishes chunk c + 1 and retires chunk c - 1, and the first thing behind it is an MFMA
   // block whose operands are already there: MFMA issue blocks the wave and the pipe holds no queue, so cycles in which all eight waves
-  // sit between a barrier and their next MFMA are lost outright (measured: 1.43x the MFMA time with the barrier in mid-chunk).
-  if (nchunks >= 3)
-    wait_vmcnt<2 * G::PW>();
-  else if (nchunks == 2)
-    wait_vmcnt<G::PW>();
-  else
-    wait_vmcnt<0>();
+  // sit between a barrier and their next MFMA are lost outright (measured: 1.43x the MFMA time with the barrier in mid-chunk).  Two
+  // fragment sets alternate: the set an MFMA block has just consumed is refilled with the K-step two ahead (the next chunk's at the end).
+  // chunk 0 has landed when at most the chunks issued behind it (up to NS - 2 of them) are outstanding
+  const int issued0 = nchunks < GSLOTS - 1 ? nchunks : GSLOTS - 1;
+  wait_chunks<G::PW>(issued0 - 1);
   workgroup_barrier();  // chunk 0 published
   if (p.clk) {  // tuning runs only: the stamp's store would sit in the counted vmcnt queue, so the ring is drained once here
     clk_mark(p, 2);
     wait_vmcnt<0>();
     workgroup_barrier();
   }
-  CVX_GEMM_READ(xa0, wb0, a_rd0, 0u, 0);
-  CVX_GEMM_READ(xa1, wb1, a_rd1, 0u, 1);
-  if (nchunks >= 3)
-    wait_vmcnt<G::PW>();
-  else
-    wait_vmcnt<0>();
+  CVX_GEMM_READ(0, 0u, 0);
+  CVX_GEMM_READ(1, 0u, 1);
+  wait_chunks<G::PW>(issued0 >= 2 ? issued0 - 2 : 0);  // chunk 1 landed
+  unsigned so = 0;  // slot of chunk c
   for (int c = 0; c + 1 < nchunks; ++c) {
-    if (!CVX_GEMM_DBG_BIT(128)) workgroup_barrier();  // chunk c + 1 published; every wave is done reading chunk c - 1: its slot takes chunk c + 3
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT + NT) : "memory");  // K-step 0 of chunk c (LDS returns in order)
-    CVX_GEMM_MFMA(xa0, wb0);
-    if (cur.chunk < nchunks && !CVX_GEMM_DBG_BIT(32)) issue();
-    const unsigned sn = (unsigned)(((c + 1) & (GSLOTS - 1)) * G::SLOT_BYTES);
-    CVX_GEMM_READ(xa0, wb0, a_rd0, sn, 0);
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT + NT) : "memory");  // K-step 1 of chunk c
-    CVX_GEMM_MFMA(xa1, wb1);
-    CVX_GEMM_READ(xa1, wb1, a_rd1, sn, 1);
-    if (c + 3 < nchunks)
-      wait_vmcnt<G::PW>();  // chunk c + 2 landed (chunk c + 3 may be in flight)
-    else
-      wait_vmcnt<0>();
+    const unsigned sn = so + G::SLOT_BYTES == GSLOTS * G::SLOT_BYTES ? 0u : so + G::SLOT_BYTES;  // slot of chunk c + 1
+    if (!CVX_GEMM_DBG_BIT(128)) workgroup_barrier();  // chunk c + 1 published; every wave is done reading chunk c - 1: its slot takes chunk c + NS - 1
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT + NT) : "memory");  // this K-step's fragments (LDS returns in order; the next set may be pending)
+      if (ks & 1) {
+        CVX_GEMM_MFMA(1);
+      } else {
+        CVX_GEMM_MFMA(0);
+      }
+      if (ks == 0 && cur.chunk < nchunks && !CVX_GEMM_DBG_BIT(32)) issue();
+      // refill the set just consumed: K-step ks + 2 of this chunk, or K-step ks + 2 - KS of the next one
+      if (ks == 0) {
+        if constexpr (KS > 2) { CVX_GEMM_READ(0, so, 2); } else { CVX_GEMM_READ(0, sn, 0); }
+      } else if (ks == 1) {
+        if constexpr (KS > 2) { CVX_GEMM_READ(1, so, 3); } else { CVX_GEMM_READ(1, sn, 1); }
+      } else if (ks == 2) {
+        CVX_GEMM_READ(0, sn, 0);
+      } else {
+        CVX_GEMM_READ(1, sn, 1);
+      }
+    }
+    // chunk c + 2 landed; the chunks issued behind it (up to NS - 3, fewer at the end of K) may stay in flight
+    const int behind = nchunks - 3 - c;
+    wait_chunks<G::PW>(behind < 0 ? 0 : behind < GSLOTS - 3 ? behind : GSLOTS - 3);
+    so = sn;
   }
-  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT + NT) : "memory");  // the last chunk
-  CVX_GEMM_MFMA(xa0, wb0);
-  wait_lgkm();
-  CVX_GEMM_MFMA(xa1, wb1);
+  // the last chunk: nothing behind it
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    if (ks + 1 < KS) {
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT + NT) : "memory");
+    } else {
+      wait_lgkm();
+    }
+    if (ks & 1) {
+      CVX_GEMM_MFMA(1);
+    } else {
+      CVX_GEMM_MFMA(0);
+    }
+    if (ks == 0 && KS > 2) CVX_GEMM_READ(0, so, 2);
+    if (ks == 1 && KS > 2) CVX_GEMM_READ(1, so, 3);
+  }
 #undef CVX_GEMM_READ
 #undef CVX_GEMM_MFMA
   clk_mark(p, 3);
@@ -554,17 +599,17 @@ struct PackSlot {
 };
 std::map<std::pair<const void*, std::pair<const void*, int>>, PackSlot> g_pack;
 
-template <int MT, int NT>
+template <int MT, int NT, int NS, int KC>
 int launch_gemm(const ConvParams& p, hipStream_t stream) {
-  using G = GemmGeom<MT, NT>;
+  using G = GemmGeom<MT, NT, NS, KC>;
   const long long M = (long long)p.B * p.OH2 * p.OW2;
   const int m_tiles = (int)((M + G::BM - 1) / G::BM), n_tiles = (p.Cout + G::BN - 1) / G::BN;
-  const int nchunks = p.ntaps * ((p.Cin + CHUNK - 1) / CHUNK);
+  const int nchunks = p.ntaps * ((p.Cin + KC - 1) / KC);
   // ---- weights -> ring image order: done for all layers at once by the engine (wt_packed), or here for a stand-alone launch ----
   static const int dbg = cvx_tune_int("CVX_GEMM_DBG", 0);  // tuning build: 1 no pack, 2 no main kernel, 16 main kernel stops after the K loop, 32.. see CVX_GEMM_DBG_BIT
-  const half_t* packed = p.wt_packed_bn == G::BN ? p.wt_packed : nullptr;
+  const half_t* packed = (p.wt_packed_bn == G::BN && p.wt_packed_kc == KC) ? p.wt_packed : nullptr;
   if (!packed) {
-    PackSlot& ps = g_pack[{p.wt, {p.taps, G::BN}}];
+    PackSlot& ps = g_pack[{p.wt, {p.taps, G::BN * 1024 + KC}}];
     const size_t need = (size_t)n_tiles * nchunks * G::B_BYTES;
     if (ps.bytes < need) {
       if (ps.buf) CVX_HIP(hipFree(ps.buf));
@@ -580,10 +625,11 @@ int launch_gemm(const ConvParams& p, hipStream_t stream) {
     a.Cin = p.Cin;
     a.ntaps = p.ntaps;
     a.BN = G::BN;
+    a.kc = KC;
     a.nblocks = n_tiles;
     a.chunks = nchunks;
     a.taps = p.taps;
-    const long long units = (long long)n_tiles * nchunks * 4 * G::BN;
+    const long long units = (long long)n_tiles * nchunks * G::UPP * G::BN;
     if (!(dbg & 1)) hipLaunchKernelGGL(gemm_pack_kernel, dim3((unsigned)((units + PACK_UNITS_PER_BLOCK - 1) / PACK_UNITS_PER_BLOCK)), dim3(256), 0, stream, a);
     packed = ps.buf;
   }
@@ -592,13 +638,31 @@ int launch_gemm(const ConvParams& p, hipStream_t stream) {
   pd.dbg = dbg;
   pd.clk = g_cvx_clk;
   static unsigned long long optin_mask = 0;
-  CVX_TRY(cvx_lds_optin((const void*)conv_gemm_kernel<MT, NT>, G::LDS_BYTES, &optin_mask));
+  CVX_TRY(cvx_lds_optin((const void*)conv_gemm_kernel<MT, NT, NS, KC>, G::LDS_BYTES, &optin_mask));
   const int grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
   const unsigned a_records = (unsigned)std::min<long long>((long long)p.B * p.in_bstride * 2, 0xffffffffLL);
-  hipLaunchKernelGGL((conv_gemm_kernel<MT, NT>), dim3(grid), dim3(64 * GW), G::LDS_BYTES, stream, pd, packed, m_tiles, n_tiles, nchunks,
+  hipLaunchKernelGGL((conv_gemm_kernel<MT, NT, NS, KC>), dim3(grid), dim3(64 * GW), G::LDS_BYTES, stream, pd, packed, m_tiles, n_tiles, nchunks,
                      a_records);
   return 0;
 }
+
+// The variants of the kernel and what the cost model knows about each (calibrated on the phase stamps of tools/gemm_debug.py, MI355X, clock as
+// held under this load): us per chunk with the CU saturated by this variant, prologue + epilogue, workgroups that share a CU.
+struct GemmVariant {
+  int bm, bn, slots, kc, per_cu;
+  double chunk_us, fixed_us;
+  long long min_wgs;  // only for grids at least this large
+};
+constexpr GemmVariant kVariants[] = {
+    {256, 256, 4, 32, 1, 0.80, 12.0, 0},   // 1
+    {256, 128, 4, 32, 1, 0.50, 7.0, 0},    // 2
+    {128, 256, 4, 32, 1, 0.52, 7.6, 0},    // 3
+    {128, 128, 4, 32, 2, 0.56, 6.0, 0},    // 4: two workgroups per CU
+    {256, 128, 3, 32, 2, 1.03, 7.0, 1024}, // 5: two per CU (their barrier gaps fill each other); a workgroup alone on its CU is slower than variant 2
+    {128, 128, 4, 64, 1, 0.58, 5.0, 0},    // 6: 64-deep chunks -- per-chunk costs (barrier, DMA issue) amortised over twice the MFMAs; one workgroup per CU
+    {256, 128, 3, 64, 1, 0.98, 7.5, 0},    // 7: (measured 5-7 % ahead of variant 2 on every probe shape)
+};
+constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
 }  // namespace
 
@@ -606,7 +670,7 @@ bool cvx_conv_gemm_shape_ok(const ConvParams& p) {
   const long long M = (long long)p.B * p.OH2 * p.OW2;
   // buffer_load offsets are 32-bit: the gathered view and one channel tile's packed weights stay below 4 GiB / 2 GiB
   return p.nphase <= 1 && p.Cin % 8 == 0 && p.ntaps <= CVX_MAX_TAPS && p.Cout % 4 == 0 && M < (1LL << 31) &&
-         (long long)p.B * p.in_bstride * 2 < (1LL << 32) && (long long)p.ntaps * (p.Cin + CHUNK) * 256 * 2 < (1LL << 31);
+         (long long)p.B * p.in_bstride * 2 < (1LL << 32) && (long long)p.ntaps * (p.Cin + 64) * 256 * 2 < (1LL << 31);
 }
 
 bool cvx_conv_gemm_supported(const ConvParams& p) {
@@ -623,43 +687,40 @@ bool cvx_conv_gemm_supported(const ConvParams& p) {
   return K >= kmin && p.Cout >= cmin && M >= mmin && 2.0 * (double)M * (double)K * p.Cout >= gfmin * 1e9;
 }
 
-// Macro tile by a cost model calibrated on the phase stamps of tools/gemm_debug.py (MI355X, clock as held under this load): time of one
-// workgroup = chunks * (us per 32-deep chunk with the CU saturated by this tile) + prologue / epilogue, times the number of rounds
-// the grid needs on 256 CUs.  The model reproduces the measured launches within 10 % (GEMM-shaped kernel).
-static int gemm_pick_tile(long long M, int Cout, int nchunks, double* est_us) {
-  struct Cfg {
-    int bm, bn, per_cu;
-    double chunk_us, fixed_us;
-  };
-  static const Cfg cfg[4] = {{256, 256, 1, 0.80, 12.0}, {256, 128, 1, 0.50, 7.0}, {128, 256, 1, 0.52, 7.6}, {128, 128, 2, 0.56, 6.0}};
-  int best = 3;
+// Variant by cost model: time of one workgroup = chunks * chunk_us + fixed_us, times the rounds the grid needs on 256 CUs (x per_cu).  The model
+// reproduces the measured launches within 10 % (GEMM-shaped kernel).  Returns the variant number (index + 1).
+static int gemm_pick_variant(long long M, int Cin, int Cout, int ntaps, double* est_us) {
+  int best = 4;
   double best_t = 1e30;
-  for (int i = 0; i < 4; ++i) {
-    if (cfg[i].bn > 128 && Cout <= 128) continue;  // half of every channel tile would be padding
-    const long long wgs = ((M + cfg[i].bm - 1) / cfg[i].bm) * ((Cout + cfg[i].bn - 1) / cfg[i].bn);
-    const long long rounds = (wgs + 256 * cfg[i].per_cu - 1) / (256 * cfg[i].per_cu);
-    // a last round that fills under half of the slots of a two-per-CU tile runs its workgroups alone on their CUs: ~0.6 of the pair time
-    double t = (double)rounds * (nchunks * cfg[i].chunk_us + cfg[i].fixed_us);
-    if (cfg[i].per_cu == 2 && (wgs - (rounds - 1) * 512) <= 256) t -= 0.4 * (nchunks * cfg[i].chunk_us + cfg[i].fixed_us);
+  for (int i = 0; i < kNumVariants; ++i) {
+    const GemmVariant& v = kVariants[i];
+    if (v.bn > 128 && Cout <= 128) continue;  // half of every channel tile would be padding
+    const long long wgs = ((M + v.bm - 1) / v.bm) * ((Cout + v.bn - 1) / v.bn);
+    if (wgs < v.min_wgs) continue;
+    const int nchunks = ntaps * ((Cin + v.kc - 1) / v.kc);
+    const long long rounds = (wgs + 256 * v.per_cu - 1) / (256 * v.per_cu);
+    double t = (double)rounds * (nchunks * v.chunk_us + v.fixed_us);
+    // a last round that fills under half of the slots of a two-per-CU variant runs its workgroups alone on their CUs: ~0.6 of the pair time
+    if (v.per_cu == 2 && (wgs - (rounds - 1) * 512) <= 256) t -= 0.4 * (nchunks * v.chunk_us + v.fixed_us);
     if (t < best_t) {
       best_t = t;
-      best = i;
+      best = i + 1;
     }
   }
   if (est_us) *est_us = best_t;
-  return best + 1;
+  return best;
 }
 
-static int gemm_tile_for(const ConvParams& p) {
-  static const int force = cvx_tune_int("CVX_GEMM_TILE", 0);  // 1: 256x256, 2: 256x128, 3: 128x256, 4: 128x128
-  if (force) return force;
-  return gemm_pick_tile((long long)p.B * p.OH2 * p.OW2, p.Cout, p.ntaps * ((p.Cin + CHUNK - 1) / CHUNK), nullptr);
+static int gemm_variant_for(const ConvParams& p) {
+  static const int force = cvx_tune_int("CVX_GEMM_TILE", 0);  // tuning build: variant number 1..7 (kVariants)
+  if (p.gemm_variant >= 1 && p.gemm_variant <= kNumVariants) return p.gemm_variant;
+  if (force >= 1 && force <= kNumVariants) return force;
+  return gemm_pick_variant((long long)p.B * p.OH2 * p.OW2, p.Cin, p.Cout, p.ntaps, nullptr);
 }
 
 bool cvx_conv_gemm_plan(const ConvParams& p, GemmPackJob* job, size_t* bytes) {
   if (p.nphase > 1 || !cvx_conv_gemm_supported(p)) return false;
-  const int pick = gemm_tile_for(p);
-  const int BN = (pick == 1 || pick == 3) ? 256 : 128;
+  const GemmVariant& v = kVariants[gemm_variant_for(p) - 1];
   memset(job, 0, sizeof(*job));
   job->src = p.wt;
   job->taps = p.taps;
@@ -667,10 +728,11 @@ bool cvx_conv_gemm_plan(const ConvParams& p, GemmPackJob* job, size_t* bytes) {
   job->rows = p.Cout;
   job->Cin = p.Cin;
   job->ntaps = p.ntaps;
-  job->BN = BN;
-  job->nblocks = (p.Cout + BN - 1) / BN;
-  job->chunks = p.ntaps * ((p.Cin + CHUNK - 1) / CHUNK);
-  const long long units = (long long)job->nblocks * job->chunks * 4 * BN;
+  job->BN = v.bn;
+  job->kc = v.kc;
+  job->nblocks = (p.Cout + v.bn - 1) / v.bn;
+  job->chunks = p.ntaps * ((p.Cin + v.kc - 1) / v.kc);
+  const long long units = (long long)job->nblocks * job->chunks * (v.kc / 8) * v.bn;
   job->nblk = (int)((units + PACK_UNITS_PER_BLOCK - 1) / PACK_UNITS_PER_BLOCK);
   *bytes = (size_t)units * 16;
   return true;
@@ -684,11 +746,14 @@ int cvx_conv_gemm_pack_jobs(const GemmPackJob* d_jobs, int njobs, int nblocks, h
 }
 
 int cvx_conv_gemm_launch(const ConvParams& p, hipStream_t stream) {
-  switch (gemm_tile_for(p)) {
-    case 1: CVX_TRY((launch_gemm<2, 4>(p, stream))); break;
-    case 2: CVX_TRY((launch_gemm<2, 2>(p, stream))); break;
-    case 3: CVX_TRY((launch_gemm<1, 4>(p, stream))); break;
-    default: CVX_TRY((launch_gemm<1, 2>(p, stream))); break;
+  switch (gemm_variant_for(p)) {
+    case 1: CVX_TRY((launch_gemm<2, 4, 4, 32>(p, stream))); break;
+    case 2: CVX_TRY((launch_gemm<2, 2, 4, 32>(p, stream))); break;
+    case 3: CVX_TRY((launch_gemm<1, 4, 4, 32>(p, stream))); break;
+    case 5: CVX_TRY((launch_gemm<2, 2, 3, 32>(p, stream))); break;
+    case 6: CVX_TRY((launch_gemm<1, 2, 4, 64>(p, stream))); break;
+    case 7: CVX_TRY((launch_gemm<2, 2, 3, 64>(p, stream))); break;
+    default: CVX_TRY((launch_gemm<1, 2, 4, 32>(p, stream))); break;
   }
   CVX_HIP(hipGetLastError());
   return 0;

@@ -71,7 +71,8 @@ struct ConvParams {
   // GEMM-shaped kernel: the weights already in its ring image order for channel tiles of wt_packed_bn rows (cvx_conv_gemm_pack_jobs, once
   // per forward for all layers); null: the launch packs them itself
   const half_t* wt_packed;
-  int wt_packed_bn;
+  int wt_packed_bn, wt_packed_kc;  // channel-tile rows and K-values per chunk of that image
+  int gemm_variant;                // unit tests: run this variant of the GEMM-shaped kernel (conv_gemm.hip: kVariants index + 1), 0 = the cost model's
 };
 
 // Packs a 9-entry tap table whose offsets all lie in the 3x3 neighbourhood into two 64-bit words, 4 bits per tap:
@@ -106,7 +107,7 @@ struct GemmPackJob {
   const half_t* src;
   half_t* dst;
   const ConvTap* taps;  // device table: chunk block `tap` reads weight tap taps[tap].wtap
-  int src_ld, rows, Cin, ntaps, BN, nblocks, chunks;
+  int src_ld, rows, Cin, ntaps, BN, kc, nblocks, chunks;  // kc: K-values per chunk (32 or 64)
   int blk0, nblk;
 };
 // Fills `job` (all but dst, blk0) and the bytes of its image when the dispatcher will take this launch to the GEMM-shaped kernel

@@ -36,7 +36,7 @@ struct DgClass {
   unsigned long long halo_pos = 0, halo_wt = 0;
   int ntaps = 0, oph = 0, opw = 0, OH2 = 0, OW2 = 0;
   const half_t* gemm_pk = nullptr;  // data-gradient weights in the GEMM-shaped kernel's ring image order (per batch plan), channel tiles of gemm_bn rows
-  int gemm_bn = 0;
+  int gemm_bn = 0, gemm_kc = 0;
 };
 
 struct ConvRt {
@@ -65,7 +65,7 @@ struct ConvRt {
   long long slab_off = 0;
   int nsplit = 1;
   const half_t* gemm_fwd = nullptr;  // forward weights in the GEMM-shaped kernel's ring image order (per batch plan)
-  int gemm_fwd_bn = 0;
+  int gemm_fwd_bn = 0, gemm_fwd_kc = 0;
 };
 
 struct PoolRt {
@@ -501,7 +501,8 @@ int plan_fused_groups(cvx_engine* e, int B) {
     ChainSpec sp;
     bool ok = false;
     // ---- Detect level: 3x3 (box | class) -> 3x3, 3x3 -> 1x1 + bias, 1x1 + bias ----
-    if (i + 4 < nops && is_bn_silu_3x3(o) && is_bn_silu_3x3(e->ops[i + 1]) && is_bn_silu_3x3(e->ops[i + 2]) && e->ops[i + 3].type == CVX_OP_CONV &&
+    static const int kinds = cvx_tune_int("CVX_CHAIN_KINDS", 3);  // tuning build: bit 0 Bottleneck pairs, bit 1 Detect levels
+    if ((kinds & 2) && i + 4 < nops && is_bn_silu_3x3(o) && is_bn_silu_3x3(e->ops[i + 1]) && is_bn_silu_3x3(e->ops[i + 2]) && e->ops[i + 3].type == CVX_OP_CONV &&
         e->ops[i + 3].act == CVX_ACT_BIAS && e->ops[i + 3].k == 1 && e->ops[i + 4].type == CVX_OP_CONV && e->ops[i + 4].act == CVX_ACT_BIAS &&
         e->ops[i + 4].k == 1 && o.res.buf < 0) {
       const cvx_op_desc &b1 = e->ops[i + 1], &b2 = e->ops[i + 2], &o1 = e->ops[i + 3], &o2 = e->ops[i + 4];
@@ -535,7 +536,7 @@ int plan_fused_groups(cvx_engine* e, int B) {
       }
     }
     // ---- Bottleneck pair: 3x3 -> 3x3 (+ shortcut) ----
-    if (!ok && i + 1 < nops && is_bn_silu_3x3(o) && is_bn_silu_3x3(e->ops[i + 1]) && o.res.buf < 0) {
+    if ((kinds & 1) && !ok && i + 1 < nops && is_bn_silu_3x3(o) && is_bn_silu_3x3(e->ops[i + 1]) && o.res.buf < 0) {
       const cvx_op_desc& o2 = e->ops[i + 1];
       const int C = o.out.c;
       const bool shortcut = o2.res.buf >= 0;
@@ -828,6 +829,7 @@ void fill_conv_fwd(const cvx_engine* e, int i, int B, ConvParams* cp) {
   cp->halo_wt = c.halo_wt;
   cp->wt_packed = c.gemm_fwd;
   cp->wt_packed_bn = c.gemm_fwd_bn;
+  cp->wt_packed_kc = c.gemm_fwd_kc;
 }
 
 void free_gemm_packs(cvx_engine* e) {
@@ -838,10 +840,10 @@ void free_gemm_packs(cvx_engine* e) {
   e->n_gemm_jobs = e->n_gemm_fwd_jobs = e->gemm_blocks = e->gemm_fwd_blocks = 0;
   for (auto& c : e->conv) {
     c.gemm_fwd = nullptr;
-    c.gemm_fwd_bn = 0;
+    c.gemm_fwd_bn = c.gemm_fwd_kc = 0;
     for (auto& d : c.dg) {
       d.gemm_pk = nullptr;
-      d.gemm_bn = 0;
+      d.gemm_bn = d.gemm_kc = 0;
     }
   }
 }
@@ -920,9 +922,11 @@ int plan_gemm_packs(cvx_engine* e, int B, bool training) {
     if (refs[k].q < 0) {
       c.gemm_fwd = jobs[k].dst;
       c.gemm_fwd_bn = jobs[k].BN;
+      c.gemm_fwd_kc = jobs[k].kc;
     } else {
       c.dg[refs[k].q].gemm_pk = jobs[k].dst;
       c.dg[refs[k].q].gemm_bn = jobs[k].BN;
+      c.dg[refs[k].q].gemm_kc = jobs[k].kc;
     }
   }
   CVX_HIP(hipMalloc((void**)&e->d_gemm_jobs, jobs.size() * sizeof(GemmPackJob)));
@@ -1613,6 +1617,7 @@ int backward_op(cvx_engine* e, int i) {
         cp.accumulate = c.in_accum;
         cp.wt_packed = dc.gemm_pk;
         cp.wt_packed_bn = dc.gemm_bn;
+        cp.wt_packed_kc = dc.gemm_kc;
         cp.out16 = gin.p;
         cp.out_ld = gin.ld;
         cp.out_bstride = gin.bstride;
@@ -1933,6 +1938,7 @@ extern "C" int cvx_conv2d_nhwc(const void* x_f16, int32_t batch, int32_t ih, int
   CVX_CHECK(x_f16 && w_f16 && out && k * k <= CVX_MAX_TAPS && stride >= 1 && dil >= 1, "bad arguments");
   hipStream_t st = (hipStream_t)hip_stream;
   const bool force_gemm = (mode & 0x100) != 0;  // unit tests of the GEMM-shaped kernel on shapes the dispatcher gives to another one
+  const int gemm_variant = (mode >> 9) & 15;    // ... and of one particular variant of it (0: the cost model's choice)
   mode &= 0xff;
   const int oh = (ih + 2 * pad - dil * (k - 1) - 1) / stride + 1, ow = (iw + 2 * pad - dil * (k - 1) - 1) / stride + 1;
   std::vector<ConvTap> taps;
@@ -1984,6 +1990,7 @@ extern "C" int cvx_conv2d_nhwc(const void* x_f16, int32_t batch, int32_t ih, int
     cp.stats_replicas = cvx_stat_replicas(cout);
   }
   int rc;
+  cp.gemm_variant = gemm_variant;
   if (force_gemm) {
     if (!cvx_conv_gemm_shape_ok(cp)) {
       (void)hipFree(dt);

@@ -180,6 +180,36 @@ def test_gemm_shaped_conv_kernel_all_epilogues(dev, B, H, W, Ci, Co, k, s, dil):
     assert rel(sums[:, 1] / n, (conv.double() ** 2).mean((0, 2, 3))) < 1e-5
 
 
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7])
+def test_gemm_shaped_conv_kernel_every_variant(dev, variant):
+    """Each variant of conv_gemm.hip (macro tile 256x256 ... 128x128, 3 / 4 ring slots, 32- / 64-deep chunks: kVariants) forced through
+    mode bits 9..12, whatever the cost model would pick: folded BN + SiLU output on a VGG shape, ragged pixel / channel tiles, a dilated
+    conv, and input channel counts that leave the last chunk of a tap ragged at both chunk depths (304, 160, 8)."""
+    lib = L.load()
+    st = L.stream_ptr(dev)
+    for (B, H, W, Ci, Co, k, s, dil) in [(8, 19, 19, 512, 512, 3, 1, 1), (3, 27, 31, 160, 200, 3, 1, 1), (2, 33, 33, 304, 256, 3, 1, 2), (2, 24, 24, 8, 128, 1, 1, 1),
+                                         (4, 40, 40, 128, 256, 3, 2, 1), (1, 33, 33, 96, 132, 1, 1, 1)]:
+        g = torch.Generator().manual_seed(variant * 100 + Ci + Co)
+        x16 = torch.randn(B, Ci, H, W, generator=g).half()
+        w16 = (torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5).half()
+        pad = dil * (k // 2)
+        xd, wd = x16.permute(0, 2, 3, 1).contiguous().to(dev), w16.permute(0, 2, 3, 1).contiguous().to(dev)
+        conv = F.conv2d(x16.float().to(dev), w16.float().to(dev), None, s, pad, dil)
+        OH, OW = conv.shape[2:]
+        sc, sh = (torch.rand(Co, generator=g) + 0.5).to(dev), torch.randn(Co, generator=g).to(dev)
+        out = torch.empty(B, OH, OW, Co, dtype=torch.float16, device=dev)
+        L.check(lib.cvx_conv2d_nhwc(L.ptr(xd), B, H, W, Ci, L.ptr(wd), Co, k, s, pad, dil, 0x101 | (variant << 9), L.ptr(sc), L.ptr(sh), L.ptr(out), st), "affine")
+        assert rel(out.float().permute(0, 3, 1, 2), F.silu(conv * sc[None, :, None, None] + sh[None, :, None, None])) < 5e-4, (variant, Ci, Co)
+        out32 = torch.empty(B, OH, OW, Co, dtype=torch.float32, device=dev)
+        R = 16 if Co <= 32 else 8 if Co <= 64 else 4 if Co <= 128 else 2 if Co <= 256 else 1
+        slab = torch.zeros(R, Co, 2, 2, dtype=torch.int64, device=dev)
+        L.check(lib.cvx_conv2d_nhwc(L.ptr(xd), B, H, W, Ci, L.ptr(wd), Co, k, s, pad, dil, 0x103 | (variant << 9), None, L.ptr(slab), L.ptr(out32), st), "stats")
+        assert rel(out32.permute(0, 3, 1, 2), conv) < 1e-5, (variant, Ci, Co)
+        tot = slab.sum(0).double()
+        sums = tot[..., 0] / 64.0 + tot[..., 1] / 2.0 ** 40
+        assert (sums[:, 0] / (B * OH * OW) - conv.double().mean((0, 2, 3))).abs().max() < 1e-5, (variant, Ci, Co)
+
+
 def test_conv_epilogues_affine_silu_and_bias(dev):
     lib = L.load()
     g = torch.Generator().manual_seed(3)
