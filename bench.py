@@ -807,7 +807,7 @@ def main():
                     help="centernet: BASELINE.json configs[3] -- CenterNet DLA-34 (nc 80) 512x512 inference + heat-map decode, batch 64 per GPU")
     ap.add_argument("--exchange", default="torch", choices=["torch", "c"], help="N > 1: gradient exchange through torch.distributed (default) or "
                     "entirely behind the C ABI (RCCL communicator owned by the engine library, no Python between the backward ranges)")
-    ap.add_argument("--fusion", type=int, default=1, help="yolov8_eval: 0 runs the eval forward layer by layer (no cross-layer fusion groups)")
+    ap.add_argument("--fusion", type=int, default=0, help="yolov8_eval: 1 runs the eval forward with the cross-layer fusion groups (Bottleneck pairs, Detect levels as one launch each; measured 1-6 %% slower, so off by default)")
     args = ap.parse_args()
     if args.workload == "yolov8_eval":
         return yolov8_eval_main(args)

@@ -679,12 +679,16 @@ bool cvx_conv_gemm_supported(const ConvParams& p) {
   const long long M = (long long)p.B * p.OH2 * p.OW2;
   const long long K = (long long)p.ntaps * p.Cin;
   // measured against the pointwise / halo / LDS-DMA ring kernels (tools/gemm_probe.py + tools/gemm_trace.py, profiles/r03_gemm_*): ahead
-  // on every shape from 128 channels up (1.5 - 2x at 256+); the tuning build moves the gates for A/B runs of whole models
-  static const int kmin = cvx_tune_int("CVX_GEMM_KMIN", 256);
+  // on every shape from ~100 channels up (1.5 - 2x at 256+); the gates below come from whole-model A/B runs of all ten workloads
+  // (profiles/r03_gemm_model_ab.txt: lower K / FLOP gates were equal or better everywhere); the tuning build moves them
+  static const int kmin = cvx_tune_int("CVX_GEMM_KMIN", 64);
   static const int mmin = cvx_tune_int("CVX_GEMM_MMIN", 2048);
-  static const int cmin = cvx_tune_int("CVX_GEMM_CMIN", 128);
-  static const int gfmin = cvx_tune_int("CVX_GEMM_GFMIN", 2);  // GFLOP per launch: below, the 20-us layers of YOLOv8-n stay where they were (profiles/r03_gemm_model_ab.txt)
-  return K >= kmin && p.Cout >= cmin && M >= mmin && 2.0 * (double)M * (double)K * p.Cout >= gfmin * 1e9;
+  static const int cmin = cvx_tune_int("CVX_GEMM_CMIN", 96);
+  static const int gfmin = cvx_tune_int("CVX_GEMM_GFMIN", 0);  // GFLOP per launch
+  // channel tiles are 128 wide: a layer that fills under 70 % of them (YOLOv8-n's Detect convs, 64 + 80 = 144 channels: 56 %) computes mostly
+  // padding -- measured 114 vs 56 us (80x80 64->144) and 153 vs 114 us (40x40 128->144) against the halo / ring kernels
+  const int padded = (p.Cout + 127) / 128 * 128;
+  return K >= kmin && p.Cout >= cmin && M >= mmin && 2.0 * (double)M * (double)K * p.Cout >= gfmin * 1e9 && p.Cout * 10 >= padded * 7;
 }
 
 // Variant by cost model: time of one workgroup = chunks * chunk_us + fixed_us, times the rounds the grid needs on 256 CUs (x per_cu).  The model

@@ -166,7 +166,7 @@ struct cvx_engine {
   std::vector<int> fused_at;              // op index -> group that STARTS there, -1 otherwise
   ChainPackJob* d_chain_jobs = nullptr;   // weight pre-pack jobs of all groups (one launch per forward)
   int n_chain_jobs = 0, chain_max_units = 0;
-  bool chain_fusion = true;
+  bool chain_fusion = false;  // off by default: parity-green but 1-6 % slower than the per-layer kernels at batch 32; cvx_engine_set_fusion
   // GEMM-shaped conv kernel: every routed layer's weights are re-ordered by ONE launch per forward, next to cvx_pack_weights
   half_t* gemm_arena = nullptr;
   GemmPackJob* d_gemm_jobs = nullptr;

@@ -49,7 +49,7 @@ class Engine:
         L.check(self.lib.cvx_engine_set_bn(self.handle, eps, momentum), "cvx_engine_set_bn")
 
     def set_fusion(self, enable: bool):
-        """eval-mode cross-layer fusion (Bottleneck pairs, Detect levels as one launch each); default on"""
+        """eval-mode cross-layer fusion (Bottleneck pairs, Detect levels as one launch each); default off (measured slower)"""
         L.check(self.lib.cvx_engine_set_fusion(self.handle, int(bool(enable))), "cvx_engine_set_fusion")
 
     def fused_groups(self) -> int:

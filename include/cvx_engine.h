@@ -104,7 +104,7 @@ int cvx_engine_set_stream(cvx_engine* e, void* hip_stream);
 
 /* BatchNorm hyper-parameters (core/models/yolov8/torch_utils.py:17-19: eps 1e-3, momentum 0.03). */
 int cvx_engine_set_bn(cvx_engine* e, float eps, float momentum);
-/* Eval-mode cross-layer fusion (default on): a Bottleneck's 3x3 -> 3x3 (+ shortcut) and a whole Detect level (3x3 -> 3x3 | 3x3 -> 1x1 | 1x1 +
+/* Eval-mode cross-layer fusion (default OFF: parity-green, but measured 1-6 % slower than the per-layer kernels at batch 32): a Bottleneck's 3x3 -> 3x3 (+ shortcut) and a whole Detect level (3x3 -> 3x3 | 3x3 -> 1x1 | 1x1 +
  * bias) run as ONE tile-resident launch each where the planner finds a feasible tile (csrc/conv_chain.hip); training-mode forwards and
  * every other op keep their per-layer kernels.  cvx_engine_fused_groups: groups in the current plan (0 before the first forward).
  * Replaces: the module-by-module execution of Bottleneck.forward / Detect.forward, core/models/yolov8/modules.py:124-135, 428-433. */

@@ -11,10 +11,10 @@ run() {  # label, env..., -- bench args
   echo "$label | $* | $(echo "$out" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["unit"], d["ms_per_step"], "ms")')"
 }
 for wl in "--workload ssd" "--workload deeplab_train" "--workload centernet" "--workload yolov8_train --model s" "--workload yolov8_train" "--workload deeplab" "--workload ssd_train" "--workload centernet_train" "--workload yolov7" "--workload yolov7_train"; do
-  if [ "$1" != "quick" ]; then run "no gemm        " CVX_NO_GEMM=1 -- $wl || exit 1; fi
-  run "gemm (shipped) " CVX_GEMM_GFMIN=2 -- $wl || exit 1
+  if [ "$1" != "quick" ]; then run "no gemm            " CVX_NO_GEMM=1 -- $wl || exit 1; fi
+  run "gemm (shipped)     " CVX_GEMM_GFMIN=0 -- $wl || exit 1
   if [ "$1" != "quick" ]; then
-    run "gemm >= 6 GF   " CVX_GEMM_GFMIN=6 -- $wl || exit 1
-    run "gemm c>=64     " CVX_GEMM_CMIN=64 -- $wl || exit 1
+    run "gemm K>=256, 2 GF  " CVX_GEMM_GFMIN=2 CVX_GEMM_KMIN=256 -- $wl || exit 1
+    run "gemm c>=64         " CVX_GEMM_GFMIN=0 CVX_GEMM_KMIN=64 CVX_GEMM_CMIN=64 -- $wl || exit 1
   fi
 done
