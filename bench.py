@@ -7,7 +7,7 @@ under torch.distributed.run (one rank per GPU, RCCL gradient all-reduce).  Rank 
   (`--model s` = the per-rank workload of configs[2]);
 * `roofline` (the contract roof is MFMA fp16 dense, 2516.6 TFLOP/s): the dominant kernel family on
   the critical path is the implicit-GEMM convolution -- the forward and data-gradient launches of conv_halo_kernel (3x3
-  stride 1), conv_pw_kernel (1x1), conv_igemm_dma_kernel (the rest) and the fp32 stem.  `achieved` = their algorithmic
+  stride 1), conv_pw_kernel (1x1), conv_gemm_kernel (96+ output channels), conv_igemm_dma_kernel (the rest) and the fp32 stem.  `achieved` = their algorithmic
   FLOPs (2 x MACs of every launch) / their summed launch duration, measured live with HIP events on the
   engine's launch stream (cvx_engine_profile) in a window right after the timed steps; `frac` = achieved / peak.
   `hbm_view` is the same launches against the 8 TB/s roof (algorithmic bytes: fp16 input view + output + weights per launch,
@@ -941,7 +941,7 @@ def main():
                        "launch": "hipGraph replay" if use_graph else "eager"},
             "roofline": {"bound": "mfma",
                          "kernel": "implicit-GEMM convolution, forward + data-gradient launches: conv_halo_kernel + conv_pw_kernel + "
-                                   "conv_igemm_dma_kernel (+ the fp32 stem passes)",
+                                   "conv_gemm_kernel + conv_igemm_dma_kernel (+ the fp32 stem passes)",
                          "achieved": round(achieved, 3), "peak": MFMA_FP16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_FP16_PEAK_TFLOPS, 5), "traffic": traffic, "traffic_source": traffic_note,
                          "mfma_busy_frac": mfma_busy, "mfma_busy_source": mfma_note,

@@ -142,6 +142,10 @@ struct WgradParams {
 };
 int cvx_conv_wgrad_launch(const WgradParams& p, hipStream_t stream);
 void cvx_conv_wgrad_tile(int cout, int jtot, int* co_b, int* j_b);  // (co, j) tile the generic kernel takes for a layer
+// GEMM-shaped weight gradient for the big-channel layers (conv_wgrad_gemm.hip); `supported` needs the geometry and strides filled in
+bool cvx_conv_wgrad_gemm_supported(const WgradParams& p);
+void cvx_conv_wgrad_gemm_tile(int cout, int jtot, int* co_b, int* j_b);
+int cvx_conv_wgrad_gemm_launch(const WgradParams& p, hipStream_t stream);
 // 3x3 stride-1 kernel with the whole (co block x 9 taps x ci block) tile in registers (conv_wgrad_halo.hip)
 bool cvx_conv_wgrad_halo_supported(const WgradParams& p);
 void cvx_conv_wgrad_halo_grid(int cout, int cin, int* gx, int* gy);

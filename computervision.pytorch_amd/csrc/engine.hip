@@ -669,15 +669,43 @@ int plan_batch(cvx_engine* e, int B, bool training) {
       int co_b, j_b;
       const int Jtot = c.ntaps * c.cin_pad16;
       cvx_conv_wgrad_tile(C, Jtot, &co_b, &j_b);
+      // the GEMM-shaped weight-gradient kernel (conv_wgrad_gemm.hip) takes the BatchNorm / bias layers with 128+ output channels: its tiles
+      // and its 512-thread workgroups size the pixel splits
+      bool wgg = false;
+      if (!c.stem && o.act != CVX_ACT_BIAS) {
+        WgradParams q;
+        memset(&q, 0, sizeof(q));
+        const Buf& xb = e->bufs[o.in.buf];
+        q.x_ld = xb.d.c;
+        q.x_bstride = (long long)xb.d.h * xb.d.w * xb.d.c;
+        q.IH = o.ih;
+        q.IW = o.iw;
+        q.Cin = c.cin_g;
+        q.dy_ld = C;
+        q.dy_bstride = (long long)o.oh * o.ow * C;
+        q.Cout = C;
+        q.B = B;
+        q.OH = o.oh;
+        q.OW = o.ow;
+        q.stride = o.stride;
+        q.ntaps = c.ntaps;
+        q.cin_pad16 = c.cin_pad16;
+        q.std3x3 = c.std3x3;
+        if (!cvx_conv_wgrad_halo_supported(q) && cvx_conv_wgrad_gemm_supported(q)) {
+          wgg = true;
+          cvx_conv_wgrad_gemm_tile(C, Jtot, &co_b, &j_b);
+        }
+      }
       const long long tiles = (long long)cvx_cdiv(C, co_b) * cvx_cdiv(Jtot, j_b);
       // the 128 x 128 tile (ResNet-sized layers) has few, fat tiles: it takes its parallelism from more pixel splits, and its slabs
       // may grow accordingly (measured on DeepLabv3+ R101: 8 -> 64 MB of slabs per layer took the step from 48.6 to 38.5 ms)
       static const long long blk_narrow = cvx_tune_int("CVX_WGRAD_BLOCKS", 2048), blk_wide = cvx_tune_int("CVX_WGRAD_BLOCKS_WIDE", 1024);
-      const long long blk_target = co_b == 128 ? blk_wide : blk_narrow;
+      static const long long blk_wgg_big = cvx_tune_int("CVX_WGG_BLOCKS_BIG", 256), blk_wgg = cvx_tune_int("CVX_WGG_BLOCKS", 512);
+      const long long blk_target = wgg ? (co_b == 256 ? blk_wgg_big : blk_wgg) : co_b == 128 ? blk_wide : blk_narrow;
       long long ns = std::min<long long>(std::max<long long>(1, M / 256), std::max<long long>(1, blk_target / tiles));
       const long long slab_elems = (long long)C * Jtot;
       static const long long cap_narrow = cvx_tune_int("CVX_SLAB_MB", 8), cap_wide = cvx_tune_int("CVX_SLAB_MB_WIDE", 64);
-      const long long slab_cap_mb = co_b == 128 ? cap_wide : cap_narrow;
+      const long long slab_cap_mb = (wgg || co_b == 128) ? cap_wide : cap_narrow;
       static const long long ns_cap = cvx_tune_int("CVX_NSPLIT_CAP", 512);
       ns = std::min(ns, std::max<long long>(1, (slab_cap_mb << 20) / (slab_elems * 4)));
       ns = std::min<long long>(ns, ns_cap);

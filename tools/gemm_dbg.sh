@@ -1,3 +1,15 @@
 set -o pipefail
-export CVX_LIB=build/libcvx_tuning.so
-for a in "CVX_GEMM_GFMIN=1 CVX_GEMM_KMIN=128" "CVX_GEMM_GFMIN=0 CVX_GEMM_KMIN=128" "CVX_GEMM_GFMIN=0 CVX_GEMM_KMIN=64" "CVX_GEMM_GFMIN=1 CVX_GEMM_KMIN=64" "CVX_GEMM_GFMIN=0 CVX_GEMM_KMIN=128 CVX_GEMM_MMIN=8192"; do echo "== $a"; env $a timeout -k 10 200 python bench.py --no-cpu-baseline --steps 30 --warmup 5 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"], d["forward_eval"]["ms_per_batch"])' || exit 1; done
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rm -rf gpurun_out/wg
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/wg -- python3 tools/micro/wgrad_shapes.py > gpurun_out/wg.log 2>&1
+python - <<'PY'
+import csv,glob
+f=glob.glob('gpurun_out/wg/*/*kernel_trace.csv')[0]
+rows=[r for r in csv.DictReader(open(f)) if 'wgrad' in r['Kernel_Name']]
+rows.sort(key=lambda r:int(r['Start_Timestamp']))
+i=0
+while i<len(rows):
+    grp=rows[i:i+3]; best=min(int(r['End_Timestamp'])-int(r['Start_Timestamp']) for r in grp)/1e3
+    print(grp[0]['Kernel_Name'][:70], f"{best:8.1f} us")
+    i+=3
+PY
