@@ -220,7 +220,8 @@ bool cvx_conv_wgrad_halo_supported(const WgradParams& p) {
   static const bool off = cvx_tune_set("CVX_NO_WGRAD_HALO");
   // wide layers (Cin * Cout >= 256 * 256) take the generic kernel's 128 x 128 tile: 3-4x faster there (DeepLabv3+ R101: 256 -> 256 at
   // 33 x 33: 260 -> 70 us, 304 -> 256 at 129 x 129: 3.1 -> 1.0 ms); the register-tile kernel is built for YOLO's narrow layers
-  static const int max_c = cvx_tune_int("CVX_WH_MAX_C", 65535);
+  // ... and from 128 x 128 channels up the GEMM-shaped kernel (conv_wgrad_gemm.hip) is ahead: 339 vs 427 us at 150 x 150, 100 vs 119 us at 80 x 80
+  static const int max_c = cvx_tune_int("CVX_WH_MAX_C", 16383);
   return !off && p.std3x3 && p.stride == 1 && p.ntaps == 9 && p.Cin >= 16 && p.IH == p.OH && p.IW == p.OW && (long long)p.Cin * p.Cout <= max_c;
 }
 
