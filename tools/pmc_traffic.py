@@ -13,7 +13,7 @@ import csv
 import json
 import sys
 
-FAMILIES = ("conv_gemm_kernel", "gemm_pack", "conv_chain_kernel", "chain_pack_kernel", "bn_act_apply", "conv_halo_kernel", "conv_pw_kernel", "conv_igemm_dma_kernel", "stem_stats_kernel", "stem_apply_kernel", "stem_wgrad_kernel", "conv_wgrad_halo_kernel", "conv_wgrad_kernel", "bn_bwd_reduce",
+FAMILIES = ("conv_wgrad_gemm_kernel", "conv_gemm_kernel", "gemm_pack", "conv_chain_kernel", "chain_pack_kernel", "bn_act_apply", "conv_halo_kernel", "conv_pw_kernel", "conv_igemm_dma_kernel", "stem_stats_kernel", "stem_apply_kernel", "stem_wgrad_kernel", "conv_wgrad_halo_kernel", "conv_wgrad_kernel", "bn_bwd_reduce",
             "bn_bwd_apply", "bn_silu_apply", "reduce_slabs")
 CONV = ("conv_gemm_kernel", "conv_chain_kernel", "conv_halo_kernel", "conv_pw_kernel", "conv_igemm_dma_kernel", "stem_stats_kernel", "stem_apply_kernel")
 
@@ -46,8 +46,8 @@ def main():
     fetch, write = one_step(sys.argv[1], "FETCH_SIZE"), one_step(sys.argv[2], "WRITE_SIZE")
     fam = {k: {"fetch_kib": fetch[k][0], "write_kib": write[k][0], "launches": fetch[k][1],
                "hbm_bytes": (2 * fetch[k][0] + write[k][0]) * 1024} for k in fetch}
-    n = sum(fam[k]["launches"] for k in CONV)
-    tot = sum(fam[k]["hbm_bytes"] for k in CONV)
+    n = sum(fam[k]["launches"] for k in CONV if k in fam)
+    tot = sum(fam[k]["hbm_bytes"] for k in CONV if k in fam)
     import hashlib
     import os
     lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "computervision.pytorch_amd", "lib", "libcvx_engine.so")
@@ -55,7 +55,7 @@ def main():
            "source": "rocprofv3 --pmc FETCH_SIZE --kernel-trace / --pmc WRITE_SIZE --kernel-trace (separate passes) -- python bench.py "
                      "--no-cpu-baseline --steps 3 --warmup 2 --profile-steps 1; one timed step",
            "correction": "bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB counters), MI355X_MICROARCH.md section HBM",
-           "conv_family": list(CONV), "launches_per_step": n, "hbm_bytes_per_step": tot, "hbm_bytes_per_launch": tot / n,
+           "conv_family": [k for k in CONV if k in fam], "launches_per_step": n, "hbm_bytes_per_step": tot, "hbm_bytes_per_launch": tot / n,
            "whole_step_hbm_bytes": sum(v["hbm_bytes"] for v in fam.values()), "families": fam}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     print(f"conv family: {n} launches, {tot / 1e9:.2f} GB per step, {tot / n / 1e6:.1f} MB per launch; whole step {out['whole_step_hbm_bytes'] / 1e9:.1f} GB")
