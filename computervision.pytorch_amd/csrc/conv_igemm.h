@@ -72,6 +72,7 @@ struct ConvParams {
   // per forward for all layers); null: the launch packs them itself
   const half_t* wt_packed;
   int wt_packed_bn, wt_packed_kc;  // channel-tile rows and K-values per chunk of that image
+  int std7x7;                      // 1 when the table is the 7x7 / pad 3 / dilation 1 neighbourhood in row-major order (conv_stem7.hip)
   int gemm_variant;                // unit tests: run this variant of the GEMM-shaped kernel (conv_gemm.hip: kVariants index + 1), 0 = the cost model's
 };
 
@@ -101,6 +102,15 @@ int cvx_conv_igemm_dma_launch(const ConvParams& p, hipStream_t stream);
 // 3x3 stride-1 halo-tile kernel (conv_halo.hip)
 bool cvx_conv_halo_supported(const ConvParams& p);
 int cvx_conv_halo_launch(const ConvParams& p, hipStream_t stream);
+// 7x7 first layer on the 8-channel-padded image (conv_stem7.hip)
+bool cvx_conv_stem7_supported(const ConvParams& p);
+int cvx_conv_stem7_launch(const ConvParams& p, hipStream_t stream);
+inline int cvx_taps_std7x7(const ConvTap* t, int n) {
+  if (n != 49) return 0;
+  for (int i = 0; i < 49; ++i)
+    if (t[i].dh != i / 7 - 3 || t[i].dw != i % 7 - 3 || t[i].wtap != i) return 0;
+  return 1;
+}
 // GEMM-shaped kernel for the big-channel layers (conv_gemm.hip)
 // one layer's weights -> ring image order ([channel tile][chunk][K-step][k-half][BN rows][8]); blocks [blk0, blk0 + nblk) of the batched launch
 struct GemmPackJob {

@@ -45,6 +45,7 @@ struct ConvRt {
   bool halo_ok = false;
   int pointwise = 0;
   int std3x3 = 0;
+  int std7x7 = 0;
   unsigned long long halo_pos = 0, halo_wt = 0;
   int ntaps = 0;
   DgClass dg[16];
@@ -301,6 +302,7 @@ int build_static(cvx_engine* e) {
     c.halo_ok = cvx_halo_pack_taps(taps.data(), T, &c.halo_pos, &c.halo_wt);
     c.pointwise = cvx_taps_pointwise(taps.data(), T);
     c.std3x3 = cvx_taps_std3x3(taps.data(), T);
+    c.std7x7 = cvx_taps_std7x7(taps.data(), T);
     // shadow weights
     PackDesc pd;
     pd.src_off = o.w_off;
@@ -855,6 +857,7 @@ void fill_conv_fwd(const cvx_engine* e, int i, int B, ConvParams* cp) {
   cp->pointwise = c.pointwise;
   cp->halo_pos = c.halo_pos;
   cp->halo_wt = c.halo_wt;
+  cp->std7x7 = c.std7x7;
   cp->wt_packed = c.gemm_fwd;
   cp->wt_packed_bn = c.gemm_fwd_bn;
   cp->wt_packed_kc = c.gemm_fwd_kc;
@@ -1996,6 +1999,7 @@ extern "C" int cvx_conv2d_nhwc(const void* x_f16, int32_t batch, int32_t ih, int
   cp.zeros = zeros_after(dt, taps.size());
   cp.halo_taps_ok = cvx_halo_pack_taps(taps.data(), (int)taps.size(), &cp.halo_pos, &cp.halo_wt) ? 1 : 0;
   cp.pointwise = cvx_taps_pointwise(taps.data(), (int)taps.size());
+  cp.std7x7 = dil == 1 ? cvx_taps_std7x7(taps.data(), (int)taps.size()) : 0;
   cp.out_ld = cout;
   cp.out_bstride = (long long)oh * ow * cout;
   if (mode == 0) {
