@@ -33,7 +33,7 @@ def main():
     dev = torch.device("cuda", 0)
     cfg = Yolo8DetConfig()
     torch.manual_seed(0)
-    model = Yolo8("n", 80, loss_scale=cfg.engine.loss_scale).to(dev).train()
+    model = Yolo8(os.environ.get("OP_PROFILE_SCALE", "n"), 80, loss_scale=cfg.engine.loss_scale).to(dev).train()  # OP_PROFILE_SCALE=s: YOLOv8-s
     step = FusedTrainStep(model, V8DetectionLoss(cfg, model), FlatAdam(model, lr=1e-3))
     B = 32
     x = synth.images(B, 640, 640, seed=1).to(dev)
