@@ -95,7 +95,6 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* y, int A,
   extern __shared__ unsigned long long keys[];  // cap2 entries (power of two >= candidates)
   __shared__ int s_n;
   __shared__ unsigned long long s_removed[NMS_CAP / 64];
-  __shared__ int s_keep[1024];
   __shared__ int s_nkeep;
   __shared__ float s_wmax[NMS_THREADS / 64];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -229,7 +228,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* y, int A,
     for (int i = 0; i < n && nkeep < max_det; ++i) {
       bool dead = (s_removed[i >> 6] >> (i & 63)) & 1ull;  // uniform
       if (dead) continue;
-      if (tid == 0) s_keep[nkeep] = i;
+      if (tid == 0) out_index[(long long)b * max_det + nkeep] = i;  // the keep list lives in the output's own index column until step 6
       ++nkeep;
       for (int wj = tid; wj < nw; wj += 64) s_removed[wj] |= mat[(long long)i * nw + wj];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -242,7 +241,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* y, int A,
   // ---- 6. emit ----
   const int nk = s_nkeep;
   for (int r = tid; r < nk; r += NMS_THREADS) {
-    int i = s_keep[r];
+    int i = out_index[(long long)b * max_det + r];  // (each thread reads and rewrites only its own slots)
     float4 bx = box[i];
     float* o = out_rows + ((long long)b * max_det + r) * 6;
     o[0] = bx.x;
@@ -309,7 +308,7 @@ extern "C" int cvx_nms_variant(const float* y, int32_t B, int32_t A, int32_t nc,
   CVX_CHECK((variant & 0xff) >= CVX_NMS_TV0141_CUDA && (variant & 0xff) <= CVX_NMS_VANILLA && (variant & ~(0xff | CVX_NMS_BOXES_XYXY)) == 0,
             "unknown batched_nms variant");
   CVX_CHECK(conf_thres >= 0.f && conf_thres <= 1.f && iou_thres >= 0.f && iou_thres <= 1.f, "thresholds must lie in [0,1]");
-  CVX_CHECK(max_det >= 1 && max_det <= 1024, "max_det must lie in [1,1024]");
+  CVX_CHECK(max_det >= 1 && max_det <= NMS_CAP, "max_det must lie in [1,16384]");
   CVX_CHECK(workspace_bytes >= cvx_nms_workspace_bytes(B, A), "workspace too small");
   const long long cap = cap_for(A);
   char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);

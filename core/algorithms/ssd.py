@@ -12,7 +12,7 @@ from computervision.pytorch_amd.ssd import MultiBoxLoss, SSD300VGG
 from configs import SsdConfig
 from registry import model_registry
 
-MAX_DET = 1024          # rows per image and class cvx_nms_variant returns
+MAX_DET = 1024          # rows per image and class cvx_nms_variant is first asked for (a full block is retried with 4x the room)
 
 
 @model_registry("ssd")
@@ -112,14 +112,20 @@ class Ssd:
             return [empty for _ in range(B)]
         # one NMS launch per class that has a score above the threshold, all queued back to back; ONE host read (the counts of every
         # class and image) afterwards, and one masked gather per image instead of a cat per (class, image)
-        outs = [_engine.nms(torch.cat((bt, prob[:, :, c].unsqueeze(1)), 1), float(conf_thr), self.nms_threshold, max_det=MAX_DET, variant="vanilla",
-                            boxes_xyxy=True) for c in classes]
-        rows = torch.stack([o[0] for o in outs])                                 # (C', B, MAX_DET, 6)
-        index = torch.stack([o[1] for o in outs]).long()                         # (C', B, MAX_DET)
-        counts = torch.stack([o[2] for o in outs])                               # (C', B)
-        counts_h = counts.cpu()
-        if bool((counts_h < 0).any()) or bool((counts_h >= MAX_DET).any()):
-            raise L.CvxError(f"more than {MAX_DET} detections of one class in one image: raise decode.confidence_threshold")
+        max_det = MAX_DET
+        while True:
+            outs = [_engine.nms(torch.cat((bt, prob[:, :, c].unsqueeze(1)), 1), float(conf_thr), self.nms_threshold, max_det=max_det, variant="vanilla",
+                                boxes_xyxy=True) for c in classes]
+            rows = torch.stack([o[0] for o in outs])                             # (C', B, max_det, 6)
+            index = torch.stack([o[1] for o in outs]).long()                     # (C', B, max_det)
+            counts = torch.stack([o[2] for o in outs])                           # (C', B)
+            counts_h = counts.cpu()                                              # the one host read (one more per retry)
+            if bool((counts_h < 0).any()):  # 8732 priors never exceed the 16384 candidates the in-LDS sort holds; kept for other prior sets
+                raise L.CvxError("cvx_nms: more than 16384 candidates of one class above the confidence threshold in one image")
+            # a full row block may have been cut short: ask again with room for every prior (the reference's decode_boxes has no limit)
+            if int(counts_h.max()) < max_det or max_det >= 16384:
+                break
+            max_det = min(max_det * 4, 16384)
         cls_col = torch.tensor(classes, device=dev).view(-1, 1, 1).expand(-1, B, rows.shape[2])      # class column per slot
         valid = torch.arange(rows.shape[2], device=dev).view(1, 1, -1) < counts.unsqueeze(2)         # (C', B, MAX_DET)
         det = torch.cat((rows[..., :4], (cls_col - 1).unsqueeze(3).to(rows.dtype), rows[..., 4:5]), 3)

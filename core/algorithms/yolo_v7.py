@@ -13,7 +13,8 @@ from computervision.pytorch_amd.yolov7 import Yolo7L, Yolo7Loss
 from configs import Yolo7Config
 from registry import model_registry
 
-MAX_DET = 1024          # rows per image cvx_nms_variant returns (the reference's _nms has no limit: exceeding this raises)
+MAX_DET = 1024          # rows per image cvx_nms_variant is first asked for; a full block is retried with 4x the room, up to ...
+MAX_CANDIDATES = 16384  # ... the candidates per image the in-LDS sort holds (the reference's _nms has no limit: only beyond this it raises)
 
 
 @model_registry("yolo7")
@@ -64,13 +65,17 @@ class YOLOv7:
         conf = self.conf_threshold if conf_threshold is None else conf_threshold
         # cvx_nms keeps scores > threshold (ultralytics_ops.py:190), the reference here keeps >= : the next float below
         thr = float(np.nextafter(np.float32(conf), np.float32(-1.0)))
-        rows, index, counts = _engine.nms(y, thr, self.nms_threshold, max_det=MAX_DET, variant="vanilla")
-        counts_h = counts.cpu().tolist()                           # the ONE host read of the tail
-        for b, n in enumerate(counts_h):
-            if n < 0:
-                raise L.CvxError(f"cvx_nms: more than 16384 candidates above the confidence threshold in image {b}")
-            if n >= MAX_DET:
-                raise L.CvxError(f"more than {MAX_DET} detections in image {b}: raise decode.conf_threshold")
+        max_det = MAX_DET
+        while True:
+            rows, index, counts = _engine.nms(y, thr, self.nms_threshold, max_det=max_det, variant="vanilla")
+            counts_h = counts.cpu().tolist()                       # the ONE host read of the tail (one more per retry)
+            for b, n in enumerate(counts_h):
+                if n < 0:  # the in-LDS sort holds 16384 candidates per image: only then is the reference's unlimited _nms out of reach
+                    raise L.CvxError(f"cvx_nms: more than {MAX_CANDIDATES} candidates above the confidence threshold in image {b}")
+            # a full row block may have been cut short: ask again with room for every candidate (mAP-style runs at conf 0.001)
+            if max(counts_h, default=0) < max_det or max_det >= MAX_CANDIDATES:
+                break
+            max_det = min(max_det * 4, MAX_CANDIDATES)
         # re-order every image's kept rows at once (no per-image kernels): class ascending, cvx_nms's descending score inside a class;
         # rows past an image's count sort to the end
         B, K = rows.shape[0], rows.shape[1]

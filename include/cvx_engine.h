@@ -235,7 +235,7 @@ int cvx_adam_step_dev(float* params, float* grads, float* exp_avg, float* exp_av
 /* ---- eval tail: DFL decode + sigmoid, then class-aware NMS ---------------------------------------
  * cvx_decode: pred (B,A,no) -> y (B, 4+nc, A) fp32 [cx,cy,w,h (pixels), class scores]
  *   Replaces: Detect eval branch, core/models/yolov8/modules.py:434-446.
- * cvx_nms: y -> per image up to max_det rows [x1,y1,x2,y2,conf,cls] + the anchor index of each row;
+ * cvx_nms: y -> per image up to max_det (1 .. 16384) rows [x1,y1,x2,y2,conf,cls] + the anchor index of each row;
  *   counts[b] = rows kept (-1: more candidates than the 16384 the in-LDS sort holds -- raise conf_thres).  Semantics = oracle/nms_ref.py (torchvision 0.14.1 batched_nms restated, both strategies).
  *   Replaces: non_max_suppression, core/utils/ultralytics_ops.py:131-264. */
 int cvx_decode(const float* pred, int32_t batch, int32_t anchors, int32_t nc, const int32_t* level_hw, const float* strides,

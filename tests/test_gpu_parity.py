@@ -1627,6 +1627,34 @@ def test_yolov7_forward_decode_nms_match_the_reference_fixture(dev, gold):
     assert len(res) == 2 and res[0].shape[1] == 7 and np.isfinite(res[0]).all()
 
 
+def test_yolov7_nms_returns_more_than_the_first_row_block(dev):
+    """The reference's _nms keeps every surviving box (yolo_v7.py:348-415); the device tail first asks cvx_nms for 1024 rows per image and
+    retries with room for more when a block comes back full: 3000 disjoint boxes of one class all survive and come back in score order;
+    the same holds for the oracle on the same input."""
+    import builder
+    from oracle import yolov7_ref as Y
+    cfg, algo_cls, _ = builder.export_from_registry("yolo7")
+    algo = algo_cls(cfg, dev)
+    nc, A = 20, 3000
+    g = torch.Generator().manual_seed(5)
+    dec = torch.zeros(1, A, 5 + nc)
+    ii = torch.arange(A)
+    dec[0, :, 0] = (ii % 60).float() / 60 + 0.004        # 60 x 50 grid of disjoint boxes (centre x, centre y, w, h), normalised
+    dec[0, :, 1] = (ii // 60).float() / 50 + 0.004
+    dec[0, :, 2] = 0.006
+    dec[0, :, 3] = 0.006
+    dec[0, :, 4] = 0.5 + 0.5 * torch.rand(A, generator=g)  # objectness
+    dec[0, :, 5 + 3] = 0.9                                 # one class
+    dec = dec.to(dev)
+    # the NMS input the decode kernel would have produced from these rows: (B, 4 + nc, A), score = objectness * class probability
+    y = torch.cat((dec[:, :, :4], dec[:, :, 4:5] * dec[:, :, 5:]), 2).permute(0, 2, 1).contiguous()
+    det, idx = algo.nms_device(y, dec, 0.3)[0]
+    assert det.shape == (A, 7) and idx.shape == (A,)
+    rows, keep = Y.nms(dec.cpu(), nc, 0.3, algo.nms_threshold)[0]
+    assert len(keep) == A and np.array_equal(np.sort(idx.cpu().numpy()), np.sort(keep))
+    assert bool((det[:-1, 4] * det[:-1, 5] >= det[1:, 4] * det[1:, 5] - 1e-7).all())  # one class: scores descending
+
+
 def test_yolov7_full_size_through_the_plugin_api(dev):
     """export_from_registry("yolo7") at 640 x 640: output shapes (coarsest level first), determinism, decode of 25200 anchors
     (beyond the 16384 the NMS kernel's sort holds -- allowed, candidates are what counts), the guards."""
