@@ -242,6 +242,29 @@ def test_7x7_first_layer_kernel(dev, B, H, W, Co, s):
     assert rel(sums[:, 1] / n, (conv.double() ** 2).mean((0, 2, 3))) < 1e-5
 
 
+@pytest.mark.parametrize("B,H,W,Ci,Co,k,s", [(2, 8, 8, 256, 128, 3, 1), (3, 4, 9, 128, 136, 1, 1), (1, 12, 40, 64, 256, 3, 2), (5, 9, 11, 48, 512, 3, 1),
+                                             (2, 16, 24, 264, 128, 1, 1), (1, 64, 8, 32, 128, 3, 1)])
+def test_gemm_shaped_weight_gradient_edges(dev, B, H, W, Ci, Co, k, s):
+    """conv_wgrad_gemm.hip at the edges of what it takes: output maps 8 pixels wide (four row wraps inside one 32-pixel chunk) and 4 rows
+    high (an image wrap per chunk), pixel counts that are not multiples of the chunk, 136 / 264 channels (ragged channel and column tiles,
+    cin_pad16 > Cin), stride 2, and both tiles (128 x 128, 256 x 256) -- against torch fp32 on fp16-valued operands."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(B * 31 + H + W + Ci + Co)
+    x16 = torch.randn(B, Ci, H, W, generator=g).half()
+    w = torch.zeros(Co, Ci, k, k, requires_grad=True)
+    ref = F.conv2d(x16.float(), w, None, s, k // 2)
+    OH, OW = ref.shape[2:]
+    dy16 = torch.randn(B, Co, OH, OW, generator=g).half()
+    ref.backward(dy16.float())
+    st = L.stream_ptr(dev)
+    xd, dyd = x16.permute(0, 2, 3, 1).contiguous().to(dev), dy16.permute(0, 2, 3, 1).contiguous().to(dev)
+    need = lib.cvx_conv2d_wgrad_workspace_bytes(B, OH, OW, Ci, Co, k)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    dw = torch.empty(Co, k, k, Ci, dtype=torch.float32, device=dev)
+    L.check(lib.cvx_conv2d_wgrad_nhwc(L.ptr(xd), L.ptr(dyd), B, H, W, Ci, Co, k, s, k // 2, 1, L.ptr(dw), L.ptr(ws), need, st), "wgrad")
+    assert rel(dw.permute(0, 3, 1, 2), w.grad) < 1e-5
+
+
 def test_conv_epilogues_affine_silu_and_bias(dev):
     lib = L.load()
     g = torch.Generator().manual_seed(3)
