@@ -167,6 +167,7 @@ struct cvx_engine {
   std::vector<int> fused_at;              // op index -> group that STARTS there, -1 otherwise
   ChainPackJob* d_chain_jobs = nullptr;   // weight pre-pack jobs of all groups (one launch per forward)
   int n_chain_jobs = 0, chain_max_units = 0;
+  std::vector<signed char> sppf3;         // per op: 1 = first of three chained 5x5 max pools (SPPF) that go out as one launch, 2 = the other two
   bool chain_fusion = false;  // off by default: parity-green but 1-6 % slower than the per-layer kernels at batch 32; cvx_engine_set_fusion
   // GEMM-shaped conv kernel: every routed layer's weights are re-ordered by ONE launch per forward, next to cvx_pack_weights
   half_t* gemm_arena = nullptr;
@@ -1050,6 +1051,21 @@ extern "C" int cvx_engine_create(cvx_engine** out, const cvx_buf_desc* bufs, int
     delete e;
     return rc;
   }
+  // SPPF (core/models/yolov8/modules.py:304-318): three chained 5x5 max pools whose maps fit in LDS go out as one launch each way
+  e->sppf3.assign(e->ops.size(), 0);
+  {
+    static const bool off = cvx_tune_set("CVX_NO_SPPF3");
+    for (size_t k = 0; !off && k + 2 < e->ops.size(); ++k) {
+      const cvx_op_desc &a = e->ops[k], &b = e->ops[k + 1], &c = e->ops[k + 2];
+      if (a.type != CVX_OP_MAXPOOL5 || b.type != CVX_OP_MAXPOOL5 || c.type != CVX_OP_MAXPOOL5) continue;
+      if (!same_view(b.in, a.out) || !same_view(c.in, b.out) || a.lane != b.lane || b.lane != c.lane) continue;
+      if (a.ih != b.ih || b.ih != c.ih || a.iw != b.iw || b.iw != c.iw || a.in.c != b.in.c || b.in.c != c.in.c) continue;
+      if (!cvx_sppf_pool3_fits(a.ih, a.iw)) continue;
+      e->sppf3[k] = 1;
+      e->sppf3[k + 1] = e->sppf3[k + 2] = 2;
+      k += 2;
+    }
+  }
   *out = e;
   return 0;
 }
@@ -1245,6 +1261,14 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
       continue;
     }
     if (o.type == CVX_OP_MAXPOOL5) {
+      if (!e->sppf3.empty() && e->sppf3[i] == 1) {  // SPPF: y1 = m(x), y2 = m(y1), y3 = m(y2) as one launch
+        ProfScope ps(e, PROF_MISC, 0, 8.0 * B * o.ih * o.iw * o.in.c, st);
+        CVX_TRY(cvx_sppf_pool3_fwd(make_view(e, o.in, false), make_view(e, o.out, false), make_view(e, e->ops[i + 1].out, false),
+                                   make_view(e, e->ops[i + 2].out, false), B, o.ih, o.iw, o.in.c, training ? e->pool[i].idx : nullptr,
+                                   training ? e->pool[i + 1].idx : nullptr, training ? e->pool[i + 2].idx : nullptr, st));
+        i += 2;
+        continue;
+      }
       ProfScope ps(e, PROF_MISC, 0, 4.0 * B * o.ih * o.iw * o.in.c, st);
       CVX_TRY(cvx_maxpool5_fwd(make_view(e, o.in, false), make_view(e, o.out, false), B, o.ih, o.iw, o.in.c,
                                training ? e->pool[i].idx : nullptr, st));
@@ -1504,6 +1528,17 @@ int backward_op(cvx_engine* e, int i) {
     if (!w.pending.empty() && w.pending_stream != st) CVX_TRY(flush_wgrads(e, e->ev_lane_fork, w.pending_stream));
     w.pending_stream = st;
     if (o.type == CVX_OP_MAXPOOL5) {
+      if (!e->sppf3.empty() && e->sppf3[i] == 2) {
+        if (i >= 2 && e->sppf3[i - 2] == 1) {  // the last pool of an SPPF triple, met first on the way back: the whole chain in one launch
+          const cvx_op_desc &p0 = e->ops[i - 2], &p1 = e->ops[i - 1];
+          ProfScope ps(e, PROF_MISC, 0, 14.0 * B * o.ih * o.iw * o.in.c, st);
+          const int acc_mask = (e->pool[i].in_accum ? 4 : 0) | (e->pool[i - 1].in_accum ? 2 : 0) | (e->pool[i - 2].in_accum ? 1 : 0);
+          CVX_TRY(cvx_sppf_pool3_bwd(make_view(e, o.out, true), make_view(e, o.in, true), make_view(e, p1.in, true), make_view(e, p0.in, true), B, o.ih,
+                                     o.iw, o.in.c, e->pool[i - 2].idx, e->pool[i - 1].idx, e->pool[i].idx, acc_mask, st));
+        }
+        return 0;  // (the middle pool: done with the last one)
+      }
+      if (!e->sppf3.empty() && e->sppf3[i] == 1) return 0;  // the first pool of the triple: done with the last one
       ProfScope ps(e, PROF_MISC, 0, 7.0 * B * o.ih * o.iw * o.in.c, st);
       CVX_TRY(cvx_maxpool5_bwd(make_view(e, o.out, true), make_view(e, o.in, true), B, o.ih, o.iw, o.in.c, e->pool[i].idx,
                                e->pool[i].in_accum, st));

@@ -49,6 +49,12 @@ int cvx_resize_bilinear_f32_nchw(const float* in, int ld, int B, int C, int IH, 
 int cvx_maxpool5_fwd(const ViewDesc& in, const ViewDesc& out, int B, int H, int W, int C, uint8_t* idx, hipStream_t st);
 // gin (+)= scatter of gout through idx, written gather-style (no atomics)
 int cvx_maxpool5_bwd(const ViewDesc& gout, const ViewDesc& gin, int B, int H, int W, int C, const uint8_t* idx, int accumulate, hipStream_t st);
+// SPPF's three chained 5x5 pools (y1 = m(x), y2 = m(y1), y3 = m(y2)) and their backward chain as one launch each
+bool cvx_sppf_pool3_fits(int H, int W);
+int cvx_sppf_pool3_fwd(const ViewDesc& in, const ViewDesc& o1, const ViewDesc& o2, const ViewDesc& o3, int B, int H, int W, int C, uint8_t* i1, uint8_t* i2,
+                       uint8_t* i3, hipStream_t st);
+int cvx_sppf_pool3_bwd(const ViewDesc& g3, const ViewDesc& g2, const ViewDesc& g1, const ViewDesc& g0, int B, int H, int W, int C, const uint8_t* i1,
+                       const uint8_t* i2, const uint8_t* i3, int acc_mask /* bit s: stage s accumulates into its input gradient */, hipStream_t st);
 
 int cvx_upsample2_fwd(const ViewDesc& in, const ViewDesc& out, int B, int H, int W, int C, hipStream_t st);  // (H,W) -> (2H,2W)
 int cvx_upsample2_bwd(const ViewDesc& gout, const ViewDesc& gin, int B, int H, int W, int C, int accumulate, hipStream_t st);

@@ -954,6 +954,138 @@ __global__ void maxpool5_bwd_kernel(ViewDesc gout, ViewDesc gin, int B, int H, i
   *reinterpret_cast<h8*>(q) = o;
 }
 
+// ---- SPPF: three chained 5x5 max pools in one launch ----------------------------------------------
+// SPPF.forward (core/models/yolov8/modules.py:304-318) pools x three times, each result feeding the next: y1 = m(x), y2 = m(y1), y3 = m(y2).
+// The maps are small (20 x 20 at 640 x 640 input), so the three launches were pure latency (46 + 35 + 35 us at batch 32).  Here a workgroup
+// keeps the H x W map of one image and one 8-channel group in LDS, pools it three times (ping-pong) and writes every stage to its slice
+// of the concat buffer (+ the argmax bytes in training).  Scan order and tie-breaking are those of maxpool5_fwd_kernel: same bits.
+__device__ __forceinline__ h8 pool5_at(const h8* src, int h, int w, int H, int W, unsigned long long* pk_out) {
+  float best[8];
+  int bi[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    best[k] = -INFINITY;
+    bi[k] = 0;
+  }
+  bool first = true;
+#pragma unroll
+  for (int dy = 0; dy < 5; ++dy) {
+    const int hh = h + dy - 2;
+    if (hh < 0 || hh >= H) continue;
+#pragma unroll
+    for (int dx = 0; dx < 5; ++dx) {
+      const int ww = w + dx - 2;
+      if (ww < 0 || ww >= W) continue;
+      const h8 v = src[hh * W + ww];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float f = (float)v[k];
+        if (first || f > best[k]) {
+          best[k] = f;
+          bi[k] = dy * 5 + dx;
+        }
+      }
+      first = false;
+    }
+  }
+  h8 o;
+  unsigned long long pk = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    o[k] = (half_t)best[k];
+    pk |= (unsigned long long)(bi[k] & 0xff) << (8 * k);
+  }
+  *pk_out = pk;
+  return o;
+}
+
+__global__ __launch_bounds__(256) void sppf_pool3_fwd_kernel(ViewDesc in, ViewDesc o1, ViewDesc o2, ViewDesc o3, int H, int W, int CG, uint8_t* i1,
+                                                             uint8_t* i2, uint8_t* i3) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sppf_lds[];
+  h8* buf = reinterpret_cast<h8*>(sppf_lds);
+  const int HW = H * W;
+  const int b = blockIdx.x / CG, cg = blockIdx.x - b * CG;
+  for (int p = threadIdx.x; p < HW; p += 256) buf[p] = *reinterpret_cast<const h8*>(in.p + voff(in, b, p) + cg * 8);
+  __syncthreads();
+  h8 *src = buf, *dst = buf + HW;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const ViewDesc& out = s == 0 ? o1 : s == 1 ? o2 : o3;
+    uint8_t* idx = s == 0 ? i1 : s == 1 ? i2 : i3;
+    for (int p = threadIdx.x; p < HW; p += 256) {
+      const int h = p / W, w = p - h * W;
+      unsigned long long pk;
+      const h8 o = pool5_at(src, h, w, H, W, &pk);
+      dst[p] = o;
+      *reinterpret_cast<h8*>(out.p + voff(out, b, p) + cg * 8) = o;
+      if (idx) *reinterpret_cast<unsigned long long*>(idx + (((long long)b * HW + p) * CG + cg) * 8) = pk;
+    }
+    __syncthreads();
+    h8* t = src;
+    src = dst;
+    dst = t;
+  }
+}
+
+// The backward chain of the same three pools in one launch: g(y2) += route3(g(y3)), g(y1) += route2(g(y2)), g(x) (+)= route1(g(y1)), each stage
+// rounded to fp16 like the tensors the three launches passed to each other (same bits).
+__global__ __launch_bounds__(256) void sppf_pool3_bwd_kernel(ViewDesc g3, ViewDesc g2, ViewDesc g1, ViewDesc g0, int H, int W, int CG, const uint8_t* i1,
+                                                             const uint8_t* i2, const uint8_t* i3, int acc_mask) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sppf_lds[];
+  const int HW = H * W;
+  h8* gcur = reinterpret_cast<h8*>(sppf_lds);                        // gradient of the stage's output
+  h8* gnext = gcur + HW;                                              // ... of its input, being built
+  unsigned long long* pks = reinterpret_cast<unsigned long long*>(gnext + HW);  // the stage's argmax bytes
+  const int b = blockIdx.x / CG, cg = blockIdx.x - b * CG;
+  for (int p = threadIdx.x; p < HW; p += 256) gcur[p] = *reinterpret_cast<const h8*>(g3.p + voff(g3, b, p) + cg * 8);
+#pragma unroll
+  for (int s = 2; s >= 0; --s) {
+    const uint8_t* idx = s == 2 ? i3 : s == 1 ? i2 : i1;
+    const ViewDesc& gin = s == 2 ? g2 : s == 1 ? g1 : g0;
+    const bool acc = ((acc_mask >> s) & 1) != 0;  // the stage's input gradient already holds the concat consumer's share
+    for (int p = threadIdx.x; p < HW; p += 256) pks[p] = *reinterpret_cast<const unsigned long long*>(idx + (((long long)b * HW + p) * CG + cg) * 8);
+    __syncthreads();
+    for (int p = threadIdx.x; p < HW; p += 256) {
+      const int h = p / W, w = p - h * W;
+      float a[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a[k] = 0.f;
+      // output (oh, ow) whose window contains (h, w): its tap for this input is (h - oh + 2, w - ow + 2); the order of maxpool5_bwd_kernel
+#pragma unroll
+      for (int dy = 0; dy < 5; ++dy) {
+        const int oh = h + dy - 2;
+        if (oh < 0 || oh >= H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) {
+          const int ow = w + dx - 2;
+          if (ow < 0 || ow >= W) continue;
+          const unsigned long long pk = pks[oh * W + ow];
+          const h8 g = gcur[oh * W + ow];
+          const int tapcode = (4 - dy) * 5 + (4 - dx);
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if ((int)((pk >> (8 * k)) & 0xff) == tapcode) a[k] += (float)g[k];
+        }
+      }
+      half_t* q = gin.p + voff(gin, b, p) + cg * 8;
+      if (acc) {
+        const h8 old = *reinterpret_cast<const h8*>(q);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] += (float)old[k];
+      }
+      h8 o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = (half_t)a[k];
+      gnext[p] = o;
+      *reinterpret_cast<h8*>(q) = o;  // every stage's total goes back to its gradient slice, like the three launches left them (debug copies, tests)
+    }
+    __syncthreads();
+    h8* t = gcur;
+    gcur = gnext;
+    gnext = t;
+  }
+}
+
 // ---- nearest 2x upsample -----------------------------------------------------------------------
 __global__ void upsample2_fwd_kernel(ViewDesc in, ViewDesc out, int B, int H, int W, int CG) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over OUTPUT elements
@@ -1296,6 +1428,22 @@ int cvx_bias_act_bwd(const ViewDesc& gout, const ViewDesc& fout, int relu, long 
 int cvx_maxpool5_fwd(const ViewDesc& in, const ViewDesc& out, int B, int H, int W, int C, uint8_t* idx, hipStream_t st) {
   CVX_CHECK(C % 8 == 0, "maxpool5: C % 8");
   return launch1d(maxpool5_fwd_kernel, (long long)B * H * W * (C / 8), st, in, out, B, H, W, C / 8, idx);
+}
+// maps the fused SPPF kernels hold in LDS (two fp16 maps + the argmax bytes of one stage: 40 bytes per pixel)
+bool cvx_sppf_pool3_fits(int H, int W) { return (long long)H * W * 40 <= 60 * 1024; }
+int cvx_sppf_pool3_fwd(const ViewDesc& in, const ViewDesc& o1, const ViewDesc& o2, const ViewDesc& o3, int B, int H, int W, int C, uint8_t* i1, uint8_t* i2,
+                       uint8_t* i3, hipStream_t st) {
+  CVX_CHECK(C % 8 == 0 && cvx_sppf_pool3_fits(H, W), "sppf_pool3: C % 8, map size");
+  hipLaunchKernelGGL(sppf_pool3_fwd_kernel, dim3(B * (C / 8)), dim3(256), (size_t)H * W * 32, st, in, o1, o2, o3, H, W, C / 8, i1, i2, i3);
+  CVX_HIP(hipGetLastError());
+  return 0;
+}
+int cvx_sppf_pool3_bwd(const ViewDesc& g3, const ViewDesc& g2, const ViewDesc& g1, const ViewDesc& g0, int B, int H, int W, int C, const uint8_t* i1,
+                       const uint8_t* i2, const uint8_t* i3, int acc_mask, hipStream_t st) {
+  CVX_CHECK(C % 8 == 0 && cvx_sppf_pool3_fits(H, W) && i1 && i2 && i3, "sppf_pool3_bwd: C % 8, map size, idx");
+  hipLaunchKernelGGL(sppf_pool3_bwd_kernel, dim3(B * (C / 8)), dim3(256), (size_t)H * W * 40, st, g3, g2, g1, g0, H, W, C / 8, i1, i2, i3, acc_mask);
+  CVX_HIP(hipGetLastError());
+  return 0;
 }
 int cvx_maxpool5_bwd(const ViewDesc& gout, const ViewDesc& gin, int B, int H, int W, int C, const uint8_t* idx, int accumulate, hipStream_t st) {
   CVX_CHECK(C % 8 == 0 && idx, "maxpool5_bwd: C % 8 / idx");
