@@ -959,34 +959,56 @@ __global__ void maxpool5_bwd_kernel(ViewDesc gout, ViewDesc gin, int B, int H, i
 // The maps are small (20 x 20 at 640 x 640 input), so the three launches were pure latency (46 + 35 + 35 us at batch 32).  Here a workgroup
 // keeps the H x W map of one image and one 8-channel group in LDS, pools it three times (ping-pong) and writes every stage to its slice
 // of the concat buffer (+ the argmax bytes in training).  Scan order and tie-breaking are those of maxpool5_fwd_kernel: same bits.
-__device__ __forceinline__ h8 pool5_at(const h8* src, int h, int w, int H, int W, unsigned long long* pk_out) {
+// One 5x5 pool as two separable passes with the 2-D scan's tie-breaking: the first maximum in (dy, dx) scan order is, among the rows in dy
+// order, the first one whose row maximum equals the window maximum, and inside it the first dx that reaches it.  10 instead of 25 window
+// reads and compare chains per pixel.
+__device__ __forceinline__ void pool5_row(const h8* src, int h, int w, int W, h8* rm, unsigned* ri) {
   float best[8];
   int bi[8];
+  bool first = true;
+#pragma unroll
+  for (int dx = 0; dx < 5; ++dx) {
+    const int ww = w + dx - 2;
+    const bool ok = ww >= 0 && ww < W;
+    const h8 v = src[h * W + min(max(ww, 0), W - 1)];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float f = (float)v[k];
+      const bool take = ok && (first || f > best[k]);
+      best[k] = take ? f : (first ? -INFINITY : best[k]);
+      bi[k] = take ? dx : (first ? 0 : bi[k]);
+    }
+    first = first && !ok;
+  }
+  h8 o;
+  unsigned pk = 0;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    best[k] = -INFINITY;
-    bi[k] = 0;
+    o[k] = (half_t)best[k];
+    pk |= (unsigned)bi[k] << (4 * k);
   }
+  rm[h * W + w] = o;
+  ri[h * W + w] = pk;
+}
+__device__ __forceinline__ h8 pool5_col(const h8* rm, const unsigned* ri, int h, int w, int H, int W, unsigned long long* pk_out) {
+  float best[8];
+  int bi[8];
   bool first = true;
 #pragma unroll
   for (int dy = 0; dy < 5; ++dy) {
     const int hh = h + dy - 2;
-    if (hh < 0 || hh >= H) continue;
+    const bool ok = hh >= 0 && hh < H;
+    const int q = min(max(hh, 0), H - 1) * W + w;
+    const h8 v = rm[q];
+    const unsigned di = ri[q];
 #pragma unroll
-    for (int dx = 0; dx < 5; ++dx) {
-      const int ww = w + dx - 2;
-      if (ww < 0 || ww >= W) continue;
-      const h8 v = src[hh * W + ww];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float f = (float)v[k];
-        if (first || f > best[k]) {
-          best[k] = f;
-          bi[k] = dy * 5 + dx;
-        }
-      }
-      first = false;
+    for (int k = 0; k < 8; ++k) {
+      const float f = (float)v[k];
+      const bool take = ok && (first || f > best[k]);
+      best[k] = take ? f : (first ? -INFINITY : best[k]);
+      bi[k] = take ? dy * 5 + (int)((di >> (4 * k)) & 7u) : (first ? 0 : bi[k]);
     }
+    first = first && !ok;
   }
   h8 o;
   unsigned long long pk = 0;
@@ -999,76 +1021,77 @@ __device__ __forceinline__ h8 pool5_at(const h8* src, int h, int w, int H, int W
   return o;
 }
 
+constexpr int SPPF_FWD_BYTES_PER_PIXEL = 16 + 16 + 4;  // stage map | row maxima | row argmax nibbles
+constexpr int SPPF_BWD_BYTES_PER_PIXEL = 16 + 32;      // stage gradient (fp16) | fp32 accumulators of the stage's input gradient
+
 __global__ __launch_bounds__(256) void sppf_pool3_fwd_kernel(ViewDesc in, ViewDesc o1, ViewDesc o2, ViewDesc o3, int H, int W, int CG, uint8_t* i1,
                                                              uint8_t* i2, uint8_t* i3) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sppf_lds[];
-  h8* buf = reinterpret_cast<h8*>(sppf_lds);
   const int HW = H * W;
+  h8* cur = reinterpret_cast<h8*>(sppf_lds);
+  h8* rm = cur + HW;
+  unsigned* ri = reinterpret_cast<unsigned*>(rm + HW);
   const int b = blockIdx.x / CG, cg = blockIdx.x - b * CG;
-  for (int p = threadIdx.x; p < HW; p += 256) buf[p] = *reinterpret_cast<const h8*>(in.p + voff(in, b, p) + cg * 8);
+  for (int p = threadIdx.x; p < HW; p += 256) cur[p] = *reinterpret_cast<const h8*>(in.p + voff(in, b, p) + cg * 8);
   __syncthreads();
-  h8 *src = buf, *dst = buf + HW;
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
     const ViewDesc& out = s == 0 ? o1 : s == 1 ? o2 : o3;
     uint8_t* idx = s == 0 ? i1 : s == 1 ? i2 : i3;
     for (int p = threadIdx.x; p < HW; p += 256) {
-      const int h = p / W, w = p - h * W;
+      const int h = p / W;
+      pool5_row(cur, h, p - h * W, W, rm, ri);
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < HW; p += 256) {
+      const int h = p / W;
       unsigned long long pk;
-      const h8 o = pool5_at(src, h, w, H, W, &pk);
-      dst[p] = o;
+      const h8 o = pool5_col(rm, ri, h, p - h * W, H, W, &pk);
+      cur[p] = o;  // (the row pass of this stage is complete: the map can take the next stage's input)
       *reinterpret_cast<h8*>(out.p + voff(out, b, p) + cg * 8) = o;
       if (idx) *reinterpret_cast<unsigned long long*>(idx + (((long long)b * HW + p) * CG + cg) * 8) = pk;
     }
     __syncthreads();
-    h8* t = src;
-    src = dst;
-    dst = t;
   }
 }
 
 // The backward chain of the same three pools in one launch: g(y2) += route3(g(y3)), g(y1) += route2(g(y2)), g(x) (+)= route1(g(y1)), each stage
-// rounded to fp16 like the tensors the three launches passed to each other (same bits).
+// rounded to fp16 like the tensors the three launches passed to each other.  Every output pixel sends its gradient to the ONE input pixel its
+// argmax byte names (an fp32 LDS atomic per channel) instead of every input pixel searching the 25 outputs that could have picked it; the
+// fp32 sums are the same up to the order of the additions.
 __global__ __launch_bounds__(256) void sppf_pool3_bwd_kernel(ViewDesc g3, ViewDesc g2, ViewDesc g1, ViewDesc g0, int H, int W, int CG, const uint8_t* i1,
                                                              const uint8_t* i2, const uint8_t* i3, int acc_mask) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sppf_lds[];
   const int HW = H * W;
-  h8* gcur = reinterpret_cast<h8*>(sppf_lds);                        // gradient of the stage's output
-  h8* gnext = gcur + HW;                                              // ... of its input, being built
-  unsigned long long* pks = reinterpret_cast<unsigned long long*>(gnext + HW);  // the stage's argmax bytes
+  h8* gcur = reinterpret_cast<h8*>(sppf_lds);              // gradient of the stage's output
+  float* acc = reinterpret_cast<float*>(gcur + HW);        // [HW][8] gradient of its input, being summed
   const int b = blockIdx.x / CG, cg = blockIdx.x - b * CG;
   for (int p = threadIdx.x; p < HW; p += 256) gcur[p] = *reinterpret_cast<const h8*>(g3.p + voff(g3, b, p) + cg * 8);
 #pragma unroll
   for (int s = 2; s >= 0; --s) {
     const uint8_t* idx = s == 2 ? i3 : s == 1 ? i2 : i1;
     const ViewDesc& gin = s == 2 ? g2 : s == 1 ? g1 : g0;
-    const bool acc = ((acc_mask >> s) & 1) != 0;  // the stage's input gradient already holds the concat consumer's share
-    for (int p = threadIdx.x; p < HW; p += 256) pks[p] = *reinterpret_cast<const unsigned long long*>(idx + (((long long)b * HW + p) * CG + cg) * 8);
+    const bool accumulate = ((acc_mask >> s) & 1) != 0;  // the stage's input gradient already holds the concat consumer's share
+    for (int t = threadIdx.x; t < HW * 8; t += 256) acc[t] = 0.f;
     __syncthreads();
     for (int p = threadIdx.x; p < HW; p += 256) {
       const int h = p / W, w = p - h * W;
+      const unsigned long long pk = *reinterpret_cast<const unsigned long long*>(idx + (((long long)b * HW + p) * CG + cg) * 8);
+      const h8 g = gcur[p];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int tap = (int)((pk >> (8 * k)) & 0xff);
+        const int dy = tap / 5, dx = tap - dy * 5;
+        atomicAdd(&acc[((h + dy - 2) * W + (w + dx - 2)) * 8 + k], (float)g[k]);
+      }
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < HW; p += 256) {
+      half_t* q = gin.p + voff(gin, b, p) + cg * 8;
       float a[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) a[k] = 0.f;
-      // output (oh, ow) whose window contains (h, w): its tap for this input is (h - oh + 2, w - ow + 2); the order of maxpool5_bwd_kernel
-#pragma unroll
-      for (int dy = 0; dy < 5; ++dy) {
-        const int oh = h + dy - 2;
-        if (oh < 0 || oh >= H) continue;
-#pragma unroll
-        for (int dx = 0; dx < 5; ++dx) {
-          const int ow = w + dx - 2;
-          if (ow < 0 || ow >= W) continue;
-          const unsigned long long pk = pks[oh * W + ow];
-          const h8 g = gcur[oh * W + ow];
-          const int tapcode = (4 - dy) * 5 + (4 - dx);
-#pragma unroll
-          for (int k = 0; k < 8; ++k)
-            if ((int)((pk >> (8 * k)) & 0xff) == tapcode) a[k] += (float)g[k];
-        }
-      }
-      half_t* q = gin.p + voff(gin, b, p) + cg * 8;
-      if (acc) {
+      for (int k = 0; k < 8; ++k) a[k] = acc[p * 8 + k];
+      if (accumulate) {
         const h8 old = *reinterpret_cast<const h8*>(q);
 #pragma unroll
         for (int k = 0; k < 8; ++k) a[k] += (float)old[k];
@@ -1076,13 +1099,10 @@ __global__ __launch_bounds__(256) void sppf_pool3_bwd_kernel(ViewDesc g3, ViewDe
       h8 o;
 #pragma unroll
       for (int k = 0; k < 8; ++k) o[k] = (half_t)a[k];
-      gnext[p] = o;
-      *reinterpret_cast<h8*>(q) = o;  // every stage's total goes back to its gradient slice, like the three launches left them (debug copies, tests)
+      gcur[p] = o;                         // the next stage's output gradient
+      *reinterpret_cast<h8*>(q) = o;       // every stage's total goes back to its slice, like the three launches left them
     }
     __syncthreads();
-    h8* t = gcur;
-    gcur = gnext;
-    gnext = t;
   }
 }
 
@@ -1429,19 +1449,19 @@ int cvx_maxpool5_fwd(const ViewDesc& in, const ViewDesc& out, int B, int H, int 
   CVX_CHECK(C % 8 == 0, "maxpool5: C % 8");
   return launch1d(maxpool5_fwd_kernel, (long long)B * H * W * (C / 8), st, in, out, B, H, W, C / 8, idx);
 }
-// maps the fused SPPF kernels hold in LDS (two fp16 maps + the argmax bytes of one stage: 40 bytes per pixel)
-bool cvx_sppf_pool3_fits(int H, int W) { return (long long)H * W * 40 <= 60 * 1024; }
+// maps the fused SPPF kernels hold in LDS (36 bytes per pixel forward, 48 backward)
+bool cvx_sppf_pool3_fits(int H, int W) { return (long long)H * W * SPPF_BWD_BYTES_PER_PIXEL <= 60 * 1024; }
 int cvx_sppf_pool3_fwd(const ViewDesc& in, const ViewDesc& o1, const ViewDesc& o2, const ViewDesc& o3, int B, int H, int W, int C, uint8_t* i1, uint8_t* i2,
                        uint8_t* i3, hipStream_t st) {
   CVX_CHECK(C % 8 == 0 && cvx_sppf_pool3_fits(H, W), "sppf_pool3: C % 8, map size");
-  hipLaunchKernelGGL(sppf_pool3_fwd_kernel, dim3(B * (C / 8)), dim3(256), (size_t)H * W * 32, st, in, o1, o2, o3, H, W, C / 8, i1, i2, i3);
+  hipLaunchKernelGGL(sppf_pool3_fwd_kernel, dim3(B * (C / 8)), dim3(256), (size_t)H * W * SPPF_FWD_BYTES_PER_PIXEL, st, in, o1, o2, o3, H, W, C / 8, i1, i2, i3);
   CVX_HIP(hipGetLastError());
   return 0;
 }
 int cvx_sppf_pool3_bwd(const ViewDesc& g3, const ViewDesc& g2, const ViewDesc& g1, const ViewDesc& g0, int B, int H, int W, int C, const uint8_t* i1,
                        const uint8_t* i2, const uint8_t* i3, int acc_mask, hipStream_t st) {
   CVX_CHECK(C % 8 == 0 && cvx_sppf_pool3_fits(H, W) && i1 && i2 && i3, "sppf_pool3_bwd: C % 8, map size, idx");
-  hipLaunchKernelGGL(sppf_pool3_bwd_kernel, dim3(B * (C / 8)), dim3(256), (size_t)H * W * 40, st, g3, g2, g1, g0, H, W, C / 8, i1, i2, i3, acc_mask);
+  hipLaunchKernelGGL(sppf_pool3_bwd_kernel, dim3(B * (C / 8)), dim3(256), (size_t)H * W * SPPF_BWD_BYTES_PER_PIXEL, st, g3, g2, g1, g0, H, W, C / 8, i1, i2, i3, acc_mask);
   CVX_HIP(hipGetLastError());
   return 0;
 }
