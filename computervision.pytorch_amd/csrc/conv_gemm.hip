@@ -1,27 +1,27 @@
-// GEMM-shaped implicit convolution for the big-channel layers (gfx950): K = taps * Cin large, Cin a multiple of 32 -- VGG's 256..1024-
-// channel 3x3 layers, ResNet-101's bottleneck 1x1 / 3x3 convs, the atrous ASPP branches, their data gradients.
+// GEMM-shaped implicit convolution (gfx950) for every forward / data-gradient launch with ~100 output channels and more (VGG, ResNet-101, ASPP,
+// DLA-34, YOLOv7, YOLOv8-s and up, YOLOv8-n's 96+-channel layers).  M = pixels, N = output channels, K = taps * Cin (Cin % 8 == 0: ragged last chunk).
 //
 //   * 512 threads = 8 waves as 4 (pixels) x 2 (channels); macro tile BM x BN = (4 * MT * 32) x (2 * NT * 32): 256 x 256, 256 x 128,
 //     128 x 256 or 128 x 128; every wave owns MT x NT tiles of v_mfma_f32_32x32x16_f16 (weights as the A operand: a lane ends up with
 //     4 consecutive channels of one pixel);
-//   * BOTH operands stream through one LDS-DMA ring of 32 (or 64: small tiles) K-values per chunk = 2 (4) MFMA K-steps, 3-4 slots, the chunks beyond the
-//     one being computed, issued as `buffer_load_dwordx4 ... lds` (tools/micro/buffer_lds_probe.hip: out-of-range lanes deliver zeros,
-//     LDS destinations above 64 KiB work):
-//       - pixels: the implicit-GEMM gather -- chunk (tap, 32 channels) of pixel p is 64 contiguous bytes of the NHWC view.  A lane's
-//         byte offset (pixel, 8-channel group) is computed ONCE; per tap one compare + select turns it into ~0 where the tap falls
-//         outside the image, and the hardware range check writes the zeros; per chunk only the scalar offset moves.  No pad units:
-//         LDS unit (16 B) pixel * 4 + (group ^ ((pixel >> 2) & 3)) -- the swizzle is applied on the global side (which group a lane
-//         fetches), so the 32 lanes of a fragment read fall on 32 different 16-byte slots (tools/lds_conflicts.py);
-//       - weights: pre-packed once per launch into the ring image order ([chunk][K-step][k-half][BN rows][8]: gemm_pack_kernel), so a
+//   * BOTH operands stream through one LDS ring of chunks of KC = 32 (or 64: small tiles) K-values = 2 (4) MFMA K-steps, 3 or 4 slots
+//     (kVariants below), every chunk beyond the one being computed in flight, issued as `buffer_load_dwordx4 ... lds`
+//     (tools/micro/buffer_lds_probe.hip: out-of-range lanes deliver zeros, LDS destinations above 64 KiB work):
+//       - pixels: the implicit-GEMM gather -- chunk (tap, KC channels) of pixel p is KC * 2 contiguous bytes of the NHWC view.  A lane's byte offset
+//         is computed ONCE; per tap one compare + select makes it ~0 where the tap leaves the image (hardware zero fill); per chunk a scalar moves.
+//         LDS unit (16 B) pixel * UPP + (group ^ swizzle(pixel)) -- the swizzle is applied on the global side (which group a lane
+//         fetches), so the lanes of a fragment read fall on different 16-byte slots (tools/lds_conflicts.py);
+//       - weights: in the ring image order ([channel tile][chunk][K-step][k-half][BN rows][8]), re-ordered for ALL routed layers of a
+//         forward by one launch (gemm_pack_jobs_kernel, planned by the engine) or by the launch itself (stand-alone entry points), so a
 //         chunk is one contiguous block and every DMA piece reads 1 KiB of consecutive bytes;
-//     every wave issues the same MT + NT / 2 DMA instructions per chunk: counted vmcnt needs no dummy transfers;
-//   * software pipeline over K-steps: the fragments of K-step 1 are requested before the MFMAs of K-step 0, the workgroup barrier
-//     that publishes chunk c + 1 sits BETWEEN the two MFMA blocks of chunk c, and the fragments of (c + 1, K-step 0) are requested
-//     before the MFMAs of (c, K-step 1) -- every ds_read has a full MFMA block (8 x 32 cycles at 2 x 4 tiles) to land.  Inline-asm
-//     ds_read / s_waitcnt: the compiler's own waitcnt insertion would put lgkmcnt(0) in front of every MFMA block;
-//   * blockIdx -> (pixel tile, channel tile) keeps the channel tiles of one pixel tile on one XCD (they share the gathered pixels in
-//     that XCD's L2).
-// Roofline: MFMA (these shapes sit above the 315 FLOP/B ridge).  Algorithmic bytes per launch: engine.hip conv_bytes.
+//     every wave issues the same number of DMA instructions per chunk (counted vmcnt, no dummy transfers);
+//   * K loop: the workgroup barrier that publishes chunk c + 1 stands at the TOP of iteration c and is followed at once by an MFMA block
+//     whose fragments were requested a block earlier (MFMA issue blocks the wave and the pipe holds no queue: cycles between a barrier
+//     and the next MFMA are lost outright); two fragment sets alternate, the set an MFMA block consumed is refilled with the K-step two
+//     ahead.  Inline-asm ds_read / s_waitcnt: the compiler's own waitcnt insertion would put lgkmcnt(0) in front of every MFMA block;
+//   * epilogues: fp16 outputs and the training epilogue's raw fp32 rows are transposed through the idle ring (contiguous stores); DPP statistics;
+//   * blockIdx -> (pixel tile, channel tile) keeps the channel tiles of one pixel tile on one XCD (shared gathered pixels in its L2).
+// Roofline: MFMA.  Measured bounds, ablations, cost model: DESIGN.md 5b, profiles/r03_gemm_*.
 #include <algorithm>
 #include <cstring>
 #include <map>
