@@ -688,7 +688,11 @@ bool cvx_conv_gemm_supported(const ConvParams& p) {
   // channel tiles are 128 wide: a layer that fills under 70 % of them (YOLOv8-n's Detect convs, 64 + 80 = 144 channels: 56 %) computes mostly
   // padding -- measured 114 vs 56 us (80x80 64->144) and 153 vs 114 us (40x40 128->144) against the halo / ring kernels
   const int padded = (p.Cout + 127) / 128 * 128;
-  return K >= kmin && p.Cout >= cmin && M >= mmin && 2.0 * (double)M * (double)K * p.Cout >= gfmin * 1e9 && p.Cout * 10 >= padded * 7;
+  // ... except where K is so deep that the ring kernel's re-gathering (every input pixel once per tap, per 64-channel output block) costs more
+  // than computing padding: SSD's loc / conf heads (3x3 on 512..1024 channels, 16..88 outputs)
+  static const int bigk = cvx_tune_int("CVX_GEMM_BIGK", 2304);  // SSD inference 7895 -> 8134 img/s, the other workloads unchanged
+  const bool deep = K >= bigk && p.Cout >= 8;
+  return K >= kmin && M >= mmin && 2.0 * (double)M * (double)K * p.Cout >= gfmin * 1e9 && (deep || (p.Cout >= cmin && p.Cout * 10 >= padded * 7));
 }
 
 // Variant by cost model: time of one workgroup = chunks * chunk_us + fixed_us, times the rounds the grid needs on 256 CUs (x per_cu).  The model

@@ -78,7 +78,8 @@ CONV_CASES = [(2, 16, 16, 16, 16, 3, 1), (2, 20, 20, 8, 16, 3, 2), (1, 24, 24, 3
               (3, 27, 31, 160, 200, 3, 1)]
 GEMM_CASES = [(8, 19, 19, 512, 512, 3, 1, 1), (2, 38, 38, 256, 512, 3, 1, 1), (4, 33, 33, 1024, 256, 1, 1, 1), (8, 40, 40, 128, 256, 3, 2, 1),
               (3, 27, 31, 160, 200, 3, 1, 1), (2, 33, 33, 256, 256, 3, 1, 2), (1, 9, 9, 32, 68, 3, 1, 1), (40, 38, 38, 512, 512, 3, 1, 1),
-              (2, 33, 33, 304, 256, 3, 1, 1), (3, 20, 20, 80, 144, 3, 1, 1), (2, 24, 24, 8, 128, 1, 1, 1)]  # Cin % 32 != 0: ragged last chunk of every tap
+              (2, 33, 33, 304, 256, 3, 1, 1), (3, 20, 20, 80, 144, 3, 1, 1), (2, 24, 24, 8, 128, 1, 1, 1),  # Cin % 32 != 0: ragged last chunk of every tap
+              (2, 19, 19, 512, 24, 3, 1, 1), (1, 38, 38, 256, 16, 3, 1, 1), (2, 10, 10, 512, 88, 3, 1, 1)]  # SSD's loc / conf heads: deep K, few outputs
 
 
 @pytest.mark.parametrize("B,H,W,C,f", [(2, 12, 10, 64, 2), (1, 7, 9, 24, 2), (2, 6, 5, 64, 4), (1, 5, 4, 16, 8), (1, 3, 3, 520, 2), (3, 24, 24, 256, 2)])
