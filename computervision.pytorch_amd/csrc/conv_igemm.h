@@ -73,6 +73,7 @@ struct ConvParams {
   const half_t* wt_packed;
   int wt_packed_bn, wt_packed_kc;  // channel-tile rows and K-values per chunk of that image
   int std7x7;                      // 1 when the table is the 7x7 / pad 3 / dilation 1 neighbourhood in row-major order (conv_stem7.hip)
+  int std3x3;                      // likewise 3x3 / pad 1 (cvx_taps_std3x3)
   int gemm_variant;                // unit tests: run this variant of the GEMM-shaped kernel (conv_gemm.hip: kVariants index + 1), 0 = the cost model's
 };
 

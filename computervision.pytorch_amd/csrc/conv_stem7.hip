@@ -1,5 +1,5 @@
-// 7x7 / pad 3 first-layer convolution on the 8-channel-padded fp16 copy of the image (gfx950): DLA-34's base layer (stride 1, 16 channels,
-// core/models/dla.py) and ResNet's conv1 (stride 2, 64 channels, core/models/resnet.py:121-143).  The generic ring kernel gathers every
+// First-layer convolution (7x7 / pad 3, or 3x3 / pad 1) on the 8-channel-padded fp16 copy of the image (gfx950): DLA-34's base layer (7x7,
+// stride 1, 16 channels, core/models/dla.py), ResNet's conv1 (7x7, stride 2, 64 channels, core/models/resnet.py:121-143), YOLOv7's first layer (3x3, 32).  The generic ring kernel gathers every
 // input pixel 49 times through the L2 -> LDS path (784 bytes per output pixel: 1.26 ms for CenterNet's 64 x 512 x 512 batch); here a
 // persistent workgroup walks 8 x 64 output tiles with the input patch ((8 - 1) s + 7 rows x (64 - 1) s + 7 + 1 columns, 16 bytes per pixel)
 // resident in LDS, double-buffered, loaded by `buffer_load ... lds` with hardware zero fill at the image border:
@@ -21,24 +21,28 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int TH7 = 8, TW7 = 64;  // output tile
 
-template <int S, int NCO>
+template <int KSZ, int S, int NCO>
 struct Stem7Geom {
-  static constexpr int PR = (TH7 - 1) * S + 7;        // patch rows
-  static constexpr int PC = (TW7 - 1) * S + 7;        // patch columns that hold image pixels
-  static constexpr int PCW = PC + 1;                  // + one zero column: the kw = 7 operand of the last output column
+  static constexpr int HS = (KSZ + 3) / 4;            // MFMA K-steps (4 pixels each) per kernel row: 7 -> 2, 3 -> 1
+  static constexpr int NK = KSZ * HS;                 // K-steps per output
+  static constexpr int PR = (TH7 - 1) * S + KSZ;      // patch rows
+  static constexpr int PC = (TW7 - 1) * S + KSZ;      // patch columns that hold image pixels
+  static constexpr int PCW = PC + (4 * HS - KSZ);     // + zero columns: the operands of the non-existent kw >= KSZ of the last output column
   static constexpr int UNITS = PR * PCW;              // 16-byte units
   static constexpr int PIECES = (UNITS + 63) / 64;    // 1-KiB DMA pieces
   static constexpr int PPW = (PIECES + 3) / 4;        // per wave
   static constexpr int PATCH_BYTES = PIECES * 1024;
-  static constexpr int W_BYTES = NCO > 1 ? 14 * NCO * 64 * 16 : 0;  // fragment-ordered weights [kh][half][co block][lane] x 16 B
+  static constexpr bool W_REGS = NK * NCO <= 14;      // the weight fragments fit the register budget (4 VGPRs each)
+  static constexpr int W_BYTES = W_REGS ? 0 : NK * NCO * 64 * 16;  // else: fragment-ordered image [kh][half][co block][lane] x 16 B
   static constexpr int STAT_BYTES = 4 * 16 * NCO * 2 * 4;
   static constexpr int LDS_BYTES = 2 * PATCH_BYTES + W_BYTES + STAT_BYTES;
 };
 
-template <int S, int NCO>
+template <int KSZ, int S, int NCO>
 __global__ __launch_bounds__(256) void conv_stem7_kernel(const ConvParams p, int tiles_w, int tiles_h, int ntiles) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (and has no __amdgpu_buffer_rsrc_t)
-  using G = Stem7Geom<S, NCO>;
+  using G = Stem7Geom<KSZ, S, NCO>;
+  constexpr int HS = G::HS, NK = G::NK, PAD = KSZ / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sW = smem + 2 * G::PATCH_BYTES;
   float* sStat = reinterpret_cast<float*>(smem + 2 * G::PATCH_BYTES + G::W_BYTES);
@@ -50,15 +54,17 @@ __global__ __launch_bounds__(256) void conv_stem7_kernel(const ConvParams p, int
   auto wfrag = [&](int kh, int half, int n) -> h8 {
     const int kw = half * 4 + fq, co = n * 16 + fr;
     h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (kw < 7 && co < p.Cout) v = *reinterpret_cast<const h8*>(p.wt + (long long)co * p.wt_ld + (kh * 7 + kw) * 8);
+    if (kw < KSZ && co < p.Cout) v = *reinterpret_cast<const h8*>(p.wt + (long long)co * p.wt_ld + (kh * KSZ + kw) * 8);
     return v;
   };
-  h8 wreg[NCO == 1 ? 14 : 1];
-  if constexpr (NCO == 1) {
+  h8 wreg[G::W_REGS ? NK * NCO : 1];
+  if constexpr (G::W_REGS) {
 #pragma unroll
-    for (int k = 0; k < 14; ++k) wreg[k] = wfrag(k >> 1, k & 1, 0);
+    for (int k = 0; k < NK; ++k)
+#pragma unroll
+      for (int n = 0; n < NCO; ++n) wreg[k * NCO + n] = wfrag(k / HS, k % HS, n);
   } else {
-    for (int f = wave; f < 14 * NCO; f += 4) *reinterpret_cast<h8*>(sW + (f * 64 + lane) * 16) = wfrag((f / NCO) >> 1, (f / NCO) & 1, f % NCO);
+    for (int f = wave; f < NK * NCO; f += 4) *reinterpret_cast<h8*>(sW + (f * 64 + lane) * 16) = wfrag((f / NCO) / HS, (f / NCO) % HS, f % NCO);
   }
 
   // ---- patch DMA: unit u = piece * 64 + lane -> (patch row, patch column), fixed for the kernel ----
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(256) void conv_stem7_kernel(const ConvParams p, int
       const_cast<half_t*>(p.in), (short)0, (int)(unsigned)std::min<long long>((long long)p.B * p.in_bstride * 2, 0xffffffffLL), 0x00020000);
   auto load_patch = [&](int t, int buf) __attribute__((always_inline)) {
     const int tw = t % tiles_w, r1 = t / tiles_w, th = r1 % tiles_h, b = r1 / tiles_h;
-    const int h0 = th * TH7 * S - 3, w0 = tw * TW7 * S - 3;
+    const int h0 = th * TH7 * S - PAD, w0 = tw * TW7 * S - PAD;
     const int base = ((b * p.IH + h0) * p.IW + w0) * 16;  // may be negative; the sum with a valid lane's offset is not
     unsigned char* dst = smem + buf * G::PATCH_BYTES;
 #pragma unroll
@@ -115,14 +121,14 @@ __global__ __launch_bounds__(256) void conv_stem7_kernel(const ConvParams p, int
 #pragma unroll
       for (int n = 0; n < NCO; ++n) acc[0][n] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < 14; ++k) {
-        const int kh = k >> 1, half = k & 1;
+      for (int k = 0; k < NK; ++k) {
+        const int kh = k / HS, half = k % HS;
         const h8 xb = *reinterpret_cast<const h8*>(pbase + ((r * S + kh) * G::PCW + half * 4) * 16);
 #pragma unroll
         for (int n = 0; n < NCO; ++n) {
           h8 wa;
-          if constexpr (NCO == 1)
-            wa = wreg[k];
+          if constexpr (G::W_REGS)
+            wa = wreg[k * NCO + n];
           else
             wa = *reinterpret_cast<const h8*>(sW + ((k * NCO + n) * 64 + lane) * 16);
           acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, xb, acc[0][n], 0, 0, 0);
@@ -142,16 +148,16 @@ __global__ __launch_bounds__(256) void conv_stem7_kernel(const ConvParams p, int
 #endif
 }
 
-template <int S, int NCO>
+template <int KSZ, int S, int NCO>
 int launch_stem7(const ConvParams& p, hipStream_t st) {
-  using G = Stem7Geom<S, NCO>;
+  using G = Stem7Geom<KSZ, S, NCO>;
   const int tiles_w = (p.OW2 + TW7 - 1) / TW7, tiles_h = (p.OH2 + TH7 - 1) / TH7;
   const int ntiles = tiles_w * tiles_h * p.B;
   static unsigned long long optin_mask = 0;
-  CVX_TRY(cvx_lds_optin((const void*)conv_stem7_kernel<S, NCO>, G::LDS_BYTES, &optin_mask));
+  CVX_TRY(cvx_lds_optin((const void*)conv_stem7_kernel<KSZ, S, NCO>, G::LDS_BYTES, &optin_mask));
   const int per_cu = std::max(1, std::min(4, (160 * 1024) / G::LDS_BYTES));
   const int grid = std::min(ntiles, 256 * per_cu / std::max(1, g_cvx_grid_div));
-  hipLaunchKernelGGL((conv_stem7_kernel<S, NCO>), dim3(grid), dim3(256), G::LDS_BYTES, st, p, tiles_w, tiles_h, ntiles);
+  hipLaunchKernelGGL((conv_stem7_kernel<KSZ, S, NCO>), dim3(grid), dim3(256), G::LDS_BYTES, st, p, tiles_w, tiles_h, ntiles);
   CVX_HIP(hipGetLastError());
   return 0;
 }
@@ -160,18 +166,21 @@ int launch_stem7(const ConvParams& p, hipStream_t st) {
 
 bool cvx_conv_stem7_supported(const ConvParams& p) {
   static const bool off = cvx_tune_set("CVX_NO_STEM7");
-  // 64 output channels (ResNet's conv1) run, but re-read their weight fragments from LDS for every 16-pixel row segment and measured 2 % behind
-  // the GEMM-shaped kernel on DeepLabv3+ (6.85 vs 6.69 ms): the dispatcher keeps them there; the tuning build and the unit test reach them
+  // 7x7 with 64 output channels (ResNet's conv1) runs, but re-reads its weight fragments from LDS for every 16-pixel row segment and measured
+  // 2 % behind the GEMM-shaped kernel on DeepLabv3+ (6.85 vs 6.69 ms): the dispatcher keeps it there; the tuning build and the unit test reach it
   static const bool wide = cvx_tune_set("CVX_STEM7_WIDE");
-  const bool cout_ok = p.Cout == 16 || (p.Cout == 64 && (wide || p.gemm_variant == 15));
-  return !off && p.std7x7 && p.Cin == 8 && p.in_ld == 8 && (p.IS == 1 || p.IS == 2) && cout_ok && p.nphase <= 1 &&
+  static const bool no3 = cvx_tune_set("CVX_NO_STEM3");
+  const bool k7 = p.std7x7 && (p.Cout == 16 || (p.Cout == 64 && (wide || p.gemm_variant == 15)));
+  const bool k3 = !no3 && p.std3x3 && p.IS == 1 && p.Cout == 32;  // YOLOv7's first layer (3 -> 32 at 640 x 640): 6 weight fragments, in registers
+  return !off && (k7 || k3) && p.Cin == 8 && p.in_ld == 8 && (p.IS == 1 || p.IS == 2) && p.nphase <= 1 &&
          (p.epi == CVX_EPI_AFFINE_SILU || p.epi == CVX_EPI_RAW_STATS) && p.in_bstride == (long long)p.IH * p.IW * 8 &&
          (long long)p.B * p.in_bstride * 2 < (1LL << 31);
 }
 
 int cvx_conv_stem7_launch(const ConvParams& p, hipStream_t st) {
-  if (p.IS == 1 && p.Cout == 16) return launch_stem7<1, 1>(p, st);
-  if (p.IS == 1) return launch_stem7<1, 4>(p, st);
-  if (p.Cout == 16) return launch_stem7<2, 1>(p, st);
-  return launch_stem7<2, 4>(p, st);
+  if (p.std3x3) return launch_stem7<3, 1, 2>(p, st);
+  if (p.IS == 1 && p.Cout == 16) return launch_stem7<7, 1, 1>(p, st);
+  if (p.IS == 1) return launch_stem7<7, 1, 4>(p, st);
+  if (p.Cout == 16) return launch_stem7<7, 2, 1>(p, st);
+  return launch_stem7<7, 2, 4>(p, st);
 }

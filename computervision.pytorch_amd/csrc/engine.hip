@@ -859,6 +859,7 @@ void fill_conv_fwd(const cvx_engine* e, int i, int B, ConvParams* cp) {
   cp->halo_pos = c.halo_pos;
   cp->halo_wt = c.halo_wt;
   cp->std7x7 = c.std7x7;
+  cp->std3x3 = c.std3x3;
   cp->wt_packed = c.gemm_fwd;
   cp->wt_packed_bn = c.gemm_fwd_bn;
   cp->wt_packed_kc = c.gemm_fwd_kc;
@@ -2035,6 +2036,7 @@ extern "C" int cvx_conv2d_nhwc(const void* x_f16, int32_t batch, int32_t ih, int
   cp.halo_taps_ok = cvx_halo_pack_taps(taps.data(), (int)taps.size(), &cp.halo_pos, &cp.halo_wt) ? 1 : 0;
   cp.pointwise = cvx_taps_pointwise(taps.data(), (int)taps.size());
   cp.std7x7 = dil == 1 ? cvx_taps_std7x7(taps.data(), (int)taps.size()) : 0;
+  cp.std3x3 = dil == 1 ? cvx_taps_std3x3(taps.data(), (int)taps.size()) : 0;
   cp.out_ld = cout;
   cp.out_bstride = (long long)oh * ow * cout;
   if (mode == 0) {

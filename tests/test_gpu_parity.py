@@ -211,30 +211,31 @@ def test_gemm_shaped_conv_kernel_every_variant(dev, variant):
         assert (sums[:, 0] / (B * OH * OW) - conv.double().mean((0, 2, 3))).abs().max() < 1e-5, (variant, Ci, Co)
 
 
-@pytest.mark.parametrize("B,H,W,Co,s", [(2, 40, 72, 16, 1), (2, 37, 53, 64, 2), (1, 64, 200, 16, 2), (3, 19, 130, 64, 1), (1, 8, 8, 16, 1)])
-def test_7x7_first_layer_kernel(dev, B, H, W, Co, s):
-    """conv_stem7.hip (DLA-34's base layer: 7x7 stride 1, 16 channels; ResNet's conv1: stride 2, 64 channels, on the image padded to 8
-    channels): the dispatcher takes every such launch there.  Folded BN + SiLU output and the training epilogue (raw fp32 + per-channel
+@pytest.mark.parametrize("B,H,W,Co,s,k", [(2, 40, 72, 16, 1, 7), (2, 37, 53, 64, 2, 7), (1, 64, 200, 16, 2, 7), (3, 19, 130, 64, 1, 7), (1, 8, 8, 16, 1, 7),
+                                          (2, 30, 70, 32, 1, 3), (1, 75, 129, 32, 1, 3)])
+def test_first_layer_kernel(dev, B, H, W, Co, s, k):
+    """conv_stem7.hip (DLA-34's base layer: 7x7 stride 1, 16 channels; ResNet's conv1: 7x7 stride 2, 64 channels; YOLOv7's first layer: 3x3,
+    32 channels -- on the image padded to 8 channels): the dispatcher takes these launches there.  Folded BN + SiLU output and the training epilogue (raw fp32 + per-channel
     statistics) against torch fp32; ragged tiles in both directions, an image smaller than one tile."""
     lib = L.load()
     st = L.stream_ptr(dev)
     g = torch.Generator().manual_seed(B * 7 + H + W + Co + s)
     x16 = torch.zeros(B, 8, H, W, dtype=torch.float16)
     x16[:, :3] = torch.rand(B, 3, H, W, generator=g).half()
-    w16 = torch.zeros(Co, 8, 7, 7, dtype=torch.float16)
-    w16[:, :3] = (torch.randn(Co, 3, 7, 7, generator=g) / 12).half()
+    w16 = torch.zeros(Co, 8, k, k, dtype=torch.float16)
+    w16[:, :3] = (torch.randn(Co, 3, k, k, generator=g) / (3 * k * k) ** 0.5).half()
     xd, wd = x16.permute(0, 2, 3, 1).contiguous().to(dev), w16.permute(0, 2, 3, 1).contiguous().to(dev)
-    conv = F.conv2d(x16.float().to(dev), w16.float().to(dev), None, s, 3)
+    conv = F.conv2d(x16.float().to(dev), w16.float().to(dev), None, s, k // 2)
     OH, OW = conv.shape[2:]
     sc, sh = (torch.rand(Co, generator=g) + 0.5).to(dev), torch.randn(Co, generator=g).to(dev)
     out = torch.empty(B, OH, OW, Co, dtype=torch.float16, device=dev)
     wide = 15 << 9  # mode bits 9..12 = 15: also the 64-channel variant, which the dispatcher leaves to the GEMM-shaped kernel (measured)
-    L.check(lib.cvx_conv2d_nhwc(L.ptr(xd), B, H, W, 8, L.ptr(wd), Co, 7, s, 3, 1, 1 | wide, L.ptr(sc), L.ptr(sh), L.ptr(out), st), "affine")
+    L.check(lib.cvx_conv2d_nhwc(L.ptr(xd), B, H, W, 8, L.ptr(wd), Co, k, s, k // 2, 1, 1 | wide, L.ptr(sc), L.ptr(sh), L.ptr(out), st), "affine")
     assert rel(out.float().permute(0, 3, 1, 2), F.silu(conv * sc[None, :, None, None] + sh[None, :, None, None])) < 5e-4
     out32 = torch.empty(B, OH, OW, Co, dtype=torch.float32, device=dev)
     R = 16 if Co <= 32 else 8
     slab = torch.zeros(R, Co, 2, 2, dtype=torch.int64, device=dev)
-    L.check(lib.cvx_conv2d_nhwc(L.ptr(xd), B, H, W, 8, L.ptr(wd), Co, 7, s, 3, 1, 3 | wide, None, L.ptr(slab), L.ptr(out32), st), "stats")
+    L.check(lib.cvx_conv2d_nhwc(L.ptr(xd), B, H, W, 8, L.ptr(wd), Co, k, s, k // 2, 1, 3 | wide, None, L.ptr(slab), L.ptr(out32), st), "stats")
     assert rel(out32.permute(0, 3, 1, 2), conv) < 1e-5
     tot = slab.sum(0).double()
     sums = tot[..., 0] / 64.0 + tot[..., 1] / 2.0 ** 40
