@@ -1070,6 +1070,28 @@ def test_nms_edge_cases(dev):
     assert int(c2[0]) == k and i2[0, :k].tolist() == list(range(k))
 
 
+@pytest.mark.parametrize("nc,slack", [(80, 0), (80, 4), (3, 0), (20, 3), (91, 0), (200, 0)])
+def test_decode_kernel_on_ragged_tiles_and_row_strides(dev, nc, slack):
+    """cvx_decode_strided (modules.py:434-446) against the oracle's decode_eval: anchor counts that end inside a 64-anchor tile, tiles that
+    straddle two images, class counts off the 16-byte path (3, 91), rows with slack behind them, and a class count whose tile does not
+    fit LDS (200: the per-row kernel).  fp32 on identical inputs; the only difference is expf (1e-6 relative on a DFL distance of up to 15
+    cells, times a stride of up to 32 pixels): boxes to 1e-3 pixel, class probabilities to 1e-6."""
+    g = torch.Generator().manual_seed(nc + slack)
+    hw, strides, B = [(5, 7), (3, 4), (2, 2)], (8.0, 16.0, 32.0), 3
+    feats = [torch.randn(B, 64 + nc, h, w, generator=g) * 3 for h, w in hw]
+    want = O.decode_eval(feats, strides, nc)
+    rows = torch.cat([f.reshape(B, 64 + nc, -1) for f in feats], 2).permute(0, 2, 1).contiguous()   # (B, A, no)
+    A = rows.shape[1]
+    buf = torch.full((B, A, 64 + nc + slack), float("nan"))
+    buf[:, :, :64 + nc] = rows
+    pred = buf.to(dev)[:, :, :64 + nc]
+    got = E.decode(pred, nc, hw, strides).cpu()
+    assert got.shape == (B, 4 + nc, A)
+    assert torch.isfinite(got).all()
+    assert torch.allclose(got[:, :4], want[:, :4], rtol=1e-5, atol=1e-3), float((got[:, :4] - want[:, :4]).abs().max())
+    assert torch.allclose(got[:, 4:], want[:, 4:], rtol=0, atol=1e-6), float((got[:, 4:] - want[:, 4:]).abs().max())
+
+
 def test_decode_box_through_the_plugin_api(dev):
     import builder
     cfg, algo_cls, _ = builder.export_from_registry("yolo8_det")
