@@ -814,6 +814,9 @@ def main():
     if args.stream == "own":
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
         torch.cuda.set_stream(torch.cuda.Stream())
+    if os.environ.get("CVX_BENCH_IDLE_STREAM"):      # diagnostic: an unused torch stream of that priority exists
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+        _idle = torch.cuda.Stream(priority=int(os.environ["CVX_BENCH_IDLE_STREAM"]))
     if args.workload == "yolov8_eval":
         return yolov8_eval_main(args)
     if args.workload == "centernet":

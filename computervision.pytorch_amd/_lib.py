@@ -82,6 +82,7 @@ PROTOTYPES = {
     "cvx_check_finite": (_I32, [_P, _I64, _P, _P]),
     "cvx_adam_step_dev": (_I32, [_P, _P, _P, _P, _I64, _F, _F, _F, _P, _P, _I32, _F, _P]),
     "cvx_engine_set_stream": (_I32, [_P, _P]),
+    "cvx_engine_exchange_stream": (_P, [_P]),
     "cvx_decode": (_I32, [_P, _I32, _I32, _I32, C.POINTER(_I32), C.POINTER(_F), _I32, _P, _P]),
     "cvx_yolo7_decode": (_I32, [_P, _I32, _I32, _I32, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
     "cvx_ssd_decode": (_I32, [_P, _P, _P, _I32, _I32, _I32, _F, _F, _P, _P, _P]),

@@ -1978,6 +1978,8 @@ extern "C" int cvx_engine_set_stream(cvx_engine* e, void* hip_stream) {
   e->stream = (hipStream_t)hip_stream;
   return 0;
 }
+extern "C" void* cvx_engine_exchange_stream(cvx_engine* e) { return e ? (void*)e->red : nullptr; }
+
 extern "C" int cvx_check_finite(const float* grads, int64_t n, int32_t* found_inf, void* hip_stream) {
   CVX_CHECK(grads && found_inf, "bad arguments");
   return cvx_check_finite_launch(grads, n, found_inf, (hipStream_t)hip_stream);

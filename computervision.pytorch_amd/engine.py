@@ -74,6 +74,16 @@ class Engine:
         self._images = images if training else None
         return pred
 
+    def exchange_stream(self) -> torch.cuda.Stream:
+        """The engine's own low-priority reduction stream as a torch stream: where the data-parallel gradient exchange is queued
+        (include/cvx_engine.h: cvx_engine_exchange_stream)."""
+        if getattr(self, "_xstream", None) is None:
+            ptr = self.lib.cvx_engine_exchange_stream(self.handle)
+            if not ptr:
+                raise L.CvxError("the engine has no reduction stream")
+            self._xstream = torch.cuda.ExternalStream(int(ptr), device=self.device)
+        return self._xstream
+
     def plan_generation(self) -> int:
         """Counts re-allocations of the per-batch buffers (a captured hipGraph is stale once this changes)."""
         return int(self.lib.cvx_engine_plan_generation(self.handle))
@@ -101,6 +111,8 @@ class Engine:
 
     def grads_ready(self, op_hi: int, op_lo: int, stream: torch.cuda.Stream):
         """Makes `stream` wait for the range's gradients and fold its weight-gradient slabs into the arena there."""
+        if stream is None:                                           # inline exchange: fold on the launch stream itself
+            stream = torch.cuda.current_stream(self.device)
         L.check(self.lib.cvx_engine_grads_ready(self.handle, op_hi, op_lo, C.c_void_p(stream.cuda_stream)), "cvx_engine_grads_ready")
 
     def backward_end(self):

@@ -278,7 +278,7 @@ class CvxComm:
         self.handle = C.c_void_p()
         dev_index = device.index if device.index is not None else torch.cuda.current_device()
         L.check(lib.cvx_comm_create(C.byref(self.handle), C.c_char_p(unique_id), self.rank, self.world, dev_index), "cvx_comm_create")
-        self.stream = torch.cuda.Stream(device=device, priority=-1)   # high priority: a hardware queue of its own
+        self.stream = None                # the exchange is queued on the engine's own reduction stream (Engine.exchange_stream)
         self._lib = lib
 
     def all_reduce_(self, t: torch.Tensor, stream: Optional[torch.cuda.Stream] = None):
@@ -290,6 +290,7 @@ class CvxComm:
         """the data-parallel backward pass in one C call (buckets: graph.grad_buckets rows)"""
         flat = (C.c_int64 * (4 * len(buckets)))(*[int(v) for b in buckets for v in b])
         eng._use_current_stream()
+        self.stream = eng.exchange_stream()
         L.check(self._lib.cvx_engine_backward_exchange(eng.handle, L.ptr(dpred), float(loss_scale), self.handle, flat, len(buckets),
                                                        C.c_void_p(self.stream.cuda_stream)), "cvx_engine_backward_exchange")
 
@@ -399,10 +400,10 @@ class FusedTrainStep:
         1/world is folded into the Adam kernel.  BASELINE.json north_star: exchange overlapped with the backward pass."""
         m = self.model
         g = m.flat_grads
-        if self._side is None:
-            # high priority = a hardware queue of its own: a default-priority stream can share the main stream's queue
-            # (4 queues, round-robin), and a slab fold waiting there for the weight gradients would stall the main chain
-            self._side = torch.cuda.Stream(device=g.device, priority=-1)
+        # The exchange is queued on the engine's OWN reduction stream (lowest priority, where the weight-gradient slabs are folded anyway).
+        # A further stream -- a torch pool stream of any priority -- put to work beside the engine's four took this step from 6.5 to
+        # 16 ms on the ROCm 7 runtime (1-rank RCCL group, bench.py CVX_FORCE_DIST=1; DESIGN.md section 6); inline on the main stream: 7.0 ms.
+        self._side = eng.exchange_stream()
         key = id(eng)
         if self._buckets_key != key:
             self._buckets = eng.grad_buckets(m.layout, self.n_buckets)
@@ -413,11 +414,6 @@ class FusedTrainStep:
         cur = torch.cuda.current_stream(g.device)
         backward_with_overlapped_exchange(eng, self._buckets, g, dpred, loss_scale, self.pg, self._side)
         cur.wait_stream(self._side)
-
-    def _allreduce(self, g: torch.Tensor):
-        if self._side is None and g.is_cuda:
-            self._side = torch.cuda.Stream(device=g.device)
-        allreduce_mean_flat(g, self.world, self.pg, self.n_buckets, self._side, average=False)
 
 
 def backward_with_overlapped_exchange(eng, buckets, g: torch.Tensor, dpred, loss_scale: float, group=None, side_stream=None):
@@ -452,8 +448,7 @@ class OverlappedExchange:
 
     def backward(self, eng, flat_grads: torch.Tensor, dpred: torch.Tensor, loss_scale: float):
         from .graph import generic_grad_buckets
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=flat_grads.device, priority=-1)
+        self._side = eng.exchange_stream()          # the engine's own reduction stream: see FusedTrainStep._backward_overlapped
         if self._key != id(eng):
             self._buckets, self._key = generic_grad_buckets(eng.graph, self.n_buckets), id(eng)
         cur = torch.cuda.current_stream(flat_grads.device)
