@@ -383,8 +383,37 @@ int cvx_conv_halo_launch(const ConvParams& p, hipStream_t stream) {
   };
   int th = (hw >= 80 * 80 || hw * p.B >= 128 * 1024) ? 8 : ((hw >= 40 * 40 || cap < 2) ? 4 : 2);
   if (th == 8 && halo_lds_bytes(8, 4, (cap < 2 ? 1 : 2) * 16, p.Cin) > 160 * 1024) th = 4;  // wide channels: the 10-row patches do not fit twice
+  // LDS bytes of the two-stream (HV = 2) form of HaloGeom<4, 1, th/4, NT, cin>: four patch buffers instead of two
+  auto lds_hv2 = [&](int th_, int nt) {
+    const int pieces = ((th_ + 2) * HW * (p.Cin / 8) + 63) / 64;
+    const int nsteps = (9 * p.Cin + BK - 1) / BK;
+    return (4 * pieces + 1) * 1024 + nsteps * nt * 16 * BK * 2 + 2 * 4 * nt * 16 * 2 * 4;
+  };
+  // 8-row tiles whose patches only fit a CU once run as ONE 4-wave workgroup per CU -- one wave per SIMD, nobody hides its LDS and MFMA
+  // latencies (80 x 80, 64 -> 64: 80 us for 15 GFLOP).  The 4-row tile of the same layer fits with two tile streams (8 waves) and
+  // measured ahead on every inference bench (tools/sweeps/ab_hv1.sh: SSD -3.7 %, YOLOv7 -2.4 %, CenterNet -2 %, YOLOv8-n eval -1.6 %,
+  // train steps equal); 2: fewer channels per workgroup instead (measured behind), 0: off
+  static const int hv1_mode = cvx_tune_int("CVX_HALO_HV1_MODE", 1);
+  int nt_force = 0;
+  if (th == 8 && hv1_mode != 0) {
+    int gy0, NT0 = pick(8, &gy0);
+    const bool one_stream = lds_hv2(8, NT0) > 160 * 1024 && 2 * halo_lds_bytes(8, 4, NT0 * 16, p.Cin) > 160 * 1024;
+    if (one_stream && hv1_mode == 1) {
+      int gy4, NT4 = pick(4, &gy4);
+      if (lds_hv2(4, NT4) <= 160 * 1024 || 2 * halo_lds_bytes(4, 4, NT4 * 16, p.Cin) <= 160 * 1024) th = 4;  // only if the 4-row form does get its 8 waves
+    }
+    if (one_stream && hv1_mode == 2) {
+      int nt = NT0;
+      while (nt > 2 && lds_hv2(8, nt) > 160 * 1024) --nt;
+      if (lds_hv2(8, nt) <= 160 * 1024) nt_force = nt;
+    }
+  }
   if (th == 8) {
     int gy, NT = pick(8, &gy);
+    if (nt_force) {
+      NT = nt_force;
+      gy = (tiles + NT - 1) / NT;
+    }
     CVX_TRY((launch_m<4, 2>(NT, p, stream, gy, 0)));
   } else if (th == 4) {
     int gy, NT = pick(4, &gy);

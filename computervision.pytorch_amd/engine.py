@@ -7,6 +7,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Optional, Sequence
 
+import warnings
+
 import torch
 
 from . import _lib as L
@@ -19,6 +21,8 @@ def _need_gpu(t: torch.Tensor, what: str):
 
 
 class Engine:
+    _warned_stream = False
+
     def __init__(self, graph: Graph, device: torch.device):
         self.lib = L.load()
         self.graph = graph
@@ -91,6 +95,11 @@ class Engine:
     def _use_current_stream(self):
         """Enqueue on torch's current stream of this device (it may be a stream under hipGraph capture)."""
         s = torch.cuda.current_stream(self.device).cuda_stream
+        if s != 0 and not Engine._warned_stream and not torch.cuda.is_current_stream_capturing():
+            Engine._warned_stream = True
+            warnings.warn("the engine is being launched on a non-default HIP stream: on the ROCm 7 runtime this measured 2.45x slower than the "
+                          "default stream (YOLOv8-n train step 16.0 vs 6.5 ms, eval forward 3.4 vs 1.4 ms; tools/stream_probe.py, DESIGN.md "
+                          "section 6) -- run the model on torch's default stream", RuntimeWarning, stacklevel=3)
         if s != getattr(self, "_stream", None):
             L.check(self.lib.cvx_engine_set_stream(self.handle, C.c_void_p(s)), "cvx_engine_set_stream")
             self._stream = s
