@@ -306,7 +306,7 @@ class FusedTrainStep:
     """One optimisation step = forward, loss(+grad), backward, optional DP all-reduce, Adam.
 
     With ``world_size > 1`` (``torch.distributed`` initialised, backend nccl == RCCL) the flat gradient
-    arena is averaged across ranks in ``n_buckets`` contiguous slices on a side HIP stream, each slice as
+    arena is averaged across ranks in ``n_buckets`` contiguous slices on the engine's reduction stream, each slice as
     soon as the backward pass has produced it; BN statistics stay per rank (the reference has no SyncBN).
     """
 
@@ -396,7 +396,7 @@ class FusedTrainStep:
 
     def _backward_overlapped(self, eng, dpred, loss_scale):
         """Backward in `n_buckets` op ranges (head first).  As soon as a range's gradients are final, its slice of the flat
-        gradient arena is SUM-all-reduced (RCCL) on a side HIP stream while the main stream runs the next range; the mean's
+        gradient arena is SUM-all-reduced (RCCL) on the engine's reduction stream while the main stream runs the next range; the mean's
         1/world is folded into the Adam kernel.  BASELINE.json north_star: exchange overlapped with the backward pass."""
         m = self.model
         g = m.flat_grads
@@ -438,7 +438,7 @@ def backward_with_overlapped_exchange(eng, buckets, g: torch.Tensor, dpred, loss
 
 class OverlappedExchange:
     """The data-parallel backward of the engine-backed train steps other than YOLOv8's: buckets from the graph's own parameter offsets
-    (``graph.generic_grad_buckets``), each bucket's slice of the flat gradient arena SUM-all-reduced (RCCL) on a high-priority side stream
+    (``graph.generic_grad_buckets``), each bucket's slice of the flat gradient arena SUM-all-reduced (RCCL) on the engine's own reduction stream
     as soon as its op range has run, while the main stream runs the next range; the caller folds 1/world into the optimiser step."""
 
     def __init__(self, process_group=None, n_buckets: int = 4):
