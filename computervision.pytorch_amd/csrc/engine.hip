@@ -11,6 +11,9 @@
 #include "conv_chain.h"
 #include "bn_act.h"
 #include "conv_igemm.h"
+#include <map>
+#include <mutex>
+
 #include "misc_ops.h"
 #include "stem.h"
 
@@ -974,6 +977,33 @@ int plan_gemm_packs(cvx_engine* e, int B, bool training) {
 }  // namespace
 
 // =============================================================================================
+// The auxiliary streams (weight gradients, slab reduction, lanes) are ONE set per device for all engines of the process.  Measured on the
+// ROCm 7 runtime (tools/stream_probe.py): as soon as a process has put more than four hardware queues to work -- the
+// default stream plus three per engine was already the limit -- the train step of EVERY engine takes 2.2-2.5x as long (6.5 -> 14.6 ms with a
+// second engine of another input size that had merely run before; 16.0 ms with one more stream at work).  Engines of one process run one
+// after the other on the caller's stream anyway; sharing the side streams only orders work that was ordered already.  The streams live as
+// long as the process.
+namespace {
+struct AuxStreams {
+  hipStream_t side = nullptr, red = nullptr, lane = nullptr;
+};
+std::mutex g_aux_mu;
+std::map<int, AuxStreams> g_aux;
+template <typename Make>
+hipError_t shared_stream(int device, hipStream_t AuxStreams::*which, hipStream_t* out, Make make) {
+  std::lock_guard<std::mutex> lk(g_aux_mu);
+  AuxStreams& a = g_aux[device];
+  if (!(a.*which)) {
+    hipStream_t s = nullptr;
+    const hipError_t rc = make(&s);
+    if (rc != hipSuccess) return rc;
+    a.*which = s;
+  }
+  *out = a.*which;
+  return hipSuccess;
+}
+}  // namespace
+
 extern "C" int cvx_engine_create(cvx_engine** out, const cvx_buf_desc* bufs, int32_t nbufs, const cvx_op_desc* ops, int32_t nops,
                                  int32_t image_buf, int32_t pred_buf, int32_t device, void* hip_stream) {
   CVX_CHECK(out && bufs && ops && nbufs > 0 && nops > 0, "null arguments");
@@ -1002,16 +1032,18 @@ extern "C" int cvx_engine_create(cvx_engine** out, const cvx_buf_desc* bufs, int
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     hipError_t side_rc;
     static const int side_cus = cvx_tune_int("CVX_SIDE_CUS", 0);  // tuning build: confine the weight-gradient stream to the first n CUs
-    if (side_cus > 0) {
-      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int c = 0; c < side_cus && c < 256; ++c) mask[c >> 5] |= 1u << (c & 31);
-      side_rc = hipExtStreamCreateWithCUMask(&e->side, 8, mask);
-    } else
-      side_rc = side_prio ? hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio_least)
-                          : hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
+    side_rc = shared_stream(e->device, &AuxStreams::side, &e->side, [&](hipStream_t* s) {
+      if (side_cus > 0) {
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int c = 0; c < side_cus && c < 256; ++c) mask[c >> 5] |= 1u << (c & 31);
+        return hipExtStreamCreateWithCUMask(s, 8, mask);
+      }
+      return side_prio ? hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio_least) : hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    });
     if (side_rc == hipSuccess)
-      side_rc = side_prio ? hipStreamCreateWithPriority(&e->red, hipStreamNonBlocking, prio_least)
-                          : hipStreamCreateWithFlags(&e->red, hipStreamNonBlocking);
+      side_rc = shared_stream(e->device, &AuxStreams::red, &e->red, [&](hipStream_t* s) {
+        return side_prio ? hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio_least) : hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+      });
     if (side_rc != hipSuccess || hipEventCreateWithFlags(&e->ev_red, cvx_event_flags()) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_fork, cvx_event_flags()) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_join, cvx_event_flags()) != hipSuccess ||
@@ -1034,15 +1066,15 @@ extern "C" int cvx_engine_create(cvx_engine** out, const cvx_buf_desc* bufs, int
     }
     const bool stem_first = !e->ops.empty() && e->ops[0].type == CVX_OP_CONV && e->conv[0].stem;  // the weight packing can run beside it
     if (rc == 0 && (any_lane || (lanes_on && stem_first))) {
-      if (hipStreamCreateWithPriority(&e->lane, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
+      if (shared_stream(e->device, &AuxStreams::lane, &e->lane,
+                        [&](hipStream_t* s) { return hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio_greatest); }) == hipSuccess &&
           hipEventCreateWithFlags(&e->ev_lane_fork, cvx_event_flags()) == hipSuccess &&
           hipEventCreateWithFlags(&e->ev_lane_join, cvx_event_flags()) == hipSuccess &&
           hipEventCreateWithFlags(&e->ev_pack, cvx_event_flags()) == hipSuccess) {
         e->use_lanes = any_lane;
       } else {
         (void)hipGetLastError();
-        if (e->lane) (void)hipStreamDestroy(e->lane);
-        e->lane = nullptr;
+        e->lane = nullptr;  // (the shared stream stays: other engines may be using it)
         for (cvx_op_desc& o : e->ops) o.lane = 0;
       }
     }
@@ -1074,23 +1106,14 @@ extern "C" int cvx_engine_create(cvx_engine** out, const cvx_buf_desc* bufs, int
 extern "C" int cvx_engine_destroy(cvx_engine* e) {
   if (!e) return 0;
   (void)hipStreamSynchronize(e->stream);
-  if (e->side) {
-    (void)hipStreamSynchronize(e->side);
-    (void)hipStreamDestroy(e->side);
-  }
+  if (e->side) (void)hipStreamSynchronize(e->side);  // shared per device (AuxStreams): never destroyed
   for (auto& c : e->conv)
     if (c.ev_dy) (void)hipEventDestroy(c.ev_dy);
-  if (e->lane) {
-    (void)hipStreamSynchronize(e->lane);
-    (void)hipStreamDestroy(e->lane);
-  }
+  if (e->lane) (void)hipStreamSynchronize(e->lane);
   if (e->ev_lane_fork) (void)hipEventDestroy(e->ev_lane_fork);
   if (e->ev_lane_join) (void)hipEventDestroy(e->ev_lane_join);
   if (e->ev_pack) (void)hipEventDestroy(e->ev_pack);
-  if (e->red) {
-    (void)hipStreamSynchronize(e->red);
-    (void)hipStreamDestroy(e->red);
-  }
+  if (e->red) (void)hipStreamSynchronize(e->red);
   if (e->ev_red) (void)hipEventDestroy(e->ev_red);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);

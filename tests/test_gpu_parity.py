@@ -1169,6 +1169,45 @@ def test_overlapped_exchange_is_bit_identical_to_plain_backward(dev):
             dist.destroy_process_group()
 
 
+def test_data_parallel_step_costs_what_the_single_gpu_step_costs(dev):
+    """The exchange path of ``bench.py --gpus N`` with a 1-rank RCCL group, at the bench's own shape (batch 32, 640 x 640), against the plain
+    step: with the exchange on a stream of its own (a torch pool stream) this was 16.0 against 6.5 ms -- a fifth stream at work beside the
+    engine's four -- and is 6.5 against 6.5 with the exchange on the engine's reduction stream.  A 2.45x cliff is
+    what this guards against: the bound is 1.3x."""
+    import time
+    import torch.distributed as dist
+    from computervision.pytorch_amd.train import FlatAdam, FusedTrainStep, V8DetectionLoss
+    from configs import Yolo8DetConfig
+    x, batch = synth.images(32, 640, 640, seed=1).to(dev), {k: v.to(dev) for k, v in synth.targets(32, seed=2).items()}
+    created = False
+    if not dist.is_initialized():
+        try:
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29617", rank=0, world_size=1, device_id=dev)
+            created = True
+        except Exception as exc:
+            pytest.skip(f"RCCL process group unavailable: {exc}")
+    try:
+        ms = []
+        for distributed in (False, True):
+            m = new_model(dev).train()
+            step = FusedTrainStep(m, V8DetectionLoss(Yolo8DetConfig(), m), FlatAdam(m, lr=1e-3), n_buckets=5)
+            step.distributed = distributed
+            for _ in range(4):
+                step(x, batch)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                step(x, batch)
+            torch.cuda.synchronize()
+            ms.append((time.perf_counter() - t0) * 100.0)
+            del step, m
+        print(f"[dp] plain step {ms[0]:.2f} ms, 1-rank RCCL step {ms[1]:.2f} ms")
+        assert ms[1] < 1.3 * ms[0], ms
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("scale,B,H,W", [("n", 4, 160, 160), ("n", 2, 96, 224), ("s", 2, 128, 128)])
 def test_per_layer_backward_against_fp64_on_the_engines_own_operands(dev, scale, B, H, W):
     """Layer by layer through the whole backward pass (cvx_engine_debug_copy: every BN conv's xhat, its completed output

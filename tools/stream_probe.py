@@ -21,6 +21,15 @@ elif mode in ("raw", "rawblocking"):
     assert rc == 0 and s.value
     torch.cuda.set_stream(torch.cuda.ExternalStream(s.value, device=dev))
 torch.manual_seed(0)
+if len(sys.argv) > 2 and sys.argv[2] == "second_engine":      # another engine (another input size) has run in this process before
+    m0 = Yolo8("n", 80).to(dev).train()
+    step0 = FusedTrainStep(m0, V8DetectionLoss(Yolo8DetConfig(), m0), FlatAdam(m0))
+    x0 = synth.images(2, 128, 128, seed=1).to(dev)
+    b0 = {k: v.to(dev) for k, v in synth.targets(2, seed=2).items()}
+    for _ in range(3):
+        step0(x0, b0)
+    torch.cuda.synchronize()
+    mode += "+2nd engine"
 m = Yolo8("n", 80).to(dev).train()
 step = FusedTrainStep(m, V8DetectionLoss(Yolo8DetConfig(), m), FlatAdam(m))
 x = synth.images(32, 640, 640, seed=1).to(dev)
@@ -43,4 +52,4 @@ with torch.no_grad():
         m._run_forward(x, False)
     torch.cuda.synchronize()
 eval_ms = (time.perf_counter() - t0) / 30 * 1e3
-print(f"launch stream {mode:12s}: train step {train_ms:7.3f} ms   eval forward {eval_ms:6.3f} ms", flush=True)
+print(f"launch stream {mode:22s}: train step {train_ms:7.3f} ms   eval forward {eval_ms:6.3f} ms", flush=True)
