@@ -985,7 +985,7 @@ int plan_gemm_packs(cvx_engine* e, int B, bool training) {
 // long as the process.
 namespace {
 struct AuxStreams {
-  hipStream_t side = nullptr, red = nullptr, lane = nullptr;
+  hipStream_t side = nullptr, red = nullptr, lane = nullptr, xchg = nullptr;
 };
 std::mutex g_aux_mu;
 std::map<int, AuxStreams> g_aux;
@@ -1040,7 +1040,12 @@ extern "C" int cvx_engine_create(cvx_engine** out, const cvx_buf_desc* bufs, int
       }
       return side_prio ? hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio_least) : hipStreamCreateWithFlags(s, hipStreamNonBlocking);
     });
-    if (side_rc == hipSuccess)
+    // The slab reduction shares the weight-gradient stream: a stream of its own measured no faster (6.50-6.52 vs 6.56-6.57 ms) and the engine
+    // then works three hardware queues instead of four -- the fourth is left to the caller (a launch stream of its own: 6.5 ms instead of
+    // 16.0) or to the gradient exchange (cvx_engine_exchange_stream).  CVX_RED_OWN_STREAM=1 (tuning build): the round-2 arrangement.
+    static const bool red_own = cvx_tune_int("CVX_RED_OWN_STREAM", 0) != 0;
+    if (side_rc == hipSuccess && !red_own) e->red = e->side;
+    else if (side_rc == hipSuccess)
       side_rc = shared_stream(e->device, &AuxStreams::red, &e->red, [&](hipStream_t* s) {
         return side_prio ? hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio_least) : hipStreamCreateWithFlags(s, hipStreamNonBlocking);
       });
@@ -1809,8 +1814,10 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
     lo_conv = i;
     ++in_chunk;
     if (in_chunk >= chunk_convs && w.pending.empty() && i > 1) {  // every weight gradient of [i, chunk_hi] is on the side stream
-      CVX_HIP(hipEventRecord(e->ev_mid, e->side));
-      CVX_HIP(hipStreamWaitEvent(rs, e->ev_mid, 0));
+      if (rs != e->side) {  // (a reduction stream of its own: it follows the weight gradients through an event)
+        CVX_HIP(hipEventRecord(e->ev_mid, e->side));
+        CVX_HIP(hipStreamWaitEvent(rs, e->ev_mid, 0));
+      }
       CVX_TRY(reduce_chunk(i, chunk_hi, first));
       first = false;
       chunk_hi = -1;
@@ -1821,8 +1828,10 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
   CVX_TRY(join_lane(e));
   CVX_TRY(flush_wgrads(e, e->ev_fork, st));  // (non-conv first ops: nothing pending in practice)
   e->cur_op = -1;
-  CVX_HIP(hipEventRecord(e->ev_join, e->side));  // the last chunk needs the remaining weight-gradient slabs ...
-  CVX_HIP(hipStreamWaitEvent(rs, e->ev_join, 0));
+  if (rs != e->side) {
+    CVX_HIP(hipEventRecord(e->ev_join, e->side));  // the last chunk needs the remaining weight-gradient slabs ...
+    CVX_HIP(hipStreamWaitEvent(rs, e->ev_join, 0));
+  }
   CVX_HIP(hipEventRecord(e->ev_fork, st));       // ... including the stem's, produced on the main stream (cvx_stem_backward)
   CVX_HIP(hipStreamWaitEvent(rs, e->ev_fork, 0));
   if (chunk_hi >= 0) CVX_TRY(reduce_chunk(lo_conv, chunk_hi, first));
@@ -1862,10 +1871,14 @@ extern "C" int cvx_engine_grads_ready(cvx_engine* e, int32_t op_hi, int32_t op_l
   hipEvent_t* ev = &e->ev_seg[(e->ev_seg_next++ % 4) * 2];
   for (int k = 0; k < 2; ++k)
     if (!ev[k]) CVX_HIP(hipEventCreateWithFlags(&ev[k], cvx_event_flags()));
-  CVX_HIP(hipEventRecord(ev[0], e->stream));
-  CVX_HIP(hipEventRecord(ev[1], e->side));
-  CVX_HIP(hipStreamWaitEvent(cs, ev[0], 0));
-  CVX_HIP(hipStreamWaitEvent(cs, ev[1], 0));
+  if (cs != e->stream) {
+    CVX_HIP(hipEventRecord(ev[0], e->stream));
+    CVX_HIP(hipStreamWaitEvent(cs, ev[0], 0));
+  }
+  if (cs != e->side) {
+    CVX_HIP(hipEventRecord(ev[1], e->side));
+    CVX_HIP(hipStreamWaitEvent(cs, ev[1], 0));
+  }
   // ... then folds the weight-gradient slabs of the range's conv ops into the gradient arena there
   int blk0 = -1, blk1 = -1;
   for (int i = op_lo; i <= op_hi; ++i) {
@@ -2001,7 +2014,21 @@ extern "C" int cvx_engine_set_stream(cvx_engine* e, void* hip_stream) {
   e->stream = (hipStream_t)hip_stream;
   return 0;
 }
-extern "C" void* cvx_engine_exchange_stream(cvx_engine* e) { return e ? (void*)e->red : nullptr; }
+// The stream of the data-parallel gradient exchange: created on first request (single-GPU processes never pay for it), lowest priority,
+// one per device like the other auxiliary streams -- with it the process works the default stream + side + lane + this = four queues.
+extern "C" void* cvx_engine_exchange_stream(cvx_engine* e) {
+  if (!e) return nullptr;
+  int prio_least = 0, prio_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  hipStream_t s = nullptr;
+  if (shared_stream(e->device, &AuxStreams::xchg, &s, [&](hipStream_t* out) { return hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio_least); }) !=
+      hipSuccess) {
+    (void)hipGetLastError();
+    cvx_set_error("cvx_engine_exchange_stream: could not create the stream");
+    return nullptr;
+  }
+  return (void*)s;
+}
 
 extern "C" int cvx_check_finite(const float* grads, int64_t n, int32_t* found_inf, void* hip_stream) {
   CVX_CHECK(grads && found_inf, "bad arguments");

@@ -79,12 +79,13 @@ class Engine:
         return pred
 
     def exchange_stream(self) -> torch.cuda.Stream:
-        """The engine's own low-priority reduction stream as a torch stream: where the data-parallel gradient exchange is queued
-        (include/cvx_engine.h: cvx_engine_exchange_stream)."""
+        """The library's exchange stream (lowest priority, one per device, created on first request) as a torch stream: where the
+        data-parallel gradient exchange is queued (include/cvx_engine.h: cvx_engine_exchange_stream) -- the fourth and last hardware queue
+        the process can put to work before every train step pays 2.2-2.5x."""
         if getattr(self, "_xstream", None) is None:
             ptr = self.lib.cvx_engine_exchange_stream(self.handle)
             if not ptr:
-                raise L.CvxError("the engine has no reduction stream")
+                raise L.CvxError("cvx_engine_exchange_stream failed")
             self._xstream = torch.cuda.ExternalStream(int(ptr), device=self.device)
         return self._xstream
 
@@ -97,9 +98,10 @@ class Engine:
         s = torch.cuda.current_stream(self.device).cuda_stream
         if s != 0 and not Engine._warned_stream and not torch.cuda.is_current_stream_capturing():
             Engine._warned_stream = True
-            warnings.warn("the engine is being launched on a non-default HIP stream: on the ROCm 7 runtime this measured 2.45x slower than the "
-                          "default stream (YOLOv8-n train step 16.0 vs 6.5 ms, eval forward 3.4 vs 1.4 ms; tools/stream_probe.py, DESIGN.md "
-                          "section 6) -- run the model on torch's default stream", RuntimeWarning, stacklevel=3)
+            warnings.warn("the engine is being launched on a non-default HIP stream: fine by itself (the engine leaves one hardware queue "
+                          "to the caller), but a process that works more than four queues -- this stream, the default stream, the engine's two, "
+                          "a data-parallel exchange stream, further torch streams -- pays 2.2-2.5x per train step on the ROCm 7 runtime "
+                          "(tools/stream_probe.py, DESIGN.md section 6)", RuntimeWarning, stacklevel=3)
         if s != getattr(self, "_stream", None):
             L.check(self.lib.cvx_engine_set_stream(self.handle, C.c_void_p(s)), "cvx_engine_set_stream")
             self._stream = s

@@ -101,10 +101,12 @@ int cvx_engine_bind(cvx_engine* e, float* params, float* grads, int64_t n_params
 
 /* Changes the HIP stream subsequent calls enqueue on (e.g. a stream that is being captured into a hipGraph). */
 int cvx_engine_set_stream(cvx_engine* e, void* hip_stream);
-/* The engine's own reduction stream (hipStream_t; lowest priority, created with the engine): the stream its weight-gradient slabs are
- * folded on.  The data-parallel gradient exchange is queued THERE (cvx_engine_grads_ready / cvx_engine_backward_exchange with this
- * stream): every further stream the process puts to work -- torch's pool streams included -- took the YOLOv8-n step from 6.5 to
- * 16 ms on this runtime.  Replaces: the side stream DDP's reducer owns (torch/nn/parallel/distributed.py). */
+/* The stream of the data-parallel gradient exchange (hipStream_t; lowest priority, created on first request, ONE per device for all engines
+ * of the process): cvx_engine_grads_ready / cvx_engine_backward_exchange fold a range's weight-gradient slabs and queue its all-reduce there.
+ * The engine works the caller's stream + two auxiliary streams (weight gradients and slab reduction; Detect lanes); this is the fourth.
+ * A process that puts MORE than four hardware queues to work pays 2.2-2.5x on every train step on this runtime (6.5 ->
+ * 16 ms with one stream too many, whichever it is) -- so do not create a stream of your own for the exchange.
+ * Replaces: the side stream DDP's reducer owns (torch/nn/parallel/distributed.py). */
 void* cvx_engine_exchange_stream(cvx_engine* e);
 
 /* BatchNorm hyper-parameters (core/models/yolov8/torch_utils.py:17-19: eps 1e-3, momentum 0.03). */
