@@ -2014,10 +2014,15 @@ extern "C" int cvx_engine_set_stream(cvx_engine* e, void* hip_stream) {
   e->stream = (hipStream_t)hip_stream;
   return 0;
 }
-// The stream of the data-parallel gradient exchange: created on first request (single-GPU processes never pay for it), lowest priority,
-// one per device like the other auxiliary streams -- with it the process works the default stream + side + lane + this = four queues.
+// The stream of the data-parallel gradient exchange = the engine's weight-gradient stream: a range's slab fold and all-reduce queue up
+// behind the weight gradients they depend on (no events needed), the next range's weight gradients behind them.  A dedicated stream
+// overlaps a little better (the all-reduces do not hold up the next weight gradients) but is the process's FOURTH hardware queue, and
+// RCCL orders every multi-rank launch against an internal stream of its own (a fifth: 2.2-2.5x on every step) --
+// which a 1-GPU box cannot measure; three queues leave room for it.  CVX_XCHG_OWN_STREAM=1 (tuning build): the dedicated stream.
 extern "C" void* cvx_engine_exchange_stream(cvx_engine* e) {
   if (!e) return nullptr;
+  static const bool own = cvx_tune_int("CVX_XCHG_OWN_STREAM", 0) != 0;
+  if (!own) return (void*)e->side;
   int prio_least = 0, prio_greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   hipStream_t s = nullptr;

@@ -79,9 +79,9 @@ class Engine:
         return pred
 
     def exchange_stream(self) -> torch.cuda.Stream:
-        """The library's exchange stream (lowest priority, one per device, created on first request) as a torch stream: where the
-        data-parallel gradient exchange is queued (include/cvx_engine.h: cvx_engine_exchange_stream) -- the fourth and last hardware queue
-        the process can put to work before every train step pays 2.2-2.5x."""
+        """The stream the data-parallel gradient exchange is queued on, as a torch stream: the engine's own weight-gradient stream
+        (include/cvx_engine.h: cvx_engine_exchange_stream) -- a stream of its own for the exchange would be one hardware queue too many
+        once RCCL's internal stream joins in."""
         if getattr(self, "_xstream", None) is None:
             ptr = self.lib.cvx_engine_exchange_stream(self.handle)
             if not ptr:

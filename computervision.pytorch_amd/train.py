@@ -278,7 +278,7 @@ class CvxComm:
         self.handle = C.c_void_p()
         dev_index = device.index if device.index is not None else torch.cuda.current_device()
         L.check(lib.cvx_comm_create(C.byref(self.handle), C.c_char_p(unique_id), self.rank, self.world, dev_index), "cvx_comm_create")
-        self.stream = None                # the exchange is queued on the library's exchange stream (Engine.exchange_stream)
+        self.stream = None                # the exchange is queued on the engine's weight-gradient stream (Engine.exchange_stream)
         self._lib = lib
 
     def all_reduce_(self, t: torch.Tensor, stream: Optional[torch.cuda.Stream] = None):
@@ -306,7 +306,7 @@ class FusedTrainStep:
     """One optimisation step = forward, loss(+grad), backward, optional DP all-reduce, Adam.
 
     With ``world_size > 1`` (``torch.distributed`` initialised, backend nccl == RCCL) the flat gradient
-    arena is averaged across ranks in ``n_buckets`` contiguous slices on the library's exchange stream, each slice as
+    arena is averaged across ranks in ``n_buckets`` contiguous slices on the engine's weight-gradient stream, each slice as
     soon as the backward pass has produced it; BN statistics stay per rank (the reference has no SyncBN).
     """
 
@@ -396,14 +396,13 @@ class FusedTrainStep:
 
     def _backward_overlapped(self, eng, dpred, loss_scale):
         """Backward in `n_buckets` op ranges (head first).  As soon as a range's gradients are final, its slice of the flat
-        gradient arena is SUM-all-reduced (RCCL) on the library's exchange stream while the main stream runs the next range; the mean's
+        gradient arena is SUM-all-reduced (RCCL) on the engine's weight-gradient stream while the main stream runs the next range; the mean's
         1/world is folded into the Adam kernel.  BASELINE.json north_star: exchange overlapped with the backward pass."""
         m = self.model
         g = m.flat_grads
-        # The exchange is queued on the library's exchange stream (lowest priority, one per device, created on first request): with the
-        # default stream and the engine's two auxiliary streams that makes four hardware queues -- a fifth at work (this used to be a torch
-        # pool stream beside an engine with three of its own) took the step from 6.5 to 16 ms on the ROCm 7 runtime (1-rank RCCL group,
-        # bench.py CVX_FORCE_DIST=1; DESIGN.md section 6).
+        # The exchange is queued on the engine's own weight-gradient stream: fold and all-reduce of a range behind the weight gradients they
+        # depend on.  A stream of its own for it (a torch pool stream, beside an engine that then had three) was the process's fifth hardware
+        # queue and took the step from 6.5 to 16 ms on the ROCm 7 runtime (1-rank RCCL group, bench.py CVX_FORCE_DIST=1; DESIGN.md section 6).
         self._side = eng.exchange_stream()
         key = id(eng)
         if self._buckets_key != key:
@@ -439,7 +438,7 @@ def backward_with_overlapped_exchange(eng, buckets, g: torch.Tensor, dpred, loss
 
 class OverlappedExchange:
     """The data-parallel backward of the engine-backed train steps other than YOLOv8's: buckets from the graph's own parameter offsets
-    (``graph.generic_grad_buckets``), each bucket's slice of the flat gradient arena SUM-all-reduced (RCCL) on the library's exchange stream
+    (``graph.generic_grad_buckets``), each bucket's slice of the flat gradient arena SUM-all-reduced (RCCL) on the engine's weight-gradient stream
     as soon as its op range has run, while the main stream runs the next range; the caller folds 1/world into the optimiser step."""
 
     def __init__(self, process_group=None, n_buckets: int = 4):
@@ -449,7 +448,7 @@ class OverlappedExchange:
 
     def backward(self, eng, flat_grads: torch.Tensor, dpred: torch.Tensor, loss_scale: float):
         from .graph import generic_grad_buckets
-        self._side = eng.exchange_stream()          # the library's exchange stream: see FusedTrainStep._backward_overlapped
+        self._side = eng.exchange_stream()          # the engine's weight-gradient stream: see FusedTrainStep._backward_overlapped
         if self._key != id(eng):
             self._buckets, self._key = generic_grad_buckets(eng.graph, self.n_buckets), id(eng)
         cur = torch.cuda.current_stream(flat_grads.device)

@@ -101,11 +101,12 @@ int cvx_engine_bind(cvx_engine* e, float* params, float* grads, int64_t n_params
 
 /* Changes the HIP stream subsequent calls enqueue on (e.g. a stream that is being captured into a hipGraph). */
 int cvx_engine_set_stream(cvx_engine* e, void* hip_stream);
-/* The stream of the data-parallel gradient exchange (hipStream_t; lowest priority, created on first request, ONE per device for all engines
- * of the process): cvx_engine_grads_ready / cvx_engine_backward_exchange fold a range's weight-gradient slabs and queue its all-reduce there.
- * The engine works the caller's stream + two auxiliary streams (weight gradients and slab reduction; Detect lanes); this is the fourth.
- * A process that puts MORE than four hardware queues to work pays 2.2-2.5x on every train step on this runtime (6.5 ->
- * 16 ms with one stream too many, whichever it is) -- so do not create a stream of your own for the exchange.
+/* The stream the data-parallel gradient exchange is to be queued on (hipStream_t): the engine's own weight-gradient stream (lowest
+ * priority, shared by all engines of the process).  cvx_engine_grads_ready / cvx_engine_backward_exchange fold a range's weight-gradient
+ * slabs and queue its all-reduce there, behind the weight gradients they depend on.  The engine works three hardware queues (the caller's
+ * stream, this one, the Detect lanes); a process that puts MORE than four to work pays 2.2-2.5x on every train step on this runtime
+ * (6.5 -> 16 ms with the exchange on a stream of its own beside an engine that then had three) -- so do not create a
+ * stream for the exchange: the fourth queue is RCCL's internal stream's, or the caller's launch stream's.
  * Replaces: the side stream DDP's reducer owns (torch/nn/parallel/distributed.py). */
 void* cvx_engine_exchange_stream(cvx_engine* e);
 
