@@ -809,14 +809,11 @@ def main():
                     "entirely behind the C ABI (RCCL communicator owned by the engine library, no Python between the backward ranges)")
     ap.add_argument("--fusion", type=int, default=0, help="yolov8_eval: 1 runs the eval forward with the cross-layer fusion groups (Bottleneck pairs, Detect levels as one launch each; measured 1-6 %% slower, so off by default)")
     ap.add_argument("--stream", default="default", choices=["default", "own"], help="own: launch on a torch.cuda.Stream of the bench's own instead of "
-                    "the legacy null stream (A/B switch)")
+                    "the legacy default stream (A/B switch for the hardware-queue budget, DESIGN.md section 6)")
     args = ap.parse_args()
     if args.stream == "own":
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
         torch.cuda.set_stream(torch.cuda.Stream())
-    if os.environ.get("CVX_BENCH_IDLE_STREAM"):      # diagnostic: an unused torch stream of that priority exists
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
-        _idle = torch.cuda.Stream(priority=int(os.environ["CVX_BENCH_IDLE_STREAM"]))
     if args.workload == "yolov8_eval":
         return yolov8_eval_main(args)
     if args.workload == "centernet":
