@@ -25,7 +25,14 @@ import os
 import sys
 import time
 
-import torch
+# Before the HIP runtime loads: one hardware queue per stream PRIORITY.  A process that puts more than four hardware queues to work pays
+# 2.2-2.5x on every step on this runtime (tools/micro/queue_count_bench.hip); the engine's three streams have three
+# different priorities, so this costs it nothing (same-box A/B of six workloads: equal within noise), while whatever further streams torch,
+# RCCL or the caller put to work can then no longer push the process over the budget (six streams at work: 6.4 instead of 14.6 ms).  An explicit
+# setting in the environment wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
