@@ -1042,7 +1042,7 @@ extern "C" int cvx_engine_create(cvx_engine** out, const cvx_buf_desc* bufs, int
     });
     // The slab reduction shares the weight-gradient stream: a stream of its own measured no faster (6.50-6.52 vs 6.56-6.57 ms) and the engine
     // then works three hardware queues instead of four -- the fourth is left to the caller (a launch stream of its own: 6.5 ms instead of
-    // 16.0) or to the gradient exchange (cvx_engine_exchange_stream).  CVX_RED_OWN_STREAM=1 (tuning build): the round-2 arrangement.
+    // 16.0) or to RCCL's internal stream (the exchange itself rides this stream too).  CVX_RED_OWN_STREAM=1 (tuning build): the round-2 arrangement.
     static const bool red_own = cvx_tune_int("CVX_RED_OWN_STREAM", 0) != 0;
     if (side_rc == hipSuccess && !red_own) e->red = e->side;
     else if (side_rc == hipSuccess)
