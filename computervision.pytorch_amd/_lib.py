@@ -67,6 +67,7 @@ PROTOTYPES = {
     "cvx_engine_profile_read": (_I32, [_P, _I32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                        C.POINTER(_I64)]),
     "cvx_debug_clock_buffer": (_I32, [_P]),
+    "cvx_debug_conv_tile_plan": (_I32, [_I32, _I32, _I32, _I32, _I32, _P]),
     "cvx_engine_profile_dump": (_I32, [_P, C.c_char_p]),
     "cvx_pred_level_to_nchw": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "cvx_nchw_grad_to_dpred": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _P, _P]),

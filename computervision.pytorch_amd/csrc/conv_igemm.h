@@ -75,6 +75,11 @@ struct ConvParams {
   int std7x7;                      // 1 when the table is the 7x7 / pad 3 / dilation 1 neighbourhood in row-major order (conv_stem7.hip)
   int std3x3;                      // likewise 3x3 / pad 1 (cvx_taps_std3x3)
   int gemm_variant;                // unit tests: run this variant of the GEMM-shaped kernel (conv_gemm.hip: kVariants index + 1), 0 = the cost model's
+  // row-band kernel (conv_tile.hip): the weights in its LDS image order for channel blocks of tile_packed_bn rows (cvx_conv_tile_pack_jobs,
+  // once per forward for all layers); null: the launch packs them itself
+  const half_t* tile_packed;
+  int tile_packed_bn;
+  int no_tile;                     // unit tests / A-B timing: keep this launch off the row-band kernel
 };
 
 // Packs a 9-entry tap table whose offsets all lie in the 3x3 neighbourhood into two 64-bit words, 4 bits per tap:
@@ -127,6 +132,20 @@ int cvx_conv_gemm_pack_jobs(const GemmPackJob* d_jobs, int njobs, int nblocks, h
 bool cvx_conv_gemm_shape_ok(const ConvParams& p);   // what the kernel can run at all
 bool cvx_conv_gemm_supported(const ConvParams& p);  // ... and where the dispatcher prefers it
 int cvx_conv_gemm_launch(const ConvParams& p, hipStream_t stream);
+// row-band kernel for the small 3x3 stride-1 maps (conv_tile.hip)
+struct TilePackPlan {
+  int BN, NB, SPT;   // channel-block rows, channel blocks, K-steps per tap of the packed image
+  size_t bytes;      // size of the image
+  double cost_us;    // the launcher's estimate for the launch (dispatcher: compared against the other kernels' measured floors)
+};
+bool cvx_conv_tile_shape_ok(const ConvParams& p);                    // what the kernel can run at all
+bool cvx_conv_tile_supported(const ConvParams& p);                   // ... and where the dispatcher prefers it
+bool cvx_conv_tile_plan(const ConvParams& p, TilePackPlan* out);     // packed-image geometry of the launch cvx_conv_tile_launch will make
+int cvx_conv_tile_fill_job(const ConvParams& p, const TilePackPlan& tp, half_t* dst, int blk0, void* job_out);  // -> pack blocks of the job
+size_t cvx_conv_tile_job_bytes();
+int cvx_conv_tile_pack_jobs(const void* d_jobs, int njobs, int nblocks, hipStream_t stream);
+int cvx_conv_tile_launch(const ConvParams& p, hipStream_t stream);
+void cvx_conv_tile_release();
 // pointwise (1x1 stride-1) persistent GEMM kernel (conv_pw.hip)
 bool cvx_conv_pw_supported(const ConvParams& p);
 int cvx_conv_pw_launch(const ConvParams& p, hipStream_t stream);

@@ -24,6 +24,7 @@ int cvx_conv_igemm_launch(const ConvParams& p_in, hipStream_t stream, int* m_blo
   if (m_blocks) *m_blocks = 0;
   if (p.nphase > 1) return cvx_conv_igemm_dma_launch(p, stream);  // merged phases: the DMA-ring kernel only
   if (cvx_conv_stem7_supported(p)) return cvx_conv_stem7_launch(p, stream);  // 7x7 first layer on the padded image
+  if (cvx_conv_tile_supported(p)) return cvx_conv_tile_launch(p, stream);  // small 3x3 stride-1 maps: one row band per workgroup
   if (cvx_conv_gemm_supported(p)) return cvx_conv_gemm_launch(p, stream);  // big-channel layers, whatever their taps
   if (cvx_conv_pw_supported(p)) return cvx_conv_pw_launch(p, stream);
   if (cvx_conv_halo_supported(p)) return cvx_conv_halo_launch(p, stream);

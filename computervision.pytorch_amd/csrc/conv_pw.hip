@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvParams p, long l
   const int fr = lane & 15, fq = lane >> 4;
   const int nblk = blockIdx.y;
   const int Cin = p.Cin;
+  clk_mark(p, 0);
 
   // ---- weights of this workgroup's channels -> LDS, once ----
   {
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvParams p, long l
     }
   }
 
+  clk_mark(p, 1);
   const bool flat_in = p.in_bstride == (long long)hw * p.in_ld;
   const bool flat_out = p.out_bstride == (long long)hw * p.out_ld;
   const half_t* wbase = wts + lds_row_off(fr, fq);  // + j*16 rows (swizzle term unchanged: 16 | row step)
@@ -115,6 +117,7 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvParams p, long l
       wait_vmcnt<0>();     // the same wait the first MFMA needs anyway
       workgroup_barrier();
       weights_ready = true;
+      clk_mark(p, 2);
     }
     f4 acc[MT][NTW];
 #pragma unroll
@@ -131,6 +134,7 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvParams p, long l
 #pragma unroll
         for (int i = 0; i < MT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[j], xa[s][i], acc[i][j], 0, 0, 0);
     }
+    if (t == blockIdx.x * 4) clk_mark(p, 3);
     epilogue_tile<4, 1, MT, NTW>(p, acc, out_off, res_off, pvalid, 0, fq, nblk, st1, st2);
   }
   if (!weights_ready) {  // a wave without tiles still owes the workgroup its weight pieces and the barrier
@@ -138,6 +142,7 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvParams p, long l
     workgroup_barrier();
   }
   if (p.epi == CVX_EPI_RAW_STATS) stats_flush<4, 1, NTW>(p, st1, st2, wave, 0, fr, fq, nblk, sStat, tid);
+  clk_mark(p, 4);
 }
 
 template <int MT, int NTW, int NSTEPS>

@@ -40,6 +40,8 @@ struct DgClass {
   int ntaps = 0, oph = 0, opw = 0, OH2 = 0, OW2 = 0;
   const half_t* gemm_pk = nullptr;  // data-gradient weights in the GEMM-shaped kernel's ring image order (per batch plan), channel tiles of gemm_bn rows
   int gemm_bn = 0, gemm_kc = 0;
+  const half_t* tile_pk = nullptr;  // ... and in the row-band kernel's LDS image order (conv_tile.hip), channel blocks of tile_bn rows
+  int tile_bn = 0;
 };
 
 struct ConvRt {
@@ -70,6 +72,8 @@ struct ConvRt {
   int nsplit = 1;
   const half_t* gemm_fwd = nullptr;  // forward weights in the GEMM-shaped kernel's ring image order (per batch plan)
   int gemm_fwd_bn = 0, gemm_fwd_kc = 0;
+  const half_t* tile_fwd = nullptr;  // forward weights in the row-band kernel's LDS image order (per batch plan)
+  int tile_fwd_bn = 0;
 };
 
 struct PoolRt {
@@ -176,6 +180,10 @@ struct cvx_engine {
   half_t* gemm_arena = nullptr;
   GemmPackJob* d_gemm_jobs = nullptr;
   int n_gemm_jobs = 0, n_gemm_fwd_jobs = 0, gemm_blocks = 0, gemm_fwd_blocks = 0;
+  // row-band conv kernel (conv_tile.hip): likewise
+  half_t* tile_arena = nullptr;
+  void* d_tile_jobs = nullptr;
+  int n_tile_jobs = 0, n_tile_fwd_jobs = 0, tile_blocks = 0, tile_fwd_blocks = 0;
   struct cvx_bw_state* bw = nullptr;  // backward-pass state (whole-pass and segmented entry points)
   std::vector<ProfRec> prof_recs;
 };
@@ -585,6 +593,8 @@ int plan_fused_groups(cvx_engine* e, int B) {
 
 int plan_gemm_packs(cvx_engine* e, int B, bool training);
 void free_gemm_packs(cvx_engine* e);
+int plan_tile_packs(cvx_engine* e, int B, bool training);
+void free_tile_packs(cvx_engine* e);
 
 int plan_batch(cvx_engine* e, int B, bool training) {
   if (e->planned_batch == B && (e->planned_train || !training)) return 0;
@@ -594,6 +604,7 @@ int plan_batch(cvx_engine* e, int B, bool training) {
   free_pool(e->batch_allocs);
   free_fused(e);
   free_gemm_packs(e);
+  free_tile_packs(e);
   e->batch_bytes = 0;
   e->planned_batch = 0;
   e->plan_generation++;  // every per-batch buffer moves: a hipGraph captured against the old plan must be dropped
@@ -831,6 +842,7 @@ int plan_batch(cvx_engine* e, int B, bool training) {
   // the fused groups hold pointers into this plan's buffers; a training plan serves eval forwards too
   CVX_TRY(plan_fused_groups(e, B));
   CVX_TRY(plan_gemm_packs(e, B, training));
+  CVX_TRY(plan_tile_packs(e, B, training));
   return 0;
 }
 
@@ -866,6 +878,8 @@ void fill_conv_fwd(const cvx_engine* e, int i, int B, ConvParams* cp) {
   cp->wt_packed = c.gemm_fwd;
   cp->wt_packed_bn = c.gemm_fwd_bn;
   cp->wt_packed_kc = c.gemm_fwd_kc;
+  cp->tile_packed = c.tile_fwd;
+  cp->tile_packed_bn = c.tile_fwd_bn;
 }
 
 void free_gemm_packs(cvx_engine* e) {
@@ -907,6 +921,13 @@ void fill_conv_dgrad_shape(const cvx_engine* e, int i, int q, int B, ConvParams*
   cp->ntaps = dc.ntaps;
   cp->taps = dc.taps;
   cp->zeros = e->zero_page;
+  cp->oph = dc.oph;
+  cp->opw = dc.opw;
+  cp->OWr = o.iw;
+  cp->halo_taps_ok = dc.halo_ok ? 1 : 0;
+  cp->halo_pos = dc.halo_pos;
+  cp->halo_wt = dc.halo_wt;
+  cp->pointwise = dc.pointwise;
 }
 
 // Every conv launch the dispatcher will give to the GEMM-shaped kernel (conv_gemm.hip) gets its weights in ring image order from one
@@ -971,6 +992,87 @@ int plan_gemm_packs(cvx_engine* e, int B, bool training) {
   e->n_gemm_fwd_jobs = n_fwd;
   e->gemm_blocks = blocks;
   e->gemm_fwd_blocks = fwd_blocks;
+  return 0;
+}
+
+void free_tile_packs(cvx_engine* e) {
+  if (e->tile_arena) (void)hipFree(e->tile_arena);
+  if (e->d_tile_jobs) (void)hipFree(e->d_tile_jobs);
+  e->tile_arena = nullptr;
+  e->d_tile_jobs = nullptr;
+  e->n_tile_jobs = e->n_tile_fwd_jobs = e->tile_blocks = e->tile_fwd_blocks = 0;
+  for (auto& c : e->conv) {
+    c.tile_fwd = nullptr;
+    c.tile_fwd_bn = 0;
+    for (auto& d : c.dg) {
+      d.tile_pk = nullptr;
+      d.tile_bn = 0;
+    }
+  }
+}
+
+// Every conv launch the dispatcher will give to the row-band kernel (conv_tile.hip: 3x3 stride 1 on the small maps) gets its weights in that
+// kernel's LDS image order from one batched launch per forward (beside cvx_pack_weights and the GEMM-shaped kernel's pack).
+int plan_tile_packs(cvx_engine* e, int B, bool training) {
+  free_tile_packs(e);
+  struct Ref {
+    int op, q;  // q < 0: forward
+    TilePackPlan tp;
+    ConvParams cp;
+  };
+  std::vector<Ref> refs;
+  std::vector<size_t> offs;
+  size_t total = 0;
+  auto add = [&](const ConvParams& cp, int op, int q) {
+    TilePackPlan tp;
+    if (!cvx_conv_tile_supported(cp) || !cvx_conv_tile_plan(cp, &tp)) return;
+    offs.push_back(total);
+    total += (tp.bytes + 255) / 256 * 256;
+    refs.push_back(Ref{op, q, tp, cp});
+  };
+  for (size_t i = 0; i < e->ops.size(); ++i) {
+    if (e->ops[i].type != CVX_OP_CONV || e->conv[i].stem) continue;
+    ConvParams cp;
+    fill_conv_fwd(e, (int)i, B, &cp);
+    add(cp, (int)i, -1);
+  }
+  const int n_fwd = (int)refs.size();
+  if (training) {
+    for (size_t i = 0; i < e->ops.size(); ++i) {
+      const cvx_op_desc& o = e->ops[i];
+      const ConvRt& c = e->conv[i];
+      if (o.type != CVX_OP_CONV || c.stem || !o.needs_dgrad || c.sh_dg < 0 || c.ndg != 1) continue;
+      if (c.dg[0].OH2 <= 0 || c.dg[0].OW2 <= 0 || c.dg[0].ntaps <= 0) continue;
+      ConvParams cp;
+      fill_conv_dgrad_shape(e, (int)i, 0, B, &cp);
+      add(cp, (int)i, 0);
+    }
+  }
+  if (refs.empty()) return 0;
+  CVX_HIP(hipMalloc((void**)&e->tile_arena, total));
+  const size_t jb = cvx_conv_tile_job_bytes();
+  std::vector<unsigned char> jobs(refs.size() * jb);
+  int blocks = 0, fwd_blocks = 0;
+  for (size_t k = 0; k < refs.size(); ++k) {
+    half_t* dst = reinterpret_cast<half_t*>(reinterpret_cast<char*>(e->tile_arena) + offs[k]);
+    blocks += cvx_conv_tile_fill_job(refs[k].cp, refs[k].tp, dst, blocks, jobs.data() + k * jb);
+    if ((int)k + 1 == n_fwd) fwd_blocks = blocks;
+    ConvRt& c = e->conv[refs[k].op];
+    if (refs[k].q < 0) {
+      c.tile_fwd = dst;
+      c.tile_fwd_bn = refs[k].tp.BN;
+    } else {
+      c.dg[refs[k].q].tile_pk = dst;
+      c.dg[refs[k].q].tile_bn = refs[k].tp.BN;
+    }
+  }
+  if (n_fwd == 0) fwd_blocks = 0;
+  CVX_HIP(hipMalloc(&e->d_tile_jobs, jobs.size()));
+  CVX_HIP(hipMemcpy(e->d_tile_jobs, jobs.data(), jobs.size(), hipMemcpyHostToDevice));
+  e->n_tile_jobs = (int)refs.size();
+  e->n_tile_fwd_jobs = n_fwd;
+  e->tile_blocks = blocks;
+  e->tile_fwd_blocks = fwd_blocks;
   return 0;
 }
 
@@ -1130,6 +1232,8 @@ extern "C" int cvx_engine_destroy(cvx_engine* e) {
   {
     if (e->gemm_arena) (void)hipFree(e->gemm_arena);
     if (e->d_gemm_jobs) (void)hipFree(e->d_gemm_jobs);
+    if (e->tile_arena) (void)hipFree(e->tile_arena);
+    if (e->d_tile_jobs) (void)hipFree(e->d_tile_jobs);
   }
   free_pool(e->batch_allocs);
   free_pool(e->static_allocs);
@@ -1249,6 +1353,7 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
       CVX_TRY(cvx_conv_gemm_pack_jobs(e->d_gemm_jobs, e->n_gemm_jobs, e->gemm_blocks, prep));
     else
       CVX_TRY(cvx_conv_gemm_pack_jobs(e->d_gemm_jobs, e->n_gemm_fwd_jobs, e->gemm_fwd_blocks, prep));
+    CVX_TRY(cvx_conv_tile_pack_jobs(e->d_tile_jobs, training ? e->n_tile_jobs : e->n_tile_fwd_jobs, training ? e->tile_blocks : e->tile_fwd_blocks, prep));
   }
   e->last_images = training ? images : nullptr;
   if (training) e->train_pass++;  // dropout masks: one per (seed, training forward, op)
@@ -1713,6 +1818,8 @@ int backward_op(cvx_engine* e, int i) {
         cp.wt_packed = dc.gemm_pk;
         cp.wt_packed_bn = dc.gemm_bn;
         cp.wt_packed_kc = dc.gemm_kc;
+        cp.tile_packed = dc.tile_pk;
+        cp.tile_packed_bn = dc.tile_bn;
         cp.out16 = gin.p;
         cp.out_ld = gin.ld;
         cp.out_bstride = gin.bstride;
@@ -2063,6 +2170,8 @@ extern "C" int cvx_conv2d_nhwc(const void* x_f16, int32_t batch, int32_t ih, int
   hipStream_t st = (hipStream_t)hip_stream;
   const bool force_gemm = (mode & 0x100) != 0;  // unit tests of the GEMM-shaped kernel on shapes the dispatcher gives to another one
   const int gemm_variant = (mode >> 9) & 15;    // ... and of one particular variant of it (0: the cost model's choice)
+  const bool force_tile = (mode & 0x2000) != 0;  // likewise the row-band kernel (conv_tile.hip); 0x4000: never the row-band kernel
+  const bool no_tile = (mode & 0x4000) != 0;
   mode &= 0xff;
   const int oh = (ih + 2 * pad - dil * (k - 1) - 1) / stride + 1, ow = (iw + 2 * pad - dil * (k - 1) - 1) / stride + 1;
   std::vector<ConvTap> taps;
@@ -2123,7 +2232,15 @@ extern "C" int cvx_conv2d_nhwc(const void* x_f16, int32_t batch, int32_t ih, int
       CVX_CHECK(false, "shape outside the GEMM-shaped kernel (cin % 8, cout % 4)");
     }
     rc = cvx_conv_gemm_launch(cp, st);
+  } else if (force_tile) {
+    if (!cvx_conv_tile_shape_ok(cp)) {
+      (void)hipFree(dt);
+      CVX_CHECK(false, "shape outside the row-band kernel (3x3 stride 1, cin % 8, cin >= 32)");
+    }
+    cp.clk = g_cvx_clk;
+    rc = cvx_conv_tile_launch(cp, st);
   } else {
+    cp.no_tile = no_tile ? 1 : 0;
     rc = cvx_conv_igemm_launch(cp, st, nullptr);
   }
   (void)hipStreamSynchronize(st);

@@ -172,6 +172,12 @@ int cvx_engine_profile_dump(cvx_engine* e, const char* path);
  * (entry, operands issued, first K-step landed, K loop done, epilogue done).  NULL switches it off. */
 int cvx_debug_clock_buffer(void* buf);
 
+/* Tuning aid / test hook: the tiling the row-band convolution kernel (csrc/conv_tile.hip: 3x3, stride 1, pad 1 on small maps) would
+ * choose for a launch -- out[0..7] = rows per tile, pixel groups per wave (MT), 16-channel tiles per workgroup (NTW), channel blocks,
+ * workgroups, K-steps per weight chunk, LDS bytes, estimated microseconds x 100.  Returns 0, or -1 when the kernel does not take the
+ * shape.  (No reference counterpart: the reference leaves the choice of algorithm to cuDNN behind nn.Conv2d, core/models/yolov8/modules.py:19-33.) */
+int cvx_debug_conv_tile_plan(int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t* out8);
+
 /* Bytes of device memory the engine currently owns (workspaces). */
 int64_t cvx_engine_workspace_bytes(const cvx_engine* e);
 /* Counts re-plans: a forward with a different batch size (or the first training forward after eval-only ones) frees and

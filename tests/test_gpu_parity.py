@@ -181,6 +181,48 @@ def test_gemm_shaped_conv_kernel_all_epilogues(dev, B, H, W, Ci, Co, k, s, dil):
     assert rel(sums[:, 1] / n, (conv.double() ** 2).mean((0, 2, 3))) < 1e-5
 
 
+TILE_CASES = [  # B, H, W, Cin, Cout: 3x3 stride 1 pad 1
+    (2, 40, 40, 64, 64), (3, 20, 20, 128, 128), (2, 80, 80, 32, 32), (1, 40, 40, 128, 144), (2, 20, 20, 256, 144), (2, 40, 40, 80, 80),
+    (1, 20, 20, 144, 256), (2, 13, 17, 32, 40), (1, 7, 5, 96, 24), (3, 33, 9, 48, 200), (1, 80, 80, 64, 144), (2, 2, 2, 64, 16), (1, 3, 50, 40, 8), (32, 20, 20, 128, 128), (32, 40, 40, 64, 64), (16, 40, 40, 128, 144),
+]
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co", TILE_CASES)
+def test_row_band_conv_kernel_all_epilogues(dev, B, H, W, Ci, Co):
+    """conv_tile.hip run directly (mode | 0x2000): plain fp16 store (+ accumulate is covered by the engine's data-gradient tests), folded
+    BN + SiLU, bias -> fp32, and the training epilogue (raw fp32 + per-channel statistics) on YOLOv8-n's small-map shapes, ragged row bands
+    (13 x 17, 33 x 9), maps smaller than one pixel group, channel counts that are not powers of two (80, 144, 96, 48, 40: no swizzle, padded
+    K-steps) and output channel counts that leave the last channel block ragged (200, 24, 8) -- against torch's fp32 convolution ON THE
+    CPU of the same fp16-valued operands (modules.py:19-33)."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(B + H * 3 + W + Ci + Co)
+    x16 = torch.randn(B, Ci, H, W, generator=g).half()
+    w16 = (torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5).half()
+    xd, wd = x16.permute(0, 2, 3, 1).contiguous().to(dev), w16.permute(0, 2, 3, 1).contiguous().to(dev)
+    conv = F.conv2d(x16.float(), w16.float(), None, 1, 1)  # CPU fp32
+    st = L.stream_ptr(dev)
+    sc, sh = torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g)
+    scd, shd = sc.to(dev), sh.to(dev)
+    out = torch.empty(B, H, W, Co, dtype=torch.float16, device=dev)
+    T = 0x2000
+    L.check(lib.cvx_conv2d_nhwc(L.ptr(xd), B, H, W, Ci, L.ptr(wd), Co, 3, 1, 1, 1, T | 0, None, None, L.ptr(out), st), "plain")
+    assert rel(out.float().permute(0, 3, 1, 2).cpu(), conv) < 5e-4
+    L.check(lib.cvx_conv2d_nhwc(L.ptr(xd), B, H, W, Ci, L.ptr(wd), Co, 3, 1, 1, 1, T | 1, L.ptr(scd), L.ptr(shd), L.ptr(out), st), "affine")
+    assert rel(out.float().permute(0, 3, 1, 2).cpu(), F.silu(conv * sc[None, :, None, None] + sh[None, :, None, None])) < 5e-4
+    out32 = torch.empty(B, H, W, Co, dtype=torch.float32, device=dev)
+    L.check(lib.cvx_conv2d_nhwc(L.ptr(xd), B, H, W, Ci, L.ptr(wd), Co, 3, 1, 1, 1, T | 2, L.ptr(shd), None, L.ptr(out32), st), "bias")
+    assert rel(out32.permute(0, 3, 1, 2).cpu(), conv + sh[None, :, None, None]) < 1e-5
+    R = 16 if Co <= 32 else 8 if Co <= 64 else 4 if Co <= 128 else 2 if Co <= 256 else 1  # cvx_stat_replicas (csrc/bn_act.h:8)
+    slab = torch.zeros(R, Co, 2, 2, dtype=torch.int64, device=dev)
+    L.check(lib.cvx_conv2d_nhwc(L.ptr(xd), B, H, W, Ci, L.ptr(wd), Co, 3, 1, 1, 1, T | 3, None, L.ptr(slab), L.ptr(out32), st), "stats")
+    assert rel(out32.permute(0, 3, 1, 2).cpu(), conv) < 1e-5
+    tot = slab.sum(0).double().cpu()
+    sums = tot[..., 0] / 64.0 + tot[..., 1] / 2.0 ** 40
+    n = B * H * W
+    assert (sums[:, 0] / n - conv.double().mean((0, 2, 3))).abs().max() < 1e-5
+    assert rel(sums[:, 1] / n, (conv.double() ** 2).mean((0, 2, 3))) < 1e-5
+
+
 @pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7])
 def test_gemm_shaped_conv_kernel_every_variant(dev, variant):
     """Each variant of conv_gemm.hip (macro tile 256x256 ... 128x128, 3 / 4 ring slots, 32- / 64-deep chunks: kVariants) forced through
