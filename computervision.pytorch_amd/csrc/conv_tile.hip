@@ -139,7 +139,9 @@ bool plan_tile(const ConvParams& p, Plan* best) {
       if (!KSC) continue;
       const int CB = KSC * NTW * 1024;
       const int nslots = R > NSTEPS / KSC ? NSTEPS / KSC : R;
-      const int lds = patch_bytes + nslots * CB + stat_bytes;
+      const int stage_bytes = kTileWaves * MT * 16 * (16 * NTW * 4 + 16);  // the epilogue's staged rows (reuses the whole allocation)
+      const int lds = std::max(patch_bytes + nslots * CB + stat_bytes, stage_bytes);
+      if (lds > 160 * 1024) continue;
       const long long wgs = (long long)tpi * p.B * NB;
       const double rounds = (double)((wgs + 255) / 256);
       // per workgroup: fixed 2.0 us + DMA of (patch + first chunk) at 60 GB/s before the first MFMA + K loop + stores

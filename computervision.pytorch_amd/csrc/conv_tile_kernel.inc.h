@@ -68,7 +68,6 @@ __global__ __launch_bounds__(64 * kTileWaves) void conv_tile_kernel(const ConvPa
   const int rows_here = H - y0 < a.TR ? H - y0 : a.TR;
   const int npix = rows_here * W;
   unsigned S0[MT], S1[MT], S2[MT];  // (three NAMED arrays: a [3][MT] array indexed by the tap's column offset went to scratch memory)
-  long long out_off[MT], res_off[MT];
   bool pvalid[MT];
   const unsigned rowpitch = (unsigned)(Wp * P * 16);
 #pragma unroll
@@ -86,9 +85,6 @@ __global__ __launch_bounds__(64 * kTileWaves) void conv_tile_kernel(const ConvPa
     S0[i] = s_of(pc);
     S1[i] = s_of(pc + 1u);
     S2[i] = s_of(pc + 2u);
-    const long long pix = (long long)(y0 + (int)pr) * W + (int)pc;
-    out_off[i] = (long long)b * p.out_bstride + pix * p.out_ld;
-    res_off[i] = (long long)b * p.res_bstride + pix * p.res_ld;
   }
 
   f4 acc[MT][NTW];
@@ -111,7 +107,7 @@ __global__ __launch_bounds__(64 * kTileWaves) void conv_tile_kernel(const ConvPa
   // everything above is needed only after the wait below: keep it ABOVE the wait (the compiler sank these ~300 instructions behind the
   // barrier, where nothing overlapped them: 2.8 us of a 6.7-us "K loop" was this address arithmetic)
 #pragma unroll
-  for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(S0[i]), "v"(S1[i]), "v"(S2[i]), "v"(out_off[i]), "v"(res_off[i]));
+  for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(S0[i]), "v"(S1[i]), "v"(S2[i]));
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -229,14 +225,122 @@ __global__ __launch_bounds__(64 * kTileWaves) void conv_tile_kernel(const ConvPa
 #undef CVX_TILE_BODY
   clk_mark(p, 3);
 
-  // ---- epilogue (conv_tile_common.h) ----
+  // ---- epilogue.  The accumulators (lane = pixel fr of a group, 4 channels per 16-channel tile) pass through the now idle LDS, wave by
+  // wave (a private region: no barrier but the one below), and come back as ROWS: a lane takes 8 consecutive channels of one pixel, so
+  // every output element leaves in a 16-byte store whose neighbours in the wave are contiguous (straight from the accumulators a
+  // lane stored 8 bytes per pixel pitch: 16 cache lines per instruction), and the activation / residual / accumulate arithmetic is ONE
+  // rolled loop (the shared epilogue's kinds sat inside MT x NTW unrolled bodies: 3-6 us of mostly instruction fetch per launch). ----
+  constexpr int RS = BN * 4 + 16;                  // bytes per staged pixel row (fp32 channels + 16: conflict-free 16-byte columns)
+  constexpr int CPR = BN / 8;                      // 8-channel chunks per row
+  constexpr int RPI = 64 / CPR;                    // rows per loop trip; lanes >= RPI * CPR idle (channel counts that do not divide 64)
+  constexpr int ROWS = MT * 16;                    // pixel rows of this wave
+  // training: per-channel sums straight from the accumulators (one lane group = 16 pixels of 4 channels), folded below
+  const int epi = p.epi;
   f4 st1[NTW], st2[NTW];
+  if (epi == CVX_EPI_RAW_STATS) {
 #pragma unroll
-  for (int j = 0; j < NTW; ++j) st1[j] = st2[j] = f4{0.f, 0.f, 0.f, 0.f};
-  epilogue_tile<kTileWaves, 1, MT, NTW>(p, acc, out_off, res_off, pvalid, 0, fq, nblk, st1, st2);
-  if (p.epi == CVX_EPI_RAW_STATS) {
-    float* sStat = reinterpret_cast<float*>(smem + a.stat_off);
-    // (conv_tile_common.h's stats_flush walks the channels with a stride of 256 threads: twice the atomics beyond 128 channels with 512)
+    for (int j = 0; j < NTW; ++j) {
+      st1[j] = st2[j] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        if (pvalid[i]) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            st1[j][r] += acc[i][j][r];
+            st2[j][r] += acc[i][j][r] * acc[i][j][r];
+          }
+        }
+    }
+  }
+  if (epi == CVX_EPI_RAW_STATS) {
+    // training: raw fp32 rows straight from the accumulators (16-byte stores, 64-byte runs per pixel: measured ahead of the staged
+    // form here -- 2.8 vs 4.2 us on 40 x 40, 64 -> 64 -- the fp32 rows are twice the bytes to stage)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      if (!pvalid[i]) continue;
+      const unsigned m = (unsigned)((wave * MT + i) * 16 + fr);
+      const unsigned pr = __umulhi(m, a.magic_w);
+      const unsigned pc = m - pr * (unsigned)W;
+      float* dst = p.out32 + (long long)b * p.out_bstride + ((long long)(y0 + (int)pr) * W + (int)pc) * p.out_ld + nblk * BN + fq * 4;
+#pragma unroll
+      for (int j = 0; j < NTW; ++j)
+        if (nblk * BN + j * 16 + fq * 4 < p.Cout) *reinterpret_cast<f4*>(dst + j * 16) = acc[i][j];
+    }
+  } else {
+  __syncthreads();  // every wave is done with the patch and the ring
+    unsigned char* wreg = smem + wave * (ROWS * RS);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) *reinterpret_cast<f4*>(wreg + (i * 16 + fr) * RS + (j * 16 + fq * 4) * 4) = acc[i][j];
+    {
+      const int q = lane % CPR, r0 = lane / CPR;
+      const int n = nblk * BN + q * 8;            // first of this lane's 8 channels
+      const bool lane_on = r0 < RPI && n < p.Cout;
+      const int act_kind = p.act_kind, res_pre = p.res_pre, accumulate = p.accumulate;
+      const half_t* res = p.res;
+      float c0[8], c1[8];                         // scale / shift (AFFINE_SILU), bias (BIAS_F32)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        c0[k] = 1.f;
+        c1[k] = 0.f;
+      }
+      if (lane_on && epi == CVX_EPI_AFFINE_SILU) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          c0[k] = p.scale[n + k];
+          c1[k] = p.shift[n + k];
+        }
+      }
+      if (lane_on && epi == CVX_EPI_BIAS_F32) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c1[k] = p.bias[n + k];
+      }
+      const int m_wave = wave * ROWS;
+      for (int r = r0; r < ROWS; r += RPI) {
+        const int m = m_wave + r;
+        if (!lane_on || m >= npix) continue;
+        const unsigned pr = __umulhi((unsigned)m, a.magic_w);
+        const unsigned pc = (unsigned)m - pr * (unsigned)W;
+        const long long pix = (long long)(y0 + (int)pr) * W + (int)pc;
+        const f4 lo = *reinterpret_cast<const f4*>(wreg + r * RS + q * 32);
+        const f4 hi = *reinterpret_cast<const f4*>(wreg + r * RS + q * 32 + 16);
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        if (epi == CVX_EPI_BIAS_F32) {
+          float* dst = p.out32 + (long long)b * p.out_bstride + pix * p.out_ld + n;
+          *reinterpret_cast<f4*>(dst) = f4{v[0] + c1[0], v[1] + c1[1], v[2] + c1[2], v[3] + c1[3]};
+          *reinterpret_cast<f4*>(dst + 4) = f4{v[4] + c1[4], v[5] + c1[5], v[6] + c1[6], v[7] + c1[7]};
+          continue;
+        }
+        half_t* dst = p.out16 + (long long)b * p.out_bstride + pix * p.out_ld + n;
+        if (epi == CVX_EPI_AFFINE_SILU) {
+          float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if (res) {
+            const h8 rr = *reinterpret_cast<const h8*>(res + (long long)b * p.res_bstride + pix * p.res_ld + n);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) rv[k] = (float)rr[k];
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            float t = v[k] * c0[k] + c1[k];
+            if (res_pre) t += rv[k];
+            if (act_kind == 0) t = cvx_silu(t);
+            else if (act_kind == 1) t = fmaxf(t, 0.f);
+            if (!res_pre) t += rv[k];
+            v[k] = t;
+          }
+        } else if (accumulate) {  // PLAIN: data gradients that add to what another consumer left there
+          const h8 old = *reinterpret_cast<const h8*>(dst);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] += (float)old[k];
+        }
+        *reinterpret_cast<h8*>(dst) = h8{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3], (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
+      }
+    }
+  }
+  if (epi == CVX_EPI_RAW_STATS) {
+    __syncthreads();  // the staged rows have been read: the scratch below may overlap them
+    float* sStat = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int j = 0; j < NTW; ++j)
 #pragma unroll
@@ -249,12 +353,12 @@ __global__ __launch_bounds__(64 * kTileWaves) void conv_tile_kernel(const ConvPa
       }
     __syncthreads();
     for (int t = tid; t < BN * 2; t += 64 * kTileWaves) {
-      const int ch = t >> 1, which = t & 1, n = nblk * BN + ch;
-      if (n < p.Cout) {
+      const int ch = t >> 1, which = t & 1, nn = nblk * BN + ch;
+      if (nn < p.Cout) {
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < kTileWaves; ++w) v += sStat[(w * BN + ch) * 2 + which];
-        cvx_fix_atomic_add(p.stats, ((long long)(blockIdx.x % p.stats_replicas) * p.Cout + n) * 2 + which, v);
+        cvx_fix_atomic_add(p.stats, ((long long)(blockIdx.x % p.stats_replicas) * p.Cout + nn) * 2 + which, v);
       }
     }
   }
