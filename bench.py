@@ -30,7 +30,13 @@ import time
 # different priorities, so this costs it nothing (same-box A/B of six workloads: equal within noise), while whatever further streams torch,
 # RCCL or the caller put to work can then no longer push the process over the budget (six streams at work: 6.4 instead of 14.6 ms).  An explicit
 # setting in the environment wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
+# ... for the single-process runs only: with more than one rank the default exchange launches its all-reduces on ProcessGroupNCCL's internal
+# stream, which has the main stream's priority -- under one queue per priority the collective (and its wait for the weight gradients) would
+# sit in the main chain's in-order queue.  Until an N-GPU A/B exists the runtime default stays for WORLD_SIZE > 1 (CVX_BENCH_HWQ overrides).
+if os.environ.get("CVX_BENCH_HWQ"):
+    os.environ["GPU_MAX_HW_QUEUES"] = os.environ["CVX_BENCH_HWQ"]
+elif int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
 
 import torch  # noqa: E402
 
@@ -40,8 +46,21 @@ sys.path.insert(0, ROOT)
 MFMA_FP16_PEAK_TFLOPS = 2516.6                  # MI355X dense fp16
 HBM_PEAK_GBS = 8000.0
 GFLOP = {"n": (8.742912, 26.140262), "s": (28.601549, 85.627699)}   # (forward, train step) per image, SURVEY section 8(d)
-TRAFFIC_FILES = ("r03_conv_traffic.json", "r02_conv_traffic.json")      # newest first; PMC passes of a build, keyed by that build's library hash
-MFMA_FILES = ("r03_mfma_busy.json",)                                     # SQ_VALU_MFMA_BUSY_CYCLES pass (tools/pmc_mfma.py), same keying
+TRAFFIC_FILES = ("r04_conv_traffic.json", "r03_conv_traffic.json", "r02_conv_traffic.json")      # newest first; PMC passes of a build, keyed by that build's library hash
+MFMA_FILES = ("r04_mfma_busy.json", "r03_mfma_busy.json")                                     # SQ_VALU_MFMA_BUSY_CYCLES pass (tools/pmc_mfma.py), same keying
+
+
+def src_sha256():
+    """Hash of the kernel sources (csrc/*.hip, *.h + the ABI header): what the PMC files of profiles/ are keyed on.  (The library's own hash
+    changes with the build directory -- hipcc compilation-unit ids -- so a rebuild elsewhere silently dropped `traffic`.)"""
+    import hashlib
+    import glob
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "computervision.pytorch_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + [os.path.join(ROOT, "include", "cvx_engine.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
 
 
 def lib_sha256():
@@ -58,7 +77,7 @@ def measured_traffic(model, batch):
         if not os.path.exists(path):
             continue
         t = json.load(open(path))
-        if t.get("lib_sha256") == sha and t.get("model", "n") == model and t.get("batch", 32) == batch:
+        if (t.get("src_sha256") == src_sha256() or t.get("lib_sha256") == sha) and t.get("model", "n") == model and t.get("batch", 32) == batch:
             return round(t["hbm_bytes_per_launch"]), f"profiles/{name} (library {sha[:12]})"
         return None, f"profiles/{name} was measured on library {str(t.get('lib_sha256'))[:12]}, running {sha[:12]}: refused"
     return None, "no PMC passes committed for this round yet"
@@ -72,7 +91,7 @@ def measured_mfma_busy():
         if not os.path.exists(path):
             continue
         t = json.load(open(path))
-        if t.get("lib_sha256") == sha:
+        if t.get("src_sha256") == src_sha256() or t.get("lib_sha256") == sha:
             return t.get("conv_mfma_busy_frac"), f"profiles/{name} (library {sha[:12]})"
         return None, f"profiles/{name} was measured on library {str(t.get('lib_sha256'))[:12]}, running {sha[:12]}: refused"
     return None, "no MFMA-busy PMC pass committed for this round yet"
@@ -917,6 +936,7 @@ def main():
         sync()
     eval_ms = (time.perf_counter() - t1) / n_eval * 1e3
     model.train()
+    elapsed_rank0 = elapsed
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -950,9 +970,15 @@ def main():
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"YOLOv8-{args.model} train step (fwd + v8 loss + bwd + Adam), batch {B}/GPU, 640x640, nc=80, random init",
                        "global_batch": B * world, "parallelism": f"dp{world}", "loss_scale": cfg.engine.loss_scale,
-                       "launch": "hipGraph replay" if use_graph else "eager"},
+                       "launch": "hipGraph replay" if use_graph else "eager",
+                       # the first multi-GPU record should be read as N = 2 against N = 1: rank 0's own time beside the
+                       # max over ranks, which exchange path ran, and the hardware-queue setting it ran under
+                       "exchange": ("none (1 rank)" if not use_dist else ("C ABI: cvx_engine_backward_exchange (RCCL through dlopen)" if comm is not None
+                                                                          else "torch.distributed all_reduce per bucket (ProcessGroupNCCL)")),
+                       "ms_per_step_rank0": round(elapsed_rank0 / args.steps * 1e3, 4),
+                       "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default")},
             "roofline": {"bound": "mfma",
-                         "kernel": "implicit-GEMM convolution, forward + data-gradient launches: conv_halo_kernel + conv_pw_kernel + "
+                         "kernel": "implicit-GEMM convolution, forward + data-gradient launches: conv_halo_kernel + conv_tile_kernel + conv_pw_kernel + "
                                    "conv_gemm_kernel + conv_igemm_dma_kernel (+ the fp32 stem passes)",
                          "achieved": round(achieved, 3), "peak": MFMA_FP16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_FP16_PEAK_TFLOPS, 5), "traffic": traffic, "traffic_source": traffic_note,

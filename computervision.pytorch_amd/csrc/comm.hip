@@ -39,11 +39,24 @@ struct Rccl {
 
 int load_rccl() {
   if (g_rccl.lib) return 0;
-  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  // The copy that is ALREADY in the process first (torch bundles one under its SONAME and has loaded it before this library is used for an
+  // exchange): a second, different RCCL in one process would be driven through the hand-declared ABI above against a version it was not
+  // written for.  RTLD_NOLOAD probes return NULL when the name is not loaded yet; only then is a copy loaded by name.
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
   void* h = nullptr;
   for (const char* n : names)
-    if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD))) break;
+  if (!h && dlsym(RTLD_DEFAULT, "ncclAllReduce")) h = dlopen(nullptr, RTLD_NOW);  // linked in under another name: resolve through the global scope
+  if (!h)
+    for (const char* n : names)
+      if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
   CVX_CHECK(h, std::string("RCCL not found (dlopen librccl.so): ") + (dlerror() ? dlerror() : ""));
+  {  // the entry points below were declared by hand against the NCCL 2.x ABI (by-value 128-byte unique id, enum values of nccl.h 2.x)
+    typedef int (*fn_get_version)(int*);
+    fn_get_version gv = (fn_get_version)dlsym(h, "ncclGetVersion");
+    int ver = 0;
+    if (gv && gv(&ver) == 0) CVX_CHECK(ver / 10000 == 2 || (ver >= 2000 && ver < 3000), "RCCL: library version " + std::to_string(ver) + " is not the 2.x ABI this binding was written for");
+  }
   g_rccl.get_unique_id = (fn_get_unique_id)dlsym(h, "ncclGetUniqueId");
   g_rccl.comm_init_rank = (fn_comm_init_rank)dlsym(h, "ncclCommInitRank");
   g_rccl.comm_destroy = (fn_comm_destroy)dlsym(h, "ncclCommDestroy");

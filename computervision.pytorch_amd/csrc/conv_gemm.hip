@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <vector>
 
 #include "conv_tile_common.h"
@@ -597,7 +598,8 @@ struct PackSlot {
   half_t* buf = nullptr;
   size_t bytes = 0;
 };
-std::map<std::pair<const void*, std::pair<const void*, int>>, PackSlot> g_pack;
+std::map<std::pair<const void*, std::pair<const void*, int>>, PackSlot> g_pack;  // stand-alone launches only (the engine packs at plan time)
+std::mutex g_pack_mu;
 
 template <int MT, int NT, int NS, int KC>
 int launch_gemm(const ConvParams& p, hipStream_t stream) {
@@ -609,9 +611,13 @@ int launch_gemm(const ConvParams& p, hipStream_t stream) {
   static const int dbg = cvx_tune_int("CVX_GEMM_DBG", 0);  // tuning build: 1 no pack, 2 no main kernel, 16 main kernel stops after the K loop, 32.. see CVX_GEMM_DBG_BIT
   const half_t* packed = (p.wt_packed_bn == G::BN && p.wt_packed_kc == KC) ? p.wt_packed : nullptr;
   if (!packed) {
+    std::lock_guard<std::mutex> lk(g_pack_mu);
     PackSlot& ps = g_pack[{p.wt, {p.taps, G::BN * 1024 + KC}}];
     const size_t need = (size_t)n_tiles * nchunks * G::B_BYTES;
     if (ps.bytes < need) {
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      (void)hipStreamIsCapturing(stream, &cs);
+      CVX_CHECK(cs == hipStreamCaptureStatusNone, "conv_gemm: the packed-weight buffer cannot be (re)allocated while the stream is capturing -- run the launch once before the capture");
       if (ps.buf) CVX_HIP(hipFree(ps.buf));
       CVX_HIP(hipMalloc((void**)&ps.buf, need));
       ps.bytes = need;
@@ -765,4 +771,12 @@ int cvx_conv_gemm_launch(const ConvParams& p, hipStream_t stream) {
   }
   CVX_HIP(hipGetLastError());
   return 0;
+}
+
+// frees the packed-weight buffers of the stand-alone launches (cvx_engine_destroy calls it: entries are keyed by weight pointers that die with their engine)
+void cvx_conv_gemm_release() {
+  std::lock_guard<std::mutex> lk(g_pack_mu);
+  for (auto& kv : g_pack)
+    if (kv.second.buf) (void)hipFree(kv.second.buf);
+  g_pack.clear();
 }

@@ -132,6 +132,7 @@ int cvx_conv_gemm_pack_jobs(const GemmPackJob* d_jobs, int njobs, int nblocks, h
 bool cvx_conv_gemm_shape_ok(const ConvParams& p);   // what the kernel can run at all
 bool cvx_conv_gemm_supported(const ConvParams& p);  // ... and where the dispatcher prefers it
 int cvx_conv_gemm_launch(const ConvParams& p, hipStream_t stream);
+void cvx_conv_gemm_release();  // packed-weight buffers of the stand-alone launches
 // row-band kernel for the small 3x3 stride-1 maps (conv_tile.hip)
 struct TilePackPlan {
   int BN, NB, SPT;   // channel-block rows, channel blocks, K-steps per tap of the packed image

@@ -1237,6 +1237,8 @@ extern "C" int cvx_engine_destroy(cvx_engine* e) {
   }
   free_pool(e->batch_allocs);
   free_pool(e->static_allocs);
+  cvx_conv_gemm_release();  // stand-alone pack caches are keyed by weight pointers: none may outlive the arenas they point into
+  cvx_conv_tile_release();
   cvx_engine_free_bw(e);
   delete e;
   return 0;

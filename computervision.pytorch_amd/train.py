@@ -175,19 +175,26 @@ class FlatAdam(torch.optim.Optimizer):
             self._m.zero_()
             self._v.zero_()
             step = 0
+            skipped = []
             for i, st in sd["state"].items():
                 i = int(i)
                 if i >= len(params):
                     raise L.CvxError(f"optimizer checkpoint has state for parameter {i}, the model has {len(params)} parameters")
                 mv = self._moment_views(params[i])
                 if mv is None:
+                    skipped.append(i)
                     continue
-                if tuple(st["exp_avg"].shape) != tuple(params[i].shape):
-                    raise L.CvxError(f"optimizer checkpoint: parameter {i} has shape {tuple(st['exp_avg'].shape)}, the model's is {tuple(params[i].shape)}")
+                for key in ("exp_avg", "exp_avg_sq"):
+                    if tuple(st[key].shape) != tuple(params[i].shape):
+                        raise L.CvxError(f"optimizer checkpoint: {key} of parameter {i} has shape {tuple(st[key].shape)}, the model's is {tuple(params[i].shape)}")
                 mv[0].copy_(st["exp_avg"])
                 mv[1].copy_(st["exp_avg_sq"])
                 step = max(step, int(float(st["step"])))
             self._step = step
+            if skipped:
+                import warnings
+                warnings.warn(f"FlatAdam.load_state_dict: state of {len(skipped)} parameter(s) (indices {skipped[:8]}...) was NOT restored: they are "
+                              "not views of the flat parameter arena (their moments start from zero)", stacklevel=2)
         else:
             self._step = int(sd["step"])
             if sd.get("exp_avg") is not None:

@@ -90,7 +90,11 @@ typedef struct cvx_engine cvx_engine;
  * Builds an engine for a fixed input size.  `image_buf` is the index of the buffer-table entry (c == 8) that stands for
  * the caller's NCHW fp32 images; exactly one op may read it: the 3 -> 16..80 channel 3x3 stride-2 BN+SiLU stem, which runs
  * in fp32 straight from the caller's tensor (no fp16 copy of the image is made).
- * Replaces: Yolo8.__init__ graph construction, core/models/yolov8/yolo_v8.py:17-62. */
+ * Replaces: Yolo8.__init__ graph construction, core/models/yolov8/yolo_v8.py:17-62.  *
+ * Threading: the auxiliary HIP streams (weight gradients, lanes) are ONE set per device shared by all engines of the process (the
+ * hardware-queue budget).  All engines of a device must therefore be driven from one host thread (or be externally
+ * serialised), and while a hipGraph capture of one engine's step is open no other engine of that device may launch: its kernels would
+ * land on the shared streams that the capture has pulled into capture mode. */
 int cvx_engine_create(cvx_engine** out, const cvx_buf_desc* bufs, int32_t nbufs, const cvx_op_desc* ops, int32_t nops,
                       int32_t image_buf, int32_t pred_buf, int32_t device, void* hip_stream);
 int cvx_engine_destroy(cvx_engine* e);

@@ -466,6 +466,56 @@ def yolov7_loss_section(builder, report):
     report["yolov7_loss"] = dict(items=[float(loss), float(box_l), float(obj_l), float(cls_l)], targets=len(rows))
 
 
+def yolov8_traj_section(builder, report):
+    """50 Adam steps of the IMPORTED REFERENCE (core/trainer/yolo8_train.py:93-111 without AMP: model, Loss, torch.optim.Adam via
+    lr_scheduler.get_optimizer) on one repeated 160x160 batch of 8 at lr 1e-4 -- a regime in which the loss curve is smooth (at lr 1e-3 on two
+    images it is chaotic: fp16 storage alone moves it by 20-30 % per window) -- next to the oracle's fp32 restatement (asserted against
+    the reference step by step) and the oracle with the engine's fp16 rounding points emulated -> tests/golden/yolov8n_traj_160.npz."""
+    sys.path.insert(0, ROOT)
+    from oracle import yolov8_ref as O
+    from oracle import synth
+    from core.trainer.lr_scheduler import get_optimizer
+    STEPS, LR = 50, 1e-4
+    torch.manual_seed(0)
+    cfg, algo_cls, _ = builder.export_from_registry("yolo8_det")
+    algo = algo_cls(cfg, torch.device("cpu"))
+    model, _ = algo.build_model()
+    crit = algo.build_loss(model)
+    opt = get_optimizer("Adam", model, LR)
+    x, batch = synth.images(8, 160, 160, seed=11), synth.targets(8, seed=12)
+    model.train()
+    ref = []
+    for _ in range(STEPS):
+        opt.zero_grad()
+        loss, _items = crit(model(x.clone()), {k: v.clone() for k, v in batch.items()})
+        loss.backward()
+        opt.step()
+        ref.append(float(loss))
+    curves = {}
+    for name, emulate in (("fp32", False), ("fp16_emulation", True)):
+        sd, state = O.init_state_dict("n", 80, seed=0), {}
+        O.FP16_STORAGE[0] = emulate
+        try:
+            curves[name] = np.array([float(O.train_step(sd, x.clone(), batch, state, "n", 80, LR)[0]) for _ in range(STEPS)])
+        finally:
+            O.FP16_STORAGE[0] = False
+    ref = np.array(ref)
+    dev32 = float(np.max(np.abs(curves["fp32"] - ref) / ref))
+    dev16 = float(np.max(np.abs(curves["fp16_emulation"] - ref) / ref))
+    # The restatement follows the reference to fp32 round-off until a discrete event (a TaskAlignedAssigner top-k flip) amplifies that
+    # round-off: steps 0-19 agree to < 1e-3 per step, from step ~24 on the two fp32 curves differ by up to 13 %.  The pinned window is the
+    # first 20 steps; the rest of the curves is recorded for reference.
+    PIN = 20
+    dev32_pin = float(np.max(np.abs(curves["fp32"][:PIN] - ref[:PIN]) / ref[:PIN]))
+    dev16_pin = float(np.max(np.abs(curves["fp16_emulation"][:PIN] - ref[:PIN]) / ref[:PIN]))
+    assert dev32_pin < 1e-3, ("oracle fp32 vs the reference over the first 20 steps", dev32_pin)
+    report["yolov8_traj"] = ("50 reference Adam steps (160x160, batch 8, lr 1e-4): oracle fp32 within %.1e per step over steps 0-19 (%.1e over all 50: "
+                             "an assignment flip near step 24 amplifies round-off), fp16-storage emulation within %.1e over steps 0-19" % (dev32_pin, dev32, dev16_pin))
+    np.savez(os.path.join(GOLD, "yolov8n_traj_160.npz"), reference=ref, fp32=curves["fp32"], fp16_emulation=curves["fp16_emulation"], steps=STEPS, lr=LR, pinned_steps=PIN,
+             note="oracle/make_golden.py yolov8_traj: images seed 11, targets seed 12, batch 8, 160x160, Adam lr 1e-4, seed-0 init")
+    print(report["yolov8_traj"], flush=True)
+
+
 def main():
     sys.path.insert(0, ROOT)
     from oracle import yolov8_ref as O
@@ -971,7 +1021,7 @@ def only(section):
     builder = _import_reference()
     torch.set_num_threads(8)
     report = {}
-    {"deeplab_train": deeplab_train_section, "yolov7_train": yolov7_train_section, "centernet_train": centernet_train_section, "ssd_train": ssd_train_section, "centernet_loss": centernet_loss_section, "ssd_loss": ssd_loss_section, "ssd_targets": ssd_targets_section, "centernet_targets": centernet_targets_section, "yolov7_loss": yolov7_loss_section}[section](builder, report)
+    {"yolov8_traj": yolov8_traj_section, "deeplab_train": deeplab_train_section, "yolov7_train": yolov7_train_section, "centernet_train": centernet_train_section, "ssd_train": ssd_train_section, "centernet_loss": centernet_loss_section, "ssd_loss": ssd_loss_section, "ssd_targets": ssd_targets_section, "centernet_targets": centernet_targets_section, "yolov7_loss": yolov7_loss_section}[section](builder, report)
     path = os.path.join(GOLD, "PIN_REPORT.json")
     full = json.load(open(path)) if os.path.exists(path) else {}
     full.update(report)

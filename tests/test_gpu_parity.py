@@ -158,7 +158,10 @@ def test_gemm_shaped_conv_kernel_all_epilogues(dev, B, H, W, Ci, Co, k, s, dil):
     w16 = (torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5).half()
     pad = dil * (k // 2)
     xd, wd = x16.permute(0, 2, 3, 1).contiguous().to(dev), w16.permute(0, 2, 3, 1).contiguous().to(dev)
-    conv = F.conv2d(x16.float().to(dev), w16.float().to(dev), None, s, pad, dil)
+    # the reference convolution: torch fp32 on the CPU for the small cases (every epilogue is then checked against a CPU result at least
+    # once per parametrisation set), torch-ROCm's own fp32 convolution for the large ones (a CPU conv of the 512-channel cases takes seconds each)
+    on_cpu = B * H * W * Ci * Co * k * k <= 2.5e9
+    conv = F.conv2d(x16.float(), w16.float(), None, s, pad, dil).to(dev) if on_cpu else F.conv2d(x16.float().to(dev), w16.float().to(dev), None, s, pad, dil)
     OH, OW = conv.shape[2:]
     st = L.stream_ptr(dev)
     sc, sh = (torch.rand(Co, generator=g) + 0.5).to(dev), torch.randn(Co, generator=g).to(dev)
@@ -720,7 +723,18 @@ def test_non_square_input_matches_oracle(dev):
     assert [tuple(o.shape) for o in outs] == [(3, 144, 12, 20), (3, 144, 6, 10), (3, 144, 3, 5)]
     ref32 = O.forward(O.init_state_dict("n", 80, seed=0), x, "n", 80, training=True)
     r = level_report("96x160 vs oracle fp32", outs, [t.detach() for t in ref32])
-    assert max(r) < 1.3e-3, r          # 3 x 5 cells at stride 32: 45 samples per BatchNorm channel at the deepest level
+    assert max(r[:2]) < LEVEL_TOL, r   # P3, P4: the stated bar
+    # P5 is 3 x 5 cells: 45 samples per BatchNorm channel at the deepest level, where a batch statistic over so few samples amplifies the
+    # fp16 operand rounding the reference's own CUDA autocast path has too.  The yardstick there is the oracle with exactly the engine's
+    # rounding points emulated (O.FP16_STORAGE): the engine may not exceed it by more than a quarter (and never 1.3e-3).
+    O.FP16_STORAGE[0] = True
+    try:
+        emu = O.forward(O.init_state_dict("n", 80, seed=0), x, "n", 80, training=True)
+    finally:
+        O.FP16_STORAGE[0] = False
+    r_emu = float((emu[2] - ref32[2]).norm() / ref32[2].norm())
+    print("P5: engine", r[2], "fp16-rounding emulation of the reference", r_emu)
+    assert r[2] < max(LEVEL_TOL, 1.25 * r_emu) and r[2] < 1.3e-3, (r, r_emu)
     # and a fused training step on it stays finite (data / weight gradients at the same odd tile edges)
     from computervision.pytorch_amd.train import FlatAdam, FusedTrainStep, V8DetectionLoss
     from configs import Yolo8DetConfig
@@ -960,6 +974,31 @@ def test_fifty_fused_steps_follow_the_oracle_loss_trajectory(dev, gold):
     assert np.abs(mine[:2] / ref[:2] - 1).max() < 2e-2
     assert d_eng.max() < 1.5 * d_emu.max() + 0.05, (d_eng, d_emu)
     assert d_eng[-1] < 0.2
+
+
+def test_twenty_fused_steps_follow_the_reference_loss_curve(dev, gold):
+    """The REAL reference's loss curve (tests/golden/yolov8n_traj_160.npz, written by oracle/make_golden.py yolov8_traj: the imported model,
+    Loss and torch.optim.Adam of core/trainer/yolo8_train.py:93-111 for 50 steps on one repeated 160x160 batch of 8 at lr 1e-4) against the
+    fused engine step from the same seed-0 initialisation.  At this setting the dynamics are smooth for ~24 steps (the oracle's fp32
+    restatement follows the reference to 7.5e-5 per step over steps 0-19; afterwards an assigner flip separates even the two fp32 runs), so
+    the pinned window is steps 0-19: the engine must stay within 6 % of the reference on every step and within 3 % on the window mean --
+    the oracle with the engine's fp16 rounding points emulated is 4.6 % / 2.4 % off on the same window."""
+    from computervision.pytorch_amd.train import FlatAdam, FusedTrainStep, V8DetectionLoss
+    from configs import Yolo8DetConfig
+    g = gold("yolov8n_traj_160.npz")
+    n = int(g["pinned_steps"])
+    ref, emu = g["reference"][:n], g["fp16_emulation"][:n]
+    x, batch = synth.images(8, 160, 160, seed=11), synth.targets(8, seed=12)
+    m = new_model(dev).train()
+    step = FusedTrainStep(m, V8DetectionLoss(Yolo8DetConfig(), m), FlatAdam(m, lr=float(g["lr"])))
+    xd = x.to(dev)
+    mine = np.array([float(step(xd, batch).sum()) * 8 for _ in range(n)])   # items are per-image means; the reference's loss is items.sum() * batch
+    d_eng, d_emu = np.abs(mine / ref - 1), np.abs(emu / ref - 1)
+    print("engine vs reference per step", np.round(d_eng, 4), "max", d_eng.max(), "mean-curve", abs(mine.mean() / ref.mean() - 1),
+          "| emulation vs reference max", d_emu.max(), "mean-curve", abs(emu.mean() / ref.mean() - 1))
+    assert np.abs(mine[:2] / ref[:2] - 1).max() < 5e-3
+    assert d_eng.max() < 0.06, d_eng
+    assert abs(mine.mean() / ref.mean() - 1) < 0.03
 
 
 def test_autograd_compat_path_matches_fused_path(dev):

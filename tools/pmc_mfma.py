@@ -26,6 +26,18 @@ def family(name):
     return "other"
 
 
+def _src_sha256():
+    """the key bench.py looks profiles/ files up by (bench.py: src_sha256)"""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    csrc = os.path.join(root, "computervision.pytorch_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + [os.path.join(root, "include", "cvx_engine.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def main():
     per = collections.OrderedDict()
     for r in csv.DictReader(open(sys.argv[1])):
@@ -46,7 +58,7 @@ def main():
     conv_act = sum(fam[k]["gui_active"] for k in CONV if k in fam) / 8.0 * 1024.0
     all_act = sum(f["gui_active"] for f in fam.values()) / 8.0 * 1024.0
     lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "computervision.pytorch_amd", "lib", "libcvx_engine.so")
-    out = {"lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(),
+    out = {"lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(), "src_sha256": _src_sha256(),
            "source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace (a pass of its own); every dispatch of the process",
            "formula": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)",
            "conv_family": [k for k in CONV if k in fam], "conv_mfma_busy_frac": conv_busy / conv_act if conv_act > 0 else None,

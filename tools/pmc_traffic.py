@@ -9,6 +9,8 @@ One timed step (between two Adam launches) is summed.  Correction as MI355X_MICR
 bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB counters; FETCH_SIZE tallies 128-byte requests at 64 bytes).
 """
 import collections
+import hashlib
+import os
 import csv
 import json
 import sys
@@ -42,6 +44,18 @@ def one_step(path, counter):
     return agg
 
 
+def _src_sha256():
+    """the key bench.py looks profiles/ files up by (bench.py: src_sha256)"""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    csrc = os.path.join(root, "computervision.pytorch_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + [os.path.join(root, "include", "cvx_engine.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def main():
     fetch, write = one_step(sys.argv[1], "FETCH_SIZE"), one_step(sys.argv[2], "WRITE_SIZE")
     fam = {k: {"fetch_kib": fetch[k][0], "write_kib": write[k][0], "launches": fetch[k][1],
@@ -51,7 +65,7 @@ def main():
     import hashlib
     import os
     lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "computervision.pytorch_amd", "lib", "libcvx_engine.so")
-    out = {"lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(), "model": "n", "batch": 32,
+    out = {"lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(), "src_sha256": _src_sha256(), "model": "n", "batch": 32,
            "source": "rocprofv3 --pmc FETCH_SIZE --kernel-trace / --pmc WRITE_SIZE --kernel-trace (separate passes) -- python bench.py "
                      "--no-cpu-baseline --steps 3 --warmup 2 --profile-steps 1; one timed step",
            "correction": "bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB counters), MI355X_MICROARCH.md section HBM",
