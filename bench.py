@@ -773,7 +773,8 @@ def yolov8_eval_main(args):
 
     step()
     eng = model._last_engine
-    eng.set_fusion(bool(args.fusion))
+    if args.fusion:  # tuning build only (CVX_LIB=build/libcvx_tuning.so): the release library raises here
+        eng.set_fusion(True)
     for _ in range(max(args.warmup, 1)):
         step()
     sync()
@@ -833,7 +834,7 @@ def main():
                     help="centernet: BASELINE.json configs[3] -- CenterNet DLA-34 (nc 80) 512x512 inference + heat-map decode, batch 64 per GPU")
     ap.add_argument("--exchange", default="torch", choices=["torch", "c"], help="N > 1: gradient exchange through torch.distributed (default) or "
                     "entirely behind the C ABI (RCCL communicator owned by the engine library, no Python between the backward ranges)")
-    ap.add_argument("--fusion", type=int, default=0, help="yolov8_eval: 1 runs the eval forward with the cross-layer fusion groups (Bottleneck pairs, Detect levels as one launch each; measured 1-6 %% slower, so off by default)")
+    ap.add_argument("--fusion", type=int, default=0, help="yolov8_eval: 1 runs the eval forward with the cross-layer fusion groups (Bottleneck pairs, Detect levels as one launch each; measured 1-6 %% slower: TUNING build only, CVX_LIB=build/libcvx_tuning.so)")
     ap.add_argument("--stream", default="default", choices=["default", "own"], help="own: launch on a torch.cuda.Stream of the bench's own instead of "
                     "the legacy default stream (A/B switch for the hardware-queue budget, DESIGN.md section 6)")
     args = ap.parse_args()

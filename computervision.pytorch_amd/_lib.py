@@ -46,6 +46,14 @@ OPF_CONV_BIAS = 2
 
 _P, _I32, _I64, _F, _U64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
 
+# entry points of the tuning build only (include/cvx_engine_experimental.h): bound when the loaded library exports them
+EXPERIMENTAL_PROTOTYPES = {
+    "cvx_chain_pair_unit": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _I32, _I32, _I32, C.POINTER(_F), _P]),
+    "cvx_chain_conv_unit": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _I32, _P, _P, _I32, _P, _I32, _I32, _I32, C.POINTER(_F), _P]),
+    "cvx_chain_detect_unit": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32,
+                                     _I32, _I32, C.POINTER(_F), _P]),
+}
+
 # name -> (restype, argtypes); every symbol include/cvx_engine.h declares
 PROTOTYPES = {
     "cvx_last_error": (C.c_char_p, []),
@@ -146,10 +154,6 @@ PROTOTYPES = {
     "cvx_allreduce_f32": (_I32, [_P, _I64, _P, _P]),
     "cvx_allreduce_grads": (_I32, [_P, _P, _P]),
     "cvx_engine_backward_exchange": (_I32, [_P, _P, _F, _P, _P, _I32, _P]),
-    "cvx_chain_pair_unit": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _I32, _I32, _I32, C.POINTER(_F), _P]),
-    "cvx_chain_conv_unit": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _I32, _P, _P, _I32, _P, _I32, _I32, _I32, C.POINTER(_F), _P]),
-    "cvx_chain_detect_unit": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32,
-                                     _I32, _I32, C.POINTER(_F), _P]),
     "cvx_stem_backward_nchw": (_I32, [_P, _I32, _I32, _I32, _P, _P, _I32, _P, _P, _P, _F, _P, _P, _P, _P]),
 }
 
@@ -169,10 +173,20 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in EXPERIMENTAL_PROTOTYPES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     if lib.cvx_abi_version() != ABI_VERSION:
         raise CvxError(f"ABI mismatch: library {lib.cvx_abi_version()} != binding {ABI_VERSION}")
     _lib = lib
     return lib
+
+
+def has_chain() -> bool:
+    """True when the loaded library is a tuning build that carries the chain kernel (tools/build_tuning.sh, CVX_LIB=...)."""
+    return hasattr(load(), "cvx_chain_pair_unit")
 
 
 def check(rc: int, what: str = ""):

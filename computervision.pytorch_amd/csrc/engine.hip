@@ -8,7 +8,9 @@
 #include <vector>
 
 #include "../../include/cvx_engine.h"
+#ifdef CVX_WITH_CHAIN  // tuning build only (tools/build_tuning.sh): the release library does not carry conv_chain.hip
 #include "conv_chain.h"
+#endif
 #include "bn_act.h"
 #include "conv_igemm.h"
 #include <map>
@@ -164,6 +166,7 @@ struct cvx_engine {
     int op;
   };
   int cur_op = -1;  // op index the launch loops are at (profile records carry it)
+#ifdef CVX_WITH_CHAIN
   // eval-mode fusion groups (conv_chain.hip): a Bottleneck's two 3x3 convs, or a whole Detect level, as one tile-resident launch
   struct FusedGroup {
     int first = 0, last = 0;  // op range the launch replaces
@@ -174,8 +177,9 @@ struct cvx_engine {
   std::vector<int> fused_at;              // op index -> group that STARTS there, -1 otherwise
   ChainPackJob* d_chain_jobs = nullptr;   // weight pre-pack jobs of all groups (one launch per forward)
   int n_chain_jobs = 0, chain_max_units = 0;
-  std::vector<signed char> sppf3;         // per op: 1 = first of three chained 5x5 max pools (SPPF) that go out as one launch, 2 = the other two
   bool chain_fusion = false;  // off by default: parity-green but 1-6 % slower than the per-layer kernels at batch 32; cvx_engine_set_fusion
+#endif
+  std::vector<signed char> sppf3;         // per op: 1 = first of three chained 5x5 max pools (SPPF) that go out as one launch, 2 = the other two
   // GEMM-shaped conv kernel: every routed layer's weights are re-ordered by ONE launch per forward, next to cvx_pack_weights
   half_t* gemm_arena = nullptr;
   GemmPackJob* d_gemm_jobs = nullptr;
@@ -426,8 +430,10 @@ int build_static(cvx_engine* e) {
   return 0;
 }
 
-// ---- eval-mode fusion groups: recognised in the op list, planned as tile-resident chains (conv_chain.hip) ----
 bool same_view(const cvx_view& a, const cvx_view& b) { return a.buf == b.buf && a.coff == b.coff && a.c == b.c && a.pix_off == b.pix_off; }
+
+#ifdef CVX_WITH_CHAIN
+// ---- eval-mode fusion groups: recognised in the op list, planned as tile-resident chains (conv_chain.hip) ----
 bool is_bn_silu_3x3(const cvx_op_desc& o) {
   return o.type == CVX_OP_CONV && o.k == 3 && o.stride == 1 && o.pad == 1 && o.dil == 1 && o.act == CVX_ACT_BN_SILU && !(o.flags & CVX_OPF_CONV_BIAS);
 }
@@ -590,6 +596,10 @@ int plan_fused_groups(cvx_engine* e, int B) {
   }
   return 0;
 }
+#else
+void free_fused(cvx_engine*) {}
+int plan_fused_groups(cvx_engine*, int) { return 0; }
+#endif
 
 int plan_gemm_packs(cvx_engine* e, int B, bool training);
 void free_gemm_packs(cvx_engine* e);
@@ -1276,6 +1286,10 @@ extern "C" int cvx_engine_set_bn(cvx_engine* e, float eps, float momentum) {
 
 extern "C" int cvx_engine_set_fusion(cvx_engine* e, int32_t enable) {
   CVX_CHECK(e, "null engine");
+#ifndef CVX_WITH_CHAIN
+  CVX_CHECK(!enable, "fusion groups: the tile-resident chain kernel (conv_chain.hip) is not part of the release library -- it measured slower "
+                     "than the per-layer launches (DESIGN.md 5b); tools/build_tuning.sh builds a library that carries it");
+#else
   if (e->chain_fusion != (enable != 0)) {
     e->chain_fusion = enable != 0;
     if (e->planned_batch > 0) {  // re-derive the groups of the current plan (the per-batch buffers stay)
@@ -1285,10 +1299,17 @@ extern "C" int cvx_engine_set_fusion(cvx_engine* e, int32_t enable) {
       e->plan_generation++;  // captured hipGraphs hold the old launch sequence
     }
   }
+#endif
   return 0;
 }
 
-extern "C" int32_t cvx_engine_fused_groups(const cvx_engine* e) { return e ? (int32_t)e->fused.size() : -1; }
+extern "C" int32_t cvx_engine_fused_groups(const cvx_engine* e) {
+#ifdef CVX_WITH_CHAIN
+  return e ? (int32_t)e->fused.size() : -1;
+#else
+  return e ? 0 : -1;
+#endif
+}
 
 extern "C" int cvx_engine_set_seed(cvx_engine* e, uint64_t seed) {
   CVX_CHECK(e, "null engine");
@@ -1350,7 +1371,9 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
   {
     ProfScope ps(e, PROF_MISC, 0, 6.0 * e->n_params, prep);
     CVX_TRY(cvx_pack_weights(e->params, e->shadow, e->d_pack, e->d_pack_blocks, e->n_pack_blocks, prep));
+#ifdef CVX_WITH_CHAIN
     if (!training && e->n_chain_jobs > 0) CVX_TRY(cvx_chain_pack_jobs(e->d_chain_jobs, e->n_chain_jobs, e->chain_max_units, prep));
+#endif
     if (training)
       CVX_TRY(cvx_conv_gemm_pack_jobs(e->d_gemm_jobs, e->n_gemm_jobs, e->gemm_blocks, prep));
     else
@@ -1389,6 +1412,7 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
       st = e->lane;
     }
     float* const ytmp = st == main_st ? e->ytmp : e->ytmp_lane;
+#ifdef CVX_WITH_CHAIN
     if (!training && !e->fused_at.empty() && e->fused_at[i] >= 0) {  // a fused group starts here: one tile-resident launch for ops i .. last
       const cvx_engine::FusedGroup& g = e->fused[e->fused_at[i]];
       ProfScope ps(e, PROF_CONV_FWD, g.plan.flops, g.plan.bytes, st);
@@ -1396,6 +1420,7 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
       i = (size_t)g.last;
       continue;
     }
+#endif
     if (o.type == CVX_OP_MAXPOOL5) {
       if (!e->sppf3.empty() && e->sppf3[i] == 1) {  // SPPF: y1 = m(x), y2 = m(y1), y3 = m(y2) as one launch
         ProfScope ps(e, PROF_MISC, 0, 8.0 * B * o.ih * o.iw * o.in.c, st);

@@ -53,7 +53,8 @@ class Engine:
         L.check(self.lib.cvx_engine_set_bn(self.handle, eps, momentum), "cvx_engine_set_bn")
 
     def set_fusion(self, enable: bool):
-        """eval-mode cross-layer fusion (Bottleneck pairs, Detect levels as one launch each); default off (measured slower)"""
+        """eval-mode cross-layer fusion (Bottleneck pairs, Detect levels as one launch each): tuning build only -- the release library raises
+        CvxError for enable=True (the chain kernel measured slower than the per-layer launches and left it in round 4)"""
         L.check(self.lib.cvx_engine_set_fusion(self.handle, int(bool(enable))), "cvx_engine_set_fusion")
 
     def fused_groups(self) -> int:

@@ -116,9 +116,10 @@ void* cvx_engine_exchange_stream(cvx_engine* e);
 
 /* BatchNorm hyper-parameters (core/models/yolov8/torch_utils.py:17-19: eps 1e-3, momentum 0.03). */
 int cvx_engine_set_bn(cvx_engine* e, float eps, float momentum);
-/* Eval-mode cross-layer fusion (default OFF: parity-green, but measured 1-6 % slower than the per-layer kernels at batch 32): a Bottleneck's 3x3 -> 3x3 (+ shortcut) and a whole Detect level (3x3 -> 3x3 | 3x3 -> 1x1 | 1x1 +
- * bias) run as ONE tile-resident launch each where the planner finds a feasible tile (csrc/conv_chain.hip); training-mode forwards and
- * every other op keep their per-layer kernels.  cvx_engine_fused_groups: groups in the current plan (0 before the first forward).
+/* Eval-mode cross-layer fusion: a Bottleneck's 3x3 -> 3x3 (+ shortcut) and a whole Detect level as ONE tile-resident launch each
+ * (csrc/conv_chain.hip).  Parity-green but measured 1-6 % slower than the per-layer kernels at batch 32, so since round 4 the kernel is part
+ * of the TUNING build only (tools/build_tuning.sh, -DCVX_WITH_CHAIN; include/cvx_engine_experimental.h): in the release library
+ * cvx_engine_set_fusion(e, 1) FAILS with an error that says so (enable = 0 is accepted) and cvx_engine_fused_groups returns 0.
  * Replaces: the module-by-module execution of Bottleneck.forward / Detect.forward, core/models/yolov8/modules.py:124-135, 428-433. */
 int cvx_engine_set_fusion(cvx_engine* e, int32_t enable);
 int32_t cvx_engine_fused_groups(const cvx_engine* e);
@@ -532,28 +533,9 @@ int cvx_allreduce_grads(cvx_engine* e, void* comm, void* hip_stream);
 int cvx_engine_backward_exchange(cvx_engine* e, const void* dpred_f16, float loss_scale, void* comm, const int64_t* buckets, int32_t n_buckets,
                                  void* comm_stream);
 
-/* ---- tile-resident convolution chains (csrc/conv_chain.hip), single-op entry points ------------------------------------
- * Eval-mode fusion groups as ONE launch each: the intermediates stay in LDS, the weights of all stages stream through one
- * LDS-DMA ring.  x / out are NHWC fp16, weights [cout][kh][kw][cin] fp16, scale / shift the folded BatchNorm (fp32);
- * th x tw is the output tile one workgroup owns; the launch is repeated `reps` times and, when `elapsed_us` is not NULL, its mean
- * device time (HIP events, after one warm-up launch) is returned there (a tuning aid; the plan is built once per call).
- * cvx_chain_pair_unit:   out = [x +] silu(bn(conv3x3(silu(bn(conv3x3(x))))))      Replaces: Bottleneck.forward,
- *                        core/models/yolov8/modules.py:124-135 (eval mode).
- * cvx_chain_conv_unit:   out = act(bn(conv_kxk, stride s (nearest_up2(x) if upsample)))   Replaces: Conv.forward_fuse, modules.py:32-33
- *                        (and nn.Upsample feeding it, core/models/yolov8/yolo_v8.py:39-41).
- * cvx_chain_detect_unit: one Detect level's train-mode rows pred[b][a_off + pixel][0:64 | 64:64+ncp] (fp32) from its input feature map:
- *                        3x3 (cb + cc channels) -> 3x3 | 3x3 -> 1x1 | 1x1 + bias.  Replaces: Detect.forward's cv2[i] / cv3[i] branches,
- *                        modules.py:428-433. */
-int cvx_chain_pair_unit(const void* x_f16, int32_t batch, int32_t h, int32_t w, int32_t c, const void* w1_f16, const float* scale1,
-                        const float* shift1, const void* w2_f16, const float* scale2, const float* shift2, int32_t shortcut, void* out_f16,
-                        int32_t th, int32_t tw, int32_t reps, float* elapsed_us, void* hip_stream);
-int cvx_chain_conv_unit(const void* x_f16, int32_t batch, int32_t ih, int32_t iw, int32_t cin, const void* w_f16, int32_t cout, int32_t k,
-                        int32_t stride, int32_t upsample, const float* scale, const float* shift, int32_t act, void* out_f16, int32_t th,
-                        int32_t tw, int32_t reps, float* elapsed_us, void* hip_stream);
-int cvx_chain_detect_unit(const void* x_f16, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cb, int32_t cc, int32_t ncp,
-                          const void* wa_f16, const float* scale_a, const float* shift_a, const void* wb1_f16, const void* wb2_f16,
-                          const float* scale_b, const float* shift_b, const void* wo1_f16, const void* wo2_f16, const float* bias, float* pred,
-                          int32_t anchors, int32_t a_off, int32_t th, int32_t tw, int32_t reps, float* elapsed_us, void* hip_stream);
+/* (The tile-resident chain kernel's unit entry points -- cvx_chain_pair_unit / _conv_unit / _detect_unit, csrc/conv_chain.hip -- live in
+ * include/cvx_engine_experimental.h: the kernel measured slower than the per-layer launches and is built into the tuning library only.) */
+
 
 #ifdef __cplusplus
 }

@@ -2944,6 +2944,13 @@ def test_loss_kernels_edge_cases(dev):
 
 
 # ---- tile-resident chains (csrc/conv_chain.hip): eval-mode cross-layer fusion ------------------------------------------------
+# Since round 4 the chain kernel is in the TUNING build only (tools/build_tuning.sh; it measured slower than the per-layer launches): these
+# tests run under CVX_LIB=build/libcvx_tuning.so and skip on the release library, which test_release_library_refuses_fusion covers.
+def _needs_chain():
+    if not L.has_chain():
+        pytest.skip("chain kernel: tuning build only (CVX_LIB=build/libcvx_tuning.so)")
+
+
 def _chain_conv_ref(x_nhwc, w_okkc, k, stride=1):
     return F.conv2d(x_nhwc.float().permute(0, 3, 1, 2), w_okkc.float().permute(0, 3, 1, 2), stride=stride, padding=k // 2).permute(0, 2, 3, 1)
 
@@ -2954,6 +2961,7 @@ def _chain_conv_ref(x_nhwc, w_okkc, k, stride=1):
 def test_chain_bottleneck_pair_unit(dev, B, H, W, C, th, tw, shortcut):
     """Bottleneck (modules.py:124-135, eval) as ONE launch vs torch fp32 on the same fp16 operands (the intermediate rounded to fp16 like the
     per-layer path); ragged tilings (tiles overhanging the image, 24 = 3 x 8) included."""
+    _needs_chain()
     g = torch.Generator().manual_seed(0)
     x = torch.randn(B, H, W, C, generator=g).half()
     w1, w2 = [(torch.randn(C, 3, 3, C, generator=g) * (9 * C) ** -0.5).half() for _ in range(2)]
@@ -2976,6 +2984,7 @@ def test_chain_bottleneck_pair_unit(dev, B, H, W, C, th, tw, shortcut):
 def test_chain_single_conv_unit(dev, B, H, W, Ci, Co, k, s, up, th, tw):
     """one conv + folded BN + SiLU as a one-stage chain: 1x1 / 3x3, stride 1 / 2, and the nearest-2x upsample folded into the load
     (yolo_v8.py:39-41) -- x is then the HALF-resolution tensor"""
+    _needs_chain()
     g = torch.Generator().manual_seed(1)
     xs = torch.randn(B, H // 2 if up else H, W // 2 if up else W, Ci, generator=g).half()
     x = xs.repeat_interleave(2, 1).repeat_interleave(2, 2) if up else xs
@@ -2994,6 +3003,7 @@ def test_chain_single_conv_unit(dev, B, H, W, Ci, Co, k, s, up, th, tw):
 @pytest.mark.parametrize("B,H,W,Cin,th,tw", [(2, 16, 24, 64, 8, 16), (2, 40, 40, 128, 8, 10), (2, 20, 20, 256, 5, 10)])
 def test_chain_detect_level_unit(dev, B, H, W, Cin, th, tw):
     """one Detect level (modules.py:428-433, train-mode rows) as ONE launch: rows outside the level stay untouched"""
+    _needs_chain()
     cb, cc, ncp = 64, 80, 80
     g = torch.Generator().manual_seed(2)
     mk = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).half()  # noqa: E731
@@ -3019,9 +3029,25 @@ def test_chain_detect_level_unit(dev, B, H, W, Cin, th, tw):
 
 
 @pytest.mark.gpu
+def test_release_library_refuses_fusion(dev):
+    """the release library has no chain kernel: enabling the fusion groups is an error that says where the kernel went, never a silent no-op"""
+    if L.has_chain():
+        pytest.skip("tuning build")
+    m = new_model(dev).eval()
+    with torch.no_grad():
+        m(synth.images(1, 64, 64, seed=0).to(dev))
+    eng = m._last_engine
+    eng.set_fusion(False)
+    assert eng.fused_groups() == 0
+    with pytest.raises(L.CvxError, match="tuning"):
+        eng.set_fusion(True)
+
+
+@pytest.mark.gpu
 def test_eval_forward_with_fused_groups_matches_the_per_layer_path(dev, gold):
     """the engine's eval forward with the fusion groups (Bottleneck pairs, Detect levels) against the same forward layer by layer, and
     both against the reference fixture: 128x128 (the 4x4 level stays unfused: no feasible tile) and 320x320 (all group kinds)"""
+    _needs_chain()
     g = gold("yolov8n_fwd_128.npz")
     m = new_model(dev).eval()
     for x in (torch.from_numpy(g["x"]), synth.images(2, 320, 320, seed=3)):

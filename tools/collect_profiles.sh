@@ -37,7 +37,7 @@ python tools/pmc_traffic.py $(ls $OUT/pmc_fetch/*/*_counter_collection.csv | hea
 cp $OUT/${R}_conv_traffic.json profiles/${R}_conv_traffic.json   # bench.py quotes it when its lib_sha256 is the running library's
 python bench.py --steps 30 --warmup 5 > $OUT/${R}_bench.json 2> $OUT/bench.err
 python bench.py --workload yolov8_eval --steps 50 --warmup 5 > $OUT/${R}_bench_yolov8_eval.json 2>> $OUT/bench.err
-python bench.py --workload yolov8_eval --fusion 1 --steps 50 --warmup 5 > $OUT/${R}_bench_yolov8_eval_fused.json 2>> $OUT/bench.err
+CVX_LIB=build/libcvx_tuning.so python bench.py --workload yolov8_eval --fusion 1 --steps 50 --warmup 5 > $OUT/${R}_bench_yolov8_eval_fused.json 2>> $OUT/bench.err
 python tools/op_profile.py 5 yolov8_eval > $OUT/${R}_op_profile_yolov8_eval.txt 2>> $OUT/bench.err
 python bench.py --workload centernet --steps 10 --warmup 2 > $OUT/${R}_bench_centernet.json 2>> $OUT/bench.err
 python bench.py --model s --steps 20 --warmup 3 --no-cpu-baseline > $OUT/${R}_bench_yolov8s.json 2>> $OUT/bench.err
