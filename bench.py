@@ -35,6 +35,8 @@ import time
 # sit in the main chain's in-order queue.  Until an N-GPU A/B exists the runtime default stays for WORLD_SIZE > 1 (CVX_BENCH_HWQ overrides).
 if os.environ.get("CVX_BENCH_HWQ"):
     os.environ["GPU_MAX_HW_QUEUES"] = os.environ["CVX_BENCH_HWQ"]
+elif any(a in ("--graph=1",) or (a == "--graph" and sys.argv[i + 1:i + 2] == ["1"]) for i, a in enumerate(sys.argv)):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")  # replaying the multi-stream capture segfaults in the HIP runtime under one queue (train.py)
 elif int(os.environ.get("WORLD_SIZE", "1")) <= 1:
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
 

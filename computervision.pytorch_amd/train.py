@@ -15,6 +15,7 @@ from typing import Dict, List, Optional
 import torch
 
 import ctypes as C
+import os
 
 from . import _lib as L
 from .engine import V8LossOp, adam_step, adam_step_dev, check_finite
@@ -325,6 +326,12 @@ class FusedTrainStep:
         self.pg = process_group
         self.n_buckets = n_buckets
         self.use_graph = use_graph     # replay the whole step as one hipGraph (single-GPU; shapes and target count fixed)
+        if use_graph and os.environ.get("GPU_MAX_HW_QUEUES") == "1":
+            # measured (round 4): hipGraphLaunch of this capture -- main, weight-gradient and Detect-lane streams as parallel branches --
+            # SEGFAULTS inside the HIP runtime when it was started with one hardware queue, the package's default
+            raise L.CvxError("use_graph=True needs more than one hardware queue: replaying the multi-stream capture crashes the HIP runtime under "
+                           "GPU_MAX_HW_QUEUES=1 (the default this package sets on import).  Export GPU_MAX_HW_QUEUES=4 before the process "
+                           "starts, or run the step eagerly (the eager step under one queue is the faster of the two anyway: DESIGN.md section 6)")
         self._graph = None
         self._graph_key = None
         self.world = 1
