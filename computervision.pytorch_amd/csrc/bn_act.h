@@ -71,6 +71,12 @@ int cvx_bn_bwd_reduce(const half_t* xhat, long long M, int C, int hw, const BnCo
 // gres receives the incoming gradient (res_pre: the pre-activation gradient dz), accumulated when res_accumulate
 int cvx_bn_bwd_apply(const half_t* xhat, long long M, int C, int hw, const BnCoef& k, const long long* part, float inv_scale, float* dgamma,
                      float* dbeta, const ViewDesc& gout, const BnActKind& ak, half_t* dy, const ViewDesc& gres, int res_accumulate, hipStream_t st);
+// reduce + apply in ONE launch behind a grid-wide gate (bn_act.hip); 1 = the layer does not qualify, take the two passes.  gate: one 64-bit
+// counter, zero on entry (the engine keeps it behind the layer's replica slabs).  Main stream only: see the kernel's comment.
+#define CVX_STAT_GATE_WORDS 2  // 64-bit words behind a layer's slabs: (gate counter, spare) -- keeps the next slab 16-byte aligned
+int cvx_bn_bwd_fused(const half_t* xhat, long long M, int C, int hw, const BnCoef& k, long long* part, unsigned long long* gate, float inv_scale,
+                     float* dgamma, float* dbeta, const ViewDesc& gout, const BnActKind& ak, half_t* dy, const ViewDesc& gres, int res_accumulate,
+                     hipStream_t st);
 // part: replica slabs [R][C][2], zero on entry
 // ... of several tensors that are views of one allocation, in two launches: descs / blocks live in device memory
 struct ColsumDesc {

@@ -13,6 +13,7 @@
 // All passes are HBM-bound streams: 16-byte accesses, one fixed channel group per thread so the per-channel
 // coefficients live in registers.  The replica slabs are zeroed once per step by the engine.
 #include "bn_common.h"
+#include <mutex>
 
 namespace {
 using namespace cvx_bn;
@@ -304,6 +305,193 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const half_t* xhat, l
   }
 }
 
+#ifdef CVX_TUNING
+// ---------------------------------------------------------------------------------------------
+// One-launch backward (round 4, TUNING BUILD ONLY -- measured slower, see the end of this comment): reduce + grid gate + apply.  A thread keeps its KR rows of (xhat, g) in registers across the gate, so the
+// pass reads 4 and writes 2 bytes per element instead of 4 + 4 + 2, and a layer costs one launch instead of two -- on the <= 40x40 layers
+// the two launches were 10-18 us each for 2-8 us of traffic.  The gate is a counter behind the layer's replica slabs (zeroed with them once
+// per pass): every block adds its partial sums (integer atomics, exact), bumps the counter and waits until all `nblocks` have.  That needs
+// every block of the grid resident at once: the host picks KR so that the grid has at most 512 blocks of 256 threads (two per CU) and
+// the engine runs the kernel on its main stream only -- blocks of OTHER kernels that share the CUs (the weight-gradient stream) finish on
+// their own, a second gated kernel beside this one could starve both.  The wait is bounded: a block that gives up poisons its output with
+// NaN (the loss-scale check then skips the step) instead of hanging the queue.
+// Measured (MI355X, batch 32; rocprofv3 kernel durations): ALONE on the device the gated launch takes 18.9 / 21.2 / 28.0 / 42.8 us on
+// 20x20x128 / 40x40x64 / 40x40x128 / 80x80x64 against 15.1 / 16.6 / 21.7 / 38.5 us for the two passes together -- every block reaches its
+// atomics at the same moment and then reads the slabs back past the L2 (device-scope loads), ~10 us that the two-pass form hides behind
+// other blocks' streaming, and at KR = 16 the 229 registers leave one wave per SIMD; inside the training step (weight-gradient stream
+// beside it) 6.93 against 6.62 ms.  So the release library does not carry it: CVX_BN_FUSED=1 enables it in the tuning build.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void fold_replicas_coherent(const long long* part, int C, long long* ws) {  // fold_replicas, reading at device scope
+  const int nacc = C * 2 * CVX_FIX_WORDS;
+  for (int i = threadIdx.x; i < nacc; i += 256) ws[i] = 0;
+  __syncthreads();
+  const int total = cvx_stat_replicas(C) * C * 2;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const long long* src = part + (long long)e * CVX_FIX_WORDS;
+    const long long q0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long q1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int cv = e % (C * 2);
+    atomicAdd(reinterpret_cast<unsigned long long*>(&ws[cv * 2]), (unsigned long long)q0);
+    atomicAdd(reinterpret_cast<unsigned long long*>(&ws[cv * 2 + 1]), (unsigned long long)q1);
+  }
+  __syncthreads();
+  double r[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int cv = threadIdx.x + 256 * k;
+    r[k] = cv < C * 2 ? cvx_fix_to_double(ws[cv * 2], ws[cv * 2 + 1]) : 0.0;
+  }
+  __syncthreads();
+  double* out = reinterpret_cast<double*>(ws);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int cv = threadIdx.x + 256 * k;
+    if (cv < C * 2) out[(cv & 1) * C + (cv >> 1)] = r[k];
+  }
+  __syncthreads();
+}
+
+constexpr int kGateSpins = 1 << 22;  // x (sleep + one coherent load, ~1 us): seconds -- far beyond any wait of a healthy grid
+
+// waves per SIMD the compiler must leave room for (it schedules for instruction-level parallelism and spends 16+ registers per row otherwise):
+// sets the blocks a CU holds, i.e. the largest grid the gate admits (the host asks the runtime for the real figure)
+template <int KR, bool RES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KR == 4 ? 4 : KR == 8 ? 3 : 2))) void bn_bwd_fused_kernel(const half_t* xhat, long long M, int C, int hw, BnCoef k, long long* part,
+                                                           unsigned long long* gate, unsigned nblocks, float inv_scale, float* dgamma, float* dbeta,
+                                                           ViewDesc gout, half_t* dy, ViewDesc gres, int res_accumulate) {
+  extern __shared__ __attribute__((aligned(16))) long long ws[];  // 16 KB of block-sum scratch first, then the fold workspace
+  __shared__ int s_gave_up;
+  const int CG = C >> 3;
+  const int RP = 256 / CG;
+  const int cg = threadIdx.x % CG, r = threadIdx.x / CG;
+  const bool active = r < RP;
+  long long mb = (long long)blockIdx.x * RP * KR + r;
+  Coef8 s;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    s.a[i] = active ? k.gamma[cg * 8 + i] : 0.f;
+    s.b[i] = active ? k.beta[cg * 8 + i] : 0.f;
+  }
+  // ---- phase 1: this thread's rows into registers (every load issued before the first use), channel sums of dz and dz * xhat ----
+  h8 v[KR], g[KR];
+#pragma unroll
+  for (int q = 0; q < KR; ++q) {
+    const long long m = mb + (long long)q * RP;
+    const long long mc = m < M ? m : M - 1;  // branch-free: rows past the end re-read the last row, and their g is zeroed below
+    v[q] = h8{};
+    g[q] = h8{};
+    if (active) {
+      v[q] = *reinterpret_cast<const h8*>(xhat + mc * C + cg * 8);
+      g[q] = *reinterpret_cast<const h8*>(gout.p + view_off(gout, mc, hw) + cg * 8);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < KR; ++q)
+    if (mb + (long long)q * RP >= M) g[q] = h8{};
+  float acc[2][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[0][i] = acc[1][i] = 0.f;
+#pragma unroll
+  for (int q = 0; q < KR; ++q) {
+    __builtin_amdgcn_sched_barrier(0);  // row by row: interleaved, the rows' unpacked floats cost 16+ registers each (spills at KR = 8)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // rows past the end hold g = 0: they add nothing
+      const float xh = (float)v[q][i];
+      const float dz = act_dz<0>((float)g[q][i], xh, s.a[i], s.b[i], 0.f);
+      acc[0][i] += dz;
+      acc[1][i] += dz * xh;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // the rows stay PACKED (8 registers per row) across the gate: without this the compiler keeps phase 1's converted floats and dz values
+  // alive for phase 2 -- 16+ registers per row, which at KR = 16 halves the blocks a CU holds and with them the largest grid the gate admits
+  // (the sums as inputs tie the statement BEHIND phase 1: moved in front of it -- where the compiler put it at first -- the laundered rows
+  // are a second copy beside the ones phase 1 still reads)
+#pragma unroll
+  for (int q = 0; q < KR; ++q) asm volatile("" : "+v"(v[q]), "+v"(g[q]) : "v"(acc[0][q & 7]), "v"(acc[1][q & 7]));
+  asm volatile("" : "+v"(mb));  // ... and phase 2 works its addresses out again: kept from phase 1 they are 4 more registers per row
+  if (threadIdx.x == 0) s_gave_up = 0;
+  block_channel_sums<2>(acc, C, CG, cg, active, reinterpret_cast<float*>(ws), part, blockIdx.x);
+  // ---- the gate ----
+  // Everything blocks exchange goes through device-scope ATOMICS (the partial sums: integer RMWs; the counter; the slabs are read back
+  // with device-scope loads), which are performed at the coherence point, so no cache maintenance is needed -- and none must be used: the
+  // first version's __threadfence() / acquire loads compiled to buffer_wbl2 / buffer_inv sc1 per thread and per poll, i.e. an L2
+  // write-back or invalidate of the whole XCD each, and ran 2-4x SLOWER than the two-launch path while slowing the weight-gradient
+  // stream's kernels by 1.7x.  What remains is order: a wave's atomics have been performed once its vmcnt is back at zero.
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(gate, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0;
+    while (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)nblocks) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > kGateSpins) {
+        s_gave_up = 1;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  const bool gave_up = s_gave_up != 0;
+  fold_replicas_coherent(part, C, ws);
+  const double* s0 = reinterpret_cast<const double*>(ws);
+  const double* s1 = s0 + C;
+  if (blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      dgamma[c] += gave_up ? __builtin_nanf("") : (float)(s1[c] * inv_scale);
+      dbeta[c] += (float)(s0[c] * inv_scale);
+    }
+  }
+  if (!active) return;
+  // ---- phase 2: dy = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat)) from the registers ----
+  float k1[8], k2[8], gi[8];
+  const double cnt = (double)M;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    k1[i] = gave_up ? __builtin_nanf("") : (float)(s0[cg * 8 + i] / cnt);
+    k2[i] = (float)(s1[cg * 8 + i] / cnt);
+    gi[i] = s.a[i] * k.invstd[cg * 8 + i];
+  }
+  constexpr int QB = 4;  // rows per trip: the residual's old values are loaded QB rows ahead of their use
+#pragma unroll
+  for (int q0 = 0; q0 < KR; q0 += QB) {
+    h8 old[QB];
+    if constexpr (RES) {
+#pragma unroll
+      for (int j = 0; j < QB; ++j) {
+        const long long m = mb + (long long)(q0 + j) * RP;
+        old[j] = h8{};
+        if (res_accumulate && m < M) old[j] = *reinterpret_cast<const h8*>(gres.p + view_off(gres, m, hw) + cg * 8);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+      const int q = q0 + j;
+      const long long m = mb + (long long)q * RP;
+      if (m >= M) return;
+      __builtin_amdgcn_sched_barrier(0);
+      h8 o;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float xh = (float)v[q][i];
+        const float dz = act_dz<0>((float)g[q][i], xh, s.a[i], s.b[i], 0.f);
+        o[i] = (half_t)(gi[i] * (dz - k1[i] - xh * k2[i]));
+      }
+      *reinterpret_cast<h8*>(dy + m * C + cg * 8) = o;
+      if constexpr (RES) {
+        h8 gg = g[q];
+        if (res_accumulate) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) gg[i] = (half_t)((float)gg[i] + (float)old[j][i]);
+        }
+        *reinterpret_cast<h8*>(gres.p + view_off(gres, m, hw) + cg * 8) = gg;
+      }
+    }
+  }
+}
+
+#endif  // CVX_TUNING
+
 // per-channel (sum, sumsq) of an fp32 [M][C] tensor into the replica slabs: what the conv epilogues do in the engine;
 // stand-alone for the single-op entry point (unit tests, other callers with an fp32 pre-activation of their own)
 __global__ __launch_bounds__(256) void bn_stats_f32_kernel(const float* y, long long M, int C, long long* part, int rows_per_block) {
@@ -521,6 +709,68 @@ int cvx_bn_bwd_apply(const half_t* xhat, long long M, int C, int hw, const BnCoe
 #undef CVX_LAUNCH_BWD
   CVX_HIP(hipGetLastError());
   return 0;
+}
+// The one-launch form.  Returns 1 when the layer does not qualify (the caller then takes cvx_bn_bwd_reduce + cvx_bn_bwd_apply): SiLU
+// without a pre-activation residual only, at most 512 blocks at 16 rows per thread.  `gate`: one 64-bit counter, zero on entry.
+int cvx_bn_bwd_fused(const half_t* xhat, long long M, int C, int hw, const BnCoef& k, long long* part, unsigned long long* gate, float inv_scale,
+                     float* dgamma, float* dbeta, const ViewDesc& gout, const BnActKind& ak, half_t* dy, const ViewDesc& gres, int res_accumulate,
+                     hipStream_t st) {
+#ifndef CVX_TUNING
+  return 1;  // the gated kernel measured slower than the two passes (see its comment): tuning build only
+#else
+  static const bool on = cvx_tune_int("CVX_BN_FUSED", 0) != 0;
+  if (!on || ak.act != 0 || ak.res_pre || C > 512 || C % 8 != 0 || !gate) return 1;
+  CVX_TRY(check_c(C, M));
+  static const int max_g = cvx_tune_int("CVX_BN_FUSED_G", 256), max_g16 = cvx_tune_int("CVX_BN_FUSED_G16", 512);
+  const size_t lds = std::max<size_t>(256 * 16 * 4, fold_ws_bytes(C));
+  const bool res = gres.p != nullptr;
+  // blocks of each variant the device holds at once, from the runtime (registers as compiled, 16 KB of LDS): the gate's hard limit
+  static int resident[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+  static std::mutex mu;
+  auto capacity = [&](int idx, const void* fn) -> int {
+    std::lock_guard<std::mutex> lock(mu);
+    if (resident[idx][res] == 0) {
+      int per_cu = 0, dev = 0;
+      hipDeviceProp_t prop;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 16384) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+          hipGetDeviceProperties(&prop, dev) != hipSuccess)
+        resident[idx][res] = -1;
+      else
+        resident[idx][res] = per_cu * prop.multiProcessorCount;
+    }
+    return resident[idx][res];
+  };
+  const int RP = 256 / (C / 8);
+  int KR = 0;
+  long long G = 0;
+  int idx = 0;
+  for (int kr : {4, 8, 16}) {
+    G = (M + (long long)RP * kr - 1) / ((long long)RP * kr);
+    const void* fn = kr == 4 ? (res ? (const void*)bn_bwd_fused_kernel<4, true> : (const void*)bn_bwd_fused_kernel<4, false>)
+                   : kr == 8 ? (res ? (const void*)bn_bwd_fused_kernel<8, true> : (const void*)bn_bwd_fused_kernel<8, false>)
+                             : (res ? (const void*)bn_bwd_fused_kernel<16, true> : (const void*)bn_bwd_fused_kernel<16, false>);
+    if (G <= (kr == 16 ? max_g16 : max_g) && G <= capacity(idx, fn)) {
+      KR = kr;
+      break;
+    }
+    ++idx;
+  }
+  if (!KR) return 1;
+  const dim3 grid((unsigned)G), block(256);
+#define CVX_LAUNCH_FUSED(K_, R_)                                                                                                              \
+  hipLaunchKernelGGL((bn_bwd_fused_kernel<K_, R_>), grid, block, lds, st, xhat, M, C, hw, k, part, gate, (unsigned)G, inv_scale, dgamma, dbeta, gout, \
+                     dy, gres, res_accumulate)
+  if (KR == 4) {
+    if (res) CVX_LAUNCH_FUSED(4, true); else CVX_LAUNCH_FUSED(4, false);
+  } else if (KR == 8) {
+    if (res) CVX_LAUNCH_FUSED(8, true); else CVX_LAUNCH_FUSED(8, false);
+  } else {
+    if (res) CVX_LAUNCH_FUSED(16, true); else CVX_LAUNCH_FUSED(16, false);
+  }
+#undef CVX_LAUNCH_FUSED
+  CVX_HIP(hipGetLastError());
+  return 0;
+#endif
 }
 int cvx_colsum_multi(const half_t* base, const ColsumDesc* descs, int ndesc, int max_c, const ColsumBlock* blocks, int nblocks, float inv_scale,
                      float* grads, hipStream_t st) {

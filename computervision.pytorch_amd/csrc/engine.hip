@@ -691,7 +691,7 @@ int plan_batch(cvx_engine* e, int B, bool training) {
       if (e->use_lanes && o.lane >= 2) ytmp_lane_elems = std::max(ytmp_lane_elems, M * C);
     }
     c.stat_fwd = (long long*)nullptr + stat_floats;  // offset for now, rebased below
-    stat_floats += (long long)cvx_stat_replicas(C) * C * CVX_STAT_WORDS;
+    stat_floats += (long long)cvx_stat_replicas(C) * C * CVX_STAT_WORDS + CVX_STAT_GATE_WORDS;  // + the gate counter of the one-launch BN backward
     if (training) {
       int co_b, j_b;
       const int Jtot = c.ntaps * c.cin_pad16;
@@ -1786,9 +1786,16 @@ int backward_op(cvx_engine* e, int i) {
       const BnActKind ak{act_kind(o), pre ? 1 : 0, act_kind(o) == 0 && pre ? make_view(e, o.res, false) : ViewDesc{nullptr, 0, 0}};
       ProfScope ps(e, PROF_BN_BWD, 0, (c.stem ? 4.0 : (gres.p ? 14.0 : 10.0)) * M * C, st);
       static const bool tune_skip_reduce = cvx_tune_int("CVX_TUNE_SKIP_BN_REDUCE", 0) != 0;  // tuning build: timing without the pass (wrong results)
-      if (!tune_skip_reduce) CVX_TRY(cvx_bn_bwd_reduce(c.ybuf, M, C, hw, k, gout, ak, c.stat_bwd, st));
+      // one launch (reduce, grid gate, apply from registers) where the layer qualifies -- on the main stream only: two gated kernels side
+      // by side (the Detect lanes) could keep each other's blocks off the CUs
+      int one = 1;
+      if (!c.stem && st == e->stream && !tune_skip_reduce)
+        one = cvx_bn_bwd_fused(c.ybuf, M, C, hw, k, c.stat_bwd, reinterpret_cast<unsigned long long*>(c.stat_bwd + (long long)cvx_stat_replicas(C) * C * CVX_STAT_WORDS),
+                               w.inv_scale, e->grads + o.gamma_off, e->grads + o.beta_off, gout, ak, c.dybuf, gres, c.res_accum, st);
+      if (one < 0) return one;
+      if (one == 1 && !tune_skip_reduce) CVX_TRY(cvx_bn_bwd_reduce(c.ybuf, M, C, hw, k, gout, ak, c.stat_bwd, st));
       // the stem's "apply" half is fused into its weight gradient (cvx_stem_backward, queued below): dy is never materialised
-      if (!c.stem)
+      if (one == 1 && !c.stem)
         CVX_TRY(cvx_bn_bwd_apply(c.ybuf, M, C, hw, k, c.stat_bwd, w.inv_scale, e->grads + o.gamma_off, e->grads + o.beta_off, gout, ak, c.dybuf,
                                  gres, c.res_accum, st));
       dyv.p = c.dybuf;

@@ -62,9 +62,17 @@ extern "C" int cvx_bn_act_bwd_nhwc(const void* xhat_f16, const void* gout_f16, c
   hipStream_t st = (hipStream_t)hip_stream;
   const long long M = (long long)batch * hw;
   Scratch slab;
-  CVX_TRY(slab.alloc(slab_bytes(c)));
+  CVX_TRY(slab.alloc(slab_bytes(c) + CVX_STAT_GATE_WORDS * 8));
   BnCoef k{invstd, gamma, beta};
   const ViewDesc g = dense(gout_f16, hw, c);
+  // the engine's choice: one gated launch where the layer qualifies, else the two passes
+  const int one = cvx_bn_bwd_fused((const half_t*)xhat_f16, M, c, hw, k, (long long*)slab.p, (unsigned long long*)((char*)slab.p + slab_bytes(c)), inv_scale,
+                                   dgamma, dbeta, g, ak, (half_t*)dy_f16, gres_f16 ? dense(gres_f16, hw, c) : ViewDesc{nullptr, 0, 0}, res_accumulate, st);
+  if (one < 0) return one;
+  if (one == 0) {
+    CVX_HIP(hipStreamSynchronize(st));
+    return 0;
+  }
   CVX_TRY(cvx_bn_bwd_reduce((const half_t*)xhat_f16, M, c, hw, k, g, ak, (long long*)slab.p, st));
   CVX_TRY(cvx_bn_bwd_apply((const half_t*)xhat_f16, M, c, hw, k, (const long long*)slab.p, inv_scale, dgamma, dbeta, g, ak, (half_t*)dy_f16,
                            gres_f16 ? dense(gres_f16, hw, c) : ViewDesc{nullptr, 0, 0}, res_accumulate, st));
