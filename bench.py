@@ -618,11 +618,30 @@ def yolov7_main(args):
     H, W = cfg.arch.input_size[1:]
     x = synth.images(B, H, W, seed=1 + rank).to(dev)
 
+    # --nms-load K: K candidates per image planted into the head rows after every forward (random-init logits are ~0: objectness * class =
+    # 0.25 everywhere, nothing passes 0.6 and the suppression kernel would idle).  K/4 clusters of 2 x 2 neighbouring cells of the first
+    # level, first anchor, one class per cluster, objectness and class logit +4 (score 0.96): neighbours' boxes overlap, so every cluster
+    # is real suppression work; the scatter is two tiny device ops inside the timed step.
+    plant = None
+    if args.nms_load > 0:
+        g = torch.Generator().manual_seed(7)
+        ncl = max(args.nms_load // 4, 1)
+        with torch.no_grad():
+            model.forward_rows(x[:1])
+        lh, lw = model._last_engine.graph.level_hw[0]             # the first level of the head rows (its rows start at 0)
+        cy, cx = torch.randint(0, lh - 1, (B, ncl), generator=g), torch.randint(0, lw - 1, (B, ncl), generator=g)
+        cls = torch.randint(0, cfg.dataset.num_classes, (B, ncl), generator=g)
+        pix = torch.stack([(cy + dy) * lw + (cx + dx) for dy in (0, 1) for dx in (0, 1)], 2).reshape(B, -1)       # (B, 4 * ncl) rows of level 0
+        plant = (torch.arange(B).unsqueeze(1).expand_as(pix).to(dev), pix.to(dev), (5 + cls).repeat_interleave(4, 1).to(dev))
+
     def step():
         with torch.no_grad():
             rows = model.forward_rows(x)
+            if plant is not None:
+                rows[plant[0], plant[1], 4] = 4.0
+                rows[plant[0], plant[1], plant[2]] = 4.0
             dec, y = algo.decode_rows(model, rows)
-            return algo.nms_device(y, dec, 0.6)      # (untrained logits ~ 0: objectness * class = 0.25 everywhere -- nothing passes)
+            return algo.nms_device(y, dec, 0.6)      # (without --nms-load: untrained logits ~ 0, nothing passes the threshold)
 
     def sync():
         if world > 1:
@@ -648,12 +667,15 @@ def yolov7_main(args):
     sync()
     prof = eng.profile_read()
     eng.profile(False)
+    planted_in = int(plant[1].shape[1]) if plant is not None else 0
+    kept_out = round(sum(0 if d is None else int(d.shape[0]) for d, _ in out) / B, 1)
     if rank == 0:
         value = B * world * args.steps / elapsed
         conv = prof["conv_fwd"]
         tf = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
         print(json.dumps({
-            "metric": "images/sec 640x640 YOLOv7-l inference + decode + NMS launch (0 candidates pass the threshold at random init: suppression not exercised)", "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
+            "metric": ("images/sec 640x640 YOLOv7-l inference + decode + NMS (" + (f"{planted_in} planted candidates/image above the threshold, {kept_out} kept" if plant is not None else
+                       "0 candidates pass the threshold at random init: suppression not exercised") + ")"), "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"YOLOv7-l (nc 20) eval forward + anchor decode + per-class NMS, batch {B}/GPU, {H}x{W}, random init",
@@ -695,9 +717,25 @@ def ssd_main(args):
     B = args.batch
     x = synth.images(B, 300, 300, seed=1 + rank).to(dev)
 
+    # --nms-load K: K candidates per image planted into the class logits after every forward (at random init no score passes 0.7 and the
+    # per-class NMS launches are skipped): K/4 runs of four consecutive priors of the 38 x 38 level (the four aspect ratios of one cell --
+    # overlapping boxes), one class per run, logit +8 (softmax 0.99)
+    plant = None
+    if args.nms_load > 0:
+        g = torch.Generator().manual_seed(7)
+        ncl = max(args.nms_load // 4, 1)
+        base = torch.randint(0, 38 * 38, (B, ncl), generator=g) * 4
+        cls = torch.randint(1, cfg.dataset.num_classes + 1, (B, ncl), generator=g)
+        pri = (base.unsqueeze(2) + torch.arange(4)).reshape(B, -1)
+        plant = (torch.arange(B).unsqueeze(1).expand_as(pri).to(dev), pri.to(dev), cls.repeat_interleave(4, 1).to(dev))
+
     def step():
         with torch.no_grad():
-            return algo.decode_device(model(x))
+            loc, conf = model(x)
+            if plant is not None:
+                conf = conf.view(B, -1, cfg.dataset.num_classes + 1)
+                conf[plant[0], plant[1], plant[2]] = 8.0
+            return algo.decode_device((loc, conf))
 
     def sync():
         if world > 1:
@@ -705,11 +743,11 @@ def ssd_main(args):
         torch.cuda.synchronize(dev)
 
     for _ in range(max(args.warmup, 1)):
-        step()
+        out = step()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        out = step()
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -723,12 +761,15 @@ def ssd_main(args):
     sync()
     prof = eng.profile_read()
     eng.profile(False)
+    planted_in = int(plant[1].shape[1]) if plant is not None else 0
+    kept_out = round(sum(int(d.shape[0]) for d, _ in out) / B, 1)
     if rank == 0:
         value = B * world * args.steps / elapsed
         conv = prof["conv_fwd"]
         tf = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
         print(json.dumps({
-            "metric": "images/sec 300x300 SSD300-VGG16 inference + decode (no score passes the threshold at random init: NMS not exercised)", "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
+            "metric": ("images/sec 300x300 SSD300-VGG16 inference + decode + per-class NMS (" + (f"{planted_in} planted candidates/image above the threshold, {kept_out} kept" if plant is not None else
+                       "no score passes the threshold at random init: NMS not exercised") + ")"), "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"SSD300 VGG16-BN (nc 20) eval forward + softmax / prior decode (+ per-class NMS when a score passes), batch {B}/GPU, "
@@ -829,6 +870,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--model", default="n")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nms-load", type=int, default=0, help="yolov7 / ssd: plant this many above-threshold candidates per image (clusters of four overlapping boxes) "
+                                                            "into the head output after every forward, so that the suppression kernels have work at random init")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the step as a hipGraph (N=1 only); 0: eager stream launches (default: "
                     "measured faster -- the side-stream weight gradients overlap better than as graph branches)")
     ap.add_argument("--profile-steps", type=int, default=10, help="steps of the per-kernel HIP-event window after the timed region")

@@ -48,6 +48,8 @@ python bench.py --workload yolov7_train --steps 20 --warmup 3 > $OUT/${R}_bench_
 python bench.py --workload ssd_train --steps 20 --warmup 3 > $OUT/${R}_bench_ssd_train.json 2>> $OUT/bench.err
 python bench.py --workload yolov7 --steps 10 --warmup 2 > $OUT/${R}_bench_yolov7.json 2>> $OUT/bench.err
 python bench.py --workload ssd --steps 10 --warmup 2 > $OUT/${R}_bench_ssd.json 2>> $OUT/bench.err
+python bench.py --workload yolov7 --nms-load 256 --steps 10 --warmup 2 > $OUT/${R}_bench_yolov7_nms256.json 2>> $OUT/bench.err
+python bench.py --workload ssd --nms-load 256 --steps 10 --warmup 2 > $OUT/${R}_bench_ssd_nms256.json 2>> $OUT/bench.err
 # data-parallel step with a 1-rank RCCL group (the exchange path of bench.py --gpus N, both flavours) and the launch-stream probes
 CVX_FORCE_DIST=1 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>> $OUT/bench.err | grep '"metric"' > $OUT/${R}_bench_dp_1rank_torch.json
 CVX_FORCE_DIST=1 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --exchange c 2>> $OUT/bench.err | grep '"metric"' > $OUT/${R}_bench_dp_1rank_c.json
