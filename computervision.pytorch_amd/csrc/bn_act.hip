@@ -78,6 +78,33 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(const float* y, long 
   extern __shared__ __attribute__((aligned(16))) long long ws[];  // fold workspace | mean, invstd (2*C floats)
   float* s_mu = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + fold_ws_bytes(C));
   float* s_is = s_mu + C;
+  const int CG = C >> 3;
+  const int RP = 256 / CG;
+  const int cg = threadIdx.x % CG, r = threadIdx.x / CG;
+  const bool active = r < RP;
+  const long long m0 = (long long)blockIdx.x * rows_per_block;
+  const long long m1 = min(M, m0 + rows_per_block);
+  long long m = m0 + r;
+  // The first trip's rows and the coefficients are requested BEFORE the statistics are folded: the fold (slab reads, LDS atomics, three
+  // barriers, fp64 conversion) is 2-3 us of every block's life that the rows' memory latency now runs under.
+  const bool first = active && m + (long long)(UNR - 1) * RP < m1;
+  f8 v0[UNR];
+  h8 rr0[UNR] = {};
+  float ga[8], be[8];
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      ga[i] = a.gamma[cg * 8 + i];
+      be[i] = a.beta[cg * 8 + i];
+    }
+  }
+  if (first) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      v0[u] = load_f8(y + (m + u * RP) * C + cg * 8);
+      if (res.p) rr0[u] = *reinterpret_cast<const h8*>(res.p + view_off(res, m + u * RP, hw) + cg * 8);
+    }
+  }
   fold_replicas(a.stats, C, ws);
   for (int c = threadIdx.x; c < C; c += 256) {
     double var;
@@ -95,20 +122,13 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(const float* y, long 
     }
   }
   __syncthreads();
-  const int CG = C >> 3;
-  const int RP = 256 / CG;
-  const int cg = threadIdx.x % CG, r = threadIdx.x / CG;
-  if (r >= RP) return;
-  float mu[8], is[8], ga[8], be[8];
+  if (!active) return;
+  float mu[8], is[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     mu[i] = s_mu[cg * 8 + i];
     is[i] = s_is[cg * 8 + i];
-    ga[i] = a.gamma[cg * 8 + i];
-    be[i] = a.beta[cg * 8 + i];
   }
-  const long long m0 = (long long)blockIdx.x * rows_per_block;
-  const long long m1 = min(M, m0 + rows_per_block);
   auto one = [&](long long m, const f8& v, const h8& rr) {
     float f[8];
     h8 xh;
@@ -138,8 +158,12 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(const float* y, long 
     *reinterpret_cast<h8*>(xhat + m * C + cg * 8) = xh;
     *reinterpret_cast<h8*>(out.p + view_off(out, m, hw) + cg * 8) = o;
   };
+  if (first) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) one(m + u * RP, v0[u], rr0[u]);
+    m += (long long)UNR * RP;
+  }
   // UNR rows per trip with every load issued before the first use: the passes are latency-bound otherwise
-  long long m = m0 + r;
   for (; m + (long long)(UNR - 1) * RP < m1; m += (long long)UNR * RP) {
     f8 v[UNR];
     h8 rr[UNR] = {};
@@ -231,6 +255,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const half_t* xhat, 
 }
 
 // RES_PRE: the residual branch receives dz (the gradient of the shared pre-activation), else the incoming gradient g
+// (requesting the first trip's rows before the fold, as the forward pass does, measured SLOWER here: 64 more live registers across the fold)
 template <int ACT, bool RES_PRE>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const half_t* xhat, long long M, int C, int hw, BnCoef k, const long long* part,
                                                            float inv_scale, float* dgamma, float* dbeta, ViewDesc gout, ViewDesc fout, half_t* dy,
@@ -594,6 +619,15 @@ int cvx_stream_rows_per_block(long long M, int C, int kb_per_block) {
   // wide layers (ResNet's 512..2048 channels): every block folds R*C*32 bytes of statistic slabs before it streams, so its share of
   // the tensor must be several times that -- at least 64 rows
   if (C > 256 && kb_per_block < C / 8) kb_per_block = C / 8;
+  // big tensors: no more than 512 blocks (in the step, same box: cap 0 / 256 / 384 / 512 / 768 / 1024 -> 6.54 / 6.45 / 6.43 / 6.41 / 6.47 / 6.52 ms).
+  // Measured alone on the device (rocprofv3, 13.1 M elements, tools/sweeps/prof_bn_kb.sh): 800 blocks of 32 KB 20.9 / 19.0 us (reduce /
+  // apply), 400 of 64 KB 14.5 / 16.3, 200 of 128 KB 16.2 / 17.0 -- every block pays its coefficient loads, slab fold and atomics once,
+  // whatever it streams; the small layers (<= 200 blocks at 32 KB) keep their size.
+  static const int max_blocks = cvx_tune_int("CVX_BN_BLOCKS", 512);
+  if (kb_env <= 0 && max_blocks > 0) {
+    const long long total_kb = (M * C * 2) >> 10;
+    if (total_kb / max_blocks > kb_per_block) kb_per_block = (int)(total_kb / max_blocks);
+  }
   long long target = ((long long)kb_per_block * 1024) / (2LL * C);
   if (target < RP) target = RP;
   long long rows = ((target + RP - 1) / RP) * RP;
