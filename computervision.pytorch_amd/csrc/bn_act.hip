@@ -18,7 +18,10 @@
 namespace {
 using namespace cvx_bn;
 
-constexpr int UNR = 4;  // rows in flight per thread in the streaming passes
+#ifndef CVX_BN_UNR
+#define CVX_BN_UNR 4
+#endif
+constexpr int UNR = CVX_BN_UNR;  // rows in flight per thread in the streaming passes
 
 // eval: fold running stats into per-channel scale/shift for the conv epilogue
 __global__ void bn_fold_kernel(int n, const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps,
