@@ -14,9 +14,9 @@ import json
 import os
 import sys
 
-FAMILIES = ("conv_wgrad_gemm_kernel", "conv_gemm_kernel", "gemm_pack", "conv_chain_kernel", "conv_halo_kernel", "conv_pw_kernel", "conv_igemm_dma_kernel", "stem_", "conv_wgrad_halo_kernel", "conv_wgrad_kernel",
+FAMILIES = ("conv_wgrad_gemm_kernel", "conv_gemm_kernel", "gemm_pack", "conv_tile_kernel", "tile_pack", "conv_chain_kernel", "conv_halo_kernel", "conv_pw_kernel", "conv_igemm_dma_kernel", "stem_", "conv_wgrad_halo_kernel", "conv_wgrad_kernel",
             "bn_act_apply", "bn_bwd_reduce", "bn_bwd_apply", "chain_pack_kernel", "pack_weights")
-CONV = ("conv_gemm_kernel", "conv_chain_kernel", "conv_halo_kernel", "conv_pw_kernel", "conv_igemm_dma_kernel")
+CONV = ("conv_gemm_kernel", "conv_tile_kernel", "conv_chain_kernel", "conv_halo_kernel", "conv_pw_kernel", "conv_igemm_dma_kernel")
 
 
 def family(name):

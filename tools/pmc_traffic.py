@@ -15,9 +15,9 @@ import csv
 import json
 import sys
 
-FAMILIES = ("conv_wgrad_gemm_kernel", "conv_gemm_kernel", "gemm_pack", "conv_chain_kernel", "chain_pack_kernel", "bn_act_apply", "conv_halo_kernel", "conv_pw_kernel", "conv_igemm_dma_kernel", "stem_stats_kernel", "stem_apply_kernel", "stem_wgrad_kernel", "conv_wgrad_halo_kernel", "conv_wgrad_kernel", "bn_bwd_reduce",
+FAMILIES = ("conv_wgrad_gemm_kernel", "conv_gemm_kernel", "gemm_pack", "conv_tile_kernel", "tile_pack", "conv_chain_kernel", "chain_pack_kernel", "bn_act_apply", "conv_halo_kernel", "conv_pw_kernel", "conv_igemm_dma_kernel", "stem_stats_kernel", "stem_apply_kernel", "stem_wgrad_kernel", "conv_wgrad_halo_kernel", "conv_wgrad_kernel", "bn_bwd_reduce",
             "bn_bwd_apply", "bn_silu_apply", "reduce_slabs")
-CONV = ("conv_gemm_kernel", "conv_chain_kernel", "conv_halo_kernel", "conv_pw_kernel", "conv_igemm_dma_kernel", "stem_stats_kernel", "stem_apply_kernel")
+CONV = ("conv_gemm_kernel", "conv_tile_kernel", "conv_chain_kernel", "conv_halo_kernel", "conv_pw_kernel", "conv_igemm_dma_kernel", "stem_stats_kernel", "stem_apply_kernel")
 
 
 def family(name):
@@ -41,7 +41,12 @@ def one_step(path, counter):
             k = family(per[i][0])
             agg[k][0] += per[i][1]
             agg[k][1] += 1
+            if k == "other":  # the kernels behind "other", by name
+                OTHER[counter][per[i][0].split("(")[0][-60:]] += per[i][1]
     return agg
+
+
+OTHER = {"FETCH_SIZE": collections.defaultdict(float), "WRITE_SIZE": collections.defaultdict(float)}
 
 
 def _src_sha256():
@@ -70,7 +75,10 @@ def main():
                      "--no-cpu-baseline --steps 3 --warmup 2 --profile-steps 1; one timed step",
            "correction": "bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB counters), MI355X_MICROARCH.md section HBM",
            "conv_family": [k for k in CONV if k in fam], "launches_per_step": n, "hbm_bytes_per_step": tot, "hbm_bytes_per_launch": tot / n,
-           "whole_step_hbm_bytes": sum(v["hbm_bytes"] for v in fam.values()), "families": fam}
+           "whole_step_hbm_bytes": sum(v["hbm_bytes"] for v in fam.values()), "families": fam,
+           "other_by_kernel_mb": {k: round((2 * OTHER["FETCH_SIZE"].get(k, 0.0) + OTHER["WRITE_SIZE"].get(k, 0.0)) * 1024 / 1e6, 1)
+                                  for k in sorted(set(OTHER["FETCH_SIZE"]) | set(OTHER["WRITE_SIZE"]),
+                                                  key=lambda k: -(2 * OTHER["FETCH_SIZE"].get(k, 0.0) + OTHER["WRITE_SIZE"].get(k, 0.0)))[:20]}}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     print(f"conv family: {n} launches, {tot / 1e9:.2f} GB per step, {tot / n / 1e6:.1f} MB per launch; whole step {out['whole_step_hbm_bytes'] / 1e9:.1f} GB")
     for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["hbm_bytes"]):
