@@ -42,7 +42,7 @@ def one_step(path, counter):
             agg[k][0] += per[i][1]
             agg[k][1] += 1
             if k == "other":  # the kernels behind "other", by name
-                OTHER[counter][per[i][0].split("(")[0][-60:]] += per[i][1]
+                OTHER[counter][per[i][0].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-60:]] += per[i][1]
     return agg
 
 
