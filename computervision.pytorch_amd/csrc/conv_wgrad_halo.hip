@@ -41,7 +41,7 @@ __device__ __forceinline__ h8 tr_frag8(const half_t* first_pixel, int row_stride
 // pixel split, i.e. a third of the slab volume for the same parallelism; the patch and the dy tile are loaded 3 times).
 template <int CO_T, int CI_T, int TPB>
 __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradParams p, int tiles_x, int tiles_y, int total_tiles, int tiles_per_split,
-                                                              int gy_ci) {
+                                                              int gy_ci, int gx, int gy, int nsplit) {
   constexpr int CO_B = 16 * CO_T, CI_B = 16 * CI_T;
   constexpr int SD = CO_B + RPAD, SX = CI_B + RPAD;  // LDS pixel-row strides (halves)
   constexpr int NJ = TPB * CI_T;                     // column tiles (tap, ci tile) of this workgroup
@@ -54,9 +54,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradParams 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lg = lane & 15, fq = lane >> 4;
-  const int co0 = blockIdx.x * CO_B, ci0 = (blockIdx.y % gy_ci) * CI_B;
-  const int tap0 = (blockIdx.y / gy_ci) * TPB;
-  const int t_begin = blockIdx.z * tiles_per_split;
+  // Block -> (output-channel block, input-channel block x tap group, pixel split).  The gx * gy workgroups of one split read the same
+  // pixel tiles (x three times over when the taps are split in three) and consecutive workgroup ids go to consecutive XCDs, each with an
+  // L2 of its own: as a 3-D grid the readers of one tile sat on different XCDs and every one fetched it from HBM -- measured 2.0 GB per
+  // step for 0.7 GB of operands (profiles/r04_conv_traffic.json).  Here the id is cut so that all workgroups of a split share id % 8.
+  const int G = gx * gy;
+  const int q = blockIdx.x / (8 * G), r8 = blockIdx.x - q * (8 * G);
+  const int bz = q * 8 + (r8 & 7), g = r8 >> 3;
+  if (bz >= nsplit) return;
+  const int bx = g % gx, by = g / gx;
+  const int co0 = bx * CO_B, ci0 = (by % gy_ci) * CI_B;
+  const int tap0 = (by / gy_ci) * TPB;
+  const int t_begin = bz * tiles_per_split;
   const int t_end = min(total_tiles, t_begin + tiles_per_split);
   const int H = p.OH, W = p.OW;  // stride 1, pad 1: input and output sizes agree
 
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradParams 
 
   // ---- write the slab: lane holds column j = ..+(lane&15), rows co = ..+4*(lane>>4)+r ----
   const int Jtot = p.ntaps * p.cin_pad16;
-  float* slab = p.slabs + (long long)blockIdx.z * p.Cout * Jtot;
+  float* slab = p.slabs + (long long)bz * p.Cout * Jtot;
 #pragma unroll
   for (int jj = 0; jj < JW; ++jj) {
     const int jt = wave * JW + jj;
@@ -187,10 +196,11 @@ int launch_wh(const WgradParams& p, hipStream_t st, int gx, int gy) {
   const int tiles_x = (p.OW + 15) / 16, tiles_y = (p.OH + TH - 1) / TH;
   const int total = tiles_x * tiles_y * p.B;
   const int per = (total + p.nsplit - 1) / p.nsplit;
+  const int ns8 = (p.nsplit + 7) / 8 * 8;  // ids are dealt to the splits in groups of 8 (one per XCD): the last group's spare workgroups exit at once
   if constexpr (CO_T * CI_T >= 8) {  // must mirror cvx_conv_wgrad_halo_grid
-    hipLaunchKernelGGL((conv_wgrad_halo_kernel<CO_T, CI_T, 3>), dim3(gx, gy * 3, p.nsplit), dim3(256), 0, st, p, tiles_x, tiles_y, total, per, gy);
+    hipLaunchKernelGGL((conv_wgrad_halo_kernel<CO_T, CI_T, 3>), dim3(gx * gy * 3 * ns8), dim3(256), 0, st, p, tiles_x, tiles_y, total, per, gy, gx, gy * 3, p.nsplit);
   } else {
-    hipLaunchKernelGGL((conv_wgrad_halo_kernel<CO_T, CI_T, 9>), dim3(gx, gy, p.nsplit), dim3(256), 0, st, p, tiles_x, tiles_y, total, per, gy);
+    hipLaunchKernelGGL((conv_wgrad_halo_kernel<CO_T, CI_T, 9>), dim3(gx * gy * ns8), dim3(256), 0, st, p, tiles_x, tiles_y, total, per, gy, gx, gy, p.nsplit);
   }
   return 0;
 }
