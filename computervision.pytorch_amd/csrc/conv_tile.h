@@ -23,7 +23,7 @@ struct TileArgs {
   int wring_off, CB, stat_off;    // LDS byte offsets / bytes per ring slot
   unsigned in_records;            // bytes of the input view (buffer descriptor range)
   const half_t* wpk;              // packed weights
-  int dbg;                        // tuning build: 1 = drain every DMA before the K loop, 2 = lgkmcnt(0) everywhere, 4 = barrier per step
+  int dbg;                        // tuning build (CVX_TILE_DBG): 1 = drain every DMA before the K loop, 8 = dump block 0's LDS image after the first barrier and stop (tools/tile_lds_dump.py)
 };
 
 template <int OFF>
