@@ -201,6 +201,15 @@ __device__ __forceinline__ void gemm_store_f16(const ConvParams& p, const f16v (
   const int lr = lane & 31, lh = lane >> 5;
   const int act_kind = p.act_kind, res_pre = p.res_pre, accumulate = p.accumulate;
   const half_t* res = p.res;
+  // pixel-shuffle store (ConvParams::ps_cin, plain epilogue only): channel n of the GEMM is channel n % ps_cin of the phase n / ps_cin, one
+  // pixel down / right of the row's base pixel per phase bit; 8 consecutive channels never straddle a phase (ps_cin % 8 == 0)
+  const int ps = EPI == CVX_EPI_PLAIN ? p.ps_cin : 0;
+  const long long ps_row = (long long)p.OWr * p.out_ld;
+  auto chan_off = [&](int n) -> long long {
+    if (EPI != CVX_EPI_PLAIN || ps == 0) return n;
+    const int ph = n / ps;
+    return (ph >> 1) * ps_row + (long long)(ph & 1) * p.out_ld + (n - ph * ps);
+  };
   if (lh == 0) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) *reinterpret_cast<long long*>(wreg + S::OFFS + (i * 32 + lr) * 8) = pvalid[i] ? out_off[i] : -1;
@@ -248,7 +257,7 @@ __device__ __forceinline__ void gemm_store_f16(const ConvParams& p, const f16v (
           }
         }
         if (accumulate && inside && pvalid[i]) {  // data gradients that add to what another consumer left there
-          const h4 old = *reinterpret_cast<const h4*>(p.out16 + out_off[i] + n0);
+          const h4 old = *reinterpret_cast<const h4*>(p.out16 + out_off[i] + chan_off(n0));
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += (float)old[r];
         }
@@ -265,7 +274,7 @@ __device__ __forceinline__ void gemm_store_f16(const ConvParams& p, const f16v (
     const long long off = *reinterpret_cast<const long long*>(wreg + S::OFFS + r * 8);
     const h8 v = *reinterpret_cast<const h8*>(wreg + r * S::RS + c16 * 16);
     if (off >= 0) {
-      half_t* dst = p.out16 + off + n;
+      half_t* dst = p.out16 + off + chan_off(n);
       if (n + 8 <= p.Cout)
         *reinterpret_cast<h8*>(dst) = v;
       else if (n + 4 <= p.Cout)
@@ -682,6 +691,10 @@ bool cvx_conv_gemm_shape_ok(const ConvParams& p) {
 bool cvx_conv_gemm_supported(const ConvParams& p) {
   static const bool off = cvx_tune_set("CVX_NO_GEMM");
   if (off || !cvx_conv_gemm_shape_ok(p)) return false;
+  if (p.ps_cin > 0) {  // pixel-shuffle data gradient (its alternative is the merged-phase launch of the ring kernel, not the kernels below)
+    static const int ps_cmin = cvx_tune_int("CVX_PS_CMIN", 64);
+    return p.Cout >= ps_cmin && p.Cin % 32 == 0;
+  }
   const long long M = (long long)p.B * p.OH2 * p.OW2;
   const long long K = (long long)p.ntaps * p.Cin;
   // measured against the pointwise / halo / LDS-DMA ring kernels (tools/gemm_probe.py + tools/gemm_trace.py, profiles/r03_gemm_*): ahead

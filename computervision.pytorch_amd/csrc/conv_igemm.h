@@ -80,6 +80,10 @@ struct ConvParams {
   const half_t* tile_packed;
   int tile_packed_bn;
   int no_tile;                     // unit tests / A-B timing: keep this launch off the row-band kernel
+  // Data gradient of a stride-2 convolution as ONE stride-1 GEMM (engine.hip: plan_ps_dgrads): the four output phases are channel blocks
+  // of ps_cin channels each -- output channel n = (2 * ph + pw) * ps_cin + c goes to pixel (oh2 * OS + ph, ow2 * OS + pw), channel c
+  // (OS = 2, oph = opw = 0).  0: off.  Served by the GEMM-shaped kernel only (plain epilogue).
+  int ps_cin;
 };
 
 // Packs a 9-entry tap table whose offsets all lie in the 3x3 neighbourhood into two 64-bit words, 4 bits per tap:

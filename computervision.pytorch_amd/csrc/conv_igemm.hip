@@ -22,6 +22,12 @@ int cvx_conv_igemm_launch(const ConvParams& p_in, hipStream_t stream, int* m_blo
   CVX_CHECK(p.zeros && ((uintptr_t)p.zeros % 16) == 0, "conv: needs a 16-byte aligned zero page (padding source of the LDS DMA)");
   CVX_CHECK((long long)p.B * p.OH2 * p.OW2 > 0, "conv: empty output");
   if (m_blocks) *m_blocks = 0;
+  if (p.ps_cin > 0) {  // stride-2 data gradient as one GEMM with a pixel-shuffle store: the GEMM-shaped kernel's plain epilogue only
+    CVX_CHECK(p.epi == CVX_EPI_PLAIN && p.nphase <= 1 && p.OS == 2 && p.oph == 0 && p.opw == 0 && p.ps_cin % 8 == 0 && p.Cout == 4 * p.ps_cin &&
+                  cvx_conv_gemm_shape_ok(p),
+              "conv: pixel-shuffle data gradient needs the GEMM-shaped kernel (plain epilogue, 4 phases of ps_cin channels, output stride 2)");
+    return cvx_conv_gemm_launch(p, stream);
+  }
   if (p.nphase > 1) return cvx_conv_igemm_dma_launch(p, stream);  // merged phases: the DMA-ring kernel only
   if (cvx_conv_stem7_supported(p)) return cvx_conv_stem7_launch(p, stream);  // 7x7 first layer on the padded image
   if (cvx_conv_tile_supported(p)) return cvx_conv_tile_launch(p, stream);  // small 3x3 stride-1 maps: one row band per workgroup

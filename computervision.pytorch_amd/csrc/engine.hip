@@ -62,6 +62,14 @@ struct ConvRt {
   int cin_pad16 = 0;
   // backward plan
   int in_accum = 0, res_accum = 0;
+  // stride-2 data gradient as one GEMM with a pixel-shuffle store (plan_gemm_packs): weights [4 phases x cin][4 window taps x C] in the shadow
+  // arena (sh_ps, rebuilt from the transposed shadow after every pack_weights), the 2 x 2 window's tap table, the GEMM kernel's packed image
+  long long sh_ps = -1;
+  PsPackDesc ps_desc;
+  ConvTap* ps_taps = nullptr;
+  bool ps_on = false;
+  const half_t* ps_pk = nullptr;
+  int ps_bn = 0, ps_kc = 0;
   int slab_blk0 = 0, slab_blk1 = 0;  // reducer workgroups [blk0, blk1) of this op in the slab block table
   bool stem = false;  // 3 -> Cout 3x3 stride-2 conv on the caller's fp32 images: stem.hip
   // per-batch
@@ -339,6 +347,10 @@ int build_static(cvx_engine* e) {
       // data-gradient tap classes: one per output phase of the forward stride
       const int S = o.stride;
       CVX_CHECK(S * S <= 16, "stride too large");
+      // 3x3 / stride 2 / pad 1 on an even map: every phase's taps lie in the 2 x 2 window (dh, dw in {0, 1}) of dy -- the four phases are
+      // four channel blocks of ONE stride-1 GEMM (pixel-shuffle data gradient, see ConvRt::sh_ps)
+      bool ps_shape = S == 2 && o.k == 3 && o.pad == 1 && o.dil == 1 && o.ih == 2 * o.oh && o.iw == 2 * o.ow && o.out.c % 32 == 0;
+      for (int q = 0; q < 16; ++q) c.ps_desc.wtap[q] = -1;
       for (int ph = 0; ph < S; ++ph)
         for (int pw = 0; pw < S; ++pw) {
           std::vector<ConvTap> dt;
@@ -349,6 +361,13 @@ int build_static(cvx_engine* e) {
               int nw = pw + o.pad - s * o.dil;
               if (((nw % S) + S) % S != 0) continue;
               dt.push_back(ConvTap{nh / S, nw / S, r * o.k + s, 0});  // exact division
+              if (ps_shape) {
+                const int dh = nh / S, dw = nw / S;
+                if (dh < 0 || dh > 1 || dw < 0 || dw > 1)
+                  ps_shape = false;
+                else
+                  c.ps_desc.wtap[(ph * 2 + pw) * 4 + dh * 2 + dw] = r * o.k + s;
+              }
             }
           }
           DgClass& dc = c.dg[c.ndg++];
@@ -361,6 +380,19 @@ int build_static(cvx_engine* e) {
           dc.halo_ok = cvx_halo_pack_taps(dt.data(), dc.ntaps, &dc.halo_pos, &dc.halo_wt);
           dc.pointwise = dc.ntaps > 0 ? cvx_taps_pointwise(dt.data(), dc.ntaps) : 0;
         }
+      if (ps_shape) {
+        c.sh_ps = sh;
+        sh += 16LL * pd.Cin_pad * pd.Cout;
+        sh = (sh + 7) & ~7LL;
+        c.ps_desc.dg_off = pd.dg_off;
+        c.ps_desc.ps_off = c.sh_ps;
+        c.ps_desc.cin_pad = pd.Cin_pad;
+        c.ps_desc.T = T;
+        c.ps_desc.C = pd.Cout;
+        std::vector<ConvTap> pt(4);
+        for (int tau = 0; tau < 4; ++tau) pt[tau] = ConvTap{tau >> 1, tau & 1, tau, 0};
+        CVX_TRY(upload(e, e->static_allocs, e->static_bytes, &c.ps_taps, pt));
+      }
     }
     const int total = pd.Cout * T * pd.Cin_pad;
     for (int s0 = 0; s0 < total; s0 += 1024) pblocks.push_back(BlockRef{(int)packs.size(), s0});
@@ -901,6 +933,9 @@ void free_gemm_packs(cvx_engine* e) {
   for (auto& c : e->conv) {
     c.gemm_fwd = nullptr;
     c.gemm_fwd_bn = c.gemm_fwd_kc = 0;
+    c.ps_on = false;
+    c.ps_pk = nullptr;
+    c.ps_bn = c.ps_kc = 0;
     for (auto& d : c.dg) {
       d.gemm_pk = nullptr;
       d.gemm_bn = d.gemm_kc = 0;
@@ -940,8 +975,40 @@ void fill_conv_dgrad_shape(const cvx_engine* e, int i, int q, int B, ConvParams*
   cp->pointwise = dc.pointwise;
 }
 
+// The data gradient of a 3x3 / stride-2 convolution as ONE launch of the GEMM-shaped kernel.  dx[2i + p, 2j + q] only sees dy[i + a, j + b],
+// a, b in {0, 1}: a stride-1 convolution over dy with the 2 x 2 window as its taps and 4 x Cin outputs -- phase (p, q) = channel block
+// 2p + q -- stored with a pixel shuffle (ConvParams::ps_cin).  7 of the 16 (phase, window position) weight blocks are zero (16 / 9 of the
+// multiplications), but it is one GEMM with K = 4 C and N = 4 Cin where the merged-phase launch of the ring kernel is four with K = C .. 4 C
+// and N = Cin: measured in DESIGN 5c.
+void fill_conv_ps_shape(const cvx_engine* e, int i, int B, ConvParams* cp) {
+  const cvx_op_desc& o = e->ops[i];
+  const ConvRt& c = e->conv[i];
+  const int C = o.out.c;
+  memset(cp, 0, sizeof(*cp));
+  cp->in_ld = C;
+  cp->in_bstride = (long long)o.oh * o.ow * C;
+  cp->IH = o.oh;
+  cp->IW = o.ow;
+  cp->Cin = C;
+  cp->wt = e->shadow + c.sh_ps;
+  cp->wt_ld = 4 * C;
+  cp->Cout = 4 * o.in.c;
+  cp->B = B;
+  cp->OH2 = o.oh;
+  cp->OW2 = o.ow;
+  cp->IS = 1;
+  cp->OS = 2;
+  cp->OWr = o.iw;
+  cp->ntaps = 4;
+  cp->taps = c.ps_taps;
+  cp->zeros = e->zero_page;
+  cp->epi = CVX_EPI_PLAIN;
+  cp->ps_cin = o.in.c;
+}
+
 // Every conv launch the dispatcher will give to the GEMM-shaped kernel (conv_gemm.hip) gets its weights in ring image order from one
 // batched launch per forward instead of a 4..8-us launch of its own in front of every convolution.
+constexpr int kPsRef = 1000;  // plan_gemm_packs: the job belongs to an op's pixel-shuffle data gradient
 int plan_gemm_packs(cvx_engine* e, int B, bool training) {
   free_gemm_packs(e);
   struct Ref {
@@ -980,6 +1047,18 @@ int plan_gemm_packs(cvx_engine* e, int B, bool training) {
       fill_conv_dgrad_shape(e, (int)i, 0, B, &cp);
       add(cp, (int)i, 0);
     }
+    static const bool ps_off = cvx_tune_set("CVX_NO_PS_DGRAD");
+    for (size_t i = 0; i < e->ops.size() && !ps_off; ++i) {  // stride-2 data gradients as one pixel-shuffle GEMM where that kernel takes the shape
+      const cvx_op_desc& o = e->ops[i];
+      ConvRt& c = e->conv[i];
+      if (o.type != CVX_OP_CONV || c.stem || !o.needs_dgrad || c.sh_ps < 0 || c.ndg != 4) continue;
+      ConvParams cp;
+      fill_conv_ps_shape(e, (int)i, B, &cp);
+      if (!cvx_conv_gemm_supported(cp)) continue;
+      const size_t before = jobs.size();
+      add(cp, (int)i, kPsRef);
+      c.ps_on = jobs.size() > before;
+    }
   }
   if (jobs.empty()) return 0;
   CVX_HIP(hipMalloc((void**)&e->gemm_arena, total));
@@ -990,6 +1069,10 @@ int plan_gemm_packs(cvx_engine* e, int B, bool training) {
       c.gemm_fwd = jobs[k].dst;
       c.gemm_fwd_bn = jobs[k].BN;
       c.gemm_fwd_kc = jobs[k].kc;
+    } else if (refs[k].q == kPsRef) {
+      c.ps_pk = jobs[k].dst;
+      c.ps_bn = jobs[k].BN;
+      c.ps_kc = jobs[k].kc;
     } else {
       c.dg[refs[k].q].gemm_pk = jobs[k].dst;
       c.dg[refs[k].q].gemm_bn = jobs[k].BN;
@@ -1374,6 +1457,10 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
 #ifdef CVX_WITH_CHAIN
     if (!training && e->n_chain_jobs > 0) CVX_TRY(cvx_chain_pack_jobs(e->d_chain_jobs, e->n_chain_jobs, e->chain_max_units, prep));
 #endif
+    if (training) {  // pixel-shuffle data-gradient weights: from the transposed shadows just written, before the GEMM kernel's pack reads them
+      for (const ConvRt& c : e->conv)
+        if (c.ps_on) CVX_TRY(cvx_pack_ps_weights(e->shadow, e->shadow, c.ps_desc, prep));
+    }
     if (training)
       CVX_TRY(cvx_conv_gemm_pack_jobs(e->d_gemm_jobs, e->n_gemm_jobs, e->gemm_blocks, prep));
     else
@@ -1817,7 +1904,24 @@ int backward_op(cvx_engine* e, int i) {
       bool empty_phase = false;
       for (int q = 0; q < c.ndg; ++q) empty_phase |= c.dg[q].OH2 > 0 && c.dg[q].OW2 > 0 && c.dg[q].ntaps == 0;
       if (empty_phase && !c.in_accum) CVX_TRY(cvx_zero_slice(gin, B, o.ih * o.iw, o.in.c, st));
-      for (int q = 0; q < c.ndg; ++q) {
+      if (c.ps_on) {  // the four phases as one GEMM with a pixel-shuffle store (fill_conv_ps_shape)
+        ConvParams cp;
+        fill_conv_ps_shape(e, i, B, &cp);
+        cp.in = dyv.p;
+        cp.in_bstride = dyv.bstride;
+        cp.in_ld = dyv.ld;
+        cp.accumulate = c.in_accum;
+        cp.wt_packed = c.ps_pk;
+        cp.wt_packed_bn = c.ps_bn;
+        cp.wt_packed_kc = c.ps_kc;
+        cp.out16 = gin.p;
+        cp.out_ld = gin.ld;
+        cp.out_bstride = gin.bstride;
+        const double fl = 2.0 * B * o.oh * o.ow * (double)o.in.c * c.ntaps * C;  // the useful multiplications (the zero blocks are not counted)
+        ProfScope ps(e, PROF_CONV_DGRAD, fl, conv_bytes(o, B) + (c.in_accum ? 2.0 * B * o.ih * o.iw * o.in.c : 0.0), st);
+        CVX_TRY(cvx_conv_igemm_launch(cp, st, nullptr));
+      }
+      for (int q = 0; q < c.ndg && !c.ps_on; ++q) {
         if (merged && q > 0) break;  // everything went out with phase 0
         const DgClass& dc = c.dg[q];
         if (dc.OH2 <= 0 || dc.OW2 <= 0 || dc.ntaps == 0) continue;
@@ -2288,6 +2392,67 @@ extern "C" int cvx_conv2d_dgrad_nhwc(const void* dy_f16, int32_t batch, int32_t 
   hipStream_t st = (hipStream_t)hip_stream;
   const int oh = (ih + 2 * pad - dil * (k - 1) - 1) / stride + 1, ow = (iw + 2 * pad - dil * (k - 1) - 1) / stride + 1;
   int rc = 0;
+  // 3x3 / stride 2 / pad 1 on an even map: the engine's route -- ONE launch of the GEMM-shaped kernel over the 2 x 2 window of dy, the four
+  // phases as channel blocks, pixel-shuffle store (ConvParams::ps_cin) -- where that kernel takes the shape
+  if (k == 3 && stride == 2 && pad == 1 && dil == 1 && ih == 2 * oh && iw == 2 * ow && cout % 32 == 0 && cin % 8 == 0) {
+    PsPackDesc pd;
+    pd.dg_off = pd.ps_off = 0;
+    pd.cin_pad = cin;
+    pd.T = 9;
+    pd.C = cout;
+    for (int q = 0; q < 16; ++q) pd.wtap[q] = -1;
+    for (int ph = 0; ph < 2; ++ph)
+      for (int pw = 0; pw < 2; ++pw)
+        for (int r = 0; r < 3; ++r)
+          for (int s = 0; s < 3; ++s) {
+            const int nh = ph + 1 - r, nw = pw + 1 - s;
+            if ((nh & 1) || (nw & 1)) continue;
+            pd.wtap[(ph * 2 + pw) * 4 + (nh / 2) * 2 + nw / 2] = r * 3 + s;
+          }
+    std::vector<ConvTap> pt(4);
+    for (int tau = 0; tau < 4; ++tau) pt[tau] = ConvTap{tau >> 1, tau & 1, tau, 0};
+    ConvTap* dt = nullptr;
+    CVX_TRY(make_taps(pt, &dt));
+    ConvParams cp;
+    memset(&cp, 0, sizeof(cp));
+    cp.in = (const half_t*)dy_f16;
+    cp.in_bstride = (long long)oh * ow * cout;
+    cp.in_ld = cout;
+    cp.IH = oh;
+    cp.IW = ow;
+    cp.Cin = cout;
+    cp.wt_ld = 4 * cout;
+    cp.Cout = 4 * cin;
+    cp.B = batch;
+    cp.OH2 = oh;
+    cp.OW2 = ow;
+    cp.IS = 1;
+    cp.OS = 2;
+    cp.OWr = iw;
+    cp.ntaps = 4;
+    cp.taps = dt;
+    cp.zeros = zeros_after(dt, pt.size());
+    cp.epi = CVX_EPI_PLAIN;
+    cp.ps_cin = cin;
+    cp.out16 = (half_t*)dx_f16;
+    cp.out_ld = cin;
+    cp.out_bstride = (long long)ih * iw * cin;
+    if (cvx_conv_gemm_supported(cp)) {
+      half_t* psw = nullptr;
+      if (hipMalloc((void**)&psw, (size_t)16 * cin * cout * 2) != hipSuccess) {
+        (void)hipFree(dt);
+        CVX_CHECK(false, "dgrad: out of memory for the pixel-shuffle weights");
+      }
+      cp.wt = psw;
+      rc = cvx_pack_ps_weights((const half_t*)wt_f16, psw, pd, st);
+      if (rc == 0) rc = cvx_conv_igemm_launch(cp, st, nullptr);
+      (void)hipStreamSynchronize(st);
+      (void)hipFree(psw);
+      (void)hipFree(dt);
+      return rc;
+    }
+    (void)hipFree(dt);
+  }
   for (int ph = 0; ph < stride && rc == 0; ++ph)
     for (int pw = 0; pw < stride && rc == 0; ++pw) {
       std::vector<ConvTap> taps;
@@ -2329,7 +2494,6 @@ extern "C" int cvx_conv2d_dgrad_nhwc(const void* dy_f16, int32_t batch, int32_t 
       cp.zeros = zeros_after(dt, taps.size());
       cp.halo_taps_ok = cvx_halo_pack_taps(taps.data(), (int)taps.size(), &cp.halo_pos, &cp.halo_wt) ? 1 : 0;
       cp.pointwise = cvx_taps_pointwise(taps.data(), (int)taps.size());
-  cp.pointwise = cvx_taps_pointwise(taps.data(), (int)taps.size());
       cp.epi = CVX_EPI_PLAIN;
       cp.out16 = (half_t*)dx_f16;
       cp.out_ld = cin;

@@ -78,6 +78,16 @@ struct BlockRef {
 };
 int cvx_pack_weights(const float* master, half_t* shadow, const PackDesc* descs, const BlockRef* blocks, int nblocks, hipStream_t st);
 
+// Weights of a stride-2 data gradient as ONE stride-1 GEMM over the 2 x 2 window of dy (engine.hip: pixel-shuffle data gradient): fp16
+// [4 phases x cin_pad rows][4 window taps x C columns], block (phase, tau) = tap wtap[phase * 4 + tau] of the transposed data-gradient
+// shadow [cin_pad][T][C] (-1: the phase does not use that window position -- zeros).
+struct PsPackDesc {
+  long long dg_off, ps_off;  // element offsets from dg_base / ps_base (the engine: both the fp16 shadow arena)
+  int cin_pad, T, C;
+  int wtap[16];
+};
+int cvx_pack_ps_weights(const half_t* dg_base, half_t* ps_base, const PsPackDesc& d, hipStream_t st);
+
 struct SlabDesc {        // one weight-gradient tensor
   long long slab_off;    // fp32 [nsplit][Cout*T][Cin_pad]
   long long dst_off;     // fp32 grad arena [Cout*T][Cin]

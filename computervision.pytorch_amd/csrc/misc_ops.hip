@@ -1219,6 +1219,20 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* master, 
   }
 }
 
+__global__ __launch_bounds__(256) void ps_pack_kernel(const half_t* dg_base, half_t* ps_base, const PsPackDesc d) {
+  const int k8 = (4 * d.C) / 8;  // 16-byte units per row
+  const long long total = 4LL * d.cin_pad * k8;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int n = (int)(idx / k8), kk = (int)(idx - (long long)n * k8) * 8;
+  const int phase = n / d.cin_pad, ci = n - phase * d.cin_pad;
+  const int tau = kk / d.C, co = kk - tau * d.C;
+  const int wt = d.wtap[phase * 4 + tau];
+  h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (wt >= 0) v = *reinterpret_cast<const h8*>(dg_base + d.dg_off + ((long long)ci * d.T + wt) * d.C + co);
+  *reinterpret_cast<h8*>(ps_base + d.ps_off + (long long)n * 4 * d.C + kk) = v;
+}
+
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* slabs, float* grads, float inv_scale, const SlabDesc* descs,
                                                            const BlockRef* blocks) {
   // block = (256 / lanes) consecutive gradient elements x `lanes` split-lanes; each lane sums a strided
@@ -1523,6 +1537,13 @@ int cvx_nchw_to_pred_f16(const float* g, int B, int A, int no, int a_off, int H,
 int cvx_pack_weights(const float* master, half_t* shadow, const PackDesc* descs, const BlockRef* blocks, int nblocks, hipStream_t st) {
   if (nblocks <= 0) return 0;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(nblocks), dim3(256), 0, st, master, shadow, descs, blocks);
+  CVX_HIP(hipGetLastError());
+  return 0;
+}
+int cvx_pack_ps_weights(const half_t* dg_base, half_t* ps_base, const PsPackDesc& d, hipStream_t st) {
+  CVX_CHECK(d.C % 8 == 0 && d.dg_off % 8 == 0 && d.ps_off % 8 == 0, "ps pack: 16-byte rows needed");
+  const long long total = 4LL * d.cin_pad * (4 * d.C / 8);
+  hipLaunchKernelGGL(ps_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dg_base, ps_base, d);
   CVX_HIP(hipGetLastError());
   return 0;
 }

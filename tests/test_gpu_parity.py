@@ -146,6 +146,27 @@ def test_conv_fwd_dgrad_wgrad(dev, B, H, W, Ci, Co, k, s):
     assert rel(dw.permute(0, 3, 1, 2), wr.grad) < 1e-5
 
 
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 16, 24, 32, 64), (3, 20, 20, 64, 128), (1, 40, 8, 16, 32), (2, 12, 12, 128, 256), (2, 10, 14, 24, 96)])
+def test_stride2_data_gradient_as_one_pixel_shuffle_gemm(dev, B, H, W, Ci, Co):
+    """cvx_conv2d_dgrad_nhwc takes the engine's route for 3x3 / stride 2 / pad 1 on even maps: the 2 x 2 window of dy as a stride-1 GEMM with
+    the four output phases as channel blocks and a pixel-shuffle store (ConvParams::ps_cin) -- against torch's conv2d backward on the CPU,
+    incl. 16 and 24 input channels (4 x 16 = 64 outputs: the smallest the route takes) and maps whose last row / column of dy has no
+    neighbour below / right (every map: the window's second tap is out of range there)."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(H * 100 + Ci)
+    x16 = torch.randn(B, Ci, H, W, generator=g).half()
+    w16 = (torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5).half()
+    xr, wr = x16.float().requires_grad_(True), w16.float()
+    ref = F.conv2d(xr, wr, None, 2, 1)
+    dy16 = torch.randn(*ref.shape, generator=g).half()
+    ref.backward(dy16.float())
+    dyd = dy16.permute(0, 2, 3, 1).contiguous().to(dev)
+    wtd = w16.permute(1, 2, 3, 0).contiguous().to(dev)
+    dx = torch.full((B, H, W, Ci), 7.0, dtype=torch.float16, device=dev)     # every pixel must be written
+    L.check(lib.cvx_conv2d_dgrad_nhwc(L.ptr(dyd), B, H, W, Ci, L.ptr(wtd), Co, 3, 2, 1, 1, L.ptr(dx), L.stream_ptr(dev)), "dgrad")
+    assert rel(dx.float().permute(0, 3, 1, 2), xr.grad) < 5e-4
+
+
 @pytest.mark.parametrize("B,H,W,Ci,Co,k,s,dil", GEMM_CASES)
 def test_gemm_shaped_conv_kernel_all_epilogues(dev, B, H, W, Ci, Co, k, s, dil):
     """conv_gemm.hip run directly (mode | 0x100) -- the dispatcher only prefers it on the largest layers: plain fp16 store, folded BN + SiLU,
