@@ -191,7 +191,7 @@ def centernet_main(args):
             "metric": "images/sec 512x512 CenterNet DLA-34 inference + decode", "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"CenterNet DLA-34 (nc 80) inference + heat-map decode (top-100, DIoU-NMS), batch {B}/GPU, 512x512, random init",
+            "config": {"weights": "constant between forwards: the engine keeps its fp16 weight images (cvx_engine_keep_shadows), BatchNorm folding still runs every forward", "workload": f"CenterNet DLA-34 (nc 80) inference + heat-map decode (top-100, DIoU-NMS), batch {B}/GPU, 512x512, random init",
                        "global_batch": B * world, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": "implicit-GEMM convolution forward launches (conv_halo / conv_pw / conv_igemm_dma)",
                          "achieved": round(tf, 3), "peak": MFMA_FP16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_FP16_PEAK_TFLOPS, 5),
@@ -270,7 +270,7 @@ def deeplab_main(args):
             "metric": "images/sec 513x513 DeepLabv3+ R101 inference", "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"DeepLabv3+ ResNet-101 (output stride 16, nc 21) eval forward + bilinear resize to the input size, batch {B}/GPU, "
+            "config": {"weights": "constant between forwards: the engine keeps its fp16 weight images (cvx_engine_keep_shadows), BatchNorm folding still runs every forward", "workload": f"DeepLabv3+ ResNet-101 (output stride 16, nc 21) eval forward + bilinear resize to the input size, batch {B}/GPU, "
                                    f"{H}x{W}, random init", "global_batch": B * world, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": "implicit-GEMM convolution forward launches (conv_halo / conv_pw / conv_igemm_dma)",
                          "achieved": round(tf, 3), "peak": MFMA_FP16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_FP16_PEAK_TFLOPS, 5),
@@ -678,7 +678,7 @@ def yolov7_main(args):
                        "0 candidates pass the threshold at random init: suppression not exercised") + ")"), "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"YOLOv7-l (nc 20) eval forward + anchor decode + per-class NMS, batch {B}/GPU, {H}x{W}, random init",
+            "config": {"weights": "constant between forwards: the engine keeps its fp16 weight images (cvx_engine_keep_shadows), BatchNorm folding still runs every forward", "workload": f"YOLOv7-l (nc 20) eval forward + anchor decode + per-class NMS, batch {B}/GPU, {H}x{W}, random init",
                        "global_batch": B * world, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": "implicit-GEMM convolution forward launches (conv_halo / conv_pw / conv_igemm_dma)",
                          "achieved": round(tf, 3), "peak": MFMA_FP16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_FP16_PEAK_TFLOPS, 5),
@@ -772,7 +772,7 @@ def ssd_main(args):
                        "no score passes the threshold at random init: NMS not exercised") + ")"), "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"SSD300 VGG16-BN (nc 20) eval forward + softmax / prior decode (+ per-class NMS when a score passes), batch {B}/GPU, "
+            "config": {"weights": "constant between forwards: the engine keeps its fp16 weight images (cvx_engine_keep_shadows), BatchNorm folding still runs every forward", "workload": f"SSD300 VGG16-BN (nc 20) eval forward + softmax / prior decode (+ per-class NMS when a score passes), batch {B}/GPU, "
                                    "300x300, random init", "global_batch": B * world, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": "implicit-GEMM convolution forward launches (conv_halo / conv_pw / conv_igemm_dma)",
                          "achieved": round(tf, 3), "peak": MFMA_FP16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_FP16_PEAK_TFLOPS, 5),
@@ -846,7 +846,7 @@ def yolov8_eval_main(args):
             "metric": f"images/sec 640x640 YOLOv8-{args.model} eval forward + decode", "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"YOLOv8-{args.model} eval forward (folded BN + SiLU epilogues, fusion groups {'on' if args.fusion else 'off'}) + DFL decode, "
+            "config": {"weights": "constant between forwards: the engine keeps its fp16 weight images (cvx_engine_keep_shadows), BatchNorm folding still runs every forward", "workload": f"YOLOv8-{args.model} eval forward (folded BN + SiLU epilogues, fusion groups {'on' if args.fusion else 'off'}) + DFL decode, "
                                    f"batch {B}/GPU, 640x640, nc=80, random init", "global_batch": B * world, "parallelism": f"dp{world}",
                        "fused_groups": eng.fused_groups()},
             "roofline": {"bound": "mfma", "kernel": "convolution launches of the eval forward (conv_chain / conv_halo / conv_pw / conv_igemm_dma + the fp32 stem), "
@@ -1039,7 +1039,7 @@ def main():
             "forward_eval": {"ms_per_batch": round(eval_ms, 4), "images_per_sec": round(B / eval_ms * 1e3, 1),
                              "tflops": round(B * fwd_gf / eval_ms, 2),
                              "frac_of_mfma_peak": round(B * fwd_gf / eval_ms / MFMA_FP16_PEAK_TFLOPS, 5),
-                             "note": "per GPU; eval-mode forward of the same batch, folded BN + SiLU in the conv epilogues"},
+                             "note": "per GPU; eval-mode forward of the same batch, folded BN + SiLU in the conv epilogues; weights constant between these forwards: fp16 weight images kept (cvx_engine_keep_shadows)"},
             "kernel_classes": classes,
             "loss_items_last_step": loss_items,
             "engine_workspace_gib": round(eng.workspace_bytes() / 2 ** 30, 3),

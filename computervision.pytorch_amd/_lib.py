@@ -111,6 +111,7 @@ PROTOTYPES = {
     "cvx_letterbox_geometry": (_I32, [_I32, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
     "cvx_letterbox_u8_to_nchw": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _I32, _I32, _P]),
     "cvx_engine_set_seed": (_I32, [_P, _U64]),
+    "cvx_engine_keep_shadows": (_I32, [_P]),
     "cvx_engine_set_fusion": (_I32, [_P, _I32]),
     "cvx_engine_fused_groups": (_I32, [_P]),
     "cvx_centernet_loss_workspace_bytes": (_I64, [_I32, _I32]),

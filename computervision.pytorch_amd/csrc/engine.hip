@@ -161,6 +161,11 @@ struct cvx_engine {
   unsigned long long seed = 0, train_pass = 0;  // dropout: cvx_engine_set_seed, training forwards so far
   bool has_bias_act = false;  // a conv + bias (+ ReLU) epilogue without BatchNorm exists (its scale / shift table entry is needed in training too)
   bool fwd_train_done = false;
+  // cvx_engine_keep_shadows: the caller vouches that no parameter changed since this engine's previous forward -- the next forward skips
+  // the fp32 -> fp16 weight conversion and the kernels' packed weight images if they were made for this plan and cover this mode
+  bool keep_shadows_once = false;
+  int shadows_gen = -1;        // plan generation the shadows / packed images were made under
+  bool shadows_train = false;  // ... by a training forward (which packs the data-gradient images too)
   bool bwd_slabs_clean = false;  // the backward statistic slabs were zeroed by the training forward and not used since
   int last_batch = 0;
   float* last_pred = nullptr;
@@ -1394,6 +1399,12 @@ extern "C" int32_t cvx_engine_fused_groups(const cvx_engine* e) {
 #endif
 }
 
+extern "C" int cvx_engine_keep_shadows(cvx_engine* e) {
+  CVX_CHECK(e, "null engine");
+  e->keep_shadows_once = true;
+  return 0;
+}
+
 extern "C" int cvx_engine_set_seed(cvx_engine* e, uint64_t seed) {
   CVX_CHECK(e, "null engine");
   e->seed = seed;
@@ -1443,7 +1454,9 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
   }
   // fp16 weight shadows: the fp32 stem does not need them, so they are prepared on the lane stream BESIDE it (33 us off the main chain); the first op after the stem waits for them
   static const int pack_lane = cvx_tune_int("CVX_PACK_LANE", 1);  // bit 0: training forward, bit 1: eval forward (measured: +0.02 ms there)
-  const bool prep_beside_stem = e->lane && !e->ops.empty() && e->ops[0].type == CVX_OP_CONV && e->conv[0].stem && !e->profile &&
+  const bool keep = e->keep_shadows_once && e->shadows_gen == e->plan_generation && (e->shadows_train || !training);
+  e->keep_shadows_once = false;
+  const bool prep_beside_stem = !keep && e->lane && !e->ops.empty() && e->ops[0].type == CVX_OP_CONV && e->conv[0].stem && !e->profile &&
                                 (pack_lane & (training ? 1 : 2)) != 0;
   hipStream_t prep = st;
   if (prep_beside_stem) {
@@ -1451,7 +1464,9 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
     CVX_HIP(hipStreamWaitEvent(e->lane, e->ev_pack, 0));
     prep = e->lane;
   }
-  {
+  if (!keep) {
+    e->shadows_gen = e->plan_generation;
+    e->shadows_train = training;
     ProfScope ps(e, PROF_MISC, 0, 6.0 * e->n_params, prep);
     CVX_TRY(cvx_pack_weights(e->params, e->shadow, e->d_pack, e->d_pack_blocks, e->n_pack_blocks, prep));
 #ifdef CVX_WITH_CHAIN

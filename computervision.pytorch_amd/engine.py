@@ -74,6 +74,14 @@ class Engine:
         if pred is None:
             pred = torch.empty(b, self.graph.anchors, no, device=images.device, dtype=torch.float32)
         self._use_current_stream()
+        # constant weights between two forwards of this engine (inference loops): skip the fp32 -> fp16 weight conversion.  "Constant" =
+        # torch's in-place version counter of the bound parameter arena (optimisers on views, load_state_dict, broadcasts all bump it) AND
+        # this package's own counter of raw-pointer writers (the Adam kernels) are where the previous forward left them.
+        params = self._keep[0] if getattr(self, "_keep", None) else None
+        wkey = None if params is None else (params.data_ptr(), params._version, PARAM_WRITES.get(params.data_ptr(), 0))
+        if wkey is not None and wkey == getattr(self, "_weights_key", None) and not torch.cuda.is_current_stream_capturing():
+            L.check(self.lib.cvx_engine_keep_shadows(self.handle), "cvx_engine_keep_shadows")
+        self._weights_key = wkey
         L.check(self.lib.cvx_engine_forward(self.handle, L.ptr(images), b, 1 if training else 0, L.ptr(pred)), "cvx_engine_forward")
         # the fp32 stem reads the caller's tensor directly, and its weight gradient reads it again in the backward pass
         self._images = images if training else None
@@ -232,9 +240,19 @@ class V8LossOp:
         return idx.long(), norm
 
 
+# writes to a parameter arena that torch does not see (raw-pointer kernels): data_ptr -> count.  Engine.forward compares it, together with
+# the tensor's own in-place version, against what it was at the engine's previous forward before it lets the engine keep its fp16 shadows.
+PARAM_WRITES: dict = {}
+
+
+def _note_param_write(params: torch.Tensor):
+    PARAM_WRITES[params.data_ptr()] = PARAM_WRITES.get(params.data_ptr(), 0) + 1
+
+
 def adam_step(params, grads, exp_avg, exp_avg_sq, lr, betas, eps, step, found_inf=None, zero_grad=True):
     lib = L.load()
     _need_gpu(params, "params")
+    _note_param_write(params)
     L.check(lib.cvx_adam_step(L.ptr(params), L.ptr(grads), L.ptr(exp_avg), L.ptr(exp_avg_sq), params.numel(), lr, betas[0], betas[1], eps,
                               step, L.ptr(found_inf), 1 if zero_grad else 0, L.stream_ptr(params.device)), "cvx_adam_step")
 
@@ -243,6 +261,7 @@ def adam_step_dev(params, grads, exp_avg, exp_avg_sq, betas, eps, state, found_i
     """Adam with the step state on the device (state = [lr, step, lr/bc1, 1/sqrt(bc2)]): graph-replayable."""
     lib = L.load()
     _need_gpu(params, "params")
+    _note_param_write(params)
     L.check(lib.cvx_adam_step_dev(L.ptr(params), L.ptr(grads), L.ptr(exp_avg), L.ptr(exp_avg_sq), params.numel(), betas[0], betas[1], eps,
                                   L.ptr(state), L.ptr(found_inf), 1 if zero_grad else 0, float(grad_scale), L.stream_ptr(params.device)),
             "cvx_adam_step_dev")

@@ -18,7 +18,7 @@ import ctypes as C
 import os
 
 from . import _lib as L
-from .engine import V8LossOp, adam_step, adam_step_dev, check_finite
+from .engine import V8LossOp, _note_param_write, adam_step, adam_step_dev, check_finite
 from .graph import STRIDES
 from .model import PredList, Yolo8
 
@@ -379,6 +379,7 @@ class FusedTrainStep:
         for k, v in batch.items():
             self._sb[k].copy_(v, non_blocking=True)
         self._graph.replay()
+        _note_param_write(self.model.flat_params)   # the replayed Adam kernel wrote the arena behind torch's back (Engine.forward: keep_shadows)
         self.optimizer._step += 1
         return self._sitems.clone()                          # the static buffer is overwritten by the next replay
 

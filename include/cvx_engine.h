@@ -121,6 +121,12 @@ int cvx_engine_set_bn(cvx_engine* e, float eps, float momentum);
  * of the TUNING build only (tools/build_tuning.sh, -DCVX_WITH_CHAIN; include/cvx_engine_experimental.h): in the release library
  * cvx_engine_set_fusion(e, 1) FAILS with an error that says so (enable = 0 is accepted) and cvx_engine_fused_groups returns 0.
  * Replaces: the module-by-module execution of Bottleneck.forward / Detect.forward, core/models/yolov8/modules.py:124-135, 428-433. */
+/* Inference with constant weights: the caller vouches that no parameter of the bound arena changed since this engine's PREVIOUS
+ * cvx_engine_forward.  The next forward (only that one) then skips the fp32 -> fp16 weight conversion and the kernels' packed weight
+ * images (40 us of a 1.4-ms YOLOv8-n forward, 90-220 us of the bigger models') -- provided they were made under the current batch plan and
+ * by a forward of the same mode, or a training one (an eval forward does not prepare the data-gradient images); otherwise the call has no effect.
+ * BatchNorm folding (running statistics -> scale / shift) is never skipped.  The reference has no counterpart: torch converts nothing. */
+int cvx_engine_keep_shadows(cvx_engine* e);
 int cvx_engine_set_fusion(cvx_engine* e, int32_t enable);
 int32_t cvx_engine_fused_groups(const cvx_engine* e);
 

@@ -3095,6 +3095,34 @@ def test_chain_detect_level_unit(dev, B, H, W, Cin, th, tw):
 
 
 @pytest.mark.gpu
+def test_inference_keeps_its_weight_shadows_only_while_the_weights_stand(dev):
+    """Engine.forward lets the engine skip the fp32 -> fp16 weight conversion (cvx_engine_keep_shadows) when neither torch's version counter of
+    the parameter arena nor the package's counter of raw-pointer writers moved since the engine's previous forward: same output bit for bit
+    with the shadows kept; an in-place torch update and an Adam kernel step must both be seen by the very next forward."""
+    m = new_model(dev).eval()
+    x = synth.images(2, 128, 128, seed=4).to(dev)
+    with torch.no_grad():
+        y0, _ = m(x)
+        y1, _ = m(x)                                  # second forward: shadows kept
+        assert torch.equal(y0, y1)
+        m.flat_params.mul_(2.0)                       # torch sees this write (version counter of the arena)
+        y2, _ = m(x)
+        assert not torch.equal(y2, y1)
+        m.flat_params.mul_(0.5)                       # exact inverse
+        y3, _ = m(x)
+        assert torch.equal(y3, y0)
+        y3b, _ = m(x)                                 # kept again
+        assert torch.equal(y3b, y0)
+        g = torch.full_like(m.flat_params, 1e-2)      # torch does not see this one: the Adam kernel writes through a raw pointer
+        mm, vv = torch.zeros_like(g), torch.zeros_like(g)
+        E.adam_step(m.flat_params, g, mm, vv, 1e-2, (0.9, 0.999), 1e-8, 1)
+        y4, _ = m(x)
+        assert not torch.equal(y4, y0)
+        y5, _ = m(x)
+        assert torch.equal(y5, y4)
+
+
+@pytest.mark.gpu
 def test_release_library_refuses_fusion(dev):
     """the release library has no chain kernel: enabling the fusion groups is an error that says where the kernel went, never a silent no-op"""
     if L.has_chain():
