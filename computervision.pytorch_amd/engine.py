@@ -22,6 +22,9 @@ def _need_gpu(t: torch.Tensor, what: str):
 
 class Engine:
     _warned_stream = False
+    # False: every forward converts the weights again (for callers that write parameters in ways neither torch's version counter nor this
+    # package can see: `p.data.mul_()` -- `.data` has a version counter of its own --, raw kernels of their own, another process)
+    keep_weight_images = True
 
     def __init__(self, graph: Graph, device: torch.device):
         self.lib = L.load()
@@ -79,7 +82,7 @@ class Engine:
         # this package's own counter of raw-pointer writers (the Adam kernels) are where the previous forward left them.
         params = self._keep[0] if getattr(self, "_keep", None) else None
         wkey = None if params is None else (params.data_ptr(), params._version, PARAM_WRITES.get(params.data_ptr(), 0))
-        if wkey is not None and wkey == getattr(self, "_weights_key", None) and not torch.cuda.is_current_stream_capturing():
+        if Engine.keep_weight_images and wkey is not None and wkey == getattr(self, "_weights_key", None) and not torch.cuda.is_current_stream_capturing():
             L.check(self.lib.cvx_engine_keep_shadows(self.handle), "cvx_engine_keep_shadows")
         self._weights_key = wkey
         L.check(self.lib.cvx_engine_forward(self.handle, L.ptr(images), b, 1 if training else 0, L.ptr(pred)), "cvx_engine_forward")
