@@ -154,6 +154,20 @@ def test_library_exports_every_declared_symbol():
     assert L.load().cvx_abi_version() == L.ABI_VERSION
 
 
+def test_release_library_does_not_carry_the_experimental_entry_points():
+    """include/cvx_engine_experimental.h (the chain kernel's unit entries) is the tuning build's: the release library must not export them,
+    and the bindings list them apart from the release prototypes"""
+    if os.path.realpath(LIB_PATH) != os.path.realpath(os.path.join(ROOT, "computervision.pytorch_amd", "lib", "libcvx_engine.so")):
+        pytest.skip("CVX_LIB points at another build")
+    header = open(os.path.join(ROOT, "include", "cvx_engine_experimental.h")).read()
+    declared = set(re.findall(r"\b(cvx_[a-z0-9_]+)\s*\(", header)) - set(L.PROTOTYPES)   # (its comment mentions release entry points)
+    assert declared == set(L.EXPERIMENTAL_PROTOTYPES) and declared
+    lib = ctypes.CDLL(LIB_PATH)
+    for name in declared:
+        assert not hasattr(lib, name), f"{name} is experimental but exported by the release library"
+        assert name not in L.PROTOTYPES
+
+
 def test_engine_refuses_cpu_device():
     from computervision.pytorch_amd.engine import Engine
     from computervision.pytorch_amd.graph import ParamLayout, build_yolov8_graph
