@@ -52,6 +52,7 @@ EXPERIMENTAL_PROTOTYPES = {
     "cvx_chain_conv_unit": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _I32, _P, _P, _I32, _P, _I32, _I32, _I32, C.POINTER(_F), _P]),
     "cvx_chain_detect_unit": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32,
                                      _I32, _I32, C.POINTER(_F), _P]),
+    "cvx_wgrad_time_unit": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I64, C.POINTER(_F), C.POINTER(_I32), _P]),
 }
 
 # name -> (restype, argtypes); every symbol include/cvx_engine.h declares

@@ -186,6 +186,14 @@ bool cvx_conv_wgrad_halo_supported(const WgradParams& p);
 void cvx_conv_wgrad_halo_grid(int cout, int cin, int* gx, int* gy);
 int cvx_conv_wgrad_halo_tiles(int B, int OH, int OW);
 int cvx_conv_wgrad_halo_launch(const WgradParams& p, hipStream_t stream);
+// streaming kernel for the narrow 1x1 / 3x3 stride-1 layers (conv_wgrad_stream.hip): LDS-DMA ring, padded-linear pixel space
+bool cvx_conv_wgrad_stream_supported(const WgradParams& p);  // needs geometry, channel counts, strides and cin_pad16 filled in
+int cvx_conv_wgrad_stream_nsplit(const WgradParams& p);      // the planner's pixel-split count (the engine sizes the slabs with it)
+int cvx_conv_wgrad_stream_launch(const WgradParams& p, hipStream_t stream);
+// fat-workgroup kernel for the 3x3 stride-1 layers with 16 ... 144 channels (conv_wgrad_k3.hip): 8 waves, a CU's whole LDS, few workgroups
+bool cvx_conv_wgrad_k3_supported(const WgradParams& p);
+int cvx_conv_wgrad_k3_nsplit(const WgradParams& p);
+int cvx_conv_wgrad_k3_launch(const WgradParams& p, hipStream_t stream);
 inline int cvx_taps_std3x3(const ConvTap* t, int n) {
   if (n != 9) return 0;
   for (int i = 0; i < 9; ++i)

@@ -205,6 +205,8 @@ int cvx_conv_wgrad_launch(const WgradParams& p, hipStream_t st) {
   CVX_CHECK(p.cin_pad16 % 16 == 0 && p.cin_pad16 >= p.Cin, "wgrad: cin_pad16");
   CVX_CHECK(p.nsplit >= 1 && p.ntaps >= 1 && p.ntaps <= CVX_MAX_TAPS, "wgrad: nsplit/ntaps");
   CVX_CHECK(((uintptr_t)p.x % 16) == 0 && ((uintptr_t)p.dy % 16) == 0, "wgrad: operands must be 16-byte aligned");
+  if (cvx_conv_wgrad_k3_supported(p)) return cvx_conv_wgrad_k3_launch(p, st);
+  if (cvx_conv_wgrad_stream_supported(p)) return cvx_conv_wgrad_stream_launch(p, st);
   if (cvx_conv_wgrad_halo_supported(p)) return cvx_conv_wgrad_halo_launch(p, st);
   if (cvx_conv_wgrad_gemm_supported(p)) return cvx_conv_wgrad_gemm_launch(p, st);
   int co_b, j_b;

@@ -736,7 +736,8 @@ int plan_batch(cvx_engine* e, int B, bool training) {
       // the GEMM-shaped weight-gradient kernel (conv_wgrad_gemm.hip) takes the BatchNorm / bias layers with 128+ output channels: its tiles
       // and its 512-thread workgroups size the pixel splits
       bool wgg = false;
-      if (!c.stem && o.act != CVX_ACT_BIAS) {
+      int ws_splits = 0;  // > 0: the streaming kernel (conv_wgrad_stream.hip) takes the layer, with its planner's pixel splits
+      if (!c.stem) {
         WgradParams q;
         memset(&q, 0, sizeof(q));
         const Buf& xb = e->bufs[o.in.buf];
@@ -747,6 +748,11 @@ int plan_batch(cvx_engine* e, int B, bool training) {
         q.Cin = c.cin_g;
         q.dy_ld = C;
         q.dy_bstride = (long long)o.oh * o.ow * C;
+        if (o.act == CVX_ACT_BIAS) {  // the head's output convs: dy is a slice of dpred
+          const Buf& pb = e->bufs[e->pred_buf];
+          q.dy_ld = pb.d.c;
+          q.dy_bstride = (long long)pb.d.h * pb.d.w * pb.d.c;
+        }
         q.Cout = C;
         q.B = B;
         q.OH = o.oh;
@@ -755,7 +761,11 @@ int plan_batch(cvx_engine* e, int B, bool training) {
         q.ntaps = c.ntaps;
         q.cin_pad16 = c.cin_pad16;
         q.std3x3 = c.std3x3;
-        if (!cvx_conv_wgrad_halo_supported(q) && cvx_conv_wgrad_gemm_supported(q)) {
+        if (cvx_conv_wgrad_k3_supported(q)) {
+          ws_splits = cvx_conv_wgrad_k3_nsplit(q);
+        } else if (cvx_conv_wgrad_stream_supported(q)) {
+          ws_splits = cvx_conv_wgrad_stream_nsplit(q);
+        } else if (o.act != CVX_ACT_BIAS && !cvx_conv_wgrad_halo_supported(q) && cvx_conv_wgrad_gemm_supported(q)) {
           wgg = true;
           cvx_conv_wgrad_gemm_tile(C, Jtot, &co_b, &j_b);
         }
@@ -787,6 +797,8 @@ int plan_batch(cvx_engine* e, int B, bool training) {
         probe.OW = o.ow;
         if (c.stem) {
           ns = cvx_stem_wgrad_splits(M);
+        } else if (ws_splits > 0) {
+          ns = ws_splits;
         } else if (cvx_conv_wgrad_halo_supported(probe)) {
           int gx, gy;
           cvx_conv_wgrad_halo_grid(C, c.cin_g, &gx, &gy);
@@ -2585,3 +2597,62 @@ extern "C" int cvx_conv2d_wgrad_nhwc(const void* x_f16, const void* dy_f16, int3
   (void)hipFree(dt);
   return rc;
 }
+
+#ifdef CVX_TUNING
+// Tuning build only (include/cvx_engine_experimental.h): device time of ONE weight-gradient launch (stride 1, pad k / 2) on operands with pixel
+// pitches x_ld / dy_ld, mean over `reps` launches between two HIP events after one warm-up launch; nsplit <= 0: the streaming kernel's
+// planner (1 when it does not take the shape).  The slabs are left in `workspace` (no reduction).
+extern "C" int cvx_wgrad_time_unit(const void* x_f16, const void* dy_f16, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t k,
+                                   int32_t x_ld, int32_t dy_ld, int32_t nsplit, int32_t reps, void* workspace, int64_t workspace_bytes,
+                                   float* us_out, int32_t* nsplit_out, void* hip_stream) {
+  CVX_CHECK(x_f16 && dy_f16 && workspace && us_out && reps >= 1 && (k == 1 || k == 3), "bad arguments");
+  hipStream_t st = (hipStream_t)hip_stream;
+  std::vector<ConvTap> taps;
+  for (int r = 0; r < k; ++r)
+    for (int s = 0; s < k; ++s) taps.push_back(ConvTap{r - k / 2, s - k / 2, r * k + s, 0});
+  ConvTap* dt = nullptr;
+  CVX_TRY(make_taps(taps, &dt));
+  WgradParams wp;
+  memset(&wp, 0, sizeof(wp));
+  wp.x = (const half_t*)x_f16;
+  wp.x_bstride = (long long)h * w * x_ld;
+  wp.x_ld = x_ld;
+  wp.IH = wp.OH = h;
+  wp.IW = wp.OW = w;
+  wp.Cin = cin;
+  wp.dy = (const half_t*)dy_f16;
+  wp.dy_bstride = (long long)h * w * dy_ld;
+  wp.dy_ld = dy_ld;
+  wp.Cout = cout;
+  wp.B = batch;
+  wp.stride = 1;
+  wp.ntaps = k * k;
+  wp.taps = dt;
+  wp.slabs = (float*)workspace;
+  wp.cin_pad16 = round_up(cin, 16);
+  wp.std3x3 = cvx_taps_std3x3(taps.data(), (int)taps.size());
+  wp.nsplit = nsplit > 0 ? nsplit : (cvx_conv_wgrad_k3_supported(wp) ? cvx_conv_wgrad_k3_nsplit(wp) : cvx_conv_wgrad_stream_supported(wp) ? cvx_conv_wgrad_stream_nsplit(wp) : 1);
+  if (nsplit_out) *nsplit_out = wp.nsplit;
+  int rc = 0;
+  if ((long long)wp.nsplit * cout * k * k * wp.cin_pad16 * 4 > workspace_bytes) {
+    cvx_set_error("cvx_wgrad_time_unit: workspace too small");
+    rc = -1;
+  }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (rc == 0 && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) rc = -1;
+  if (rc == 0) rc = cvx_conv_wgrad_launch(wp, st);
+  if (rc == 0) {
+    (void)hipEventRecord(e0, st);
+    for (int i = 0; i < reps && rc == 0; ++i) rc = cvx_conv_wgrad_launch(wp, st);
+    (void)hipEventRecord(e1, st);
+    if (hipEventSynchronize(e1) != hipSuccess) rc = -1;
+    float ms = 0.f;
+    if (rc == 0 && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) *us_out = ms * 1e3f / reps;
+  }
+  (void)hipStreamSynchronize(st);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(dt);
+  return rc;
+}
+#endif

@@ -32,6 +32,15 @@ int cvx_chain_detect_unit(const void* x_f16, int32_t batch, int32_t h, int32_t w
                           const float* scale_b, const float* shift_b, const void* wo1_f16, const void* wo2_f16, const float* bias, float* pred,
                           int32_t anchors, int32_t a_off, int32_t th, int32_t tw, int32_t reps, float* elapsed_us, void* hip_stream);
 
+/* ---- weight-gradient timing aid (csrc/engine.hip, -DCVX_TUNING) ------------------------------------------------------------
+ * Mean device time (us, HIP events, `reps` launches after one warm-up) of ONE weight-gradient launch of a k x k (1 or 3) / stride-1 / pad k/2
+ * convolution on NHWC fp16 operands with pixel pitches x_ld / dy_ld; the fp32 slabs stay in `workspace` (no reduction).  nsplit <= 0: the
+ * streaming kernel's own pixel-split count.  Replaces nothing in the reference: a tuning aid for the kernels behind autograd's weight
+ * gradient of nn.Conv2d (core/models/yolov8/modules.py:19-33). */
+int cvx_wgrad_time_unit(const void* x_f16, const void* dy_f16, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t k,
+                        int32_t x_ld, int32_t dy_ld, int32_t nsplit, int32_t reps, void* workspace, int64_t workspace_bytes, float* us_out,
+                        int32_t* nsplit_out, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

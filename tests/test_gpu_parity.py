@@ -146,6 +146,39 @@ def test_conv_fwd_dgrad_wgrad(dev, B, H, W, Ci, Co, k, s):
     assert rel(dw.permute(0, 3, 1, 2), wr.grad) < 1e-5
 
 
+# round 5: the fat-workgroup 3x3 kernel (conv_wgrad_k3.hip: every configuration A..F, column blocks, ragged last row block / column block, chunk
+# ranges that end inside an image, channel padding 8 -> 16 and 72 -> 80, co blocks with an empty tail) and the streaming 1x1 kernel
+# (conv_wgrad_stream.hip: K-step waves, odd ci-tile counts, ragged last chunk) -- beyond what CONV_CASES holds
+WGRAD_R05_CASES = [(2, 13, 160, 16, 16, 3), (3, 11, 80, 32, 32, 3), (2, 40, 40, 64, 64, 3), (5, 20, 20, 64, 64, 3), (2, 9, 37, 64, 64, 3), (1, 80, 80, 64, 144, 3),
+                   (2, 21, 40, 128, 144, 3), (3, 20, 20, 128, 128, 3), (2, 23, 19, 80, 80, 3), (2, 20, 20, 256, 144, 3), (3, 6, 250, 16, 16, 3),
+                   (2, 17, 29, 64, 32, 3), (2, 12, 12, 8, 16, 3), (1, 7, 7, 72, 80, 3), (2, 30, 30, 32, 24, 3),
+                   (40, 160, 160, 32, 32, 1), (36, 160, 160, 48, 32, 1), (34, 157, 163, 16, 32, 1), (33, 160, 160, 64, 16, 1)]
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,k", WGRAD_R05_CASES)
+def test_weight_gradient_kernels_of_round_5(dev, B, H, W, Ci, Co, k):
+    """cvx_conv2d_wgrad_nhwc on the shapes the two round-5 kernels take, against fp32 F.conv2d backward on the CPU (1x1 cases: a matmul
+    in fp64 -- they are 800k+ pixels because the streaming kernel only takes such layers)."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(B * 1000 + H + Ci + Co + k)
+    x16 = (torch.randn(B, H, W, Ci, generator=g) * 0.5).half()
+    dy16 = (torch.randn(B, H, W, Co, generator=g) * 0.5).half()
+    if k == 1:
+        want = (dy16.reshape(-1, Co).double().t() @ x16.reshape(-1, Ci).double()).float().reshape(Co, 1, 1, Ci)
+    else:
+        xr = x16.permute(0, 3, 1, 2).float()
+        wr = torch.zeros(Co, Ci, k, k, requires_grad=True)
+        F.conv2d(xr, wr, None, 1, k // 2).backward(dy16.permute(0, 3, 1, 2).float())
+        want = wr.grad.permute(0, 2, 3, 1)
+    st = L.stream_ptr(dev)
+    need = lib.cvx_conv2d_wgrad_workspace_bytes(B, H, W, Ci, Co, k)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    dw = torch.empty(Co, k, k, Ci, dtype=torch.float32, device=dev)
+    xd, dyd = x16.to(dev), dy16.to(dev)
+    L.check(lib.cvx_conv2d_wgrad_nhwc(L.ptr(xd), L.ptr(dyd), B, H, W, Ci, Co, k, 1, k // 2, 1, L.ptr(dw), L.ptr(ws), need, st), "wgrad")
+    assert rel(dw.cpu(), want) < 1e-5, rel(dw.cpu(), want)
+
+
 @pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 16, 24, 32, 64), (3, 20, 20, 64, 128), (1, 40, 8, 16, 32), (2, 12, 12, 128, 256), (2, 10, 14, 24, 96)])
 def test_stride2_data_gradient_as_one_pixel_shuffle_gemm(dev, B, H, W, Ci, Co):
     """cvx_conv2d_dgrad_nhwc takes the engine's route for 3x3 / stride 2 / pad 1 on even maps: the 2 x 2 window of dy as a stride-1 GEMM with
