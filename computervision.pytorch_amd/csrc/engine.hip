@@ -775,7 +775,16 @@ int plan_batch(cvx_engine* e, int B, bool training) {
       // may grow accordingly (measured on DeepLabv3+ R101: 8 -> 64 MB of slabs per layer took the step from 48.6 to 38.5 ms)
       static const long long blk_narrow = cvx_tune_int("CVX_WGRAD_BLOCKS", 2048), blk_wide = cvx_tune_int("CVX_WGRAD_BLOCKS_WIDE", 1024);
       static const long long blk_wgg_big = cvx_tune_int("CVX_WGG_BLOCKS_BIG", 256), blk_wgg = cvx_tune_int("CVX_WGG_BLOCKS", 512);
-      const long long blk_target = wgg ? (co_b == 256 ? blk_wgg_big : blk_wgg) : co_b == 128 ? blk_wide : blk_narrow;
+      // Round 5: these launches run beside the backward pass on the lowest-priority stream, and what they cost the step is the CUs their
+      // workgroups hold while a main-chain kernel waits to be placed -- not their own duration.  A small layer therefore gets
+      // only as many workgroups as its work needs (YOLOv8-n, same box: 512 -> 96 and 2048 -> 256 took 0.12 ms off the step); the big layers
+      // of the other models keep the counts that were tuned on them.
+      static const long long wgg_mflop = cvx_tune_int("CVX_WGG_MFLOP", 40), gen_mflop = cvx_tune_int("CVX_WGRAD_MFLOP", 20);
+      static const long long wgg_min = cvx_tune_int("CVX_WGG_BLOCKS_MIN", 96), gen_min = cvx_tune_int("CVX_WGRAD_BLOCKS_MIN", 256);
+      const double wflops = 2.0 * (double)M * C * c.cin_g * c.ntaps;
+      const long long wgg_by_work = std::max(wgg_min, std::min(blk_wgg, (long long)(wflops / (wgg_mflop * 1e6))));
+      const long long gen_by_work = std::max(gen_min, std::min(blk_narrow, (long long)(wflops / (gen_mflop * 1e6))));
+      const long long blk_target = wgg ? (co_b == 256 ? blk_wgg_big : wgg_by_work) : co_b == 128 ? blk_wide : gen_by_work;
       long long ns = std::min<long long>(std::max<long long>(1, M / 256), std::max<long long>(1, blk_target / tiles));
       const long long slab_elems = (long long)C * Jtot;
       static const long long cap_narrow = cvx_tune_int("CVX_SLAB_MB", 8), cap_wide = cvx_tune_int("CVX_SLAB_MB_WIDE", 64);

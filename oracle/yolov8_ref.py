@@ -199,10 +199,27 @@ def _q(t: torch.Tensor) -> torch.Tensor:
     return t.half().float() if FP16_STORAGE[0] else t
 
 
+# Layers (state_dict prefixes, e.g. "model.2.cv1") whose raw conv output the engine stores in fp16 between the convolution and its
+# normalisation pass (round 5: the large early layers, where the fp32 buffer is most of the BatchNorm traffic).  The batch statistics
+# still come from the fp32 accumulators (the conv epilogue sums them before it rounds); only the normalised VALUE starts from the
+# rounded number.  Empty: every raw output stays fp32 (rounds 2-4).
+FP16_RAW_LAYERS: set = set()
+
+
 def _unit(x, sd, p, k, s, training):
     """Conv2d(no bias, 'same' pad) -> BatchNorm -> SiLU   (modules.py:29-30)."""
     w = sd[p + ".conv.weight"]
     y = F.conv2d(x, w if p == "model.0" else _q(w), None, s, k // 2)
+    if FP16_STORAGE[0] and training and p in FP16_RAW_LAYERS:
+        mean, var = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=False)
+        n = y.numel() // y.shape[1]
+        with torch.no_grad():  # running statistics exactly as F.batch_norm updates them
+            sd[p + ".bn.running_mean"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * mean)
+            sd[p + ".bn.running_var"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * var * (n / max(n - 1, 1)))
+            sd[p + ".bn.num_batches_tracked"] += 1
+        yq = _q(y)
+        y = (yq - mean.view(1, -1, 1, 1)) * torch.rsqrt(var.view(1, -1, 1, 1) + BN_EPS) * sd[p + ".bn.weight"].view(1, -1, 1, 1) + sd[p + ".bn.bias"].view(1, -1, 1, 1)
+        return _q(F.silu(y))
     y = F.batch_norm(y, sd[p + ".bn.running_mean"], sd[p + ".bn.running_var"], sd[p + ".bn.weight"],
                      sd[p + ".bn.bias"], training, BN_MOMENTUM, BN_EPS)
     if training:
