@@ -486,7 +486,7 @@ bool k3_plan(const WgradParams& p, int nsplit, K3Plan* out, K3Shape* shape, int*
   int ns = nsplit;
   if (ns <= 0) {
     static const int one_round = cvx_tune_int("CVX_K3_ONE_ROUND", 1);
-    static const int mflop_wg = cvx_tune_int("CVX_K3_MFLOP", 80), kb_wg = cvx_tune_int("CVX_K3_KB", 768), wg_max = cvx_tune_int("CVX_K3_WGMAX", 256),
+    static const int mflop_wg = cvx_tune_int("CVX_K3_MFLOP", 60), kb_wg = cvx_tune_int("CVX_K3_KB", 576), wg_max = cvx_tune_int("CVX_K3_WGMAX", 96),
                      wg_min = cvx_tune_int("CVX_K3_WGMIN", 32);
     const double flops = 2.0 * p.B * p.OH * p.OW * 9.0 * p.Cin * p.Cout, bytes = 2.0 * p.B * p.OH * p.OW * (p.Cin + p.Cout);
     int wgs = (int)std::max(flops / (mflop_wg * 1e6), bytes / (kb_wg * 1024.0));
