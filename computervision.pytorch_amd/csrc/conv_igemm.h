@@ -192,7 +192,7 @@ int cvx_conv_wgrad_stream_nsplit(const WgradParams& p);      // the planner's pi
 int cvx_conv_wgrad_stream_launch(const WgradParams& p, hipStream_t stream);
 // fat-workgroup kernel for the 3x3 stride-1 layers with 16 ... 144 channels (conv_wgrad_k3.hip): 8 waves, a CU's whole LDS, few workgroups
 bool cvx_conv_wgrad_k3_supported(const WgradParams& p);
-int cvx_conv_wgrad_k3_nsplit(const WgradParams& p);
+int cvx_conv_wgrad_k3_nsplit(const WgradParams& p, bool wide = false);  // wide: the tail of the backward pass -- the whole chip
 int cvx_conv_wgrad_k3_launch(const WgradParams& p, hipStream_t stream);
 inline int cvx_taps_std3x3(const ConvTap* t, int n) {
   if (n != 9) return 0;

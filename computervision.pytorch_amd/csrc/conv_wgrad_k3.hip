@@ -412,7 +412,7 @@ bool k3_shape_ok(const WgradParams& p) {
 }
 
 // The plan of a launch with `nsplit` pixel splits (nsplit <= 0: the planner's own choice, returned in *nsplit_out).
-bool k3_plan(const WgradParams& p, int nsplit, K3Plan* out, K3Shape* shape, int* nsplit_out) {
+bool k3_plan(const WgradParams& p, int nsplit, K3Plan* out, K3Shape* shape, int* nsplit_out, bool wide = false) {
   if (!k3_shape_ok(p)) return false;
   const K3Shape sh = k3_pick(p);
   K3Plan a;
@@ -491,6 +491,8 @@ bool k3_plan(const WgradParams& p, int nsplit, K3Plan* out, K3Shape* shape, int*
     const double flops = 2.0 * p.B * p.OH * p.OW * 9.0 * p.Cin * p.Cout, bytes = 2.0 * p.B * p.OH * p.OW * (p.Cin + p.Cout);
     int wgs = (int)std::max(flops / (mflop_wg * 1e6), bytes / (kb_wg * 1024.0));
     wgs = std::max(wg_min, std::min(one_round ? wg_max : 4096, wgs));
+    // the last layers of the backward pass: nothing is left on the main stream to disturb, the launch is the tail of the step -- the whole chip
+    if (wide) wgs = std::max(wgs, std::min(240, (int)std::max(flops / 15e6, bytes / (128 * 1024.0))));
     ns = std::max(1, wgs / G);
     ns = std::min(ns, std::max(1, a.total_units / 2));  // at least two chunks per workgroup
     // one round: a workgroup takes a whole CU, and the launch rounds the split count up to a multiple of 8 (XCD-aware ids)
@@ -530,11 +532,11 @@ bool cvx_conv_wgrad_k3_supported(const WgradParams& p) {
 }
 
 // the planner's pixel-split count for a layer (the engine sizes the layer's slabs with it)
-int cvx_conv_wgrad_k3_nsplit(const WgradParams& p) {
+int cvx_conv_wgrad_k3_nsplit(const WgradParams& p, bool wide) {
   K3Plan a;
   K3Shape sh;
   int ns = 1;
-  if (!k3_plan(p, 0, &a, &sh, &ns)) return 1;
+  if (!k3_plan(p, 0, &a, &sh, &ns, wide)) return 1;
   return ns;
 }
 

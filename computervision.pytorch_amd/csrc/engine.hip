@@ -735,6 +735,10 @@ int plan_batch(cvx_engine* e, int B, bool training) {
       cvx_conv_wgrad_tile(C, Jtot, &co_b, &j_b);
       // the GEMM-shaped weight-gradient kernel (conv_wgrad_gemm.hip) takes the BatchNorm / bias layers with 128+ output channels: its tiles
       // and its 512-thread workgroups size the pixel splits
+      // the first conv ops are the LAST of the backward pass: their weight gradients are the tail of the step (nothing of the main chain is
+      // left to disturb) and may keep the whole-chip workgroup counts -- measured: no difference (6.16-6.23 ms for 0 ... 7 such layers), so off
+      static const int tail_convs = cvx_tune_int("CVX_WGRAD_TAIL_OPS", -1);
+      const bool tail_layer = (int)i <= tail_convs;
       bool wgg = false;
       int ws_splits = 0;  // > 0: the streaming kernel (conv_wgrad_stream.hip) takes the layer, with its planner's pixel splits
       if (!c.stem) {
@@ -762,7 +766,7 @@ int plan_batch(cvx_engine* e, int B, bool training) {
         q.cin_pad16 = c.cin_pad16;
         q.std3x3 = c.std3x3;
         if (cvx_conv_wgrad_k3_supported(q)) {
-          ws_splits = cvx_conv_wgrad_k3_nsplit(q);
+          ws_splits = cvx_conv_wgrad_k3_nsplit(q, tail_layer);
         } else if (cvx_conv_wgrad_stream_supported(q)) {
           ws_splits = cvx_conv_wgrad_stream_nsplit(q);
         } else if (o.act != CVX_ACT_BIAS && !cvx_conv_wgrad_halo_supported(q) && cvx_conv_wgrad_gemm_supported(q)) {
@@ -784,7 +788,7 @@ int plan_batch(cvx_engine* e, int B, bool training) {
       const double wflops = 2.0 * (double)M * C * c.cin_g * c.ntaps;
       const long long wgg_by_work = std::max(wgg_min, std::min(blk_wgg, (long long)(wflops / (wgg_mflop * 1e6))));
       const long long gen_by_work = std::max(gen_min, std::min(blk_narrow, (long long)(wflops / (gen_mflop * 1e6))));
-      const long long blk_target = wgg ? (co_b == 256 ? blk_wgg_big : wgg_by_work) : co_b == 128 ? blk_wide : gen_by_work;
+      const long long blk_target = wgg ? (co_b == 256 ? blk_wgg_big : tail_layer ? blk_wgg : wgg_by_work) : co_b == 128 ? blk_wide : tail_layer ? blk_narrow : gen_by_work;
       long long ns = std::min<long long>(std::max<long long>(1, M / 256), std::max<long long>(1, blk_target / tiles));
       const long long slab_elems = (long long)C * Jtot;
       static const long long cap_narrow = cvx_tune_int("CVX_SLAB_MB", 8), cap_wide = cvx_tune_int("CVX_SLAB_MB_WIDE", 64);
@@ -1772,7 +1776,7 @@ int backward_begin(cvx_engine* e, const void* dpred_f16, float loss_scale) {
   w.pending.clear();
   w.active = true;
   w.next_op = (int)e->ops.size() - 1;
-  static const int wg_batch_env = cvx_tune_int("CVX_WGRAD_BATCH", 3);
+  static const int wg_batch_env = cvx_tune_int("CVX_WGRAD_BATCH", 2);
   w.wg_batch = wg_batch_env < 1 ? 1 : wg_batch_env;
   if (!e->bwd_slabs_clean) CVX_HIP(hipMemsetAsync(e->stat_region + e->stat_half, 0, (size_t)e->stat_half * 8, st));  // (a second backward on one forward)
   e->bwd_slabs_clean = false;

@@ -44,7 +44,11 @@ def main():
     print("layers with >= 80x80 outputs at 640x640:", big)
     cases = [("128x128 b2", synth.images(2, 128, 128, seed=1)), ("96x160 b2", synth.images(2, 96, 160, seed=3)), ("320x320 b2", synth.images(2, 320, 320, seed=1)),
              ("640x640 b1", synth.images(1, 640, 640, seed=1))]
-    groups = {"none (rounds 2-4)": [], "large layers": big, "all layers": layers,
+    neck = [p for p in layers if p.startswith(("model.12.", "model.15.", "model.16", "model.18.", "model.19", "model.21."))]
+    head = [p for p in layers if p.startswith("model.22.")]
+    groups = {"none (rounds 2-4)": [], "neck + head": neck + head, "head": head, "neck": neck, "neck+head+SPPF(9)": neck + head + [p for p in layers if p.startswith("model.9.")],
+              "neck+head+8+9": neck + head + [p for p in layers if p.startswith(("model.9.", "model.8.", "model.7"))]}
+    groups_old = {"large layers": big, "all layers": layers,
               "large w/o model.1": [p for p in big if p != "model.1"], "large w/o Detect": [p for p in big if not p.startswith("model.22")],
               "only model.1+model.2": [p for p in big if p.startswith(("model.1", "model.2."))], "only Detect P3": [p for p in big if p.startswith("model.22")],
               "only model.4": [p for p in big if p.startswith("model.4.")], "only model.15": [p for p in big if p.startswith("model.15.")]}

@@ -15,7 +15,7 @@ import csv
 import json
 import sys
 
-FAMILIES = ("conv_wgrad_gemm_kernel", "conv_gemm_kernel", "gemm_pack", "conv_tile_kernel", "tile_pack", "conv_chain_kernel", "chain_pack_kernel", "bn_act_apply", "conv_halo_kernel", "conv_pw_kernel", "conv_igemm_dma_kernel", "stem_stats_kernel", "stem_apply_kernel", "stem_wgrad_kernel", "conv_wgrad_halo_kernel", "conv_wgrad_kernel", "bn_bwd_reduce",
+FAMILIES = ("conv_wgrad_k3_kernel", "conv_wgrad_stream_kernel", "conv_wgrad_gemm_kernel", "conv_gemm_kernel", "gemm_pack", "conv_tile_kernel", "tile_pack", "conv_chain_kernel", "chain_pack_kernel", "bn_act_apply", "conv_halo_kernel", "conv_pw_kernel", "conv_igemm_dma_kernel", "stem_stats_kernel", "stem_apply_kernel", "stem_wgrad_kernel", "conv_wgrad_halo_kernel", "conv_wgrad_kernel", "bn_bwd_reduce",
             "bn_bwd_apply", "bn_silu_apply", "reduce_slabs")
 CONV = ("conv_gemm_kernel", "conv_tile_kernel", "conv_chain_kernel", "conv_halo_kernel", "conv_pw_kernel", "conv_igemm_dma_kernel", "stem_stats_kernel", "stem_apply_kernel")
 
