@@ -43,6 +43,7 @@ OP_DROPOUT = 12
 ACT_BN_SILU, ACT_BIAS, ACT_BN_RELU, ACT_BN_LINEAR, ACT_BIAS_RELU, ACT_BIAS_LINEAR = 1, 2, 3, 4, 5, 6
 OPF_RES_PRE_ACT = 1
 OPF_CONV_BIAS = 2
+OPF_RAW_F16 = 4
 
 _P, _I32, _I64, _F, _U64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
 

@@ -20,6 +20,7 @@ struct BnCoef {
   const float* invstd;  // batch 1/sqrt(var+eps) of the forward pass
   const float* gamma;
   const float* beta;
+  const float* mean = nullptr;  // not null: the kept tensor is the RAW conv output y in fp16 (CVX_OPF_RAW_F16), xhat = (y - mean) * invstd on the fly
 };
 
 // training-mode forward: fixed-point statistics replicas [R][C][2][CVX_FIX_WORDS] filled by the conv epilogue (zero before it)
@@ -59,6 +60,12 @@ int cvx_bn_silu_apply(const float* y, long long M, int C, int hw, const BnTrainA
 // ResNet's relu(bn(conv) + identity); else added to the activation's output, YOLO's x + cv2(cv1(x)))
 int cvx_bn_act_apply(const float* y, long long M, int C, int hw, const BnTrainArgs& a, const ViewDesc& out, const ViewDesc& res, int act,
                      int res_pre, half_t* xhat, hipStream_t st);
+// ... of a CVX_OPF_RAW_F16 layer: y16 is the raw conv output rounded to fp16 (it stays, for the backward pass: no xhat is written); SiLU, no residual
+// debug aid (cvx_engine_debug_copy): xhat = (y16 - mean) * invstd, rounded to fp16, of a raw-fp16 layer
+// ... in fp32, exactly as the backward passes form it (mean == nullptr: `kept` IS xhat, widened)
+int cvx_kept_to_xhat_f32(const half_t* kept, long long M, int C, const float* mean, const float* invstd, float* xhat, hipStream_t st);
+int cvx_raw16_to_xhat(const half_t* y16, long long M, int C, const float* mean, const float* invstd, half_t* xhat, hipStream_t st);
+int cvx_bn_silu_apply_raw16(const half_t* y16, long long M, int C, int hw, const BnTrainArgs& a, const ViewDesc& out, hipStream_t st);
 struct BnActKind {
   int act, res_pre;
   ViewDesc fout;  // SiLU + res_pre: the residual's forward value; else unused (ReLU's mask rides in the lowest bit of xhat)

@@ -14,6 +14,7 @@
 // coefficients live in registers.  The replica slabs are zeroed once per step by the engine.
 #include "bn_common.h"
 #include <mutex>
+#include <type_traits>
 
 namespace {
 using namespace cvx_bn;
@@ -75,8 +76,14 @@ __device__ __forceinline__ float act_fwd(float z) {
 }
 
 // RES_PRE: the residual joins the pre-activation (ResNet Bottleneck: relu(bn(conv) + identity)), else it is added to the output
-template <int ACT, bool RES_PRE>
-__global__ __launch_bounds__(256) void bn_act_apply_kernel(const float* y, long long M, int C, int hw, BnTrainArgs a, ViewDesc out,
+// RAW16: y is the raw output rounded to fp16 (CVX_OPF_RAW_F16 layers): 2 instead of 4 bytes read per element, and no xhat is written -- the
+// backward passes normalise y themselves
+__device__ __forceinline__ f8 load_f8(const half_t* p) {
+  const h8 v = *reinterpret_cast<const h8*>(p);
+  return f8{f4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}, f4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]}};
+}
+template <int ACT, bool RES_PRE, bool RAW16 = false>
+__global__ __launch_bounds__(256) void bn_act_apply_kernel(const typename std::conditional<RAW16, half_t, float>::type* y, long long M, int C, int hw, BnTrainArgs a, ViewDesc out,
                                                            ViewDesc res, half_t* xhat, int rows_per_block) {
   extern __shared__ __attribute__((aligned(16))) long long ws[];  // fold workspace | mean, invstd (2*C floats)
   float* s_mu = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + fold_ws_bytes(C));
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(const float* y, long 
 #pragma unroll
       for (int i = 0; i < 8; ++i) xb[i] = (unsigned short)((xb[i] & 0xFFFEu) | ((float)o[i] > 0.f ? 1u : 0u));
     }
-    *reinterpret_cast<h8*>(xhat + m * C + cg * 8) = xh;
+    if constexpr (!RAW16) *reinterpret_cast<h8*>(xhat + m * C + cg * 8) = xh;
     *reinterpret_cast<h8*>(out.p + view_off(out, m, hw) + cg * 8) = o;
   };
   if (first) {
@@ -204,7 +211,7 @@ __device__ __forceinline__ float act_dz(float g, float xh, float ga, float be, f
   return g;
 }
 
-template <int ACT>
+template <int ACT, bool RAW = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const half_t* xhat, long long M, int C, int hw, BnCoef k, ViewDesc gout, ViewDesc fout,
                                                             long long* part, int rows_per_block) {
   __shared__ float sacc[256 * 16];
@@ -217,10 +224,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const half_t* xhat, 
   for (int i = 0; i < 8; ++i) acc[0][i] = acc[1][i] = 0.f;
   if (active) {
     Coef8 s;
+    float mu[8], is[8];  // RAW: the kept tensor is y, xhat = (y - mean) * invstd
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       s.a[i] = k.gamma[cg * 8 + i];
       s.b[i] = k.beta[cg * 8 + i];
+      if constexpr (RAW) {
+        mu[i] = k.mean[cg * 8 + i];
+        is[i] = k.invstd[cg * 8 + i];
+      }
     }
     const long long m0 = (long long)blockIdx.x * rows_per_block;
     const long long m1 = min(M, m0 + rows_per_block);
@@ -228,6 +240,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const half_t* xhat, 
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         float xh = (float)v[i];
+        if constexpr (RAW) xh = (xh - mu[i]) * is[i];
         const float fb = ACT == 1 ? (float)(reinterpret_cast<const unsigned short*>(&v)[i] & 1u) : (float)fo[i];  // ReLU: the mask bit of xhat
         float dz = act_dz<ACT>((float)g[i], xh, s.a[i], s.b[i], fb);
         acc[0][i] += dz;
@@ -259,7 +272,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const half_t* xhat, 
 
 // RES_PRE: the residual branch receives dz (the gradient of the shared pre-activation), else the incoming gradient g
 // (requesting the first trip's rows before the fold, as the forward pass does, measured SLOWER here: 64 more live registers across the fold)
-template <int ACT, bool RES_PRE>
+template <int ACT, bool RES_PRE, bool RAW = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const half_t* xhat, long long M, int C, int hw, BnCoef k, const long long* part,
                                                            float inv_scale, float* dgamma, float* dbeta, ViewDesc gout, ViewDesc fout, half_t* dy,
                                                            ViewDesc gres, int res_accumulate, int rows_per_block) {
@@ -278,7 +291,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const half_t* xhat, l
   const int cg = threadIdx.x % CG, r = threadIdx.x / CG;
   if (r >= RP) return;
   Coef8 s;
-  float k1[8], k2[8], gi[8];
+  float k1[8], k2[8], gi[8], mu[8], is[8];
   const double cnt = (double)M;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -286,7 +299,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const half_t* xhat, l
     s.b[i] = k.beta[cg * 8 + i];
     k1[i] = (float)(s0[cg * 8 + i] / cnt);
     k2[i] = (float)(s1[cg * 8 + i] / cnt);
-    gi[i] = s.a[i] * k.invstd[cg * 8 + i];
+    is[i] = k.invstd[cg * 8 + i];
+    gi[i] = s.a[i] * is[i];
+    if constexpr (RAW) mu[i] = k.mean[cg * 8 + i];
   }
   const long long m0 = (long long)blockIdx.x * rows_per_block;
   const long long m1 = min(M, m0 + rows_per_block);
@@ -295,6 +310,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const half_t* xhat, l
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       float xh = (float)v[i];
+      if constexpr (RAW) xh = (xh - mu[i]) * is[i];
       const float fb = ACT == 1 ? (float)(reinterpret_cast<const unsigned short*>(&v)[i] & 1u) : (float)fo[i];  // ReLU: the mask bit of xhat
       float dz = act_dz<ACT>((float)g[i], xh, s.a[i], s.b[i], fb);
       o[i] = (half_t)(gi[i] * (dz - k1[i] - xh * k2[i]));
@@ -691,6 +707,41 @@ int cvx_bn_act_apply(const float* y, long long M, int C, int hw, const BnTrainAr
   CVX_HIP(hipGetLastError());
   return 0;
 }
+__global__ __launch_bounds__(256) void raw16_to_xhat_kernel(const half_t* y, long long n, int C, const float* mean, const float* invstd, half_t* xhat) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const int c = (int)(i % C);
+    xhat[i] = (half_t)(((float)y[i] - mean[c]) * invstd[c]);
+  }
+}
+__global__ __launch_bounds__(256) void kept_to_xhat_f32_kernel(const half_t* y, long long n, int C, const float* mean, const float* invstd, float* xhat) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const int c = (int)(i % C);
+    xhat[i] = mean ? ((float)y[i] - mean[c]) * invstd[c] : (float)y[i];
+  }
+}
+int cvx_kept_to_xhat_f32(const half_t* kept, long long M, int C, const float* mean, const float* invstd, float* xhat, hipStream_t st) {
+  const long long n = M * C;
+  hipLaunchKernelGGL(kept_to_xhat_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, kept, n, C, mean, invstd, xhat);
+  CVX_HIP(hipGetLastError());
+  return 0;
+}
+int cvx_raw16_to_xhat(const half_t* y16, long long M, int C, const float* mean, const float* invstd, half_t* xhat, hipStream_t st) {
+  const long long n = M * C;
+  hipLaunchKernelGGL(raw16_to_xhat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y16, n, C, mean, invstd, xhat);
+  CVX_HIP(hipGetLastError());
+  return 0;
+}
+int cvx_bn_silu_apply_raw16(const half_t* y16, long long M, int C, int hw, const BnTrainArgs& a, const ViewDesc& out, hipStream_t st) {
+  CVX_TRY(check_c(C, M));
+  int rows = cvx_stream_rows_per_block(M, C, 16);
+  const dim3 grid(blocks_for(M, rows)), block(256);
+  const size_t lds = fold_ws_bytes(C) + 2 * (size_t)C * 4;
+  hipLaunchKernelGGL((bn_act_apply_kernel<0, false, true>), grid, block, lds, st, y16, M, C, hw, a, out, ViewDesc{nullptr, 0, 0}, (half_t*)nullptr, rows);
+  CVX_HIP(hipGetLastError());
+  return 0;
+}
 int cvx_bn_silu_apply(const float* y, long long M, int C, int hw, const BnTrainArgs& a, const ViewDesc& out, const ViewDesc& res,
                       half_t* xhat, hipStream_t st) {
   return cvx_bn_act_apply(y, M, C, hw, a, out, res, 0, 0, xhat, st);
@@ -707,10 +758,13 @@ int cvx_bn_bwd_reduce(const half_t* xhat, long long M, int C, int hw, const BnCo
   CVX_TRY(check_c(C, M));
   CVX_CHECK(ak.act >= 0 && ak.act <= 2, "bn_bwd: activation kind");
   CVX_CHECK(!(ak.act == 0 && ak.res_pre) || ak.fout.p, "bn_bwd: SiLU with a pre-activation residual needs the residual's forward value");
+  CVX_CHECK(!k.mean || (ak.act == 0 && !ak.res_pre), "bn_bwd: a raw-fp16 layer (BnCoef::mean) is SiLU without a pre-activation residual");
   int rows = cvx_stream_rows_per_block(M, C, 32);
   const dim3 grid(blocks_for(M, rows)), block(256);
   if (ak.act == 0 && ak.res_pre)
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<3>, grid, block, 0, st, xhat, M, C, hw, k, gout, ak.fout, part, rows);
+  else if (ak.act == 0 && k.mean)
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<0, true>), grid, block, 0, st, xhat, M, C, hw, k, gout, ak.fout, part, rows);
   else if (ak.act == 0)
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<0>, grid, block, 0, st, xhat, M, C, hw, k, gout, ak.fout, part, rows);
   else if (ak.act == 1)
@@ -725,6 +779,7 @@ int cvx_bn_bwd_apply(const half_t* xhat, long long M, int C, int hw, const BnCoe
   CVX_TRY(check_c(C, M));
   CVX_TRY(check_act(ak.act, ak.res_pre, gres.p != nullptr));
   CVX_CHECK(!(ak.act == 0 && ak.res_pre) || ak.fout.p, "bn_bwd: SiLU with a pre-activation residual needs the residual's forward value");
+  CVX_CHECK(!k.mean || (ak.act == 0 && !ak.res_pre), "bn_bwd: a raw-fp16 layer (BnCoef::mean) is SiLU without a pre-activation residual");
   int rows = cvx_stream_rows_per_block(M, C, 32);
   const dim3 grid(blocks_for(M, rows)), block(256);
   const size_t lds = fold_ws_bytes(C);
@@ -733,6 +788,9 @@ int cvx_bn_bwd_apply(const half_t* xhat, long long M, int C, int hw, const BnCoe
                      res_accumulate, rows)
   if (ak.act == 0 && ak.res_pre)
     CVX_LAUNCH_BWD(3, true);
+  else if (ak.act == 0 && k.mean)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<0, false, true>), grid, block, lds, st, xhat, M, C, hw, k, part, inv_scale, dgamma, dbeta, gout, ak.fout, dy, gres,
+                       res_accumulate, rows);
   else if (ak.act == 0)
     CVX_LAUNCH_BWD(0, false);
   else if (ak.act == 1 && ak.res_pre)

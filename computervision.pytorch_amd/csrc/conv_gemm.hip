@@ -189,7 +189,7 @@ __device__ __forceinline__ void gemm_store_raw(const ConvParams& p, const f16v (
       const int r = it * PPI + pr;
       const long long off = *reinterpret_cast<const long long*>(wreg + S::OFFS + r * 8);
       const f4 v = *reinterpret_cast<const f4*>(wreg + r * S::RS + c16 * 16);
-      if (off >= 0 && n < p.Cout) *reinterpret_cast<f4*>(p.out32 + off + n) = v;
+      if (off >= 0 && n < p.Cout) cvx_store_raw4(p, off + n, v);
     }
   }
 }

@@ -84,7 +84,16 @@ struct ConvParams {
   // of ps_cin channels each -- output channel n = (2 * ph + pw) * ps_cin + c goes to pixel (oh2 * OS + ph, ow2 * OS + pw), channel c
   // (OS = 2, oph = opw = 0).  0: off.  Served by the GEMM-shaped kernel only (plain epilogue).
   int ps_cin;
+  // RAW_STATS: 1 = the raw output goes out rounded to fp16 (out16 / out_ld / out_bstride) instead of fp32 (out32): CVX_OPF_RAW_F16 layers.
+  // The statistics are summed from the fp32 accumulators either way.
+  int raw16;
 };
+
+// RAW_STATS store of 4 consecutive channels of one pixel at element offset `off` of the raw-output tensor
+__device__ __forceinline__ void cvx_store_raw4(const ConvParams& p, long long off, const f4& v) {
+  if (p.raw16) *reinterpret_cast<h4*>(p.out16 + off) = h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+  else *reinterpret_cast<f4*>(p.out32 + off) = v;
+}
 
 // Packs a 9-entry tap table whose offsets all lie in the 3x3 neighbourhood into two 64-bit words, 4 bits per tap:
 // pos = (dh+1)*4 + (dw+1), wt = weight tap index.  Kernel arguments instead of a device table: the halo kernel reads

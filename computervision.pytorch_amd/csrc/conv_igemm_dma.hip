@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
       for (int i = 0; i < MT; ++i) {
         if (pvalid[i]) {
           if (n0 < p.Cout) {
-            *reinterpret_cast<f4*>(p.out32 + out_off[i] + n0) = acc[i][j];  // fp32, see conv_tile_common.h
+            cvx_store_raw4(p, out_off[i] + n0, acc[i][j]);  // fp32 (fp16: raw16), see conv_tile_common.h
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {

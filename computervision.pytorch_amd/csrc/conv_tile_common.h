@@ -66,7 +66,7 @@ __device__ __forceinline__ void epilogue_tile(const ConvParams& p, f4 (&acc)[MT]
       if (!pvalid[i]) continue;
       f4 v = acc[i][j];
       if (p.epi == CVX_EPI_RAW_STATS) {
-        *reinterpret_cast<f4*>(p.out32 + out_off[i] + n0) = v;  // fp32: normalisation reads the un-rounded accumulators
+        cvx_store_raw4(p, out_off[i] + n0, v);  // fp32: normalisation reads the un-rounded accumulators (fp16 for CVX_OPF_RAW_F16 layers)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           st1[j][r] += v[r];

@@ -261,10 +261,10 @@ __global__ __launch_bounds__(64 * kTileWaves) void conv_tile_kernel(const ConvPa
       const unsigned m = (unsigned)((wave * MT + i) * 16 + fr);
       const unsigned pr = __umulhi(m, a.magic_w);
       const unsigned pc = m - pr * (unsigned)W;
-      float* dst = p.out32 + (long long)b * p.out_bstride + ((long long)(y0 + (int)pr) * W + (int)pc) * p.out_ld + nblk * BN + fq * 4;
+      const long long dst = (long long)b * p.out_bstride + ((long long)(y0 + (int)pr) * W + (int)pc) * p.out_ld + nblk * BN + fq * 4;
 #pragma unroll
       for (int j = 0; j < NTW; ++j)
-        if (nblk * BN + j * 16 + fq * 4 < p.Cout) *reinterpret_cast<f4*>(dst + j * 16) = acc[i][j];
+        if (nblk * BN + j * 16 + fq * 4 < p.Cout) cvx_store_raw4(p, dst + j * 16, acc[i][j]);
     }
   } else {
   __syncthreads();  // every wave is done with the patch and the ring

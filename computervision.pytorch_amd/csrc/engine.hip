@@ -71,6 +71,7 @@ struct ConvRt {
   const half_t* ps_pk = nullptr;
   int ps_bn = 0, ps_kc = 0;
   int slab_blk0 = 0, slab_blk1 = 0;  // reducer workgroups [blk0, blk1) of this op in the slab block table
+  bool raw16 = false;                // CVX_OPF_RAW_F16 honoured: training keeps the raw output in fp16 in ybuf (no xhat, no fp32 scratch)
   bool stem = false;  // 3 -> Cout 3x3 stride-2 conv on the caller's fp32 images: stem.hip
   // per-batch
   half_t* ybuf = nullptr;   // xhat = (y - mean) * invstd of the training forward, fp16 (operand of the BN backward passes)
@@ -717,6 +718,9 @@ int plan_batch(cvx_engine* e, int B, bool training) {
       CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, M * C * 2));
       c.dybuf = (half_t*)p;
     }
+    // CVX_OPF_RAW_F16 is honoured for plain Conv + BatchNorm + SiLU layers: no residual, no bias in front of the BatchNorm, not the fp32 stem
+    static const bool raw16_off = cvx_tune_set("CVX_NO_RAW_F16");
+    c.raw16 = training && !raw16_off && (o.flags & CVX_OPF_RAW_F16) && o.act == CVX_ACT_BN_SILU && o.res.buf < 0 && !(o.flags & CVX_OPF_CONV_BIAS) && !c.stem;
     if (training && (o.act == CVX_ACT_BN_SILU || o.act == CVX_ACT_BN_RELU || o.act == CVX_ACT_BN_LINEAR)) {
       CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, M * C * 2));
       c.ybuf = (half_t*)p;
@@ -724,8 +728,8 @@ int plan_batch(cvx_engine* e, int B, bool training) {
         CVX_TRY(dev_alloc(e, e->batch_allocs, e->batch_bytes, &p, M * C * 2));
         c.dybuf = (half_t*)p;
       }
-      if (!c.stem) ytmp_elems = std::max(ytmp_elems, M * C);
-      if (e->use_lanes && o.lane >= 2) ytmp_lane_elems = std::max(ytmp_lane_elems, M * C);
+      if (!c.stem && !c.raw16) ytmp_elems = std::max(ytmp_elems, M * C);
+      if (e->use_lanes && o.lane >= 2 && !c.raw16) ytmp_lane_elems = std::max(ytmp_lane_elems, M * C);
     }
     c.stat_fwd = (long long*)nullptr + stat_floats;  // offset for now, rebased below
     stat_floats += (long long)cvx_stat_replicas(C) * C * CVX_STAT_WORDS + CVX_STAT_GATE_WORDS;  // + the gate counter of the one-launch BN backward
@@ -1438,6 +1442,22 @@ extern "C" int cvx_engine_set_seed(cvx_engine* e, uint64_t seed) {
 
 extern "C" int cvx_engine_debug_copy(cvx_engine* e, int32_t buf, int32_t which, void* dst, int64_t bytes) {
   CVX_CHECK(e && dst && buf >= 0, "bad arguments");
+  if (which == 4) {  // the normalised output as the backward passes use it, fp32: `buf` is an op index
+    CVX_CHECK(buf < (int)e->ops.size() && e->ops[buf].type == CVX_OP_CONV, "which 4: `buf` must be the index of a conv op");
+    const ConvRt& c = e->conv[buf];
+    const cvx_op_desc& o = e->ops[buf];
+    CVX_CHECK(c.ybuf && e->planned_batch > 0 && e->planned_train, "no training plan, or the op keeps no such tensor");
+    const long long M = (long long)e->planned_batch * o.oh * o.ow;
+    const int64_t want = (int64_t)M * o.out.c * 4;
+    CVX_CHECK(bytes == want, "size mismatch: the tensor holds " + std::to_string(want) + " bytes");
+    float* tmp = nullptr;
+    CVX_HIP(hipMalloc((void**)&tmp, (size_t)bytes));
+    int rc = cvx_kept_to_xhat_f32(c.ybuf, M, o.out.c, c.raw16 ? c.mean : nullptr, c.invstd, tmp, e->stream);
+    if (rc == 0 && hipMemcpyAsync(dst, tmp, (size_t)bytes, hipMemcpyDefault, e->stream) != hipSuccess) rc = -1;
+    (void)hipStreamSynchronize(e->stream);
+    (void)hipFree(tmp);
+    return rc;
+  }
   if (which == 2 || which == 3) {  // per-layer operands of the backward pass: `buf` is an op index
     CVX_CHECK(buf < (int)e->ops.size() && e->ops[buf].type == CVX_OP_CONV, "which 2/3: `buf` must be the index of a conv op");
     const ConvRt& c = e->conv[buf];
@@ -1446,6 +1466,15 @@ extern "C" int cvx_engine_debug_copy(cvx_engine* e, int32_t buf, int32_t which, 
     CVX_CHECK(src && e->planned_batch > 0 && e->planned_train, "no training plan, or the op keeps no such tensor");
     const int64_t want = (int64_t)e->planned_batch * o.oh * o.ow * o.out.c * 2;
     CVX_CHECK(bytes == want, "size mismatch: the tensor holds " + std::to_string(want) + " bytes");
+    if (which == 2 && c.raw16) {  // the layer keeps its RAW output (CVX_OPF_RAW_F16): hand out what the backward passes make of it
+      half_t* tmp = nullptr;
+      CVX_HIP(hipMalloc((void**)&tmp, (size_t)bytes));
+      int rc = cvx_raw16_to_xhat(c.ybuf, (long long)e->planned_batch * o.oh * o.ow, o.out.c, c.mean, c.invstd, tmp, e->stream);
+      if (rc == 0 && hipMemcpyAsync(dst, tmp, (size_t)bytes, hipMemcpyDefault, e->stream) != hipSuccess) rc = -1;
+      (void)hipStreamSynchronize(e->stream);
+      (void)hipFree(tmp);
+      return rc;
+    }
     CVX_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDefault, e->stream));
     return 0;
   }
@@ -1657,18 +1686,24 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
       cp.out32 = ytmp;  // raw fp32 output: lives until the normalisation pass right below, then the next layer (of this stream) reuses it
       cp.out_ld = C;
       cp.out_bstride = (long long)o.oh * o.ow * C;
+      if (c.raw16) {    // CVX_OPF_RAW_F16: rounded to fp16 straight into the tensor the backward pass keeps
+        cp.raw16 = 1;
+        cp.out32 = nullptr;
+        cp.out16 = c.ybuf;
+      }
       cp.stats = c.stat_fwd;
       cp.stats_replicas = cvx_stat_replicas(C);
       int P = 0;
       {
-        ProfScope ps(e, PROF_CONV_FWD, conv_flops(o, B), conv_bytes(o, B) + 2.0 * M * C, st);
+        ProfScope ps(e, PROF_CONV_FWD, conv_flops(o, B), conv_bytes(o, B) + (c.raw16 ? 0.0 : 2.0 * M * C), st);
         CVX_TRY(cvx_conv_igemm_launch(cp, st, &P));
       }
-      ProfScope ps(e, PROF_BN_FWD, 0, (resv.p ? 10.0 : 8.0) * M * C, st);
+      ProfScope ps(e, PROF_BN_FWD, 0, (c.raw16 ? 4.0 : resv.p ? 10.0 : 8.0) * M * C, st);
       BnTrainArgs ta{c.stat_fwd,           e->params + o.gamma_off, e->params + o.beta_off, c.mean, c.invstd, e->stats + o.rmean_off,
                      e->stats + o.rvar_off, e->bn_eps,       e->bn_momentum};
       if (o.flags & CVX_OPF_CONV_BIAS) ta.cbias = e->params + o.bias_off;  // (its gradient is exactly zero: BatchNorm removes the mean)
-      CVX_TRY(cvx_bn_act_apply(ytmp, M, C, o.oh * o.ow, ta, outv, resv, act_kind(o), (o.flags & CVX_OPF_RES_PRE_ACT) ? 1 : 0, c.ybuf, st));
+      if (c.raw16) CVX_TRY(cvx_bn_silu_apply_raw16(c.ybuf, M, C, o.oh * o.ow, ta, outv, st));
+      else CVX_TRY(cvx_bn_act_apply(ytmp, M, C, o.oh * o.ow, ta, outv, resv, act_kind(o), (o.flags & CVX_OPF_RES_PRE_ACT) ? 1 : 0, c.ybuf, st));
     } else {
       // scale / shift were folded for every layer at once before the op loop (cvx_bn_fold_all)
       cp.epi = CVX_EPI_AFFINE_SILU;
@@ -1907,7 +1942,7 @@ int backward_op(cvx_engine* e, int i) {
     } else {
       ViewDesc gout = make_view(e, o.out, true);
       ViewDesc gres = make_view(e, o.res, true);
-      BnCoef k{c.invstd, e->params + o.gamma_off, e->params + o.beta_off};
+      BnCoef k{c.invstd, e->params + o.gamma_off, e->params + o.beta_off, c.raw16 ? c.mean : nullptr};
       // SiLU with a pre-activation residual needs the residual's forward value (ReLU's mask rides in xhat's lowest bit)
       const bool pre = (o.flags & CVX_OPF_RES_PRE_ACT) != 0 && o.res.buf >= 0;
       const BnActKind ak{act_kind(o), pre ? 1 : 0, act_kind(o) == 0 && pre ? make_view(e, o.res, false) : ViewDesc{nullptr, 0, 0}};
@@ -1916,7 +1951,7 @@ int backward_op(cvx_engine* e, int i) {
       // one launch (reduce, grid gate, apply from registers) where the layer qualifies -- on the main stream only: two gated kernels side
       // by side (the Detect lanes) could keep each other's blocks off the CUs
       int one = 1;
-      if (!c.stem && st == e->stream && !tune_skip_reduce)
+      if (!c.stem && !c.raw16 && st == e->stream && !tune_skip_reduce)
         one = cvx_bn_bwd_fused(c.ybuf, M, C, hw, k, c.stat_bwd, reinterpret_cast<unsigned long long*>(c.stat_bwd + (long long)cvx_stat_replicas(C) * C * CVX_STAT_WORDS),
                                w.inv_scale, e->grads + o.gamma_off, e->grads + o.beta_off, gout, ak, c.dybuf, gres, c.res_accum, st);
       if (one < 0) return one;

@@ -152,10 +152,13 @@ class Engine:
         return out
 
     def read_layer(self, op: int, batch: int, what: str = "xhat") -> torch.Tensor:
-        """Debug: a conv op's normalised output (``xhat``) or the gradient w.r.t. its raw output (``dy``), NHWC fp16."""
+        """Debug: a conv op's normalised output (``xhat``, fp16 as kept -- or rounded from the kept raw output of a CVX_OPF_RAW_F16 layer;
+        ``xhat32``: in fp32, exactly as the backward passes use it) or the gradient w.r.t. its raw output (``dy``), NHWC."""
         o = self.graph.ops[op]
-        out = torch.empty(batch, o["oh"], o["ow"], o["out"][2], dtype=torch.float16, device=self.device)
-        L.check(self.lib.cvx_engine_debug_copy(self.handle, op, 2 if what == "xhat" else 3, L.ptr(out), out.numel() * 2), "cvx_engine_debug_copy")
+        wide = what == "xhat32"
+        out = torch.empty(batch, o["oh"], o["ow"], o["out"][2], dtype=torch.float32 if wide else torch.float16, device=self.device)
+        which = {"xhat": 2, "dy": 3, "xhat32": 4}[what]
+        L.check(self.lib.cvx_engine_debug_copy(self.handle, op, which, L.ptr(out), out.numel() * (4 if wide else 2)), "cvx_engine_debug_copy")
         return out
 
     PROFILE_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn_silu_fwd", "bn_silu_bwd", "misc", "slab_reduce")

@@ -224,6 +224,12 @@ class Graph:
         return bufs, ops
 
 
+# Convs of the top-level modules from this index on keep their raw output in fp16 during training (CVX_OPF_RAW_F16): the neck and the
+# head, 62 % of the BatchNorm elements of YOLOv8-n.  Their rounding does not reach the logits (oracle/fp16_raw_study.py: the per-level error
+# against the fp32 reference moves by <= 0.5 %), while rounding the backbone's raw outputs costs 8-19 % of it.  None: every layer fp32.
+RAW_F16_FROM = 12
+
+
 def build_yolov8_graph(lay: ParamLayout, H: int, W: int) -> Graph:
     """Buffer plan + op list for an (H, W) input (both multiples of 32)."""
     if H % 32 or W % 32:
@@ -246,6 +252,8 @@ def build_yolov8_graph(lay: ParamLayout, H: int, W: int) -> Graph:
         op["in"] = vin
         if res is not None:
             op["res"] = res
+        if s.bn and res is None and RAW_F16_FROM is not None and int(name.split(".")[0]) >= RAW_F16_FROM:
+            op["flags"] = L.OPF_RAW_F16
         g.ops.append(op)
         return ho, wo
 

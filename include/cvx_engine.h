@@ -61,6 +61,10 @@ enum { CVX_ACT_BN_SILU = 1, CVX_ACT_BIAS = 2,
        CVX_ACT_BIAS_LINEAR = 6 }; /* Conv + bias, fp16 output, no activation (SSD ExtraLayer, ssd_model.py:90-110) */
 #define CVX_OPF_RES_PRE_ACT 1 /* cvx_op_desc.flags: the residual is added before the activation (BasicBlock, :20-27) */
 #define CVX_OPF_CONV_BIAS 2   /* a BN_* conv that also has a bias of its own at bias_off (VGG-BN: Conv2d(bias=True) + BatchNorm) */
+#define CVX_OPF_RAW_F16 4     /* training: a BN_SILU conv (no residual, no bias) may keep its raw output in fp16 between the convolution and its
+                                 normalisation pass -- and keeps THAT, not the normalised value, for the backward pass: 6 instead of 12 bytes
+                                 per element around the forward BatchNorm.  The batch statistics still come from the fp32 accumulators.  For
+                                 layers whose rounding the outputs do not see (YOLOv8: the neck and the head, modules 12 .. 22) */
 
 typedef struct {
   int32_t type;
@@ -149,7 +153,8 @@ int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float loss_scale);
 /* Debug/inspection: copies activation (which=0) or gradient (which=1) buffer `buf` of the last planned
  * batch, NHWC fp16, into dst (device or host memory, `bytes` must equal batch*h*w*c*2).  which=2 / 3: `buf` is the index
  * of a conv op and the tensor is its normalised output xhat = (y-mean)*invstd / the gradient w.r.t. its raw output,
- * dense (batch, oh, ow, cout) fp16 -- the per-layer operands of the backward pass (training plans only). */
+ * dense (batch, oh, ow, cout) fp16 -- the per-layer operands of the backward pass (training plans only).   which=4: the normalised output as the backward passes USE it, fp32 (bytes = batch*h*w*c*4): the kept fp16 xhat widened, or --
+ * for a CVX_OPF_RAW_F16 layer, which keeps its raw fp16 output instead -- (y - mean) * invstd computed as they compute it. */
 int cvx_engine_debug_copy(cvx_engine* e, int32_t buf, int32_t which, void* dst, int64_t bytes);
 
 /* Segmented backward for data-parallel training: the same pass as cvx_engine_backward, cut into op ranges so that the

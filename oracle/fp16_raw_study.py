@@ -32,7 +32,7 @@ def run(sd, x, raw):
     O.FP16_RAW_LAYERS = set(raw)
     out = O.forward(copy.deepcopy(sd), x, "n", 80, True)
     O.FP16_STORAGE[0] = False
-    O.FP16_RAW_LAYERS = set()
+    O.FP16_RAW_LAYERS = None
     return out
 
 

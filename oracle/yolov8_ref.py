@@ -202,15 +202,23 @@ def _q(t: torch.Tensor) -> torch.Tensor:
 # Layers (state_dict prefixes, e.g. "model.2.cv1") whose raw conv output the engine stores in fp16 between the convolution and its
 # normalisation pass (round 5: the large early layers, where the fp32 buffer is most of the BatchNorm traffic).  The batch statistics
 # still come from the fp32 accumulators (the conv epilogue sums them before it rounds); only the normalised VALUE starts from the
-# rounded number.  Empty: every raw output stays fp32 (rounds 2-4).
-FP16_RAW_LAYERS: set = set()
+# rounded number.  None: the engine's own rule (graph.py: RAW_F16_FROM) -- every Conv of the neck and the head, top-level modules 12 .. 22,
+# whose rounding the logits do not see (oracle/fp16_raw_study.py: <= 0.5 % of the error on every level); a set overrides it (the study).
+FP16_RAW_LAYERS = None
+ENGINE_RAW_F16_FROM = 12
+
+
+def _raw_f16(p: str) -> bool:
+    if FP16_RAW_LAYERS is not None:
+        return p in FP16_RAW_LAYERS
+    return int(p.split(".")[1]) >= ENGINE_RAW_F16_FROM
 
 
 def _unit(x, sd, p, k, s, training):
     """Conv2d(no bias, 'same' pad) -> BatchNorm -> SiLU   (modules.py:29-30)."""
     w = sd[p + ".conv.weight"]
     y = F.conv2d(x, w if p == "model.0" else _q(w), None, s, k // 2)
-    if FP16_STORAGE[0] and training and p in FP16_RAW_LAYERS:
+    if FP16_STORAGE[0] and training and _raw_f16(p):
         mean, var = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=False)
         n = y.numel() // y.shape[1]
         with torch.no_grad():  # running statistics exactly as F.batch_norm updates them

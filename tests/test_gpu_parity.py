@@ -1413,7 +1413,7 @@ def test_per_layer_backward_against_fp64_on_the_engines_own_operands(dev, scale,
             continue                                      # (the stem keeps no fp16 dy: stem_bwd forms it in registers)
         cs = m.layout.convs[o["name"]]
         C = cs.cout_eng
-        xh = eng.read_layer(i, B, "xhat").double().reshape(-1, C)
+        xh = eng.read_layer(i, B, "xhat32").double().reshape(-1, C)     # (as the backward passes use it: round 5's raw-fp16 layers normalise on the fly)
         dy = eng.read_layer(i, B, "dy").double().reshape(-1, C)
         ob = o["out"]
         gout = eng.read_buffer(ob[0], B, grad=True).double().reshape(-1, eng.graph.bufs[ob[0]][2])[:, ob[1]:ob[1] + ob[2]]
