@@ -16,17 +16,19 @@ def _hardware_queue_budget():
     it loses nothing and the process becomes immune to whatever streams torch or the caller add.  Set here -- for trainers and tests as
     for bench.py -- when the HIP runtime has not been initialised yet and the process is not one rank of several (there the collective's
     stream shares the main stream's priority: bench.py explains); an explicit setting in the environment always wins."""
-    if "GPU_MAX_HW_QUEUES" in _os.environ or int(_os.environ.get("WORLD_SIZE", "1") or 1) > 1:
-        return
+    if "GPU_MAX_HW_QUEUES" in _os.environ or int(_os.environ.get("WORLD_SIZE", "1") or 1) > 1 or _os.environ.get("CVX_KEEP_HW_QUEUES"):
+        return None        # (CVX_KEEP_HW_QUEUES=1: the opt-out for hosts that manage the variable themselves)
     torch = _sys.modules.get("torch")
     if torch is not None and getattr(torch, "cuda", None) is not None and torch.cuda.is_initialized():
         _warnings.warn("computervision.pytorch_amd imported after the HIP runtime was initialised: GPU_MAX_HW_QUEUES=1 cannot be applied any "
                        "more; export it before the process starts if other libraries create HIP streams (README: hardware queues)", stacklevel=2)
-        return
+        return None
     _os.environ["GPU_MAX_HW_QUEUES"] = "1"
+    return "1"
 
 
-_hardware_queue_budget()
+# what this import set GPU_MAX_HW_QUEUES to (None: left alone -- already set by the caller, a rank of a multi-GPU job, opted out, or too late)
+HW_QUEUES_APPLIED = _hardware_queue_budget()
 
 from . import _lib  # noqa: E402
 from ._lib import CvxError, LIB_PATH  # noqa: E402

@@ -176,6 +176,9 @@ bool cvx_conv_tile_shape_ok(const ConvParams& p) {
   if (p.IS != 1 || p.OS != 1 || p.oph != 0 || p.opw != 0) return false;
   if (p.OH2 != p.IH || p.OW2 != p.IW || p.OWr != p.IW) return false;
   if (p.Cin % 8 != 0 || p.Cin < 32 || p.Cin > 512 || p.in_ld % 8 != 0) return false;
+  // the staged epilogue hands a lane 8 consecutive channels of a pixel (8 scale / shift / bias reads, one 16-byte store): output channel
+  // counts and pitches that are multiples of 4 only (36, 68: legal for cvx_conv_igemm_launch) stay on the kernels with 4-channel epilogues
+  if (p.Cout % 8 != 0 || p.out_ld % 8 != 0 || (p.res && p.res_ld % 8 != 0)) return false;
   if (p.IW > 4000 || p.IH > 4000 || p.IW < 2) return false;  // (a 1-wide map: the magic-number division needs a divisor >= 2)
   const long long extent = ((long long)(p.B - 1) * p.in_bstride + ((long long)p.IH * p.IW - 1) * p.in_ld + p.Cin) * 2;
   if (extent >= (1LL << 32) - 65536) return false;  // 32-bit buffer offsets

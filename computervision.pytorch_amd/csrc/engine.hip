@@ -2,6 +2,7 @@
 // outputs, gradient buffers, fp16 weight shadows, gradient slabs), plans the concat-free buffer
 // views and the backward write/accumulate modes once, and replays the op list on one HIP stream.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
@@ -1233,6 +1234,8 @@ hipError_t shared_stream(int device, hipStream_t AuxStreams::*which, hipStream_t
 }
 }  // namespace
 
+static std::atomic<int> g_live_engines{0};  // engines of this process: the process-global stand-alone pack caches go with the last one
+
 extern "C" int cvx_engine_create(cvx_engine** out, const cvx_buf_desc* bufs, int32_t nbufs, const cvx_op_desc* ops, int32_t nops,
                                  int32_t image_buf, int32_t pred_buf, int32_t device, void* hip_stream) {
   CVX_CHECK(out && bufs && ops && nbufs > 0 && nops > 0, "null arguments");
@@ -1333,6 +1336,7 @@ extern "C" int cvx_engine_create(cvx_engine** out, const cvx_buf_desc* bufs, int
       k += 2;
     }
   }
+  g_live_engines.fetch_add(1);
   *out = e;
   return 0;
 }
@@ -1364,8 +1368,13 @@ extern "C" int cvx_engine_destroy(cvx_engine* e) {
   }
   free_pool(e->batch_allocs);
   free_pool(e->static_allocs);
-  cvx_conv_gemm_release();  // stand-alone pack caches are keyed by weight pointers: none may outlive the arenas they point into
-  cvx_conv_tile_release();
+  // The stand-alone pack caches (unit-op entry points) are process-global and keyed by weight pointers; other live engines and concurrent
+  // unit-op callers may be using them, so they go only with the LAST engine of the process (a stale entry is harmless: a stand-alone
+  // launch re-packs its weights into the cached buffer every time, the cache only saves the allocation)
+  if (g_live_engines.fetch_sub(1) == 1) {
+    cvx_conv_gemm_release();
+    cvx_conv_tile_release();
+  }
   cvx_engine_free_bw(e);
   delete e;
   return 0;
@@ -1391,6 +1400,7 @@ extern "C" int cvx_engine_bind(cvx_engine* e, float* params, float* grads, int64
   e->stats = stats;
   e->n_params = n_params;
   e->n_stats = n_stats;
+  e->shadows_gen = -1;  // the fp16 images were made from the arena bound before: cvx_engine_keep_shadows must not vouch for them
   return 0;
 }
 
@@ -1508,7 +1518,10 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
   }
   // fp16 weight shadows: the fp32 stem does not need them, so they are prepared on the lane stream BESIDE it (33 us off the main chain); the first op after the stem waits for them
   static const int pack_lane = cvx_tune_int("CVX_PACK_LANE", 1);  // bit 0: training forward, bit 1: eval forward (measured: +0.02 ms there)
-  const bool keep = e->keep_shadows_once && e->shadows_gen == e->plan_generation && (e->shadows_train || !training);
+  bool keep = e->keep_shadows_once && e->shadows_gen == e->plan_generation && (e->shadows_train || !training);
+#ifdef CVX_WITH_CHAIN
+  if (!training && e->shadows_train && e->n_chain_jobs > 0) keep = false;  // the chain kernel's images are packed by eval forwards only
+#endif
   e->keep_shadows_once = false;
   const bool prep_beside_stem = !keep && e->lane && !e->ops.empty() && e->ops[0].type == CVX_OP_CONV && e->conv[0].stem && !e->profile &&
                                 (pack_lane & (training ? 1 : 2)) != 0;
@@ -1519,8 +1532,7 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
     prep = e->lane;
   }
   if (!keep) {
-    e->shadows_gen = e->plan_generation;
-    e->shadows_train = training;
+    e->shadows_gen = -1;  // (recorded as packed only once every pack launch below has been queued: a failed launch leaves no stale claim)
     ProfScope ps(e, PROF_MISC, 0, 6.0 * e->n_params, prep);
     CVX_TRY(cvx_pack_weights(e->params, e->shadow, e->d_pack, e->d_pack_blocks, e->n_pack_blocks, prep));
 #ifdef CVX_WITH_CHAIN
@@ -1535,6 +1547,8 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
     else
       CVX_TRY(cvx_conv_gemm_pack_jobs(e->d_gemm_jobs, e->n_gemm_fwd_jobs, e->gemm_fwd_blocks, prep));
     CVX_TRY(cvx_conv_tile_pack_jobs(e->d_tile_jobs, training ? e->n_tile_jobs : e->n_tile_fwd_jobs, training ? e->tile_blocks : e->tile_fwd_blocks, prep));
+    e->shadows_gen = e->plan_generation;  // every image of this plan is queued
+    e->shadows_train = training;
   }
   e->last_images = training ? images : nullptr;
   if (training) e->train_pass++;  // dropout masks: one per (seed, training forward, op)

@@ -292,6 +292,7 @@ class CvxComm:
     def all_reduce_(self, t: torch.Tensor, stream: Optional[torch.cuda.Stream] = None):
         st = stream or torch.cuda.current_stream(t.device)
         L.check(self._lib.cvx_allreduce_f32(L.ptr(t), t.numel(), self.handle, C.c_void_p(st.cuda_stream)), "cvx_allreduce_f32")
+        _note_param_write(t)              # a raw-pointer write torch's version counter does not see (Engine.forward: keep_shadows)
         return t
 
     def backward_exchange(self, eng, buckets, dpred: torch.Tensor, loss_scale: float):
@@ -319,21 +320,15 @@ class FusedTrainStep:
     """
 
     def __init__(self, model: Yolo8, criterion: V8DetectionLoss, optimizer: FlatAdam, process_group=None, n_buckets: int = 4,
-                 use_graph: bool = False, scaler: Optional[DynamicLossScale] = None, comm: Optional["CvxComm"] = None):
+                 scaler: Optional[DynamicLossScale] = None, comm: Optional["CvxComm"] = None):
         self.model, self.criterion, self.optimizer = model, criterion, optimizer
         self.comm = comm               # CvxComm: the exchange runs behind the C ABI (cvx_engine_backward_exchange) instead of torch.distributed
-        self.scaler = scaler           # None: static loss scale (criterion.loss_scale); hipGraph replay needs the static one
+        self.scaler = scaler           # None: static loss scale (criterion.loss_scale)
         self.pg = process_group
         self.n_buckets = n_buckets
-        self.use_graph = use_graph     # replay the whole step as one hipGraph (single-GPU; shapes and target count fixed)
-        if use_graph and os.environ.get("GPU_MAX_HW_QUEUES") == "1":
-            # measured (round 4): hipGraphLaunch of this capture -- main, weight-gradient and Detect-lane streams as parallel branches --
-            # SEGFAULTS inside the HIP runtime when it was started with one hardware queue, the package's default
-            raise L.CvxError("use_graph=True needs more than one hardware queue: replaying the multi-stream capture crashes the HIP runtime under "
-                           "GPU_MAX_HW_QUEUES=1 (the default this package sets on import).  Export GPU_MAX_HW_QUEUES=4 before the process "
-                           "starts, or run the step eagerly (the eager step under one queue is the faster of the two anyway: DESIGN.md section 6)")
-        self._graph = None
-        self._graph_key = None
+        # (Launches are eager.  The hipGraph replay of the step was removed in round 5: the multi-stream capture could not run under the
+        # package's own default of one hardware queue, measured 13.9 ms under four, and even a single-stream chain replays no faster than it
+        # launches -- profiles/r05_graph_main_chain_ab.txt.)
         self.world = 1
         self.distributed = False
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
@@ -348,40 +343,8 @@ class FusedTrainStep:
         self.found_inf = None
 
     def __call__(self, images: torch.Tensor, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
-        if self.use_graph and not self.distributed:
-            return self._graphed(images, batch)
         self.optimizer.sync_lr()
         return self._eager(images, batch)
-
-    def _graphed(self, images, batch):
-        """hipGraph replay of the step: removes ~500 host launches per step.  Inputs are copied into static buffers;
-        a new (batch, size, target-count) signature is run eagerly once (plans workspaces) and then captured."""
-        dev = self.model.flat_params.device
-        n_t = int(batch["batch_idx"].numel())
-        eng = self.model.engine_for(int(images.shape[2]), int(images.shape[3]))
-        # the graph holds raw engine buffer addresses: a re-plan (other batch size through the same engine, e.g. an eval
-        # pass or predict() between two train steps) bumps the engine's plan generation and invalidates it
-        key = (tuple(images.shape), n_t, id(eng), eng.plan_generation())
-        self.optimizer.sync_lr()
-        if key != self._graph_key:
-            self._graph = None
-            items = self._eager(images, batch)               # warm-up: allocations, attribute opt-ins, first plan
-            key = key[:3] + (eng.plan_generation(),)         # the warm-up itself may have planned
-            self._sx = images.detach().clone()
-            self._sb = {k: v.detach().to(dev).clone() for k, v in batch.items()}
-            torch.cuda.synchronize(dev)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._sitems = self._eager(self._sx, self._sb)
-            self._graph, self._graph_key = g, key
-            return items
-        self._sx.copy_(images, non_blocking=True)
-        for k, v in batch.items():
-            self._sb[k].copy_(v, non_blocking=True)
-        self._graph.replay()
-        _note_param_write(self.model.flat_params)   # the replayed Adam kernel wrote the arena behind torch's back (Engine.forward: keep_shadows)
-        self.optimizer._step += 1
-        return self._sitems.clone()                          # the static buffer is overwritten by the next replay
 
     def _eager(self, images: torch.Tensor, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         m, crit = self.model, self.criterion
@@ -393,7 +356,7 @@ class FusedTrainStep:
             self._pred = torch.empty(B, A, no, device=dev)
             self._dpred = torch.zeros(B, A, no, device=dev, dtype=torch.float16)   # the loss never writes the padding
         targets = flatten_targets(batch, dev)
-        dynamic = self.scaler is not None and not self.use_graph
+        dynamic = self.scaler is not None
         scale = self.scaler.begin_step() if dynamic else crit.loss_scale
         pred = m._run_forward(images, training=True, pred=self._pred)
         items, dpred = crit.op(pred, targets, m.level_shapes(H, W), STRIDES, scale, self._dpred)
