@@ -444,13 +444,22 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* pred, int B
 }
 
 // ---- K7 -------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* loss_part, int nblocks, const float* tss_part, int n_tss_part,
-                                                            float gain_box, float gain_cls, float gain_dfl, float* items, float* aux) {
-  __shared__ double sw[4][3];
-  const float tss_raw = block_sum_partials(tss_part, n_tss_part);
-  const float tss = fmaxf(tss_raw, 1.f);
+// 1024 threads (round 5: with 256 the one workgroup walked 16,800 x 3 partials in 66 dependent trips, 22 us of the main chain for three
+// numbers); the target-score total is summed exactly as loss_grad_kernel's blocks sum it (the first 256 threads, same order)
+__global__ __launch_bounds__(1024) void loss_finalize_kernel(const float* loss_part, int nblocks, const float* tss_part, int n_tss_part,
+                                                             float gain_box, float gain_cls, float gain_dfl, float* items, float* aux) {
+  __shared__ double sw[16][3];
+  __shared__ float st[4];
+  {
+    float v = 0.f;
+    if (threadIdx.x < 256) {
+      for (int i = threadIdx.x; i < n_tss_part; i += 256) v += tss_part[i];
+      v = cvx_wave_sum64(v);
+      if ((threadIdx.x & 63) == 0) st[threadIdx.x >> 6] = v;
+    }
+  }
   double acc[3] = {0, 0, 0};
-  for (int i = threadIdx.x; i < nblocks; i += 256)
+  for (int i = threadIdx.x; i < nblocks; i += 1024)
     for (int k = 0; k < 3; ++k) acc[k] += (double)loss_part[(long long)i * 3 + k];
   for (int k = 0; k < 3; ++k) {
     for (int o = 1; o < 64; o <<= 1) acc[k] += __shfl_xor(acc[k], o);
@@ -458,8 +467,14 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* loss_pa
   }
   __syncthreads();
   if (threadIdx.x == 0) {
+    const float tss_raw = (st[0] + st[1]) + (st[2] + st[3]);
+    const float tss = fmaxf(tss_raw, 1.f);
     const float gains[3] = {gain_box, gain_cls, gain_dfl};
-    for (int k = 0; k < 3; ++k) items[k] = (float)((sw[0][k] + sw[1][k] + sw[2][k] + sw[3][k]) / (double)tss) * gains[k];
+    for (int k = 0; k < 3; ++k) {
+      double t = 0;
+      for (int w = 0; w < 16; ++w) t += sw[w][k];
+      items[k] = (float)(t / (double)tss) * gains[k];
+    }
     if (aux) aux[0] = tss_raw;
   }
 }
@@ -573,7 +588,7 @@ extern "C" int cvx_loss_v8_strided(const float* pred, int32_t pred_ld, int32_t B
   hipLaunchKernelGGL(tal_norm_kernel, dim3(n_tss), dim3(256), 0, st, BA, A, w.gt_idx, w.metric, w.pos_align, w.pos_ov, w.norm, w.tss_part);
   hipLaunchKernelGGL(loss_grad_kernel, dim3(n_lb), dim3(256), 0, st, pred, B, A, no, nc, L, w.pbox, w.gtbox, w.gtlabel, w.gt_idx, w.norm,
                      w.tss_part, n_tss, gain_box, gain_cls, gain_dfl, loss_scale, dpred, w.loss_part);
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, w.loss_part, n_lb, w.tss_part, n_tss, gain_box, gain_cls, gain_dfl,
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, st, w.loss_part, n_lb, w.tss_part, n_tss, gain_box, gain_cls, gain_dfl,
                      loss_items, w.aux);
   CVX_HIP(hipGetLastError());
   return 0;
