@@ -224,10 +224,16 @@ class Graph:
         return bufs, ops
 
 
-# Convs of the top-level modules from this index on keep their raw output in fp16 during training (CVX_OPF_RAW_F16): the neck and the
-# head, 62 % of the BatchNorm elements of YOLOv8-n.  Their rounding does not reach the logits (oracle/fp16_raw_study.py: the per-level error
-# against the fp32 reference moves by <= 0.5 %), while rounding the backbone's raw outputs costs 8-19 % of it.  None: every layer fp32.
+# Which convs keep their raw output in fp16 during training (CVX_OPF_RAW_F16: 6 instead of 12 bytes per element around the forward BatchNorm):
+# * every Conv of the neck and the head (top-level modules 12 .. 22, 62 % of the BatchNorm elements of YOLOv8-n): their rounding does not
+#   reach the logits (oracle/fp16_raw_study.py: the per-level error against the fp32 reference moves by <= 0.5 %);
+# * backbone Convs outside the Bottlenecks whose output is at least 80 x 80 per image -- where the bytes are (at 640 x 640: 1, 2.cv1, 2.cv2,
+#   3, 4.cv1, 4.cv2; 0.13 G elements at batch 32).  Each of those costs 2-6 % of the logits' error (P5 6.98e-4 -> 8.1e-4 at 640 x 640, 7.6e-4 -> 8.3e-4 at 320 x 320, under the 9e-4 line
+#   the round set); the backbone layers below 80 x 80 would add as much again for a tenth of the bytes and stay fp32, and so does everything at
+#   the small shapes of the fixtures (128 x 128, 96 x 160), whose P5 statistics over 32-45 samples leave no margin.
+# Layers with a residual input and the fp32 stem never take the flag.  None / 0 switch a rule off.
 RAW_F16_FROM = 12
+RAW_F16_MIN_PIXELS = 80 * 80
 
 
 def build_yolov8_graph(lay: ParamLayout, H: int, W: int) -> Graph:
@@ -252,7 +258,8 @@ def build_yolov8_graph(lay: ParamLayout, H: int, W: int) -> Graph:
         op["in"] = vin
         if res is not None:
             op["res"] = res
-        if s.bn and res is None and RAW_F16_FROM is not None and int(name.split(".")[0]) >= RAW_F16_FROM:
+        if s.bn and res is None and name != "0" and ((RAW_F16_FROM is not None and int(name.split(".")[0]) >= RAW_F16_FROM) or
+                                                     (RAW_F16_MIN_PIXELS and ".m" not in name and ho * wo >= RAW_F16_MIN_PIXELS)):
             op["flags"] = L.OPF_RAW_F16
         g.ops.append(op)
         return ho, wo

@@ -200,25 +200,29 @@ def _q(t: torch.Tensor) -> torch.Tensor:
 
 
 # Layers (state_dict prefixes, e.g. "model.2.cv1") whose raw conv output the engine stores in fp16 between the convolution and its
-# normalisation pass (round 5: the large early layers, where the fp32 buffer is most of the BatchNorm traffic).  The batch statistics
-# still come from the fp32 accumulators (the conv epilogue sums them before it rounds); only the normalised VALUE starts from the
-# rounded number.  None: the engine's own rule (graph.py: RAW_F16_FROM) -- every Conv of the neck and the head, top-level modules 12 .. 22,
-# whose rounding the logits do not see (oracle/fp16_raw_study.py: <= 0.5 % of the error on every level); a set overrides it (the study).
+# normalisation pass.  The batch statistics still come from the fp32 accumulators (the conv epilogue sums them before it rounds); only the
+# normalised VALUE starts from the rounded number.  None: the engine's own rule (graph.py: RAW_F16_FROM, RAW_F16_MIN_PIXELS) -- every Conv of
+# the neck and the head (top-level modules 12 .. 22), plus the backbone's Convs outside the Bottlenecks with outputs of at least 80 x 80 per
+# image; never the stem.  A set overrides the rule (oracle/fp16_raw_study.py).
 FP16_RAW_LAYERS = None
 ENGINE_RAW_F16_FROM = 12
+ENGINE_RAW_F16_MIN_PIXELS = 80 * 80
 
 
-def _raw_f16(p: str) -> bool:
+def _raw_f16(p: str, pixels: int) -> bool:
     if FP16_RAW_LAYERS is not None:
         return p in FP16_RAW_LAYERS
-    return int(p.split(".")[1]) >= ENGINE_RAW_F16_FROM
+    part = p.split(".")
+    if int(part[1]) >= ENGINE_RAW_F16_FROM:
+        return True
+    return p != "model.0" and "m" not in part[2:] and pixels >= ENGINE_RAW_F16_MIN_PIXELS   # (not the Bottlenecks' convs)
 
 
 def _unit(x, sd, p, k, s, training):
     """Conv2d(no bias, 'same' pad) -> BatchNorm -> SiLU   (modules.py:29-30)."""
     w = sd[p + ".conv.weight"]
     y = F.conv2d(x, w if p == "model.0" else _q(w), None, s, k // 2)
-    if FP16_STORAGE[0] and training and _raw_f16(p):
+    if FP16_STORAGE[0] and training and _raw_f16(p, y.shape[2] * y.shape[3]):
         mean, var = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=False)
         n = y.numel() // y.shape[1]
         with torch.no_grad():  # running statistics exactly as F.batch_norm updates them
