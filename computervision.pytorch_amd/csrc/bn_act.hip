@@ -22,6 +22,9 @@ using namespace cvx_bn;
 #ifndef CVX_BN_UNR
 #define CVX_BN_UNR 4
 #endif
+#ifndef CVX_BN_RAW_MULT
+#define CVX_BN_RAW_MULT 1
+#endif
 constexpr int UNR = CVX_BN_UNR;  // rows in flight per thread in the streaming passes
 
 // eval: fold running stats into per-channel scale/shift for the conv epilogue
@@ -78,10 +81,8 @@ __device__ __forceinline__ float act_fwd(float z) {
 // RES_PRE: the residual joins the pre-activation (ResNet Bottleneck: relu(bn(conv) + identity)), else it is added to the output
 // RAW16: y is the raw output rounded to fp16 (CVX_OPF_RAW_F16 layers): 2 instead of 4 bytes read per element, and no xhat is written -- the
 // backward passes normalise y themselves
-__device__ __forceinline__ f8 load_f8(const half_t* p) {
-  const h8 v = *reinterpret_cast<const h8*>(p);
-  return f8{f4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}, f4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]}};
-}
+__device__ __forceinline__ f8 load_row(const float* p) { return load_f8(p); }
+__device__ __forceinline__ h8 load_row(const half_t* p) { return *reinterpret_cast<const h8*>(p); }
 template <int ACT, bool RES_PRE, bool RAW16 = false>
 __global__ __launch_bounds__(256) void bn_act_apply_kernel(const typename std::conditional<RAW16, half_t, float>::type* y, long long M, int C, int hw, BnTrainArgs a, ViewDesc out,
                                                            ViewDesc res, half_t* xhat, int rows_per_block) {
@@ -95,11 +96,15 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(const typename std::c
   const long long m0 = (long long)blockIdx.x * rows_per_block;
   const long long m1 = min(M, m0 + rows_per_block);
   long long m = m0 + r;
+  // rows in flight per thread.  A RAW16 row is 16 bytes per thread instead of 32, but more rows do not pay: CVX_BN_RAW_MULT 1 / 2 / 4 ->
+  // 5.911 / 5.933 / 5.938 ms per step, same box (round 5)
+  constexpr int RIF = RAW16 ? CVX_BN_RAW_MULT * UNR : UNR;
+  using YV = typename std::conditional<RAW16, h8, f8>::type;  // a row as loaded: converted where it is used
   // The first trip's rows and the coefficients are requested BEFORE the statistics are folded: the fold (slab reads, LDS atomics, three
   // barriers, fp64 conversion) is 2-3 us of every block's life that the rows' memory latency now runs under.
-  const bool first = active && m + (long long)(UNR - 1) * RP < m1;
-  f8 v0[UNR];
-  h8 rr0[UNR] = {};
+  const bool first = active && m + (long long)(RIF - 1) * RP < m1;
+  YV v0[RIF];
+  h8 rr0[RIF] = {};
   float ga[8], be[8];
   if (active) {
 #pragma unroll
@@ -110,8 +115,8 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(const typename std::c
   }
   if (first) {
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      v0[u] = load_f8(y + (m + u * RP) * C + cg * 8);
+    for (int u = 0; u < RIF; ++u) {
+      v0[u] = load_row(y + (m + u * RP) * C + cg * 8);
       if (res.p) rr0[u] = *reinterpret_cast<const h8*>(res.p + view_off(res, m + u * RP, hw) + cg * 8);
     }
   }
@@ -139,12 +144,12 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(const typename std::c
     mu[i] = s_mu[cg * 8 + i];
     is[i] = s_is[cg * 8 + i];
   }
-  auto one = [&](long long m, const f8& v, const h8& rr) {
+  auto one = [&](long long m, const YV& v, const h8& rr) {
     float f[8];
     h8 xh;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const float x = (v[i] - mu[i]) * is[i];
+      const float x = ((float)v[i] - mu[i]) * is[i];
       xh[i] = (half_t)x;
       if constexpr (RES_PRE)
         f[i] = act_fwd<ACT>(x * ga[i] + be[i] + (float)rr[i]);
@@ -170,23 +175,23 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(const typename std::c
   };
   if (first) {
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) one(m + u * RP, v0[u], rr0[u]);
-    m += (long long)UNR * RP;
+    for (int u = 0; u < RIF; ++u) one(m + u * RP, v0[u], rr0[u]);
+    m += (long long)RIF * RP;
   }
-  // UNR rows per trip with every load issued before the first use: the passes are latency-bound otherwise
-  for (; m + (long long)(UNR - 1) * RP < m1; m += (long long)UNR * RP) {
-    f8 v[UNR];
-    h8 rr[UNR] = {};
+  // RIF rows per trip with every load issued before the first use: the passes are latency-bound otherwise
+  for (; m + (long long)(RIF - 1) * RP < m1; m += (long long)RIF * RP) {
+    YV v[RIF];
+    h8 rr[RIF] = {};
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      v[u] = load_f8(y + (m + u * RP) * C + cg * 8);
+    for (int u = 0; u < RIF; ++u) {
+      v[u] = load_row(y + (m + u * RP) * C + cg * 8);
       if (res.p) rr[u] = *reinterpret_cast<const h8*>(res.p + view_off(res, m + u * RP, hw) + cg * 8);
     }
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) one(m + u * RP, v[u], rr[u]);
+    for (int u = 0; u < RIF; ++u) one(m + u * RP, v[u], rr[u]);
   }
   for (; m < m1; m += RP) {
-    f8 v = load_f8(y + m * C + cg * 8);
+    YV v = load_row(y + m * C + cg * 8);
     h8 rr = {};
     if (res.p) rr = *reinterpret_cast<const h8*>(res.p + view_off(res, m, hw) + cg * 8);
     one(m, v, rr);

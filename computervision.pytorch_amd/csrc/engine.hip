@@ -1980,6 +1980,57 @@ int backward_op(cvx_engine* e, int i) {
     }
     // dy of this layer is complete here; the side stream learns it through an event, recorded once per `w.wg_batch`
     // layers (a marker packet between two main-chain kernels costs ~5 us, see flush_wgrads below)
+    // ---- weight gradient -> fp32 slabs (queued for the side stream) ----
+    auto queue_wgrad = [&]() -> int {
+      ViewDesc xin = c.stem ? ViewDesc{nullptr, 0, 0} : make_view(e, o.in, false);
+      WgradParams wp;
+      memset(&wp, 0, sizeof(wp));
+      wp.x = xin.p;
+      wp.x_bstride = xin.bstride;
+      wp.x_ld = xin.ld;
+      wp.IH = o.ih;
+      wp.IW = o.iw;
+      wp.Cin = c.cin_g;
+      wp.dy = dyv.p;
+      wp.dy_bstride = dyv.bstride;
+      wp.dy_ld = dyv.ld;
+      wp.Cout = C;
+      wp.B = B;
+      wp.OH = o.oh;
+      wp.OW = o.ow;
+      wp.stride = o.stride;
+      wp.ntaps = c.ntaps;
+      wp.taps = c.taps_fwd;
+      wp.slabs = e->slabs + c.slab_off;
+      wp.nsplit = c.nsplit;
+      wp.cin_pad16 = c.cin_pad16;
+      wp.std3x3 = c.std3x3;
+      PendingWgrad pw{wp, c.stem, StemParams{}, ViewDesc{nullptr, 0, 0}, BnCoef{nullptr, nullptr, nullptr}, nullptr, 0.f, nullptr, nullptr,
+                      conv_flops(o, B), conv_bytes(o, B) + 4.0 * c.nsplit * C * c.ntaps * c.cin_pad16, i};
+      if (c.stem) {
+        const Buf& ib = e->bufs[e->image_buf];
+        CVX_CHECK(e->last_images, "the stem's weight gradient needs the images of the training forward");
+        pw.sp = StemParams{e->last_images, B, ib.d.h, ib.d.w, o.oh, o.ow, e->params + o.w_off, C};
+        pw.bytes = 12.0 * B * ib.d.h * ib.d.w + 4.0 * M * C + 4.0 * c.nsplit * C * 144;
+        pw.wp.dy = c.ybuf;  // xhat
+        pw.gout = make_view(e, o.out, true);
+        pw.coef = BnCoef{c.invstd, e->params + o.gamma_off, e->params + o.beta_off};
+        pw.part = c.stat_bwd;
+        pw.inv_scale = w.inv_scale;
+        pw.dgamma = e->grads + o.gamma_off;
+        pw.dbeta = e->grads + o.beta_off;
+      }
+      w.pending.push_back(pw);
+      // batches of wg_batch layers share one event record -- except at the end of the pass: the last layers' weight
+      // gradients are the largest and form the tail of the step, they start the moment their dy exists
+      if ((int)w.pending.size() >= w.wg_batch || i <= e->slab_tail_op || e->slab_tail_op < 0) CVX_TRY(flush_wgrads(e, c.ev_dy, st));
+      return 0;
+    };
+    // The weight gradient needs dy only: for the layers of the step's tail it is queued BEFORE the layer's data gradient, so that it
+    // starts beside it instead of behind it (the last layers' weight gradients are the largest and nothing follows them to hide behind).
+    static const int wgrad_early = cvx_tune_int("CVX_WGRAD_EARLY", 1);  // 0: never, 1: the tail layers, 2: every layer
+    const bool wgrad_first = !c.stem && (wgrad_early >= 2 || (wgrad_early == 1 && e->slab_tail_op >= 0 && i <= e->slab_tail_op));
+    if (wgrad_first) CVX_TRY(queue_wgrad());
     // ---- data gradient: dx = dy (*) W^T, one launch per output phase of the forward stride ----
     if (o.needs_dgrad) {
       ViewDesc gin = make_view(e, o.in, true);
@@ -2068,51 +2119,7 @@ int backward_op(cvx_engine* e, int i) {
         CVX_TRY(cvx_conv_igemm_launch(cp, st, nullptr));
       }
     }
-    // ---- weight gradient -> fp32 slabs ----
-    {
-      ViewDesc xin = c.stem ? ViewDesc{nullptr, 0, 0} : make_view(e, o.in, false);
-      WgradParams wp;
-      memset(&wp, 0, sizeof(wp));
-      wp.x = xin.p;
-      wp.x_bstride = xin.bstride;
-      wp.x_ld = xin.ld;
-      wp.IH = o.ih;
-      wp.IW = o.iw;
-      wp.Cin = c.cin_g;
-      wp.dy = dyv.p;
-      wp.dy_bstride = dyv.bstride;
-      wp.dy_ld = dyv.ld;
-      wp.Cout = C;
-      wp.B = B;
-      wp.OH = o.oh;
-      wp.OW = o.ow;
-      wp.stride = o.stride;
-      wp.ntaps = c.ntaps;
-      wp.taps = c.taps_fwd;
-      wp.slabs = e->slabs + c.slab_off;
-      wp.nsplit = c.nsplit;
-      wp.cin_pad16 = c.cin_pad16;
-      wp.std3x3 = c.std3x3;
-      PendingWgrad pw{wp, c.stem, StemParams{}, ViewDesc{nullptr, 0, 0}, BnCoef{nullptr, nullptr, nullptr}, nullptr, 0.f, nullptr, nullptr,
-                      conv_flops(o, B), conv_bytes(o, B) + 4.0 * c.nsplit * C * c.ntaps * c.cin_pad16, i};
-      if (c.stem) {
-        const Buf& ib = e->bufs[e->image_buf];
-        CVX_CHECK(e->last_images, "the stem's weight gradient needs the images of the training forward");
-        pw.sp = StemParams{e->last_images, B, ib.d.h, ib.d.w, o.oh, o.ow, e->params + o.w_off, C};
-        pw.bytes = 12.0 * B * ib.d.h * ib.d.w + 4.0 * M * C + 4.0 * c.nsplit * C * 144;
-        pw.wp.dy = c.ybuf;  // xhat
-        pw.gout = make_view(e, o.out, true);
-        pw.coef = BnCoef{c.invstd, e->params + o.gamma_off, e->params + o.beta_off};
-        pw.part = c.stat_bwd;
-        pw.inv_scale = w.inv_scale;
-        pw.dgamma = e->grads + o.gamma_off;
-        pw.dbeta = e->grads + o.beta_off;
-      }
-      w.pending.push_back(pw);
-      // batches of wg_batch layers share one event record -- except at the end of the pass: the last layers' weight
-      // gradients are the largest and form the tail of the step, they start the moment their dy exists
-      if ((int)w.pending.size() >= w.wg_batch || i <= e->slab_tail_op || e->slab_tail_op < 0) CVX_TRY(flush_wgrads(e, c.ev_dy, st));
-    }
+    if (!wgrad_first) CVX_TRY(queue_wgrad());
   return 0;
 }
 
