@@ -389,6 +389,174 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const StemParams p, long 
     }
 }
 
+// ---- the same fused backward on the matrix cores (round 5) ---------------------------------------------------------------
+// dW[co][tap] = sum over pixels of dy[co][pixel] * window[pixel][tap] is a [16 x pixels] . [pixels x 27] product: v_mfma_f32_16x16x4_f32 takes four
+// pixels per instruction (fp32 operands, products and sums: the arithmetic of the VALU kernel above in another order), two N tiles
+// cover the 27 taps.  What the VALU kernel spent its time on is gone: 108 FMAs per pixel and wave, window reads once per wave (here one
+// ds_read_b32 per lane and N tile), 8-byte strided loads of xhat / gout (here the tile's rows come in by LDS-DMA, 1 KiB per instruction,
+// the next tile's while this one is being multiplied).
+//   workgroup = 4 waves, one 8 x 32 tile of output pixels at a time (grid-stride), wave w owns tile rows 2w, 2w + 1 = 16 steps of 4 pixels;
+//   lane (g = lane / 16, m = lane % 16): A operand = dy of channel m at the step's pixel g (formed in registers from xhat / gout as the
+//   VALU kernel forms it, rounded to fp16 once), B operand = the window value of tap n = m (N tile 0) / 16 + m (N tile 1) at that pixel;
+//   LDS per stage: window [3][17 rows][72] fp32 from column 2*ox0 - 4 on (16-byte chunks: whole chunks are in or out of the image; out
+//   of range = zero fill by the buffer bounds check), xhat and gout tiles [8][32][16 channels] fp16.  Two stages.
+constexpr int SM_TH = 8, SM_TW = 32, SM_WR = 2 * SM_TH + 1, SM_P = 72, SM_PL = SM_WR * SM_P + 16;  // row pitch / plane pitch (floats)
+constexpr int SM_WIN_CHUNKS = 16 * 64;                                                             // 16 DMA instructions of 64 chunks (3 * SM_PL / 4 = 930 used)
+constexpr int SM_STAGE_BYTES = SM_WIN_CHUNKS * 16 + 2 * SM_TH * SM_TW * 32;
+static_assert(3 * SM_PL / 4 <= SM_WIN_CHUNKS, "window chunks");
+
+typedef __attribute__((address_space(3))) void* stem_lds_ptr;
+
+__global__ __launch_bounds__(256) void stem_bwd_mfma_kernel(const StemParams p, long long M, const half_t* xhat, ViewDesc gout, BnCoef k,
+                                                            const long long* part, float inv_scale, float* dgamma, float* dbeta, float* slabs,
+                                                            int tiles_x, int tiles_y, int total_tiles) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) long long ws[];  // fold workspace | 5 x Cout coefficients | 2 stages
+  float* sG = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + fold_ws_bytes(p.Cout));
+  float* sB = sG + p.Cout;
+  float* sK1 = sB + p.Cout;
+  float* sK2 = sK1 + p.Cout;
+  float* sGi = sK2 + p.Cout;
+  unsigned char* stage0 = reinterpret_cast<unsigned char*>(reinterpret_cast<uintptr_t>(sGi + p.Cout + 3) & ~(uintptr_t)15);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int g = lane >> 4, m = lane & 15;
+  const int co0 = blockIdx.y * 16;
+  const long long plane = (long long)p.H * p.W;
+
+  const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.img), (short)0, (int)(unsigned)((long long)p.B * 3 * plane * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_xh = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(xhat), (short)0, (int)(unsigned)(M * p.Cout * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(gout.p, (short)0, (int)(unsigned)((long long)p.B * gout.bstride * 2), 0x00020000);
+
+  // per-lane DMA tables: window instruction q = 4 * j + wave (j = 0..3) -> chunk q * 64 + lane of the stage's window area
+  int w_rel[4], w_r[4], w_j[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int chunk = (4 * j + wave) * 64 + lane;
+    const int ci = chunk / (SM_PL / 4), rem = chunk - ci * (SM_PL / 4);
+    const int r = rem / (SM_P / 4), cj = rem - r * (SM_P / 4);
+    const bool used = ci < 3 && r < SM_WR && cj < 17;
+    w_r[j] = used ? r : -100000;  // (never in range)
+    w_j[j] = cj;
+    w_rel[j] = (int)((ci * (long long)p.H + (r - 1)) * p.W + (4 * cj - 4)) * 4;
+  }
+  // xhat / gout: instruction = tile row 2 * wave + j (j = 0, 1), lane -> pixel lane / 2, 16-byte half lane % 2
+  const int t_px = lane >> 1, t_half = lane & 1;
+
+  auto issue = [&](int tile, unsigned char* st) {
+    const int tx = tile % tiles_x;
+    const int t2 = tile / tiles_x;
+    const int ty = t2 % tiles_y;
+    const int b = t2 / tiles_y;
+    const int oy0 = ty * SM_TH, ox0 = tx * SM_TW;
+    const unsigned base = (unsigned)((((long long)b * 3 * p.H + 2 * oy0) * p.W + 2 * ox0) * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int iy = 2 * oy0 - 1 + w_r[j], ix = 2 * ox0 - 4 + 4 * w_j[j];
+      const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const unsigned vo = ok ? base + (unsigned)w_rel[j] : 0xffffffffu;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_img, (stem_lds_ptr)(st + (4 * j + wave) * 1024), 16, vo, 0, 0, 0);
+    }
+    unsigned char* sx = st + SM_WIN_CHUNKS * 16;
+    unsigned char* sg = sx + SM_TH * SM_TW * 32;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = 2 * wave + j;
+      const int oy = oy0 + row, ox = ox0 + t_px;
+      const bool ok = oy < p.OH && ox < p.OW;
+      const long long pix = (long long)oy * p.OW + ox;
+      const unsigned vx = ok ? (unsigned)((((long long)b * p.OH * p.OW + pix) * p.Cout + co0) * 2 + t_half * 16) : 0xffffffffu;
+      const unsigned vg = ok ? (unsigned)(((long long)b * gout.bstride + pix * gout.ld + co0) * 2 + t_half * 16) : 0xffffffffu;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_xh, (stem_lds_ptr)(sx + row * 1024), 16, vx, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (stem_lds_ptr)(sg + row * 1024), 16, vg, 0, 0, 0);
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < total_tiles) issue(tile, stage0);  // in flight while the statistics are folded
+
+  fold_replicas(part, p.Cout, ws);
+  {
+    const double* s0 = reinterpret_cast<const double*>(ws);
+    const double* s1 = s0 + p.Cout;
+    const double cnt = (double)M;
+    for (int c = threadIdx.x; c < p.Cout; c += 256) {
+      const float gm = k.gamma[c];
+      sG[c] = gm;
+      sB[c] = k.beta[c];
+      sK1[c] = (float)(s0[c] / cnt);
+      sK2[c] = (float)(s1[c] / cnt);
+      sGi[c] = gm * k.invstd[c];
+      if (blockIdx.x == 0 && blockIdx.y == 0) {
+        dgamma[c] += (float)(s1[c] * inv_scale);
+        dbeta[c] += (float)(s0[c] * inv_scale);
+      }
+    }
+  }
+  __syncthreads();
+  const float ga = sG[co0 + m], be = sB[co0 + m], k1 = sK1[co0 + m], k2 = sK2[co0 + m], gi = sGi[co0 + m];
+
+  // B operand: tap n of N tile t is k = 16 t + m = (kh * 3 + kw) * 3 + ci (k >= 27: a padding column, never stored)
+  int boff[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int kk = min(16 * t + m, KT - 1);
+    const int ci = kk % 3, kw = (kk / 3) % 3, kh = kk / 9;
+    // window column of output column c, tap kw: 2 * (ox0 + c) + kw - 1 - (2 * ox0 - 4) = 2 c + kw + 3; row of tile row r, tap kh: 2 r + kh
+    boff[t] = (ci * SM_PL + (4 * wave + kh) * SM_P + kw + 3 + 2 * g) * 4;
+  }
+  const int aoff = (2 * wave * SM_TW + g) * 32 + m * 2;
+
+  f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  int cur = 0;
+  for (; tile < total_tiles; tile += gridDim.x) {
+    unsigned char* st = stage0 + cur * SM_STAGE_BYTES;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // this tile has landed for every wave, and every wave is done with the other stage
+    asm volatile("" ::: "memory");
+    if (tile + (int)gridDim.x < total_tiles) issue(tile + gridDim.x, stage0 + (cur ^ 1) * SM_STAGE_BYTES);
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y;
+    const int oy0 = ty * SM_TH + 2 * wave, ox0 = tx * SM_TW + g;
+    const unsigned char* sw = st;
+    const unsigned char* sx = st + SM_WIN_CHUNKS * 16 + aoff;
+    const unsigned char* sg = sx + SM_TH * SM_TW * 32;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int row = s >> 3, c4 = (s & 7) * 4;  // tile row 2 * wave + row, column c4 + g
+      const float xv = (float)*reinterpret_cast<const half_t*>(sx + s * 128);
+      const float gv = (float)*reinterpret_cast<const half_t*>(sg + s * 128);
+      const float b0 = *reinterpret_cast<const float*>(sw + boff[0] + (row * 2 * SM_P + 2 * c4) * 4);
+      const float b1 = *reinterpret_cast<const float*>(sw + boff[1] + (row * 2 * SM_P + 2 * c4) * 4);
+      const bool ok = oy0 + row < p.OH && ox0 + c4 < p.OW;
+      const float dz = gv * cvx_silu_grad(xv * ga + be);
+      const float dy = ok ? (float)(half_t)(gi * (dz - k1 - xv * k2)) : 0.f;  // rounded to fp16 once, as bn_bwd_apply stores it
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dy, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dy, b1, acc1, 0, 0, 0);
+    }
+    cur ^= 1;
+  }
+  // the four waves' partial blocks -> one slab per workgroup: D row 4 g + i = channel, column m = tap within the N tile
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(stage0);  // [wave][2 tiles][4 i][64 lanes]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    red[((wave * 2 + 0) * 4 + i) * 64 + lane] = acc0[i];
+    red[((wave * 2 + 1) * 4 + i) * 64 + lane] = acc1[i];
+  }
+  __syncthreads();
+  float* slab = slabs + (long long)blockIdx.x * p.Cout * 144;
+  for (int e = threadIdx.x; e < 512; e += 256) {
+    const int l = e & 63, i = (e >> 6) & 3, t = e >> 8;
+    const int kk = 16 * t + (l & 15), co = 4 * (l >> 4) + i;
+    if (kk < KT) {
+      const int q = (t * 4 + i) * 64 + l;
+      const float v = ((red[q] + red[q + 512]) + red[q + 1024]) + red[q + 1536];
+      slab[(co0 + co) * 144 + (kk / 3) * 16 + (kk % 3)] = v;
+    }
+  }
+#endif
+}
+
 int stem_grid(long long M, int per_block) {
   long long blocks = (M + per_block - 1) / per_block;
   const long long cap = 256 * 8;  // persistent: grid-stride over the pixels, 8 workgroups per CU at most
@@ -452,7 +620,10 @@ int cvx_stem_apply_eval(const StemParams& p, const float* scale, const float* sh
   return launch_apply<false>(p, none, scale, shift, out, nullptr, st);
 }
 
-int cvx_stem_wgrad_splits(long long M) { return stem_grid(M, 64 * 16) < 512 ? stem_grid(M, 64 * 16) : 512; }
+int cvx_stem_wgrad_splits(long long M) {
+  static const int cap = cvx_tune_int("CVX_STEM_SPLITS", 512);
+  return stem_grid(M, 64 * 16) < cap ? stem_grid(M, 64 * 16) : cap;
+}
 
 int cvx_stem_wgrad(const StemParams& p, const half_t* dy, float* slabs, int nsplit, hipStream_t st) {
   CVX_TRY(check(p));
@@ -470,6 +641,19 @@ int cvx_stem_backward(const StemParams& p, const half_t* xhat, const ViewDesc& g
   CVX_CHECK(xhat && gout.p && part && dgamma && dbeta && slabs && nsplit == cvx_stem_wgrad_splits(M), "stem backward: bad arguments");
   CVX_CHECK(gout.ld % 4 == 0 && ((uintptr_t)gout.p % 8) == 0, "stem backward: gradient view alignment");
   const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + 7) / 8;
+  // the matrix-core kernel moves 16-byte pieces: image rows and the two gradient-side tensors must be 16-byte granular and within a buffer
+  // descriptor's 4 GiB
+  static const bool mfma_on = cvx_tune_int("CVX_STEM_BWD_MFMA", 1) != 0;
+  const bool mfma_ok = mfma_on && p.W % 4 == 0 && ((uintptr_t)p.img % 16) == 0 && ((uintptr_t)xhat % 16) == 0 && ((uintptr_t)gout.p % 16) == 0 &&
+                       gout.ld % 8 == 0 && gout.bstride % 8 == 0 && (long long)p.B * 3 * p.H * p.W * 4 < (1LL << 32) && M * p.Cout * 2 < (1LL << 32) &&
+                       (long long)p.B * gout.bstride * 2 < (1LL << 32);
+  if (mfma_ok) {
+    const int lds_m = fold_ws_bytes(p.Cout) + 5 * p.Cout * 4 + 32 + 2 * SM_STAGE_BYTES;
+    hipLaunchKernelGGL(stem_bwd_mfma_kernel, dim3(nsplit, p.Cout / 16), dim3(256), lds_m, st, p, M, xhat, gout, k, part, inv_scale, dgamma, dbeta,
+                       slabs, tiles_x, tiles_y, tiles_x * tiles_y * p.B);
+    CVX_HIP(hipGetLastError());
+    return 0;
+  }
   const int lds = fold_ws_bytes(p.Cout) + 5 * p.Cout * 4 + 3 * 17 * 66 * 4;
   hipLaunchKernelGGL(stem_bwd_kernel, dim3(nsplit, p.Cout / 16), dim3(256), lds, st, p, M, xhat, gout, k, part, inv_scale, dgamma, dbeta, slabs,
                      tiles_x, tiles_y, tiles_x * tiles_y * p.B);
