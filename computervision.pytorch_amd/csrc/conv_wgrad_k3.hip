@@ -44,6 +44,7 @@ struct K3Plan {
   int upi, total_units, units_per_split;  // chunks per image, in all, per pixel split
   int n_co_blk, n_ci_blk;
   int lds_bytes;
+  int s2, PP, IW, IH;        // stride 2: the x image is FOUR phase planes of PP padded pixels each (see the kernel); the input map
   unsigned m_wp;             // ceil(2^32 / Wp)
   unsigned long long* clk;   // tuning aid (cvx_debug_clock_buffer): thread 0 of every workgroup stores 100 MHz stamps, 8 slots each
 };
@@ -148,6 +149,20 @@ __global__ __launch_bounds__(64 * C::NW) void conv_wgrad_k3_kernel(const WgradPa
       const int t = u / upp, v = u - t * upp;
       const int f = (t >> C::X_SH) & C::X_MASK;
       const int ch = ci0 + ((((v >> 1) ^ f) << 1) | (v & 1)) * 8;
+      if (a.s2) {
+        // Stride 2: input pixel (2 r + kh - 1, 2 c + kw - 1) of output pixel (r, c).  The x image holds the input's four phase planes
+        // (row parity py, column parity px), each in the dy image's padded linear space: plane pixel (rr, colp) = input pixel
+        // (2 (y0 - 1 + rr) + py, 2 (c0 - 2 + colp) + px).  Inside a plane a tap is a constant offset again (xB below), and a K-step is 32
+        // consecutive plane pixels.  Tags: row / column relative to input pixel (2 y0 - 2, 2 c0 - 4).
+        const int pi = t / a.PP, tt = t - pi * a.PP;
+        const int rr = (int)__umulhi((unsigned)tt, a.m_wp), colp = tt - rr * Wp;
+        const int py = pi >> 1, px = pi & 1;
+        if (ch < p.Cin && pi < 4 && rr <= a.R && colp >= 1 && colp <= a.Wc + 1) {
+          prel[k] = (unsigned)((((2 * rr - 2 + py) * a.IW + (2 * colp - 4 + px)) * p.x_ld + ch) * 2);
+          ptag[k] = (unsigned)((2 * rr + py) | ((2 * colp + px) << 8));
+        }
+        continue;
+      }
       const int tt = t - 1;  // (pixel 0 of the x image is slack: tap (-1, -1) of padded pixel 0)
       const int rr = tt >= 0 ? (int)__umulhi((unsigned)tt, a.m_wp) : 0, colp = tt - rr * Wp;
       if (ch < p.Cin && tt >= 0 && rr < a.R + 2) {
@@ -177,6 +192,13 @@ __global__ __launch_bounds__(64 * C::NW) void conv_wgrad_k3_kernel(const WgradPa
     q.x_rhi = std::min(a.R + 2, a.H - y0 + 1);
     q.x_clo = c0 == 0 ? 1 : 0;
     q.x_chi = std::min(a.Wc + 2, W - c0 + 1);
+    if (a.s2) {
+      q.x_org = (unsigned)(((long long)ib * p.x_bstride + ((long long)(2 * y0) * a.IW + 2 * c0) * p.x_ld) * 2);
+      q.x_rlo = std::max(0, 2 - 2 * y0);
+      q.x_rhi = std::min(2 * a.R + 2, a.IH - 2 * y0 + 2);
+      q.x_clo = std::max(0, 4 - 2 * c0);
+      q.x_chi = std::min(2 * a.Wc + 4, a.IW - 2 * c0 + 4);
+    }
     if (++icb == a.ncb) {
       icb = 0;
       if (++irb * a.R >= a.H) {
@@ -237,7 +259,11 @@ __global__ __launch_bounds__(64 * C::NW) void conv_wgrad_k3_kernel(const WgradPa
       int jt = jj * C::WN + wn;  // column tile -> (tap, ci tile); the surplus ones repeat the last valid tile (computed, not stored)
       jt = jt < C::NJ ? jt : C::NJ - 1;
       const int tap = jt / C::CI_T, cit = jt - tap * C::CI_T;
-      const int shift = (tap / 3) * Wp + (tap - (tap / 3) * 3);  // (dh + 1) * Wp + dw + 1
+      int shift = (tap / 3) * Wp + (tap - (tap / 3) * 3);  // (dh + 1) * Wp + dw + 1
+      if (a.s2) {  // plane of the tap's parities, one row down for kh >= 1, one column right for kw >= 1
+        const int kh = tap / 3, kw = tap - kh * 3;
+        shift = ((kh == 1 ? 0 : 2) + (kw == 1 ? 0 : 1)) * a.PP + (kh == 0 ? 0 : Wp) + (kw == 0 ? 0 : 1);
+      }
       const int pix = 4 * kg + rr + shift;
       const int f = (pix >> C::X_SH) & C::X_MASK;
       xB[jj] = lds0 + x_off + (unsigned)(32 * PX * wk + pix * PX + ((cit ^ f) << 5) + cc * 8);
@@ -384,27 +410,37 @@ typedef K3Cfg<4, 4, 2, 4, 1> CfgC;  // 64 -> 64 blocks     : 2 co halves x 36 co
 typedef K3Cfg<3, 5, 1, 8, 1> CfgD;  // 80 -> 80            : co blocks of 48 (the 5 x 6 tile of the whole layer spills), 45 column tiles over 8 waves (3 x 6)
 typedef K3Cfg<3, 4, 1, 8, 1> CfgE;  // 48-channel co blocks x 64-channel ci blocks (64 / 128 / 256 -> 144)          (3 x 5)
 typedef K3Cfg<2, 4, 1, 8, 1> CfgF;  // 32-channel co blocks x 64-channel ci blocks (64 -> 32 ...)                   (2 x 5)
+typedef K3Cfg<2, 1, 1, 4, 2> CfgG;  // 16 -> 32 (stride 2: model.1)                                                     (2 x 3)
+typedef K3Cfg<4, 2, 2, 4, 1> CfgH;  // 32 -> 64 (stride 2: model.3)                                                     (2 x 5)
 
 struct K3Shape {
-  int co_t, ci_t, wk, cfg;
+  int co_t, ci_t, wk, cfg, nw;
 };
 
 // which configuration serves a layer (cfg < 0: none)
 K3Shape k3_pick(const WgradParams& p) {
   const int ct = (p.Cout + 15) / 16, it = p.cin_pad16 / 16;
-  if (ct == 1 && it == 1) return {1, 1, 2, 0};
-  if (ct == 2 && it == 2) return {2, 2, 2, 1};
-  if (ct == 5 && it == 5) return {3, 5, 1, 3};
-  if (ct % 4 == 0 && it % 4 == 0) return {4, 4, 1, 2};
-  if (ct % 3 == 0 && it % 4 == 0) return {3, 4, 1, 4};
-  if (ct == 2 && it % 4 == 0) return {2, 4, 1, 5};
-  return {0, 0, 0, -1};
+  if (p.stride == 2) {  // the large early layers only: four phase planes of a 64-channel x image do not fit a slot
+    static const bool s2_off = cvx_tune_set("CVX_K3_NO_S2");
+    if (s2_off) return {0, 0, 0, -1, 0};
+    if (ct == 2 && it == 1) return {2, 1, 2, 6, 8};
+    if (ct == 4 && it == 2) return {4, 2, 1, 7, 8};
+    return {0, 0, 0, -1, 0};
+  }
+  if (ct == 1 && it == 1) return {1, 1, 2, 0, 6};
+  if (ct == 2 && it == 2) return {2, 2, 2, 1, 8};
+  if (ct == 5 && it == 5) return {3, 5, 1, 3, 8};
+  if (ct % 4 == 0 && it % 4 == 0) return {4, 4, 1, 2, 8};
+  if (ct % 3 == 0 && it % 4 == 0) return {3, 4, 1, 4, 8};
+  if (ct == 2 && it % 4 == 0) return {2, 4, 1, 5, 8};
+  return {0, 0, 0, -1, 0};
 }
 
 unsigned k3_magic(int d) { return (unsigned)((0x100000000ULL + (unsigned long long)d - 1) / (unsigned long long)d); }
 
 bool k3_shape_ok(const WgradParams& p) {
-  if (!(p.std3x3 && p.ntaps == 9 && p.stride == 1 && p.IH == p.OH && p.IW == p.OW)) return false;
+  if (!(p.std3x3 && p.ntaps == 9)) return false;
+  if (!((p.stride == 1 && p.IH == p.OH && p.IW == p.OW) || (p.stride == 2 && p.OH == (p.IH - 1) / 2 + 1 && p.OW == (p.IW - 1) / 2 + 1))) return false;
   if (p.Cin % 8 || p.Cout % 8 || p.x_ld % 8 || p.dy_ld % 8 || p.Cin < 8) return false;
   if ((long long)p.B * p.x_bstride * 2 >= (1LL << 32) || (long long)p.B * p.dy_bstride * 2 >= (1LL << 32)) return false;
   if (p.OW < 4 || p.OH > 250) return false;
@@ -420,7 +456,11 @@ bool k3_plan(const WgradParams& p, int nsplit, K3Plan* out, K3Shape* shape, int*
   static const int force_r = cvx_tune_int("CVX_K3_R", 0), force_ns = cvx_tune_int("CVX_K3_NSLOT", 0), force_wc = cvx_tune_int("CVX_K3_WC", 0);
   static const int lds_kb = cvx_tune_int("CVX_K3_LDS_KB", 152);
   const int budget = lds_kb * 1024;
-  const int PD = sh.co_t * 32, PX = sh.ci_t * 32, NW = sh.cfg == 0 ? 6 : 8;
+  const int PD = sh.co_t * 32, PX = sh.ci_t * 32, NW = sh.nw;
+  const bool s2 = p.stride == 2;
+  a.s2 = s2 ? 1 : 0;
+  a.IW = p.IW;
+  a.IH = p.IH;
   const int QD = 32 * K3_KSW * sh.wk;  // K3Cfg::QD
   a.W = p.OW;
   a.H = p.OH;
@@ -435,6 +475,10 @@ bool k3_plan(const WgradParams& p, int nsplit, K3Plan* out, K3Shape* shape, int*
     a.Wp = Wc + 2;
     a.ncb = cvx_cdiv(p.OW, Wc);
     a.Tx = QD + 2 * a.Wp + 2;
+    if (s2) {  // every plane covers the pixels a K-step can reach: QD + one row + one column (all of it is written by every chunk's DMA)
+      a.PP = QD + a.Wp + 2;
+      a.Tx = 4 * a.PP;
+    }
     a.d_pieces = cvx_cdiv((long long)QD * PD, 1024);
     a.x_pieces = cvx_cdiv((long long)a.Tx * PX, 1024);
     a.slot_bytes = (a.d_pieces + a.x_pieces) * 1024;
@@ -446,11 +490,12 @@ bool k3_plan(const WgradParams& p, int nsplit, K3Plan* out, K3Shape* shape, int*
   for (int parts = 1; parts <= 16; ++parts) {
     const int Wc = cvx_cdiv(p.OW, parts);
     if (Wc < 6) break;
-    if (Wc > 250 || Wc + 2 > QD || (force_wc && Wc != force_wc)) continue;
+    if (Wc > (s2 ? 124 : 250) || Wc + 2 > QD || (force_wc && Wc != force_wc)) continue;
     const int R = std::min(p.OH, QD / (Wc + 2));
     if (R < 1 || (force_r && R != force_r)) continue;
     geom(R, Wc);
     if ((long long)((R + 2) * p.OW) * p.x_ld * 2 >= (1LL << 31) || (long long)(R * p.OW) * p.dy_ld * 2 >= (1LL << 31)) continue;
+    if (s2 && ((long long)((2 * R + 4) * p.IW) * p.x_ld * 2 >= (1LL << 31) || 2 * R + 2 > 255)) continue;
     if (a.d_pieces + a.x_pieces > K3_MAXP * NW) continue;
     const int pw = cvx_cdiv(a.d_pieces + a.x_pieces, NW);
     int ns = 0;
@@ -465,7 +510,9 @@ bool k3_plan(const WgradParams& p, int nsplit, K3Plan* out, K3Shape* shape, int*
     const double useful = (double)p.OH * p.OW / a.upi;  // useful pixels per chunk, averaged over an image
     const double kpad = (double)QD / useful;
     const double fill = (double)a.slot_bytes / (useful * (PD + PX));
-    const double cost = (0.65 * kpad + 0.35 * fill) * (ns >= 3 ? 1.0 : 1.12);
+    double cost = (0.65 * kpad + 0.35 * fill) * (ns >= 3 ? 1.0 : 1.12);
+    // stride 2: what the cut costs is the input halo it re-reads ((2 R + 2) x (2 Wc + 2) input pixels for 2 R x 2 Wc) beside the padded K-steps
+    if (s2) cost = 0.5 * kpad + 0.5 * ((2.0 * R + 2) * (2.0 * Wc + 2)) / (4.0 * R * Wc);
     if (!found || cost < best) {
       found = true;
       best = cost;
@@ -488,7 +535,7 @@ bool k3_plan(const WgradParams& p, int nsplit, K3Plan* out, K3Shape* shape, int*
     static const int one_round = cvx_tune_int("CVX_K3_ONE_ROUND", 1);
     static const int mflop_wg = cvx_tune_int("CVX_K3_MFLOP", 60), kb_wg = cvx_tune_int("CVX_K3_KB", 576), wg_max = cvx_tune_int("CVX_K3_WGMAX", 96),
                      wg_min = cvx_tune_int("CVX_K3_WGMIN", 32);
-    const double flops = 2.0 * p.B * p.OH * p.OW * 9.0 * p.Cin * p.Cout, bytes = 2.0 * p.B * p.OH * p.OW * (p.Cin + p.Cout);
+    const double flops = 2.0 * p.B * p.OH * p.OW * 9.0 * p.Cin * p.Cout, bytes = 2.0 * p.B * p.OH * p.OW * ((s2 ? 4.0 : 1.0) * p.Cin + p.Cout);
     int wgs = (int)std::max(flops / (mflop_wg * 1e6), bytes / (kb_wg * 1024.0));
     wgs = std::max(wg_min, std::min(one_round ? wg_max : 4096, wgs));
     // the last layers of the backward pass: nothing is left on the main stream to disturb, the launch is the tail of the step -- the whole chip
@@ -554,6 +601,8 @@ int cvx_conv_wgrad_k3_launch(const WgradParams& p, hipStream_t st) {
     case 3: return launch_k3<CfgD>(p, a, st);
     case 4: return launch_k3<CfgE>(p, a, st);
     case 5: return launch_k3<CfgF>(p, a, st);
+    case 6: return launch_k3<CfgG>(p, a, st);
+    case 7: return launch_k3<CfgH>(p, a, st);
   }
   CVX_FAIL("wgrad k3: no kernel for the planned tile");
 }

@@ -214,6 +214,29 @@ def test_weight_gradient_kernels_of_round_5(dev, B, H, W, Ci, Co, k):
     assert rel(dw.cpu(), want) < 1e-5, rel(dw.cpu(), want)
 
 
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 64, 64, 16, 32), (3, 36, 320, 16, 32), (2, 50, 38, 16, 32), (1, 25, 31, 16, 32), (2, 80, 80, 32, 64), (3, 22, 160, 32, 64),
+                                         (2, 33, 47, 32, 64), (5, 8, 8, 16, 32), (1, 6, 250, 32, 64)])
+def test_stride2_weight_gradient_in_phase_planes(dev, B, H, W, Ci, Co):
+    """conv_wgrad_k3.hip on 3x3 / stride 2 / pad 1 (model.1: 16 -> 32, model.3: 32 -> 64): the input's four phase planes side by side in LDS,
+    every tap a constant offset inside one plane.  Even and odd maps (the last input row / column is then read by kh, kw = 1 only), maps
+    wide enough for several column blocks, maps smaller than one chunk; against fp32 F.conv2d backward on the CPU."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(B * 1000 + H + W + Ci)
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    x16 = (torch.randn(B, H, W, Ci, generator=g) * 0.5).half()
+    dy16 = (torch.randn(B, OH, OW, Co, generator=g) * 0.5).half()
+    wr = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    F.conv2d(x16.permute(0, 3, 1, 2).float(), wr, None, 2, 1).backward(dy16.permute(0, 3, 1, 2).float())
+    want = wr.grad.permute(0, 2, 3, 1)
+    st = L.stream_ptr(dev)
+    need = lib.cvx_conv2d_wgrad_workspace_bytes(B, OH, OW, Ci, Co, 3)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    dw = torch.empty(Co, 3, 3, Ci, dtype=torch.float32, device=dev)
+    xd, dyd = x16.to(dev), dy16.to(dev)
+    L.check(lib.cvx_conv2d_wgrad_nhwc(L.ptr(xd), L.ptr(dyd), B, H, W, Ci, Co, 3, 2, 1, 1, L.ptr(dw), L.ptr(ws), need, st), "wgrad stride 2")
+    assert rel(dw.cpu(), want) < 1e-5, rel(dw.cpu(), want)
+
+
 @pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 16, 24, 32, 64), (3, 20, 20, 64, 128), (1, 40, 8, 16, 32), (2, 12, 12, 128, 256), (2, 10, 14, 24, 96)])
 def test_stride2_data_gradient_as_one_pixel_shuffle_gemm(dev, B, H, W, Ci, Co):
     """cvx_conv2d_dgrad_nhwc takes the engine's route for 3x3 / stride 2 / pad 1 on even maps: the 2 x 2 window of dy as a stride-1 GEMM with
