@@ -163,19 +163,21 @@ __global__ void pred_prep_kernel(const float* pred, int B, int A, int no, Levels
 }
 
 // ---- K2: one block per target -----------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tal_metric_kernel(const float* pred, int A, int no, int nc, Levels L, const float* pbox, const float* gtbox,
+// (one target per block, TAL_TPB threads: the block's life is a chain of short scans over the 8400 anchors -- 96 blocks of 256 threads took 53 us)
+constexpr int TAL_TPB = 1024;
+__global__ __launch_bounds__(TAL_TPB) void tal_metric_kernel(const float* pred, int A, int no, int nc, Levels L, const float* pbox, const float* gtbox,
                                                          const int* gtlabel, const int* gtb, const int* gtvalid, float* ov, float* metric,
                                                          uint8_t* mask) {
   extern __shared__ float smet[];  // A floats
-  __shared__ float rv[4];
-  __shared__ int ri[4];
+  __shared__ float rv[TAL_TPB / 64];
+  __shared__ int ri[TAL_TPB / 64];
   const int n = blockIdx.x;
   const int b = gtb[n];
   const bool valid = gtvalid[n] != 0;
   const float gx1 = gtbox[n * 4], gy1 = gtbox[n * 4 + 1], gx2 = gtbox[n * 4 + 2], gy2 = gtbox[n * 4 + 3];
   int label = gtlabel[n];
   label = min(max(label, 0), nc - 1);
-  for (int a = threadIdx.x; a < A; a += 256) {
+  for (int a = threadIdx.x; a < A; a += TAL_TPB) {
     float ax, ay, st;
     anchor_of(L, a, &ax, &ay, &st);
     float px = ax * st, py = ay * st;
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256) void tal_metric_kernel(const float* pred, int 
   for (int r = 0; r < TOPK; ++r) {
     float best = 0.f;
     int bi = 0x7fffffff;
-    for (int a = threadIdx.x; a < A; a += 256) {
+    for (int a = threadIdx.x; a < A; a += TAL_TPB) {
       float m = smet[a];
       if (m > best) {  // strided ascending scan: first (lowest) index wins ties inside a thread
         best = m;
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(256) void tal_metric_kernel(const float* pred, int 
     float fb = rv[0];
     int fi = ri[0];
 #pragma unroll
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < TAL_TPB / 64; ++w)
       if (rv[w] > fb || (rv[w] == fb && ri[w] < fi)) {
         fb = rv[w];
         fi = ri[w];
@@ -259,13 +261,13 @@ __global__ void tal_resolve_kernel(int B, int A, const int* img_start, const int
 }
 
 // ---- K4: one block per target -----------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tal_posmax_kernel(int A, const int* gtb, const int* gt_idx, const float* ov, const float* metric,
+__global__ __launch_bounds__(TAL_TPB) void tal_posmax_kernel(int A, const int* gtb, const int* gt_idx, const float* ov, const float* metric,
                                                          float* pos_align, float* pos_ov) {
-  __shared__ float sa[4], so[4];
+  __shared__ float sa[TAL_TPB / 64], so[TAL_TPB / 64];
   const int n = blockIdx.x;
   const int b = gtb[n];
   float ma = 0.f, mo = 0.f;
-  for (int a = threadIdx.x; a < A; a += 256) {
+  for (int a = threadIdx.x; a < A; a += TAL_TPB) {
     if (gt_idx[(long long)b * A + a] == n) {
       ma = fmaxf(ma, metric[(long long)n * A + a]);
       mo = fmaxf(mo, ov[(long long)n * A + a]);
@@ -279,8 +281,14 @@ __global__ __launch_bounds__(256) void tal_posmax_kernel(int A, const int* gtb, 
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    pos_align[n] = fmaxf(fmaxf(sa[0], sa[1]), fmaxf(sa[2], sa[3]));
-    pos_ov[n] = fmaxf(fmaxf(so[0], so[1]), fmaxf(so[2], so[3]));
+    float fa = sa[0], fo = so[0];
+#pragma unroll
+    for (int w = 1; w < TAL_TPB / 64; ++w) {
+      fa = fmaxf(fa, sa[w]);
+      fo = fmaxf(fo, so[w]);
+    }
+    pos_align[n] = fa;
+    pos_ov[n] = fo;
   }
 }
 
@@ -579,12 +587,12 @@ extern "C" int cvx_loss_v8_strided(const float* pred, int32_t pred_ld, int32_t B
     hipLaunchKernelGGL(tgt_prep_kernel, dim3(cvx_cdiv(N, 128)), dim3(128), 0, st, targets, N, B, img_w, img_h, w.gtbox, w.gtlabel, w.gtb,
                        w.gtvalid, w.img_start, w.img_end);
     hipLaunchKernelGGL(pred_prep_kernel, dim3(cvx_cdiv(BA * 4, 256)), dim3(256), 0, st, pred, B, A, no, L, w.pbox);
-    hipLaunchKernelGGL(tal_metric_kernel, dim3(N), dim3(256), (size_t)A * 4, st, pred, A, no, nc, L, w.pbox, w.gtbox, w.gtlabel, w.gtb,
+    hipLaunchKernelGGL(tal_metric_kernel, dim3(N), dim3(TAL_TPB), (size_t)A * 4, st, pred, A, no, nc, L, w.pbox, w.gtbox, w.gtlabel, w.gtb,
                        w.gtvalid, w.ov, w.metric, w.mask);
   }
   hipLaunchKernelGGL(tal_resolve_kernel, dim3(cvx_cdiv(BA, 256)), dim3(256), 0, st, B, A, w.img_start, w.img_end, w.ov, w.mask, w.gt_idx);
   if (N > 0)
-    hipLaunchKernelGGL(tal_posmax_kernel, dim3(N), dim3(256), 0, st, A, w.gtb, w.gt_idx, w.ov, w.metric, w.pos_align, w.pos_ov);
+    hipLaunchKernelGGL(tal_posmax_kernel, dim3(N), dim3(TAL_TPB), 0, st, A, w.gtb, w.gt_idx, w.ov, w.metric, w.pos_align, w.pos_ov);
   hipLaunchKernelGGL(tal_norm_kernel, dim3(n_tss), dim3(256), 0, st, BA, A, w.gt_idx, w.metric, w.pos_align, w.pos_ov, w.norm, w.tss_part);
   hipLaunchKernelGGL(loss_grad_kernel, dim3(n_lb), dim3(256), 0, st, pred, B, A, no, nc, L, w.pbox, w.gtbox, w.gtlabel, w.gt_idx, w.norm,
                      w.tss_part, n_tss, gain_box, gain_cls, gain_dfl, loss_scale, dpred, w.loss_part);
