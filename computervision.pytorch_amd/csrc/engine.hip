@@ -2138,11 +2138,11 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
   static const int chunk_convs = cvx_tune_int("CVX_SLAB_CHUNK", 6);
   double slab_bytes = 0;
   int chunk_hi = -1, in_chunk = 0;  // conv ops [i, chunk_hi] whose slabs are not reduced yet
-  auto reduce_chunk = [&](int lo, int hi, bool first) -> int {
+  auto reduce_chunk = [&](int lo, int hi, bool first, hipStream_t on) -> int {
     const int blk0 = e->conv[lo].slab_blk0, blk1 = e->conv[hi].slab_blk1;
     if (blk1 <= blk0) return 0;
-    ProfScope ps(e, PROF_SLAB_REDUCE, 0, first ? slab_bytes + 8.0 * e->n_params : 0.0, rs);
-    return cvx_reduce_slabs(e->slabs, e->grads, inv_scale, e->d_slab, e->d_slab_blocks + blk0, blk1 - blk0, rs);
+    ProfScope ps(e, PROF_SLAB_REDUCE, 0, first ? slab_bytes + 8.0 * e->n_params : 0.0, on);
+    return cvx_reduce_slabs(e->slabs, e->grads, inv_scale, e->d_slab, e->d_slab_blocks + blk0, blk1 - blk0, on);
   };
   for (size_t i = 0; i < e->ops.size(); ++i)
     if (e->ops[i].type == CVX_OP_CONV) slab_bytes += 4.0 * e->conv[i].nsplit * e->ops[i].out.c * e->conv[i].ntaps * e->conv[i].cin_pad16;
@@ -2159,7 +2159,7 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
         CVX_HIP(hipEventRecord(e->ev_mid, e->side));
         CVX_HIP(hipStreamWaitEvent(rs, e->ev_mid, 0));
       }
-      CVX_TRY(reduce_chunk(i, chunk_hi, first));
+      CVX_TRY(reduce_chunk(i, chunk_hi, first, rs));
       first = false;
       chunk_hi = -1;
       in_chunk = 0;
@@ -2169,13 +2169,27 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
   CVX_TRY(join_lane(e));
   CVX_TRY(flush_wgrads(e, e->ev_fork, st));  // (non-conv first ops: nothing pending in practice)
   e->cur_op = -1;
+  // The last, small chunk holds the stem's slabs, which the MAIN stream has just produced (cvx_stem_backward), and the first layers' weight
+  // gradients, long finished on the side stream by then: it is reduced on the main stream -- one cross-stream hop (side -> main) in the
+  // step's tail instead of two (main -> side -> main).
+  static const bool tail_on_main = cvx_tune_int("CVX_TAIL_REDUCE_MAIN", 1) != 0;
+  if (tail_on_main) {
+    CVX_HIP(hipEventRecord(e->ev_red, rs));        // everything queued on the reduction / weight-gradient streams so far
+    if (rs != e->side) {
+      CVX_HIP(hipEventRecord(e->ev_join, e->side));
+      CVX_HIP(hipStreamWaitEvent(st, e->ev_join, 0));
+    }
+    CVX_HIP(hipStreamWaitEvent(st, e->ev_red, 0));
+    if (chunk_hi >= 0) CVX_TRY(reduce_chunk(lo_conv, chunk_hi, first, st));
+    return 0;
+  }
   if (rs != e->side) {
     CVX_HIP(hipEventRecord(e->ev_join, e->side));  // the last chunk needs the remaining weight-gradient slabs ...
     CVX_HIP(hipStreamWaitEvent(rs, e->ev_join, 0));
   }
   CVX_HIP(hipEventRecord(e->ev_fork, st));       // ... including the stem's, produced on the main stream (cvx_stem_backward)
   CVX_HIP(hipStreamWaitEvent(rs, e->ev_fork, 0));
-  if (chunk_hi >= 0) CVX_TRY(reduce_chunk(lo_conv, chunk_hi, first));
+  if (chunk_hi >= 0) CVX_TRY(reduce_chunk(lo_conv, chunk_hi, first, rs));
   CVX_HIP(hipEventRecord(e->ev_red, rs));
   CVX_HIP(hipStreamWaitEvent(st, e->ev_red, 0));
   return 0;
