@@ -79,7 +79,8 @@ typedef struct {
   int64_t gamma_off, beta_off; /* BN affine (param arena) */
   int64_t bias_off;            /* CVX_ACT_BIAS */
   int64_t rmean_off, rvar_off; /* BN running statistics (stats arena) */
-  int32_t lane; /* reserved (ignored): independent tails on own HIP streams measured slower than one stream */
+  int32_t lane; /* 0 / 1: the main chain.  >= 2: an independent tail (Detect levels 1, 2) the engine MAY run on its high-priority lane
+                   stream beside the main chain, forked at the first such op and joined after the last (a hint: results do not depend on it) */
   int32_t flags; /* CVX_OPF_* */
 } cvx_op_desc;
 
