@@ -46,8 +46,8 @@ sys.path.insert(0, ROOT)
 MFMA_FP16_PEAK_TFLOPS = 2516.6                  # MI355X dense fp16
 HBM_PEAK_GBS = 8000.0
 GFLOP = {"n": (8.742912, 26.140262), "s": (28.601549, 85.627699)}   # (forward, train step) per image, SURVEY section 8(d)
-TRAFFIC_FILES = ("r04_conv_traffic.json", "r03_conv_traffic.json", "r02_conv_traffic.json")      # newest first; PMC passes of a build, keyed by that build's library hash
-MFMA_FILES = ("r04_mfma_busy.json", "r03_mfma_busy.json")                                     # SQ_VALU_MFMA_BUSY_CYCLES pass (tools/pmc_mfma.py), same keying
+TRAFFIC_FILES = ("r05_conv_traffic.json", "r04_conv_traffic.json", "r03_conv_traffic.json", "r02_conv_traffic.json")      # newest first; PMC passes of a build, keyed by that build's library hash
+MFMA_FILES = ("r05_mfma_busy.json", "r04_mfma_busy.json", "r03_mfma_busy.json")                                  # SQ_VALU_MFMA_BUSY_CYCLES pass (tools/pmc_mfma.py), same keying
 
 
 def src_sha256():
