@@ -294,3 +294,40 @@ def test_generic_grad_buckets_on_every_graph():
     own = graph.grad_buckets(graphs["yolov8"], m8.layout, 5)
     gen = graph.generic_grad_buckets(graphs["yolov8"], 5)
     assert gen[-1][2] == 0 and abs(gen[0][3] - own[0][3]) <= 4                # same arena extent (up to the 16-byte alignment of the last slot)
+
+
+@pytest.mark.parametrize("H,W", [(640, 640), (320, 320), (128, 128), (96, 160)])
+def test_raw_fp16_layer_rule_is_the_same_in_the_graph_and_in_the_oracle(H, W):
+    """Which convs keep their raw output in fp16 during training (CVX_OPF_RAW_F16) is decided in graph.py; the oracle's fp16 emulation
+    (yolov8_ref._raw_f16) has to round exactly those layers, or the engine-vs-emulation tests compare two different networks."""
+    from computervision.pytorch_amd.graph import ParamLayout, build_yolov8_graph
+    g = build_yolov8_graph(ParamLayout("n", 80), H, W)
+    flagged, pixels = set(), {}
+    for op in g.ops:
+        if op["type"] != L.OP_CONV:
+            continue
+        pixels[op["name"]] = op["oh"] * op["ow"]
+        if op.get("flags", 0) & L.OPF_RAW_F16:
+            flagged.add(op["name"])
+
+    def oracle_prefix(name):       # engine op name -> the state_dict prefix of the oracle's _unit
+        part = name.split(".")
+        if part[0] == "22":        # Detect: "22.<lvl>.0" = cv2[lvl][0] + cv3[lvl][0] in one launch, "1b" / "1c" = cv2[lvl][1] / cv3[lvl][1]
+            return None
+        if len(part) == 3 and part[1].startswith("m"):
+            return f"model.{part[0]}.m.{part[1][1:]}.{part[2]}"
+        return "model." + name
+
+    assert "0" not in flagged                                  # the fp32 stem never
+    for name, px in pixels.items():
+        p = oracle_prefix(name)
+        if p is None:
+            if not name.endswith(("2b", "2c")):                # the head's BN convs: always (module 22); its bias convs have no BatchNorm
+                assert name in flagged, name
+            continue
+        res = ".m" in name and name.endswith("cv2") and int(name.split(".")[0]) < 10    # backbone Bottlenecks add their input
+        assert (name in flagged) == (O._raw_f16(p, px) and p != "model.0" and not res), (name, px)
+    if H * W <= 160 * 160:                                       # the fixtures' shapes: no backbone layer (outputs below 80 x 80)
+        assert all(int(n.split(".")[0]) >= 12 for n in flagged)
+    else:
+        assert {"1", "2.cv1", "2.cv2"} <= flagged and "2.m0.cv1" not in flagged
