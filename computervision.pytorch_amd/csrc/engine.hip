@@ -839,7 +839,7 @@ int plan_batch(cvx_engine* e, int B, bool training) {
       SlabDesc sd;
       sd.slab_off = c.slab_off;
       sd.dst_off = o.w_off;
-      sd.nsplit = c.nsplit;
+      sd.nsplit = c.stem ? 0 : c.nsplit;  // the stem folds its own slabs / partial blocks (cvx_stem_backward_fold): nothing for the table-driven reducer
       sd.rows = C * c.ntaps;
       sd.Cin = o.w_cin;
       sd.Cin_pad = c.cin_pad16;
@@ -1757,6 +1757,7 @@ struct PendingWgrad {
   float *dgamma, *dbeta;
   double flops, bytes;
   int op;
+  float* dw = nullptr;       // stem: its slice of the gradient arena (cvx_stem_backward_fold adds the folded weight gradient itself)
 };
 struct cvx_bw_state {
   half_t* dpred = nullptr;
@@ -1788,7 +1789,7 @@ int flush_wgrads(cvx_engine* e, hipEvent_t ev, hipStream_t producer) {
       // the last op of the pass: the main stream has nothing else left, while the side stream still holds the previous
       // layers' weight gradients -- the fused stem backward runs on the producer (main) stream, beside them
       ProfScope ps(e, PROF_CONV_WGRAD, g.flops, g.bytes, producer);
-      CVX_TRY(cvx_stem_backward(g.sp, g.wp.dy /* = xhat */, g.gout, g.coef, g.part, g.inv_scale, g.dgamma, g.dbeta, g.wp.slabs, g.wp.nsplit, producer));
+      CVX_TRY(cvx_stem_backward_fold(g.sp, g.wp.dy /* = xhat */, g.gout, g.coef, g.part, g.inv_scale, g.dgamma, g.dbeta, g.dw, g.wp.slabs, g.wp.nsplit, producer));
       continue;
     }
     // tuning build only (cvx_tune_int is a constant in the release library): time the main stream without its competitor
@@ -1969,7 +1970,13 @@ int backward_op(cvx_engine* e, int i) {
         one = cvx_bn_bwd_fused(c.ybuf, M, C, hw, k, c.stat_bwd, reinterpret_cast<unsigned long long*>(c.stat_bwd + (long long)cvx_stat_replicas(C) * C * CVX_STAT_WORDS),
                                w.inv_scale, e->grads + o.gamma_off, e->grads + o.beta_off, gout, ak, c.dybuf, gres, c.res_accum, st);
       if (one < 0) return one;
-      if (one == 1 && !tune_skip_reduce) CVX_TRY(cvx_bn_bwd_reduce(c.ybuf, M, C, hw, k, gout, ak, c.stat_bwd, st));
+      // (the stem's one-pass backward produces these sums itself: cvx_stem_backward_fold, queued below)
+      bool stem_onepass = false;
+      if (c.stem && e->last_images) {
+        const Buf& ib = e->bufs[e->image_buf];
+        stem_onepass = cvx_stem_backward_onepass_ok(StemParams{e->last_images, B, ib.d.h, ib.d.w, o.oh, o.ow, e->params + o.w_off, C}, c.ybuf, gout, c.nsplit);
+      }
+      if (one == 1 && !tune_skip_reduce && !stem_onepass) CVX_TRY(cvx_bn_bwd_reduce(c.ybuf, M, C, hw, k, gout, ak, c.stat_bwd, st));
       // the stem's "apply" half is fused into its weight gradient (cvx_stem_backward, queued below): dy is never materialised
       if (one == 1 && !c.stem)
         CVX_TRY(cvx_bn_bwd_apply(c.ybuf, M, C, hw, k, c.stat_bwd, w.inv_scale, e->grads + o.gamma_off, e->grads + o.beta_off, gout, ak, c.dybuf,
@@ -2019,6 +2026,7 @@ int backward_op(cvx_engine* e, int i) {
         pw.inv_scale = w.inv_scale;
         pw.dgamma = e->grads + o.gamma_off;
         pw.dbeta = e->grads + o.beta_off;
+        pw.dw = e->grads + o.w_off;
       }
       w.pending.push_back(pw);
       // batches of wg_batch layers share one event record -- except at the end of the pass: the last layers' weight

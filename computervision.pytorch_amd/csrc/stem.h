@@ -23,3 +23,9 @@ int cvx_stem_wgrad(const StemParams& p, const half_t* dy, float* slabs, int nspl
 // bn_bwd_reduce in `part`) + weight gradient; accumulates dgamma / dbeta; dy itself is never stored
 int cvx_stem_backward(const StemParams& p, const half_t* xhat, const ViewDesc& gout, const BnCoef& k, const long long* part, float inv_scale,
                       float* dgamma, float* dbeta, float* slabs, int nsplit, hipStream_t st);
+// The whole backward of the stem, folded into the gradient arena: dw [Cout][27] (+=), dgamma / dbeta (+=).  Where the images and the two
+// gradient-side tensors are 16-byte granular (cvx_stem_backward_onepass_ok) it is ONE pass over them -- the BatchNorm-backward sums come out of
+// the weight-gradient kernel instead of going in, `part` is not read and bn_bwd_reduce need not have run; otherwise `part` must hold its sums.
+bool cvx_stem_backward_onepass_ok(const StemParams& p, const half_t* xhat, const ViewDesc& gout, int nsplit);
+int cvx_stem_backward_fold(const StemParams& p, const half_t* xhat, const ViewDesc& gout, const BnCoef& k, const long long* part, float inv_scale,
+                           float* dgamma, float* dbeta, float* dw, float* slabs, int nsplit, hipStream_t st);

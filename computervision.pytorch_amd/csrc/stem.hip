@@ -407,6 +407,15 @@ static_assert(3 * SM_PL / 4 <= SM_WIN_CHUNKS, "window chunks");
 
 typedef __attribute__((address_space(3))) void* stem_lds_ptr;
 
+// ONEPASS: the BatchNorm-backward sums are not an input (`part`) but an OUTPUT.  dy = gi (dz - mean(dz) - xhat mean(dz xhat)) is linear in the
+// two means, so  dW = gi (S1 - mean(dz) S2 - mean(dz xhat) S3)  with  S1 = sum dz x,  S2 = sum x,  S3 = sum xhat x  over the pixels: the
+// workgroup accumulates S1 and S3 (four MFMAs per step instead of two: dz and xhat as two A operands), S2 and the two sums on the vector
+// ALUs, and stores ONE partial block [S1 16 x 32 | S3 16 x 32 | S2 32 | sum dz 16 | sum dz xhat 16] (SM_PART floats) in place of its slab;
+// stem_onepass_fold_kernel combines the workgroups' blocks in fp64.  The separate bn_bwd_reduce pass over gout and xhat (0.21 GB, 45-70 us
+// in the step's tail) is gone; dy is not rounded to fp16 on the way (it was, "as bn_bwd_apply stores it": one rounding less).
+constexpr int SM_PART = 16 * 32 * 2 + 32 + 16 + 16;
+
+template <bool ONEPASS>
 __global__ __launch_bounds__(256) void stem_bwd_mfma_kernel(const StemParams p, long long M, const half_t* xhat, ViewDesc gout, BnCoef k,
                                                             const long long* part, float inv_scale, float* dgamma, float* dbeta, float* slabs,
                                                             int tiles_x, int tiles_y, int total_tiles) {
@@ -474,15 +483,14 @@ __global__ __launch_bounds__(256) void stem_bwd_mfma_kernel(const StemParams p, 
   int tile = blockIdx.x;
   if (tile < total_tiles) issue(tile, stage0);  // in flight while the statistics are folded
 
-  fold_replicas(part, p.Cout, ws);
-  {
+  float k1 = 0.f, k2 = 0.f, gi = 0.f;
+  if constexpr (!ONEPASS) {
+    fold_replicas(part, p.Cout, ws);
     const double* s0 = reinterpret_cast<const double*>(ws);
     const double* s1 = s0 + p.Cout;
     const double cnt = (double)M;
     for (int c = threadIdx.x; c < p.Cout; c += 256) {
       const float gm = k.gamma[c];
-      sG[c] = gm;
-      sB[c] = k.beta[c];
       sK1[c] = (float)(s0[c] / cnt);
       sK2[c] = (float)(s1[c] / cnt);
       sGi[c] = gm * k.invstd[c];
@@ -491,9 +499,12 @@ __global__ __launch_bounds__(256) void stem_bwd_mfma_kernel(const StemParams p, 
         dbeta[c] += (float)(s0[c] * inv_scale);
       }
     }
+    __syncthreads();
+    k1 = sK1[co0 + m];
+    k2 = sK2[co0 + m];
+    gi = sGi[co0 + m];
   }
-  __syncthreads();
-  const float ga = sG[co0 + m], be = sB[co0 + m], k1 = sK1[co0 + m], k2 = sK2[co0 + m], gi = sGi[co0 + m];
+  const float ga = k.gamma[co0 + m], be = k.beta[co0 + m];
 
   // B operand: tap n of N tile t is k = 16 t + m = (kh * 3 + kw) * 3 + ci (k >= 27: a padding column, never stored)
   int boff[2];
@@ -507,6 +518,8 @@ __global__ __launch_bounds__(256) void stem_bwd_mfma_kernel(const StemParams p, 
   const int aoff = (2 * wave * SM_TW + g) * 32 + m * 2;
 
   f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  f4 acx0 = {0.f, 0.f, 0.f, 0.f}, acx1 = {0.f, 0.f, 0.f, 0.f};  // ONEPASS: S3 (xhat rows)
+  float sdz = 0.f, sdzx = 0.f, sb0 = 0.f, sb1 = 0.f;            // ONEPASS: per lane (pixel group g, channel / tap m)
   int cur = 0;
   for (; tile < total_tiles; tile += gridDim.x) {
     unsigned char* st = stage0 + cur * SM_STAGE_BYTES;
@@ -529,11 +542,55 @@ __global__ __launch_bounds__(256) void stem_bwd_mfma_kernel(const StemParams p, 
       const float b1 = *reinterpret_cast<const float*>(sw + boff[1] + (row * 2 * SM_P + 2 * c4) * 4);
       const bool ok = oy0 + row < p.OH && ox0 + c4 < p.OW;
       const float dz = gv * cvx_silu_grad(xv * ga + be);
-      const float dy = ok ? (float)(half_t)(gi * (dz - k1 - xv * k2)) : 0.f;  // rounded to fp16 once, as bn_bwd_apply stores it
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dy, b0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dy, b1, acc1, 0, 0, 0);
+      if constexpr (ONEPASS) {
+        // pixels outside the map: xhat and gout were zero-filled (dz = 0, xv = 0), only the window sum needs the mask
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dz, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dz, b1, acc1, 0, 0, 0);
+        acx0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, b0, acx0, 0, 0, 0);
+        acx1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, b1, acx1, 0, 0, 0);
+        sdz += dz;
+        sdzx = fmaf(dz, xv, sdzx);
+        sb0 += ok ? b0 : 0.f;
+        sb1 += ok ? b1 : 0.f;
+      } else {
+        const float dy = ok ? (float)(half_t)(gi * (dz - k1 - xv * k2)) : 0.f;  // rounded to fp16 once, as bn_bwd_apply stores it
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dy, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dy, b1, acc1, 0, 0, 0);
+      }
     }
     cur ^= 1;
+  }
+  if constexpr (ONEPASS) {
+    // ---- the workgroup's partial block.  D row 4 g + i = channel, column m = tap within the N tile; the lane sums run over g and the waves ----
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(stage0);  // [wave][SM_PART]
+    float* mine = red + wave * SM_PART;
+    sdz += __shfl_xor(sdz, 16);
+    sdz += __shfl_xor(sdz, 32);
+    sdzx += __shfl_xor(sdzx, 16);
+    sdzx += __shfl_xor(sdzx, 32);
+    sb0 += __shfl_xor(sb0, 16);
+    sb0 += __shfl_xor(sb0, 32);
+    sb1 += __shfl_xor(sb1, 16);
+    sb1 += __shfl_xor(sb1, 32);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      mine[(4 * g + i) * 32 + m] = acc0[i];
+      mine[(4 * g + i) * 32 + 16 + m] = acc1[i];
+      mine[512 + (4 * g + i) * 32 + m] = acx0[i];
+      mine[512 + (4 * g + i) * 32 + 16 + m] = acx1[i];
+    }
+    if (g == 0) {
+      mine[1024 + m] = sb0;
+      mine[1024 + 16 + m] = sb1;
+      mine[1056 + m] = sdz;
+      mine[1072 + m] = sdzx;
+    }
+    __syncthreads();
+    float* out = slabs + (long long)blockIdx.x * p.Cout * 144 + blockIdx.y * (16 * 144);
+    for (int e = threadIdx.x; e < SM_PART; e += 256) out[e] = ((red[e] + red[e + SM_PART]) + red[e + 2 * SM_PART]) + red[e + 3 * SM_PART];
+    if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned*>(out)[2 * SM_PART + 64] = 0u;  // the fold kernel's arrival counter
+    return;
   }
   // the four waves' partial blocks -> one slab per workgroup: D row 4 g + i = channel, column m = tap within the N tile
   __syncthreads();
@@ -555,6 +612,66 @@ __global__ __launch_bounds__(256) void stem_bwd_mfma_kernel(const StemParams p, 
     }
   }
 #endif
+}
+
+// ---- fold of the one-pass partial blocks: column sums over the splits in fp64 (one workgroup per 16 columns), then the LAST workgroup to
+// arrive forms  dW = gi (S1 - k1 S2 - k2 S3),  dgamma = sum dz xhat,  dbeta = sum dz  and adds them to the gradient arena.
+// Column sums live in the unused part of the split rows' strides (row r, floats [SM_PART, 2 SM_PART) = 544 doubles): needs >= 2 splits.
+constexpr int SM_FOLD_BLOCKS = SM_PART / 16;  // 68
+__global__ __launch_bounds__(256) void stem_onepass_fold_kernel(float* slabs, int nsplit, int Cout, long long M, const float* gamma, const float* invstd,
+                                                                float inv_scale, float* dw, float* dgamma, float* dbeta) {
+  __shared__ double sd[256];
+  __shared__ double col[SM_PART];
+  __shared__ bool last;
+  const int slice = blockIdx.y;
+  const long long stride = (long long)Cout * 144;
+  float* base = slabs + slice * (16 * 144);
+  const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
+  const int column = blockIdx.x * 16 + c;
+  double a = 0.0;
+  for (int sp = r; sp < nsplit; sp += 16) a += (double)base[(long long)sp * stride + column];
+  sd[threadIdx.x] = a;
+  __syncthreads();
+  for (int off = 128; off >= 16; off >>= 1) {
+    if ((int)threadIdx.x < off) sd[threadIdx.x] += sd[threadIdx.x + off];
+    __syncthreads();
+  }
+  auto colsum_at = [&](int q) -> double* { return reinterpret_cast<double*>(base + (long long)(q / 544) * stride + SM_PART) + (q % 544); };
+  if (threadIdx.x < 16) __hip_atomic_store(colsum_at(column), sd[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    unsigned* ctr = reinterpret_cast<unsigned*>(base) + 2 * SM_PART + 64;
+    last = atomicAdd(ctr, 1u) == gridDim.x - 1;
+    if (last) __threadfence();
+  }
+  __syncthreads();
+  if (!last) return;
+  for (int q = threadIdx.x; q < SM_PART; q += 256) col[q] = __hip_atomic_load(colsum_at(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const double cnt = (double)M;
+  for (int e = threadIdx.x; e < 16 * KT; e += 256) {
+    const int co = e / KT, kk = e - co * KT;
+    const double k1 = col[1056 + co] / cnt, k2 = col[1072 + co] / cnt;
+    const double g = (double)gamma[slice * 16 + co] * (double)invstd[slice * 16 + co];
+    const double v = g * (col[co * 32 + kk] - k1 * col[1024 + kk] - k2 * col[512 + co * 32 + kk]);
+    dw[(long long)(slice * 16 + co) * KT + kk] += (float)(v * inv_scale);
+  }
+  if (threadIdx.x < 16) {
+    dgamma[slice * 16 + threadIdx.x] += (float)(col[1072 + threadIdx.x] * inv_scale);
+    dbeta[slice * 16 + threadIdx.x] += (float)(col[1056 + threadIdx.x] * inv_scale);
+  }
+}
+
+// plain slabs [nsplit][Cout][9 * 16] -> dw [Cout][27] (+=): what the engine's table-driven reducer does for every other layer
+__global__ __launch_bounds__(256) void stem_slab_fold_kernel(const float* slabs, int nsplit, int Cout, float inv_scale, float* dw) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= Cout * KT) return;
+  const int co = e / KT, kk = e - co * KT;
+  const float* s = slabs + (long long)co * 144 + (kk / 3) * 16 + (kk % 3);
+  float a = 0.f;
+  for (int sp = 0; sp < nsplit; ++sp) a += s[(long long)sp * Cout * 144];
+  dw[e] += a * inv_scale;
 }
 
 int stem_grid(long long M, int per_block) {
@@ -649,7 +766,7 @@ int cvx_stem_backward(const StemParams& p, const half_t* xhat, const ViewDesc& g
                        (long long)p.B * gout.bstride * 2 < (1LL << 32);
   if (mfma_ok) {
     const int lds_m = fold_ws_bytes(p.Cout) + 5 * p.Cout * 4 + 32 + 2 * SM_STAGE_BYTES;
-    hipLaunchKernelGGL(stem_bwd_mfma_kernel, dim3(nsplit, p.Cout / 16), dim3(256), lds_m, st, p, M, xhat, gout, k, part, inv_scale, dgamma, dbeta,
+    hipLaunchKernelGGL(stem_bwd_mfma_kernel<false>, dim3(nsplit, p.Cout / 16), dim3(256), lds_m, st, p, M, xhat, gout, k, part, inv_scale, dgamma, dbeta,
                        slabs, tiles_x, tiles_y, tiles_x * tiles_y * p.B);
     CVX_HIP(hipGetLastError());
     return 0;
@@ -657,6 +774,39 @@ int cvx_stem_backward(const StemParams& p, const half_t* xhat, const ViewDesc& g
   const int lds = fold_ws_bytes(p.Cout) + 5 * p.Cout * 4 + 3 * 17 * 66 * 4;
   hipLaunchKernelGGL(stem_bwd_kernel, dim3(nsplit, p.Cout / 16), dim3(256), lds, st, p, M, xhat, gout, k, part, inv_scale, dgamma, dbeta, slabs,
                      tiles_x, tiles_y, tiles_x * tiles_y * p.B);
+  CVX_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- the whole backward of the stem with the fold into the gradient arena (what the engine and cvx_stem_backward_nchw call) ----
+static bool stem_dma_ok(const StemParams& p, const half_t* xhat, const ViewDesc& gout, long long M) {
+  return p.W % 4 == 0 && ((uintptr_t)p.img % 16) == 0 && ((uintptr_t)xhat % 16) == 0 && ((uintptr_t)gout.p % 16) == 0 && gout.ld % 8 == 0 &&
+         gout.bstride % 8 == 0 && (long long)p.B * 3 * p.H * p.W * 4 < (1LL << 32) && M * p.Cout * 2 < (1LL << 32) &&
+         (long long)p.B * gout.bstride * 2 < (1LL << 32);
+}
+bool cvx_stem_backward_onepass_ok(const StemParams& p, const half_t* xhat, const ViewDesc& gout, int nsplit) {
+  static const bool on = cvx_tune_int("CVX_STEM_ONEPASS", 1) != 0;
+  const long long M = (long long)p.B * p.OH * p.OW;
+  return on && nsplit >= 2 && p.Cout % 16 == 0 && stem_dma_ok(p, xhat, gout, M);
+}
+int cvx_stem_backward_fold(const StemParams& p, const half_t* xhat, const ViewDesc& gout, const BnCoef& k, const long long* part, float inv_scale,
+                           float* dgamma, float* dbeta, float* dw, float* slabs, int nsplit, hipStream_t st) {
+  CVX_TRY(check(p));
+  const long long M = (long long)p.B * p.OH * p.OW;
+  CVX_CHECK(xhat && gout.p && dgamma && dbeta && dw && slabs && nsplit == cvx_stem_wgrad_splits(M), "stem backward: bad arguments");
+  if (cvx_stem_backward_onepass_ok(p, xhat, gout, nsplit)) {
+    const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + 7) / 8;
+    const int lds_m = fold_ws_bytes(p.Cout) + 5 * p.Cout * 4 + 32 + 2 * SM_STAGE_BYTES;
+    hipLaunchKernelGGL(stem_bwd_mfma_kernel<true>, dim3(nsplit, p.Cout / 16), dim3(256), lds_m, st, p, M, xhat, gout, k, (const long long*)nullptr, inv_scale,
+                       dgamma, dbeta, slabs, tiles_x, tiles_y, tiles_x * tiles_y * p.B);
+    hipLaunchKernelGGL(stem_onepass_fold_kernel, dim3(SM_FOLD_BLOCKS, p.Cout / 16), dim3(256), 0, st, slabs, nsplit, p.Cout, M, k.gamma, k.invstd, inv_scale,
+                       dw, dgamma, dbeta);
+    CVX_HIP(hipGetLastError());
+    return 0;
+  }
+  CVX_CHECK(part, "stem backward: the two-pass path needs the sums of bn_bwd_reduce");
+  CVX_TRY(cvx_stem_backward(p, xhat, gout, k, part, inv_scale, dgamma, dbeta, slabs, nsplit, st));
+  hipLaunchKernelGGL(stem_slab_fold_kernel, dim3((p.Cout * KT + 255) / 256), dim3(256), 0, st, slabs, nsplit, p.Cout, inv_scale, dw);
   CVX_HIP(hipGetLastError());
   return 0;
 }

@@ -302,18 +302,11 @@ extern "C" int cvx_stem_backward_nchw(const float* images, int32_t batch, int32_
   CVX_TRY(slabs.alloc((size_t)ns * cout * 144 * 4));
   BnCoef k{invstd, gamma, beta};
   const ViewDesc g = dense(gout_f16, hw, cout);
-  CVX_TRY(cvx_bn_bwd_reduce((const half_t*)xhat_f16, M, cout, hw, k, g, BnActKind{0, 0, ViewDesc{nullptr, 0, 0}}, (long long*)part.p, st));
-  CVX_TRY(cvx_stem_backward(sp, (const half_t*)xhat_f16, g, k, (const long long*)part.p, inv_scale, dgamma, dbeta, (float*)slabs.p, ns, st));
-  SlabDesc sd{0, 0, ns, cout * 9, 3, 16, cvx_slab_lanes(ns)};
-  std::vector<BlockRef> blocks;
-  const long long total = (long long)sd.rows * sd.Cin;
-  for (long long s0 = 0; s0 < total; s0 += 256 / sd.lanes) blocks.push_back(BlockRef{0, (int)s0});
-  CVX_TRY(dsd.alloc(sizeof(sd)));
-  CVX_TRY(dbl.alloc(blocks.size() * sizeof(BlockRef)));
-  CVX_HIP(hipMemcpy(dsd.p, &sd, sizeof(sd), hipMemcpyHostToDevice));
-  CVX_HIP(hipMemcpy(dbl.p, blocks.data(), blocks.size() * sizeof(BlockRef), hipMemcpyHostToDevice));
+  // the engine's sequence: the BatchNorm-backward sums only where the one-pass kernel does not take the shape, then kernel + fold
+  if (!cvx_stem_backward_onepass_ok(sp, (const half_t*)xhat_f16, g, ns))
+    CVX_TRY(cvx_bn_bwd_reduce((const half_t*)xhat_f16, M, cout, hw, k, g, BnActKind{0, 0, ViewDesc{nullptr, 0, 0}}, (long long*)part.p, st));
   CVX_HIP(hipMemsetAsync(dw, 0, (size_t)cout * 27 * 4, st));
-  CVX_TRY(cvx_reduce_slabs((const float*)slabs.p, dw, inv_scale, (const SlabDesc*)dsd.p, (const BlockRef*)dbl.p, (int)blocks.size(), st));
+  CVX_TRY(cvx_stem_backward_fold(sp, (const half_t*)xhat_f16, g, k, (const long long*)part.p, inv_scale, dgamma, dbeta, dw, (float*)slabs.p, ns, st));
   CVX_HIP(hipStreamSynchronize(st));
   return 0;
 }

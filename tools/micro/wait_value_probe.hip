@@ -72,7 +72,18 @@ int main() {
       ++seq;
       if (mode == 2) hipLaunchKernelGGL(work, dim3(256), dim3(BLK), 0, A, pa, n, flag, seq, ctr);
       else hipLaunchKernelGGL(work, dim3(256), dim3(BLK), 0, A, pa, n, (unsigned*)nullptr, 0u, (unsigned*)nullptr);
-      if (mode == 1) {
+      if (mode == 6 || mode == 7) {    // a stream-ordered value write on A, a polling wait on B (7: and a consumer behind it)
+        (void)hipStreamWriteValue32(A, flag, seq, 0);
+        (void)hipStreamWaitValue32(B, flag, seq, hipStreamWaitValueGte, 0xffffffffu);
+        if (mode == 7) hipLaunchKernelGGL(consumer, dim3(64), dim3(BLK), 0, B, pb, n, (const unsigned*)flag, seq, bad);
+      } else if (mode == 3) {
+        (void)hipEventRecord(ev, A);   // the marker alone: nobody waits for it
+      } else if (mode == 4) {
+        (void)hipEventRecord(ev, A);   // marker + a waiting stream with nothing to run
+        (void)hipStreamWaitEvent(B, ev, 0);
+      } else if (mode == 5) {          // no marker: an independent consumer on B (what the consumer's own CU-time costs A)
+        hipLaunchKernelGGL(consumer, dim3(64), dim3(BLK), 0, B, pb, n, (const unsigned*)nullptr, 0u, bad);
+      } else if (mode == 1) {
         (void)hipEventRecord(ev, A);
         (void)hipStreamWaitEvent(B, ev, 0);
         hipLaunchKernelGGL(consumer, dim3(64), dim3(BLK), 0, B, pb, n, (const unsigned*)nullptr, 0u, bad);
@@ -97,6 +108,9 @@ int main() {
     int hb = 0;
     CK(hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost));
     printf("per iteration (2 kernels on A): plain %.2f us | + event record/wait for B %.2f us | + in-kernel flag, wait-value on B %.2f us | consumer saw a stale flag %d times\n", a, b, c, hb);
+    const double d3 = run(3), d4 = run(4), d5 = run(5), d6 = run(6), d7 = run(7);
+    printf("                                hipStreamWriteValue32 on A + hipStreamWaitValue32 on B %.2f us | ... + consumer %.2f us\n", d6, d7);
+    printf("                                event record alone %.2f us | record + waiting (empty) stream %.2f us | independent consumer on B, no marker %.2f us\n", d3, d4, d5);
   }
   return 0;
 }
