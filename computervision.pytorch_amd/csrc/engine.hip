@@ -2177,10 +2177,10 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
   CVX_TRY(join_lane(e));
   CVX_TRY(flush_wgrads(e, e->ev_fork, st));  // (non-conv first ops: nothing pending in practice)
   e->cur_op = -1;
-  // The last, small chunk holds the stem's slabs, which the MAIN stream has just produced (cvx_stem_backward), and the first layers' weight
-  // gradients, long finished on the side stream by then: it is reduced on the main stream -- one cross-stream hop (side -> main) in the
-  // step's tail instead of two (main -> side -> main).
-  static const bool tail_on_main = cvx_tune_int("CVX_TAIL_REDUCE_MAIN", 1) != 0;
+  // The last, small chunk: the first layers' weight-gradient slabs (the stem folds its own partial blocks on the main stream, inside
+  // cvx_stem_backward_fold).  It is reduced on the reduction stream behind those weight gradients -- i.e. beside the stem's backward kernel
+  // -- and the main stream waits for it once, at the very end.  CVX_TAIL_REDUCE_MAIN=1 (tuning): on the main stream, behind the stem.
+  static const bool tail_on_main = cvx_tune_int("CVX_TAIL_REDUCE_MAIN", 0) != 0;
   if (tail_on_main) {
     CVX_HIP(hipEventRecord(e->ev_red, rs));        // everything queued on the reduction / weight-gradient streams so far
     if (rs != e->side) {
@@ -2192,11 +2192,9 @@ extern "C" int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float l
     return 0;
   }
   if (rs != e->side) {
-    CVX_HIP(hipEventRecord(e->ev_join, e->side));  // the last chunk needs the remaining weight-gradient slabs ...
+    CVX_HIP(hipEventRecord(e->ev_join, e->side));
     CVX_HIP(hipStreamWaitEvent(rs, e->ev_join, 0));
   }
-  CVX_HIP(hipEventRecord(e->ev_fork, st));       // ... including the stem's, produced on the main stream (cvx_stem_backward)
-  CVX_HIP(hipStreamWaitEvent(rs, e->ev_fork, 0));
   if (chunk_hi >= 0) CVX_TRY(reduce_chunk(lo_conv, chunk_hi, first, rs));
   CVX_HIP(hipEventRecord(e->ev_red, rs));
   CVX_HIP(hipStreamWaitEvent(st, e->ev_red, 0));

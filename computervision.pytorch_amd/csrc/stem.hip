@@ -628,8 +628,17 @@ __global__ __launch_bounds__(256) void stem_onepass_fold_kernel(float* slabs, in
   float* base = slabs + slice * (16 * 144);
   const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
   const int column = blockIdx.x * 16 + c;
+  // (eight independent loads per trip: one dependent 4-byte load per addition made this 17 us of the step's tail)
   double a = 0.0;
-  for (int sp = r; sp < nsplit; sp += 16) a += (double)base[(long long)sp * stride + column];
+  int sp = r;
+  for (; sp + 7 * 16 < nsplit; sp += 8 * 16) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = base[(long long)(sp + 16 * u) * stride + column];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a += (double)v[u];
+  }
+  for (; sp < nsplit; sp += 16) a += (double)base[(long long)sp * stride + column];
   sd[threadIdx.x] = a;
   __syncthreads();
   for (int off = 128; off >= 16; off >>= 1) {
