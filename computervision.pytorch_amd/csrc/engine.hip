@@ -1674,7 +1674,9 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
         ProfScope ps(e, PROF_CONV_FWD, conv_flops(o, B), img_bytes + 4.0 * M * C, st);
         BnTrainArgs ta{c.stat_fwd,           e->params + o.gamma_off, e->params + o.beta_off, c.mean, c.invstd, e->stats + o.rmean_off,
                        e->stats + o.rvar_off, e->bn_eps,       e->bn_momentum};
-        CVX_TRY(cvx_stem_apply_train(sp, ta, outv, c.ybuf, st));
+        // (xhat is not stored where the backward pass recomputes it from the images: cvx_stem_keeps_xhat, the same test on both sides)
+        const bool keep_xhat = cvx_stem_keeps_xhat(sp, make_view(e, o.out, true), c.nsplit);
+        CVX_TRY(cvx_stem_apply_train(sp, ta, outv, keep_xhat ? c.ybuf : nullptr, st));
       } else {
         ProfScope ps(e, PROF_CONV_FWD, conv_flops(o, B), img_bytes + 2.0 * M * C, st);
         CVX_TRY(cvx_stem_apply_eval(sp, c.scale, c.shift, outv, st));
@@ -2021,7 +2023,7 @@ int backward_op(cvx_engine* e, int i) {
         pw.bytes = 12.0 * B * ib.d.h * ib.d.w + 4.0 * M * C + 4.0 * c.nsplit * C * 144;
         pw.wp.dy = c.ybuf;  // xhat
         pw.gout = make_view(e, o.out, true);
-        pw.coef = BnCoef{c.invstd, e->params + o.gamma_off, e->params + o.beta_off};
+        pw.coef = BnCoef{c.invstd, e->params + o.gamma_off, e->params + o.beta_off, c.mean};  // (mean: for the recomputed xhat)
         pw.part = c.stat_bwd;
         pw.inv_scale = w.inv_scale;
         pw.dgamma = e->grads + o.gamma_off;

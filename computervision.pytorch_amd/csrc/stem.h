@@ -29,3 +29,6 @@ int cvx_stem_backward(const StemParams& p, const half_t* xhat, const ViewDesc& g
 bool cvx_stem_backward_onepass_ok(const StemParams& p, const half_t* xhat, const ViewDesc& gout, int nsplit);
 int cvx_stem_backward_fold(const StemParams& p, const half_t* xhat, const ViewDesc& gout, const BnCoef& k, const long long* part, float inv_scale,
                            float* dgamma, float* dbeta, float* dw, float* slabs, int nsplit, hipStream_t st);
+// false: cvx_stem_backward_fold (given BnCoef::mean) recomputes xhat from the images, and the training forward need not store it --
+// cvx_stem_apply_train accepts xhat == nullptr.  Decided from the same conditions on both sides.
+bool cvx_stem_keeps_xhat(const StemParams& p, const ViewDesc& gout, int nsplit);

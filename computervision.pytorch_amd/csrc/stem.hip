@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void stem_apply_kernel(const StemParams p, lon
       }
       *reinterpret_cast<h8*>(o + g * 16) = av[0];
       *reinterpret_cast<h8*>(o + g * 16 + 8) = av[1];
-      if (TRAIN) {
+      if (TRAIN && xhat) {  // (nullptr: the backward pass recomputes it, cvx_stem_keeps_xhat)
         half_t* xo = xhat + m * p.Cout + g * 16;
         *reinterpret_cast<h8*>(xo) = xv[0];
         *reinterpret_cast<h8*>(xo + 8) = xv[1];
@@ -415,7 +415,12 @@ typedef __attribute__((address_space(3))) void* stem_lds_ptr;
 // in the step's tail) is gone; dy is not rounded to fp16 on the way (it was, "as bn_bwd_apply stores it": one rounding less).
 constexpr int SM_PART = 16 * 32 * 2 + 32 + 16 + 16;
 
-template <bool ONEPASS>
+// RECOMP (with ONEPASS): xhat is not read either -- the tile's input window is in LDS anyway, so the conv output of a 16-pixel block is
+// recomputed as a [16 pixels x 28 taps] . [28 x 16 channels] product (seven more MFMAs per 16 pixels: lane (g, m) ends with pixels 4 g + i,
+// channel m, exactly the operand layout of the four steps that follow), normalised with the forward's published mean / invstd and rounded to
+// fp16 as the forward pass would have stored it.  The forward then does not store xhat at all: 0.1 GB less written there, 0.1 GB less read
+// here, in the step's tail.
+template <bool ONEPASS, bool RECOMP = false>
 __global__ __launch_bounds__(256) void stem_bwd_mfma_kernel(const StemParams p, long long M, const half_t* xhat, ViewDesc gout, BnCoef k,
                                                             const long long* part, float inv_scale, float* dgamma, float* dbeta, float* slabs,
                                                             int tiles_x, int tiles_y, int total_tiles) {
@@ -466,7 +471,7 @@ __global__ __launch_bounds__(256) void stem_bwd_mfma_kernel(const StemParams p, 
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_img, (stem_lds_ptr)(st + (4 * j + wave) * 1024), 16, vo, 0, 0, 0);
     }
     unsigned char* sx = st + SM_WIN_CHUNKS * 16;
-    unsigned char* sg = sx + SM_TH * SM_TW * 32;
+    unsigned char* sg = sx + (RECOMP ? 0 : SM_TH * SM_TW * 32);  // (RECOMP: no xhat tile, the stage is one tile smaller)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int row = 2 * wave + j;
@@ -475,7 +480,7 @@ __global__ __launch_bounds__(256) void stem_bwd_mfma_kernel(const StemParams p, 
       const long long pix = (long long)oy * p.OW + ox;
       const unsigned vx = ok ? (unsigned)((((long long)b * p.OH * p.OW + pix) * p.Cout + co0) * 2 + t_half * 16) : 0xffffffffu;
       const unsigned vg = ok ? (unsigned)(((long long)b * gout.bstride + pix * gout.ld + co0) * 2 + t_half * 16) : 0xffffffffu;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_xh, (stem_lds_ptr)(sx + row * 1024), 16, vx, 0, 0, 0);
+      if constexpr (!RECOMP) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_xh, (stem_lds_ptr)(sx + row * 1024), 16, vx, 0, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (stem_lds_ptr)(sg + row * 1024), 16, vg, 0, 0, 0);
     }
   };
@@ -516,23 +521,83 @@ __global__ __launch_bounds__(256) void stem_bwd_mfma_kernel(const StemParams p, 
     boff[t] = (ci * SM_PL + (4 * wave + kh) * SM_P + kw + 3 + 2 * g) * 4;
   }
   const int aoff = (2 * wave * SM_TW + g) * 32 + m * 2;
+  // RECOMP: conv operands (pixel m of the 16-pixel block, tap 4 t + g) and the step operands for pixels 4 g + i
+  int toff7[7], boffr[2];
+  float wreg[7];
+  float mean_c = 0.f, invstd_c = 0.f;
+  if constexpr (RECOMP) {
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+      const int kq = 4 * t + g, kk = min(kq, KT - 1);
+      const int ci = kk % 3, kw = (kk / 3) % 3, kh = kk / 9;
+      toff7[t] = (ci * SM_PL + (4 * wave + kh) * SM_P + kw + 3 + 2 * m) * 4;
+      wreg[t] = kq < KT ? p.w[(long long)(co0 + m) * KT + kq] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) boffr[t] = boff[t] + (2 * (4 * g) - 2 * g) * 4;
+    mean_c = k.mean[co0 + m];
+    invstd_c = k.invstd[co0 + m];
+  }
+  const int aoffr = (2 * wave * SM_TW + 4 * g) * 32 + m * 2;
 
   f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   f4 acx0 = {0.f, 0.f, 0.f, 0.f}, acx1 = {0.f, 0.f, 0.f, 0.f};  // ONEPASS: S3 (xhat rows)
   float sdz = 0.f, sdzx = 0.f, sb0 = 0.f, sb1 = 0.f;            // ONEPASS: per lane (pixel group g, channel / tap m)
   int cur = 0;
   for (; tile < total_tiles; tile += gridDim.x) {
-    unsigned char* st = stage0 + cur * SM_STAGE_BYTES;
+    constexpr int STAGE = SM_STAGE_BYTES - (RECOMP ? SM_TH * SM_TW * 32 : 0);
+    unsigned char* st = stage0 + cur * STAGE;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();  // this tile has landed for every wave, and every wave is done with the other stage
     asm volatile("" ::: "memory");
-    if (tile + (int)gridDim.x < total_tiles) issue(tile + gridDim.x, stage0 + (cur ^ 1) * SM_STAGE_BYTES);
+    if (tile + (int)gridDim.x < total_tiles) issue(tile + gridDim.x, stage0 + (cur ^ 1) * STAGE);
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y;
     const int oy0 = ty * SM_TH + 2 * wave, ox0 = tx * SM_TW + g;
     const unsigned char* sw = st;
     const unsigned char* sx = st + SM_WIN_CHUNKS * 16 + aoff;
     const unsigned char* sg = sx + SM_TH * SM_TW * 32;
+    if constexpr (ONEPASS && RECOMP) {
+      const unsigned char* sgr = st + SM_WIN_CHUNKS * 16 + aoffr;
+      const int oxb = tx * SM_TW + 4 * g;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = q >> 1, cb = (q & 1) * 16;  // tile row 2 * wave + row, columns cb .. cb + 15
+        f4 y = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+          const float a = *reinterpret_cast<const float*>(sw + toff7[t] + (row * 2 * SM_P + 2 * cb) * 4);
+          y = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wreg[t], y, 0, 0, 0);
+        }
+        // the block's 16 pixels are ONE K = 16 step of v_mfma_f32_16x16x16_f16: lane (g, m) holds K = pixels 4 g + i of both operands.  dz and the
+        // window values are rounded to fp16 here -- what every other layer's weight gradient does with its dy and its input (xhat is fp16 already)
+        typedef _Float16 hv4 __attribute__((ext_vector_type(4)));
+        hv4 dz4, xv4, b04, b14;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // pixel cb + 4 g + i
+          const bool ok = oy0 + row < p.OH && oxb + cb + i < p.OW;
+          const half_t xh = (half_t)((y[i] - mean_c) * invstd_c);  // as the forward pass would have stored it
+          const float xv = ok ? (float)xh : 0.f;
+          const float gv = (float)*reinterpret_cast<const half_t*>(sgr + (row * SM_TW + cb + i) * 32);
+          const half_t b0 = (half_t)*reinterpret_cast<const float*>(sw + boffr[0] + (row * 2 * SM_P + 2 * (cb + i)) * 4);
+          const half_t b1 = (half_t)*reinterpret_cast<const float*>(sw + boffr[1] + (row * 2 * SM_P + 2 * (cb + i)) * 4);
+          const half_t dzh = (half_t)(gv * cvx_silu_grad(xv * ga + be));
+          const float dz = (float)dzh;
+          dz4[i] = dzh;
+          xv4[i] = (half_t)xv;
+          b04[i] = b0;
+          b14[i] = b1;
+          sdz += dz;
+          sdzx = fmaf(dz, xv, sdzx);
+          sb0 += ok ? (float)b0 : 0.f;
+          sb1 += ok ? (float)b1 : 0.f;
+        }
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x16f16(dz4, b04, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x16f16(dz4, b14, acc1, 0, 0, 0);
+        acx0 = __builtin_amdgcn_mfma_f32_16x16x16f16(xv4, b04, acx0, 0, 0, 0);
+        acx1 = __builtin_amdgcn_mfma_f32_16x16x16f16(xv4, b14, acx1, 0, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int row = s >> 3, c4 = (s & 7) * 4;  // tile row 2 * wave + row, column c4 + g
@@ -557,6 +622,7 @@ __global__ __launch_bounds__(256) void stem_bwd_mfma_kernel(const StemParams p, 
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dy, b0, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dy, b1, acc1, 0, 0, 0);
       }
+    }
     }
     cur ^= 1;
   }
@@ -735,7 +801,7 @@ static int launch_apply(const StemParams& p, const BnTrainArgs& a, const float* 
 
 int cvx_stem_apply_train(const StemParams& p, const BnTrainArgs& a, const ViewDesc& out, half_t* xhat, hipStream_t st) {
   CVX_TRY(check(p));
-  CVX_CHECK(out.p && xhat && ((uintptr_t)out.p % 16) == 0 && out.ld % 8 == 0, "stem: output view");
+  CVX_CHECK(out.p && ((uintptr_t)out.p % 16) == 0 && out.ld % 8 == 0, "stem: output view");  // (xhat == nullptr: not stored, cvx_stem_keeps_xhat)
   return launch_apply<true>(p, a, nullptr, nullptr, out, xhat, st);
 }
 
@@ -793,6 +859,11 @@ static bool stem_dma_ok(const StemParams& p, const half_t* xhat, const ViewDesc&
          gout.bstride % 8 == 0 && (long long)p.B * 3 * p.H * p.W * 4 < (1LL << 32) && M * p.Cout * 2 < (1LL << 32) &&
          (long long)p.B * gout.bstride * 2 < (1LL << 32);
 }
+bool cvx_stem_keeps_xhat(const StemParams& p, const ViewDesc& gout, int nsplit) {
+  static const bool recomp = cvx_tune_int("CVX_STEM_RECOMP", 1) != 0;
+  // (the one-pass conditions with a 16-byte aligned dummy in place of the xhat pointer: xhat is what would not exist)
+  return !(recomp && cvx_stem_backward_onepass_ok(p, reinterpret_cast<const half_t*>((uintptr_t)16), gout, nsplit));
+}
 bool cvx_stem_backward_onepass_ok(const StemParams& p, const half_t* xhat, const ViewDesc& gout, int nsplit) {
   static const bool on = cvx_tune_int("CVX_STEM_ONEPASS", 1) != 0;
   const long long M = (long long)p.B * p.OH * p.OW;
@@ -806,6 +877,10 @@ int cvx_stem_backward_fold(const StemParams& p, const half_t* xhat, const ViewDe
   if (cvx_stem_backward_onepass_ok(p, xhat, gout, nsplit)) {
     const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + 7) / 8;
     const int lds_m = fold_ws_bytes(p.Cout) + 5 * p.Cout * 4 + 32 + 2 * SM_STAGE_BYTES;
+    if (k.mean && !cvx_stem_keeps_xhat(p, gout, nsplit)) {  // the forward pass stored no xhat: recomputed from the window
+      hipLaunchKernelGGL((stem_bwd_mfma_kernel<true, true>), dim3(nsplit, p.Cout / 16), dim3(256), lds_m - 2 * SM_TH * SM_TW * 32, st, p, M, xhat, gout, k, (const long long*)nullptr,
+                         inv_scale, dgamma, dbeta, slabs, tiles_x, tiles_y, tiles_x * tiles_y * p.B);
+    } else
     hipLaunchKernelGGL(stem_bwd_mfma_kernel<true>, dim3(nsplit, p.Cout / 16), dim3(256), lds_m, st, p, M, xhat, gout, k, (const long long*)nullptr, inv_scale,
                        dgamma, dbeta, slabs, tiles_x, tiles_y, tiles_x * tiles_y * p.B);
     hipLaunchKernelGGL(stem_onepass_fold_kernel, dim3(SM_FOLD_BLOCKS, p.Cout / 16), dim3(256), 0, st, slabs, nsplit, p.Cout, M, k.gamma, k.invstd, inv_scale,
