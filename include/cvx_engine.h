@@ -155,8 +155,7 @@ int cvx_engine_backward(cvx_engine* e, const void* dpred_f16, float loss_scale);
  * batch, NHWC fp16, into dst (device or host memory, `bytes` must equal batch*h*w*c*2).  which=2 / 3: `buf` is the index
  * of a conv op and the tensor is its normalised output xhat = (y-mean)*invstd / the gradient w.r.t. its raw output,
  * dense (batch, oh, ow, cout) fp16 -- the per-layer operands of the backward pass (training plans only).   which=4: the normalised output as the backward passes USE it, fp32 (bytes = batch*h*w*c*4): the kept fp16 xhat widened, or --
- * for a CVX_OPF_RAW_F16 layer, which keeps its raw fp16 output instead -- (y - mean) * invstd computed as they compute it.  Not for the fp32
- * stem (op 0 of the YOLOv8 graphs) where its backward kernel recomputes xhat from the images: nothing is kept there (which = 2 / 4 undefined). */
+ * for a CVX_OPF_RAW_F16 layer, which keeps its raw fp16 output instead -- (y - mean) * invstd computed as they compute it. */
 int cvx_engine_debug_copy(cvx_engine* e, int32_t buf, int32_t which, void* dst, int64_t bytes);
 
 /* Segmented backward for data-parallel training: the same pass as cvx_engine_backward, cut into op ranges so that the
