@@ -158,6 +158,7 @@ PROTOTYPES = {
     "cvx_allreduce_grads": (_I32, [_P, _P, _P]),
     "cvx_engine_backward_exchange": (_I32, [_P, _P, _F, _P, _P, _I32, _P]),
     "cvx_stem_backward_nchw": (_I32, [_P, _I32, _I32, _I32, _P, _P, _I32, _P, _P, _P, _F, _P, _P, _P, _P]),
+    "cvx_stem_backward_recompute_nchw": (_I32, [_P, _I32, _I32, _I32, _P, _P, _I32, _P, _P, _P, _P, _F, _P, _P, _P, _P]),
 }
 
 _lib = None

@@ -286,6 +286,28 @@ extern "C" int cvx_stem_wgrad_nchw(const float* images, int32_t batch, int32_t h
   return 0;
 }
 
+// the engine's one-pass route with the recomputed xhat (include/cvx_engine.h)
+extern "C" int cvx_stem_backward_recompute_nchw(const float* images, int32_t batch, int32_t h, int32_t w, const float* weight, const void* gout_f16, int32_t cout,
+                                                const float* gamma, const float* beta, const float* mean, const float* invstd, float inv_scale,
+                                                float* dgamma, float* dbeta, float* dw, void* hip_stream) {
+  CVX_CHECK(images && weight && gout_f16 && gamma && beta && mean && invstd && dgamma && dbeta && dw, "null arguments");
+  hipStream_t st = (hipStream_t)hip_stream;
+  const StemParams sp{images, batch, h, w, h / 2, w / 2, weight, cout};
+  const int hw = (h / 2) * (w / 2);
+  const long long M = (long long)batch * hw;
+  const int ns = cvx_stem_wgrad_splits(M);
+  const ViewDesc g = dense(gout_f16, hw, cout);
+  CVX_CHECK(!cvx_stem_keeps_xhat(sp, g, ns), "the one-pass stem backward does not take this shape (rows of 16-byte granularity, >= 2 pixel splits)");
+  Scratch slabs;
+  CVX_TRY(slabs.alloc((size_t)ns * cout * 144 * 4));
+  BnCoef k{invstd, gamma, beta, mean};
+  CVX_HIP(hipMemsetAsync(dw, 0, (size_t)cout * 27 * 4, st));
+  // (the xhat argument only has to be a 16-byte aligned non-null pointer: it is not read)
+  CVX_TRY(cvx_stem_backward_fold(sp, (const half_t*)slabs.p, g, k, nullptr, inv_scale, dgamma, dbeta, dw, (float*)slabs.p, ns, st));
+  CVX_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
 // the stem's whole backward pass (BatchNorm + SiLU backward and the weight gradient, fused as in the engine): gout = gradient
 // w.r.t. the stem's activation, fp16 (B, h/2, w/2, cout); xhat / invstd from cvx_stem_train_nchw; dgamma / dbeta accumulated
 extern "C" int cvx_stem_backward_nchw(const float* images, int32_t batch, int32_t h, int32_t w, const void* xhat_f16, const void* gout_f16,

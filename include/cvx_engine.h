@@ -527,6 +527,14 @@ int cvx_stem_wgrad_nchw(const float* images, int32_t batch, int32_t h, int32_t w
 int cvx_stem_backward_nchw(const float* images, int32_t batch, int32_t h, int32_t w, const void* xhat_f16, const void* gout_f16, int32_t cout,
                            const float* gamma, const float* beta, const float* invstd, float inv_scale, float* dgamma, float* dbeta, float* dw,
                            void* hip_stream);
+/* The same pass where the engine keeps no xhat (round 5; images with 16-byte granular rows, >= 2 pixel splits: every YOLOv8 training shape): the
+ * kernel recomputes the conv output from the images and `weight` ([cout][3][3][3] fp32, as cvx_stem_train_nchw takes it) and normalises it with the
+ * forward's batch mean / invstd (cvx_stem_train_nchw's outputs),
+ * and the BatchNorm-backward sums come out of the same pass (no reduction over gout beforehand).  Fails with an error on shapes the one-pass
+ * kernel does not take (the engine falls back to cvx_stem_backward_nchw's route there). */
+int cvx_stem_backward_recompute_nchw(const float* images, int32_t batch, int32_t h, int32_t w, const float* weight, const void* gout_f16, int32_t cout,
+                                     const float* gamma, const float* beta, const float* mean, const float* invstd, float inv_scale,
+                                     float* dgamma, float* dbeta, float* dw, void* hip_stream);
 
 /* ---- data-parallel gradient exchange over RCCL (csrc/comm.hip), SURVEY.md section 8(b) / 8(e) --------------------------------------
  * One process per GPU.  Rank 0 calls cvx_comm_unique_id (128 bytes, ncclGetUniqueId), ships them to every rank by any means, all ranks

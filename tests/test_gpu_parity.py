@@ -724,7 +724,8 @@ def test_training_pool_resize_dropout_units(dev, B, H, W, C):
     assert torch.equal(out2, (prev.float() + 1).half())                                 # p = 0 keeps everything; accumulate adds
 
 
-@pytest.mark.parametrize("B,H,W,Co", [(2, 64, 64, 16), (1, 32, 96, 32), (3, 16, 16, 48), (1, 128, 128, 80)])
+@pytest.mark.parametrize("B,H,W,Co", [(2, 64, 64, 16), (1, 32, 96, 32), (3, 16, 16, 48), (1, 128, 128, 80),
+                                      (2, 640, 640, 16), (1, 72, 200, 16), (2, 96, 160, 32)])   # round 5: the bench's width (10 tiles per row), maps that end inside a tile
 def test_fp32_stem_unit(dev, B, H, W, Co):
     """stem.hip (model.0 = Conv(3, c, 3, 2), yolo_v8.py:28) against torch fp32: train pass (batch statistics, running
     update, xhat), eval pass (folded scale / shift) and the weight gradient."""
@@ -770,6 +771,14 @@ def test_fp32_stem_unit(dev, B, H, W, Co):
                                        L.ptr(dgam), L.ptr(dbet), L.ptr(dw), st), "stem backward")
     assert rel(dgam, gr2.grad) < 1e-3 and rel(dbet, br2.grad) < 1e-3
     assert rel(dw.permute(0, 3, 1, 2), wr2.grad) < 3e-3       # dy passes through one fp16 rounding (as bn_bwd_apply stores it) and xhat is fp16
+    # ... and the route the engine takes on every YOLOv8 training shape: ONE pass, xhat recomputed from the images (no xhat argument), the
+    # weight-gradient sums on fp16 MFMAs.  (Shapes with a single pixel split take the route above in the engine too.)
+    if B * (H // 2) * (W // 2) > 1024 and W % 4 == 0:
+        dgam2, dbet2, dw2 = torch.zeros(Co, device=dev), torch.zeros(Co, device=dev), torch.empty(Co, 3, 3, 3, device=dev)
+        L.check(lib.cvx_stem_backward_recompute_nchw(L.ptr(xd), B, H, W, L.ptr(wd), L.ptr(_nhwc(dy16).to(dev)), Co, L.ptr(gd), L.ptr(bd), L.ptr(mean), L.ptr(invstd),
+                                                     1.0, L.ptr(dgam2), L.ptr(dbet2), L.ptr(dw2), st), "stem backward (one pass, recomputed xhat)")
+        assert rel(dgam2, gr2.grad) < 1e-3 and rel(dbet2, br2.grad) < 1e-3
+        assert rel(dw2.permute(0, 3, 1, 2), wr2.grad) < 3e-3
 
 
 # ---- whole network -----------------------------------------------------------------------------------------
