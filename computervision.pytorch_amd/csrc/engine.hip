@@ -136,6 +136,12 @@ struct cvx_engine {
   hipStream_t lane = nullptr;
   hipEvent_t ev_lane_fork = nullptr, ev_lane_join = nullptr, ev_pack = nullptr;
   bool use_lanes = false;
+  // FORWARD overlap of the Detect levels with the neck's bottom-up path: level l may start on the lane stream as soon as the op that produces its
+  // input has run on the main stream (head_producer[l], plan time), not only after the whole neck
+  hipEvent_t ev_head[3] = {nullptr, nullptr, nullptr};
+  int head_producer[3] = {-1, -1, -1};
+  int head_join_op[3] = {-1, -1, -1};  // BACKWARD: the first main-chain op (highest index) whose backward touches the gradient of level l's input
+  bool head_overlap = false;
   float* ytmp_lane = nullptr;         // raw fp32 conv output of the lane's layer in flight
   hipEvent_t ev_red = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -730,7 +736,7 @@ int plan_batch(cvx_engine* e, int B, bool training) {
         c.dybuf = (half_t*)p;
       }
       if (!c.stem && !c.raw16) ytmp_elems = std::max(ytmp_elems, M * C);
-      if (e->use_lanes && o.lane >= 2 && !c.raw16) ytmp_lane_elems = std::max(ytmp_lane_elems, M * C);
+      if (e->use_lanes && (o.lane >= 2 || (e->head_overlap && o.lane >= 1)) && !c.raw16) ytmp_lane_elems = std::max(ytmp_lane_elems, M * C);
     }
     c.stat_fwd = (long long*)nullptr + stat_floats;  // offset for now, rebased below
     stat_floats += (long long)cvx_stat_replicas(C) * C * CVX_STAT_WORDS + CVX_STAT_GATE_WORDS;  // + the gate counter of the one-launch BN backward
@@ -1309,6 +1315,36 @@ extern "C" int cvx_engine_create(cvx_engine** out, const cvx_buf_desc* bufs, int
           hipEventCreateWithFlags(&e->ev_lane_join, cvx_event_flags()) == hipSuccess &&
           hipEventCreateWithFlags(&e->ev_pack, cvx_event_flags()) == hipSuccess) {
         e->use_lanes = any_lane;
+        static const int head_overlap = cvx_tune_int("CVX_HEAD_OVERLAP", 1);
+        if (any_lane && head_overlap) {
+          bool ok = true;
+          for (int l = 0; l < 3 && ok; ++l) {
+            int first = -1;
+            for (size_t i = 0; i < e->ops.size(); ++i)
+              if (e->ops[i].lane == l + 1) {
+                first = (int)i;
+                break;
+              }
+            if (first < 0) {
+              ok = false;
+              break;
+            }
+            for (int j = first - 1; j >= 0; --j)
+              if (e->ops[j].out.buf == e->ops[first].in.buf && e->ops[j].lane == 0) {
+                e->head_producer[l] = j;
+                break;
+              }
+            for (int j = first - 1; j >= 0; --j) {
+              const cvx_op_desc& q = e->ops[j];
+              if (q.lane == 0 && (q.out.buf == e->ops[first].in.buf || q.in.buf == e->ops[first].in.buf || q.res.buf == e->ops[first].in.buf)) {
+                e->head_join_op[l] = j;
+                break;
+              }
+            }
+            ok = e->head_producer[l] >= 0 && e->head_join_op[l] >= 0 && hipEventCreateWithFlags(&e->ev_head[l], cvx_event_flags()) == hipSuccess;
+          }
+          e->head_overlap = ok;
+        }
       } else {
         (void)hipGetLastError();
         e->lane = nullptr;  // (the shared stream stays: other engines may be using it)
@@ -1349,6 +1385,8 @@ extern "C" int cvx_engine_destroy(cvx_engine* e) {
     if (c.ev_dy) (void)hipEventDestroy(c.ev_dy);
   if (e->lane) (void)hipStreamSynchronize(e->lane);
   if (e->ev_lane_fork) (void)hipEventDestroy(e->ev_lane_fork);
+  for (int l = 0; l < 3; ++l)
+    if (e->ev_head[l]) (void)hipEventDestroy(e->ev_head[l]);
   if (e->ev_lane_join) (void)hipEventDestroy(e->ev_lane_join);
   if (e->ev_pack) (void)hipEventDestroy(e->ev_pack);
   if (e->red) (void)hipStreamSynchronize(e->red);
@@ -1562,6 +1600,8 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
 
   const hipStream_t main_st = st;
   bool lane_forked = false, lane_used = false;
+  bool head_rec[3] = {false, false, false}, head_waited[3] = {false, false, false};
+  static const int head_lane_mask = cvx_tune_int("CVX_HEAD_LANE_MASK", 6);  // bit l: Detect level l runs on the lane stream (levels 1 and 2: measured best of the eight)
   for (size_t i = 0; i < e->ops.size(); ++i) {
     const cvx_op_desc& o = e->ops[i];
     e->cur_op = (int)i;
@@ -1576,7 +1616,20 @@ extern "C" int cvx_engine_forward(cvx_engine* e, const float* images, int32_t ba
       CVX_HIP(hipEventRecord(e->ev_lane_fork, main_st));
       lane_forked = true;
     }
-    if (e->use_lanes && o.lane >= 2) {
+    if (e->head_overlap && !e->profile) {
+      for (int l = 0; l < 3; ++l)
+        if (!head_rec[l] && (int)i > e->head_producer[l]) {  // the level's input is complete on the main stream from here on
+          CVX_HIP(hipEventRecord(e->ev_head[l], main_st));
+          head_rec[l] = true;
+        }
+      const int lvl = o.lane - 1;
+      if (lvl >= 0 && lvl < 3 && ((head_lane_mask >> lvl) & 1)) {
+        if (!head_waited[lvl]) CVX_HIP(hipStreamWaitEvent(e->lane, e->ev_head[lvl], 0));
+        head_waited[lvl] = true;
+        lane_used = true;
+        st = e->lane;
+      }
+    } else if (e->use_lanes && o.lane >= 2) {
       if (!lane_used) CVX_HIP(hipStreamWaitEvent(e->lane, e->ev_lane_fork, 0));
       lane_used = true;
       st = e->lane;
@@ -1769,6 +1822,7 @@ struct cvx_bw_state {
   int wg_batch = 1;
   int next_op = -1;  // next op (descending) the segmented interface expects
   bool lane_pending = false;       // kernels queued on the lane stream since the last join
+  int lane_join_op = -1;           // head overlap: the main chain joins the lane stream at the first op i <= lane_join_op
   hipStream_t pending_stream = nullptr;  // stream that produced the dy tensors of `pending`
   std::vector<PendingWgrad> pending;
 };
@@ -1811,6 +1865,7 @@ int join_lane(cvx_engine* e) {
   CVX_HIP(hipEventRecord(e->ev_lane_join, e->lane));
   CVX_HIP(hipStreamWaitEvent(e->stream, e->ev_lane_join, 0));
   w.lane_pending = false;
+  w.lane_join_op = -1;
   return 0;
 }
 
@@ -1845,6 +1900,7 @@ int backward_begin(cvx_engine* e, const void* dpred_f16, float loss_scale) {
   CVX_HIP(hipStreamWaitEvent(e->side, e->ev_fork, 0));
   if (e->use_lanes) CVX_HIP(hipStreamWaitEvent(e->lane, e->ev_fork, 0));
   w.lane_pending = false;
+  w.lane_join_op = -1;
   w.pending_stream = nullptr;
   return 0;
 }
@@ -1858,7 +1914,20 @@ int backward_op(cvx_engine* e, int i) {
   const cvx_op_desc& o = e->ops[i];
   e->cur_op = i;
     hipStream_t st = e->stream;
-    if (e->use_lanes && o.lane >= 2) {
+    static const int head_bwd_mask = cvx_tune_int("CVX_HEAD_BWD_MASK", 6);  // bit l: Detect level l's backward runs on the lane stream
+    if (e->head_overlap && !e->profile) {
+      // Detect levels by mask on the lane stream; the main chain (the other levels, then the neck) joins it only where it first touches the
+      // gradient of a lane level's input (head_join_op): the neck's bottom-up path runs beside a level that is still on the lane stream
+      const int lvl = o.lane - 1;
+      if (lvl >= 0 && lvl < 3 && ((head_bwd_mask >> lvl) & 1)) {
+        st = e->lane;
+        w.lane_pending = true;
+        w.lane_join_op = std::max(w.lane_join_op, e->head_join_op[lvl]);
+      } else if (w.lane_pending && lvl < 0 && i <= w.lane_join_op) {
+        CVX_TRY(join_lane(e));
+        w.lane_join_op = -1;
+      }
+    } else if (e->use_lanes && o.lane >= 2) {
       st = e->lane;
       w.lane_pending = true;
     } else if (w.lane_pending && o.lane == 0) {
